@@ -1,0 +1,211 @@
+/* rnet_hip.h — C ABI of librnet_hip.so, the MI355X (gfx950) hot path that sits behind the
+ * `retinanet` Python surface of srihari-humbarwadi/retinanet-tensorflow2.x.
+ *
+ * The reference has no FFI of its own: every entry point below replaces
+ * the TensorFlow op kernels one reference function dispatches to, and cites that function
+ * (paths relative to the reference checkout).  Conventions:
+ *   - all functions return 0 on success or a negative rn_status; rn_last_error() returns a
+ *     thread-local message for the last failure; no C++ exception crosses the boundary;
+ *   - the caller owns every buffer; pointers are DEVICE pointers unless a parameter says
+ *     "host"; tensors are dense, NHWC where spatial, 16-byte aligned;
+ *   - every launch takes an explicit hipStream_t (passed as void*) and is asynchronous;
+ *   - nothing here allocates device memory: workspaces are passed in, and each
+ *     `*_workspace_bytes` function says how much a call needs.
+ */
+#ifndef RNET_HIP_H_
+#define RNET_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  RN_OK = 0,
+  RN_EINVAL = -1, /* bad shape / dtype / alignment / null pointer */
+  RN_ENOMEM = -2, /* workspace too small */
+  RN_EHIP = -3,   /* a HIP runtime call or launch failed (message has hipGetErrorString) */
+  RN_ECOMM = -4   /* collective failure */
+} rn_status;
+
+enum { RN_DT_F32 = 0, RN_DT_BF16 = 1 };
+enum { RN_ACT_NONE = 0, RN_ACT_RELU = 1, RN_ACT_RELU6 = 2, RN_ACT_SWISH = 3 };
+
+const char* rn_last_error(void);
+/* library ABI version; bumped when a signature changes */
+int rn_abi_version(void);
+/* 1 if a gfx950 device is visible to this process, 0 otherwise (never initialises more
+ * than hipGetDeviceCount + properties) */
+int rn_device_ok(void);
+
+/* ---------------------------------------------------------------------------------------
+ * a1  AnchorBoxGenerator  (retinanet/dataloader/anchor_generator.py:24-104)
+ * out: boxes f32[n_total,4] rows [cx,cy,w,h], ordered level -> y -> x -> (ratio-major,
+ * scale-minor) anchor.  area_over_ratio is host f32[num_levels*num_ratios] =
+ * f32(area/ratio) (the reference does that division in Python floats, :56), areas host
+ * f32[num_levels], scales host f32[num_scales].  Returns n_total through *n_out (host).
+ */
+int rn_anchors_generate(float* boxes, int64_t boxes_capacity_rows, int img_h, int img_w, int min_level,
+                        int max_level, const float* areas, const float* area_over_ratio, int num_ratios,
+                        const float* scales, int num_scales, int64_t* n_out, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a2-a4  compute_iou + LabelEncoder._match_anchor_boxes/_compute_box_target/encode_sample
+ * (retinanet/dataloader/utils.py:27-46, retinanet/dataloader/label_encoder.py:27-125)
+ * in : anchors f32[A,4] cxcywh; gt_boxes f32[B,Gmax,4] cxcywh pixels; gt_classes
+ *      f32[B,Gmax]; gt_counts i32[B] (0 <= count <= Gmax)
+ * out: matches i32[B,A] in {-2,-1,0..G-1}; class_targets f32[B,A] (class id, -1
+ *      background, -2 ignore); box_targets f32[B,A,4]; num_positives f32[B]
+ * box_variance: host f32[4] or NULL (encoder_params.scale_box_targets, :73-76).
+ * workspace: rn_match_workspace_bytes(B, Gmax) bytes.
+ */
+size_t rn_match_workspace_bytes(int B, int Gmax);
+int rn_anchor_match_encode(const float* anchors, int64_t A, const float* gt_boxes, const float* gt_classes,
+                           const int32_t* gt_counts, int B, int Gmax, float match_iou, float ignore_iou,
+                           const float* box_variance, int32_t* matches, float* class_targets,
+                           float* box_targets, float* num_positives, void* workspace, size_t workspace_bytes,
+                           void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a9  RetinaNetLoss / ClassLoss / FocalLossV1 / BoxLoss
+ * (retinanet/losses/retinanet_loss.py:37-83, retinanet/losses/loss_impl.py:15-28,41-105)
+ * Fused forward + backward over all pyramid levels in one launch.
+ * level l (0..num_levels-1): class_logits[l] f32[B, n_l, K], box_preds[l] f32[B, n_l, 4]
+ * (n_l = anchors on that level; pointers are host arrays of device pointers),
+ * level_offsets host i64[num_levels+1] = anchor boundaries.  Targets are the flattened
+ * outputs of rn_anchor_match_encode.  normalizer: device f32[1] (already all-reduced and
+ * divided by replicas, retinanet_loss.py:46-49).  grad_scale multiplies both gradients
+ * (1/num_replicas, times the loss scale under fp16: executor.py:421-425).
+ * out: losses f32[4] = {box-loss, class-loss, weighted-loss, normalizer}; d_class_logits[l],
+ * d_box_preds[l] same shapes as the inputs (may be NULL arrays to skip the backward).
+ */
+size_t rn_loss_workspace_bytes(int B, int64_t A, int K);
+int rn_retinanet_loss_fwd_bwd(const float* const* class_logits, const float* const* box_preds,
+                              float* const* d_class_logits, float* const* d_box_preds,
+                              const int64_t* level_offsets, int num_levels, int B, int K,
+                              const float* class_targets, const float* box_targets, const float* normalizer,
+                              float alpha, float gamma, float label_smoothing, float delta,
+                              float box_loss_weight, float class_loss_weight, float grad_scale, float* losses,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a11+a12  FuseDetections + TransformBoxesAndScores
+ * (retinanet/model/layers/postprocessing_ops.py:15-56, 87-117)
+ * Box decode only: the sigmoid of a12 is fused into rn_detect_per_class / rn_sigmoid_scores.
+ * in : box_preds[l] f32[B,n_l,4] per level, anchors f32[A,4]
+ * out: boxes f32[B,A,4] = [x1,y1,x2,y2] / [W? see note] normalised by (input_h,input_w,input_h,
+ *      input_w) exactly as the reference divides (postprocessing_ops.py:65-69,104).
+ */
+int rn_decode_boxes(const float* const* box_preds, const int64_t* level_offsets, int num_levels, int B,
+                    const float* anchors, const float* box_variance, float input_h, float input_w,
+                    float* boxes, void* stream);
+
+/* scores = sigmoid(logits) flattened over levels: f32[B,A,K] (a12, :114). */
+int rn_sigmoid_scores(const float* const* class_logits, const int64_t* level_offsets, int num_levels, int B,
+                      int K, float* scores, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a13  FilterTopKDetections._filter_per_class  (postprocessing_ops.py:128-147)
+ * in : scores f32[B,A,K]; out: topk_scores f32[B,k,K], topk_indices i32[B,k,K] (anchor ids),
+ * canonical order: descending score, ties by ascending anchor index.
+ * k = min(top_k, A).
+ */
+size_t rn_topk_workspace_bytes(int B, int64_t A, int K);
+int rn_topk_per_class(const float* scores, int B, int64_t A, int K, int top_k, float* topk_scores,
+                      int32_t* topk_indices, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a12+a13+a14 fused detection post-process: TransformBoxesAndScores -> FilterTopKDetections
+ * -> GenerateDetections._per_class_nms  (postprocessing_ops.py:107-117,128-147,434-535)
+ * in : class_logits[l] f32[B,n_l,K] per level; boxes f32[B,A,4] from rn_decode_boxes
+ * out: det_boxes f32[B,max_det,4], det_scores f32[B,max_det], det_classes i32[B,max_det],
+ *      valid i32[B].  soft_nms_sigma == 0 -> PerClassHardNMS, > 0 -> PerClassSoftNMS (the
+ *      reference passes sigma/2 to NonMaxSuppressionV5 and iou_threshold 1.0, :448-450;
+ *      pass the CONFIG sigma here).  pre_nms_top_k <= 0 disables the top-k filter.
+ */
+size_t rn_detect_workspace_bytes(int B, int64_t A, int K, int max_det);
+int rn_detect_per_class(const float* const* class_logits, const int64_t* level_offsets, int num_levels, int B,
+                        int K, const float* boxes, int pre_nms_top_k, float iou_threshold,
+                        float score_threshold, float soft_nms_sigma, int max_det, float* det_boxes,
+                        float* det_scores, int32_t* det_classes, int32_t* valid, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
+/* a14 stand-alone: per-class NMS on already filtered candidates
+ * in : cand_scores f32[B,n,K], cand_boxes f32[B,n,K,4] (class-specific boxes, as
+ * FilterTopKDetections emits them); same outputs as rn_detect_per_class. */
+size_t rn_nms_workspace_bytes(int B, int n, int K, int max_det);
+int rn_nms_per_class(const float* cand_scores, const float* cand_boxes, int B, int n, int K,
+                     float iou_threshold, float score_threshold, float soft_nms_sigma, int max_det,
+                     float* det_boxes, float* det_scores, int32_t* det_classes, int32_t* valid,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * K1/K2 (a5,a6,a8)  tf.keras.layers.Conv2D as used by resnet.py:118-144, fpn_base.py:44-50,
+ * fpn.py:47-66, detection_head.py:56-88 — grouped implicit-GEMM convolution on MFMA.
+ *
+ * One launch runs up to RN_CONV_MAX_SEGMENTS independent problems that share kernel size,
+ * stride and Cout tile shape (e.g. the five pyramid levels of one shared head conv, or the
+ * FPN's per-level 3x3 convs).  Activations NHWC bf16; weights PREPACKED bf16
+ * [Cout_pad][R][S][Cin] (rn_pack_conv_weight); accumulation fp32; epilogue
+ * y = act(acc*scale[c] + shift[c] + residual) written as bf16 or f32.
+ */
+#define RN_CONV_MAX_SEGMENTS 10
+
+typedef struct {
+  const void* x;        /* bf16 [N,H,W,pix_stride] (pix_stride >= Cin elements between pixels) */
+  const void* w;        /* bf16 [Cout_pad, R, S, Cin] */
+  void* y;              /* bf16 or f32 [N,Ho,Wo,Cout] */
+  const float* scale;   /* f32[Cout] or NULL (=1) */
+  const float* shift;   /* f32[Cout] or NULL (=0) */
+  const void* residual; /* bf16 [N,Ho,Wo,Cout] or NULL */
+  int32_t N, H, W, Cin, pix_stride, Ho, Wo, Cout;
+} rn_conv_segment;
+
+typedef struct {
+  int32_t R, S, stride_h, stride_w, pad_top, pad_left; /* x index = o*stride - pad + r */
+  int32_t act;       /* RN_ACT_* applied after residual add */
+  int32_t out_dtype; /* RN_DT_BF16 or RN_DT_F32 */
+  int32_t num_segments;
+  rn_conv_segment seg[RN_CONV_MAX_SEGMENTS];
+} rn_conv_problem;
+
+int rn_conv2d_nhwc_fwd(const rn_conv_problem* problem /* host */, void* stream);
+
+/* HWIO f32 [R,S,Cin,Cout] (the Keras kernel layout, resnet.py:137-144) -> bf16
+ * [Cout_pad,R,S,Cin_pad], zero padded.  Cout_pad = rn_conv_cout_pad(Cout). */
+int rn_conv_cout_pad(int Cout);
+int rn_pack_conv_weight(const float* w_hwio, int R, int S, int Cin, int Cout, int Cin_pad, void* w_packed,
+                        void* stream);
+/* Stem repack: 7x7x3 HWIO -> bf16 [64][7][32] rows = (kernel row r) x (8 taps x 4 channels),
+ * tap 7 and channel 3 zero, matching rn_pack_stem_input's padded NHWC4 image. */
+int rn_pack_stem_weight(const float* w_hwio, int Cout, void* w_packed, void* stream);
+/* images f32 [N,H,W,3] -> bf16 [N,H+6,Wp,4] zero padded by 3 (fixed_padding, resnet.py:92-115),
+ * Wp = rn_stem_padded_width(W). */
+int rn_stem_padded_width(int W);
+int rn_pack_stem_input(const float* images, int N, int H, int W, void* packed, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * K6  tf.keras.layers.MaxPool2D  (resnet.py:304-307 3x3 s2 SAME; fpn_base.py:25-26,68 2x2 s2)
+ * explicit pads; padded taps are skipped (-inf). bf16 NHWC.
+ */
+int rn_maxpool2d_nhwc(const void* x, void* y, int N, int H, int W, int C, int k, int stride, int pad_top,
+                      int pad_left, int Ho, int Wo, void* stream);
+
+/* K7 (a6)  FPN top-down path, FeatureFusion mode 'sum' + NearestUpsampling2D + activation
+ * (fpn.py:93-98, feature_fusion.py:41-56, nearest_upsampling.py:19-21):
+ * for l = num_levels-1 .. 1: out[l-1] = act(in[l-1] + up2(out[l])), out[top] = in[top] (not
+ * written); p[l] bf16 [N,H0>>l,W0>>l,C] with level 0 the finest; out must not alias in. */
+int rn_fpn_topdown(void* const* p_in /* host array of device ptrs */, void* const* p_out, int num_levels,
+                   int N, int H0, int W0, int C, int act, void* stream);
+
+/* K8 (a7)  BalanceFeatures  (balance_features.py:19-60); out[l] may alias in[l];
+ * mid = index of the intermediate level; scratch: bf16 [N,Hmid,Wmid,C]. */
+int rn_balance_features(void* const* p_in, void* const* p_out, int num_levels, int mid, int N, int H0, int W0,
+                        int C, void* scratch, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RNET_HIP_H_ */

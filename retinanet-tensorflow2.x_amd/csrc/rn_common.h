@@ -1,0 +1,73 @@
+// rn_common.h — shared host/device helpers for librnet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/rnet_hip.h"
+
+void rn_set_error(const char* fmt, ...);
+
+#define RN_CHECK_ARG(cond, ...)  \
+  do {                           \
+    if (!(cond)) {               \
+      rn_set_error(__VA_ARGS__); \
+      return RN_EINVAL;          \
+    }                            \
+  } while (0)
+
+#define RN_CHECK_HIP(expr)                                                              \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess) {                                                             \
+      rn_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return RN_EHIP;                                                                   \
+    }                                                                                   \
+  } while (0)
+
+#define RN_CHECK_LAUNCH() RN_CHECK_HIP(hipGetLastError())
+
+static inline int64_t rn_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t rn_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- bf16 <-> f32 (round to nearest even), device side ------------------------------------
+__device__ __forceinline__ float rn_bf16_to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ uint16_t rn_f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);  // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t rn_pack_bf16x2(float lo, float hi) {
+  return (uint32_t)rn_f32_to_bf16(lo) | ((uint32_t)rn_f32_to_bf16(hi) << 16);
+}
+
+__device__ __forceinline__ float rn_apply_act(float v, int act) {
+  switch (act) {
+    case RN_ACT_RELU: return fmaxf(v, 0.0f);
+    case RN_ACT_RELU6: return fminf(fmaxf(v, 0.0f), 6.0f);
+    case RN_ACT_SWISH: return v / (1.0f + __expf(-v));
+    default: return v;
+  }
+}
+
+// 64-wide wavefront reductions
+__device__ __forceinline__ float rn_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double rn_wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ unsigned long long rn_wave_max_u64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    unsigned long long t = __shfl_xor(v, o, 64);
+    v = t > v ? t : v;
+  }
+  return v;
+}

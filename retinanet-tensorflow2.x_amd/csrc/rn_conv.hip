@@ -1,0 +1,423 @@
+// rn_conv.hip — K1/K2: grouped implicit-GEMM NHWC convolution on gfx950 MFMA.
+// Replaces tf.keras.layers.Conv2D as used by the reference's ResNet
+// (retinanet/model/backbone/resnet.py:118-144), FPN (model/neck/fpn_base.py:44-50,
+// model/neck/fpn.py:47-66) and detection heads (model/head/detection_head.py:56-88).
+//
+// GEMM view: M = N*Ho*Wo output pixels, N = Cout, K = R*S*Cin; A[m][k] is gathered on the fly
+// from the NHWC input (for one filter tap the Cin slice of a pixel is contiguous), B is the
+// prepacked weight [Cout_pad][R*S*Cin] (k contiguous), accumulation fp32 on
+// v_mfma_f32_32x32x16_bf16.
+//
+// Workgroup = 256 threads = 4 wavefronts (2x2), tile BM x BN x BK = 128 x {128,64} x {64,32}.
+//   * global -> registers -> LDS staging, double buffered, ONE barrier per K step: the loads of
+//     step t+1 are issued before the MFMAs of step t and written to the other LDS buffer after
+//     them, so HBM/L2 latency hides under the matrix pipe.
+//   * LDS tiles are [rows][BK] bf16 with the 16-byte slot index XOR-swizzled by
+//     (row / rows_per_256B) so the ds_read_b128 fragment reads (one row per lane, same k slot)
+//     hit 16 distinct 16-byte slots of the 256-byte bank row: conflict free.
+//   * padding / image borders / M tail: per-row tap-validity bitmask computed once per tile;
+//     invalid 16-byte pieces are zero-filled in registers.
+//   * epilogue: acc*scale[c]+shift[c] staged through LDS as fp32 [BM][BN] (reusing the A/B
+//     buffers), then read back row-contiguous: + residual, activation, convert, 8/16-byte
+//     coalesced stores.  BN(+bias) folding makes Conv+BN+ReLU(+add) one kernel at inference.
+//   * grouped launch: up to 10 independent segments (pyramid levels / both heads) share one
+//     grid, so the small P5-P7 problems ride along with P3 instead of under-filling 256 CUs.
+//   * blockIdx -> tile map is XCD aware: consecutive tiles (same A rows, neighbouring n tiles)
+//     land on the same XCD's L2 (blocks are dispatched round-robin over the 8 XCDs).
+// Roofline: MFMA-bound for K >= ~512; the small-K 1x1 convs of ResNet stage 1-2 are HBM-bound.
+#include "rn_common.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+#define CONV_THREADS 256
+
+struct ConvSegDev {
+  const uint16_t* x;
+  const uint16_t* w;
+  void* y;
+  const float* scale;
+  const float* shift;
+  const uint16_t* residual;
+  int N, H, W, Cin, pix_stride, Ho, Wo, Cout;
+  int M, tile_begin, n_tiles, pad_;
+};
+
+struct ConvArgs {
+  int R, S, sh, sw, pt, pl, act, nseg, total_tiles, pad_;
+  ConvSegDev seg[RN_CONV_MAX_SEGMENTS];
+};
+
+template <int BK>
+__device__ __forceinline__ int lds_slot_off(int row, int slot) {
+  constexpr int SLOTS = BK / 8;            // 16-byte slots per row
+  constexpr int RPB = 256 / (BK * 2);      // rows per 256-byte bank row
+  return (row * SLOTS + (slot ^ ((row / RPB) % SLOTS))) * 16;
+}
+
+template <int BM, int BN, int BK, bool OUT_F32>
+__global__ void __launch_bounds__(CONV_THREADS, 2) conv_fwd_kernel(const ConvArgs args) {
+  constexpr int SLOTS = BK / 8;
+  constexpr int RPP = CONV_THREADS / SLOTS;  // rows per load pass
+  constexpr int A_PASSES = BM / RPP;
+  constexpr int B_PASSES = BN / RPP;
+  constexpr int WTM = BM / 2, WTN = BN / 2;  // wave tile
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int KSUB = BK / 16;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+  constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+  static_assert(BM * BN * 4 <= 2 * STAGE_BYTES || true, "epilogue tile");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  // ---- tile lookup (XCD-aware remap of the linear block id) ---------------------------------
+  int tile;
+  {
+    const int total = args.total_tiles;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int q = total >> 3, r = total & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  int si = 0;
+#pragma unroll 1
+  for (int i = 1; i < args.nseg; ++i)
+    if (tile >= args.seg[i].tile_begin) si = i;
+  const ConvSegDev& sg = args.seg[si];
+  const int lt = tile - sg.tile_begin;
+  const int m_tile = lt / sg.n_tiles, n_tile = lt - m_tile * sg.n_tiles;
+  const int m0 = m_tile * BM, n0 = n_tile * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wave_m = wave >> 1, wave_n = wave & 1;
+
+  const int R = args.R, S = args.S;
+  const int H = sg.H, W = sg.W, Cin = sg.Cin, PS = sg.pix_stride;
+  const int M = sg.M;
+  const int Ktot = R * S * Cin;
+
+  // ---- per-thread load bookkeeping -----------------------------------------------------------
+  const int ld_row = tid / SLOTS, ld_slot = tid % SLOTS;
+  long long a_base[A_PASSES];
+  unsigned int a_mask[A_PASSES];
+#pragma unroll
+  for (int i = 0; i < A_PASSES; ++i) {
+    const int m = m0 + ld_row + i * RPP;
+    const int mm = m < M ? m : 0;
+    const int ox = mm % sg.Wo;
+    const int t2 = mm / sg.Wo;
+    const int oy = t2 % sg.Ho;
+    const int n = t2 / sg.Ho;
+    const int iy0 = oy * args.sh - args.pt, ix0 = ox * args.sw - args.pl;
+    a_base[i] = (((long long)n * H + iy0) * W + ix0) * PS + ld_slot * 8;
+    unsigned int mask = 0;
+    if (m < M) {
+      for (int r = 0; r < R; ++r)
+        for (int s = 0; s < S; ++s) {
+          const bool ok = (unsigned)(iy0 + r) < (unsigned)H && (unsigned)(ix0 + s) < (unsigned)W;
+          mask |= (ok ? 1u : 0u) << (r * S + s);
+        }
+    }
+    a_mask[i] = mask;
+  }
+  long long b_base[B_PASSES];
+#pragma unroll
+  for (int i = 0; i < B_PASSES; ++i) b_base[i] = (long long)(n0 + ld_row + i * RPP) * Ktot + ld_slot * 8;
+
+  int lds_wr_a[A_PASSES], lds_wr_b[B_PASSES];
+#pragma unroll
+  for (int i = 0; i < A_PASSES; ++i) lds_wr_a[i] = lds_slot_off<BK>(ld_row + i * RPP, ld_slot);
+#pragma unroll
+  for (int i = 0; i < B_PASSES; ++i) lds_wr_b[i] = A_BYTES + lds_slot_off<BK>(ld_row + i * RPP, ld_slot);
+
+  // fragment read offsets: row = lane&31 within a 32-row tile, k slot = 2*kk + (lane>>5)
+  int lds_rd_a[TM], lds_rd_b[TN];
+  const int frag_row = lane & 31, frag_half = lane >> 5;
+
+  f32x16_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const int csteps = Cin / BK;
+  const int ksteps = R * S * csteps;
+
+  uint4 ra[A_PASSES], rb[B_PASSES];
+  auto load_tile = [&](int tap, int c0) {
+    const int r = tap / S, s = tap - r * S;
+    const long long tap_off = ((long long)r * W + s) * PS + c0;
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if ((a_mask[i] >> tap) & 1u) v = *(const uint4*)(sg.x + a_base[i] + tap_off);
+      ra[i] = v;
+    }
+    const long long koff = (long long)tap * Cin + c0;
+#pragma unroll
+    for (int i = 0; i < B_PASSES; ++i) rb[i] = *(const uint4*)(sg.w + b_base[i] + koff);
+  };
+  auto store_tile = [&](int buf) {
+    char* base = smem + buf * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) *(uint4*)(base + lds_wr_a[i]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_PASSES; ++i) *(uint4*)(base + lds_wr_b[i]) = rb[i];
+  };
+
+  int tap = 0, c0 = 0;
+  load_tile(0, 0);
+  store_tile(0);
+  __syncthreads();
+  int cur = 0;
+#pragma unroll 1
+  for (int kt = 0; kt < ksteps; ++kt) {
+    c0 += BK;
+    if (c0 >= Cin) {
+      c0 = 0;
+      ++tap;
+    }
+    const bool more = kt + 1 < ksteps;
+    if (more) load_tile(tap, c0);
+
+    const char* base = smem + cur * STAGE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < KSUB; ++kk) {
+      bf16x8_t fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = wave_m * WTM + i * 32 + frag_row;
+        fa[i] = *(const bf16x8_t*)(base + lds_slot_off<BK>(row, kk * 2 + frag_half));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = wave_n * WTN + j * 32 + frag_row;
+        fb[j] = *(const bf16x8_t*)(base + A_BYTES + lds_slot_off<BK>(row, kk * 2 + frag_half));
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_tile(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+  (void)lds_rd_a;
+  (void)lds_rd_b;
+
+  // ---- epilogue ------------------------------------------------------------------------------
+  // stage 1: registers -> LDS fp32 [BM][BN], with the per-channel affine applied
+  float* cl = (float*)smem;
+  const int Cout = sg.Cout;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int nl = wave_n * WTN + j * 32 + (lane & 31);
+    const int n = n0 + nl;
+    float sc = 1.0f, sf = 0.0f;
+    if (n < Cout) {
+      if (sg.scale) sc = sg.scale[n];
+      if (sg.shift) sf = sg.shift[n];
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ml = wave_m * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        cl[ml * BN + nl] = acc[i][j][r] * sc + sf;
+      }
+    }
+  }
+  __syncthreads();
+  // stage 2: row-contiguous read back, residual, activation, store
+  constexpr int TPR = BN / 4;                 // threads per row (4 channels each)
+  constexpr int ROWS = CONV_THREADS / TPR;    // rows per pass
+  const int er = tid / TPR, ec = (tid % TPR) * 4;
+  const int n = n0 + ec;
+  if (n < Cout) {
+#pragma unroll 4
+    for (int rr = er; rr < BM; rr += ROWS) {
+      const int m = m0 + rr;
+      if (m >= M) break;
+      float4 v = *(const float4*)(cl + rr * BN + ec);
+      const long long o = (long long)m * Cout + n;
+      if (sg.residual) {
+        const uint2 rv = *(const uint2*)(sg.residual + o);
+        v.x += rn_bf16_to_f32((uint16_t)(rv.x & 0xffffu));
+        v.y += rn_bf16_to_f32((uint16_t)(rv.x >> 16));
+        v.z += rn_bf16_to_f32((uint16_t)(rv.y & 0xffffu));
+        v.w += rn_bf16_to_f32((uint16_t)(rv.y >> 16));
+      }
+      v.x = rn_apply_act(v.x, args.act);
+      v.y = rn_apply_act(v.y, args.act);
+      v.z = rn_apply_act(v.z, args.act);
+      v.w = rn_apply_act(v.w, args.act);
+      if (OUT_F32) {
+        *(float4*)((float*)sg.y + o) = v;
+      } else {
+        uint2 pk;
+        pk.x = rn_pack_bf16x2(v.x, v.y);
+        pk.y = rn_pack_bf16x2(v.z, v.w);
+        *(uint2*)((uint16_t*)sg.y + o) = pk;
+      }
+    }
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------------
+extern "C" int rn_conv_cout_pad(int Cout) { return Cout <= 64 ? 64 : (int)rn_align_up((size_t)Cout, 128); }
+
+template <int BM, int BN, int BK, bool F32>
+static int launch_conv(const ConvArgs& a, hipStream_t st) {
+  constexpr int stage = (BM + BN) * BK * 2;
+  constexpr int epi = BM * BN * 4;
+  constexpr int lds = (2 * stage > epi) ? 2 * stage : epi;
+  auto kern = conv_fwd_kernel<BM, BN, BK, F32>;
+  if (lds > 48 * 1024)
+    RN_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  hipLaunchKernelGGL(kern, dim3(a.total_tiles), dim3(CONV_THREADS), lds, st, a);
+  RN_CHECK_LAUNCH();
+  return RN_OK;
+}
+
+extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
+  RN_CHECK_ARG(p != nullptr, "rn_conv2d_nhwc_fwd: null problem");
+  RN_CHECK_ARG(p->num_segments >= 1 && p->num_segments <= RN_CONV_MAX_SEGMENTS,
+               "rn_conv2d_nhwc_fwd: num_segments=%d", p->num_segments);
+  RN_CHECK_ARG(p->R >= 1 && p->S >= 1 && p->R * p->S <= 32, "rn_conv2d_nhwc_fwd: R*S=%d > 32", p->R * p->S);
+  RN_CHECK_ARG(p->stride_h >= 1 && p->stride_w >= 1, "rn_conv2d_nhwc_fwd: bad stride");
+  RN_CHECK_ARG(p->out_dtype == RN_DT_BF16 || p->out_dtype == RN_DT_F32, "rn_conv2d_nhwc_fwd: bad out_dtype");
+  ConvArgs a;
+  a.R = p->R; a.S = p->S; a.sh = p->stride_h; a.sw = p->stride_w; a.pt = p->pad_top; a.pl = p->pad_left;
+  a.act = p->act; a.nseg = p->num_segments; a.pad_ = 0;
+  const int cout_pad0 = rn_conv_cout_pad(p->seg[0].Cout);
+  const int BN = cout_pad0 <= 64 ? 64 : 128;
+  const int BK = (p->seg[0].Cin % 64 == 0) ? 64 : 32;
+  int tiles = 0;
+  for (int i = 0; i < p->num_segments; ++i) {
+    const rn_conv_segment& s = p->seg[i];
+    RN_CHECK_ARG(s.x && s.w && s.y, "rn_conv2d_nhwc_fwd: segment %d has a null tensor", i);
+    RN_CHECK_ARG(s.N > 0 && s.H > 0 && s.W > 0 && s.Ho > 0 && s.Wo > 0 && s.Cout > 0 && s.Cin > 0,
+                 "rn_conv2d_nhwc_fwd: segment %d bad shape", i);
+    RN_CHECK_ARG(s.Cin % BK == 0, "rn_conv2d_nhwc_fwd: segment %d Cin=%d not a multiple of %d", i, s.Cin, BK);
+    RN_CHECK_ARG(s.pix_stride % 4 == 0 && s.pix_stride > 0,
+                 "rn_conv2d_nhwc_fwd: segment %d pix_stride=%d must be a positive multiple of 4", i, s.pix_stride);
+    RN_CHECK_ARG(s.Cout % 4 == 0, "rn_conv2d_nhwc_fwd: segment %d Cout=%d not a multiple of 4", i, s.Cout);
+    const int cp = rn_conv_cout_pad(s.Cout);
+    RN_CHECK_ARG((cp <= 64 ? 64 : 128) == BN, "rn_conv2d_nhwc_fwd: segments mix Cout tile widths");
+    RN_CHECK_ARG(((uintptr_t)s.x | (uintptr_t)s.w | (uintptr_t)s.y | (uintptr_t)s.residual) % 16 == 0,
+                 "rn_conv2d_nhwc_fwd: segment %d tensors must be 16-byte aligned", i);
+    const long long M = (long long)s.N * s.Ho * s.Wo;
+    RN_CHECK_ARG(M < (1ll << 31) && (long long)s.N * s.H * s.W * s.pix_stride < (1ll << 40),
+                 "rn_conv2d_nhwc_fwd: segment %d too large", i);
+    // the last input row/col a valid tap may touch must be inside the image
+    ConvSegDev& d = a.seg[i];
+    d.x = (const uint16_t*)s.x; d.w = (const uint16_t*)s.w; d.y = s.y;
+    d.scale = s.scale; d.shift = s.shift; d.residual = (const uint16_t*)s.residual;
+    d.N = s.N; d.H = s.H; d.W = s.W; d.Cin = s.Cin; d.pix_stride = s.pix_stride;
+    d.Ho = s.Ho; d.Wo = s.Wo; d.Cout = s.Cout;
+    d.M = (int)M;
+    d.tile_begin = tiles;
+    d.n_tiles = cp / BN;
+    d.pad_ = 0;
+    tiles += (int)rn_cdiv(M, 128) * d.n_tiles;
+  }
+  a.total_tiles = tiles;
+  hipStream_t st = (hipStream_t)stream;
+  const bool f32 = p->out_dtype == RN_DT_F32;
+  if (BN == 128 && BK == 64) return f32 ? launch_conv<128, 128, 64, true>(a, st) : launch_conv<128, 128, 64, false>(a, st);
+  if (BN == 64 && BK == 64) return f32 ? launch_conv<128, 64, 64, true>(a, st) : launch_conv<128, 64, 64, false>(a, st);
+  if (BN == 128 && BK == 32) return f32 ? launch_conv<128, 128, 32, true>(a, st) : launch_conv<128, 128, 32, false>(a, st);
+  return f32 ? launch_conv<128, 64, 32, true>(a, st) : launch_conv<128, 64, 32, false>(a, st);
+}
+
+// ---- weight / input packing ----------------------------------------------------------------
+__global__ void pack_weight_kernel(const float* __restrict__ w, int R, int S, int Cin, int Cout, int Cin_pad,
+                                   int Cout_pad, uint16_t* __restrict__ out) {
+  const long long total = (long long)Cout_pad * R * S * Cin_pad;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cin_pad);
+    long long t = i / Cin_pad;
+    const int s = (int)(t % S);
+    t /= S;
+    const int r = (int)(t % R);
+    const int o = (int)(t / R);
+    float v = 0.0f;
+    if (o < Cout && c < Cin) v = w[(((long long)r * S + s) * Cin + c) * Cout + o];
+    out[i] = rn_f32_to_bf16(v);
+  }
+}
+
+extern "C" int rn_pack_conv_weight(const float* w_hwio, int R, int S, int Cin, int Cout, int Cin_pad,
+                                   void* w_packed, void* stream) {
+  RN_CHECK_ARG(w_hwio && w_packed && R > 0 && S > 0 && Cin > 0 && Cout > 0 && Cin_pad >= Cin,
+               "rn_pack_conv_weight: bad argument");
+  const int Cout_pad = rn_conv_cout_pad(Cout);
+  const long long total = (long long)Cout_pad * R * S * Cin_pad;
+  int blocks = (int)(rn_cdiv(total, 256) < 4096 ? rn_cdiv(total, 256) : 4096);
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_hwio, R, S, Cin,
+                     Cout, Cin_pad, Cout_pad, (uint16_t*)w_packed);
+  RN_CHECK_LAUNCH();
+  return RN_OK;
+}
+
+// stem: HWIO [7,7,3,Cout] -> [Cout_pad][7][8 taps][4 ch]; tap 7 and channel 3 are zero
+__global__ void pack_stem_weight_kernel(const float* __restrict__ w, int Cout, int Cout_pad,
+                                        uint16_t* __restrict__ out) {
+  const int total = Cout_pad * 7 * 32;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int c = i & 3, s = (i >> 2) & 7, r = (i >> 5) % 7, o = i / (7 * 32);
+    float v = 0.0f;
+    if (o < Cout && c < 3 && s < 7) v = w[((r * 7 + s) * 3 + c) * Cout + o];
+    out[i] = rn_f32_to_bf16(v);
+  }
+}
+
+extern "C" int rn_pack_stem_weight(const float* w_hwio, int Cout, void* w_packed, void* stream) {
+  RN_CHECK_ARG(w_hwio && w_packed && Cout > 0, "rn_pack_stem_weight: bad argument");
+  const int Cout_pad = rn_conv_cout_pad(Cout);
+  hipLaunchKernelGGL(pack_stem_weight_kernel, dim3((Cout_pad * 7 * 32 + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, w_hwio, Cout, Cout_pad, (uint16_t*)w_packed);
+  RN_CHECK_LAUNCH();
+  return RN_OK;
+}
+
+extern "C" int rn_stem_padded_width(int W) { return (int)rn_align_up((size_t)W + 6 + 2, 8); }
+
+// images f32 [N,H,W,3] -> bf16 [N,H+6,Wp,4], zero border of 3 (fixed_padding for k=7) and zero
+// 4th channel.  One thread per output pixel (8-byte store); reads are 12-byte pixels.
+__global__ void __launch_bounds__(256)
+pack_stem_input_kernel(const float* __restrict__ img, int N, int H, int W, int Wp, uint2* __restrict__ out) {
+  const long long total = (long long)N * (H + 6) * Wp;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int xp = (int)(i % Wp);
+    const long long t = i / Wp;
+    const int yp = (int)(t % (H + 6));
+    const int n = (int)(t / (H + 6));
+    const int x = xp - 3, y = yp - 3;
+    uint2 o = make_uint2(0u, 0u);
+    if ((unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H) {
+      const float* p = img + (((long long)n * H + y) * W + x) * 3;
+      o.x = rn_pack_bf16x2(p[0], p[1]);
+      o.y = rn_pack_bf16x2(p[2], 0.0f);
+    }
+    out[i] = o;
+  }
+}
+
+extern "C" int rn_pack_stem_input(const float* images, int N, int H, int W, void* packed, void* stream) {
+  RN_CHECK_ARG(images && packed && N > 0 && H > 0 && W > 0, "rn_pack_stem_input: bad argument");
+  const int Wp = rn_stem_padded_width(W);
+  const long long total = (long long)N * (H + 6) * Wp;
+  int blocks = (int)(rn_cdiv(total, 256) < 8192 ? rn_cdiv(total, 256) : 8192);
+  hipLaunchKernelGGL(pack_stem_input_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, images, N, H, W,
+                     Wp, (uint2*)packed);
+  RN_CHECK_LAUNCH();
+  return RN_OK;
+}

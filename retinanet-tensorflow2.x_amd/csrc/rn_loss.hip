@@ -1,0 +1,233 @@
+// rn_loss.hip — a9: sigmoid focal loss + Huber box loss, fused forward + backward.
+// Reference: retinanet/losses/loss_impl.py:15-28 (FocalLossV1.call), :41-77 (ClassLoss),
+//            :88-105 (BoxLoss), retinanet/losses/retinanet_loss.py:37-83 (normaliser, weights).
+//
+// Per logit x with one-hot label y (targets -1/-2 give an all-zero row, loss_impl.py:52-56):
+//   ys = y(1-ls) + 0.5 ls;  ce = max(x,0) - x ys + log1p(exp(-|x|));  p = sigmoid(x)
+//   a_t = y==1 ? alpha : 1-alpha;  q = 1 - p_t = y==1 ? 1-p : p;  L = a_t q^gamma ce
+//   dL/dx = a_t [ q^gamma (p - ys) + ce * dq^gamma/dx ],
+//           dq^gamma/dx = y==1 ? -gamma p q^gamma : gamma (1-p) q^gamma
+// masked (L = 0, dL = 0) where the anchor's target is -2 (loss_impl.py:60-70).
+// Box: e = pred - target; Huber(delta); weight = (target != 0) per coordinate (:94-101).
+// Sums are two-stage and deterministic: per-thread fp32 -> per-block double partial ->
+// one finalize block adds the partials in index order.
+// HBM-bound: algorithmic bytes 8 B per logit (4 read + 4 grad write) + 4 B/80 target.
+#include "rn_common.h"
+#include "../../include/rn_math.h"
+
+#define RN_LOSS_THREADS 256
+#define RN_LOSS_MAX_LEVELS 8
+
+struct LossLevels {
+  int num_levels;
+  const float* cls[RN_LOSS_MAX_LEVELS];
+  const float* box[RN_LOSS_MAX_LEVELS];
+  float* dcls[RN_LOSS_MAX_LEVELS];
+  float* dbox[RN_LOSS_MAX_LEVELS];
+  long long off[RN_LOSS_MAX_LEVELS + 1];   // anchor boundaries
+  long long vbeg[RN_LOSS_MAX_LEVELS + 1];  // prefix of B*n_l*(K/V) work items
+};
+
+__device__ __forceinline__ void focal_elem(float x, bool pos, float alpha, float gamma, float ls, float& loss,
+                                           float& grad) {
+  const float y = pos ? 1.0f : 0.0f;
+  const float ys = y * (1.0f - ls) + 0.5f * ls;
+  const float ax = fabsf(x);
+  const float t = rn_expf(-ax);                     // e^-|x| in (0,1]
+  const float ce = fmaxf(x, 0.0f) - x * ys + rn_log1pf_pos(t);
+  const float inv = 1.0f / (1.0f + t);
+  const float p = x >= 0.0f ? inv : t * inv;        // sigmoid(x), stable both signs
+  const float omp = x >= 0.0f ? t * inv : inv;      // 1 - sigmoid(x)
+  const float q = pos ? omp : p;
+  const float a_t = pos ? alpha : 1.0f - alpha;
+  const float mod = q > 0.0f ? rn_expf(gamma * rn_logf(q)) : 0.0f;  // q^gamma
+  loss = a_t * mod * ce;
+  const float dmod = pos ? -gamma * p * mod : gamma * omp * mod;
+  grad = a_t * (mod * (p - ys) + ce * dmod);
+}
+
+template <int V>
+__global__ void __launch_bounds__(RN_LOSS_THREADS)
+focal_kernel(LossLevels lv, int B, int K, long long A, const float* __restrict__ class_targets,
+             const float* __restrict__ normalizer, float alpha, float gamma, float ls, float gscale,
+             int write_grad, double* __restrict__ partials) {
+  const int KV = K / V;
+  const long long total = lv.vbeg[lv.num_levels];
+  float acc = 0.0f;
+  const float gs = gscale / normalizer[0];
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    int l = 0;
+    while (l + 1 < lv.num_levels && i >= lv.vbeg[l + 1]) ++l;
+    const long long local = i - lv.vbeg[l];
+    const long long n_l = lv.off[l + 1] - lv.off[l];
+    const long long row = local / KV;  // b * n_l + j
+    const int kv = (int)(local - row * KV);
+    const long long b = row / n_l;
+    const long long j = row - b * n_l;
+    const float ct = class_targets[b * A + lv.off[l] + j];
+    const bool ignore = (ct == -2.0f);
+    const int cls = (int)ct;
+    const float* src = lv.cls[l] + row * K + (long long)kv * V;
+    float x[V], g[V];
+    if (V == 4) {
+      const float4 v = *(const float4*)src;
+      x[0] = v.x; x[1 % V] = v.y; x[2 % V] = v.z; x[3 % V] = v.w;
+    } else {
+      x[0] = src[0];
+    }
+#pragma unroll
+    for (int u = 0; u < V; ++u) {
+      float lo, gr;
+      focal_elem(x[u], (kv * V + u) == cls, alpha, gamma, ls, lo, gr);
+      if (ignore) { lo = 0.0f; gr = 0.0f; }
+      acc += lo;
+      g[u] = gr * gs;
+    }
+    if (write_grad) {
+      float* dst = lv.dcls[l] + row * K + (long long)kv * V;
+      if (V == 4) *(float4*)dst = make_float4(g[0], g[1 % V], g[2 % V], g[3 % V]);
+      else dst[0] = g[0];
+    }
+  }
+  __shared__ double sred[RN_LOSS_THREADS / 64];
+  double d = rn_wave_sum_d((double)acc);
+  if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = d;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int w = 0; w < RN_LOSS_THREADS / 64; ++w) s += sred[w];
+    partials[blockIdx.x] = s;
+  }
+}
+
+__global__ void __launch_bounds__(RN_LOSS_THREADS)
+huber_kernel(LossLevels lv, int B, long long A, const float4* __restrict__ box_targets,
+             const float* __restrict__ normalizer, float delta, float gscale, int write_grad,
+             double* __restrict__ partials) {
+  const long long total = (long long)B * A;
+  float acc = 0.0f;
+  const float gs = gscale / normalizer[0];
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / A;
+    const long long a = i - b * A;
+    int l = 0;
+    while (l + 1 < lv.num_levels && a >= lv.off[l + 1]) ++l;
+    const long long n_l = lv.off[l + 1] - lv.off[l];
+    const long long row = b * n_l + (a - lv.off[l]);
+    const float4 p = ((const float4*)lv.box[l])[row];
+    const float4 t = box_targets[i];
+    const float pv[4] = {p.x, p.y, p.z, p.w};
+    const float tv[4] = {t.x, t.y, t.z, t.w};
+    float gv[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float e = pv[c] - tv[c];
+      const float ae = fabsf(e);
+      const bool quad = ae <= delta;
+      float lo = quad ? 0.5f * (e * e) : delta * ae - 0.5f * (delta * delta);
+      float gr = quad ? e : (e > 0.0f ? delta : -delta);
+      if (tv[c] == 0.0f) { lo = 0.0f; gr = 0.0f; }
+      acc += lo;
+      gv[c] = gr * gs;
+    }
+    if (write_grad) ((float4*)lv.dbox[l])[row] = make_float4(gv[0], gv[1], gv[2], gv[3]);
+  }
+  __shared__ double sred[RN_LOSS_THREADS / 64];
+  double d = rn_wave_sum_d((double)acc);
+  if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = d;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int w = 0; w < RN_LOSS_THREADS / 64; ++w) s += sred[w];
+    partials[blockIdx.x] = s;
+  }
+}
+
+__global__ void loss_finalize(const double* __restrict__ cls_part, int ncls, const double* __restrict__ box_part,
+                              int nbox, const float* __restrict__ normalizer, float box_w, float cls_w,
+                              float* __restrict__ losses) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double cs = 0.0, bs = 0.0;
+    for (int i = 0; i < ncls; ++i) cs += cls_part[i];
+    for (int i = 0; i < nbox; ++i) bs += box_part[i];
+    const float norm = normalizer[0];
+    const float class_loss = (float)cs / norm;
+    const float box_loss = ((float)bs / 4.0f) / norm;  // loss_impl.py:105 then retinanet_loss.py:59-60
+    losses[0] = box_loss;
+    losses[1] = class_loss;
+    losses[2] = box_w * box_loss + cls_w * class_loss;
+    losses[3] = norm;
+  }
+}
+
+static int loss_blocks(long long items) {
+  long long b = rn_cdiv(items, RN_LOSS_THREADS);
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+extern "C" size_t rn_loss_workspace_bytes(int B, int64_t A, int K) {
+  (void)B; (void)A; (void)K;
+  return 2 * 2048 * sizeof(double);
+}
+
+extern "C" int rn_retinanet_loss_fwd_bwd(const float* const* class_logits, const float* const* box_preds,
+                                         float* const* d_class_logits, float* const* d_box_preds,
+                                         const int64_t* level_offsets, int num_levels, int B, int K,
+                                         const float* class_targets, const float* box_targets,
+                                         const float* normalizer, float alpha, float gamma,
+                                         float label_smoothing, float delta, float box_loss_weight,
+                                         float class_loss_weight, float grad_scale, float* losses,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+  RN_CHECK_ARG(class_logits && box_preds && level_offsets && class_targets && box_targets && normalizer && losses,
+               "rn_retinanet_loss_fwd_bwd: null argument");
+  RN_CHECK_ARG(num_levels >= 1 && num_levels <= RN_LOSS_MAX_LEVELS && B > 0 && K > 0,
+               "rn_retinanet_loss_fwd_bwd: bad num_levels=%d B=%d K=%d", num_levels, B, K);
+  if (!workspace || workspace_bytes < rn_loss_workspace_bytes(B, 0, K)) {
+    rn_set_error("rn_retinanet_loss_fwd_bwd: workspace too small");
+    return RN_ENOMEM;
+  }
+  const int V = (K % 4 == 0) ? 4 : 1;
+  const int write_grad = (d_class_logits && d_box_preds) ? 1 : 0;
+  LossLevels lv;
+  lv.num_levels = num_levels;
+  lv.off[0] = level_offsets[0];
+  lv.vbeg[0] = 0;
+  for (int l = 0; l < num_levels; ++l) {
+    lv.cls[l] = class_logits[l];
+    lv.box[l] = box_preds[l];
+    lv.dcls[l] = write_grad ? d_class_logits[l] : nullptr;
+    lv.dbox[l] = write_grad ? d_box_preds[l] : nullptr;
+    lv.off[l + 1] = level_offsets[l + 1];
+    const long long n_l = level_offsets[l + 1] - level_offsets[l];
+    RN_CHECK_ARG(n_l > 0, "rn_retinanet_loss_fwd_bwd: empty level %d", l);
+    lv.vbeg[l + 1] = lv.vbeg[l] + (long long)B * n_l * (K / V);
+  }
+  RN_CHECK_ARG(lv.off[0] == 0, "rn_retinanet_loss_fwd_bwd: level_offsets[0] must be 0");
+  const long long A = lv.off[num_levels];
+  hipStream_t st = (hipStream_t)stream;
+  double* cls_part = (double*)workspace;
+  double* box_part = cls_part + 2048;
+  const int nb_cls = loss_blocks(lv.vbeg[num_levels]);
+  const int nb_box = loss_blocks((long long)B * A);
+  if (V == 4)
+    hipLaunchKernelGGL(focal_kernel<4>, dim3(nb_cls), dim3(RN_LOSS_THREADS), 0, st, lv, B, K, A, class_targets,
+                       normalizer, alpha, gamma, label_smoothing, class_loss_weight * grad_scale, write_grad,
+                       cls_part);
+  else
+    hipLaunchKernelGGL(focal_kernel<1>, dim3(nb_cls), dim3(RN_LOSS_THREADS), 0, st, lv, B, K, A, class_targets,
+                       normalizer, alpha, gamma, label_smoothing, class_loss_weight * grad_scale, write_grad,
+                       cls_part);
+  RN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(huber_kernel, dim3(nb_box), dim3(RN_LOSS_THREADS), 0, st, lv, B, A,
+                     (const float4*)box_targets, normalizer, delta, box_loss_weight * grad_scale / 4.0f,
+                     write_grad, box_part);
+  RN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(loss_finalize, dim3(1), dim3(64), 0, st, cls_part, nb_cls, box_part, nb_box, normalizer,
+                     box_loss_weight, class_loss_weight, losses);
+  RN_CHECK_LAUNCH();
+  return RN_OK;
+}

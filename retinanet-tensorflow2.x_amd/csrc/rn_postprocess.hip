@@ -1,0 +1,716 @@
+// rn_postprocess.hip — a11-a14: box decode, sigmoid, per-class top-k, per-class NMS, merge.
+// Reference: retinanet/model/layers/postprocessing_ops.py:15-56 (FuseDetections), :87-117
+// (TransformBoxesAndScores), :128-147 (FilterTopKDetections._filter_per_class), :434-535
+// (GenerateDetections._per_class_nms) and TensorFlow's NonMaxSuppressionV5 semantics as
+// restated in SURVEY.md §8(c) item 6 (TF itself is not vendored in the reference).
+//
+// MI355X design (not a translation of the TF op chain):
+//   * The per-level head outputs [B,s,s,A*K] are already [B, n_l, K] row-major, so
+//     FuseDetections is pure indexing: kernels take the 5 level pointers + anchor boundaries.
+//   * compact: ONE coalesced pass over the logits computes sigmoid and appends
+//     key = score_bits<<32 | ~anchor to the (image,class) candidate list iff score >
+//     score_threshold.  NonMaxSuppressionV5 only ever looks at such candidates and top-k keeps
+//     the k largest, so "top-k then threshold" == "threshold then top-k of the survivors":
+//     the [B,5000,K] scores / [B,5000,K,4] boxes tensors of the reference are never built.
+//     Sorting keys descending gives (score desc, anchor asc) = the canonical top_k order.
+//   * select/sort/NMS: one 256-thread workgroup per (image,class).  Candidates stream through
+//     LDS in descending order in chunks of <= 8192 keys (bitonic sort; a radix select over the
+//     global list finds each chunk's lower bound when the list is longer), and a single
+//     wavefront runs greedy NMS over 64 candidates at a time: IoU against the already selected
+//     boxes in parallel, a 64x64 in-register suppression mask, then a 64-step ballot scan.
+//   * merge: one workgroup per image sorts the K*max_det padded scores and emits the final
+//     top max_det (descending, ties by class-major slot), valid count, -1 padding.
+// All fp32 arithmetic is contraction-free and uses rn_math.h, so scores, keep masks and
+// outputs are bit-identical to the C oracle.
+#include "rn_common.h"
+#include "../../include/rn_math.h"
+
+#define RN_PP_THREADS 256
+#define RN_PP_MAX_LEVELS 8
+#define RN_SORT_CAP 8192
+#define RN_MAX_DET 256
+
+struct PPLevels {
+  int num_levels;
+  const float* ptr[RN_PP_MAX_LEVELS];
+  long long off[RN_PP_MAX_LEVELS + 1];
+  long long vbeg[RN_PP_MAX_LEVELS + 1];
+};
+
+static int pp_fill_levels(PPLevels& lv, const float* const* ptrs, const int64_t* level_offsets, int num_levels,
+                          int B, int per_anchor_items) {
+  if (num_levels < 1 || num_levels > RN_PP_MAX_LEVELS || !ptrs || !level_offsets) return -1;
+  lv.num_levels = num_levels;
+  lv.off[0] = level_offsets[0];
+  lv.vbeg[0] = 0;
+  if (lv.off[0] != 0) return -1;
+  for (int l = 0; l < num_levels; ++l) {
+    lv.ptr[l] = ptrs[l];
+    lv.off[l + 1] = level_offsets[l + 1];
+    const long long n_l = lv.off[l + 1] - lv.off[l];
+    if (n_l <= 0 || !ptrs[l]) return -1;
+    lv.vbeg[l + 1] = lv.vbeg[l] + (long long)B * n_l * per_anchor_items;
+  }
+  return 0;
+}
+
+static int pp_blocks(long long items) {
+  long long b = rn_cdiv(items, RN_PP_THREADS);
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// ------------------------------------------------------------------------------------------
+// decode  (postprocessing_ops.py:87-105)
+__global__ void __launch_bounds__(RN_PP_THREADS)
+decode_kernel(PPLevels lv, int B, long long A, const float4* __restrict__ anchors, float4 var, int use_var,
+              float in_h, float in_w, float4* __restrict__ boxes) {
+  const long long total = (long long)B * A;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / A, a = i - b * A;
+    int l = 0;
+    while (l + 1 < lv.num_levels && a >= lv.off[l + 1]) ++l;
+    const long long n_l = lv.off[l + 1] - lv.off[l];
+    float4 t = ((const float4*)lv.ptr[l])[b * n_l + (a - lv.off[l])];
+    const float4 an = anchors[a];
+    if (use_var) {
+      t.x = t.x * var.x; t.y = t.y * var.y; t.z = t.z * var.z; t.w = t.w * var.w;
+    }
+    const float cx = t.x * an.z + an.x;
+    const float cy = t.y * an.w + an.y;
+    const float w = rn_expf(t.z) * an.z;
+    const float h = rn_expf(t.w) * an.w;
+    const float hw = w / 2.0f, hh = h / 2.0f;
+    float4 o;
+    // the reference divides [x1,y1,x2,y2] by tile(input_shape) = [h,w,h,w] (:65-69,104)
+    o.x = (cx - hw) / in_h;
+    o.y = (cy - hh) / in_w;
+    o.z = (cx + hw) / in_h;
+    o.w = (cy + hh) / in_w;
+    boxes[i] = o;
+  }
+}
+
+extern "C" int rn_decode_boxes(const float* const* box_preds, const int64_t* level_offsets, int num_levels,
+                               int B, const float* anchors, const float* box_variance, float input_h,
+                               float input_w, float* boxes, void* stream) {
+  PPLevels lv;
+  RN_CHECK_ARG(B > 0 && anchors && boxes, "rn_decode_boxes: bad argument");
+  RN_CHECK_ARG(pp_fill_levels(lv, box_preds, level_offsets, num_levels, B, 1) == 0,
+               "rn_decode_boxes: bad level table");
+  const long long A = lv.off[num_levels];
+  float4 var = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (box_variance) var = make_float4(box_variance[0], box_variance[1], box_variance[2], box_variance[3]);
+  hipLaunchKernelGGL(decode_kernel, dim3(pp_blocks((long long)B * A)), dim3(RN_PP_THREADS), 0,
+                     (hipStream_t)stream, lv, B, A, (const float4*)anchors, var, box_variance ? 1 : 0, input_h,
+                     input_w, (float4*)boxes);
+  RN_CHECK_LAUNCH();
+  return RN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// sigmoid scores, flattened [B,A,K]  (postprocessing_ops.py:111-114)
+__global__ void __launch_bounds__(RN_PP_THREADS)
+sigmoid_kernel(PPLevels lv, int B, int K, long long A, float* __restrict__ scores) {
+  const long long total = lv.vbeg[lv.num_levels];
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    int l = 0;
+    while (l + 1 < lv.num_levels && i >= lv.vbeg[l + 1]) ++l;
+    const long long local = i - lv.vbeg[l];
+    const long long n_l = lv.off[l + 1] - lv.off[l];
+    const long long row = local / K;
+    const int k = (int)(local - row * K);
+    const long long b = row / n_l, j = row - b * n_l;
+    scores[(b * A + lv.off[l] + j) * K + k] = rn_sigmoidf(lv.ptr[l][local]);
+  }
+}
+
+extern "C" int rn_sigmoid_scores(const float* const* class_logits, const int64_t* level_offsets,
+                                 int num_levels, int B, int K, float* scores, void* stream) {
+  PPLevels lv;
+  RN_CHECK_ARG(B > 0 && K > 0 && scores, "rn_sigmoid_scores: bad argument");
+  RN_CHECK_ARG(pp_fill_levels(lv, class_logits, level_offsets, num_levels, B, K) == 0,
+               "rn_sigmoid_scores: bad level table");
+  hipLaunchKernelGGL(sigmoid_kernel, dim3(pp_blocks(lv.vbeg[num_levels])), dim3(RN_PP_THREADS), 0,
+                     (hipStream_t)stream, lv, B, K, lv.off[num_levels], scores);
+  RN_CHECK_LAUNCH();
+  return RN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// candidate compaction
+// float -> uint32 whose unsigned order equals the float order (negatives included)
+__device__ __forceinline__ unsigned int ord_bits(float f) {
+  const unsigned int u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_score(unsigned long long key) {
+  const unsigned int o = (unsigned int)(key >> 32);
+  return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+__device__ __forceinline__ unsigned int key_index(unsigned long long key) {
+  return ~(unsigned int)(key & 0xffffffffull);
+}
+__device__ __forceinline__ unsigned long long make_key(float score, unsigned int idx) {
+  return (((unsigned long long)ord_bits(score)) << 32) | (unsigned long long)(~idx);
+}
+
+// from logits (fused sigmoid), all levels
+__global__ void __launch_bounds__(RN_PP_THREADS)
+compact_logits_kernel(PPLevels lv, int B, int K, long long A, float thr, int* __restrict__ counts,
+                      unsigned long long* __restrict__ keys, long long cap) {
+  const long long total = lv.vbeg[lv.num_levels];
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    int l = 0;
+    while (l + 1 < lv.num_levels && i >= lv.vbeg[l + 1]) ++l;
+    const long long local = i - lv.vbeg[l];
+    const long long n_l = lv.off[l + 1] - lv.off[l];
+    const long long row = local / K;
+    const int k = (int)(local - row * K);
+    const long long b = row / n_l, j = row - b * n_l;
+    const float s = rn_sigmoidf(lv.ptr[l][local]);
+    if (s > thr) {
+      const long long list = b * K + k;
+      const int slot = atomicAdd(&counts[list], 1);
+      if (slot < cap) keys[list * cap + slot] = make_key(s, (unsigned int)(lv.off[l] + j));
+    }
+  }
+}
+
+// from a dense score tensor [B, n, K] (stand-alone top-k / NMS entry points)
+__global__ void __launch_bounds__(RN_PP_THREADS)
+compact_scores_kernel(const float* __restrict__ scores, int B, long long n, int K, float thr, int use_thr,
+                      int* __restrict__ counts, unsigned long long* __restrict__ keys, long long cap) {
+  const long long total = (long long)B * n * K;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i / K;
+    const int k = (int)(i - row * K);
+    const long long b = row / n, j = row - b * n;
+    const float s = scores[i];
+    if (!use_thr || s > thr) {
+      const long long list = b * K + k;
+      const int slot = atomicAdd(&counts[list], 1);
+      if (slot < cap) keys[list * cap + slot] = make_key(s, (unsigned int)j);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// block-level helpers over an LDS key array
+__device__ void bitonic_sort_desc(unsigned long long* s, int N) {
+  for (int k = 2; k <= N; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = threadIdx.x; t < (N >> 1); t += blockDim.x) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int p = i | j;
+        const unsigned long long a = s[i], b = s[p];
+        const bool desc = (i & k) == 0;
+        if (desc ? (a < b) : (a > b)) {
+          s[i] = b;
+          s[p] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// k-th largest (1-based) among keys[0..n) that are < upper.  Keys are unique.
+__device__ unsigned long long radix_select_desc(const unsigned long long* __restrict__ keys, int n,
+                                                unsigned long long upper, int kth, int* hist /*256*/,
+                                                unsigned long long* s_prefix, int* s_k) {
+  if (threadIdx.x == 0) {
+    *s_prefix = 0ull;
+    *s_k = kth;
+  }
+  unsigned long long mask = 0ull;
+  for (int shift = 56; shift >= 0; shift -= 8) {
+    for (int t = threadIdx.x; t < 256; t += blockDim.x) hist[t] = 0;
+    __syncthreads();
+    const unsigned long long prefix = *s_prefix;
+    for (int t = threadIdx.x; t < n; t += blockDim.x) {
+      const unsigned long long key = keys[t];
+      if (key < upper && (key & mask) == prefix) atomicAdd(&hist[(int)((key >> shift) & 255ull)], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int kk = *s_k, cum = 0, d = 255;
+      for (; d > 0; --d) {
+        if (cum + hist[d] >= kk) break;
+        cum += hist[d];
+      }
+      *s_k = kk - cum;
+      *s_prefix = prefix | (((unsigned long long)d) << shift);
+    }
+    mask |= 255ull << shift;
+    __syncthreads();
+  }
+  return *s_prefix;
+}
+
+struct BoxSrc {
+  const float4* base;
+  long long img_stride, idx_stride, cls_stride;  // float4 units
+};
+
+__device__ __forceinline__ float4 fetch_clipped(const BoxSrc& bs, int b, int c, unsigned int idx) {
+  float4 v = bs.base[(long long)b * bs.img_stride + (long long)idx * bs.idx_stride + (long long)c * bs.cls_stride];
+  // tf.clip_by_value(boxes, 0, 1)  (postprocessing_ops.py:501)
+  v.x = fminf(fmaxf(v.x, 0.0f), 1.0f);
+  v.y = fminf(fmaxf(v.y, 0.0f), 1.0f);
+  v.z = fminf(fmaxf(v.z, 0.0f), 1.0f);
+  v.w = fminf(fmaxf(v.w, 0.0f), 1.0f);
+  return v;
+}
+
+// TensorFlow NonMaxSuppression IOU: canonicalise corners, zero/negative area -> 0.
+__device__ __forceinline__ float nms_iou(float4 a, float4 b) {
+  const float ay0 = fminf(a.x, a.z), ax0 = fminf(a.y, a.w), ay1 = fmaxf(a.x, a.z), ax1 = fmaxf(a.y, a.w);
+  const float by0 = fminf(b.x, b.z), bx0 = fminf(b.y, b.w), by1 = fmaxf(b.x, b.z), bx1 = fmaxf(b.y, b.w);
+  const float area_a = (ay1 - ay0) * (ax1 - ax0);
+  const float area_b = (by1 - by0) * (bx1 - bx0);
+  if (area_a <= 0.0f || area_b <= 0.0f) return 0.0f;
+  const float iy0 = fmaxf(ay0, by0), ix0 = fmaxf(ax0, bx0);
+  const float iy1 = fminf(ay1, by1), ix1 = fminf(ax1, bx1);
+  const float inter = fmaxf(iy1 - iy0, 0.0f) * fmaxf(ix1 - ix0, 0.0f);
+  return inter / (area_a + area_b - inter);
+}
+
+__device__ __forceinline__ float4 shfl_box(float4 v, int src) {
+  float4 r;
+  r.x = __shfl(v.x, src, 64);
+  r.y = __shfl(v.y, src, 64);
+  r.z = __shfl(v.z, src, 64);
+  r.w = __shfl(v.w, src, 64);
+  return r;
+}
+
+// One workgroup per (image, class).  Dynamic LDS: keys[RN_SORT_CAP] | sel boxes | sel scores
+// | soft-NMS state | hist.
+struct NmsParams {
+  int B, K, max_det, top_k;
+  float iou_thr, score_thr, soft_scale;  // soft_scale = -0.5/(sigma/2) when soft, else 0
+  int soft;
+  long long cap;
+};
+
+__global__ void __launch_bounds__(RN_PP_THREADS)
+nms_per_class_kernel(NmsParams p, const int* __restrict__ counts, const unsigned long long* __restrict__ keys_g,
+                     BoxSrc bs, float* __restrict__ sel_scores, float4* __restrict__ sel_boxes) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned long long* skeys = (unsigned long long*)smem;                       // RN_SORT_CAP * 8
+  float4* s_selbox = (float4*)(smem + (size_t)RN_SORT_CAP * 8);                // RN_MAX_DET * 16
+  float* s_selscore = (float*)((char*)s_selbox + (size_t)RN_MAX_DET * 16);     // RN_MAX_DET * 4
+  int* s_hist = (int*)((char*)s_selscore + (size_t)RN_MAX_DET * 4);            // 256 * 4
+  unsigned long long* s_prefix = (unsigned long long*)((char*)s_hist + 1024);  // 8
+  int* s_misc = (int*)((char*)s_prefix + 8);                                   // [0]=k scratch [1]=fill [2]=nsel
+  float* s_cur = (float*)((char*)s_misc + 16);                                 // soft: RN_SORT_CAP * 4
+  unsigned short* s_sbi = (unsigned short*)((char*)s_cur + (p.soft ? (size_t)RN_SORT_CAP * 4 : 0));
+
+  const int list = blockIdx.x;  // b*K + c
+  const int b = list / p.K, c = list - b * p.K;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  long long n_ll = counts[list];
+  if (n_ll > p.cap) n_ll = p.cap;
+  const int n = (int)n_ll;
+  const unsigned long long* keys = keys_g + (long long)list * p.cap;
+  int limit = n;
+  if (p.top_k > 0 && limit > p.top_k) limit = p.top_k;
+  if (p.soft && limit > RN_SORT_CAP) limit = RN_SORT_CAP;  // host rejects configs that could reach this
+
+  if (threadIdx.x == 0) s_misc[2] = 0;
+  __syncthreads();
+
+  unsigned long long upper = ~0ull;
+  int processed = 0;
+  while (processed < limit) {
+    if (s_misc[2] >= p.max_det) break;
+    const int take = (limit - processed) < RN_SORT_CAP ? (limit - processed) : RN_SORT_CAP;
+    unsigned long long lower = 0ull;
+    if (n - processed > take) lower = radix_select_desc(keys, n, upper, take, s_hist, s_prefix, &s_misc[0]);
+    // gather keys in [lower, upper) into LDS
+    int N2 = 64;
+    while (N2 < take) N2 <<= 1;
+    if (threadIdx.x == 0) s_misc[1] = 0;
+    for (int t = threadIdx.x; t < N2; t += blockDim.x) skeys[t] = 0ull;
+    __syncthreads();
+    for (int t = threadIdx.x; t < n; t += blockDim.x) {
+      const unsigned long long key = keys[t];
+      if (key >= lower && key < upper) {
+        const int slot = atomicAdd(&s_misc[1], 1);
+        if (slot < N2) skeys[slot] = key;
+      }
+    }
+    __syncthreads();
+    bitonic_sort_desc(skeys, N2);
+    const int m = take;
+
+    if (wave == 0) {
+      int nsel = s_misc[2];
+      if (!p.soft) {
+        // ---- greedy hard NMS, 64 candidates per step --------------------------------------
+        for (int base = 0; base < m && nsel < p.max_det; base += 64) {
+          const int i = base + lane;
+          const bool valid = i < m;
+          const unsigned long long key = valid ? skeys[i] : 0ull;
+          const float score = key_score(key);
+          const unsigned int idx = key_index(key);
+          float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (valid) box = fetch_clipped(bs, b, c, idx);
+          bool alive = valid;
+          for (int j = 0; j < nsel; ++j) {
+            const float4 sb = s_selbox[j];
+            if (alive && nms_iou(box, sb) > p.iou_thr) alive = false;
+          }
+          unsigned long long mask = 0ull;  // earlier lanes of this group that suppress me
+          for (int j = 0; j < 63; ++j) {
+            const float4 ob = shfl_box(box, j);
+            if (j < lane && nms_iou(box, ob) > p.iou_thr) mask |= 1ull << j;
+          }
+          unsigned long long alive_mask = __ballot(alive);
+          for (int j = 0; j < 64; ++j) {
+            if (!((alive_mask >> j) & 1ull)) continue;
+            if (nsel >= p.max_det) break;
+            if (lane == j) {
+              s_selbox[nsel] = box;
+              s_selscore[nsel] = score;
+            }
+            ++nsel;
+            const unsigned long long kill = __ballot((mask >> j) & 1ull);
+            alive_mask &= ~kill;
+          }
+          __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): selected boxes visible to the wave
+        }
+      } else {
+        // ---- soft NMS: exact emulation of NonMaxSuppressionV5's priority queue ------------
+        for (int i = lane; i < m; i += 64) {
+          s_cur[i] = key_score(skeys[i]);
+          s_sbi[i] = 0;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        while (nsel < p.max_det) {
+          // argmax (score, then lowest position) over live candidates (score > thr)
+          float best = -1.0f;
+          int besti = 0x7fffffff;
+          for (int i = lane; i < m; i += 64) {
+            const float sc = s_cur[i];
+            if (sc > p.score_thr && (sc > best)) {  // ascending i per lane -> first max kept
+              best = sc;
+              besti = i;
+            }
+          }
+          for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(besti, o, 64);
+            if (ob > best || (ob == best && oi < besti)) {
+              best = ob;
+              besti = oi;
+            }
+          }
+          if (besti == 0x7fffffff) break;  // queue empty
+          const unsigned int idx = key_index(skeys[besti]);
+          const float4 box = fetch_clipped(bs, b, c, idx);
+          const int begin = s_sbi[besti];
+          float score = best;
+          // newest -> oldest; weights computed 64 at a time, multiplied in order by all lanes
+          for (int hi = nsel - 1; hi >= begin && score > p.score_thr; hi -= 64) {
+            const int j = hi - lane;
+            float w = 1.0f;
+            if (j >= begin) {
+              const float sim = nms_iou(box, s_selbox[j]);
+              w = rn_expf(p.soft_scale * sim * sim);
+            }
+            const int cnt = (hi - begin + 1) < 64 ? (hi - begin + 1) : 64;
+            for (int q = 0; q < cnt; ++q) {
+              score = score * __shfl(w, q, 64);
+              if (score <= p.score_thr) break;
+            }
+          }
+          if (lane == 0) {
+            s_sbi[besti] = (unsigned short)nsel;
+            if (score == best) {
+              s_selbox[nsel] = box;
+              s_selscore[nsel] = score;
+              s_cur[besti] = -1.0f;  // popped for good
+            } else {
+              s_cur[besti] = score > p.score_thr ? score : -1.0f;
+            }
+          }
+          if (score == best) ++nsel;
+          __builtin_amdgcn_s_waitcnt(0xc07f);
+        }
+      }
+      if (lane == 0) s_misc[2] = nsel;
+    }
+    __syncthreads();
+    upper = lower;
+    processed += take;
+    if (lower == 0ull) break;
+  }
+  __syncthreads();
+  // write padded per-class results (NonMaxSuppressionV5 pads scores with 0)
+  const int nsel = s_misc[2];
+  for (int t = threadIdx.x; t < p.max_det; t += blockDim.x) {
+    const bool ok = t < nsel;
+    sel_scores[(long long)list * p.max_det + t] = ok ? s_selscore[t] : 0.0f;
+    sel_boxes[(long long)list * p.max_det + t] = ok ? s_selbox[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+// ---- merge: top max_det over K*max_det padded class results (postprocessing_ops.py:471-490)
+__global__ void __launch_bounds__(RN_PP_THREADS)
+merge_kernel(int K, int max_det, const float* __restrict__ sel_scores, const float4* __restrict__ sel_boxes,
+             float4* __restrict__ det_boxes, float* __restrict__ det_scores, int* __restrict__ det_classes,
+             int* __restrict__ valid_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned long long* skeys = (unsigned long long*)smem;
+  const int b = blockIdx.x;
+  const int total = K * max_det;
+  int N2 = 64;
+  while (N2 < total) N2 <<= 1;
+  int& s_valid = *(int*)(smem + (size_t)N2 * 8);
+  if (threadIdx.x == 0) s_valid = 0;
+  for (int t = threadIdx.x; t < N2; t += blockDim.x)
+    skeys[t] = t < total ? make_key(sel_scores[(long long)b * total + t], (unsigned int)t) : 0ull;
+  __syncthreads();
+  bitonic_sort_desc(skeys, N2);
+  int cnt = 0;
+  for (int t = threadIdx.x; t < max_det; t += blockDim.x) {
+    const float s = key_score(skeys[t]);
+    if (s > 0.0f) ++cnt;
+  }
+  if (cnt) atomicAdd(&s_valid, cnt);
+  __syncthreads();
+  const int valid = s_valid;
+  for (int t = threadIdx.x; t < max_det; t += blockDim.x) {
+    const unsigned long long key = skeys[t];
+    const float s = key_score(key);
+    const unsigned int flat = key_index(key);
+    const bool ok = t < valid;
+    det_scores[(long long)b * max_det + t] = ok ? s : -1.0f;
+    det_classes[(long long)b * max_det + t] = ok ? (int)(flat / (unsigned int)max_det) : -1;
+    det_boxes[(long long)b * max_det + t] =
+        ok ? sel_boxes[(long long)b * total + flat] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (threadIdx.x == 0) valid_out[b] = valid;
+}
+
+// ---- top-k emit: sorted chunks written straight to [B,k,K] ---------------------------------
+__global__ void __launch_bounds__(RN_PP_THREADS)
+topk_emit_kernel(int K, int k_out, const int* __restrict__ counts, const unsigned long long* __restrict__ keys_g,
+                 long long cap, float* __restrict__ out_scores, int* __restrict__ out_idx) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned long long* skeys = (unsigned long long*)smem;
+  int* s_hist = (int*)(smem + (size_t)RN_SORT_CAP * 8);
+  unsigned long long* s_prefix = (unsigned long long*)((char*)s_hist + 1024);
+  int* s_misc = (int*)((char*)s_prefix + 8);
+  const int list = blockIdx.x;
+  const int b = list / K, c = list - b * K;
+  long long n_ll = counts[list];
+  if (n_ll > cap) n_ll = cap;
+  const int n = (int)n_ll;
+  const unsigned long long* keys = keys_g + (long long)list * cap;
+  const int limit = n < k_out ? n : k_out;
+  unsigned long long upper = ~0ull;
+  int processed = 0;
+  while (processed < limit) {
+    const int take = (limit - processed) < RN_SORT_CAP ? (limit - processed) : RN_SORT_CAP;
+    unsigned long long lower = 0ull;
+    if (n - processed > take) lower = radix_select_desc(keys, n, upper, take, s_hist, s_prefix, &s_misc[0]);
+    int N2 = 64;
+    while (N2 < take) N2 <<= 1;
+    if (threadIdx.x == 0) s_misc[1] = 0;
+    for (int t = threadIdx.x; t < N2; t += blockDim.x) skeys[t] = 0ull;
+    __syncthreads();
+    for (int t = threadIdx.x; t < n; t += blockDim.x) {
+      const unsigned long long key = keys[t];
+      if (key >= lower && key < upper) {
+        const int slot = atomicAdd(&s_misc[1], 1);
+        if (slot < N2) skeys[slot] = key;
+      }
+    }
+    __syncthreads();
+    bitonic_sort_desc(skeys, N2);
+    for (int t = threadIdx.x; t < take; t += blockDim.x) {
+      const unsigned long long key = skeys[t];
+      const long long o = ((long long)b * k_out + processed + t) * K + c;
+      out_scores[o] = key_score(key);
+      out_idx[o] = (int)key_index(key);
+    }
+    __syncthreads();
+    upper = lower;
+    processed += take;
+    if (lower == 0ull) break;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+static size_t nms_lds_bytes(int soft) {
+  size_t s = (size_t)RN_SORT_CAP * 8 + (size_t)RN_MAX_DET * 16 + (size_t)RN_MAX_DET * 4 + 1024 + 8 + 16;
+  if (soft) s += (size_t)RN_SORT_CAP * 4 + (size_t)RN_SORT_CAP * 2;
+  return rn_align_up(s, 16);
+}
+
+struct DetectWs {
+  int* counts;
+  unsigned long long* keys;
+  float* sel_scores;
+  float4* sel_boxes;
+  size_t total;
+};
+
+static DetectWs detect_ws_layout(void* base, int B, long long cap, int K, int max_det) {
+  DetectWs w;
+  size_t off = 0;
+  char* p = (char*)base;
+  w.counts = (int*)(p + off);
+  off += rn_align_up((size_t)B * K * 4, 256);
+  w.keys = (unsigned long long*)(p + off);
+  off += rn_align_up((size_t)B * K * cap * 8, 256);
+  w.sel_scores = (float*)(p + off);
+  off += rn_align_up((size_t)B * K * max_det * 4, 256);
+  w.sel_boxes = (float4*)(p + off);
+  off += rn_align_up((size_t)B * K * max_det * 16, 256);
+  w.total = off;
+  return w;
+}
+
+extern "C" size_t rn_detect_workspace_bytes(int B, int64_t A, int K, int max_det) {
+  if (B <= 0 || A <= 0 || K <= 0 || max_det <= 0) return 0;
+  return detect_ws_layout(nullptr, B, A, K, max_det).total;
+}
+extern "C" size_t rn_nms_workspace_bytes(int B, int n, int K, int max_det) {
+  return rn_detect_workspace_bytes(B, n, K, max_det);
+}
+extern "C" size_t rn_topk_workspace_bytes(int B, int64_t A, int K) {
+  if (B <= 0 || A <= 0 || K <= 0) return 0;
+  return rn_align_up((size_t)B * K * 4, 256) + rn_align_up((size_t)B * K * A * 8, 256);
+}
+
+static int run_nms_stage(const DetectWs& w, int B, long long cap, int K, const BoxSrc& bs, int top_k,
+                         float iou_threshold, float score_threshold, float soft_nms_sigma, int max_det,
+                         float* det_boxes, float* det_scores, int32_t* det_classes, int32_t* valid,
+                         hipStream_t st) {
+  NmsParams p;
+  p.B = B; p.K = K; p.max_det = max_det; p.top_k = top_k;
+  p.soft = soft_nms_sigma > 0.0f ? 1 : 0;
+  // the reference hands NonMaxSuppressionV5 sigma/2 and iou_threshold 1.0 in soft mode
+  // (postprocessing_ops.py:448-450); TF then uses scale = -0.5 / soft_nms_sigma.
+  p.soft_scale = p.soft ? -0.5f / (soft_nms_sigma / 2.0f) : 0.0f;
+  p.iou_thr = iou_threshold;
+  p.score_thr = score_threshold;
+  p.cap = cap;
+  const size_t lds = nms_lds_bytes(p.soft);
+  RN_CHECK_HIP(hipFuncSetAttribute((const void*)nms_per_class_kernel,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(nms_per_class_kernel, dim3(B * K), dim3(RN_PP_THREADS), lds, st, p, w.counts, w.keys, bs,
+                     w.sel_scores, w.sel_boxes);
+  RN_CHECK_LAUNCH();
+  int N2 = 64;
+  while (N2 < K * max_det) N2 <<= 1;
+  RN_CHECK_HIP(hipFuncSetAttribute((const void*)merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   N2 * 8 + 16));
+  hipLaunchKernelGGL(merge_kernel, dim3(B), dim3(RN_PP_THREADS), (size_t)N2 * 8 + 16, st, K, max_det, w.sel_scores,
+                     w.sel_boxes, (float4*)det_boxes, det_scores, det_classes, valid);
+  RN_CHECK_LAUNCH();
+  return RN_OK;
+}
+
+static int check_nms_args(const char* fn, int B, long long n, int K, int top_k, float soft_sigma, int max_det) {
+  RN_CHECK_ARG(B > 0 && n > 0 && K > 0, "%s: bad B=%d n=%lld K=%d", fn, B, n, K);
+  RN_CHECK_ARG(n < (1ll << 31) && (long long)B * K < (1ll << 31), "%s: problem too large", fn);
+  RN_CHECK_ARG(max_det >= 1 && max_det <= RN_MAX_DET, "%s: max_det=%d outside 1..%d", fn, max_det, RN_MAX_DET);
+  RN_CHECK_ARG((long long)K * max_det <= 16384, "%s: K*max_det=%lld > 16384", fn, (long long)K * max_det);
+  if (soft_sigma > 0.0f)
+    RN_CHECK_ARG((top_k > 0 && top_k <= RN_SORT_CAP) || n <= RN_SORT_CAP,
+                 "%s: soft NMS needs 0 < pre_nms_top_k <= %d (or <= %d candidates)", fn, RN_SORT_CAP, RN_SORT_CAP);
+  return RN_OK;
+}
+
+extern "C" int rn_detect_per_class(const float* const* class_logits, const int64_t* level_offsets,
+                                   int num_levels, int B, int K, const float* boxes, int pre_nms_top_k,
+                                   float iou_threshold, float score_threshold, float soft_nms_sigma,
+                                   int max_det, float* det_boxes, float* det_scores, int32_t* det_classes,
+                                   int32_t* valid, void* workspace, size_t workspace_bytes, void* stream) {
+  PPLevels lv;
+  RN_CHECK_ARG(boxes && det_boxes && det_scores && det_classes && valid, "rn_detect_per_class: null argument");
+  RN_CHECK_ARG(pp_fill_levels(lv, class_logits, level_offsets, num_levels, B > 0 ? B : 1, K > 0 ? K : 1) == 0,
+               "rn_detect_per_class: bad level table");
+  const long long A = lv.off[num_levels];
+  int rc = check_nms_args("rn_detect_per_class", B, A, K, pre_nms_top_k, soft_nms_sigma, max_det);
+  if (rc) return rc;
+  const size_t need = rn_detect_workspace_bytes(B, A, K, max_det);
+  if (!workspace || workspace_bytes < need) {
+    rn_set_error("rn_detect_per_class: workspace %zu < %zu", workspace_bytes, need);
+    return RN_ENOMEM;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  DetectWs w = detect_ws_layout(workspace, B, A, K, max_det);
+  RN_CHECK_HIP(hipMemsetAsync(w.counts, 0, (size_t)B * K * 4, st));
+  hipLaunchKernelGGL(compact_logits_kernel, dim3(pp_blocks(lv.vbeg[num_levels])), dim3(RN_PP_THREADS), 0, st,
+                     lv, B, K, A, score_threshold, w.counts, w.keys, A);
+  RN_CHECK_LAUNCH();
+  BoxSrc bs;
+  bs.base = (const float4*)boxes;
+  bs.img_stride = A; bs.idx_stride = 1; bs.cls_stride = 0;
+  return run_nms_stage(w, B, A, K, bs, pre_nms_top_k, iou_threshold, score_threshold, soft_nms_sigma, max_det,
+                       det_boxes, det_scores, det_classes, valid, st);
+}
+
+extern "C" int rn_nms_per_class(const float* cand_scores, const float* cand_boxes, int B, int n, int K,
+                                float iou_threshold, float score_threshold, float soft_nms_sigma, int max_det,
+                                float* det_boxes, float* det_scores, int32_t* det_classes, int32_t* valid,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  RN_CHECK_ARG(cand_scores && cand_boxes && det_boxes && det_scores && det_classes && valid,
+               "rn_nms_per_class: null argument");
+  int rc = check_nms_args("rn_nms_per_class", B, n, K, 0, soft_nms_sigma, max_det);
+  if (rc) return rc;
+  const size_t need = rn_nms_workspace_bytes(B, n, K, max_det);
+  if (!workspace || workspace_bytes < need) {
+    rn_set_error("rn_nms_per_class: workspace %zu < %zu", workspace_bytes, need);
+    return RN_ENOMEM;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  DetectWs w = detect_ws_layout(workspace, B, n, K, max_det);
+  RN_CHECK_HIP(hipMemsetAsync(w.counts, 0, (size_t)B * K * 4, st));
+  hipLaunchKernelGGL(compact_scores_kernel, dim3(pp_blocks((long long)B * n * K)), dim3(RN_PP_THREADS), 0, st,
+                     cand_scores, B, (long long)n, K, score_threshold, 1, w.counts, w.keys, (long long)n);
+  RN_CHECK_LAUNCH();
+  BoxSrc bs;
+  bs.base = (const float4*)cand_boxes;
+  bs.img_stride = (long long)n * K; bs.idx_stride = K; bs.cls_stride = 1;
+  return run_nms_stage(w, B, n, K, bs, 0, iou_threshold, score_threshold, soft_nms_sigma, max_det, det_boxes,
+                       det_scores, det_classes, valid, st);
+}
+
+extern "C" int rn_topk_per_class(const float* scores, int B, int64_t A, int K, int top_k, float* topk_scores,
+                                 int32_t* topk_indices, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+  RN_CHECK_ARG(scores && topk_scores && topk_indices, "rn_topk_per_class: null argument");
+  RN_CHECK_ARG(B > 0 && A > 0 && K > 0 && top_k > 0 && A < (1ll << 31), "rn_topk_per_class: bad shape");
+  const size_t need = rn_topk_workspace_bytes(B, A, K);
+  if (!workspace || workspace_bytes < need) {
+    rn_set_error("rn_topk_per_class: workspace %zu < %zu", workspace_bytes, need);
+    return RN_ENOMEM;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  int* counts = (int*)workspace;
+  unsigned long long* keys = (unsigned long long*)((char*)workspace + rn_align_up((size_t)B * K * 4, 256));
+  RN_CHECK_HIP(hipMemsetAsync(counts, 0, (size_t)B * K * 4, st));
+  hipLaunchKernelGGL(compact_scores_kernel, dim3(pp_blocks((long long)B * A * K)), dim3(RN_PP_THREADS), 0, st,
+                     scores, B, (long long)A, K, 0.0f, 0, counts, keys, (long long)A);
+  RN_CHECK_LAUNCH();
+  const int k_out = top_k < A ? top_k : (int)A;
+  const size_t lds = rn_align_up((size_t)RN_SORT_CAP * 8 + 1024 + 8 + 16, 16);
+  RN_CHECK_HIP(hipFuncSetAttribute((const void*)topk_emit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+  hipLaunchKernelGGL(topk_emit_kernel, dim3(B * K), dim3(RN_PP_THREADS), lds, st, K, k_out, counts, keys,
+                     (long long)A, topk_scores, topk_indices);
+  RN_CHECK_LAUNCH();
+  return RN_OK;
+}

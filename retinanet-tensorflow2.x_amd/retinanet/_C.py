@@ -1,0 +1,136 @@
+"""ctypes binding of librnet_hip.so (C ABI declared in include/rnet_hip.h).
+
+The library is the product: there is no CPU fallback.  `lib()` raises if the shared object
+is missing, and every call raises `RnetError` on a non-zero status.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librnet_hip.so")
+
+RN_DT_F32, RN_DT_BF16 = 0, 1
+RN_ACT_NONE, RN_ACT_RELU, RN_ACT_RELU6, RN_ACT_SWISH = 0, 1, 2, 3
+RN_CONV_MAX_SEGMENTS = 10
+ACT_IDS = {None: RN_ACT_NONE, "none": RN_ACT_NONE, "relu": RN_ACT_RELU, "relu6": RN_ACT_RELU6,
+           "swish": RN_ACT_SWISH}
+
+
+class RnetError(RuntimeError):
+    pass
+
+
+class ConvSegment(Structure):
+    _fields_ = [("x", c_void_p), ("w", c_void_p), ("y", c_void_p), ("scale", c_void_p), ("shift", c_void_p),
+                ("residual", c_void_p), ("N", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32),
+                ("pix_stride", c_int32), ("Ho", c_int32), ("Wo", c_int32), ("Cout", c_int32)]
+
+
+class ConvProblem(Structure):
+    _fields_ = [("R", c_int32), ("S", c_int32), ("stride_h", c_int32), ("stride_w", c_int32),
+                ("pad_top", c_int32), ("pad_left", c_int32), ("act", c_int32), ("out_dtype", c_int32),
+                ("num_segments", c_int32), ("seg", ConvSegment * RN_CONV_MAX_SEGMENTS)]
+
+
+_PP = POINTER(c_void_p)
+_SIGNATURES = {
+    "rn_last_error": (c_char_p, []),
+    "rn_abi_version": (c_int, []),
+    "rn_device_ok": (c_int, []),
+    "rn_anchors_generate": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int, POINTER(c_float),
+                                    POINTER(c_float), c_int, POINTER(c_float), c_int, POINTER(c_int64),
+                                    c_void_p]),
+    "rn_match_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "rn_anchor_match_encode": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float,
+                                       c_float, POINTER(c_float), c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_size_t, c_void_p]),
+    "rn_loss_workspace_bytes": (c_size_t, [c_int, c_int64, c_int]),
+    "rn_retinanet_loss_fwd_bwd": (c_int, [_PP, _PP, _PP, _PP, POINTER(c_int64), c_int, c_int, c_int, c_void_p,
+                                          c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_float,
+                                          c_float, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rn_decode_boxes": (c_int, [_PP, POINTER(c_int64), c_int, c_int, c_void_p, POINTER(c_float), c_float,
+                                c_float, c_void_p, c_void_p]),
+    "rn_sigmoid_scores": (c_int, [_PP, POINTER(c_int64), c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rn_topk_workspace_bytes": (c_size_t, [c_int, c_int64, c_int]),
+    "rn_topk_per_class": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                  c_size_t, c_void_p]),
+    "rn_detect_workspace_bytes": (c_size_t, [c_int, c_int64, c_int, c_int]),
+    "rn_detect_per_class": (c_int, [_PP, POINTER(c_int64), c_int, c_int, c_int, c_void_p, c_int, c_float,
+                                    c_float, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_size_t, c_void_p]),
+    "rn_nms_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "rn_nms_per_class": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_float, c_int,
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rn_conv2d_nhwc_fwd": (c_int, [POINTER(ConvProblem), c_void_p]),
+    "rn_conv_cout_pad": (c_int, [c_int]),
+    "rn_pack_conv_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rn_pack_stem_weight": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "rn_stem_padded_width": (c_int, [c_int]),
+    "rn_pack_stem_input": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rn_maxpool2d_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                  c_int, c_int, c_void_p]),
+    "rn_fpn_topdown": (c_int, [_PP, _PP, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "rn_balance_features": (c_int, [_PP, _PP, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    """Names include/rnet_hip.h declares (used by the CPU-side ABI test)."""
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RnetError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(status: int, what: str = ""):
+    if status != 0:
+        msg = lib().rn_last_error()
+        raise RnetError(f"{what} failed with status {status}: {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor, None -> NULL."""
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def ptr_array(tensors):
+    """Host array of addresses for a `const T* const*` parameter (None -> NULL array)."""
+    if tensors is None:
+        return None
+    arr = (c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else t.data_ptr()
+    return ctypes.cast(arr, _PP)
+
+
+def f32_array(values):
+    if values is None:
+        return None
+    return (c_float * len(values))(*[float(v) for v in values])
+
+
+def i64_array(values):
+    return (c_int64 * len(values))(*[int(v) for v in values])
+
+
+def current_stream():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)

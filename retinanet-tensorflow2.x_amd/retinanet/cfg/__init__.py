@@ -1,0 +1,3 @@
+from retinanet.cfg.config import AttrDict, Config, default_params
+
+__all__ = ["AttrDict", "Config", "default_params"]

@@ -1,0 +1,92 @@
+"""RetinaNetLoss on the GPU (reference retinanet/losses/retinanet_loss.py:9-83 and
+retinanet/losses/loss_impl.py:4-105).
+
+`RetinaNetLoss(num_classes, params)(targets, predictions)` returns the reference's loss dict.
+One fused HIP launch set computes the focal + Huber sums AND the gradients with respect to
+every level's logits / box predictions (stored in `.grads` for the backward pass), so the
+autograd tape of the reference is replaced by closed-form derivatives.
+
+Distributed: the normaliser is all-reduced over `process_group` exactly where the reference
+calls replica_context.all_reduce (retinanet_loss.py:46-49).
+"""
+from __future__ import annotations
+
+import torch
+
+from retinanet import _C
+
+
+class RetinaNetLoss:
+    def __init__(self, num_classes, params, process_group=None):
+        self._num_classes = int(num_classes)
+        self._alpha = float(params.focal_loss.alpha)
+        self._gamma = float(params.focal_loss.gamma)
+        self._label_smoothing = float(params.focal_loss.label_smoothing)
+        self._delta = float(params.smooth_l1_loss.delta)
+        self._box_loss_weight = float(params.box_loss_weight)
+        self._class_loss_weight = float(params.class_loss_weight)
+        self._auxillary_loss_weight = float(params.auxillary_loss_weight)
+        if params.normalizer.use_moving_average:
+            raise NotImplementedError("loss.normalizer.use_moving_average is false in every shipped config "
+                                      "and is out of scope (SURVEY §2.2 C6)")
+        self._pg = process_group
+        self._ws = None
+        self.grads = None
+
+    def _num_replicas(self):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(self._pg)
+        return 1
+
+    def __call__(self, targets, predictions, compute_grads=True, grad_scale=None):
+        lib = _C.lib()
+        cls_pred = predictions["class-predictions"]
+        box_pred = predictions["box-predictions"]
+        levels = sorted(cls_pred.keys(), key=int)
+        flat = targets["_flat"]
+        cls_t, box_t = flat["class-targets"], flat["box-targets"]
+        dev = cls_t.device
+        B = cls_t.shape[0]
+        K = self._num_classes
+        # normaliser = all_reduce_sum(sum(num-positives) + 1) / replicas  (retinanet_loss.py:38-49)
+        normalizer = (targets["num-positives"].sum() + 1.0).reshape(1).to(torch.float32)
+        R = self._num_replicas()
+        if R > 1:
+            import torch.distributed as dist
+            dist.all_reduce(normalizer, group=self._pg)
+            normalizer = normalizer / R
+        offs = [0]
+        cl, bl = [], []
+        for lv in levels:
+            c = cls_pred[lv]
+            b = box_pred[lv]
+            if c.dtype != torch.float32 or b.dtype != torch.float32:
+                raise TypeError("predictions must be float32 (the reference's prediction convs are fp32)")
+            c = c.contiguous()
+            b = b.contiguous()
+            n_l = c.numel() // (B * K)
+            offs.append(offs[-1] + n_l)
+            cl.append(c)
+            bl.append(b)
+        if offs[-1] != cls_t.shape[1]:
+            raise ValueError(f"predictions cover {offs[-1]} anchors, targets {cls_t.shape[1]}")
+        dcl = [torch.empty_like(c) for c in cl] if compute_grads else None
+        dbl = [torch.empty_like(b) for b in bl] if compute_grads else None
+        need = lib.rn_loss_workspace_bytes(B, offs[-1], K)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty((need,), dtype=torch.uint8, device=dev)
+        out = torch.empty((4,), dtype=torch.float32, device=dev)
+        if grad_scale is None:
+            grad_scale = 1.0 / R  # per_replica_loss = total / replicas  (executor.py:421)
+        with torch.cuda.device(dev):
+            _C.check(lib.rn_retinanet_loss_fwd_bwd(
+                _C.ptr_array(cl), _C.ptr_array(bl), _C.ptr_array(dcl), _C.ptr_array(dbl),
+                _C.i64_array(offs), len(levels), B, K, _C.ptr(cls_t), _C.ptr(box_t), _C.ptr(normalizer),
+                self._alpha, self._gamma, self._label_smoothing, self._delta, self._box_loss_weight,
+                self._class_loss_weight, float(grad_scale), _C.ptr(out), _C.ptr(self._ws), self._ws.numel(),
+                _C.current_stream()), "rn_retinanet_loss_fwd_bwd")
+        if compute_grads:
+            self.grads = {"class-predictions": dict(zip(levels, dcl)), "box-predictions": dict(zip(levels, dbl))}
+        return {"box-loss": out[0], "class-loss": out[1], "weighted-loss": out[2],
+                "num-anchors-matched": out[3], "iou-prediction-loss": 0.0}

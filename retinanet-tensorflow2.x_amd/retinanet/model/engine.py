@@ -1,0 +1,245 @@
+"""Executors that turn the static layer graph into HIP launches.
+
+`InferenceEngine` is the MI355X replacement of `model(images, training=False)` for the Keras
+model the reference builds (retinanet/model/builder.py:94-106): weights are packed once to the
+MFMA-friendly bf16 [Cout][R][S][Cin] layout, BatchNorm (inference mode: moving statistics) and
+conv bias are folded into a per-channel scale/shift applied in the conv epilogue together with
+the activation and the residual add, all activations live in buffers allocated once, and the
+launch list is fixed — so the whole forward pass can be captured in a HIP graph
+(`capture_graph=True`) and replayed with one host call instead of ~70.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from retinanet import _C
+
+_DT = {"bf16": torch.bfloat16, "f32": torch.float32}
+
+
+def _conv_out_hw(H, W, k, s, pad):
+    return (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+
+
+class InferenceEngine:
+    def __init__(self, graph, variables, batch_size, device, bn_epsilon=1e-3, capture_graph=False):
+        self.g = graph
+        self.B = int(batch_size)
+        self.dev = torch.device(device)
+        self.eps = float(bn_epsilon)
+        self.lib = _C.lib()
+        self._keep = []     # ctypes structs / arrays that must outlive the launches
+        self.steps = []     # list of (callable, name)
+        self.t = {}         # tensor name -> torch tensor
+        self.packed = {}    # conv name -> packed bf16 weight
+        self._graph = None
+        self._capture = bool(capture_graph)
+        with torch.cuda.device(self.dev):
+            self._alloc()
+            self.load_variables(variables)
+            self._build()
+
+    # ---- buffers ---------------------------------------------------------------------------
+    def _alloc(self):
+        for name, (H, W, C, dt) in self.g.tensors.items():
+            self.t[name] = torch.empty((self.B, H, W, C), dtype=_DT[dt], device=self.dev)
+        H, W, _, _ = self.g.tensors["images"]
+        self.Wp = self.lib.rn_stem_padded_width(W)
+        self.stem_in = torch.empty((self.B, H + 6, self.Wp, 4), dtype=torch.bfloat16, device=self.dev)
+
+    # ---- weights -----------------------------------------------------------------------------
+    def load_variables(self, variables):
+        """(Re)pack conv kernels and refold BN/bias from a name -> tensor dict."""
+        lib = self.lib
+        st = _C.current_stream()
+        self.fold = getattr(self, "fold", {})
+        for op in self.g.ops:
+            if op["op"] not in ("conv", "stem"):
+                continue
+            cname = op["conv"]
+            c = self.g.convs[cname]
+            w = variables[cname + "/kernel"].to(self.dev, torch.float32).contiguous()
+            cout_pad = lib.rn_conv_cout_pad(c["cout"])
+            if cname not in self.packed or True:
+                if op["op"] == "stem":
+                    buf = self.packed.get(cname)
+                    if buf is None:
+                        buf = torch.empty((cout_pad, 7, 32), dtype=torch.bfloat16, device=self.dev)
+                    _C.check(lib.rn_pack_stem_weight(_C.ptr(w), c["cout"], _C.ptr(buf), st), "rn_pack_stem_weight")
+                else:
+                    buf = self.packed.get(cname)
+                    if buf is None:
+                        buf = torch.empty((cout_pad, c["k"], c["k"], c["cin"]), dtype=torch.bfloat16,
+                                          device=self.dev)
+                    _C.check(lib.rn_pack_conv_weight(_C.ptr(w), c["k"], c["k"], c["cin"], c["cout"], c["cin"],
+                                                     _C.ptr(buf), st), "rn_pack_conv_weight")
+                self.packed[cname] = buf
+            # fold: y = conv*scale + shift;  BN inference: gamma*(x+bias-mean)/sqrt(var+eps)+beta
+            key = op["out"]
+            bias = variables.get(cname + "/bias")
+            bias = None if bias is None else bias.to(self.dev, torch.float32)
+            if op.get("bn"):
+                bn = op["bn"]
+                gamma = variables[bn + "/gamma"].to(self.dev, torch.float32)
+                beta = variables[bn + "/beta"].to(self.dev, torch.float32)
+                mean = variables[bn + "/moving_mean"].to(self.dev, torch.float32)
+                var = variables[bn + "/moving_variance"].to(self.dev, torch.float32)
+                scale = gamma / torch.sqrt(var + self.eps)
+                shift = beta - mean * scale
+                if bias is not None:
+                    shift = shift + bias * scale
+            else:
+                scale = None
+                shift = bias
+            old = self.fold.get(key)
+            if old is None:
+                self.fold[key] = [None if scale is None else scale.contiguous(),
+                                  None if shift is None else shift.contiguous()]
+            else:  # keep addresses stable for a captured graph
+                if scale is not None:
+                    old[0].copy_(scale)
+                if shift is not None:
+                    old[1].copy_(shift)
+
+    # ---- launch list -------------------------------------------------------------------------
+    def _conv_segment(self, seg, op):
+        c = self.g.convs[op["conv"]]
+        x, y = self.t[op["inp"]], self.t[op["out"]]
+        scale, shift = self.fold[op["out"]]
+        seg.x = x.data_ptr()
+        seg.w = self.packed[op["conv"]].data_ptr()
+        seg.y = y.data_ptr()
+        seg.scale = scale.data_ptr() if scale is not None else None
+        seg.shift = shift.data_ptr() if shift is not None else None
+        seg.residual = self.t[op["residual"]].data_ptr() if op.get("residual") else None
+        seg.N, seg.H, seg.W, seg.Cin = self.B, x.shape[1], x.shape[2], c["cin"]
+        seg.pix_stride = x.shape[3]
+        seg.Ho, seg.Wo, seg.Cout = y.shape[1], y.shape[2], c["cout"]
+
+    def _add_conv_launch(self, ops):
+        first = ops[0]
+        c0 = self.g.convs[first["conv"]]
+        p = _C.ConvProblem()
+        p.R = p.S = c0["k"]
+        p.stride_h = p.stride_w = c0["stride"]
+        p.pad_top = p.pad_left = first["pad"]
+        p.act = _C.ACT_IDS[first["act"]]
+        p.out_dtype = _C.RN_DT_F32 if first["out_dtype"] == "f32" else _C.RN_DT_BF16
+        p.num_segments = len(ops)
+        for i, op in enumerate(ops):
+            c = self.g.convs[op["conv"]]
+            if (c["k"], c["stride"], op["pad"], op["act"], op["out_dtype"]) != \
+                    (c0["k"], c0["stride"], first["pad"], first["act"], first["out_dtype"]):
+                raise ValueError(f"conv group {first.get('group')} mixes shapes")
+            self._conv_segment(p.seg[i], op)
+        self._keep.append(p)
+        lib = self.lib
+        pref = ctypes.byref(p)
+        name = first.get("group") or first["out"]
+
+        def run(st):
+            _C.check(lib.rn_conv2d_nhwc_fwd(pref, st), f"rn_conv2d_nhwc_fwd[{name}]")
+        self.steps.append((run, "conv:" + name))
+
+    def _build(self):
+        lib = self.lib
+        B = self.B
+        done_groups = set()
+        for op in self.g.ops:
+            kind = op["op"]
+            if kind == "stem":
+                img = self.t["images"]
+                H, W = img.shape[1], img.shape[2]
+                y = self.t[op["out"]]
+                c = self.g.convs[op["conv"]]
+                pin, pout, pimg = self.stem_in.data_ptr(), y.data_ptr(), img.data_ptr()
+
+                def pack(st, pimg=pimg, pin=pin, H=H, W=W):
+                    _C.check(lib.rn_pack_stem_input(pimg, B, H, W, pin, st), "rn_pack_stem_input")
+                self.steps.append((pack, "pack_stem_input"))
+                p = _C.ConvProblem()
+                p.R, p.S, p.stride_h, p.stride_w, p.pad_top, p.pad_left = 7, 1, 2, 2, 0, 0
+                p.act = _C.ACT_IDS[op["act"]]
+                p.out_dtype = _C.RN_DT_BF16
+                p.num_segments = 1
+                s = p.seg[0]
+                scale, shift = self.fold[op["out"]]
+                s.x, s.w, s.y = pin, self.packed[op["conv"]].data_ptr(), pout
+                s.scale, s.shift, s.residual = scale.data_ptr(), shift.data_ptr(), None
+                s.N, s.H, s.W, s.Cin, s.pix_stride = B, H + 6, self.Wp, 32, 4
+                s.Ho, s.Wo, s.Cout = y.shape[1], y.shape[2], c["cout"]
+                self._keep.append(p)
+                pref = ctypes.byref(p)
+
+                def stem(st, pref=pref):
+                    _C.check(lib.rn_conv2d_nhwc_fwd(pref, st), "rn_conv2d_nhwc_fwd[stem]")
+                self.steps.append((stem, "conv:stem"))
+            elif kind == "conv":
+                grp = op.get("group")
+                if grp is None:
+                    self._add_conv_launch([op])
+                elif grp not in done_groups:
+                    done_groups.add(grp)
+                    self._add_conv_launch([o for o in self.g.ops if o["op"] == "conv" and o.get("group") == grp])
+            elif kind == "maxpool":
+                x, y = self.t[op["inp"]], self.t[op["out"]]
+                args = (x.data_ptr(), y.data_ptr(), B, x.shape[1], x.shape[2], x.shape[3], op["k"], op["stride"],
+                        op["pad_top"], op["pad_left"], y.shape[1], y.shape[2])
+
+                def pool(st, args=args):
+                    _C.check(lib.rn_maxpool2d_nhwc(*args, st), "rn_maxpool2d_nhwc")
+                self.steps.append((pool, "maxpool:" + op["out"]))
+            elif kind == "topdown":
+                ins = [self.t[n] for n in op["ins"]]
+                outs = [self.t[n] for n in op["outs"]]
+                pin, pout = _C.ptr_array(ins), _C.ptr_array(outs)
+                self._keep += [pin, pout]
+                H0, W0, C = ins[0].shape[1], ins[0].shape[2], ins[0].shape[3]
+                act = _C.ACT_IDS[op["act"]]
+
+                def td(st, pin=pin, pout=pout, L=len(ins), H0=H0, W0=W0, C=C, act=act):
+                    _C.check(lib.rn_fpn_topdown(pin, pout, L, B, H0, W0, C, act, st), "rn_fpn_topdown")
+                self.steps.append((td, "fpn_topdown"))
+            elif kind == "balance":
+                ts = [self.t[n] for n in op["tensors"]]
+                pin = _C.ptr_array(ts)
+                self._keep.append(pin)
+                mid = op["mid"]
+                scratch = torch.empty_like(ts[mid])
+                self._keep.append(scratch)
+                H0, W0, C = ts[0].shape[1], ts[0].shape[2], ts[0].shape[3]
+
+                def bal(st, pin=pin, L=len(ts), mid=mid, H0=H0, W0=W0, C=C, sp=scratch.data_ptr()):
+                    _C.check(lib.rn_balance_features(pin, pin, L, mid, B, H0, W0, C, sp, st),
+                             "rn_balance_features")
+                self.steps.append((bal, "balance_features"))
+            else:
+                raise ValueError(kind)
+        self.outputs = {k: {lv: self.t[n] for lv, n in d.items()} for k, d in self.g.outputs.items()}
+
+    # ---- run -----------------------------------------------------------------------------------
+    def _launch_all(self):
+        st = _C.current_stream()
+        for fn, _ in self.steps:
+            fn(st)
+
+    def __call__(self, images):
+        """images f32[B,H,W,3] (already normalised) -> prediction dict of static output buffers."""
+        if tuple(images.shape) != tuple(self.t["images"].shape):
+            raise ValueError(f"expected images of shape {tuple(self.t['images'].shape)}, got {tuple(images.shape)}")
+        with torch.cuda.device(self.dev):
+            if images.data_ptr() != self.t["images"].data_ptr():
+                self.t["images"].copy_(images, non_blocking=True)
+            if self._capture:
+                if self._graph is None:
+                    self._launch_all()  # warm-up outside capture (lazy module loads, attribute sets)
+                    torch.cuda.synchronize()
+                    self._graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self._graph):
+                        self._launch_all()
+                self._graph.replay()
+            else:
+                self._launch_all()
+        return self.outputs

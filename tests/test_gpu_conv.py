@@ -1,0 +1,235 @@
+"""GPU parity: K1/K2 implicit-GEMM conv (+ folded BN / bias / residual / activation) and the
+pooling / FPN / BalanceFeatures kernels against a plain PyTorch-CPU float32 reference on the
+same bf16-rounded inputs.  Tolerance: fp32 accumulation-order noise plus one bf16 rounding of
+the output (2^-8 relative)."""
+import ctypes
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+def _conv_gpu(cuda, segs, k, stride, pad, act, out_f32):
+    from retinanet import _C
+    lib = _C.lib()
+    p = _C.ConvProblem()
+    p.R = p.S = k
+    p.stride_h = p.stride_w = stride
+    p.pad_top = p.pad_left = pad
+    p.act = _C.ACT_IDS[act]
+    p.out_dtype = _C.RN_DT_F32 if out_f32 else _C.RN_DT_BF16
+    p.num_segments = len(segs)
+    keep, outs = [], []
+    for i, s in enumerate(segs):
+        x = _bf(s["x"]).to(cuda).contiguous()
+        w = s["w"].to(cuda).float().contiguous()          # HWIO
+        kk, _, cin, cout = w.shape
+        wp = torch.empty((lib.rn_conv_cout_pad(cout), kk, kk, cin), dtype=torch.bfloat16, device=cuda)
+        _C.check(lib.rn_pack_conv_weight(_C.ptr(w), kk, kk, cin, cout, cin, _C.ptr(wp), _C.current_stream()))
+        N, H, W, _ = x.shape
+        Ho, Wo = (H + 2 * pad - kk) // stride + 1, (W + 2 * pad - kk) // stride + 1
+        y = torch.empty((N, Ho, Wo, cout), dtype=torch.float32 if out_f32 else torch.bfloat16, device=cuda)
+        sc = s.get("scale"); sh = s.get("shift"); res = s.get("residual")
+        sc = None if sc is None else sc.to(cuda).float().contiguous()
+        sh = None if sh is None else sh.to(cuda).float().contiguous()
+        res = None if res is None else _bf(res).to(cuda).contiguous()
+        g = p.seg[i]
+        g.x, g.w, g.y = x.data_ptr(), wp.data_ptr(), y.data_ptr()
+        g.scale = sc.data_ptr() if sc is not None else None
+        g.shift = sh.data_ptr() if sh is not None else None
+        g.residual = res.data_ptr() if res is not None else None
+        g.N, g.H, g.W, g.Cin, g.pix_stride, g.Ho, g.Wo, g.Cout = N, H, W, cin, cin, Ho, Wo, cout
+        keep += [x, wp, sc, sh, res]
+        outs.append(y)
+    _C.check(lib.rn_conv2d_nhwc_fwd(ctypes.byref(p), _C.current_stream()), "conv")
+    torch.cuda.synchronize()
+    return [y.float().cpu() for y in outs]
+
+
+def _conv_ref(s, k, stride, pad, act, out_f32):
+    x = _bf(s["x"]).float().permute(0, 3, 1, 2)
+    w = _bf(s["w"]).float().permute(3, 2, 0, 1)
+    y = F.conv2d(x.double(), w.double(), stride=stride, padding=pad).float().permute(0, 2, 3, 1)
+    if s.get("scale") is not None:
+        y = y * s["scale"]
+    if s.get("shift") is not None:
+        y = y + s["shift"]
+    if s.get("residual") is not None:
+        y = y + _bf(s["residual"]).float()
+    if act == "relu":
+        y = F.relu(y)
+    elif act == "relu6":
+        y = F.relu6(y)
+    return y if out_f32 else _bf(y).float()
+
+
+def _close(got, want, out_f32):
+    scale = want.abs().max().item() + 1e-6
+    if out_f32:
+        torch.testing.assert_close(got, want, rtol=2e-4, atol=2e-4 * scale)
+    else:
+        torch.testing.assert_close(got, want, rtol=1.0 / 128, atol=scale / 256)
+        assert (got - want).abs().mean().item() <= 2e-3 * scale
+
+
+CASES = [
+    # N, H, W, Cin, Cout, k, stride, act, residual, out_f32
+    (2, 20, 20, 64, 64, 1, 1, "relu", False, False),
+    (2, 20, 20, 64, 256, 1, 1, "relu", True, False),
+    (1, 40, 40, 256, 512, 1, 2, None, False, False),     # strided projection shortcut
+    (2, 24, 24, 64, 64, 3, 1, "relu", False, False),
+    (1, 40, 40, 128, 128, 3, 2, "relu", False, False),   # stride in the 3x3 (ResNet v1.5)
+    (1, 10, 10, 512, 2048, 1, 1, "relu", True, False),
+    (2, 10, 10, 256, 256, 3, 1, "relu6", False, False),
+    (2, 5, 5, 256, 36, 3, 1, None, False, True),         # box prediction conv, f32 out, Cout pad 64
+    (1, 10, 10, 256, 720, 3, 1, None, False, True),      # class prediction conv, 6 n-tiles
+    (1, 13, 9, 192, 128, 3, 1, "relu", False, False),    # odd sizes, M tail, Cin = 3*64
+    (1, 7, 7, 96, 64, 3, 1, None, False, False),         # Cin multiple of 32 only -> BK=32 path
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_conv_single(cuda, case):
+    N, H, W, Cin, Cout, k, stride, act, use_res, out_f32 = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    pad = (k - 1) // 2
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    s = {"x": torch.randn((N, H, W, Cin), generator=g),
+         "w": torch.randn((k, k, Cin, Cout), generator=g) / math.sqrt(k * k * Cin),
+         "scale": torch.rand((Cout,), generator=g) + 0.5, "shift": torch.randn((Cout,), generator=g) * 0.1}
+    if use_res:
+        s["residual"] = torch.randn((N, Ho, Wo, Cout), generator=g)
+    got = _conv_gpu(cuda, [s], k, stride, pad, act, out_f32)[0]
+    _close(got, _conv_ref(s, k, stride, pad, act, out_f32), out_f32)
+
+
+def test_conv_asymmetric_weights_detect_transposes(cuda):
+    """A=I style check with an asymmetric filter: channel c of the output must be input channel
+    (c+1)%C shifted by one pixel — catches row/col or r/s swaps that random data would blur."""
+    C = 64
+    x = torch.arange(1 * 6 * 6 * C, dtype=torch.float32).reshape(1, 6, 6, C) % 97
+    w = torch.zeros((3, 3, C, C))
+    for c in range(C):
+        w[0, 2, (c + 1) % C, c] = 1.0      # tap (r=0, s=2): reads pixel (y-1, x+1)
+    got = _conv_gpu(cuda, [{"x": x, "w": w}], 3, 1, 1, None, True)[0]
+    want = torch.zeros_like(got)
+    want[:, 1:, :-1, :] = torch.roll(x, -1, dims=3)[:, :-1, 1:, :]
+    torch.testing.assert_close(got, want, rtol=0, atol=0)
+
+
+def test_conv_grouped_pyramid(cuda):
+    """One launch, 10 segments: the two head towers over five pyramid levels (shared kernel
+    size, per-segment weights/BN) — the shape of detection_head.py:94-100."""
+    g = torch.Generator().manual_seed(5)
+    segs = []
+    for head in range(2):
+        w = torch.randn((3, 3, 256, 256), generator=g) / 48.0
+        for s in (16, 8, 4, 2, 1):
+            segs.append({"x": torch.randn((2, s, s, 256), generator=g), "w": w,
+                         "scale": torch.rand((256,), generator=g) + 0.5, "shift": torch.randn((256,), generator=g) * 0.1})
+    got = _conv_gpu(cuda, segs, 3, 1, 1, "relu", False)
+    for s, y in zip(segs, got):
+        _close(y, _conv_ref(s, 3, 1, 1, "relu", False), False)
+
+
+def test_stem_conv(cuda):
+    """7x7 s2 stem through the packed NHWC4 image + [64][7][32] weights (resnet.py:297-300)."""
+    from retinanet import _C
+    lib = _C.lib()
+    g = torch.Generator().manual_seed(9)
+    N, H, W = 2, 64, 96
+    img = torch.randn((N, H, W, 3), generator=g)
+    w = torch.randn((7, 7, 3, 64), generator=g) / math.sqrt(147)
+    scale, shift = torch.rand((64,), generator=g) + 0.5, torch.randn((64,), generator=g) * 0.1
+    Wp = lib.rn_stem_padded_width(W)
+    imd = img.to(cuda).contiguous()
+    packed = torch.empty((N, H + 6, Wp, 4), dtype=torch.bfloat16, device=cuda)
+    _C.check(lib.rn_pack_stem_input(_C.ptr(imd), N, H, W, _C.ptr(packed), _C.current_stream()))
+    wd = w.to(cuda).contiguous()
+    wp = torch.empty((64, 7, 32), dtype=torch.bfloat16, device=cuda)
+    _C.check(lib.rn_pack_stem_weight(_C.ptr(wd), 64, _C.ptr(wp), _C.current_stream()))
+    y = torch.empty((N, H // 2, W // 2, 64), dtype=torch.bfloat16, device=cuda)
+    sc, sh = scale.to(cuda), shift.to(cuda)
+    p = _C.ConvProblem()
+    p.R, p.S, p.stride_h, p.stride_w, p.pad_top, p.pad_left = 7, 1, 2, 2, 0, 0
+    p.act, p.out_dtype, p.num_segments = _C.RN_ACT_RELU, _C.RN_DT_BF16, 1
+    s = p.seg[0]
+    s.x, s.w, s.y, s.scale, s.shift, s.residual = packed.data_ptr(), wp.data_ptr(), y.data_ptr(), sc.data_ptr(), sh.data_ptr(), None
+    s.N, s.H, s.W, s.Cin, s.pix_stride, s.Ho, s.Wo, s.Cout = N, H + 6, Wp, 32, 4, H // 2, W // 2, 64
+    _C.check(lib.rn_conv2d_nhwc_fwd(ctypes.byref(p), _C.current_stream()))
+    torch.cuda.synchronize()
+    # packed image: border and 4th channel zero, interior = bf16(image)
+    pk = packed.float().cpu()
+    assert (pk[:, :3] == 0).all() and (pk[:, :, :3] == 0).all() and (pk[..., 3] == 0).all()
+    torch.testing.assert_close(pk[:, 3:3 + H, 3:3 + W, :3], _bf(img).float(), rtol=0, atol=0)
+    want = _conv_ref({"x": img, "w": w, "scale": scale, "shift": shift}, 7, 2, 3, "relu", False)
+    _close(y.float().cpu(), want, False)
+
+
+def test_maxpool_same_and_valid(cuda):
+    from retinanet import _C
+    lib = _C.lib()
+    g = torch.Generator().manual_seed(2)
+    x = _bf(torch.randn((2, 20, 20, 64), generator=g))
+    xd = x.to(cuda)
+    y = torch.empty((2, 10, 10, 64), dtype=torch.bfloat16, device=cuda)
+    # 3x3 s2 SAME on an even size: pad 0 top/left, 1 bottom/right
+    _C.check(lib.rn_maxpool2d_nhwc(_C.ptr(xd), _C.ptr(y), 2, 20, 20, 64, 3, 2, 0, 0, 10, 10, _C.current_stream()))
+    xp = F.pad(x.float().permute(0, 3, 1, 2), (0, 1, 0, 1), value=float("-inf"))
+    torch.testing.assert_close(y.float().cpu(), F.max_pool2d(xp, 3, 2).permute(0, 2, 3, 1), rtol=0, atol=0)
+    _C.check(lib.rn_maxpool2d_nhwc(_C.ptr(xd), _C.ptr(y), 2, 20, 20, 64, 2, 2, 0, 0, 10, 10, _C.current_stream()))
+    torch.testing.assert_close(y.float().cpu(), F.max_pool2d(x.float().permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1), rtol=0, atol=0)
+
+
+def _pyramid(g, N, H0, C, L=5):
+    return [_bf(torch.randn((N, H0 >> l, H0 >> l, C), generator=g)) for l in range(L)]
+
+
+@pytest.mark.parametrize("act", ["relu", "relu6"])
+def test_fpn_topdown(cuda, act):
+    from retinanet import _C
+    lib = _C.lib()
+    g = torch.Generator().manual_seed(3)
+    pyr = _pyramid(g, 2, 32, 64)
+    ins = [p.to(cuda) for p in pyr]
+    outs = [torch.empty_like(t) for t in ins[:-1]] + [ins[-1]]
+    _C.check(lib.rn_fpn_topdown(_C.ptr_array(ins), _C.ptr_array(outs), 5, 2, 32, 32, 64, _C.ACT_IDS[act], _C.current_stream()))
+    torch.cuda.synchronize()
+    ref = [p.float() for p in pyr]
+    for l in range(4, 0, -1):   # fpn.py:93-98
+        up = F.interpolate(ref[l].permute(0, 3, 1, 2), scale_factor=2, mode="nearest").permute(0, 2, 3, 1)
+        v = ref[l - 1] + up
+        v = F.relu(v) if act == "relu" else F.relu6(v)
+        ref[l - 1] = _bf(v).float()
+    for l in range(5):
+        torch.testing.assert_close(outs[l].float().cpu(), ref[l], rtol=0, atol=0)
+
+
+def test_balance_features(cuda):
+    from retinanet import _C
+    lib = _C.lib()
+    g = torch.Generator().manual_seed(4)
+    pyr = _pyramid(g, 2, 32, 64)
+    ts = [p.to(cuda).clone() for p in pyr]
+    scratch = torch.empty_like(ts[1])
+    arr = _C.ptr_array(ts)
+    _C.check(lib.rn_balance_features(arr, arr, 5, 1, 2, 32, 32, 64, _C.ptr(scratch), _C.current_stream()))
+    torch.cuda.synchronize()
+    f = [p.float().permute(0, 3, 1, 2) for p in pyr]
+    rs = [F.max_pool2d(f[0], 2), f[1]] + [F.interpolate(f[l], scale_factor=2 ** (l - 1), mode="nearest") for l in (2, 3, 4)]
+    avg = rs[0]
+    for r in rs[1:]:
+        avg = avg + r
+    avg = _bf(avg / 5.0).float()
+    back = [F.interpolate(avg, scale_factor=2, mode="nearest"), avg] + [F.max_pool2d(avg, 2 ** (l - 1)) for l in (2, 3, 4)]
+    for l in range(5):
+        want = _bf(f[l] + back[l]).float().permute(0, 2, 3, 1)
+        torch.testing.assert_close(ts[l].float().cpu(), want, rtol=1 / 128, atol=1e-2)
