@@ -49,24 +49,39 @@ struct ConvArgs {
 };
 
 template <int BK>
+__device__ __forceinline__ int lds_swz(int row) {
+  constexpr int SLOTS = BK / 8;        // 16-byte slots per row
+  constexpr int RPB = 256 / (BK * 2);  // rows per 256-byte bank row
+  return (row / RPB) % SLOTS;
+}
+template <int BK>
 __device__ __forceinline__ int lds_slot_off(int row, int slot) {
-  constexpr int SLOTS = BK / 8;            // 16-byte slots per row
-  constexpr int RPB = 256 / (BK * 2);      // rows per 256-byte bank row
-  return (row * SLOTS + (slot ^ ((row / RPB) % SLOTS))) * 16;
+  return (row * (BK / 8) + (slot ^ lds_swz<BK>(row))) * 16;
 }
 
-template <int BM, int BN, int BK, bool OUT_F32>
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+// 16-byte buffer load straight into LDS (no VGPR round trip).  LDS address = M0 base (wave
+// uniform) + lane*16; the global source offset is per lane; out-of-range offsets write zeros.
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, unsigned voff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)lds_wave_base, 16, (int)voff, 0, 0, 0);
+}
+
+#define RN_OOB 0x80000000u
+
+// ABL: ablation mask for tools/bench_conv.py (0 in production): 1 = B tile loaded once,
+// 2 = A tile loaded once, 4 = no MFMA.
+template <int BM, int BN, int BK, bool OUT_F32, int ABL = 0>
 __global__ void __launch_bounds__(CONV_THREADS, 2) conv_fwd_kernel(const ConvArgs args) {
   constexpr int SLOTS = BK / 8;
-  constexpr int RPP = CONV_THREADS / SLOTS;  // rows per load pass
-  constexpr int A_PASSES = BM / RPP;
-  constexpr int B_PASSES = BN / RPP;
-  constexpr int WTM = BM / 2, WTN = BN / 2;  // wave tile
+  constexpr int RPI = 64 / SLOTS;              // rows per wave DMA instruction (1 KiB)
+  constexpr int A_INSTR = BM / RPI / 4;        // DMA instructions per wave for the A tile
+  constexpr int B_INSTR = BN / RPI / 4;
+  constexpr int WTM = BM / 2, WTN = BN / 2;    // wave tile
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int KSUB = BK / 16;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
   constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
-  static_assert(BM * BN * 4 <= 2 * STAGE_BYTES || true, "epilogue tile");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -89,7 +104,8 @@ __global__ void __launch_bounds__(CONV_THREADS, 2) conv_fwd_kernel(const ConvArg
   const int m0 = m_tile * BM, n0 = n_tile * BN;
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave_m = wave >> 1, wave_n = wave & 1;
 
   const int R = args.R, S = args.S;
@@ -97,21 +113,28 @@ __global__ void __launch_bounds__(CONV_THREADS, 2) conv_fwd_kernel(const ConvArg
   const int M = sg.M;
   const int Ktot = R * S * Cin;
 
-  // ---- per-thread load bookkeeping -----------------------------------------------------------
-  const int ld_row = tid / SLOTS, ld_slot = tid % SLOTS;
-  long long a_base[A_PASSES];
-  unsigned int a_mask[A_PASSES];
+  const __amdgpu_buffer_rsrc_t rs_x =
+      __builtin_amdgcn_make_buffer_rsrc((void*)sg.x, 0, (int)((long long)sg.N * H * W * PS * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w =
+      __builtin_amdgcn_make_buffer_rsrc((void*)sg.w, 0, (int)((long long)sg.n_tiles * BN * Ktot * 2), 0x00020000);
+
+  // ---- per-lane DMA bookkeeping: instruction j of this wave fills rows (j*4 + wave)*RPI .. ----
+  const int d_row = lane / SLOTS, d_pos = lane % SLOTS;
+  unsigned a_off[A_INSTR];   // byte offset of (row's first tap pixel, its k chunk) or RN_OOB
+  unsigned a_mask[A_INSTR];
 #pragma unroll
-  for (int i = 0; i < A_PASSES; ++i) {
-    const int m = m0 + ld_row + i * RPP;
+  for (int j = 0; j < A_INSTR; ++j) {
+    const int row = (j * 4 + wave) * RPI + d_row;
+    const int chunk = d_pos ^ lds_swz<BK>(row);
+    const int m = m0 + row;
     const int mm = m < M ? m : 0;
     const int ox = mm % sg.Wo;
     const int t2 = mm / sg.Wo;
     const int oy = t2 % sg.Ho;
     const int n = t2 / sg.Ho;
     const int iy0 = oy * args.sh - args.pt, ix0 = ox * args.sw - args.pl;
-    a_base[i] = (((long long)n * H + iy0) * W + ix0) * PS + ld_slot * 8;
-    unsigned int mask = 0;
+    a_off[j] = (unsigned)(((((long long)n * H + iy0) * W + ix0) * PS + chunk * 8) * 2);
+    unsigned mask = 0;
     if (m < M) {
       for (int r = 0; r < R; ++r)
         for (int s = 0; s < S; ++s) {
@@ -119,21 +142,29 @@ __global__ void __launch_bounds__(CONV_THREADS, 2) conv_fwd_kernel(const ConvArg
           mask |= (ok ? 1u : 0u) << (r * S + s);
         }
     }
-    a_mask[i] = mask;
+    a_mask[j] = mask;
   }
-  long long b_base[B_PASSES];
+  unsigned b_off[B_INSTR];
 #pragma unroll
-  for (int i = 0; i < B_PASSES; ++i) b_base[i] = (long long)(n0 + ld_row + i * RPP) * Ktot + ld_slot * 8;
+  for (int j = 0; j < B_INSTR; ++j) {
+    const int row = (j * 4 + wave) * RPI + d_row;
+    const int chunk = d_pos ^ lds_swz<BK>(row);
+    b_off[j] = (unsigned)(((long long)(n0 + row) * Ktot + chunk * 8) * 2);
+  }
 
-  int lds_wr_a[A_PASSES], lds_wr_b[B_PASSES];
-#pragma unroll
-  for (int i = 0; i < A_PASSES; ++i) lds_wr_a[i] = lds_slot_off<BK>(ld_row + i * RPP, ld_slot);
-#pragma unroll
-  for (int i = 0; i < B_PASSES; ++i) lds_wr_b[i] = A_BYTES + lds_slot_off<BK>(ld_row + i * RPP, ld_slot);
-
-  // fragment read offsets: row = lane&31 within a 32-row tile, k slot = 2*kk + (lane>>5)
-  int lds_rd_a[TM], lds_rd_b[TN];
+  // fragment read offsets (row = lane&31 of a 32-row tile, k slot = 2*kk + (lane>>5))
   const int frag_row = lane & 31, frag_half = lane >> 5;
+  int rd_a[TM][KSUB], rd_b[TN][KSUB];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int kk = 0; kk < KSUB; ++kk)
+      rd_a[i][kk] = lds_slot_off<BK>(wave_m * WTM + i * 32 + frag_row, kk * 2 + frag_half);
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int kk = 0; kk < KSUB; ++kk)
+      rd_b[j][kk] = A_BYTES + lds_slot_off<BK>(wave_n * WTN + j * 32 + frag_row, kk * 2 + frag_half);
 
   f32x16_t acc[TM][TN];
 #pragma unroll
@@ -143,34 +174,29 @@ __global__ void __launch_bounds__(CONV_THREADS, 2) conv_fwd_kernel(const ConvArg
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  const int csteps = Cin / BK;
-  const int ksteps = R * S * csteps;
+  const int ksteps = R * S * (Cin / BK);
 
-  uint4 ra[A_PASSES], rb[B_PASSES];
-  auto load_tile = [&](int tap, int c0) {
-    const int r = tap / S, s = tap - r * S;
-    const long long tap_off = ((long long)r * W + s) * PS + c0;
-#pragma unroll
-    for (int i = 0; i < A_PASSES; ++i) {
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if ((a_mask[i] >> tap) & 1u) v = *(const uint4*)(sg.x + a_base[i] + tap_off);
-      ra[i] = v;
-    }
-    const long long koff = (long long)tap * Cin + c0;
-#pragma unroll
-    for (int i = 0; i < B_PASSES; ++i) rb[i] = *(const uint4*)(sg.w + b_base[i] + koff);
-  };
-  auto store_tile = [&](int buf) {
-    char* base = smem + buf * STAGE_BYTES;
-#pragma unroll
-    for (int i = 0; i < A_PASSES; ++i) *(uint4*)(base + lds_wr_a[i]) = ra[i];
-#pragma unroll
-    for (int i = 0; i < B_PASSES; ++i) *(uint4*)(base + lds_wr_b[i]) = rb[i];
-  };
+#define RN_ISSUE_TILE(buf, tap_, c0_)                                                         \
+  do {                                                                                        \
+    const int r__ = (tap_) / S, s__ = (tap_) - r__ * S;                                       \
+    const unsigned tap_off__ = (unsigned)((((long long)r__ * W + s__) * PS + (c0_)) * 2);     \
+    char* st__ = smem + (buf) * STAGE_BYTES;                                                  \
+    if (!(ABL & 2) || ((tap_) == 0 && (c0_) == 0)) {                                          \
+      _Pragma("unroll") for (int j = 0; j < A_INSTR; ++j) {                                   \
+        const unsigned v__ = ((a_mask[j] >> (tap_)) & 1u) ? a_off[j] + tap_off__ : RN_OOB;    \
+        dma16(rs_x, st__ + (j * 4 + wave) * 1024, v__);                                       \
+      }                                                                                       \
+    }                                                                                         \
+    const unsigned koff__ = (unsigned)(((long long)(tap_) * Cin + (c0_)) * 2);                \
+    if (!(ABL & 1) || ((tap_) == 0 && (c0_) == 0)) {                                          \
+      _Pragma("unroll") for (int j = 0; j < B_INSTR; ++j)                                     \
+        dma16(rs_w, st__ + A_BYTES + (j * 4 + wave) * 1024, b_off[j] + koff__);               \
+    }                                                                                         \
+  } while (0)
 
   int tap = 0, c0 = 0;
-  load_tile(0, 0);
-  store_tile(0);
+  RN_ISSUE_TILE(0, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int cur = 0;
 #pragma unroll 1
@@ -180,35 +206,31 @@ __global__ void __launch_bounds__(CONV_THREADS, 2) conv_fwd_kernel(const ConvArg
       c0 = 0;
       ++tap;
     }
-    const bool more = kt + 1 < ksteps;
-    if (more) load_tile(tap, c0);
+    if (kt + 1 < ksteps) RN_ISSUE_TILE(cur ^ 1, tap, c0);
 
     const char* base = smem + cur * STAGE_BYTES;
 #pragma unroll
     for (int kk = 0; kk < KSUB; ++kk) {
       bf16x8_t fa[TM], fb[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int row = wave_m * WTM + i * 32 + frag_row;
-        fa[i] = *(const bf16x8_t*)(base + lds_slot_off<BK>(row, kk * 2 + frag_half));
-      }
+      for (int i = 0; i < TM; ++i) fa[i] = *(const bf16x8_t*)(base + rd_a[i][kk]);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int row = wave_n * WTN + j * 32 + frag_row;
-        fb[j] = *(const bf16x8_t*)(base + A_BYTES + lds_slot_off<BK>(row, kk * 2 + frag_half));
-      }
+      for (int j = 0; j < TN; ++j) fb[j] = *(const bf16x8_t*)(base + rd_b[j][kk]);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          if (!(ABL & 4)) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          } else {
+            acc[i][j][0] += (float)fa[i][0] + (float)fb[j][0];
+          }
     }
-    if (more) store_tile(cur ^ 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     cur ^= 1;
   }
-  (void)lds_rd_a;
-  (void)lds_rd_b;
+#undef RN_ISSUE_TILE
 
   // ---- epilogue ------------------------------------------------------------------------------
   // stage 1: registers -> LDS fp32 [BM][BN], with the per-channel affine applied
@@ -284,6 +306,20 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
   return RN_OK;
 }
 
+static int g_conv_ablate = 0;
+// internal (not in rnet_hip.h): select an ablated kernel for tools/bench_conv.py
+extern "C" void rn_debug_conv_ablate(int mask) { g_conv_ablate = mask; }
+
+template <int ABL>
+static int launch_ablate(const ConvArgs& a, hipStream_t st) {
+  constexpr int lds = 2 * (128 + 128) * 64 * 2;
+  auto kern = conv_fwd_kernel<128, 128, 64, false, ABL>;
+  RN_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  hipLaunchKernelGGL(kern, dim3(a.total_tiles), dim3(CONV_THREADS), lds, st, a);
+  RN_CHECK_LAUNCH();
+  return RN_OK;
+}
+
 extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
   RN_CHECK_ARG(p != nullptr, "rn_conv2d_nhwc_fwd: null problem");
   RN_CHECK_ARG(p->num_segments >= 1 && p->num_segments <= RN_CONV_MAX_SEGMENTS,
@@ -312,8 +348,8 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
     RN_CHECK_ARG(((uintptr_t)s.x | (uintptr_t)s.w | (uintptr_t)s.y | (uintptr_t)s.residual) % 16 == 0,
                  "rn_conv2d_nhwc_fwd: segment %d tensors must be 16-byte aligned", i);
     const long long M = (long long)s.N * s.Ho * s.Wo;
-    RN_CHECK_ARG(M < (1ll << 31) && (long long)s.N * s.H * s.W * s.pix_stride < (1ll << 40),
-                 "rn_conv2d_nhwc_fwd: segment %d too large", i);
+    RN_CHECK_ARG(M < (1ll << 31) && (long long)s.N * s.H * s.W * s.pix_stride * 2 < (1ll << 31),
+                 "rn_conv2d_nhwc_fwd: segment %d input exceeds the 2 GiB buffer-addressing limit", i);
     // the last input row/col a valid tap may touch must be inside the image
     ConvSegDev& d = a.seg[i];
     d.x = (const uint16_t*)s.x; d.w = (const uint16_t*)s.w; d.y = s.y;
@@ -329,6 +365,18 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
   a.total_tiles = tiles;
   hipStream_t st = (hipStream_t)stream;
   const bool f32 = p->out_dtype == RN_DT_F32;
+  if (g_conv_ablate && BN == 128 && BK == 64 && !f32) {
+    switch (g_conv_ablate) {
+      case 1: return launch_ablate<1>(a, st);
+      case 2: return launch_ablate<2>(a, st);
+      case 3: return launch_ablate<3>(a, st);
+      case 4: return launch_ablate<4>(a, st);
+      case 5: return launch_ablate<5>(a, st);
+      case 6: return launch_ablate<6>(a, st);
+      case 7: return launch_ablate<7>(a, st);
+      default: break;
+    }
+  }
   if (BN == 128 && BK == 64) return f32 ? launch_conv<128, 128, 64, true>(a, st) : launch_conv<128, 128, 64, false>(a, st);
   if (BN == 64 && BK == 64) return f32 ? launch_conv<128, 64, 64, true>(a, st) : launch_conv<128, 64, 64, false>(a, st);
   if (BN == 128 && BK == 32) return f32 ? launch_conv<128, 128, 32, true>(a, st) : launch_conv<128, 128, 32, false>(a, st);

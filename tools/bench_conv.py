@@ -1,0 +1,79 @@
+"""Micro-benchmark of rn_conv2d_nhwc_fwd on one (grouped) problem — used for A/B timing and
+for short rocprofv3 PMC passes.  python tools/bench_conv.py --preset tower --batch 8 --iters 20"""
+import argparse
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "retinanet-tensorflow2.x_amd"))
+import torch  # noqa: E402
+
+from retinanet import _C  # noqa: E402
+
+PRESETS = {
+    # name: (list of (H, Cin, Cout) segments, k, stride, out_f32, residual)
+    "tower": ([(s, 256, 256) for s in (80, 40, 20, 10, 5)] * 2, 3, 1, False, False),
+    "pred_class": ([(s, 256, 720) for s in (80, 40, 20, 10, 5)], 3, 1, True, False),
+    "g1_3x3": ([(160, 64, 64)], 3, 1, False, False),
+    "g1_out": ([(160, 64, 256)], 1, 1, False, True),
+    "g1_a": ([(160, 256, 64)], 1, 1, False, False),
+    "g2_3x3": ([(80, 128, 128)], 3, 1, False, False),
+    "g3_3x3": ([(40, 256, 256)], 3, 1, False, False),
+    "g3_out": ([(40, 256, 1024)], 1, 1, False, True),
+    "g4_3x3": ([(20, 512, 512)], 3, 1, False, False),
+    "g4_a": ([(20, 2048, 512)], 1, 1, False, False),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--preset", default="tower")
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--ablate", type=int, default=0)
+    a = ap.parse_args()
+    lib = _C.lib()
+    if a.ablate:
+        lib.rn_debug_conv_ablate(a.ablate)
+    dev = torch.device("cuda:0")
+    for name in a.preset.split(","):
+        segs, k, stride, f32, use_res = PRESETS[name]
+        p = _C.ConvProblem()
+        p.R = p.S = k
+        p.stride_h = p.stride_w = stride
+        p.pad_top = p.pad_left = (k - 1) // 2
+        p.act, p.out_dtype, p.num_segments = _C.RN_ACT_RELU, (_C.RN_DT_F32 if f32 else _C.RN_DT_BF16), len(segs)
+        keep, flops, byts = [], 0, 0
+        for i, (H, cin, cout) in enumerate(segs):
+            x = torch.randn((a.batch, H, H, cin), device=dev).to(torch.bfloat16)
+            w = (torch.randn((lib.rn_conv_cout_pad(cout), k, k, cin), device=dev) / (k * k * cin) ** 0.5).to(torch.bfloat16)
+            Ho = (H + 2 * p.pad_top - k) // stride + 1
+            y = torch.empty((a.batch, Ho, Ho, cout), dtype=torch.float32 if f32 else torch.bfloat16, device=dev)
+            sc = torch.rand((cout,), device=dev) + 0.5
+            sh = torch.randn((cout,), device=dev)
+            res = torch.randn((a.batch, Ho, Ho, cout), device=dev).to(torch.bfloat16) if use_res else None
+            s = p.seg[i]
+            s.x, s.w, s.y, s.scale, s.shift = x.data_ptr(), w.data_ptr(), y.data_ptr(), sc.data_ptr(), sh.data_ptr()
+            s.residual = res.data_ptr() if use_res else None
+            s.N, s.H, s.W, s.Cin, s.pix_stride, s.Ho, s.Wo, s.Cout = a.batch, H, H, cin, cin, Ho, Ho, cout
+            keep += [x, w, y, sc, sh, res]
+            flops += 2 * a.batch * Ho * Ho * k * k * cin * cout
+            byts += x.numel() * 2 + y.numel() * y.element_size() + (res.numel() * 2 if use_res else 0) + k * k * cin * cout * 2
+        st = _C.current_stream()
+        for _ in range(3):
+            _C.check(lib.rn_conv2d_nhwc_fwd(ctypes.byref(p), st))
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.iters):
+            _C.check(lib.rn_conv2d_nhwc_fwd(ctypes.byref(p), st))
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / a.iters
+        print(f"{name:12s} B={a.batch} {ms * 1e3:9.1f} us  {flops / ms / 1e9:8.1f} TFLOP/s  "
+              f"{byts / ms / 1e6:8.1f} GB/s (algorithmic {byts / 1e6:.1f} MB)", flush=True)
+
+
+if __name__ == "__main__":
+    main()
