@@ -24,6 +24,7 @@
 // outputs are bit-identical to the C oracle.
 #include "rn_common.h"
 #include "../../include/rn_math.h"
+#include <math.h>
 
 #define RN_PP_THREADS 256
 #define RN_PP_MAX_LEVELS 8
@@ -158,25 +159,104 @@ __device__ __forceinline__ unsigned long long make_key(float score, unsigned int
   return (((unsigned long long)ord_bits(score)) << 32) | (unsigned long long)(~idx);
 }
 
-// from logits (fused sigmoid), all levels
+// from logits (fused sigmoid), all levels.
+// One workgroup = one chunk of 64 consecutive anchors x K classes of one (level, image) = a
+// contiguous run of 64*K floats, streamed once with coalesced 16-byte loads.
+//   A  every value passes a cheap logit pre-test (x < logit(thr) - margin => sigmoid(x) <= thr
+//      for sure); the few survivors (a detector keeps ~0.1-5 %) are appended to an LDS list.
+//   B  the dense list is walked by all 256 threads: exact rn_sigmoidf, exact threshold test,
+//      rank within (workgroup, class) from an LDS counter.
+//   C  ONE global atomicAdd per (workgroup, class) with a non-zero count, all issued by
+//      different lanes at once, reserves the slots (a returning atomic per candidate, or per
+//      wave and class, serialises on its ~us latency: 2.3 ms -> this form).
+//   D  survivors write key = score_bits<<32 | ~anchor to their reserved slot.
+// Sigmoid work is proportional to the number of candidates, not to the number of logits, and
+// there are no 64-bit divisions in the element loop.
+#define RN_CT_ANCHORS 64
+struct CompactTiles {
+  int num_levels;
+  int tile_begin[RN_PP_MAX_LEVELS + 1];  // prefix over levels of B * ceil(n_l / 64)
+  int tiles_per_img[RN_PP_MAX_LEVELS];
+};
+
 __global__ void __launch_bounds__(RN_PP_THREADS)
-compact_logits_kernel(PPLevels lv, int B, int K, long long A, float thr, int* __restrict__ counts,
-                      unsigned long long* __restrict__ keys, long long cap) {
-  const long long total = lv.vbeg[lv.num_levels];
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    int l = 0;
-    while (l + 1 < lv.num_levels && i >= lv.vbeg[l + 1]) ++l;
-    const long long local = i - lv.vbeg[l];
-    const long long n_l = lv.off[l + 1] - lv.off[l];
-    const long long row = local / K;
-    const int k = (int)(local - row * K);
-    const long long b = row / n_l, j = row - b * n_l;
-    const float s = rn_sigmoidf(lv.ptr[l][local]);
-    if (s > thr) {
-      const long long list = b * K + k;
-      const int slot = atomicAdd(&counts[list], 1);
-      if (slot < cap) keys[list * cap + slot] = make_key(s, (unsigned int)(lv.off[l] + j));
+compact_logits_kernel(PPLevels lv, CompactTiles ct, int B, int K, float thr, float x_skip,
+                      int* __restrict__ counts, unsigned long long* __restrict__ keys, long long cap) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int cap_list = RN_CT_ANCHORS * K;
+  float* l_val = (float*)smem;                                   // [cap_list] logit, then score
+  unsigned short* l_meta = (unsigned short*)(l_val + cap_list);  // [cap_list] anchor_local<<8 | class
+  unsigned short* l_rank = l_meta + cap_list;                    // [cap_list] rank or 0xffff
+  int* c_cnt = (int*)(l_rank + cap_list + (cap_list & 1));       // [K]
+  int* c_base = c_cnt + K;                                       // [K]
+  int* l_n = c_base + K;                                         // [1]
+  int l = 0;
+  const int t = blockIdx.x;
+  while (l + 1 < ct.num_levels && t >= ct.tile_begin[l + 1]) ++l;
+  const int lt = t - ct.tile_begin[l];
+  const int b = lt / ct.tiles_per_img[l];
+  const int chunk = lt - b * ct.tiles_per_img[l];
+  const int n_l = (int)(lv.off[l + 1] - lv.off[l]);
+  const int a0 = chunk * RN_CT_ANCHORS;
+  const int rows = (n_l - a0) < RN_CT_ANCHORS ? (n_l - a0) : RN_CT_ANCHORS;
+  const float* src = lv.ptr[l] + ((long long)b * n_l + a0) * K;
+  const int total = rows * K;
+  for (int i = threadIdx.x; i < K; i += RN_PP_THREADS) c_cnt[i] = 0;
+  if (threadIdx.x == 0) *l_n = 0;
+  __syncthreads();
+  // ---- A: stream + pre-test ---------------------------------------------------------------
+  if ((K & 3) == 0) {
+    for (int i = threadIdx.x * 4; i < total; i += RN_PP_THREADS * 4) {
+      const float4 v = *(const float4*)(src + i);
+      const float x4[4] = {v.x, v.y, v.z, v.w};
+      const int r = i / K, c = i - r * K;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (!(x4[u] < x_skip)) {
+          const int slot = atomicAdd(l_n, 1);
+          l_val[slot] = x4[u];
+          l_meta[slot] = (unsigned short)((r << 8) | (c + u));
+        }
+      }
+    }
+  } else {
+    for (int i = threadIdx.x; i < total; i += RN_PP_THREADS) {
+      const float x = src[i];
+      if (!(x < x_skip)) {
+        const int r = i / K, c = i - r * K;
+        const int slot = atomicAdd(l_n, 1);
+        l_val[slot] = x;
+        l_meta[slot] = (unsigned short)((r << 8) | c);
+      }
+    }
+  }
+  __syncthreads();
+  const int nl = *l_n;
+  // ---- B: exact sigmoid + threshold, rank per class ---------------------------------------------
+  for (int i = threadIdx.x; i < nl; i += RN_PP_THREADS) {
+    const float sc = rn_sigmoidf(l_val[i]);
+    unsigned short rank = 0xffffu;
+    if (sc > thr) {
+      rank = (unsigned short)atomicAdd(&c_cnt[l_meta[i] & 0xff], 1);
+      l_val[i] = sc;
+    }
+    l_rank[i] = rank;
+  }
+  __syncthreads();
+  // ---- C: reserve global slots -------------------------------------------------------------------
+  for (int c = threadIdx.x; c < K; c += RN_PP_THREADS) {
+    const int n = c_cnt[c];
+    c_base[c] = n ? atomicAdd(&counts[(long long)b * K + c], n) : 0;
+  }
+  __syncthreads();
+  // ---- D: write keys -----------------------------------------------------------------------------
+  const unsigned int anchor0 = (unsigned int)(lv.off[l] + a0);
+  for (int i = threadIdx.x; i < nl; i += RN_PP_THREADS) {
+    const unsigned short rank = l_rank[i];
+    if (rank != 0xffffu) {
+      const int c = l_meta[i] & 0xff;
+      const long long slot = (long long)c_base[c] + rank;
+      if (slot < cap) keys[((long long)b * K + c) * cap + slot] = make_key(l_val[i], anchor0 + (l_meta[i] >> 8));
     }
   }
 }
@@ -203,16 +283,30 @@ compact_scores_kernel(const float* __restrict__ scores, int B, long long n, int 
 // ------------------------------------------------------------------------------------------
 // block-level helpers over an LDS key array
 __device__ void bitonic_sort_desc(unsigned long long* s, int N) {
+  const int half = N >> 1;
   for (int k = 2; k <= N; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = threadIdx.x; t < (N >> 1); t += blockDim.x) {
-        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-        const int p = i | j;
-        const unsigned long long a = s[i], b = s[p];
-        const bool desc = (i & k) == 0;
-        if (desc ? (a < b) : (a > b)) {
-          s[i] = b;
-          s[p] = a;
+      // 4 independent compare-exchanges per trip so the LDS reads pipeline
+      for (int t0 = threadIdx.x; t0 < half; t0 += 4 * blockDim.x) {
+        int ii[4], pp[4];
+        unsigned long long a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int t = t0 + u * blockDim.x;
+          const int tt = t < half ? t : t0;
+          ii[u] = ((tt & ~(j - 1)) << 1) | (tt & (j - 1));
+          pp[u] = ii[u] | j;
+          a[u] = s[ii[u]];
+          b[u] = s[pp[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int t = t0 + u * blockDim.x;
+          const bool desc = (ii[u] & k) == 0;
+          if (t < half && (desc ? (a[u] < b[u]) : (a[u] > b[u]))) {
+            s[ii[u]] = b[u];
+            s[pp[u]] = a[u];
+          }
         }
       }
       __syncthreads();
@@ -220,10 +314,21 @@ __device__ void bitonic_sort_desc(unsigned long long* s, int N) {
   }
 }
 
+struct GlobalKeys {
+  const unsigned long long* p;
+  __device__ __forceinline__ unsigned long long operator()(int t) const { return p[t]; }
+};
+struct ScoreKeys {  // keys built on the fly from a dense score array (merge stage)
+  const float* s;
+  __device__ __forceinline__ unsigned long long operator()(int t) const {
+    return make_key(s[t], (unsigned int)t);
+  }
+};
+
 // k-th largest (1-based) among keys[0..n) that are < upper.  Keys are unique.
-__device__ unsigned long long radix_select_desc(const unsigned long long* __restrict__ keys, int n,
-                                                unsigned long long upper, int kth, int* hist /*256*/,
-                                                unsigned long long* s_prefix, int* s_k) {
+template <class Loader>
+__device__ unsigned long long radix_select_desc(Loader keys, int n, unsigned long long upper, int kth,
+                                                int* hist /*256*/, unsigned long long* s_prefix, int* s_k) {
   if (threadIdx.x == 0) {
     *s_prefix = 0ull;
     *s_k = kth;
@@ -234,7 +339,7 @@ __device__ unsigned long long radix_select_desc(const unsigned long long* __rest
     __syncthreads();
     const unsigned long long prefix = *s_prefix;
     for (int t = threadIdx.x; t < n; t += blockDim.x) {
-      const unsigned long long key = keys[t];
+      const unsigned long long key = keys(t);
       if (key < upper && (key & mask) == prefix) atomicAdd(&hist[(int)((key >> shift) & 255ull)], 1);
     }
     __syncthreads();
@@ -251,6 +356,31 @@ __device__ unsigned long long radix_select_desc(const unsigned long long* __rest
     __syncthreads();
   }
   return *s_prefix;
+}
+
+// Load the `take` largest keys below `upper` into skeys (sorted descending) and return the
+// smallest of them (the next chunk's exclusive upper bound; 0 when the list is exhausted).
+template <class Loader>
+__device__ unsigned long long next_chunk_sorted(Loader keys, int n, int remaining, int take,
+                                                unsigned long long upper, unsigned long long* skeys,
+                                                int* s_hist, unsigned long long* s_prefix, int* s_misc) {
+  unsigned long long lower = 0ull;
+  if (remaining > take) lower = radix_select_desc(keys, n, upper, take, s_hist, s_prefix, &s_misc[0]);
+  int N2 = 64;
+  while (N2 < take) N2 <<= 1;
+  if (threadIdx.x == 0) s_misc[1] = 0;
+  for (int t = threadIdx.x; t < N2; t += blockDim.x) skeys[t] = 0ull;
+  __syncthreads();
+  for (int t = threadIdx.x; t < n; t += blockDim.x) {
+    const unsigned long long key = keys(t);
+    if (key >= lower && key < upper) {
+      const int slot = atomicAdd(&s_misc[1], 1);
+      if (slot < N2) skeys[slot] = key;
+    }
+  }
+  __syncthreads();
+  bitonic_sort_desc(skeys, N2);
+  return lower;
 }
 
 struct BoxSrc {
@@ -328,26 +458,16 @@ nms_per_class_kernel(NmsParams p, const int* __restrict__ counts, const unsigned
 
   unsigned long long upper = ~0ull;
   int processed = 0;
+  const GlobalKeys kload{keys};
   while (processed < limit) {
     if (s_misc[2] >= p.max_det) break;
-    const int take = (limit - processed) < RN_SORT_CAP ? (limit - processed) : RN_SORT_CAP;
-    unsigned long long lower = 0ull;
-    if (n - processed > take) lower = radix_select_desc(keys, n, upper, take, s_hist, s_prefix, &s_misc[0]);
-    // gather keys in [lower, upper) into LDS
-    int N2 = 64;
-    while (N2 < take) N2 <<= 1;
-    if (threadIdx.x == 0) s_misc[1] = 0;
-    for (int t = threadIdx.x; t < N2; t += blockDim.x) skeys[t] = 0ull;
-    __syncthreads();
-    for (int t = threadIdx.x; t < n; t += blockDim.x) {
-      const unsigned long long key = keys[t];
-      if (key >= lower && key < upper) {
-        const int slot = atomicAdd(&s_misc[1], 1);
-        if (slot < N2) skeys[slot] = key;
-      }
-    }
-    __syncthreads();
-    bitonic_sort_desc(skeys, N2);
+    // hard NMS usually fills max_det from the first few hundred candidates: sort a small first
+    // chunk, fall back to full LDS-sized chunks only when suppression eats through it
+    int cap_chunk = RN_SORT_CAP;
+    if (!p.soft && processed == 0) cap_chunk = 1024;
+    const int take = (limit - processed) < cap_chunk ? (limit - processed) : cap_chunk;
+    const unsigned long long lower =
+        next_chunk_sorted(kload, n, n - processed, take, upper, skeys, s_hist, s_prefix, s_misc);
     const int m = take;
 
     if (wave == 0) {
@@ -468,25 +588,23 @@ merge_kernel(int K, int max_det, const float* __restrict__ sel_scores, const flo
              float4* __restrict__ det_boxes, float* __restrict__ det_scores, int* __restrict__ det_classes,
              int* __restrict__ valid_out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  unsigned long long* skeys = (unsigned long long*)smem;
+  unsigned long long* skeys = (unsigned long long*)smem;               // RN_MAX_DET * 8
+  int* s_hist = (int*)(smem + (size_t)RN_MAX_DET * 8);                 // 1024
+  unsigned long long* s_prefix = (unsigned long long*)((char*)s_hist + 1024);
+  int* s_misc = (int*)((char*)s_prefix + 8);                           // [0..1] scratch, [2] valid
   const int b = blockIdx.x;
   const int total = K * max_det;
-  int N2 = 64;
-  while (N2 < total) N2 <<= 1;
-  int& s_valid = *(int*)(smem + (size_t)N2 * 8);
-  if (threadIdx.x == 0) s_valid = 0;
-  for (int t = threadIdx.x; t < N2; t += blockDim.x)
-    skeys[t] = t < total ? make_key(sel_scores[(long long)b * total + t], (unsigned int)t) : 0ull;
-  __syncthreads();
-  bitonic_sort_desc(skeys, N2);
+  const ScoreKeys kload{sel_scores + (long long)b * total};
+  if (threadIdx.x == 0) s_misc[2] = 0;
+  next_chunk_sorted(kload, total, total, max_det, ~0ull, skeys, s_hist, s_prefix, s_misc);
   int cnt = 0;
   for (int t = threadIdx.x; t < max_det; t += blockDim.x) {
     const float s = key_score(skeys[t]);
     if (s > 0.0f) ++cnt;
   }
-  if (cnt) atomicAdd(&s_valid, cnt);
+  if (cnt) atomicAdd(&s_misc[2], cnt);
   __syncthreads();
-  const int valid = s_valid;
+  const int valid = s_misc[2];
   for (int t = threadIdx.x; t < max_det; t += blockDim.x) {
     const unsigned long long key = skeys[t];
     const float s = key_score(key);
@@ -518,24 +636,11 @@ topk_emit_kernel(int K, int k_out, const int* __restrict__ counts, const unsigne
   const int limit = n < k_out ? n : k_out;
   unsigned long long upper = ~0ull;
   int processed = 0;
+  const GlobalKeys kload{keys};
   while (processed < limit) {
     const int take = (limit - processed) < RN_SORT_CAP ? (limit - processed) : RN_SORT_CAP;
-    unsigned long long lower = 0ull;
-    if (n - processed > take) lower = radix_select_desc(keys, n, upper, take, s_hist, s_prefix, &s_misc[0]);
-    int N2 = 64;
-    while (N2 < take) N2 <<= 1;
-    if (threadIdx.x == 0) s_misc[1] = 0;
-    for (int t = threadIdx.x; t < N2; t += blockDim.x) skeys[t] = 0ull;
-    __syncthreads();
-    for (int t = threadIdx.x; t < n; t += blockDim.x) {
-      const unsigned long long key = keys[t];
-      if (key >= lower && key < upper) {
-        const int slot = atomicAdd(&s_misc[1], 1);
-        if (slot < N2) skeys[slot] = key;
-      }
-    }
-    __syncthreads();
-    bitonic_sort_desc(skeys, N2);
+    const unsigned long long lower =
+        next_chunk_sorted(kload, n, n - processed, take, upper, skeys, s_hist, s_prefix, s_misc);
     for (int t = threadIdx.x; t < take; t += blockDim.x) {
       const unsigned long long key = skeys[t];
       const long long o = ((long long)b * k_out + processed + t) * K + c;
@@ -611,11 +716,8 @@ static int run_nms_stage(const DetectWs& w, int B, long long cap, int K, const B
   hipLaunchKernelGGL(nms_per_class_kernel, dim3(B * K), dim3(RN_PP_THREADS), lds, st, p, w.counts, w.keys, bs,
                      w.sel_scores, w.sel_boxes);
   RN_CHECK_LAUNCH();
-  int N2 = 64;
-  while (N2 < K * max_det) N2 <<= 1;
-  RN_CHECK_HIP(hipFuncSetAttribute((const void*)merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   N2 * 8 + 16));
-  hipLaunchKernelGGL(merge_kernel, dim3(B), dim3(RN_PP_THREADS), (size_t)N2 * 8 + 16, st, K, max_det, w.sel_scores,
+  const size_t lds_m = (size_t)RN_MAX_DET * 8 + 1024 + 8 + 16;
+  hipLaunchKernelGGL(merge_kernel, dim3(B), dim3(RN_PP_THREADS), lds_m, st, K, max_det, w.sel_scores,
                      w.sel_boxes, (float4*)det_boxes, det_scores, det_classes, valid);
   RN_CHECK_LAUNCH();
   return RN_OK;
@@ -652,8 +754,23 @@ extern "C" int rn_detect_per_class(const float* const* class_logits, const int64
   hipStream_t st = (hipStream_t)stream;
   DetectWs w = detect_ws_layout(workspace, B, A, K, max_det);
   RN_CHECK_HIP(hipMemsetAsync(w.counts, 0, (size_t)B * K * 4, st));
-  hipLaunchKernelGGL(compact_logits_kernel, dim3(pp_blocks(lv.vbeg[num_levels])), dim3(RN_PP_THREADS), 0, st,
-                     lv, B, K, A, score_threshold, w.counts, w.keys, A);
+  CompactTiles ct;
+  ct.num_levels = num_levels;
+  ct.tile_begin[0] = 0;
+  for (int l = 0; l < num_levels; ++l) {
+    const long long n_l = lv.off[l + 1] - lv.off[l];
+    ct.tiles_per_img[l] = (int)rn_cdiv(n_l, RN_CT_ANCHORS);
+    ct.tile_begin[l + 1] = ct.tile_begin[l] + B * ct.tiles_per_img[l];
+  }
+  // sigmoid(x) <= thr is certain when x < logit(thr) - margin (sigmoid is monotone; the margin
+  // covers rn_sigmoidf's <= 3 ulp error many times over); thr outside (0,1) disables the skip
+  float x_skip = -INFINITY;
+  if (score_threshold > 0.0f && score_threshold < 1.0f)
+    x_skip = (float)(log((double)score_threshold / (1.0 - (double)score_threshold)) - 1e-3);
+  const size_t lds_ct = rn_align_up((size_t)RN_CT_ANCHORS * K * 8 + 4 + (size_t)K * 8 + 16, 16);
+  RN_CHECK_ARG(K <= 255 && lds_ct <= 64 * 1024, "rn_detect_per_class: K=%d too large for the compaction tile", K);
+  hipLaunchKernelGGL(compact_logits_kernel, dim3(ct.tile_begin[num_levels]), dim3(RN_PP_THREADS), lds_ct, st, lv,
+                     ct, B, K, score_threshold, x_skip, w.counts, w.keys, A);
   RN_CHECK_LAUNCH();
   BoxSrc bs;
   bs.base = (const float4*)boxes;
