@@ -187,6 +187,118 @@ int rn_stem_padded_width(int W);
 int rn_pack_stem_input(const float* images, int N, int H, int W, void* packed, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Backward of K1/K2 (the tape.gradient of executor.py:427-428 through Conv2D).
+ * Weight gradient: dw f32 [Cout][R][S][Cin] (the packed compute layout) = beta*dw + sum over
+ * all segments' output pixels of dy[p][co] * x[shifted pixel][ci].  Segments share one weight
+ * (pyramid levels of a shared head conv).  x bf16 [N,H,W,Cin], dy bf16 [N,Ho,Wo,Cout].
+ * Deterministic split-K: partial tiles go to the workspace and are added in index order.
+ */
+typedef struct {
+  const void* x;
+  const void* dy;
+  int32_t N, H, W, Cin, Ho, Wo, Cout;
+} rn_wgrad_segment;
+
+typedef struct {
+  int32_t R, S, stride_h, stride_w, pad_top, pad_left;
+  int32_t num_segments;
+  rn_wgrad_segment seg[RN_CONV_MAX_SEGMENTS];
+} rn_wgrad_problem;
+
+size_t rn_wgrad_workspace_bytes(const rn_wgrad_problem* problem /* host */);
+int rn_conv2d_nhwc_wgrad(const rn_wgrad_problem* problem /* host */, float* dw, float beta, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
+/* dgrad: the data gradient of a stride-1 conv is rn_conv2d_nhwc_fwd run on dy with these weights
+ * (bf16 [Cin_pad][R][S][Cout], taps flipped) and pad' = k-1-pad; stride 2 goes through
+ * rn_upsample_zero2x first.  w_ohwi is the f32 master in compute layout [Cout][R][S][Cin]. */
+int rn_pack_conv_weight_dgrad(const float* w_ohwi, int R, int S, int Cin, int Cout, void* w_packed, void* stream);
+/* y[n,2h,2w,:] = x[n,h,w,:], zero elsewhere; bf16 NHWC */
+int rn_upsample_zero2x(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, void* stream);
+int rn_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
+/* dy = dz * act'(z) for a layer with an activation but no BatchNorm in front */
+int rn_act_bwd(const void* dz, const void* z, void* dy, int64_t n, int act, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * K3  BatchNormalization / SyncBatchNormalization in training mode (model/utils.py:7-22, used at
+ * resnet.py:59-79, fpn.py:54-69, detection_head.py:68-74,99), forward and backward, with the
+ * activation and the residual add of resnet.py:248 fused.  Grouped like the convs.
+ *   rn_bn_stats        y -> sums[2][C] = (sum, sum of squares) of THIS rank's pixels
+ *   (SyncBN: the caller all-reduces `sums` over ranks and sets count_scale = replicas)
+ *   rn_bn_finalize     sums -> fwd[4][C] = (mean, invstd, scale, shift); moving stats update
+ *   rn_bn_apply        z = act(y*scale + shift + residual)
+ *   rn_bn_bwd_reduce   dz, z, y -> bsums[2][C] = (sum g, sum g*xhat), g = dz*act'(z)
+ *   (SyncBN: all-reduce `bsums`)
+ *   rn_bn_bwd_apply    dy = scale*(g - sum_g/n - xhat*sum_gxhat/n); dres (+)= g; dgamma, dbeta
+ * All tensors bf16 [P,C] (P = N*H*W), per-channel arrays f32.
+ */
+typedef struct {
+  const void* y;
+  void* z;
+  const void* residual;
+  const void* dz;
+  void* dy;
+  void* dres;
+  float* sums;
+  float* fwd;
+  float* bsums;
+  const float* gamma;
+  const float* beta;
+  float* moving_mean;
+  float* moving_var;
+  float* dgamma;
+  float* dbeta;
+  int64_t P;
+  int32_t C;
+  int32_t dres_accumulate;
+} rn_bn_segment;
+
+typedef struct {
+  int32_t num_segments;
+  int32_t act;
+  int32_t bessel;        /* 1: moving variance uses the n/(n-1) corrected batch variance (fused BN) */
+  float eps;
+  float momentum;
+  float count_scale;     /* replicas contributing to `sums` (1 for local BN) */
+  rn_bn_segment seg[RN_CONV_MAX_SEGMENTS];
+} rn_bn_problem;
+
+size_t rn_bn_workspace_bytes(const rn_bn_problem* problem /* host */);
+int rn_bn_stats(const rn_bn_problem* problem, void* workspace, size_t workspace_bytes, void* stream);
+int rn_bn_finalize(const rn_bn_problem* problem, void* stream);
+int rn_bn_apply(const rn_bn_problem* problem, void* stream);
+int rn_bn_bwd_reduce(const rn_bn_problem* problem, void* workspace, size_t workspace_bytes, void* stream);
+int rn_bn_bwd_apply(const rn_bn_problem* problem, void* stream);
+
+/* backward of K6/K7/K8 */
+int rn_maxpool2d_nhwc_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int k, int Ho,
+                          int Wo, int accumulate, void* stream);
+/* one level of the FPN top-down backward: din = (dout + sum2x2(din_finer)) * act'(out) */
+int rn_fpn_topdown_bwd_level(const void* dout, const void* din_finer, const void* out, void* din, int N, int H,
+                             int W, int C, int act, void* stream);
+int rn_balance_features_bwd(void* const* dout, void* const* in, void* const* din, const void* avg,
+                            void* davg_scratch, int num_levels, int mid, int N, int H0, int W0, int C,
+                            void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a10  Executor._train_step's optimizer side (executor.py:296-327,401-441; optimizers/builder.py:27-71)
+ * over flat f32 arenas.  segs_dev: device array of {i64 offset, i64 size, i32 weight_decay,
+ * i32 block_begin, i32 nblocks, i32 pad, i64 bf16_offset}; block_seg_dev: device i32[num_blocks]
+ * (block -> segment), blocks of rn_optim_chunk() elements.
+ *   rn_optim_clip      g += wd_coeff*w (decayed tensors); per-tensor clip_by_norm then
+ *                      clip_by_global_norm; metrics f32[4] = {norm after, norm before, factor}
+ *   rn_optim_sgd_step  v = m v - lr g; w += v; ema -= (1-d)(ema - w); bf16 copy of w
+ */
+int rn_optim_chunk(void);
+size_t rn_optim_workspace_bytes(int num_blocks, int num_segments);
+int rn_optim_clip(float* grads, const float* params, const void* segs_dev, int num_segments,
+                  const int32_t* block_seg_dev, int num_blocks, float wd_coeff, float clipnorm, float* metrics,
+                  void* workspace, size_t workspace_bytes, void* stream);
+int rn_optim_sgd_step(float* params, const float* grads, float* momentum_buf, float* ema, void* params_bf16,
+                      const void* segs_dev, const int32_t* block_seg_dev, int num_blocks, float lr, float momentum,
+                      float ema_decay, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * K6  tf.keras.layers.MaxPool2D  (resnet.py:304-307 3x3 s2 SAME; fpn_base.py:25-26,68 2x2 s2)
  * explicit pads; padded taps are skipped (-inf). bf16 NHWC.
  */

@@ -1,0 +1,188 @@
+// rn_optim.hip — a10: the optimizer side of Executor._train_step (retinanet/executor.py:409-441)
+// as multi-tensor kernels over ONE flat fp32 parameter arena (the reference walks 295 separate
+// tf.Variables; here params / grads / momentum / EMA are four flat buffers and a tensor is a
+// (offset, size) segment — one launch per stage instead of ~300).
+//   stage 1  g <- g + (alpha/R) * w for weight-decay tensors (l2_loss gradient, executor.py:296-299,
+//            417-421 with the 1/R of per_replica_loss), per-block sum of squares;
+//   stage 2  per-tensor norm -> clip_by_norm factor, global norm of the clipped tensors ->
+//            clip_by_global_norm factor (executor.py:401-407; tf semantics c/max(norm,c));
+//   stage 3  g <- g * factor[tensor]                      (then the data-parallel all-reduce SUM)
+//   stage 4  Keras SGD momentum  v <- m v - lr g ; w <- w + v   (optimizers/builder.py:45)
+//            tfa MovingAverage   ema <- ema - (1-d)(ema - w)    (optimizers/builder.py:51-54)
+//            and the bf16 compute copy of w for the next forward.
+// Deterministic: block partials are added in index order.  HBM-bound: 34.4 M params.
+#include "rn_common.h"
+
+#define OPT_THREADS 256
+#define OPT_CHUNK 8192  // elements per block
+
+struct OptSeg { long long offset, size; int wd, block_begin, nblocks, pad_; long long bf16_offset; };
+
+__global__ void __launch_bounds__(OPT_THREADS)
+optim_sqnorm_kernel(float* __restrict__ g, const float* __restrict__ w, const OptSeg* __restrict__ segs,
+                    const int* __restrict__ block_seg, float wdc, double* __restrict__ partial) {
+  const int si = block_seg[blockIdx.x];
+  const OptSeg s = segs[si];
+  const long long b0 = (long long)(blockIdx.x - s.block_begin) * OPT_CHUNK;
+  long long b1 = b0 + OPT_CHUNK;
+  if (b1 > s.size) b1 = s.size;
+  float acc = 0.0f;
+  for (long long i = b0 + threadIdx.x; i < b1; i += OPT_THREADS) {
+    float v = g[s.offset + i];
+    if (s.wd) {
+      v += wdc * w[s.offset + i];
+      g[s.offset + i] = v;
+    }
+    acc += v * v;
+  }
+  __shared__ double red[OPT_THREADS / 64];
+  const double d = rn_wave_sum_d((double)acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int k = 0; k < OPT_THREADS / 64; ++k) t += red[k];
+    partial[blockIdx.x] = t;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+optim_factors_kernel(const OptSeg* __restrict__ segs, int nseg, const double* __restrict__ partial, float clip,
+                     float* __restrict__ factor, float* __restrict__ metrics) {
+  __shared__ double s_sq[256];
+  double local = 0.0;
+  for (int t = threadIdx.x; t < nseg; t += blockDim.x) {
+    const OptSeg s = segs[t];
+    double sq = 0.0;
+    for (int b = 0; b < s.nblocks; ++b) sq += partial[s.block_begin + b];
+    const float norm = (float)sqrt(sq);
+    const float f = clip > 0.0f ? clip / fmaxf(norm, clip) : 1.0f;  // tf.clip_by_norm
+    factor[t] = f;
+    const float cn = norm * f;
+    local += (double)cn * (double)cn;
+  }
+  s_sq[threadIdx.x] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+    for (int k = 0; k < 256; ++k) tot += s_sq[k];
+    const float gn = (float)sqrt(tot);
+    const float F = clip > 0.0f ? clip / fmaxf(gn, clip) : 1.0f;    // tf.clip_by_global_norm
+    metrics[0] = gn * F;  // global norm of the clipped gradients (executor.py:440 multiplies by R)
+    metrics[1] = gn;      // before the global clip
+    metrics[2] = F;
+    s_sq[0] = (double)F;
+  }
+  __syncthreads();
+  const float F = (float)s_sq[0];
+  for (int t = threadIdx.x; t < nseg; t += blockDim.x) factor[t] *= F;
+}
+
+__global__ void __launch_bounds__(OPT_THREADS)
+optim_scale_kernel(float* __restrict__ g, const OptSeg* __restrict__ segs, const int* __restrict__ block_seg,
+                   const float* __restrict__ factor) {
+  const int si = block_seg[blockIdx.x];
+  const OptSeg s = segs[si];
+  const float f = factor[si];
+  if (f == 1.0f) return;
+  const long long b0 = (long long)(blockIdx.x - s.block_begin) * OPT_CHUNK;
+  long long b1 = b0 + OPT_CHUNK;
+  if (b1 > s.size) b1 = s.size;
+  for (long long i = b0 + threadIdx.x; i < b1; i += OPT_THREADS) g[s.offset + i] *= f;
+}
+
+__global__ void __launch_bounds__(OPT_THREADS)
+optim_sgd_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ v, float* __restrict__ ema,
+                 uint16_t* __restrict__ wbf16, const OptSeg* __restrict__ segs, const int* __restrict__ block_seg,
+                 float lr, float momentum, float ema_decay, int use_ema) {
+  const int si = block_seg[blockIdx.x];
+  const OptSeg s = segs[si];
+  const long long b0 = (long long)(blockIdx.x - s.block_begin) * OPT_CHUNK;
+  long long b1 = b0 + OPT_CHUNK;
+  if (b1 > s.size) b1 = s.size;
+  for (long long i = b0 + threadIdx.x; i < b1; i += OPT_THREADS) {
+    const long long o = s.offset + i;
+    const float vel = momentum * v[o] - lr * g[o];
+    const float nw = w[o] + vel;
+    v[o] = vel;
+    w[o] = nw;
+    if (use_ema) {
+      const float e = ema[o];
+      ema[o] = e - (1.0f - ema_decay) * (e - nw);
+    }
+    if (s.bf16_offset >= 0) wbf16[s.bf16_offset + i] = rn_f32_to_bf16(nw);
+  }
+}
+
+extern "C" size_t rn_optim_workspace_bytes(int num_blocks, int num_segments) {
+  return rn_align_up((size_t)num_blocks * sizeof(double), 256) + rn_align_up((size_t)num_segments * sizeof(float), 256) + 256;
+}
+extern "C" int rn_optim_chunk(void) { return OPT_CHUNK; }
+
+extern "C" int rn_optim_clip(float* grads, const float* params, const void* segs_dev, int num_segments,
+                             const int32_t* block_seg_dev, int num_blocks, float wd_coeff, float clipnorm,
+                             float* metrics /* dev f32[4] */, void* workspace, size_t workspace_bytes,
+                             void* stream) {
+  RN_CHECK_ARG(grads && params && segs_dev && block_seg_dev && metrics && num_segments > 0 && num_blocks > 0,
+               "rn_optim_clip: bad argument");
+  if (!workspace || workspace_bytes < rn_optim_workspace_bytes(num_blocks, num_segments)) {
+    rn_set_error("rn_optim_clip: workspace too small");
+    return RN_ENOMEM;
+  }
+  double* partial = (double*)workspace;
+  float* factor = (float*)((char*)workspace + rn_align_up((size_t)num_blocks * sizeof(double), 256));
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(optim_sqnorm_kernel, dim3(num_blocks), dim3(OPT_THREADS), 0, st, grads, params,
+                     (const OptSeg*)segs_dev, block_seg_dev, wd_coeff, partial);
+  RN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(optim_factors_kernel, dim3(1), dim3(256), 0, st, (const OptSeg*)segs_dev, num_segments,
+                     partial, clipnorm, factor, metrics);
+  RN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(optim_scale_kernel, dim3(num_blocks), dim3(OPT_THREADS), 0, st, grads,
+                     (const OptSeg*)segs_dev, block_seg_dev, factor);
+  RN_CHECK_LAUNCH();
+  return RN_OK;
+}
+
+extern "C" int rn_optim_sgd_step(float* params, const float* grads, float* momentum_buf, float* ema,
+                                 void* params_bf16, const void* segs_dev, const int32_t* block_seg_dev,
+                                 int num_blocks, float lr, float momentum, float ema_decay, void* stream) {
+  RN_CHECK_ARG(params && grads && momentum_buf && segs_dev && block_seg_dev && num_blocks > 0,
+               "rn_optim_sgd_step: bad argument");
+  hipLaunchKernelGGL(optim_sgd_kernel, dim3(num_blocks), dim3(OPT_THREADS), 0, (hipStream_t)stream, params, grads,
+                     momentum_buf, ema, (uint16_t*)params_bf16, (const OptSeg*)segs_dev, block_seg_dev, lr, momentum,
+                     ema_decay, ema ? 1 : 0);
+  RN_CHECK_LAUNCH();
+  return RN_OK;
+}
+
+// ---- dgrad weight transform: master f32 [Cout][R][S][Cin] -> bf16 [Cin_pad][R][S][Cout], taps
+// flipped, so the data gradient is the SAME implicit-GEMM forward kernel run on dy. ---------------
+__global__ void __launch_bounds__(256)
+pack_dgrad_kernel(const float* __restrict__ w, int R, int S, int Cin, int Cout, int Cin_pad,
+                  uint16_t* __restrict__ out) {
+  const long long total = (long long)Cin_pad * R * S * Cout;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int co = (int)(i % Cout);
+    long long t = i / Cout;
+    const int s = (int)(t % S);
+    t /= S;
+    const int r = (int)(t % R);
+    const int ci = (int)(t / R);
+    float v = 0.0f;
+    if (ci < Cin) v = w[(((long long)co * R + (R - 1 - r)) * S + (S - 1 - s)) * Cin + ci];
+    out[i] = rn_f32_to_bf16(v);
+  }
+}
+extern "C" int rn_pack_conv_weight_dgrad(const float* w_ohwi, int R, int S, int Cin, int Cout, void* out,
+                                         void* stream) {
+  RN_CHECK_ARG(w_ohwi && out && R > 0 && S > 0 && Cin > 0 && Cout > 0, "rn_pack_conv_weight_dgrad: bad argument");
+  const int Cin_pad = rn_conv_cout_pad(Cin);
+  const long long total = (long long)Cin_pad * R * S * Cout;
+  int blocks = (int)(rn_cdiv(total, 256) < 4096 ? rn_cdiv(total, 256) : 4096);
+  hipLaunchKernelGGL(pack_dgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_ohwi, R, S, Cin, Cout,
+                     Cin_pad, (uint16_t*)out);
+  RN_CHECK_LAUNCH();
+  return RN_OK;
+}

@@ -1,0 +1,641 @@
+// rn_train.hip — training-mode BatchNorm (forward + backward), bias gradients and the
+// backward of the pooling / FPN-fusion / BalanceFeatures layers.  All activations and
+// activation gradients are bf16 [P][C] (P = N*H*W pixels, NHWC), math is fp32, 8 channels
+// (16 bytes) per thread.  HBM-bound.
+//
+// Reference: tf.keras BatchNormalization / SyncBatchNormalization selected by
+// retinanet/model/utils.py:7-22 (momentum/epsilon from the config), used at
+// resnet.py:59-79, fpn_base.py:51-52, fpn.py:54-69, detection_head.py:68-74,99; the
+// activation (model/utils.py:45-70) and the residual add (resnet.py:248) are fused in.
+// Semantics restated from TF 2.8: normalise with the biased batch
+// variance; moving stats <- m*mom + batch*(1-mom), with the Bessel-corrected variance for the
+// fused single-replica layer and the biased one for SyncBatchNormalization.
+//
+// Two-stage deterministic reductions: stage 1 writes per-(row chunk) partial sums, stage 2
+// (the finalize kernels) adds them in index order in double.  SyncBN inserts an all-reduce of
+// the [2][C] sums between the stages (host side, RCCL).
+#include "rn_common.h"
+
+#define TR_THREADS 256
+
+struct bf8 { float v[8]; };
+__device__ __forceinline__ bf8 unpack8(uint4 u) {
+  bf8 r;
+  r.v[0] = rn_bf16_to_f32((uint16_t)(u.x & 0xffffu)); r.v[1] = rn_bf16_to_f32((uint16_t)(u.x >> 16));
+  r.v[2] = rn_bf16_to_f32((uint16_t)(u.y & 0xffffu)); r.v[3] = rn_bf16_to_f32((uint16_t)(u.y >> 16));
+  r.v[4] = rn_bf16_to_f32((uint16_t)(u.z & 0xffffu)); r.v[5] = rn_bf16_to_f32((uint16_t)(u.z >> 16));
+  r.v[6] = rn_bf16_to_f32((uint16_t)(u.w & 0xffffu)); r.v[7] = rn_bf16_to_f32((uint16_t)(u.w >> 16));
+  return r;
+}
+__device__ __forceinline__ uint4 pack8(const bf8& r) {
+  uint4 u;
+  u.x = rn_pack_bf16x2(r.v[0], r.v[1]); u.y = rn_pack_bf16x2(r.v[2], r.v[3]);
+  u.z = rn_pack_bf16x2(r.v[4], r.v[5]); u.w = rn_pack_bf16x2(r.v[6], r.v[7]);
+  return u;
+}
+__device__ __forceinline__ float act_mask(float z, int act) {
+  if (act == RN_ACT_RELU) return z > 0.0f ? 1.0f : 0.0f;
+  if (act == RN_ACT_RELU6) return (z > 0.0f && z < 6.0f) ? 1.0f : 0.0f;
+  return 1.0f;
+}
+
+static int tr_blocks(long long items, int cap = 8192) {
+  long long b = rn_cdiv(items, TR_THREADS);
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+struct BnSegDev {
+  const uint4* y; uint4* z; const uint4* residual; const uint4* dz; uint4* dy; uint4* dres;
+  float* sums; float* fwd; float* bsums;
+  const float* gamma; const float* beta; float* moving_mean; float* moving_var; float* dgamma; float* dbeta;
+  long long P;
+  int C, dres_accumulate, chunks, rows_per_chunk;
+};
+struct BnArgs {
+  int nseg, act, bessel, mode;
+  float eps, momentum, count_scale;
+  float* ws;           // partials: [seg][chunk][2][C] laid out with ws_off
+  long long ws_off[RN_CONV_MAX_SEGMENTS];
+  BnSegDev seg[RN_CONV_MAX_SEGMENTS];
+};
+
+// mode 0: (sum y, sum y^2); mode 1: (sum g, sum g*xhat), g = dz*mask(z), xhat = (y-mean)*invstd
+__global__ void __launch_bounds__(TR_THREADS) bn_colreduce_kernel(const BnArgs a) {
+  const BnSegDev& s = a.seg[blockIdx.z];
+  const int chunk = blockIdx.x;
+  const int slab = blockIdx.y;  // 64-channel slab
+  if (chunk >= s.chunks || slab * 64 >= s.C) return;
+  const int C8 = s.C >> 3;
+  const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;  // 8 channel groups x 32 row lanes
+  const int c8 = slab * 8 + cg;
+  const bool live = c8 < C8;
+  const long long r0 = (long long)chunk * s.rows_per_chunk;
+  long long r1 = r0 + s.rows_per_chunk;
+  if (r1 > s.P) r1 = s.P;
+  float s0[8], s1[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) s0[q] = s1[q] = 0.0f;
+  float mean[8], istd[8];
+  if (a.mode == 1 && live) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      mean[q] = s.fwd[0 * s.C + c8 * 8 + q];
+      istd[q] = s.fwd[1 * s.C + c8 * 8 + q];
+    }
+  }
+  if (live) {
+    for (long long r = r0 + rl; r < r1; r += 32) {
+      const long long o = r * C8 + c8;
+      const bf8 y = unpack8(s.y[o]);
+      if (a.mode == 0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          s0[q] += y.v[q];
+          s1[q] += y.v[q] * y.v[q];
+        }
+      } else {
+        const bf8 dz = unpack8(s.dz[o]);
+        bf8 z;
+        if (a.act != RN_ACT_NONE) z = unpack8(s.z[o]);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float g = a.act != RN_ACT_NONE ? dz.v[q] * act_mask(z.v[q], a.act) : dz.v[q];
+          s0[q] += g;
+          s1[q] += g * ((y.v[q] - mean[q]) * istd[q]);
+        }
+      }
+    }
+  }
+  __shared__ float red[2][32][65];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    red[0][rl][cg * 8 + q] = s0[q];
+    red[1][rl][cg * 8 + q] = s1[q];
+  }
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int which = threadIdx.x >> 6, c = threadIdx.x & 63;
+    float t = 0.0f;
+    for (int r = 0; r < 32; ++r) t += red[which][r][c];
+    const int ch = slab * 64 + c;
+    if (ch < s.C) a.ws[a.ws_off[blockIdx.z] + ((long long)chunk * 2 + which) * s.C + ch] = t;
+  }
+}
+
+// stage 2 of the column reductions: out[which][c] = sum over chunks (double, index order)
+__global__ void bn_colreduce_final_kernel(const BnArgs a) {
+  const BnSegDev& s = a.seg[blockIdx.y];
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= s.C) return;
+  double t0 = 0.0, t1 = 0.0;
+  const float* p = a.ws + a.ws_off[blockIdx.y];
+  for (int k = 0; k < s.chunks; ++k) {
+    t0 += (double)p[((long long)k * 2 + 0) * s.C + c];
+    t1 += (double)p[((long long)k * 2 + 1) * s.C + c];
+  }
+  float* out = a.mode == 0 ? s.sums : s.bsums;
+  out[c] = (float)t0;
+  out[s.C + c] = (float)t1;
+}
+
+// forward finalize: sums (local or all-reduced) -> mean, invstd, scale, shift; moving stats
+__global__ void bn_finalize_kernel(const BnArgs a) {
+  const BnSegDev& s = a.seg[blockIdx.y];
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= s.C) return;
+  const double n = (double)s.P * (double)a.count_scale;
+  const double mean = (double)s.sums[c] / n;
+  double var = (double)s.sums[s.C + c] / n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float istd = (float)(1.0 / sqrt(var + (double)a.eps));
+  const float sc = s.gamma[c] * istd;
+  s.fwd[0 * s.C + c] = (float)mean;
+  s.fwd[1 * s.C + c] = istd;
+  s.fwd[2 * s.C + c] = sc;
+  s.fwd[3 * s.C + c] = s.beta[c] - (float)mean * sc;
+  if (s.moving_mean) {
+    const double vm = a.bessel && n > 1.0 ? var * n / (n - 1.0) : var;
+    s.moving_mean[c] = s.moving_mean[c] * a.momentum + (float)mean * (1.0f - a.momentum);
+    s.moving_var[c] = s.moving_var[c] * a.momentum + (float)vm * (1.0f - a.momentum);
+  }
+}
+
+// z = act(y*scale + shift + residual)
+__global__ void __launch_bounds__(TR_THREADS) bn_apply_kernel(const BnArgs a) {
+  const BnSegDev& s = a.seg[blockIdx.y];
+  const int C8 = s.C >> 3;
+  const long long total = s.P * C8;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % C8);
+    const bf8 y = unpack8(s.y[i]);
+    bf8 o;
+    bf8 res;
+    if (s.residual) res = unpack8(s.residual[i]);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float v = y.v[q] * s.fwd[2 * s.C + c8 * 8 + q] + s.fwd[3 * s.C + c8 * 8 + q];
+      if (s.residual) v += res.v[q];
+      o.v[q] = rn_apply_act(v, a.act);
+    }
+    s.z[i] = pack8(o);
+  }
+}
+
+// dy = scale*(g - sum_g/n - xhat*sum_gxhat/n); dres (+)= g; block 0 also writes dgamma/dbeta
+__global__ void __launch_bounds__(TR_THREADS) bn_bwd_apply_kernel(const BnArgs a) {
+  const BnSegDev& s = a.seg[blockIdx.y];
+  const int C8 = s.C >> 3;
+  const long long total = s.P * C8;
+  const float inv_n = (float)(1.0 / ((double)s.P * (double)a.count_scale));
+  if (blockIdx.x == 0) {
+    for (int c = threadIdx.x; c < s.C; c += blockDim.x) {
+      if (s.dbeta) s.dbeta[c] = s.bsums[c];
+      if (s.dgamma) s.dgamma[c] = s.bsums[s.C + c];
+    }
+  }
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % C8);
+    const bf8 y = unpack8(s.y[i]);
+    const bf8 dz = unpack8(s.dz[i]);
+    bf8 z;
+    if (a.act != RN_ACT_NONE) z = unpack8(s.z[i]);
+    bf8 g, o;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int c = c8 * 8 + q;
+      g.v[q] = a.act != RN_ACT_NONE ? dz.v[q] * act_mask(z.v[q], a.act) : dz.v[q];
+      const float xh = (y.v[q] - s.fwd[0 * s.C + c]) * s.fwd[1 * s.C + c];
+      o.v[q] = s.fwd[2 * s.C + c] * (g.v[q] - s.bsums[c] * inv_n - xh * (s.bsums[s.C + c] * inv_n));
+    }
+    s.dy[i] = pack8(o);
+    if (s.dres) {
+      if (s.dres_accumulate) {
+        const bf8 old = unpack8(s.dres[i]);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) g.v[q] += old.v[q];
+      }
+      s.dres[i] = pack8(g);
+    }
+  }
+}
+
+static int bn_fill(const rn_bn_problem* p, BnArgs& a, int need_ws) {
+  if (!p || p->num_segments < 1 || p->num_segments > RN_CONV_MAX_SEGMENTS) return -1;
+  a.nseg = p->num_segments; a.act = p->act; a.bessel = p->bessel; a.mode = 0;
+  a.eps = p->eps; a.momentum = p->momentum; a.count_scale = p->count_scale > 0 ? p->count_scale : 1.0f;
+  long long off = 0;
+  for (int i = 0; i < p->num_segments; ++i) {
+    const rn_bn_segment& s = p->seg[i];
+    if (s.P <= 0 || s.C <= 0 || (s.C % 8)) return -1;
+    BnSegDev& d = a.seg[i];
+    d.y = (const uint4*)s.y; d.z = (uint4*)s.z; d.residual = (const uint4*)s.residual;
+    d.dz = (const uint4*)s.dz; d.dy = (uint4*)s.dy; d.dres = (uint4*)s.dres;
+    d.sums = s.sums; d.fwd = s.fwd; d.bsums = s.bsums; d.gamma = s.gamma; d.beta = s.beta;
+    d.moving_mean = s.moving_mean; d.moving_var = s.moving_var; d.dgamma = s.dgamma; d.dbeta = s.dbeta;
+    d.P = s.P; d.C = s.C; d.dres_accumulate = s.dres_accumulate;
+    long long rpc = rn_cdiv(rn_cdiv(s.P, 256), 32) * 32;  // <= 256 chunks, multiple of 32 rows
+    if (rpc < 32) rpc = 32;
+    d.rows_per_chunk = (int)rpc;
+    d.chunks = (int)rn_cdiv(s.P, rpc);
+    a.ws_off[i] = off;
+    off += (long long)d.chunks * 2 * s.C;
+  }
+  (void)need_ws;
+  return 0;
+}
+
+extern "C" size_t rn_bn_workspace_bytes(const rn_bn_problem* p) {
+  BnArgs a;
+  if (bn_fill(p, a, 1)) return 0;
+  const BnSegDev& l = a.seg[a.nseg - 1];
+  return (size_t)(a.ws_off[a.nseg - 1] + (long long)l.chunks * 2 * l.C) * sizeof(float);
+}
+
+static int bn_colreduce(const rn_bn_problem* p, int mode, void* ws, size_t ws_bytes, hipStream_t st,
+                        const char* fn) {
+  BnArgs a;
+  RN_CHECK_ARG(bn_fill(p, a, 1) == 0, "%s: bad problem (C %% 8 == 0, 1..10 segments)", fn);
+  if (!ws || ws_bytes < rn_bn_workspace_bytes(p)) {
+    rn_set_error("%s: workspace too small", fn);
+    return RN_ENOMEM;
+  }
+  a.mode = mode;
+  a.ws = (float*)ws;
+  int max_chunks = 0, max_slabs = 0, max_c = 0;
+  for (int i = 0; i < a.nseg; ++i) {
+    const BnSegDev& s = a.seg[i];
+    RN_CHECK_ARG(s.y && (mode == 0 ? s.sums != nullptr : (s.dz && s.bsums && s.fwd)), "%s: null tensor", fn);
+    RN_CHECK_ARG(mode == 0 || a.act == RN_ACT_NONE || s.z, "%s: z needed for the activation mask", fn);
+    if (s.chunks > max_chunks) max_chunks = s.chunks;
+    if ((s.C + 63) / 64 > max_slabs) max_slabs = (s.C + 63) / 64;
+    if (s.C > max_c) max_c = s.C;
+  }
+  hipLaunchKernelGGL(bn_colreduce_kernel, dim3(max_chunks, max_slabs, a.nseg), dim3(TR_THREADS), 0, st, a);
+  RN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bn_colreduce_final_kernel, dim3((max_c + 255) / 256, a.nseg), dim3(256), 0, st, a);
+  RN_CHECK_LAUNCH();
+  return RN_OK;
+}
+
+extern "C" int rn_bn_stats(const rn_bn_problem* p, void* ws, size_t ws_bytes, void* stream) {
+  return bn_colreduce(p, 0, ws, ws_bytes, (hipStream_t)stream, "rn_bn_stats");
+}
+extern "C" int rn_bn_bwd_reduce(const rn_bn_problem* p, void* ws, size_t ws_bytes, void* stream) {
+  return bn_colreduce(p, 1, ws, ws_bytes, (hipStream_t)stream, "rn_bn_bwd_reduce");
+}
+
+extern "C" int rn_bn_finalize(const rn_bn_problem* p, void* stream) {
+  BnArgs a;
+  RN_CHECK_ARG(bn_fill(p, a, 0) == 0, "rn_bn_finalize: bad problem");
+  int max_c = 0;
+  for (int i = 0; i < a.nseg; ++i) {
+    RN_CHECK_ARG(a.seg[i].sums && a.seg[i].fwd && a.seg[i].gamma && a.seg[i].beta, "rn_bn_finalize: null tensor");
+    if (a.seg[i].C > max_c) max_c = a.seg[i].C;
+  }
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((max_c + 255) / 256, a.nseg), dim3(256), 0, (hipStream_t)stream, a);
+  RN_CHECK_LAUNCH();
+  return RN_OK;
+}
+
+extern "C" int rn_bn_apply(const rn_bn_problem* p, void* stream) {
+  BnArgs a;
+  RN_CHECK_ARG(bn_fill(p, a, 0) == 0, "rn_bn_apply: bad problem");
+  long long mx = 0;
+  for (int i = 0; i < a.nseg; ++i) {
+    RN_CHECK_ARG(a.seg[i].y && a.seg[i].z && a.seg[i].fwd, "rn_bn_apply: null tensor");
+    const long long t = a.seg[i].P * (a.seg[i].C / 8);
+    if (t > mx) mx = t;
+  }
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(tr_blocks(mx, 4096), a.nseg), dim3(TR_THREADS), 0, (hipStream_t)stream, a);
+  RN_CHECK_LAUNCH();
+  return RN_OK;
+}
+
+extern "C" int rn_bn_bwd_apply(const rn_bn_problem* p, void* stream) {
+  BnArgs a;
+  RN_CHECK_ARG(bn_fill(p, a, 0) == 0, "rn_bn_bwd_apply: bad problem");
+  long long mx = 0;
+  for (int i = 0; i < a.nseg; ++i) {
+    RN_CHECK_ARG(a.seg[i].y && a.seg[i].dz && a.seg[i].dy && a.seg[i].fwd && a.seg[i].bsums,
+                 "rn_bn_bwd_apply: null tensor");
+    RN_CHECK_ARG(a.act == RN_ACT_NONE || a.seg[i].z, "rn_bn_bwd_apply: z needed for the activation mask");
+    const long long t = a.seg[i].P * (a.seg[i].C / 8);
+    if (t > mx) mx = t;
+  }
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(tr_blocks(mx, 4096), a.nseg), dim3(TR_THREADS), 0,
+                     (hipStream_t)stream, a);
+  RN_CHECK_LAUNCH();
+  return RN_OK;
+}
+
+// ---- gradient of an activation without BN (prediction-free layers): dy = dz * mask(z) --------
+__global__ void __launch_bounds__(TR_THREADS)
+act_bwd_kernel(const uint4* __restrict__ dz, const uint4* __restrict__ z, uint4* __restrict__ dy, long long n8,
+               int act) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n8;
+       i += (long long)gridDim.x * blockDim.x) {
+    bf8 g = unpack8(dz[i]);
+    const bf8 zz = unpack8(z[i]);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) g.v[q] *= act_mask(zz.v[q], act);
+    dy[i] = pack8(g);
+  }
+}
+
+// ---- f32 -> bf16 cast (loss gradients of the fp32 prediction convs feed bf16 dgrad/wgrad) ------
+__global__ void __launch_bounds__(TR_THREADS)
+cast_f32_bf16_kernel(const float4* __restrict__ x, uint2* __restrict__ y, long long n4) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
+       i += (long long)gridDim.x * blockDim.x) {
+    const float4 v = x[i];
+    uint2 o;
+    o.x = rn_pack_bf16x2(v.x, v.y);
+    o.y = rn_pack_bf16x2(v.z, v.w);
+    y[i] = o;
+  }
+}
+extern "C" int rn_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream) {
+  RN_CHECK_ARG(x && y && n > 0 && n % 4 == 0, "rn_cast_f32_to_bf16: bad argument (n %% 4 == 0)");
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(tr_blocks(n / 4)), dim3(TR_THREADS), 0, (hipStream_t)stream,
+                     (const float4*)x, (uint2*)y, (long long)(n / 4));
+  RN_CHECK_LAUNCH();
+  return RN_OK;
+}
+
+// ---- zero-insertion upsample: y[n,2h,2w,:] = x[n,h,w,:], zeros elsewhere (dgrad of stride 2) ---
+__global__ void __launch_bounds__(TR_THREADS)
+upsample_zero_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int N, int H, int W, int C8, int Ho,
+                     int Wo) {
+  const long long total = (long long)N * Ho * Wo * C8;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C8);
+    long long t = i / C8;
+    const int ox = (int)(t % Wo);
+    t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (!(ox & 1) && !(oy & 1) && (oy >> 1) < H && (ox >> 1) < W)
+      v = x[(((long long)n * H + (oy >> 1)) * W + (ox >> 1)) * C8 + c];
+    y[i] = v;
+  }
+}
+extern "C" int rn_upsample_zero2x(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo,
+                                  void* stream) {
+  RN_CHECK_ARG(x && y && N > 0 && H > 0 && W > 0 && C % 8 == 0 && Ho >= 2 * H - 1 && Wo >= 2 * W - 1,
+               "rn_upsample_zero2x: bad argument");
+  hipLaunchKernelGGL(upsample_zero_kernel, dim3(tr_blocks((long long)N * Ho * Wo * (C / 8))), dim3(TR_THREADS), 0,
+                     (hipStream_t)stream, (const uint4*)x, (uint4*)y, N, H, W, C / 8, Ho, Wo);
+  RN_CHECK_LAUNCH();
+  return RN_OK;
+}
+
+extern "C" int rn_act_bwd(const void* dz, const void* z, void* dy, int64_t n, int act, void* stream) {
+  RN_CHECK_ARG(dz && z && dy && n > 0 && n % 8 == 0, "rn_act_bwd: bad argument");
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(tr_blocks(n / 8)), dim3(TR_THREADS), 0, (hipStream_t)stream,
+                     (const uint4*)dz, (const uint4*)z, (uint4*)dy, (long long)(n / 8), act);
+  RN_CHECK_LAUNCH();
+  return RN_OK;
+}
+
+// ---- max-pool backward, non-overlapping windows (k == stride): gradient to the FIRST maximum ---
+__global__ void __launch_bounds__(TR_THREADS)
+maxpool_bwd_kernel(const uint4* __restrict__ x, const uint4* __restrict__ dy, uint4* __restrict__ dx, int N, int H,
+                   int W, int C8, int k, int Ho, int Wo, int accumulate) {
+  const long long total = (long long)N * Ho * Wo * C8;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C8);
+    long long t = i / C8;
+    const int ox = (int)(t % Wo);
+    t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    const bf8 g = unpack8(dy[i]);
+    float best[8];
+    int arg[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { best[q] = -INFINITY; arg[q] = 0; }
+    for (int r = 0; r < k; ++r)
+      for (int s = 0; s < k; ++s) {
+        const bf8 v = unpack8(x[(((long long)n * H + oy * k + r) * W + ox * k + s) * C8 + c]);
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (v.v[q] > best[q]) { best[q] = v.v[q]; arg[q] = r * k + s; }
+      }
+    for (int r = 0; r < k; ++r)
+      for (int s = 0; s < k; ++s) {
+        const long long o = (((long long)n * H + oy * k + r) * W + ox * k + s) * C8 + c;
+        bf8 out;
+        if (accumulate) out = unpack8(dx[o]);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float v = arg[q] == r * k + s ? g.v[q] : 0.0f;
+          out.v[q] = accumulate ? out.v[q] + v : v;
+        }
+        dx[o] = pack8(out);
+      }
+  }
+}
+extern "C" int rn_maxpool2d_nhwc_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int k,
+                                     int Ho, int Wo, int accumulate, void* stream) {
+  RN_CHECK_ARG(x && dy && dx && C % 8 == 0 && k >= 1 && Ho * k <= H && Wo * k <= W && Ho * k == H && Wo * k == W,
+               "rn_maxpool2d_nhwc_bwd: only non-overlapping windows that tile the input exactly are built");
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(tr_blocks((long long)N * Ho * Wo * (C / 8))), dim3(TR_THREADS), 0,
+                     (hipStream_t)stream, (const uint4*)x, (const uint4*)dy, (uint4*)dx, N, H, W, C / 8, k, Ho,
+                     Wo, accumulate);
+  RN_CHECK_LAUNCH();
+  return RN_OK;
+}
+
+// ---- FPN top-down backward, one level: din = (dout + sum2x2(din_finer)) * mask(out) ------------
+__global__ void __launch_bounds__(TR_THREADS)
+topdown_bwd_kernel(const uint4* __restrict__ dout, const uint4* __restrict__ din_finer,
+                   const uint4* __restrict__ out, uint4* __restrict__ din, int N, int H, int W, int C8, int act) {
+  const long long total = (long long)N * H * W * C8;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C8);
+    long long t = i / C8;
+    const int x = (int)(t % W);
+    t /= W;
+    const int y = (int)(t % H);
+    const int n = (int)(t / H);
+    bf8 g = unpack8(dout[i]);
+    if (din_finer) {
+      for (int dy = 0; dy < 2; ++dy)
+        for (int dx = 0; dx < 2; ++dx) {
+          const bf8 v = unpack8(din_finer[(((long long)n * 2 * H + 2 * y + dy) * 2 * W + 2 * x + dx) * C8 + c]);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) g.v[q] += v.v[q];
+        }
+    }
+    if (out && act != RN_ACT_NONE) {
+      const bf8 z = unpack8(out[i]);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) g.v[q] *= act_mask(z.v[q], act);
+    }
+    din[i] = pack8(g);
+  }
+}
+extern "C" int rn_fpn_topdown_bwd_level(const void* dout, const void* din_finer, const void* out, void* din, int N,
+                                        int H, int W, int C, int act, void* stream) {
+  RN_CHECK_ARG(dout && din && C % 8 == 0 && N > 0 && H > 0 && W > 0, "rn_fpn_topdown_bwd_level: bad argument");
+  hipLaunchKernelGGL(topdown_bwd_kernel, dim3(tr_blocks((long long)N * H * W * (C / 8))), dim3(TR_THREADS), 0,
+                     (hipStream_t)stream, (const uint4*)dout, (const uint4*)din_finer, (const uint4*)out,
+                     (uint4*)din, N, H, W, C / 8, act);
+  RN_CHECK_LAUNCH();
+  return RN_OK;
+}
+
+// ---- BalanceFeatures backward (balance_features.py:19-60) -----------------------------------
+#define RN_PYR_MAX 8
+struct BalBwd {
+  int L, mid, N, H0, W0, C8;
+  const uint4* dout[RN_PYR_MAX];
+  const uint4* in[RN_PYR_MAX];  // forward inputs (only levels < mid are read: max-pool argmax)
+  uint4* din[RN_PYR_MAX];
+  const uint4* avg;             // forward average at the intermediate level
+  uint4* davg;                  // scratch
+  long long begin[RN_PYR_MAX + 1];
+};
+
+// d_avg = sum over levels of R_l^T(dout_l): finer levels sum their children, coarser levels
+// route to the first maximum of avg inside the pooling window.
+__global__ void __launch_bounds__(TR_THREADS) balance_bwd_avg_kernel(BalBwd b) {
+  const int Hm = b.H0 >> b.mid, Wm = b.W0 >> b.mid;
+  const long long total = (long long)b.N * Hm * Wm * b.C8;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % b.C8);
+    long long t = i / b.C8;
+    const int x = (int)(t % Wm);
+    t /= Wm;
+    const int y = (int)(t % Hm);
+    const int n = (int)(t / Hm);
+    bf8 acc;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc.v[q] = 0.0f;
+    for (int l = 0; l < b.L; ++l) {
+      const int Hl = b.H0 >> l, Wl = b.W0 >> l;
+      if (l <= b.mid) {
+        const int f = 1 << (b.mid - l);
+        for (int dy = 0; dy < f; ++dy)
+          for (int dx = 0; dx < f; ++dx) {
+            const bf8 v = unpack8(b.dout[l][(((long long)n * Hl) + y * f + dy) * Wl * b.C8 +
+                                            (long long)(x * f + dx) * b.C8 + c]);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc.v[q] += v.v[q];
+          }
+      } else {
+        const int f = 1 << (l - b.mid);
+        const int wy = y / f, wx = x / f;
+        float best[8];
+        int arg[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { best[q] = -INFINITY; arg[q] = 0; }
+        for (int dy = 0; dy < f; ++dy)
+          for (int dx = 0; dx < f; ++dx) {
+            const bf8 v = unpack8(b.avg[(((long long)n * Hm) + wy * f + dy) * Wm * b.C8 +
+                                        (long long)(wx * f + dx) * b.C8 + c]);
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+              if (v.v[q] > best[q]) { best[q] = v.v[q]; arg[q] = dy * f + dx; }
+          }
+        const bf8 g = unpack8(b.dout[l][(((long long)n * Hl) + wy) * Wl * b.C8 + (long long)wx * b.C8 + c]);
+        const int me = (y - wy * f) * f + (x - wx * f);
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (arg[q] == me) acc.v[q] += g.v[q];
+      }
+    }
+    b.davg[i] = pack8(acc);
+  }
+}
+
+// din_l = dout_l + S_l^T(d_avg / L)
+__global__ void __launch_bounds__(TR_THREADS) balance_bwd_in_kernel(BalBwd b) {
+  const int Hm = b.H0 >> b.mid, Wm = b.W0 >> b.mid;
+  const long long total = b.begin[b.L];
+  const float invL = 1.0f / (float)b.L;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    int l = 0;
+    while (i >= b.begin[l + 1]) ++l;
+    long long t = i - b.begin[l];
+    const int c = (int)(t % b.C8);
+    t /= b.C8;
+    const int Wl = b.W0 >> l, Hl = b.H0 >> l;
+    const int x = (int)(t % Wl);
+    t /= Wl;
+    const int y = (int)(t % Hl);
+    const int n = (int)(t / Hl);
+    const long long o = (((long long)n * Hl) + y) * Wl * b.C8 + (long long)x * b.C8 + c;
+    bf8 g = unpack8(b.dout[l][o]);
+    if (l >= b.mid) {
+      const int f = 1 << (l - b.mid);
+      for (int dy = 0; dy < f; ++dy)
+        for (int dx = 0; dx < f; ++dx) {
+          const bf8 v = unpack8(b.davg[(((long long)n * Hm) + y * f + dy) * Wm * b.C8 +
+                                       (long long)(x * f + dx) * b.C8 + c]);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) g.v[q] += v.v[q] * invL;
+        }
+    } else {
+      const int f = 1 << (b.mid - l);
+      const int wy = y / f, wx = x / f;
+      float best[8];
+      int arg[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { best[q] = -INFINITY; arg[q] = 0; }
+      for (int dy = 0; dy < f; ++dy)
+        for (int dx = 0; dx < f; ++dx) {
+          const bf8 v = unpack8(b.in[l][(((long long)n * Hl) + wy * f + dy) * Wl * b.C8 +
+                                        (long long)(wx * f + dx) * b.C8 + c]);
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            if (v.v[q] > best[q]) { best[q] = v.v[q]; arg[q] = dy * f + dx; }
+        }
+      const bf8 a = unpack8(b.davg[(((long long)n * Hm) + wy) * Wm * b.C8 + (long long)wx * b.C8 + c]);
+      const int me = (y - wy * f) * f + (x - wx * f);
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (arg[q] == me) g.v[q] += a.v[q] * invL;
+    }
+    b.din[l][o] = pack8(g);
+  }
+}
+
+extern "C" int rn_balance_features_bwd(void* const* dout, void* const* in, void* const* din, const void* avg,
+                                       void* davg_scratch, int num_levels, int mid, int N, int H0, int W0, int C,
+                                       void* stream) {
+  RN_CHECK_ARG(dout && in && din && avg && davg_scratch && num_levels >= 2 && num_levels <= RN_PYR_MAX &&
+                   mid >= 0 && mid < num_levels && C % 8 == 0,
+               "rn_balance_features_bwd: bad argument");
+  RN_CHECK_ARG(H0 % (1 << (num_levels - 1)) == 0 && W0 % (1 << (num_levels - 1)) == 0,
+               "rn_balance_features_bwd: levels must halve exactly");
+  BalBwd b;
+  b.L = num_levels; b.mid = mid; b.N = N; b.H0 = H0; b.W0 = W0; b.C8 = C / 8;
+  b.avg = (const uint4*)avg;
+  b.davg = (uint4*)davg_scratch;
+  b.begin[0] = 0;
+  for (int l = 0; l < num_levels; ++l) {
+    RN_CHECK_ARG(dout[l] && din[l] && (l >= mid || in[l]), "rn_balance_features_bwd: null level %d", l);
+    b.dout[l] = (const uint4*)dout[l];
+    b.in[l] = (const uint4*)in[l];
+    b.din[l] = (uint4*)din[l];
+    b.begin[l + 1] = b.begin[l] + (long long)N * (H0 >> l) * (W0 >> l) * (C / 8);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(balance_bwd_avg_kernel, dim3(tr_blocks((long long)N * (H0 >> mid) * (W0 >> mid) * (C / 8))),
+                     dim3(TR_THREADS), 0, st, b);
+  RN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(balance_bwd_in_kernel, dim3(tr_blocks(b.begin[num_levels])), dim3(TR_THREADS), 0, st, b);
+  RN_CHECK_LAUNCH();
+  return RN_OK;
+}

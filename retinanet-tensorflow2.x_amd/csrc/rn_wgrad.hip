@@ -1,0 +1,266 @@
+// rn_wgrad.hip — weight gradient of the NHWC convolutions (backward of K1/K2; the autodiff of
+// tf.keras.layers.Conv2D at resnet.py:137-144, fpn.py:47-66, detection_head.py:56-88 taken by
+// tape.gradient in executor.py:427-428).
+//
+//   dW[co][r][s][ci] = sum over output pixels p of dy[p][co] * x[pixel(p) shifted by tap (r,s)][ci]
+//
+// GEMM view per filter tap: M = Cout, N = Cin, K = output pixels (all images, and for the shared
+// head convs all pyramid levels).  Both operands are pixel-major ([pixel][channel], the
+// reduction index is the SLOW axis), so neither has the k-contiguous fragment MFMA wants; tiles
+// are DMA'd into LDS as they lie in HBM and the fragments are read with the gfx950 transpose
+// read ds_read_b64_tr_b16 (each 16-lane group turns a 4-pixel x 16-channel block into
+// 4 k-values per lane).  The tap shift is then just a row (pixel) offset of the x tile.
+//   * workgroup = 256 threads, C tile 128 (co) x 128 (ci) for ONE tap, K step 64 pixels,
+//     2 LDS stages fed by buffer_load...lds (OOB rows -> zeros: image borders, chunk tails);
+//   * LDS rows are 256 B (128 channels); the 16-byte slot is XOR-swizzled by (row & 3) << 2 so
+//     the 4 pixel rows a transpose read touches fall in different bank groups;
+//   * split-K over pixel chunks for parallelism: every (tile, chunk) workgroup writes its fp32
+//     partial tile to the workspace, a second kernel adds the chunks in index order
+//     (deterministic; no float atomics).
+// MFMA-bound for large layers; the partial-tile traffic is chunks * |W| * 4 B.
+#include "rn_common.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(3))) bf16x4_t lds_b4_t;
+
+#define WG_THREADS 256
+#define WG_BK 64
+#define WG_TILE_BYTES (WG_BK * 256)
+#define WG_OOB 0x80000000u
+
+struct WgSegDev {
+  const uint16_t* x;
+  const uint16_t* dy;
+  int N, H, W, Ho, Wo, P, chunk_begin, pad_;
+};
+
+struct WgArgs {
+  int R, S, sh, sw, pt, pl, nseg, total_chunks, CH, co_tiles, ci_tiles, Cin, Cout, pad_;
+  float* ws;
+  WgSegDev seg[RN_CONV_MAX_SEGMENTS];
+};
+
+__device__ __forceinline__ void wg_dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, unsigned voff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)lds_wave_base, 16, (int)voff, 0, 0, 0);
+}
+
+// transpose-read fragment: 8 k-values (pixels kb..kb+7 of this lane's k half) for channel `col`
+__device__ __forceinline__ bf16x8_t wg_frag(const char* tile, int kb, int lane, int col0) {
+  const int g = lane >> 4, i = lane & 15;
+  const int col = col0 + 16 * (g & 1) + 4 * (i & 3);
+  const int row0 = kb + (g >> 1) * 8 + (i >> 2);
+  const int slot = col >> 3, sub = (col & 7) * 2;
+  const int r0 = row0, r1 = row0 + 4;
+  const lds_b4_t* p0 = (const lds_b4_t*)(tile + r0 * 256 + ((slot ^ ((r0 & 3) << 2)) << 4) + sub);
+  const lds_b4_t* p1 = (const lds_b4_t*)(tile + r1 * 256 + ((slot ^ ((r1 & 3) << 2)) << 4) + sub);
+  const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_t*)p0);
+  const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_t*)p1);
+  bf16x8_t r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return r;
+}
+
+__global__ void __launch_bounds__(WG_THREADS, 2) wgrad_kernel(const WgArgs args) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (A 16K + B 16K)
+  const int tiles_per_tap = args.co_tiles * args.ci_tiles;
+  const int tap = blockIdx.x / tiles_per_tap;
+  const int tt = blockIdx.x - tap * tiles_per_tap;
+  const int co_t = tt / args.ci_tiles, ci_t = tt - co_t * args.ci_tiles;
+  const int co0 = co_t * 128, ci0 = ci_t * 128;
+  const int r = tap / args.S, s = tap - r * args.S;
+  const int chunk = blockIdx.y;
+  int si = 0;
+#pragma unroll 1
+  for (int i = 1; i < args.nseg; ++i)
+    if (chunk >= args.seg[i].chunk_begin) si = i;
+  const WgSegDev& sg = args.seg[si];
+  const int p_begin = (chunk - sg.chunk_begin) * args.CH;
+  const int p_end = (p_begin + args.CH) < sg.P ? (p_begin + args.CH) : sg.P;
+  const int Cin = args.Cin, Cout = args.Cout;
+  const int H = sg.H, W = sg.W, Ho = sg.Ho, Wo = sg.Wo;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_m = wave >> 1, wave_n = wave & 1;
+
+  const __amdgpu_buffer_rsrc_t rs_dy =
+      __builtin_amdgcn_make_buffer_rsrc((void*)sg.dy, 0, (int)((long long)sg.P * Cout * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x =
+      __builtin_amdgcn_make_buffer_rsrc((void*)sg.x, 0, (int)((long long)sg.N * H * W * Cin * 2), 0x00020000);
+
+  // DMA bookkeeping: instruction j of this wave fills rows (j*4 + wave)*4 .. +3 of a 64-row tile
+  const int d_row = lane >> 4, d_pos = lane & 15;
+  const float inv_wo = 1.0f / (float)Wo, inv_ho = 1.0f / (float)Ho;
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.0f;
+
+  const int ksteps = (p_end - p_begin + WG_BK - 1) / WG_BK;
+
+#define WG_ISSUE(buf, p0_)                                                                        \
+  do {                                                                                            \
+    char* st__ = smem + (buf) * (2 * WG_TILE_BYTES);                                              \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
+      const int row__ = (j * 4 + wave) * 4 + d_row;                                               \
+      const int chunk__ = d_pos ^ ((row__ & 3) << 2);                                             \
+      const int p__ = (p0_) + row__;                                                              \
+      const bool in__ = p__ < p_end;                                                              \
+      const unsigned va__ = in__ ? (unsigned)(((long long)p__ * Cout + co0 + chunk__ * 8) * 2) : WG_OOB; \
+      wg_dma16(rs_dy, st__ + (j * 4 + wave) * 1024, va__);                                        \
+      /* p -> (n, oy, ox) with a float reciprocal + one correction (p < 2^24) */                  \
+      int t2__ = (int)((float)p__ * inv_wo);                                                      \
+      int ox__ = p__ - t2__ * Wo;                                                                 \
+      if (ox__ < 0) { ox__ += Wo; --t2__; } else if (ox__ >= Wo) { ox__ -= Wo; ++t2__; }          \
+      int n__ = (int)((float)t2__ * inv_ho);                                                      \
+      int oy__ = t2__ - n__ * Ho;                                                                 \
+      if (oy__ < 0) { oy__ += Ho; --n__; } else if (oy__ >= Ho) { oy__ -= Ho; ++n__; }            \
+      const int iy__ = oy__ * args.sh - args.pt + r, ix__ = ox__ * args.sw - args.pl + s;         \
+      const bool ok__ = in__ && (unsigned)iy__ < (unsigned)H && (unsigned)ix__ < (unsigned)W;     \
+      const unsigned vb__ =                                                                       \
+          ok__ ? (unsigned)(((((long long)n__ * H + iy__) * W + ix__) * Cin + ci0 + chunk__ * 8) * 2) : WG_OOB; \
+      wg_dma16(rs_x, st__ + WG_TILE_BYTES + (j * 4 + wave) * 1024, vb__);                         \
+    }                                                                                             \
+  } while (0)
+
+  WG_ISSUE(0, p_begin);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0;
+#pragma unroll 1
+  for (int kt = 0; kt < ksteps; ++kt) {
+    if (kt + 1 < ksteps) WG_ISSUE(cur ^ 1, p_begin + (kt + 1) * WG_BK);
+    const char* ta = smem + cur * (2 * WG_TILE_BYTES);
+    const char* tb = ta + WG_TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < WG_BK / 16; ++kk) {
+      bf16x8_t fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = wg_frag(ta, kk * 16, lane, wave_m * 64 + i * 32);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = wg_frag(tb, kk * 16, lane, wave_n * 64 + j * 32);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+#undef WG_ISSUE
+
+  // partial tile -> workspace[chunk][co][tap][ci]
+  const int taps = args.R * args.S;
+  float* out = args.ws + (long long)chunk * Cout * taps * Cin;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int ci = ci0 + wave_n * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int co = co0 + wave_m * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+        if (co < Cout && ci < Cin) out[((long long)co * taps + tap) * Cin + ci] = acc[i][j][q];
+      }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+wgrad_reduce_kernel(const float4* __restrict__ ws, long long n4, int chunks, float4* __restrict__ dw, float beta) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
+       i += (long long)gridDim.x * blockDim.x) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c = 0; c < chunks; ++c) {
+      const float4 v = ws[(long long)c * n4 + i];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    if (beta != 0.0f) {
+      const float4 o = dw[i];
+      a.x += beta * o.x; a.y += beta * o.y; a.z += beta * o.z; a.w += beta * o.w;
+    }
+    dw[i] = a;
+  }
+}
+
+static int wgrad_plan(const rn_wgrad_problem* p, WgArgs& a) {
+  if (!p || p->num_segments < 1 || p->num_segments > RN_CONV_MAX_SEGMENTS) return -1;
+  if (p->R < 1 || p->S < 1 || p->stride_h < 1 || p->stride_w < 1) return -1;
+  a.R = p->R; a.S = p->S; a.sh = p->stride_h; a.sw = p->stride_w; a.pt = p->pad_top; a.pl = p->pad_left;
+  a.nseg = p->num_segments;
+  a.Cin = p->seg[0].Cin; a.Cout = p->seg[0].Cout;
+  if (a.Cin % 8 || a.Cout % 4 || a.Cin <= 0 || a.Cout <= 0) return -1;
+  a.co_tiles = (int)rn_cdiv(a.Cout, 128);
+  a.ci_tiles = (int)rn_cdiv(a.Cin, 128);
+  long long Ptot = 0;
+  for (int i = 0; i < p->num_segments; ++i) {
+    const rn_wgrad_segment& s = p->seg[i];
+    if (!s.x || !s.dy || s.Cin != a.Cin || s.Cout != a.Cout) return -1;
+    const long long P = (long long)s.N * s.Ho * s.Wo;
+    if (P <= 0 || P >= (1ll << 24)) return -1;
+    if ((long long)s.N * s.H * s.W * s.Cin * 2 >= (1ll << 31) || P * s.Cout * 2 >= (1ll << 31)) return -1;
+    Ptot += P;
+  }
+  const int tiles = a.co_tiles * a.ci_tiles * a.R * a.S;
+  long long target = rn_cdiv(2048, tiles);
+  if (target < 1) target = 1;
+  if (target > 256) target = 256;
+  long long CH = rn_cdiv(rn_cdiv(Ptot, target), WG_BK) * WG_BK;
+  if (CH < WG_BK) CH = WG_BK;
+  a.CH = (int)CH;
+  int chunks = 0;
+  for (int i = 0; i < p->num_segments; ++i) {
+    const rn_wgrad_segment& s = p->seg[i];
+    WgSegDev& d = a.seg[i];
+    d.x = (const uint16_t*)s.x; d.dy = (const uint16_t*)s.dy;
+    d.N = s.N; d.H = s.H; d.W = s.W; d.Ho = s.Ho; d.Wo = s.Wo;
+    d.P = s.N * s.Ho * s.Wo;
+    d.chunk_begin = chunks;
+    d.pad_ = 0;
+    chunks += (int)rn_cdiv(d.P, CH);
+  }
+  a.total_chunks = chunks;
+  a.pad_ = 0;
+  return 0;
+}
+
+extern "C" size_t rn_wgrad_workspace_bytes(const rn_wgrad_problem* p) {
+  WgArgs a;
+  if (wgrad_plan(p, a)) return 0;
+  return (size_t)a.total_chunks * a.Cout * a.R * a.S * a.Cin * sizeof(float);
+}
+
+extern "C" int rn_conv2d_nhwc_wgrad(const rn_wgrad_problem* p, float* dw, float beta, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+  WgArgs a;
+  RN_CHECK_ARG(wgrad_plan(p, a) == 0, "rn_conv2d_nhwc_wgrad: bad problem (Cin %% 8, Cout %% 4, < 2^24 pixels, < 2 GiB tensors)");
+  RN_CHECK_ARG(dw != nullptr, "rn_conv2d_nhwc_wgrad: null dw");
+  const size_t need = rn_wgrad_workspace_bytes(p);
+  if (!workspace || workspace_bytes < need) {
+    rn_set_error("rn_conv2d_nhwc_wgrad: workspace %zu < %zu", workspace_bytes, need);
+    return RN_ENOMEM;
+  }
+  a.ws = (float*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  const int lds = 4 * WG_TILE_BYTES;
+  RN_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  dim3 grid((unsigned)(a.co_tiles * a.ci_tiles * a.R * a.S), (unsigned)a.total_chunks);
+  hipLaunchKernelGGL(wgrad_kernel, grid, dim3(WG_THREADS), lds, st, a);
+  RN_CHECK_LAUNCH();
+  const long long n = (long long)a.Cout * a.R * a.S * a.Cin;
+  const long long n4 = n / 4;
+  int blocks = (int)(rn_cdiv(n4, 256) < 2048 ? rn_cdiv(n4, 256) : 2048);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)workspace, n4,
+                     a.total_chunks, (float4*)dw, beta);
+  RN_CHECK_LAUNCH();
+  return RN_OK;
+}

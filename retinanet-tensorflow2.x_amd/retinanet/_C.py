@@ -35,6 +35,30 @@ class ConvProblem(Structure):
                 ("num_segments", c_int32), ("seg", ConvSegment * RN_CONV_MAX_SEGMENTS)]
 
 
+class WgradSegment(Structure):
+    _fields_ = [("x", c_void_p), ("dy", c_void_p), ("N", c_int32), ("H", c_int32), ("W", c_int32),
+                ("Cin", c_int32), ("Ho", c_int32), ("Wo", c_int32), ("Cout", c_int32)]
+
+
+class WgradProblem(Structure):
+    _fields_ = [("R", c_int32), ("S", c_int32), ("stride_h", c_int32), ("stride_w", c_int32),
+                ("pad_top", c_int32), ("pad_left", c_int32), ("num_segments", c_int32),
+                ("seg", WgradSegment * RN_CONV_MAX_SEGMENTS)]
+
+
+class BnSegment(Structure):
+    _fields_ = [("y", c_void_p), ("z", c_void_p), ("residual", c_void_p), ("dz", c_void_p), ("dy", c_void_p),
+                ("dres", c_void_p), ("sums", c_void_p), ("fwd", c_void_p), ("bsums", c_void_p),
+                ("gamma", c_void_p), ("beta", c_void_p), ("moving_mean", c_void_p), ("moving_var", c_void_p),
+                ("dgamma", c_void_p), ("dbeta", c_void_p), ("P", c_int64), ("C", c_int32),
+                ("dres_accumulate", c_int32)]
+
+
+class BnProblem(Structure):
+    _fields_ = [("num_segments", c_int32), ("act", c_int32), ("bessel", c_int32), ("eps", c_float),
+                ("momentum", c_float), ("count_scale", c_float), ("seg", BnSegment * RN_CONV_MAX_SEGMENTS)]
+
+
 _PP = POINTER(c_void_p)
 _SIGNATURES = {
     "rn_last_error": (c_char_p, []),
@@ -70,6 +94,30 @@ _SIGNATURES = {
     "rn_pack_stem_weight": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "rn_stem_padded_width": (c_int, [c_int]),
     "rn_pack_stem_input": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rn_wgrad_workspace_bytes": (c_size_t, [POINTER(WgradProblem)]),
+    "rn_conv2d_nhwc_wgrad": (c_int, [POINTER(WgradProblem), c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
+    "rn_pack_conv_weight_dgrad": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rn_upsample_zero2x": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "rn_cast_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "rn_act_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "rn_bn_workspace_bytes": (c_size_t, [POINTER(BnProblem)]),
+    "rn_bn_stats": (c_int, [POINTER(BnProblem), c_void_p, c_size_t, c_void_p]),
+    "rn_bn_finalize": (c_int, [POINTER(BnProblem), c_void_p]),
+    "rn_bn_apply": (c_int, [POINTER(BnProblem), c_void_p]),
+    "rn_bn_bwd_reduce": (c_int, [POINTER(BnProblem), c_void_p, c_size_t, c_void_p]),
+    "rn_bn_bwd_apply": (c_int, [POINTER(BnProblem), c_void_p]),
+    "rn_maxpool2d_nhwc_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                      c_int, c_int, c_void_p]),
+    "rn_fpn_topdown_bwd_level": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                         c_int, c_void_p]),
+    "rn_balance_features_bwd": (c_int, [_PP, _PP, _PP, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                        c_int, c_void_p]),
+    "rn_optim_chunk": (c_int, []),
+    "rn_optim_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "rn_optim_clip": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_float, c_float, c_void_p,
+                              c_void_p, c_size_t, c_void_p]),
+    "rn_optim_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                  c_float, c_float, c_float, c_void_p]),
     "rn_maxpool2d_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                   c_int, c_int, c_void_p]),
     "rn_fpn_topdown": (c_int, [_PP, _PP, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

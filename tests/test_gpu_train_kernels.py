@@ -1,0 +1,318 @@
+"""GPU parity of the training kernels (backward of a5-a8, a10) against PyTorch-CPU autograd in
+float32 on the same bf16-rounded inputs."""
+import ctypes
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+def _ws(nbytes, dev):
+    return torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=dev)
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [
+    # list of (N, H, Cin, Cout) segments, k, stride
+    ([(2, 12, 128, 128)], 3, 1),
+    ([(2, 16, 256, 128)], 1, 1),
+    ([(1, 16, 128, 256)], 3, 2),
+    ([(2, 8, 256, 36)], 3, 1),                                   # box prediction conv (Cout tail)
+    ([(2, s, 256, 256) for s in (8, 4, 2, 1)], 3, 1),            # shared head conv over a pyramid
+    ([(1, 10, 192, 720)], 3, 1),                                 # Cin tail tile, 6 co tiles
+], ids=["3x3", "1x1", "3x3s2", "pred36", "pyramid", "cin192_720"])
+def test_wgrad(cuda, shape):
+    from retinanet import _C
+    lib = _C.lib()
+    segs, k, stride = shape
+    g = torch.Generator().manual_seed(len(segs) * 100 + k + stride)
+    pad = (k - 1) // 2
+    cin, cout = segs[0][2], segs[0][3]
+    p = _C.WgradProblem()
+    p.R = p.S = k
+    p.stride_h = p.stride_w = stride
+    p.pad_top = p.pad_left = pad
+    p.num_segments = len(segs)
+    keep = []
+    want = torch.zeros((cout, k, k, cin), dtype=torch.float64)
+    for i, (N, H, ci, co) in enumerate(segs):
+        x = _bf(torch.randn((N, H, H, ci), generator=g))
+        Ho = (H + 2 * pad - k) // stride + 1
+        dy = _bf(torch.randn((N, Ho, Ho, co), generator=g))
+        xd, dyd = x.to(cuda), dy.to(cuda)
+        s = p.seg[i]
+        s.x, s.dy = xd.data_ptr(), dyd.data_ptr()
+        s.N, s.H, s.W, s.Cin, s.Ho, s.Wo, s.Cout = N, H, H, ci, Ho, Ho, co
+        keep += [xd, dyd]
+        w = torch.zeros((co, ci, k, k), dtype=torch.float64, requires_grad=True)
+        y = F.conv2d(x.double().permute(0, 3, 1, 2), w, stride=stride, padding=pad)
+        y.backward(dy.double().permute(0, 3, 1, 2))
+        want += w.grad.permute(0, 2, 3, 1)
+    ws = _ws(lib.rn_wgrad_workspace_bytes(ctypes.byref(p)), cuda)
+    dw = torch.full((cout, k, k, cin), 7.0, dtype=torch.float32, device=cuda)
+    _C.check(lib.rn_conv2d_nhwc_wgrad(ctypes.byref(p), _C.ptr(dw), 0.0, _C.ptr(ws), ws.numel(), _C.current_stream()))
+    torch.cuda.synchronize()
+    scale = want.abs().max().item()
+    torch.testing.assert_close(dw.cpu().double(), want, rtol=1e-3, atol=1e-3 * scale)
+    # beta = 1 accumulates
+    _C.check(lib.rn_conv2d_nhwc_wgrad(ctypes.byref(p), _C.ptr(dw), 1.0, _C.ptr(ws), ws.numel(), _C.current_stream()))
+    torch.cuda.synchronize()
+    torch.testing.assert_close(dw.cpu().double(), 2 * want, rtol=1e-3, atol=2e-3 * scale)
+
+
+@pytest.mark.parametrize("k,stride,cin,cout", [(3, 1, 128, 256), (1, 1, 256, 128), (3, 2, 128, 128), (1, 2, 256, 512)])
+def test_dgrad_via_forward_kernel(cuda, k, stride, cin, cout):
+    """dx = conv_fwd(dy [zero-upsampled for stride 2], flipped/transposed weights)."""
+    from retinanet import _C
+    lib = _C.lib()
+    g = torch.Generator().manual_seed(k * 10 + stride)
+    N, H = 2, 12
+    pad = (k - 1) // 2
+    Ho = (H + 2 * pad - k) // stride + 1
+    w = torch.randn((cout, k, k, cin), generator=g) / math.sqrt(k * k * cin)     # compute layout OHWI
+    dy = _bf(torch.randn((N, Ho, Ho, cout), generator=g))
+    xr = torch.zeros((N, cin, H, H), dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(xr, _bf(w).double().permute(0, 3, 1, 2), stride=stride, padding=pad)
+    y.backward(dy.double().permute(0, 3, 1, 2))
+    want = xr.grad.permute(0, 2, 3, 1).float()
+    wd = w.to(cuda).contiguous()
+    wp = torch.empty((lib.rn_conv_cout_pad(cin), k, k, cout), dtype=torch.bfloat16, device=cuda)
+    _C.check(lib.rn_pack_conv_weight_dgrad(_C.ptr(wd), k, k, cin, cout, _C.ptr(wp), _C.current_stream()))
+    dyd = dy.to(cuda).contiguous()
+    if stride == 2:
+        up = torch.empty((N, H, H, cout), dtype=torch.bfloat16, device=cuda)
+        _C.check(lib.rn_upsample_zero2x(_C.ptr(dyd), _C.ptr(up), N, Ho, Ho, cout, H, H, _C.current_stream()))
+        src = up
+    else:
+        src = dyd
+    dx = torch.empty((N, H, H, cin), dtype=torch.bfloat16, device=cuda)
+    acc = _bf(torch.randn((N, H, H, cin), generator=g)).to(cuda)   # accumulate into an existing gradient
+    dx.copy_(acc)
+    p = _C.ConvProblem()
+    p.R = p.S = k
+    p.stride_h = p.stride_w = 1
+    p.pad_top = p.pad_left = k - 1 - pad
+    p.act, p.out_dtype, p.num_segments = _C.RN_ACT_NONE, _C.RN_DT_BF16, 1
+    s = p.seg[0]
+    s.x, s.w, s.y, s.scale, s.shift, s.residual = src.data_ptr(), wp.data_ptr(), dx.data_ptr(), None, None, dx.data_ptr()
+    s.N, s.H, s.W, s.Cin, s.pix_stride, s.Ho, s.Wo, s.Cout = N, H, H, cout, cout, H, H, cin
+    _C.check(lib.rn_conv2d_nhwc_fwd(ctypes.byref(p), _C.current_stream()))
+    torch.cuda.synchronize()
+    ref = _bf(want + acc.float().cpu()).float()
+    scale = ref.abs().max().item()
+    torch.testing.assert_close(dx.float().cpu(), ref, rtol=1 / 128, atol=scale / 200)
+
+
+# ---------------------------------------------------------------------------------------------
+def _bn_problem(cuda, segs, act, eps=1e-3, momentum=0.99, bessel=1, with_bwd=False):
+    from retinanet import _C
+    p = _C.BnProblem()
+    p.num_segments, p.act, p.bessel, p.eps, p.momentum, p.count_scale = len(segs), _C.ACT_IDS[act], bessel, eps, momentum, 1.0
+    dev = []
+    for i, s in enumerate(segs):
+        P, C = s["y"].shape[0] * s["y"].shape[1] * s["y"].shape[2], s["y"].shape[3]
+        d = {k: (_bf(v).to(cuda).contiguous() if v is not None else None) for k, v in s.items()
+             if k in ("y", "residual", "dz")}
+        d["z"] = torch.empty_like(d["y"])
+        d["dy"] = torch.empty_like(d["y"])
+        d["dres"] = torch.zeros_like(d["y"])
+        for k in ("sums", "bsums"):
+            d[k] = torch.zeros((2, C), dtype=torch.float32, device=cuda)
+        d["fwd"] = torch.zeros((4, C), dtype=torch.float32, device=cuda)
+        for k in ("gamma", "beta", "moving_mean", "moving_var"):
+            d[k] = s[k].to(cuda).float().contiguous()
+        d["dgamma"] = torch.zeros((C,), dtype=torch.float32, device=cuda)
+        d["dbeta"] = torch.zeros((C,), dtype=torch.float32, device=cuda)
+        g = p.seg[i]
+        for k in ("y", "z", "residual", "dz", "dy", "dres", "sums", "fwd", "bsums", "gamma", "beta", "moving_mean",
+                  "moving_var", "dgamma", "dbeta"):
+            t = d.get(k)
+            setattr(g, k, t.data_ptr() if t is not None else None)
+        g.P, g.C, g.dres_accumulate = P, C, 0
+        dev.append(d)
+    return p, dev
+
+
+@pytest.mark.parametrize("act,use_res", [("relu", True), ("relu", False), (None, False), ("relu6", True)])
+def test_bn_train_forward_backward(cuda, act, use_res):
+    from retinanet import _C
+    lib = _C.lib()
+    g = torch.Generator().manual_seed(11)
+    shapes = [(2, 9, 7, 64), (1, 5, 5, 256), (3, 4, 4, 8)]
+    segs = []
+    for (N, H, W, C) in shapes:
+        segs.append({"y": torch.randn((N, H, W, C), generator=g) * 2 + 0.5,
+                     "residual": torch.randn((N, H, W, C), generator=g) if use_res else None,
+                     "dz": torch.randn((N, H, W, C), generator=g),
+                     "gamma": torch.rand((C,), generator=g) + 0.5, "beta": torch.randn((C,), generator=g) * 0.2,
+                     "moving_mean": torch.randn((C,), generator=g), "moving_var": torch.rand((C,), generator=g) + 0.5})
+    p, dev = _bn_problem(cuda, segs, act)
+    ws = _ws(lib.rn_bn_workspace_bytes(ctypes.byref(p)), cuda)
+    st = _C.current_stream()
+    _C.check(lib.rn_bn_stats(ctypes.byref(p), _C.ptr(ws), ws.numel(), st))
+    _C.check(lib.rn_bn_finalize(ctypes.byref(p), st))
+    _C.check(lib.rn_bn_apply(ctypes.byref(p), st))
+    _C.check(lib.rn_bn_bwd_reduce(ctypes.byref(p), _C.ptr(ws), ws.numel(), st))
+    _C.check(lib.rn_bn_bwd_apply(ctypes.byref(p), st))
+    torch.cuda.synchronize()
+    for s, d in zip(segs, dev):
+        y = _bf(s["y"]).double().requires_grad_(True)
+        gam = s["gamma"].double().requires_grad_(True)
+        bet = s["beta"].double().requires_grad_(True)
+        res = _bf(s["residual"]).double().requires_grad_(True) if use_res else None
+        n = y.numel() // y.shape[-1]
+        mean = y.mean(dim=(0, 1, 2))
+        var = y.var(dim=(0, 1, 2), unbiased=False)
+        v = (y - mean) / torch.sqrt(var + 1e-3) * gam + bet
+        if use_res:
+            v = v + res
+        z = F.relu(v) if act == "relu" else (F.relu6(v) if act == "relu6" else v)
+        torch.testing.assert_close(d["z"].float().cpu().double(), z.detach(), rtol=1 / 100, atol=2e-2)
+        # backward through the bf16-rounded z mask the kernel sees
+        zk = d["z"].float().cpu().double()
+        mask = torch.ones_like(zk) if act is None else ((zk > 0) & ((zk < 6) if act == "relu6" else True)).double()
+        gz = _bf(s["dz"]).double() * mask
+        (v * gz.detach()).sum().backward()
+        torch.testing.assert_close(d["dy"].float().cpu().double(), y.grad, rtol=2e-2, atol=2e-2 * y.grad.abs().max().item())
+        torch.testing.assert_close(d["dgamma"].cpu().double(), gam.grad, rtol=2e-3, atol=2e-3 * gam.grad.abs().max().item() + 1e-4)
+        torch.testing.assert_close(d["dbeta"].cpu().double(), bet.grad, rtol=2e-3, atol=2e-3 * bet.grad.abs().max().item() + 1e-4)
+        if use_res:
+            torch.testing.assert_close(d["dres"].float().cpu().double(), gz, rtol=1 / 128, atol=1e-2)
+        # moving statistics: momentum 0.99, Bessel-corrected variance (fused BN)
+        mm = s["moving_mean"].double() * 0.99 + mean.detach() * 0.01
+        mv = s["moving_var"].double() * 0.99 + var.detach() * n / (n - 1) * 0.01
+        torch.testing.assert_close(d["moving_mean"].cpu().double(), mm, rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(d["moving_var"].cpu().double(), mv, rtol=1e-5, atol=1e-5)
+
+
+def test_pool_topdown_balance_backward(cuda):
+    from retinanet import _C
+    lib = _C.lib()
+    g = torch.Generator().manual_seed(21)
+    st = _C.current_stream()
+    N, C = 2, 64
+    # max-pool 2x2 backward
+    x = _bf(torch.randn((N, 8, 8, C), generator=g))
+    dy = _bf(torch.randn((N, 4, 4, C), generator=g))
+    xd, dyd = x.to(cuda), dy.to(cuda)
+    dx = torch.empty_like(xd)
+    _C.check(lib.rn_maxpool2d_nhwc_bwd(_C.ptr(xd), _C.ptr(dyd), _C.ptr(dx), N, 8, 8, C, 2, 4, 4, 0, st))
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    F.max_pool2d(xr, 2).backward(dy.float().permute(0, 3, 1, 2))
+    torch.cuda.synchronize()
+    torch.testing.assert_close(dx.float().cpu(), xr.grad.permute(0, 2, 3, 1), rtol=0, atol=0)
+    # FPN top-down backward over 4 levels
+    L, H0 = 4, 16
+    ins = [_bf(torch.randn((N, H0 >> l, H0 >> l, C), generator=g)) for l in range(L)]
+    douts = [_bf(torch.randn((N, H0 >> l, H0 >> l, C), generator=g)) for l in range(L)]
+    leaves = [t.float().requires_grad_(True) for t in ins]
+    outs = [None] * L
+    outs[L - 1] = leaves[L - 1]
+    for l in range(L - 2, -1, -1):
+        up = F.interpolate(outs[l + 1].permute(0, 3, 1, 2), scale_factor=2, mode="nearest").permute(0, 2, 3, 1)
+        outs[l] = F.relu(leaves[l] + up)
+    sum((o * d.float()).sum() for o, d in zip(outs, douts)).backward()
+    outs_d = [o.detach().to(torch.bfloat16).to(cuda) for o in outs]
+    d_d = [d.to(cuda) for d in douts]
+    din = [torch.empty_like(t) for t in d_d]
+    for l in range(L):
+        _C.check(lib.rn_fpn_topdown_bwd_level(_C.ptr(d_d[l]), _C.ptr(din[l - 1]) if l > 0 else None,
+                                              _C.ptr(outs_d[l]) if l < L - 1 else None, _C.ptr(din[l]), N,
+                                              H0 >> l, H0 >> l, C, _C.RN_ACT_RELU if l < L - 1 else _C.RN_ACT_NONE, st))
+    torch.cuda.synchronize()
+    for l in range(L):
+        ref = leaves[l].grad
+        torch.testing.assert_close(din[l].float().cpu(), ref, rtol=2e-2, atol=2e-2 * ref.abs().max().item())
+    # BalanceFeatures backward, 5 levels, mid = 1
+    L, H0, mid = 5, 32, 1
+    ins = [_bf(torch.randn((N, H0 >> l, H0 >> l, C), generator=g)) for l in range(L)]
+    douts = [_bf(torch.randn((N, H0 >> l, H0 >> l, C), generator=g)) for l in range(L)]
+    leaves = [t.float().permute(0, 3, 1, 2).requires_grad_(True) for t in ins]
+    rs = [F.max_pool2d(leaves[0], 2), leaves[1]] + [F.interpolate(leaves[l], scale_factor=2 ** (l - 1), mode="nearest") for l in (2, 3, 4)]
+    avg = sum(rs) / 5.0
+    back = [F.interpolate(avg, scale_factor=2, mode="nearest"), avg] + [F.max_pool2d(avg, 2 ** (l - 1)) for l in (2, 3, 4)]
+    sum(((leaves[l] + back[l]) * douts[l].float().permute(0, 3, 1, 2)).sum() for l in range(L)).backward()
+    ins_d = [t.to(cuda) for t in ins]
+    d_d = [t.to(cuda) for t in douts]
+    din = [torch.empty_like(t) for t in d_d]
+    avg_d = avg.detach().permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(cuda)
+    scratch = torch.empty_like(avg_d)
+    _C.check(lib.rn_balance_features_bwd(_C.ptr_array(d_d), _C.ptr_array(ins_d), _C.ptr_array(din), _C.ptr(avg_d),
+                                         _C.ptr(scratch), L, mid, N, H0, H0, C, st))
+    torch.cuda.synchronize()
+    for l in range(L):
+        ref = leaves[l].grad.permute(0, 2, 3, 1)
+        err = (din[l].float().cpu() - ref).abs()
+        # bf16 rounding of avg can move an argmax between near-equal neighbours: bound the mean too
+        assert err.mean().item() <= 2e-2 * ref.abs().max().item(), l
+        assert (err > 5e-2 * ref.abs().max().item()).float().mean().item() < 0.02, l
+
+
+def test_optimizer_step(cuda):
+    from retinanet import _C
+    lib = _C.lib()
+    g = torch.Generator().manual_seed(5)
+    sizes = [64, 36864, 256, 70000, 8]
+    wd = [0, 1, 0, 1, 0]
+    chunk = lib.rn_optim_chunk()
+    offs, segs, block_seg, o, b = [], [], [], 0, 0
+    for i, n in enumerate(sizes):
+        nb = (n + chunk - 1) // chunk
+        segs.append((o, n, wd[i], b, nb, 0, o if wd[i] else -1))
+        block_seg += [i] * nb
+        offs.append(o)
+        o += n
+        b += nb
+    total = o
+    w = torch.randn((total,), generator=g)
+    gr = torch.randn((total,), generator=g) * torch.cat([torch.full((n,), s) for n, s in zip(sizes, [0.1, 0.2, 30.0, 0.05, 1.0])])
+    v = torch.randn((total,), generator=g) * 0.01
+    ema = w.clone() + 0.01
+    seg_np = np.zeros((len(sizes),), dtype=np.dtype([("offset", "<i8"), ("size", "<i8"), ("wd", "<i4"), ("bb", "<i4"),
+                                                     ("nb", "<i4"), ("pad", "<i4"), ("bf", "<i8")]))
+    for i, s in enumerate(segs):
+        seg_np[i] = s
+    segs_d = torch.from_numpy(seg_np.view(np.uint8)).to(cuda)
+    bs_d = torch.tensor(block_seg, dtype=torch.int32, device=cuda)
+    wdv, gd, vd, ed = w.to(cuda), gr.to(cuda), v.to(cuda), ema.to(cuda)
+    bf = torch.zeros((total,), dtype=torch.bfloat16, device=cuda)
+    metrics = torch.zeros((4,), dtype=torch.float32, device=cuda)
+    ws = _ws(lib.rn_optim_workspace_bytes(len(block_seg), len(sizes)), cuda)
+    alpha, R, clip, lr, mom, dec = 1e-4, 4, 10.0, 0.1, 0.9, 0.5
+    st = _C.current_stream()
+    _C.check(lib.rn_optim_clip(_C.ptr(gd), _C.ptr(wdv), _C.ptr(segs_d), len(sizes), _C.ptr(bs_d), len(block_seg),
+                               alpha / R, clip, _C.ptr(metrics), _C.ptr(ws), ws.numel(), st))
+    torch.cuda.synchronize()
+    # reference (executor.py:401-407 on float64)
+    gs, ws64 = gr.double(), w.double()
+    parts = []
+    for i, n in enumerate(sizes):
+        t = gs[offs[i]:offs[i] + n] + (alpha / R * ws64[offs[i]:offs[i] + n] if wd[i] else 0)
+        parts.append(t * (clip / max(t.norm().item(), clip)))
+    gn = math.sqrt(sum(t.norm().item() ** 2 for t in parts))
+    parts = [t * (clip / max(gn, clip)) for t in parts]
+    want_g = torch.cat(parts)
+    torch.testing.assert_close(gd.cpu().double(), want_g, rtol=1e-5, atol=1e-7)
+    assert metrics[1].item() == pytest.approx(gn, rel=1e-5)
+    assert metrics[0].item() == pytest.approx(min(gn, clip), rel=1e-5)
+    _C.check(lib.rn_optim_sgd_step(_C.ptr(wdv), _C.ptr(gd), _C.ptr(vd), _C.ptr(ed), _C.ptr(bf), _C.ptr(segs_d),
+                                   _C.ptr(bs_d), len(block_seg), lr, mom, dec, st))
+    torch.cuda.synchronize()
+    v2 = mom * v.double() - lr * want_g
+    w2 = w.double() + v2
+    e2 = ema.double() - (1 - dec) * (ema.double() - w2)
+    torch.testing.assert_close(vd.cpu().double(), v2, rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(wdv.cpu().double(), w2, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(ed.cpu().double(), e2, rtol=1e-5, atol=1e-6)
+    for i, n in enumerate(sizes):
+        got = bf[offs[i]:offs[i] + n].float().cpu()
+        want = w2[offs[i]:offs[i] + n].float().to(torch.bfloat16).float() if wd[i] else torch.zeros(n)
+        torch.testing.assert_close(got, want, rtol=1 / 128, atol=1e-3)
