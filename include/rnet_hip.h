@@ -197,6 +197,7 @@ typedef struct {
   const void* x;
   const void* dy;
   int32_t N, H, W, Cin, Ho, Wo, Cout;
+  int32_t dy_pix_stride; /* elements between dy pixels; 0 = Cout (dense) */
 } rn_wgrad_segment;
 
 typedef struct {
@@ -210,9 +211,13 @@ int rn_conv2d_nhwc_wgrad(const rn_wgrad_problem* problem /* host */, float* dw, 
                          size_t workspace_bytes, void* stream);
 
 /* dgrad: the data gradient of a stride-1 conv is rn_conv2d_nhwc_fwd run on dy with these weights
- * (bf16 [Cin_pad][R][S][Cout], taps flipped) and pad' = k-1-pad; stride 2 goes through
+ * (bf16 [Cin_pad][R][S][Cout_pad], taps flipped, zero rows/columns in the padding) and pad' = k-1-pad; stride 2 goes through
  * rn_upsample_zero2x first.  w_ohwi is the f32 master in compute layout [Cout][R][S][Cin]. */
-int rn_pack_conv_weight_dgrad(const float* w_ohwi, int R, int S, int Cin, int Cout, void* w_packed, void* stream);
+int rn_pack_conv_weight_dgrad(const float* w_ohwi, int R, int S, int Cin, int Cout, int Cout_pad, void* w_packed,
+                              void* stream);
+/* f32 [P,C] -> bf16 [P,Cpad], zero padded channels (dy of the 36/720-channel prediction convs is
+ * padded to a multiple of 64 so it can be the K dimension of the dgrad GEMM) */
+int rn_cast_pad_f32_to_bf16(const float* x, void* y, int64_t P, int C, int Cpad, void* stream);
 /* y[n,2h,2w,:] = x[n,h,w,:], zero elsewhere; bf16 NHWC */
 int rn_upsample_zero2x(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, void* stream);
 int rn_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);

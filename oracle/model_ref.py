@@ -19,11 +19,28 @@ import math
 import torch
 import torch.nn.functional as F
 
-_LAYERS = {50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3]}
+_LAYERS = {14: [1, 1, 1, 1], 26: [2, 2, 2, 2], 50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3]}
+
+
+class _RoundBF16(torch.autograd.Function):
+    """Round to bfloat16 in the forward AND the backward pass: what materialising an activation
+    (and, in training, its gradient) as a bf16 tensor does on the GPU path."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
 
 
 def _r(x, on):
-    return x.to(torch.bfloat16).to(torch.float32) if on else x
+    if not on:
+        return x
+    if x.requires_grad:
+        return _RoundBF16.apply(x)
+    return x.to(torch.bfloat16).to(x.dtype)
 
 
 class RefModel:
@@ -178,3 +195,116 @@ class RefModel:
             return {"class-predictions": self.head(feats, "class-head"),
                     "box-predictions": self.head(feats, "box-head"),
                     "_features": {k: v.permute(0, 2, 3, 1).contiguous() for k, v in feats.items()}}
+
+
+# ==============================================================================================
+# Training-step restatement (Executor._train_step, retinanet/executor.py:409-441) with autograd.
+class RefTrainer(RefModel):
+    """float64 CPU restatement of one training step: training-mode BatchNorm (batch statistics,
+    frozen layers in inference mode — executor.py:154-176), RetinaNetLoss
+    (losses/retinanet_loss.py:37-83), l2 weight decay on conv kernels of trainable layers
+    (executor.py:296-327), per-tensor + global clipping (executor.py:401-407), Keras SGD momentum
+    and the tfa moving average (optimizers/builder.py:45-54)."""
+
+    def __init__(self, params, variables, frozen_names=(), emulate_bf16=False):
+        super().__init__(params, variables, emulate_bf16=emulate_bf16)
+        self.v = {k: v.detach().to("cpu", torch.float64).clone() for k, v in variables.items()}
+        self.frozen = set(frozen_names)
+        self.leaf = {}
+        for k, t in self.v.items():
+            if k.endswith(("/moving_mean", "/moving_variance")) or k in self.frozen:
+                continue
+            t.requires_grad_(True)
+            self.leaf[k] = t
+        self.momentum = float(params.architecture.batch_norm.momentum)
+        self.new_stats = {}
+
+    def _conv(self, x, name, stride=1, pad=None, f32=False):
+        y = super()._conv(x, name, stride, pad, f32)
+        # training materialises the pre-BN conv output as bf16 (frozen layers fold BN: no rounding;
+        # the fp32 prediction convs stay fp32)
+        if self.bf and not f32 and (name + "/kernel") not in self.frozen:
+            y = _r(y, True)
+        return y
+
+    def _bn(self, x, name):
+        g, b = self.v[name + "/gamma"], self.v[name + "/beta"]
+        if (name + "/gamma") in self.frozen:  # layer.trainable=False -> inference mode
+            return super()._bn(x, name)
+        mean = x.mean(dim=(0, 2, 3))
+        var = x.var(dim=(0, 2, 3), unbiased=False)
+        n = x.numel() / x.shape[1]
+        self.new_stats[name + "/moving_mean"] = (self.v[name + "/moving_mean"] * self.momentum
+                                                 + mean.detach() * (1 - self.momentum))
+        self.new_stats[name + "/moving_variance"] = (self.v[name + "/moving_variance"] * self.momentum
+                                                     + var.detach() * n / (n - 1) * (1 - self.momentum))
+        xh = (x - mean[None, :, None, None]) / torch.sqrt(var + self.eps)[None, :, None, None]
+        return xh * g[None, :, None, None] + b[None, :, None, None]
+
+    def forward_train(self, images_nhwc):
+        feats = self.fpn(self.backbone(images_nhwc.to(torch.float64)))
+        if self.p.architecture.feature_fusion.use_balanced_features:
+            feats = self.balance(feats)
+        return {"class-predictions": self.head(feats, "class-head"), "box-predictions": self.head(feats, "box-head")}
+
+    def loss(self, preds, cls_t, box_t, num_pos, replicas=1):
+        lp = self.p.loss
+        K = self.p.architecture.head.num_classes
+        B = cls_t.shape[0]
+        logits = torch.cat([preds["class-predictions"][l].reshape(B, -1, K) for l in "34567"], dim=1)
+        boxes = torch.cat([preds["box-predictions"][l].reshape(B, -1, 4) for l in "34567"], dim=1)
+        ct = torch.as_tensor(cls_t, dtype=torch.float64)
+        bt = torch.as_tensor(box_t, dtype=torch.float64)
+        normalizer = float(num_pos) + 1.0
+        y = (torch.arange(K)[None, None, :] == ct.long()[..., None]).double()
+        a, gma, ls = lp.focal_loss.alpha, lp.focal_loss.gamma, lp.focal_loss.label_smoothing
+        ys = y * (1 - ls) + 0.5 * ls
+        ce = torch.clamp(logits, min=0) - logits * ys + torch.log1p(torch.exp(-logits.abs()))
+        p = torch.sigmoid(logits)
+        at = torch.where(y == 1, torch.tensor(a, dtype=torch.float64), torch.tensor(1 - a, dtype=torch.float64))
+        pt = torch.where(y == 1, p, 1 - p)
+        fl = at * (1 - pt).pow(gma) * ce * (ct != -2.0).double()[..., None]
+        class_loss = fl.sum() / normalizer
+        e = boxes - bt
+        d = lp.smooth_l1_loss.delta
+        hub = torch.where(e.abs() <= d, 0.5 * e * e, d * e.abs() - 0.5 * d * d) * (bt != 0).double()
+        box_loss = hub.sum() / 4.0 / normalizer
+        weighted = lp.box_loss_weight * box_loss + lp.class_loss_weight * class_loss
+        return {"box-loss": box_loss, "class-loss": class_loss, "weighted-loss": weighted}
+
+    def weight_decay(self):
+        alpha = self.p.training.weight_decay_alpha
+        tot = 0.0
+        for k, t in self.leaf.items():
+            if k.endswith("/kernel"):
+                tot = tot + alpha * 0.5 * (t * t).sum()   # tf.nn.l2_loss = sum(w^2)/2
+        return tot
+
+    def step(self, images, cls_t, box_t, num_pos, lr, momentum_state=None, ema_state=None, ema_decay=None,
+             replicas=1):
+        preds = self.forward_train(images)
+        losses = self.loss(preds, cls_t, box_t, num_pos, replicas)
+        total = losses["weighted-loss"]
+        if self.p.training.use_weight_decay:
+            total = total + self.weight_decay()
+        (total / replicas).backward()
+        clip = float(self.p.training.optimizer.clipnorm)
+        grads = {k: t.grad.clone() for k, t in self.leaf.items()}
+        raw = {k: g.clone() for k, g in grads.items()}
+        for k in grads:  # tf.clip_by_norm per tensor, then tf.clip_by_global_norm (executor.py:401-407)
+            grads[k] = grads[k] * (clip / max(grads[k].norm().item(), clip))
+        gn = math.sqrt(sum(g.norm().item() ** 2 for g in grads.values()))
+        for k in grads:
+            grads[k] = grads[k] * (clip / max(gn, clip))
+        mom = float(self.p.training.optimizer.momentum)
+        new_w, new_v, new_e = {}, {}, {}
+        for k, t in self.leaf.items():
+            v0 = momentum_state[k] if momentum_state else torch.zeros_like(t)
+            v1 = mom * v0 - lr * grads[k] * replicas   # all-reduce SUM over identical replicas
+            new_v[k] = v1
+            new_w[k] = t.detach() + v1
+            if ema_state is not None:
+                new_e[k] = ema_state[k] - (1 - ema_decay) * (ema_state[k] - new_w[k])
+        return {"losses": {k: float(v) for k, v in losses.items()}, "raw_grads": raw, "clipped_grads": grads,
+                "grad_norm": min(gn, clip), "weights": new_w, "momentum": new_v, "ema": new_e,
+                "moving_stats": dict(self.new_stats), "preds": preds}

@@ -159,30 +159,31 @@ extern "C" int rn_optim_sgd_step(float* params, const float* grads, float* momen
 // ---- dgrad weight transform: master f32 [Cout][R][S][Cin] -> bf16 [Cin_pad][R][S][Cout], taps
 // flipped, so the data gradient is the SAME implicit-GEMM forward kernel run on dy. ---------------
 __global__ void __launch_bounds__(256)
-pack_dgrad_kernel(const float* __restrict__ w, int R, int S, int Cin, int Cout, int Cin_pad,
+pack_dgrad_kernel(const float* __restrict__ w, int R, int S, int Cin, int Cout, int Cin_pad, int Cout_pad,
                   uint16_t* __restrict__ out) {
-  const long long total = (long long)Cin_pad * R * S * Cout;
+  const long long total = (long long)Cin_pad * R * S * Cout_pad;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
-    const int co = (int)(i % Cout);
-    long long t = i / Cout;
+    const int co = (int)(i % Cout_pad);
+    long long t = i / Cout_pad;
     const int s = (int)(t % S);
     t /= S;
     const int r = (int)(t % R);
     const int ci = (int)(t / R);
     float v = 0.0f;
-    if (ci < Cin) v = w[(((long long)co * R + (R - 1 - r)) * S + (S - 1 - s)) * Cin + ci];
+    if (ci < Cin && co < Cout) v = w[(((long long)co * R + (R - 1 - r)) * S + (S - 1 - s)) * Cin + ci];
     out[i] = rn_f32_to_bf16(v);
   }
 }
-extern "C" int rn_pack_conv_weight_dgrad(const float* w_ohwi, int R, int S, int Cin, int Cout, void* out,
-                                         void* stream) {
-  RN_CHECK_ARG(w_ohwi && out && R > 0 && S > 0 && Cin > 0 && Cout > 0, "rn_pack_conv_weight_dgrad: bad argument");
+extern "C" int rn_pack_conv_weight_dgrad(const float* w_ohwi, int R, int S, int Cin, int Cout, int Cout_pad,
+                                         void* out, void* stream) {
+  RN_CHECK_ARG(w_ohwi && out && R > 0 && S > 0 && Cin > 0 && Cout > 0 && Cout_pad >= Cout,
+               "rn_pack_conv_weight_dgrad: bad argument");
   const int Cin_pad = rn_conv_cout_pad(Cin);
-  const long long total = (long long)Cin_pad * R * S * Cout;
+  const long long total = (long long)Cin_pad * R * S * Cout_pad;
   int blocks = (int)(rn_cdiv(total, 256) < 4096 ? rn_cdiv(total, 256) : 4096);
   hipLaunchKernelGGL(pack_dgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_ohwi, R, S, Cin, Cout,
-                     Cin_pad, (uint16_t*)out);
+                     Cin_pad, Cout_pad, (uint16_t*)out);
   RN_CHECK_LAUNCH();
   return RN_OK;
 }

@@ -358,6 +358,30 @@ cast_f32_bf16_kernel(const float4* __restrict__ x, uint2* __restrict__ y, long l
     y[i] = o;
   }
 }
+__global__ void __launch_bounds__(TR_THREADS)
+cast_pad_kernel(const float* __restrict__ x, uint2* __restrict__ y, long long P, int C, int Cpad) {
+  const int q = Cpad / 4;
+  const long long total = P * q;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / q;
+    const int c = (int)(i - r * q) * 4;
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = (c + u) < C ? x[r * C + c + u] : 0.0f;
+    uint2 o;
+    o.x = rn_pack_bf16x2(v[0], v[1]);
+    o.y = rn_pack_bf16x2(v[2], v[3]);
+    y[i] = o;
+  }
+}
+extern "C" int rn_cast_pad_f32_to_bf16(const float* x, void* y, int64_t P, int C, int Cpad, void* stream) {
+  RN_CHECK_ARG(x && y && P > 0 && C > 0 && Cpad >= C && Cpad % 4 == 0, "rn_cast_pad_f32_to_bf16: bad argument");
+  hipLaunchKernelGGL(cast_pad_kernel, dim3(tr_blocks(P * (Cpad / 4))), dim3(TR_THREADS), 0, (hipStream_t)stream, x,
+                     (uint2*)y, (long long)P, C, Cpad);
+  RN_CHECK_LAUNCH();
+  return RN_OK;
+}
 extern "C" int rn_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream) {
   RN_CHECK_ARG(x && y && n > 0 && n % 4 == 0, "rn_cast_f32_to_bf16: bad argument (n %% 4 == 0)");
   hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(tr_blocks(n / 4)), dim3(TR_THREADS), 0, (hipStream_t)stream,

@@ -34,7 +34,7 @@ typedef __attribute__((address_space(3))) bf16x4_t lds_b4_t;
 struct WgSegDev {
   const uint16_t* x;
   const uint16_t* dy;
-  int N, H, W, Ho, Wo, P, chunk_begin, pad_;
+  int N, H, W, Ho, Wo, P, chunk_begin, dyS;
 };
 
 struct WgArgs {
@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wgrad_kernel(const WgArgs args)
   const int wave_m = wave >> 1, wave_n = wave & 1;
 
   const __amdgpu_buffer_rsrc_t rs_dy =
-      __builtin_amdgcn_make_buffer_rsrc((void*)sg.dy, 0, (int)((long long)sg.P * Cout * 2), 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc((void*)sg.dy, 0, (int)((long long)sg.P * sg.dyS * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_x =
       __builtin_amdgcn_make_buffer_rsrc((void*)sg.x, 0, (int)((long long)sg.N * H * W * Cin * 2), 0x00020000);
 
@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wgrad_kernel(const WgArgs args)
       const int chunk__ = d_pos ^ ((row__ & 3) << 2);                                             \
       const int p__ = (p0_) + row__;                                                              \
       const bool in__ = p__ < p_end;                                                              \
-      const unsigned va__ = in__ ? (unsigned)(((long long)p__ * Cout + co0 + chunk__ * 8) * 2) : WG_OOB; \
+      const unsigned va__ = in__ ? (unsigned)(((long long)p__ * sg.dyS + co0 + chunk__ * 8) * 2) : WG_OOB; \
       wg_dma16(rs_dy, st__ + (j * 4 + wave) * 1024, va__);                                        \
       /* p -> (n, oy, ox) with a float reciprocal + one correction (p < 2^24) */                  \
       int t2__ = (int)((float)p__ * inv_wo);                                                      \
@@ -207,7 +207,9 @@ static int wgrad_plan(const rn_wgrad_problem* p, WgArgs& a) {
     if (!s.x || !s.dy || s.Cin != a.Cin || s.Cout != a.Cout) return -1;
     const long long P = (long long)s.N * s.Ho * s.Wo;
     if (P <= 0 || P >= (1ll << 24)) return -1;
-    if ((long long)s.N * s.H * s.W * s.Cin * 2 >= (1ll << 31) || P * s.Cout * 2 >= (1ll << 31)) return -1;
+    const long long dyS = s.dy_pix_stride > 0 ? s.dy_pix_stride : s.Cout;
+    if (dyS < s.Cout || (dyS % 4)) return -1;
+    if ((long long)s.N * s.H * s.W * s.Cin * 2 >= (1ll << 31) || P * dyS * 2 >= (1ll << 31)) return -1;
     Ptot += P;
   }
   const int tiles = a.co_tiles * a.ci_tiles * a.R * a.S;
@@ -225,7 +227,7 @@ static int wgrad_plan(const rn_wgrad_problem* p, WgArgs& a) {
     d.N = s.N; d.H = s.H; d.W = s.W; d.Ho = s.Ho; d.Wo = s.Wo;
     d.P = s.N * s.Ho * s.Wo;
     d.chunk_begin = chunks;
-    d.pad_ = 0;
+    d.dyS = s.dy_pix_stride > 0 ? s.dy_pix_stride : s.Cout;
     chunks += (int)rn_cdiv(d.P, CH);
   }
   a.total_chunks = chunks;

@@ -37,7 +37,8 @@ class ConvProblem(Structure):
 
 class WgradSegment(Structure):
     _fields_ = [("x", c_void_p), ("dy", c_void_p), ("N", c_int32), ("H", c_int32), ("W", c_int32),
-                ("Cin", c_int32), ("Ho", c_int32), ("Wo", c_int32), ("Cout", c_int32)]
+                ("Cin", c_int32), ("Ho", c_int32), ("Wo", c_int32), ("Cout", c_int32),
+                ("dy_pix_stride", c_int32)]
 
 
 class WgradProblem(Structure):
@@ -96,7 +97,8 @@ _SIGNATURES = {
     "rn_pack_stem_input": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rn_wgrad_workspace_bytes": (c_size_t, [POINTER(WgradProblem)]),
     "rn_conv2d_nhwc_wgrad": (c_int, [POINTER(WgradProblem), c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
-    "rn_pack_conv_weight_dgrad": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rn_pack_conv_weight_dgrad": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rn_cast_pad_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "rn_upsample_zero2x": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rn_cast_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "rn_act_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),

@@ -1,0 +1,727 @@
+"""TrainEngine — the MI355X replacement of Executor._train_step (retinanet/executor.py:409-441).
+
+One call = forward (training-mode BatchNorm) -> RetinaNetLoss forward+backward -> backward
+through heads / BalanceFeatures / FPN / ResNet -> weight decay + per-tensor and global clipping
+-> data-parallel all-reduce (RCCL) -> SGD momentum + EMA, all as HIP launches on static buffers.
+
+There is no autograd tape: the backward pass is the closed-form gradient of every layer,
+scheduled from the same static graph as the forward pass.
+  * conv backward = wgrad (transpose-read MFMA kernel, deterministic split-K) + dgrad (the
+    forward implicit-GEMM kernel run on dy with flipped/transposed weights; stride-2 layers go
+    through a zero-insertion upsample), gradients of multi-consumer tensors are accumulated in
+    the dgrad epilogue (residual add in place);
+  * BatchNorm forward/backward are two-stage reductions; with `use_sync` and >1 rank the
+    per-group [sum, sumsq] / [sum g, sum g*xhat] vectors are all-reduced between the stages
+    (SyncBatchNormalization, model/utils.py:10-12);
+  * frozen layers (training.freeze_variables, executor.py:154-176) keep inference-mode BN folded
+    into their conv epilogue and get no backward at all;
+  * parameters, gradients, momentum and EMA live in four flat fp32 arenas (conv kernels in the
+    compute layout [Cout][R][S][Cin]); the optimizer is three multi-tensor launches and also
+    refreshes the bf16 compute copy of every kernel.
+Limitation (documented in DESIGN.md): the stem (7x7 conv + 3x3/2 max-pool) has no backward yet,
+so `resnet_initial` (or any pattern covering the stem) must be frozen — true for every shipped
+ImageNet-initialised ResNet config.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from retinanet import _C
+
+_DT = {"bf16": torch.bfloat16, "f32": torch.float32}
+_SEG_DTYPE = np.dtype([("offset", "<i8"), ("size", "<i8"), ("wd", "<i4"), ("bb", "<i4"), ("nb", "<i4"),
+                       ("pad", "<i4"), ("bf", "<i8")])
+
+
+def _hwio_to_ohwi(w):
+    return w.permute(3, 0, 1, 2).contiguous()
+
+
+def _ohwi_to_hwio(w):
+    return w.permute(1, 2, 3, 0).contiguous()
+
+
+class TrainEngine:
+    def __init__(self, model, batch_size, frozen_regexes=(), process_group=None, world_size=1):
+        self.model = model
+        self.g = model.graph
+        self.params_cfg = model.params
+        self.B = int(batch_size)
+        self.dev = model.device
+        self.lib = _C.lib()
+        self.pg = process_group
+        self.world = int(world_size)
+        bn = self.params_cfg.architecture.batch_norm
+        self.eps, self.momentum_bn = float(bn.epsilon), float(bn.momentum)
+        self.sync_bn = bool(bn.use_sync) and self.world > 1
+        self.frozen = set()
+        for k in model.variables:
+            if any(rx.search(k) for rx in frozen_regexes):
+                self.frozen.add(k)
+        self._keep = []
+        self.step_count = 0
+        with torch.cuda.device(self.dev):
+            self._analyse()
+            self._alloc_params()
+            self._alloc_tensors()
+            self._fold_frozen()
+            self._build_forward()
+            self._build_backward()
+
+    # ------------------------------------------------------------------------------------------
+    def _conv_trainable(self, op):
+        return (op["conv"] + "/kernel") not in self.frozen
+
+    def _bn_trainable(self, op):
+        return op.get("bn") and (op["bn"] + "/gamma") not in self.frozen
+
+    def _analyse(self):
+        g = self.g
+        self.requires = {"images": False}
+        for op in g.ops:
+            kind = op["op"]
+            if kind in ("conv", "stem"):
+                tr = self._conv_trainable(op) or bool(self._bn_trainable(op))
+                if kind == "stem" and tr:
+                    raise NotImplementedError("the stem has no backward yet: freeze it (e.g. 'resnet_initial')")
+                ins = [op["inp"]] + ([op["residual"]] if op.get("residual") else [])
+                self.requires[op["out"]] = tr or any(self.requires[i] for i in ins)
+            elif kind == "maxpool":
+                self.requires[op["out"]] = self.requires[op["inp"]]
+                if self.requires[op["inp"]] and op["k"] != op["stride"]:
+                    raise NotImplementedError("overlapping max-pool backward (the stem pool) is not built: "
+                                              "freeze the stem and block_group1 ('resnet_initial')")
+            elif kind == "topdown":
+                r = any(self.requires[i] for i in op["ins"])
+                for o in op["outs"]:
+                    self.requires[o] = r or self.requires.get(o, False)
+            elif kind == "balance":
+                pass
+        # a conv layer is "live" when its kernel trains; mixed frozen conv / live BN is not a shipped case
+        for op in g.ops:
+            if op["op"] == "conv" and op.get("bn") and self._conv_trainable(op) != bool(self._bn_trainable(op)):
+                raise NotImplementedError(f"{op['conv']}: conv and its BatchNorm must be frozen together")
+
+    # ---- flat parameter arenas ---------------------------------------------------------------------
+    def _alloc_params(self):
+        lib = self.lib
+        chunk = lib.rn_optim_chunk()
+        v = self.model.variables
+        names = [k for k in v if self.g.var_specs[k].get("trainable", True) and k not in self.frozen]
+        self.train_names = names
+        segs, block_seg = [], []
+        off = bf_off = nblk = 0
+        self.p_off, self.bf_off = {}, {}
+        for i, k in enumerate(names):
+            n = v[k].numel()
+            is_kernel = k.endswith("/kernel")
+            bfo = -1
+            if is_kernel:
+                cname = k[:-len("/kernel")]
+                c = self.g.convs[cname]
+                bfo = bf_off
+                self.bf_off[cname] = bf_off
+                bf_off += lib.rn_conv_cout_pad(c["cout"]) * c["k"] * c["k"] * c["cin"]
+                bf_off = (bf_off + 7) // 8 * 8
+            nb = (n + chunk - 1) // chunk
+            segs.append((off, n, 1 if is_kernel else 0, nblk, nb, 0, bfo))   # executor.py:308-327: kernels only
+            block_seg += [i] * nb
+            self.p_off[k] = (off, n)
+            off += (n + 3) // 4 * 4
+            nblk += nb
+        self.n_params = off
+        self.P = torch.zeros((off,), dtype=torch.float32, device=self.dev)
+        self.G = torch.zeros_like(self.P)
+        self.V = torch.zeros_like(self.P)
+        self.E = torch.zeros_like(self.P)
+        self.Pbf = torch.zeros((max(bf_off, 8),), dtype=torch.bfloat16, device=self.dev)
+        seg_np = np.zeros((len(segs),), dtype=_SEG_DTYPE)
+        for i, s in enumerate(segs):
+            seg_np[i] = s
+        self.segs_dev = torch.from_numpy(seg_np.view(np.uint8).copy()).to(self.dev)
+        self.block_seg_dev = torch.tensor(block_seg, dtype=torch.int32, device=self.dev)
+        self.n_blocks, self.n_segs = len(block_seg), len(segs)
+        self.opt_ws = torch.empty((lib.rn_optim_workspace_bytes(self.n_blocks, self.n_segs),), dtype=torch.uint8,
+                                  device=self.dev)
+        self.metrics = torch.zeros((4,), dtype=torch.float32, device=self.dev)
+        self.load_from_model()
+
+    def _pview(self, name, arena=None):
+        off, n = self.p_off[name]
+        return (self.P if arena is None else arena)[off:off + n]
+
+    def load_from_model(self):
+        """model.variables (HWIO kernels) -> flat arenas (OHWI) + bf16 compute copies."""
+        v = self.model.variables
+        for k in self.train_names:
+            t = v[k].to(self.dev, torch.float32)
+            if k.endswith("/kernel"):
+                t = _hwio_to_ohwi(t)
+            self._pview(k).copy_(t.reshape(-1))
+        self.E.copy_(self.P)
+        self.V.zero_()
+        for k in self.train_names:
+            if k.endswith("/kernel"):
+                cname = k[:-len("/kernel")]
+                off, n = self.p_off[k]
+                self.Pbf[self.bf_off[cname]:self.bf_off[cname] + n].copy_(self.P[off:off + n])
+
+    def store_to_model(self, use_ema=False):
+        """flat arenas -> model.variables (executor.assign_moving_averaged_weights when use_ema)."""
+        v = self.model.variables
+        src = self.E if use_ema else self.P
+        for k in self.train_names:
+            t = self._pview(k, src)
+            if k.endswith("/kernel"):
+                c = self.g.convs[k[:-len("/kernel")]]
+                t = _ohwi_to_hwio(t.reshape(c["cout"], c["k"], c["k"], c["cin"]))
+            v[k].copy_(t.reshape(v[k].shape))
+        for bn, d in self.bn_state.items():
+            v[bn + "/moving_mean"].copy_(d["mm"])
+            v[bn + "/moving_variance"].copy_(d["mv"])
+        self.model._refresh()
+
+    # ---- activations / gradients ---------------------------------------------------------------------
+    def _alloc_tensors(self):
+        B, dev = self.B, self.dev
+        self.t, self.raw, self.grad = {}, {}, {}
+        for name, (H, W, C, dt) in self.g.tensors.items():
+            self.t[name] = torch.empty((B, H, W, C), dtype=_DT[dt], device=dev)
+        H, W, _, _ = self.g.tensors["images"]
+        self.Wp = self.lib.rn_stem_padded_width(W)
+        self.stem_in = torch.empty((B, H + 6, self.Wp, 4), dtype=torch.bfloat16, device=dev)
+        for op in self.g.ops:
+            if op["op"] == "conv" and self._bn_trainable(op):
+                self.raw[op["out"]] = torch.empty_like(self.t[op["out"]])
+        # balance features runs out of place in training (its backward needs the inputs)
+        self.bal_out = {}
+        for op in self.g.ops:
+            if op["op"] == "balance":
+                for n in op["tensors"]:
+                    self.bal_out[n] = torch.empty_like(self.t[n])
+        # gradient buffers (bf16) for every tensor that needs one
+        need = set()
+        for op in self.g.ops:
+            if op["op"] == "conv" and self.requires.get(op["out"]):
+                need.add(op["out"])
+                for i in [op["inp"]] + ([op["residual"]] if op.get("residual") else []):
+                    if self.requires.get(i):
+                        need.add(i)
+            elif op["op"] in ("maxpool",) and self.requires.get(op["out"]):
+                need.update([op["out"], op["inp"]])
+            elif op["op"] == "topdown":
+                for n in op["ins"] + op["outs"]:
+                    if self.requires.get(n):
+                        need.add(n)
+        for n in need:
+            H, W, C, _ = self.g.tensors[n]
+            self.grad[n] = torch.zeros((B, H, W, C), dtype=torch.bfloat16, device=dev)
+        for n, t in self.bal_out.items():
+            self.grad["bal:" + n] = torch.zeros_like(t)
+        self.bn_state = {}
+        for op in self.g.ops:
+            if op["op"] == "conv" and self._bn_trainable(op):
+                bn = op["bn"]
+                self.bn_state[bn] = {"mm": self.model.variables[bn + "/moving_mean"].to(dev, torch.float32).clone(),
+                                     "mv": self.model.variables[bn + "/moving_variance"].to(dev, torch.float32).clone()}
+
+    def _fold_frozen(self):
+        """inference-mode scale/shift + packed weights for frozen conv(+BN) layers."""
+        lib, v = self.lib, self.model.variables
+        st = _C.current_stream()
+        self.fold, self.packed_frozen = {}, {}
+        for op in self.g.ops:
+            if op["op"] not in ("conv", "stem") or self._conv_trainable(op):
+                continue
+            cname = op["conv"]
+            c = self.g.convs[cname]
+            w = v[cname + "/kernel"].to(self.dev, torch.float32).contiguous()
+            cp = lib.rn_conv_cout_pad(c["cout"])
+            if op["op"] == "stem":
+                buf = torch.empty((cp, 7, 32), dtype=torch.bfloat16, device=self.dev)
+                _C.check(lib.rn_pack_stem_weight(_C.ptr(w), c["cout"], _C.ptr(buf), st), "rn_pack_stem_weight")
+            else:
+                buf = torch.empty((cp, c["k"], c["k"], c["cin"]), dtype=torch.bfloat16, device=self.dev)
+                _C.check(lib.rn_pack_conv_weight(_C.ptr(w), c["k"], c["k"], c["cin"], c["cout"], c["cin"],
+                                                 _C.ptr(buf), st), "rn_pack_conv_weight")
+            self.packed_frozen[cname] = buf
+            bias = v.get(cname + "/bias")
+            scale = shift = None
+            if op.get("bn"):
+                bn = op["bn"]
+                gmm, bta = v[bn + "/gamma"].to(self.dev).float(), v[bn + "/beta"].to(self.dev).float()
+                mean, var = v[bn + "/moving_mean"].to(self.dev).float(), v[bn + "/moving_variance"].to(self.dev).float()
+                scale = (gmm / torch.sqrt(var + self.eps)).contiguous()
+                shift = bta - mean * scale
+                if bias is not None:
+                    shift = shift + bias.to(self.dev).float() * scale
+                shift = shift.contiguous()
+            elif bias is not None:
+                shift = bias.to(self.dev).float().contiguous()
+            self.fold[op["out"]] = (scale, shift)
+
+    # ---- helpers to build launches ---------------------------------------------------------------------
+    def _weight_ptr(self, cname):
+        if cname in self.packed_frozen:
+            return self.packed_frozen[cname].data_ptr()
+        return self.Pbf.data_ptr() + 2 * self.bf_off[cname]
+
+    def _conv_problem(self, ops, dst_of, raw_mode):
+        """forward conv launch over `ops`; raw_mode: write pre-BN output (+bias) without activation."""
+        first = ops[0]
+        c0 = self.g.convs[first["conv"]]
+        p = _C.ConvProblem()
+        p.R = p.S = c0["k"]
+        p.stride_h = p.stride_w = c0["stride"]
+        p.pad_top = p.pad_left = first["pad"]
+        p.act = _C.RN_ACT_NONE if raw_mode else _C.ACT_IDS[first["act"]]
+        p.out_dtype = _C.RN_DT_F32 if first["out_dtype"] == "f32" else _C.RN_DT_BF16
+        p.num_segments = len(ops)
+        for i, op in enumerate(ops):
+            c = self.g.convs[op["conv"]]
+            x, y = self.t[op["inp"]] if op["inp"] not in self.bal_src else self.bal_src[op["inp"]], dst_of(op)
+            s = p.seg[i]
+            s.x, s.w, s.y = x.data_ptr(), self._weight_ptr(op["conv"]), y.data_ptr()
+            if raw_mode:
+                s.scale = None
+                s.shift = (self._pview(op["conv"] + "/bias").data_ptr() if c["bias"] else None)
+                s.residual = None
+            else:
+                if self._conv_trainable(op):      # live conv without BN (prediction convs)
+                    s.scale = None
+                    s.shift = (self._pview(op["conv"] + "/bias").data_ptr() if c["bias"] else None)
+                else:
+                    sc, sh = self.fold[op["out"]]
+                    s.scale = sc.data_ptr() if sc is not None else None
+                    s.shift = sh.data_ptr() if sh is not None else None
+                s.residual = self.t[op["residual"]].data_ptr() if op.get("residual") else None
+            s.N, s.H, s.W, s.Cin, s.pix_stride = self.B, x.shape[1], x.shape[2], c["cin"], x.shape[3]
+            s.Ho, s.Wo, s.Cout = y.shape[1], y.shape[2], c["cout"]
+        self._keep.append(p)
+        return p
+
+    def _bn_problem(self, ops):
+        p = _C.BnProblem()
+        p.num_segments = len(ops)
+        p.act = _C.ACT_IDS[ops[0]["act"]]
+        p.bessel = 0 if self.sync_bn else 1
+        p.eps, p.momentum, p.count_scale = self.eps, self.momentum_bn, float(self.world if self.sync_bn else 1)
+        csum = sum(self.g.convs[o["conv"]]["cout"] for o in ops)
+        sums = torch.zeros((2 * csum,), dtype=torch.float32, device=self.dev)
+        bsums = torch.zeros((2 * csum,), dtype=torch.float32, device=self.dev)
+        fwd = torch.zeros((4 * csum,), dtype=torch.float32, device=self.dev)
+        off = 0
+        dys = []
+        for i, op in enumerate(ops):
+            C = self.g.convs[op["conv"]]["cout"]
+            bn = op["bn"]
+            y, z = self.raw[op["out"]], self.t[op["out"]]
+            dy = torch.empty_like(y)
+            dys.append(dy)
+            s = p.seg[i]
+            s.y, s.z, s.dy = y.data_ptr(), z.data_ptr(), dy.data_ptr()
+            s.residual = self.t[op["residual"]].data_ptr() if op.get("residual") else None
+            s.dz = self.grad[op["out"]].data_ptr() if op["out"] in self.grad else None
+            s.dres = None
+            s.sums = sums.data_ptr() + 4 * 2 * off
+            s.bsums = bsums.data_ptr() + 4 * 2 * off
+            s.fwd = fwd.data_ptr() + 4 * 4 * off
+            s.gamma = self._pview(bn + "/gamma").data_ptr()
+            s.beta = self._pview(bn + "/beta").data_ptr()
+            s.moving_mean = self.bn_state[bn]["mm"].data_ptr()
+            s.moving_var = self.bn_state[bn]["mv"].data_ptr()
+            s.dgamma = self._pview(bn + "/gamma", self.G).data_ptr()
+            s.dbeta = self._pview(bn + "/beta", self.G).data_ptr()
+            s.P, s.C, s.dres_accumulate = y.shape[0] * y.shape[1] * y.shape[2], C, 0
+            off += C
+        ws = torch.empty((max(self.lib.rn_bn_workspace_bytes(ctypes.byref(p)), 256),), dtype=torch.uint8,
+                         device=self.dev)
+        self._keep += [p, sums, bsums, fwd, ws] + dys
+        return p, sums, bsums, ws, dys
+
+    # ---- forward --------------------------------------------------------------------------------------
+    def _build_forward(self):
+        lib, B = self.lib, self.B
+        self.fwd_steps = []
+        self.bn_groups = {}   # first op out -> (problem, sums, bsums, ws, dys, ops)
+        self.bal_src = {}     # tensor name -> balance output tensor (consumers read the balanced copy)
+        done = set()
+        for op in self.g.ops:
+            kind = op["op"]
+            if kind == "stem":
+                img, y = self.t["images"], self.t[op["out"]]
+                H, W = img.shape[1], img.shape[2]
+                c = self.g.convs[op["conv"]]
+                pin, pimg = self.stem_in.data_ptr(), img.data_ptr()
+                self.fwd_steps.append(lambda st, pimg=pimg, pin=pin, H=H, W=W: _C.check(
+                    lib.rn_pack_stem_input(pimg, B, H, W, pin, st), "rn_pack_stem_input"))
+                p = _C.ConvProblem()
+                p.R, p.S, p.stride_h, p.stride_w, p.pad_top, p.pad_left = 7, 1, 2, 2, 0, 0
+                p.act, p.out_dtype, p.num_segments = _C.ACT_IDS[op["act"]], _C.RN_DT_BF16, 1
+                s = p.seg[0]
+                sc, sh = self.fold[op["out"]]
+                s.x, s.w, s.y = pin, self.packed_frozen[op["conv"]].data_ptr(), y.data_ptr()
+                s.scale, s.shift, s.residual = sc.data_ptr(), sh.data_ptr(), None
+                s.N, s.H, s.W, s.Cin, s.pix_stride = B, H + 6, self.Wp, 32, 4
+                s.Ho, s.Wo, s.Cout = y.shape[1], y.shape[2], c["cout"]
+                self._keep.append(p)
+                self.fwd_steps.append(lambda st, pr=ctypes.byref(p): _C.check(lib.rn_conv2d_nhwc_fwd(pr, st), "stem"))
+            elif kind == "conv":
+                grp = op.get("group")
+                if grp is not None:
+                    if grp in done:
+                        continue
+                    done.add(grp)
+                    ops = [o for o in self.g.ops if o["op"] == "conv" and o.get("group") == grp]
+                else:
+                    ops = [op]
+                live_bn = bool(self._bn_trainable(ops[0]))
+                if any(bool(self._bn_trainable(o)) != live_bn for o in ops):
+                    raise NotImplementedError("a conv group mixes frozen and live BatchNorm")
+                if live_bn:
+                    pc = self._conv_problem(ops, lambda o: self.raw[o["out"]], raw_mode=True)
+                    pb, sums, bsums, ws, dys = self._bn_problem(ops)
+                    self.bn_groups[ops[0]["out"]] = (pb, sums, bsums, ws, dys, ops)
+                    prc, prb = ctypes.byref(pc), ctypes.byref(pb)
+
+                    def run(st, prc=prc, prb=prb, ws=ws, sums=sums):
+                        _C.check(lib.rn_conv2d_nhwc_fwd(prc, st), "conv(train)")
+                        _C.check(lib.rn_bn_stats(prb, _C.ptr(ws), ws.numel(), st), "rn_bn_stats")
+                        if self.sync_bn:
+                            import torch.distributed as dist
+                            dist.all_reduce(sums, group=self.pg)
+                        _C.check(lib.rn_bn_finalize(prb, st), "rn_bn_finalize")
+                        _C.check(lib.rn_bn_apply(prb, st), "rn_bn_apply")
+                    self.fwd_steps.append(run)
+                else:
+                    pc = self._conv_problem(ops, lambda o: self.t[o["out"]], raw_mode=False)
+                    self.fwd_steps.append(lambda st, pr=ctypes.byref(pc): _C.check(lib.rn_conv2d_nhwc_fwd(pr, st), "conv"))
+            elif kind == "maxpool":
+                x, y = self.t[op["inp"]], self.t[op["out"]]
+                args = (x.data_ptr(), y.data_ptr(), B, x.shape[1], x.shape[2], x.shape[3], op["k"], op["stride"],
+                        op["pad_top"], op["pad_left"], y.shape[1], y.shape[2])
+                self.fwd_steps.append(lambda st, a=args: _C.check(lib.rn_maxpool2d_nhwc(*a, st), "maxpool"))
+            elif kind == "topdown":
+                ins, outs = [self.t[n] for n in op["ins"]], [self.t[n] for n in op["outs"]]
+                pin, pout = _C.ptr_array(ins), _C.ptr_array(outs)
+                self._keep += [pin, pout]
+                a = (pin, pout, len(ins), B, ins[0].shape[1], ins[0].shape[2], ins[0].shape[3], _C.ACT_IDS[op["act"]])
+                self.fwd_steps.append(lambda st, a=a: _C.check(lib.rn_fpn_topdown(*a, st), "rn_fpn_topdown"))
+            elif kind == "balance":
+                ts = [self.t[n] for n in op["tensors"]]
+                outs = [self.bal_out[n] for n in op["tensors"]]
+                for n in op["tensors"]:
+                    self.bal_src[n] = self.bal_out[n]
+                pin, pout = _C.ptr_array(ts), _C.ptr_array(outs)
+                self.bal_avg = torch.empty_like(ts[op["mid"]])
+                self._keep += [pin, pout]
+                a = (pin, pout, len(ts), op["mid"], B, ts[0].shape[1], ts[0].shape[2], ts[0].shape[3],
+                     self.bal_avg.data_ptr())
+                self.fwd_steps.append(lambda st, a=a: _C.check(lib.rn_balance_features(*a, st), "rn_balance_features"))
+        # the tower convs were built before `balance` registered its outputs: rebuild is avoided by
+        # resolving inputs lazily — _conv_problem reads self.bal_src at build time, so build again
+        # for the groups that consume balanced tensors
+        if self.bal_src:
+            self._rebuild_consumers_of_balanced()
+        self.outputs = {k: {lv: self.t[n] for lv, n in d.items()} for k, d in self.g.outputs.items()}
+
+    def _rebuild_consumers_of_balanced(self):
+        # the graph lists `balance` before the heads, so bal_src was already populated when the tower
+        # groups were built (ops are visited in order); nothing to do.  Kept as an assertion.
+        order = [o["op"] for o in self.g.ops]
+        bi = order.index("balance")
+        for o in self.g.ops[:bi]:
+            if o["op"] == "conv":
+                assert o["inp"] not in self.bal_src
+
+    def _src(self, name):
+        return self.bal_src.get(name, self.t[name])
+
+    def _gradbuf(self, name):
+        return self.grad["bal:" + name] if name in self.bal_src else self.grad[name]
+
+    # ---- backward ---------------------------------------------------------------------------------------
+    def _build_backward(self):
+        lib, B = self.lib, self.B
+        self.bwd_steps = []
+        self.grad_init = {}       # tensor -> runtime flag "gradient buffer already written this step"
+        self.dgrad_packs = []     # (master offset, conv dims, packed buffer)
+        ops = self.g.ops
+        first_of_group, seen = {}, set()
+        for i, op in enumerate(ops):
+            if op["op"] == "conv" and op.get("group") and op["group"] not in seen:
+                seen.add(op["group"])
+                first_of_group[op["group"]] = i
+        plan = []
+        for i in range(len(ops) - 1, -1, -1):
+            op = ops[i]
+            if op["op"] == "conv":
+                grp = op.get("group")
+                if grp is None:
+                    plan.append(("conv", [op]))
+                elif first_of_group[grp] == i:
+                    plan.append(("conv", [o for o in ops if o["op"] == "conv" and o.get("group") == grp]))
+            elif op["op"] in ("maxpool", "topdown", "balance"):
+                plan.append((op["op"], op))
+        # which tensor gradients get more than one contribution is decided at build time
+        written = set()
+
+        def mark(name):
+            first = name not in written
+            written.add(name)
+            return first
+
+        for kind, item in plan:
+            if kind == "conv":
+                self._plan_conv_backward(item, mark)
+            elif kind == "maxpool":
+                op = item
+                if not self.requires.get(op["inp"]):
+                    continue
+                x, dy, dx = self.t[op["inp"]], self.grad[op["out"]], self.grad[op["inp"]]
+                acc = 0 if mark(op["inp"]) else 1
+                a = (x.data_ptr(), dy.data_ptr(), dx.data_ptr(), B, x.shape[1], x.shape[2], x.shape[3], op["k"],
+                     dy.shape[1], dy.shape[2], acc)
+                self.bwd_steps.append(lambda st, a=a: _C.check(lib.rn_maxpool2d_nhwc_bwd(*a, st), "maxpool_bwd"))
+            elif kind == "topdown":
+                op = item
+                L = len(op["ins"])
+                act = _C.ACT_IDS[op["act"]]
+                prev = None
+                for l in range(L):
+                    dout = self.grad[op["outs"][l]]
+                    din = self.grad[op["ins"][l]]
+                    mark(op["ins"][l])
+                    outp = self.t[op["outs"][l]].data_ptr() if l < L - 1 else None
+                    a = (dout.data_ptr(), prev, outp, din.data_ptr(), B, dout.shape[1], dout.shape[2], dout.shape[3],
+                         act if l < L - 1 else _C.RN_ACT_NONE)
+                    self.bwd_steps.append(lambda st, a=a: _C.check(lib.rn_fpn_topdown_bwd_level(*a, st), "topdown_bwd"))
+                    prev = din.data_ptr()
+            elif kind == "balance":
+                op = item
+                names = op["tensors"]
+                dout = [self.grad["bal:" + n] for n in names]
+                ins = [self.t[n] for n in names]
+                din = [self.grad[n] for n in names]
+                for n in names:
+                    mark(n)
+                scratch = torch.empty_like(self.bal_avg)
+                pd, pi, pn = _C.ptr_array(dout), _C.ptr_array(ins), _C.ptr_array(din)
+                self._keep += [pd, pi, pn, scratch]
+                a = (pd, pi, pn, self.bal_avg.data_ptr(), scratch.data_ptr(), len(names), op["mid"], B,
+                     ins[0].shape[1], ins[0].shape[2], ins[0].shape[3])
+                self.bwd_steps.append(lambda st, a=a: _C.check(lib.rn_balance_features_bwd(*a, st), "balance_bwd"))
+
+    def _plan_conv_backward(self, ops, mark):
+        lib, B = self.lib, self.B
+        if not self._conv_trainable(ops[0]) and not any(self.requires.get(o["inp"]) for o in ops):
+            return
+        if not self._conv_trainable(ops[0]):
+            raise NotImplementedError("backward through a frozen conv that sits above trainable layers")
+        live_bn = bool(self._bn_trainable(ops[0]))
+        # (a) gradient wrt the conv output
+        if live_bn:
+            pb, sums, bsums, ws, dys, _ = self.bn_groups[ops[0]["out"]]
+            for i, op in enumerate(ops):
+                s = pb.seg[i]
+                s.dz = self.grad[op["out"]].data_ptr()
+                if op.get("residual") and self.requires.get(op["residual"]):
+                    res = op["residual"]
+                    s.dres = self.grad[res].data_ptr()
+                    s.dres_accumulate = 0 if mark(res) else 1
+            prb = ctypes.byref(pb)
+
+            def run(st, prb=prb, ws=ws, bsums=bsums):
+                _C.check(lib.rn_bn_bwd_reduce(prb, _C.ptr(ws), ws.numel(), st), "rn_bn_bwd_reduce")
+                if self.sync_bn:
+                    import torch.distributed as dist
+                    dist.all_reduce(bsums, group=self.pg)
+                _C.check(lib.rn_bn_bwd_apply(prb, st), "rn_bn_bwd_apply")
+            self.bwd_steps.append(run)
+            dy_of = {op["out"]: dys[i] for i, op in enumerate(ops)}
+        else:
+            dy_of = {}
+            for op in ops:
+                if op["out_dtype"] == "f32":      # prediction convs: loss gradient arrives in fp32
+                    shp = list(self.t[op["out"]].shape)
+                    shp[3] = (shp[3] + 63) // 64 * 64     # K dimension of the dgrad GEMM: pad 36/720 -> 64/768
+                    dyb = torch.zeros(shp, dtype=torch.bfloat16, device=self.dev)
+                    dy_of[op["out"]] = dyb
+                else:
+                    dyb = torch.empty_like(self.t[op["out"]])
+                    dy_of[op["out"]] = dyb
+                    a = (self.grad[op["out"]].data_ptr(), self.t[op["out"]].data_ptr(), dyb.data_ptr(),
+                         dyb.numel(), _C.ACT_IDS[op["act"]])
+                    self.bwd_steps.append(lambda st, a=a: _C.check(lib.rn_act_bwd(*a, st), "rn_act_bwd"))
+            self._keep += list(dy_of.values())
+        self.dy_of = getattr(self, "dy_of", {})
+        self.dy_of.update(dy_of)
+        # (b) weight / bias gradients, one problem per distinct (shared) conv layer
+        by_conv = {}
+        for op in ops:
+            by_conv.setdefault(op["conv"], []).append(op)
+        for cname, cops in by_conv.items():
+            c = self.g.convs[cname]
+            p = _C.WgradProblem()
+            p.R = p.S = c["k"]
+            p.stride_h = p.stride_w = c["stride"]
+            p.pad_top = p.pad_left = cops[0]["pad"]
+            p.num_segments = len(cops)
+            for i, op in enumerate(cops):
+                x, dy = self._src(op["inp"]), dy_of[op["out"]]
+                s = p.seg[i]
+                s.x, s.dy = x.data_ptr(), dy.data_ptr()
+                s.N, s.H, s.W, s.Cin, s.Ho, s.Wo, s.Cout = B, x.shape[1], x.shape[2], c["cin"], dy.shape[1], dy.shape[2], c["cout"]
+                s.dy_pix_stride = dy.shape[3]
+            ws = torch.empty((max(lib.rn_wgrad_workspace_bytes(ctypes.byref(p)), 256),), dtype=torch.uint8,
+                             device=self.dev)
+            dw = self._pview(cname + "/kernel", self.G)
+            self._keep += [p, ws]
+            a = (ctypes.byref(p), dw.data_ptr(), 0.0, ws.data_ptr(), ws.numel())
+            self.bwd_steps.append(lambda st, a=a: _C.check(lib.rn_conv2d_nhwc_wgrad(*a, st), "rn_conv2d_nhwc_wgrad"))
+            if c["bias"]:
+                # bias gradient = column sums of dy over every segment (two-stage reduction kernel)
+                pb2 = _C.BnProblem()
+                pb2.num_segments, pb2.act, pb2.bessel, pb2.eps, pb2.momentum, pb2.count_scale = len(cops), 0, 0, 0.0, 0.0, 1.0
+                cw = dy_of[cops[0]["out"]].shape[3]    # channel width of dy (padded for prediction convs)
+                bs = torch.zeros((len(cops), 2, cw), dtype=torch.float32, device=self.dev)
+                for i, op in enumerate(cops):
+                    dy = dy_of[op["out"]]
+                    s = pb2.seg[i]
+                    s.y, s.sums = dy.data_ptr(), bs[i].data_ptr()
+                    s.P, s.C = dy.shape[0] * dy.shape[1] * dy.shape[2], cw
+                ws2 = torch.empty((max(lib.rn_bn_workspace_bytes(ctypes.byref(pb2)), 256),), dtype=torch.uint8,
+                                  device=self.dev)
+                db = self._pview(cname + "/bias", self.G)
+                self._keep += [pb2, bs, ws2]
+
+                def bias_grad(st, pr=ctypes.byref(pb2), ws2=ws2, bs=bs, db=db, n=c["cout"]):
+                    _C.check(lib.rn_bn_stats(pr, _C.ptr(ws2), ws2.numel(), st), "bias colsum")
+                    torch.sum(bs[:, 0, :n], dim=0, out=db)
+                self.bwd_steps.append(bias_grad)
+        # (c) data gradients.  Segments of one launch must write distinct gradient buffers (both
+        # heads read the same pyramid level): split the group into launches with unique inputs.
+        need = [op for op in ops if self.requires.get(op["inp"])]
+        launches = []
+        for op in need:
+            for sub in launches:
+                if all(o["inp"] != op["inp"] for o in sub):
+                    sub.append(op)
+                    break
+            else:
+                launches.append([op])
+        packs = {}
+        for sub in launches:
+            self._plan_dgrad_launch(sub, dy_of, mark, packs)
+
+    def _plan_dgrad_launch(self, need, dy_of, mark, packs):
+        lib, B = self.lib, self.B
+        c0 = self.g.convs[need[0]["conv"]]
+        k, stride = c0["k"], c0["stride"]
+        p = _C.ConvProblem()
+        p.R = p.S = k
+        p.stride_h = p.stride_w = 1
+        p.pad_top = p.pad_left = k - 1 - need[0]["pad"]
+        p.act, p.out_dtype, p.num_segments = _C.RN_ACT_NONE, _C.RN_DT_BF16, len(need)
+        ups = []
+        for i, op in enumerate(need):
+            c = self.g.convs[op["conv"]]
+            dy = dy_of[op["out"]]
+            cw = dy.shape[3]
+            if op["conv"] not in packs:
+                buf = torch.empty((lib.rn_conv_cout_pad(c["cin"]), k, k, cw), dtype=torch.bfloat16, device=self.dev)
+                packs[op["conv"]] = buf
+                off, _ = self.p_off[op["conv"] + "/kernel"]
+                self.dgrad_packs.append((self.P.data_ptr() + 4 * off, k, c["cin"], c["cout"], cw, buf))
+            x = self._src(op["inp"])
+            H, W = x.shape[1], x.shape[2]
+            if stride == 2:
+                up = torch.empty((B, H, W, cw), dtype=torch.bfloat16, device=self.dev)
+                ups.append((dy.data_ptr(), up.data_ptr(), B, dy.shape[1], dy.shape[2], cw, H, W))
+                self._keep.append(up)
+                src = up
+            elif stride == 1:
+                src = dy
+            else:
+                raise NotImplementedError("stride > 2")
+            gbuf = self._gradbuf(op["inp"])
+            first = mark(op["inp"] if op["inp"] not in self.bal_src else "bal:" + op["inp"])
+            s = p.seg[i]
+            s.x, s.w, s.y = src.data_ptr(), packs[op["conv"]].data_ptr(), gbuf.data_ptr()
+            s.scale, s.shift = None, None
+            s.residual = None if first else gbuf.data_ptr()
+            s.N, s.H, s.W, s.Cin, s.pix_stride = B, src.shape[1], src.shape[2], cw, cw
+            s.Ho, s.Wo, s.Cout = H, W, c["cin"]
+        self._keep.append(p)
+
+        def dgrad(st, pr=ctypes.byref(p), ups=ups):
+            for u in ups:
+                _C.check(lib.rn_upsample_zero2x(*u, st), "rn_upsample_zero2x")
+            _C.check(lib.rn_conv2d_nhwc_fwd(pr, st), "dgrad")
+        self.bwd_steps.append(dgrad)
+
+    # ---- one training step -----------------------------------------------------------------------------
+    def refresh_dgrad_weights(self, st):
+        lib = self.lib
+        for (mptr, k, cin, cout, cw, buf) in self.dgrad_packs:
+            _C.check(lib.rn_pack_conv_weight_dgrad(mptr, k, k, cin, cout, cw, buf.data_ptr(), st), "pack dgrad")
+
+    def forward(self, images):
+        st = _C.current_stream()
+        if images.data_ptr() != self.t["images"].data_ptr():
+            self.t["images"].copy_(images, non_blocking=True)
+        for fn in self.fwd_steps:
+            fn(st)
+        return self.outputs
+
+    def backward(self, loss_grads):
+        """loss_grads: RetinaNetLoss.grads (f32, per level) -> parameter gradients in self.G."""
+        lib, st = self.lib, _C.current_stream()
+        for key, okey in (("class-predictions", "class-predictions"), ("box-predictions", "box-predictions")):
+            for lv, name in self.g.outputs[okey].items():
+                gsrc = loss_grads[key][lv]
+                dst = self.dy_of[name]
+                C = gsrc.shape[-1]
+                _C.check(lib.rn_cast_pad_f32_to_bf16(gsrc.data_ptr(), dst.data_ptr(), gsrc.numel() // C, C,
+                                                     dst.shape[3], st), "cast")
+        self.refresh_dgrad_weights(st)
+        for fn in self.bwd_steps:
+            fn(st)
+
+    def optimizer_step(self, lr, momentum, clipnorm, wd_alpha, ema_decay):
+        lib, st = self.lib, _C.current_stream()
+        _C.check(lib.rn_optim_clip(self.G.data_ptr(), self.P.data_ptr(), self.segs_dev.data_ptr(), self.n_segs,
+                                   self.block_seg_dev.data_ptr(), self.n_blocks, wd_alpha / self.world,
+                                   clipnorm if clipnorm else 0.0, self.metrics.data_ptr(), self.opt_ws.data_ptr(),
+                                   self.opt_ws.numel(), st), "rn_optim_clip")
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.G, group=self.pg)      # executor.py:436-437: SUM over replicas after clipping
+        _C.check(lib.rn_optim_sgd_step(self.P.data_ptr(), self.G.data_ptr(), self.V.data_ptr(),
+                                       self.E.data_ptr() if ema_decay is not None else None, self.Pbf.data_ptr(),
+                                       self.segs_dev.data_ptr(), self.block_seg_dev.data_ptr(), self.n_blocks,
+                                       lr, momentum, ema_decay if ema_decay is not None else 0.0, st),
+                 "rn_optim_sgd_step")
+
+    def train_step(self, images, targets):
+        """(images f32[B,H,W,3], targets from LabelEncoder.encode_batch) -> loss dict (device scalars)."""
+        cfg = self.params_cfg.training
+        opt = self.model.optimizer
+        with torch.cuda.device(self.dev):
+            preds = self.forward(images)
+            loss = self.model.loss(targets, preds, compute_grads=True, grad_scale=1.0 / self.world)
+            self.backward(self.model.loss.grads)
+            step = self.step_count
+            self.optimizer_step(opt.lr(step), opt.momentum, opt.clipnorm,
+                                cfg.weight_decay_alpha if cfg.use_weight_decay else 0.0,
+                                opt.ema_decay(step) if opt.use_moving_average else None)
+            self.step_count += 1
+            opt.iterations = self.step_count
+        out = dict(loss)
+        out["gradient-norm"] = self.metrics[0] * self.world      # executor.py:440
+        out["num-anchors-matched"] = loss["num-anchors-matched"] / self.B   # executor.py:439
+        return out

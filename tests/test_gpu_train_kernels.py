@@ -85,7 +85,7 @@ def test_dgrad_via_forward_kernel(cuda, k, stride, cin, cout):
     want = xr.grad.permute(0, 2, 3, 1).float()
     wd = w.to(cuda).contiguous()
     wp = torch.empty((lib.rn_conv_cout_pad(cin), k, k, cout), dtype=torch.bfloat16, device=cuda)
-    _C.check(lib.rn_pack_conv_weight_dgrad(_C.ptr(wd), k, k, cin, cout, _C.ptr(wp), _C.current_stream()))
+    _C.check(lib.rn_pack_conv_weight_dgrad(_C.ptr(wd), k, k, cin, cout, cout, _C.ptr(wp), _C.current_stream()))
     dyd = dy.to(cuda).contiguous()
     if stride == 2:
         up = torch.empty((N, H, H, cout), dtype=torch.bfloat16, device=cuda)
