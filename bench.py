@@ -1,19 +1,24 @@
-"""bench.py — images/s of the RetinaNet hot path on MI355X (BASELINE.json metric).
+"""bench.py — images/s of the RetinaNet hot path on MI355X (BASELINE.json metric:
+"images/sec train+infer, ResNet50-640 RetinaNet, 1/2/4/8 MI355X").
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode infer]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N>1: launched by torch.distributed.run)
 
-N=1 workload = BASELINE config 1: ResNet50-640x640 bf16 inference, batch 8 per GPU, one step =
-images (resident in HBM) -> backbone + FPN + heads -> decode + per-class top-k + per-class NMS
--> detections.  Synthetic N(0,1) images (seed 1337), reference initialisers (seed 1337).
-Inference does not shard below an image ("replicas only"): with N>1 every rank
-runs its own batch, value = N*B*K / max-over-ranks time.
+`value` = data-parallel TRAINING throughput (the path that shards): every rank runs the per-GPU
+shard of BASELINE configs[2] — ResNet50-640x640 bf16, 32 images per GPU (global batch 256 at
+N=8), `resnet_initial` frozen, SyncBN when N>1 — and one step is
+  targets encoded on the GPU (a2-a4) -> forward with training-mode BatchNorm -> focal + Huber
+  loss forward/backward -> backward through heads / FPN / ResNet -> weight decay, per-tensor and
+  global clipping -> RCCL all-reduce of the gradient arena -> SGD momentum + EMA.
+Weak scaling: per-GPU work is fixed, value = N * 32 * K / max-over-ranks time.
 
-Extra objects on the JSON line:
-  roofline     — the dominant kernel (implicit-GEMM conv, 128x128x64 bf16 tile): algorithmic
-                 FLOPs of its launches / their HIP-event time inside the timed region, against
-                 the 2.5 PFLOP/s dense bf16 MFMA peak.
-  cpu_baseline — the CPU restatement (oracle/model_ref.py + oracle/oracle.py, PyTorch-CPU fp32,
-                 NOT TensorFlow) timed on the host cores for a bounded sample; rank 0, N=1 only.
+At N=1 the line also carries `infer`: BASELINE configs[1] (bf16 inference, batch 8, images
+resident in HBM -> backbone + FPN + heads -> decode + per-class top-k + NMS -> detections),
+which does not shard ("replicas only"), and `cpu_baseline`: the CPU restatement
+(oracle/model_ref.py, PyTorch-CPU — NOT TensorFlow) timed on the host cores.
+
+`roofline` = the dominant kernel of the timed region, conv_fwd_kernel<128,128,64,bf16> (forward
+convs and every dgrad): sum of algorithmic FLOPs of its launches / sum of their HIP-event times
+(events recorded on the launch stream inside the timed steps), against 2.5 PFLOP/s dense bf16.
 """
 import argparse
 import json
@@ -24,14 +29,27 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "retinanet-tensorflow2.x_amd"))
 
+import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def usable_cores():
+    """Host cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def conv_flops(engine, step_name):
-    """Algorithmic FLOPs (2*MACs) of one conv launch, from the static graph."""
+    """Algorithmic FLOPs (2*MACs) of one inference conv launch, from the static graph."""
     g = engine.g
     name = step_name.split(":", 1)[1]
     ops = [o for o in g.ops if o["op"] == "conv" and (o.get("group") == name or o["out"] == name)]
@@ -56,59 +74,187 @@ def is_dominant_variant(engine, step_name):
     return False
 
 
-def usable_cores():
-    """Host cores this process may really use: affinity mask capped by the cgroup CPU quota."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except Exception:
-        pass
-    return max(1, n)
+def synth_ground_truth(B, size, seed):
+    """G ~ U{1..32} boxes per image, centre U(0,size)^2, w,h = exp(U(ln 8, ln 512)),
+    clipped to the image, classes U{0..79}."""
+    rng = np.random.default_rng(seed)
+    Gmax = 32
+    gb, gc, cnt = np.zeros([B, Gmax, 4], np.float32), np.zeros([B, Gmax], np.float32), np.zeros([B], np.int32)
+    for i in range(B):
+        G = int(rng.integers(1, 33))
+        c = rng.uniform(0, size, (G, 2))
+        wh = np.exp(rng.uniform(np.log(8), np.log(512), (G, 2)))
+        x1, x2 = np.clip(c - wh / 2, 0, size), np.clip(c + wh / 2, 0, size)
+        gb[i, :G] = np.concatenate([(x1 + x2) / 2, np.maximum(x2 - x1, 1.0)], 1)
+        gc[i, :G] = rng.integers(0, 80, G)
+        cnt[i] = G
+    return torch.from_numpy(gb), torch.from_numpy(gc), torch.from_numpy(cnt)
 
 
-def cpu_baseline(params, model, sample_images=4):
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import numpy as np
-    import oracle as o
-    from model_ref import RefModel
-    size = params.input.input_shape[0]
-    torch.set_num_threads(usable_cores())
-    ref = RefModel(params, model.variables, emulate_bf16=False)
-    an = o.generate_anchors(size, size, 3, 7, params.anchor_params.areas, params.anchor_params.aspect_ratios,
-                            params.anchor_params.scales)
-    g = torch.Generator().manual_seed(1337)
-    img = torch.randn((1, size, size, 3), generator=g)
+# ------------------------------------------------------------------------------------------------
+def run_train(args, dev, rank, world):
+    from retinanet.cfg import default_params
+    from retinanet.dataloader import LabelEncoder
+    from retinanet.model import ModelBuilder
+    from retinanet.model.train_engine import TrainEngine
+    B = args.train_batch
+    params = default_params(input_size=args.size, batch_train=B * world)
+    builder = ModelBuilder(params, "train", device=dev, seed=1337)
+    model = builder()
+    rx = [builder.FREEZE_VARS_REGEX[n] for n in params.training.freeze_variables]
+    eng = TrainEngine(model, B, frozen_regexes=rx, world_size=world)
+    enc = LabelEncoder(params, device=dev)
+    gb, gc, cnt = [t.to(dev) for t in synth_ground_truth(B, args.size, 1337 + rank)]
+    images = torch.randn((B, args.size, args.size, 3), generator=torch.Generator().manual_seed(1337 + rank)).to(dev)
 
-    def one():
-        p = ref(img)
-        logits = np.concatenate([p["class-predictions"][l].numpy().reshape(1, -1, 80) for l in "34567"], 1)
-        enc = np.concatenate([p["box-predictions"][l].numpy().reshape(1, -1, 4) for l in "34567"], 1)
-        return o.postprocess(logits, enc, an, size, size)
-    one()  # warm-up (oneDNN primitive creation)
+    def step():
+        targets = enc.encode_batch(gb, gc, cnt)
+        return eng.train_step(images, targets)
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    eng.conv_profile = []
     t0 = time.perf_counter()
-    for _ in range(sample_images):
-        one()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return {"value": round(sample_images / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(),
-            "kind": "port",
-            "sample": f"{sample_images} images, batch 1, ResNet50-{size} forward + decode + top-k 5000 + "
-                      "per-class NMS; PyTorch-CPU fp32 restatement (not TensorFlow)"}
+    prof, eng.conv_profile = eng.conv_profile, None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    dom_ms = sum(a.elapsed_time(b) for a, b, _ in prof)
+    dom_flops = sum(f for _, _, f in prof)
+    res = {"dt": dt, "B": B, "loss": float(out["weighted-loss"].item()),
+           "grad_norm": float(out["gradient-norm"].item()),
+           "roofline": {"bound": "mfma", "achieved": round(dom_flops / (dom_ms * 1e-3) / 1e12, 2) if dom_ms else 0.0,
+                        "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(dom_flops / (dom_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if dom_ms else 0.0,
+                        "traffic": None, "kernel": "conv_fwd_kernel<128,128,64,bf16> (forward + dgrad launches)",
+                        "launches_per_step": len(prof) // max(args.steps, 1),
+                        "avg_launch_us": round(dom_ms * 1e3 / max(len(prof), 1), 2),
+                        "algorithmic_gflop_per_launch": round(dom_flops / max(len(prof), 1) / 1e9, 3)}}
+    return res, params, model, eng
+
+
+def run_infer(args, dev, rank):
+    from retinanet.cfg import default_params
+    from retinanet.model import ModelBuilder
+    B = args.infer_batch
+    params = default_params(input_size=args.size, inference_batch=B)
+    builder = ModelBuilder(params, "val", device=dev, seed=1337)
+    model = builder()
+    images = torch.randn((B, args.size, args.size, 3), generator=torch.Generator().manual_seed(1337 + rank)).to(dev)
+    if args.logit_std > 0:
+        # rescale the class prediction kernel so logits ~ N(-4.595, std): with the raw initialiser every
+        # score is 0.01 < 0.05 and the NMS stage would have no work (SURVEY §8(d) microbench distribution)
+        preds = model(images)
+        std = torch.cat([preds["class-predictions"][l].reshape(-1) for l in "34567"]).std().item()
+        model.variables["class-head/class-head-prediction-conv2d/kernel"].mul_(args.logit_std / max(std, 1e-12))
+        model._refresh()
+    infer = builder.add_post_processing_stage(model)
+    engine, post = model.inference_engine(B), infer.post
+    from retinanet import _C
+    dom = set(i for i, (_, n) in enumerate(engine.steps) if is_dominant_variant(engine, n))
+    dom_flops = sum(conv_flops(engine, engine.steps[i][1]) for i in dom)
+    ev = []
+
+    def step(record):
+        st = _C.current_stream()
+        for i, (fn, _) in enumerate(engine.steps):
+            if record and i in dom:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fn(st)
+                e1.record()
+                ev.append((e0, e1))
+            else:
+                fn(st)
+        return post(engine.outputs)
+    engine.t["images"].copy_(images)
+    for _ in range(args.warmup):
+        out = step(False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.infer_steps):
+        out = step(True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    dom_ms = sum(a.elapsed_time(b) for a, b in ev)
+    ach = dom_flops * args.infer_steps / (dom_ms * 1e-3) / 1e12 if dom_ms else 0.0
+    res = {"workload": f"ResNet50-{args.size}x{args.size} bf16 inference batch={B} (BASELINE configs[1]): forward + decode "
+                       "+ per-class top-k 5000 + per-class NMS; replicas only",
+           "value": round(B * args.infer_steps / dt, 2), "unit": "images/s", "ms_per_step": round(dt / args.infer_steps * 1e3, 3),
+           "steps": args.infer_steps, "valid_detections": out["valid_detections"].tolist(),
+           "data": "synthetic N(0,1) images, reference initialisers"
+                   + (f", class logits rescaled to std {args.logit_std}" if args.logit_std > 0 else ""),
+           "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(ach / PEAK_BF16_TFLOPS, 4), "kernel": "conv_fwd_kernel<128,128,64,bf16>",
+                        "launches_per_step": len(dom)}}
+    return res, params, model
+
+
+def cpu_baseline(params_train, model_train, frozen, params_infer, model_infer):
+    """Bounded sample on the host cores: one training step (batch 2) and two inference images."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as o
+    from model_ref import RefModel, RefTrainer
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    size = params_train.input.input_shape[0]
+    an = o.generate_anchors(size, size, 3, 7, params_train.anchor_params.areas, params_train.anchor_params.aspect_ratios,
+                            params_train.anchor_params.scales)
+    B = 2
+    gb, gc, cnt = synth_ground_truth(B, size, 1337)
+    enc = [o.encode_sample(an, gb[i, :cnt[i]].numpy(), gc[i, :cnt[i]].numpy()) for i in range(B)]
+    cls_t, box_t = np.stack([e[1] for e in enc]), np.stack([e[2] for e in enc])
+    npos = float(sum(e[3] for e in enc))
+    img = torch.randn((B, size, size, 3), generator=torch.Generator().manual_seed(1337))
+    tr = RefTrainer(params_train, model_train.variables, frozen_names=frozen, dtype=torch.float32)
+    t0 = time.perf_counter()
+    for i in range(B):   # the target encoding is part of the step
+        o.encode_sample(an, gb[i, :cnt[i]].numpy(), gc[i, :cnt[i]].numpy())
+    tr.step(img, cls_t, box_t, npos, 0.01)
+    dt_train = time.perf_counter() - t0
+    out = {"value": round(B / dt_train, 3), "unit": "images/s", "cores": cores, "kind": "port",
+           "sample": f"1 training step, batch {B}, ResNet50-{size}: target encode + forward + loss + autograd backward + "
+                     "clip + SGD; PyTorch-CPU fp32 restatement (oracle/model_ref.py::RefTrainer), not TensorFlow"}
+    if model_infer is not None:
+        ref = RefModel(params_infer, model_infer.variables, emulate_bf16=False)
+
+        def one():
+            p = ref(img[:1])
+            logits = np.concatenate([p["class-predictions"][l].numpy().reshape(1, -1, 80) for l in "34567"], 1)
+            encd = np.concatenate([p["box-predictions"][l].numpy().reshape(1, -1, 4) for l in "34567"], 1)
+            return o.postprocess(logits, encd, an, size, size)
+        one()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            one()
+        out["infer"] = {"value": round(2 / (time.perf_counter() - t0), 3), "unit": "images/s",
+                        "sample": "2 images, batch 1, forward + decode + top-k 5000 + per-class NMS"}
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--mode", default="infer", choices=["infer"])
-    ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--train-batch", type=int, default=32, help="images per GPU per training step (configs[2]: 256/8)")
+    ap.add_argument("--infer-batch", type=int, default=8)
+    ap.add_argument("--infer-steps", type=int, default=30)
     ap.add_argument("--size", type=int, default=640)
-    ap.add_argument("--logit-std", type=float, default=1.0,
-                    help="rescale the class prediction kernel so logits ~ N(-4.595, std): gives the "
-                         "per-class NMS a detector-like candidate load (SURVEY §8(d) microbench "
-                         "distribution); 0 keeps the raw initialiser (no candidate passes 0.05)")
+    ap.add_argument("--logit-std", type=float, default=1.0)
+    ap.add_argument("--no-infer", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -121,96 +267,39 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from retinanet.cfg import default_params
-    from retinanet.model import ModelBuilder
-    params = default_params(input_size=args.size, inference_batch=args.batch)
-    builder = ModelBuilder(params, "val", device=dev, seed=1337)
-    model = builder()
-    B = args.batch
-    gen = torch.Generator().manual_seed(1337 + rank)
-    images = torch.randn((B, args.size, args.size, 3), generator=gen).to(dev)
-    if args.logit_std > 0:
-        preds = model(images)
-        lg = torch.cat([preds["class-predictions"][l].reshape(-1) for l in "34567"])
-        std = lg.std().item()
-        k = "class-head/class-head-prediction-conv2d/kernel"
-        model.variables[k].mul_(args.logit_std / max(std, 1e-12))
-        model._refresh()
-    infer = builder.add_post_processing_stage(model)
-    engine = model.inference_engine(B)
-    post = infer.post
-
-    # events around every launch of the dominant kernel variant
-    dom = [i for i, (_, n) in enumerate(engine.steps) if is_dominant_variant(engine, n)]
-    dom_flops = sum(conv_flops(engine, engine.steps[i][1]) for i in dom)
-    ev = []
-
-    def step(record):
-        st_fns = engine.steps
-        from retinanet import _C
-        st = _C.current_stream()
-        for i, (fn, _) in enumerate(st_fns):
-            if record and i in dom_set:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                fn(st)
-                e1.record()
-                ev.append((e0, e1))
-            else:
-                fn(st)
-        return post(engine.outputs)
-    dom_set = set(dom)
-    engine.t["images"].copy_(images)
-
-    for _ in range(args.warmup):
-        out = step(False)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step(True)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
-    dom_ms = sum(a.elapsed_time(b) for a, b in ev)  # all launches, all steps
-    valid = out["valid_detections"].tolist()
-
+    train, p_train, m_train, eng = run_train(args, dev, rank, world)
+    B = train["B"]
+    line = {
+        "metric": "images/sec train, ResNet50-640 RetinaNet data-parallel step (encode + fwd + loss + bwd + clip + "
+                  "all-reduce + SGD/EMA); inference images/s under `infer`",
+        "value": round(world * B * args.steps / train["dt"], 2), "unit": "images/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(train["dt"] / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+        "data": "synthetic N(0,1) images + U{1..32} random boxes per image (seed 1337+rank), reference initialisers",
+        "config": {"workload": f"ResNet50-{args.size}x{args.size} bf16 training, {B} images/GPU (BASELINE configs[2] "
+                               f"shard: global batch {world * B}), resnet_initial frozen, "
+                               f"{'SyncBN + RCCL gradient all-reduce' if world > 1 else 'single GPU'}",
+                   "global_batch": world * B, "parallelism": f"dp{world}",
+                   "final_loss": round(train["loss"], 4), "gradient_norm": round(train["grad_norm"], 4)},
+        "roofline": train["roofline"],
+    }
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            line["roofline"]["traffic"] = json.load(open(tpath)).get("conv_fwd_128x128x64_bf16_bytes_per_launch")
+        except Exception:
+            pass
+    if world == 1 and rank == 0:
+        frozen = set(eng.frozen)
+        del eng
+        torch.cuda.empty_cache()
+        p_inf = m_inf = None
+        if not args.no_infer:
+            inf, p_inf, m_inf = run_infer(args, dev, rank)
+            line["infer"] = inf
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(p_train, m_train, frozen, p_inf, m_inf)
     if rank == 0:
-        n_launch = len(dom) * args.steps
-        achieved = (dom_flops * args.steps) / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("conv_fwd_128x128x64_bf16_bytes_per_launch")
-            except Exception:
-                traffic = None
-        line = {
-            "metric": "images/sec infer, ResNet50-640 RetinaNet (forward + decode + top-k + per-class NMS)",
-            "value": round(world * B * args.steps / dt, 2), "unit": "images/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
-            "data": "synthetic N(0,1) images seed 1337, reference initialisers seed 1337"
-                    + (f", class logits rescaled to std {args.logit_std}" if args.logit_std > 0 else ""),
-            "config": {"workload": f"ResNet50-{args.size}x{args.size} bf16 inference batch={B} per GPU "
-                                   "(BASELINE configs[1]); replicas only", "global_batch": world * B,
-                       "valid_detections_rank0": valid},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                         "kernel": "conv_fwd_kernel<128,128,64,bf16>",
-                         "launches_per_step": len(dom), "avg_launch_us": round(dom_ms * 1e3 / max(n_launch, 1), 2),
-                         "algorithmic_gflop_per_launch": round(dom_flops / max(len(dom), 1) / 1e9, 3)},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(params, model)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

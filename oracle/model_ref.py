@@ -206,9 +206,10 @@ class RefTrainer(RefModel):
     (executor.py:296-327), per-tensor + global clipping (executor.py:401-407), Keras SGD momentum
     and the tfa moving average (optimizers/builder.py:45-54)."""
 
-    def __init__(self, params, variables, frozen_names=(), emulate_bf16=False):
+    def __init__(self, params, variables, frozen_names=(), emulate_bf16=False, dtype=torch.float64):
         super().__init__(params, variables, emulate_bf16=emulate_bf16)
-        self.v = {k: v.detach().to("cpu", torch.float64).clone() for k, v in variables.items()}
+        self.dtype = dtype
+        self.v = {k: v.detach().to("cpu", dtype).clone() for k, v in variables.items()}
         self.frozen = set(frozen_names)
         self.leaf = {}
         for k, t in self.v.items():
@@ -242,7 +243,7 @@ class RefTrainer(RefModel):
         return xh * g[None, :, None, None] + b[None, :, None, None]
 
     def forward_train(self, images_nhwc):
-        feats = self.fpn(self.backbone(images_nhwc.to(torch.float64)))
+        feats = self.fpn(self.backbone(images_nhwc.to(self.dtype)))
         if self.p.architecture.feature_fusion.use_balanced_features:
             feats = self.balance(feats)
         return {"class-predictions": self.head(feats, "class-head"), "box-predictions": self.head(feats, "box-head")}
@@ -253,21 +254,21 @@ class RefTrainer(RefModel):
         B = cls_t.shape[0]
         logits = torch.cat([preds["class-predictions"][l].reshape(B, -1, K) for l in "34567"], dim=1)
         boxes = torch.cat([preds["box-predictions"][l].reshape(B, -1, 4) for l in "34567"], dim=1)
-        ct = torch.as_tensor(cls_t, dtype=torch.float64)
-        bt = torch.as_tensor(box_t, dtype=torch.float64)
+        ct = torch.as_tensor(cls_t, dtype=self.dtype)
+        bt = torch.as_tensor(box_t, dtype=self.dtype)
         normalizer = float(num_pos) + 1.0
-        y = (torch.arange(K)[None, None, :] == ct.long()[..., None]).double()
+        y = (torch.arange(K)[None, None, :] == ct.long()[..., None]).to(self.dtype)
         a, gma, ls = lp.focal_loss.alpha, lp.focal_loss.gamma, lp.focal_loss.label_smoothing
         ys = y * (1 - ls) + 0.5 * ls
         ce = torch.clamp(logits, min=0) - logits * ys + torch.log1p(torch.exp(-logits.abs()))
         p = torch.sigmoid(logits)
-        at = torch.where(y == 1, torch.tensor(a, dtype=torch.float64), torch.tensor(1 - a, dtype=torch.float64))
+        at = torch.where(y == 1, torch.tensor(a, dtype=self.dtype), torch.tensor(1 - a, dtype=self.dtype))
         pt = torch.where(y == 1, p, 1 - p)
-        fl = at * (1 - pt).pow(gma) * ce * (ct != -2.0).double()[..., None]
+        fl = at * (1 - pt).pow(gma) * ce * (ct != -2.0).to(self.dtype)[..., None]
         class_loss = fl.sum() / normalizer
         e = boxes - bt
         d = lp.smooth_l1_loss.delta
-        hub = torch.where(e.abs() <= d, 0.5 * e * e, d * e.abs() - 0.5 * d * d) * (bt != 0).double()
+        hub = torch.where(e.abs() <= d, 0.5 * e * e, d * e.abs() - 0.5 * d * d) * (bt != 0).to(self.dtype)
         box_loss = hub.sum() / 4.0 / normalizer
         weighted = lp.box_loss_weight * box_loss + lp.class_loss_weight * class_loss
         return {"box-loss": box_loss, "class-loss": class_loss, "weighted-loss": weighted}
@@ -305,6 +306,6 @@ class RefTrainer(RefModel):
             new_w[k] = t.detach() + v1
             if ema_state is not None:
                 new_e[k] = ema_state[k] - (1 - ema_decay) * (ema_state[k] - new_w[k])
-        return {"losses": {k: float(v) for k, v in losses.items()}, "raw_grads": raw, "clipped_grads": grads,
+        return {"losses": {k: float(v.detach()) for k, v in losses.items()}, "raw_grads": raw, "clipped_grads": grads,
                 "grad_norm": min(gn, clip), "weights": new_w, "momentum": new_v, "ema": new_e,
                 "moving_stats": dict(self.new_stats), "preds": preds}

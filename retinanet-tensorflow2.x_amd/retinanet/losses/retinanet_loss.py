@@ -50,12 +50,9 @@ class RetinaNetLoss:
         B = cls_t.shape[0]
         K = self._num_classes
         # normaliser = all_reduce_sum(sum(num-positives) + 1) / replicas  (retinanet_loss.py:38-49)
-        normalizer = (targets["num-positives"].sum() + 1.0).reshape(1).to(torch.float32)
+        from retinanet.distribute import global_normalizer
         R = self._num_replicas()
-        if R > 1:
-            import torch.distributed as dist
-            dist.all_reduce(normalizer, group=self._pg)
-            normalizer = normalizer / R
+        normalizer = global_normalizer(targets["num-positives"].sum(), R, self._pg)
         offs = [0]
         cl, bl = [], []
         for lv in levels:

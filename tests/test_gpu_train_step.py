@@ -127,7 +127,7 @@ def test_train_step_losses_and_optimizer_arithmetic(cuda):
     rl = ref.loss(ref.forward_train(images), targets["_flat"]["class-targets"].cpu().numpy(),
                   targets["_flat"]["box-targets"].cpu().numpy(), float(targets["num-positives"].sum().item()))
     for k in ("box-loss", "class-loss", "weighted-loss"):
-        assert loss[k].item() == pytest.approx(float(rl[k]), rel=0.03), k
+        assert loss[k].item() == pytest.approx(float(rl[k].detach()), rel=0.03), k
     # float64 replay of the optimizer on the engine's raw gradients
     parts, norms = {}, []
     for k in eng.train_names:

@@ -1,0 +1,81 @@
+"""CPU: host-side logic that needs no GPU — config attr-dict, graph/variable inventory against the
+reference's counts, freeze regexes, LR schedules, optimizer config."""
+import json
+import re
+
+import pytest
+
+import oracle as o
+
+
+def test_attrdict_and_config(tmp_path):
+    from retinanet.cfg import AttrDict, Config, default_params
+    p = default_params()
+    f = tmp_path / "c.json"
+    f.write_text(json.dumps(p.to_dict()))
+    q = Config(str(f)).params
+    assert q.input.input_shape == [640, 640] and q.architecture.head.num_classes == 80
+    assert q.training.optimizer.lr_params.schedule_type == "cosine_decay"
+    q.inference.mode = "PerClassSoftNMS"
+    assert q["inference"]["mode"] == "PerClassSoftNMS"
+    assert isinstance(q.anchor_params, AttrDict) and q.anchor_params.scales[0] == 1
+    with pytest.raises(AttributeError):
+        _ = q.nonexistent
+
+
+def test_graph_matches_reference_inventory():
+    from retinanet.cfg import default_params
+    from retinanet.model.builder import ModelBuilder
+    from retinanet.model.graph import build_retinanet_graph, init_variables
+    g = build_retinanet_graph(default_params())
+    v = init_variables(g)
+    tr = [k for k in v if g.var_specs[k].get("trainable", True)]
+    assert len(tr) == 295 and sum(v[k].numel() for k in tr) == 34389556
+    assert len(g.bns) == 102
+    rx = ModelBuilder.FREEZE_VARS_REGEX["resnet_initial"]
+    fr = [k for k in tr if rx.search(k)]
+    assert len(fr) == 33 and sum(v[k].numel() for k in fr) == 225344
+    assert "conv2d_10/kernel" in fr and "conv2d_11/kernel" not in fr and not any(k.startswith("fpn") for k in fr)
+    head = ModelBuilder.FREEZE_VARS_REGEX["head"]
+    assert head.search("box-head/box-head-0-conv2d/kernel") and not head.search("box-head/box-head-prediction-conv2d/kernel")
+    # initialisers
+    assert float(v["class-head/class-head-prediction-conv2d/bias"][0]) == pytest.approx(-4.59511985, rel=1e-6)
+    assert float(v["box-head/box-head-prediction-conv2d/bias"].abs().max()) == 0.0
+    zero_gammas = [k for k, b in g.bns.items() if b["gamma_zero"]]
+    assert len(zero_gammas) == 16 and all(float(v[k + "/gamma"].abs().max()) == 0.0 for k in zero_gammas)
+    assert abs(float(v["box-head/box-head-0-conv2d/kernel"].std()) - 0.01) < 5e-4
+    # feature map sizes and the output dict of model/builder.py:94-106
+    assert g.tensors["g4b2_out"][:3] == (20, 20, 2048) and g.tensors["fpn_out7"][:3] == (5, 5, 256)
+    assert g.tensors[g.outputs["class-predictions"]["3"]] == (80, 80, 720, "f32")
+    assert g.tensors[g.outputs["box-predictions"]["7"]] == (5, 5, 36, "f32")
+
+
+def test_unsupported_configs_fail_loudly():
+    from retinanet.cfg import default_params
+    from retinanet.model.graph import build_retinanet_graph
+    p = default_params()
+    p.architecture.backbone.type = "efficientnet-b3"
+    with pytest.raises(NotImplementedError):
+        build_retinanet_graph(p)
+    p = default_params()
+    p.architecture.feature_fusion.type = "bifpn"
+    with pytest.raises(ValueError):
+        build_retinanet_graph(p)
+
+
+def test_lr_schedules_match_oracle():
+    from retinanet.cfg import default_params
+    from retinanet.optimizers import build_optimizer
+    p = default_params()
+    opt = build_optimizer(p.training.optimizer, p.training.train_steps, p.floatx.precision)
+    for s in (0, 1, 200, 499, 500, 501, 8000, 16374, 16375, 16874):
+        assert opt.lr(s) == pytest.approx(o.cosine_decay_with_warmup(s, 0.32, 0.008, 500, 16875, 1e-4), rel=1e-12)
+    assert opt.lr(500) == pytest.approx(0.31926448651596, rel=1e-12)   # hand-derived, SURVEY 8(c)
+    assert opt.momentum == 0.9 and opt.clipnorm == 10.0 and opt.use_moving_average
+    assert opt.ema_decay(0) == pytest.approx(0.1) and opt.ema_decay(10 ** 6) == 0.9998   # min(d, (1+t)/(10+t))
+    p.training.optimizer.lr_params = {"schedule_type": "piecewise_constant_decay", "warmup_learning_rate": 0.0067,
+                                      "warmup_steps": 500, "boundaries": [1000, 2000], "values": [0.08, 0.008, 0.0008]}
+    opt = build_optimizer(p.training.optimizer, 3000, "mixed_bfloat16")
+    for s in (0, 250, 499, 500, 998, 999, 1000, 1998, 1999, 2000, 2999):
+        assert opt.lr(s) == pytest.approx(o.piecewise_constant_with_warmup(s, 0.0067, 500, [1000, 2000], [0.08, 0.008, 0.0008]))
+    assert opt.lr(999) == 0.08 and opt.lr(1000) == 0.008     # boundaries shifted by -1 (piecewise...py:8-9)
