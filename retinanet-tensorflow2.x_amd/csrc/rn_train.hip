@@ -124,20 +124,35 @@ __global__ void __launch_bounds__(TR_THREADS) bn_colreduce_kernel(const BnArgs a
   }
 }
 
-// stage 2 of the column reductions: out[which][c] = sum over chunks (double, index order)
-__global__ void bn_colreduce_final_kernel(const BnArgs a) {
+// stage 2 of the column reductions: out[which][c] = sum over chunks.  32 channels x 8 chunk lanes
+// per workgroup: lane j adds chunks j, j+8, ... in order (double), the 8 lane sums are then added
+// in lane order — a fixed association, so the result is deterministic.
+__global__ void __launch_bounds__(256) bn_colreduce_final_kernel(const BnArgs a) {
   const BnSegDev& s = a.seg[blockIdx.y];
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= s.C) return;
+  __shared__ double red[2][8][33];
+  const int cl = threadIdx.x & 31, lane = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   double t0 = 0.0, t1 = 0.0;
-  const float* p = a.ws + a.ws_off[blockIdx.y];
-  for (int k = 0; k < s.chunks; ++k) {
-    t0 += (double)p[((long long)k * 2 + 0) * s.C + c];
-    t1 += (double)p[((long long)k * 2 + 1) * s.C + c];
+  if (c < s.C) {
+    const float* p = a.ws + a.ws_off[blockIdx.y];
+    for (int k = lane; k < s.chunks; k += 8) {
+      t0 += (double)p[((long long)k * 2 + 0) * s.C + c];
+      t1 += (double)p[((long long)k * 2 + 1) * s.C + c];
+    }
   }
-  float* out = a.mode == 0 ? s.sums : s.bsums;
-  out[c] = (float)t0;
-  out[s.C + c] = (float)t1;
+  red[0][lane][cl] = t0;
+  red[1][lane][cl] = t1;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int which = threadIdx.x >> 5;
+    const int cc = blockIdx.x * 32 + cl;
+    if (cc < s.C) {
+      double t = 0.0;
+      for (int j = 0; j < 8; ++j) t += red[which][j][cl];
+      float* out = a.mode == 0 ? s.sums : s.bsums;
+      out[which * s.C + cc] = (float)t;
+    }
+  }
 }
 
 // forward finalize: sums (local or all-reduced) -> mean, invstd, scale, shift; moving stats
@@ -162,21 +177,31 @@ __global__ void bn_finalize_kernel(const BnArgs a) {
   }
 }
 
-// z = act(y*scale + shift + residual)
+// z = act(y*scale + shift + residual).  The grid-stride is rounded to a multiple of C/8 so a
+// thread keeps ONE 8-channel group for all its rows and holds that group's scale/shift in registers.
 __global__ void __launch_bounds__(TR_THREADS) bn_apply_kernel(const BnArgs a) {
   const BnSegDev& s = a.seg[blockIdx.y];
   const int C8 = s.C >> 3;
   const long long total = s.P * C8;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int c8 = (int)(i % C8);
+  const long long nthreads = (long long)gridDim.x * blockDim.x;
+  const long long lanes = nthreads / C8 * C8;
+  const long long gtid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (gtid >= lanes) return;
+  const int c8 = (int)(gtid % C8);
+  float sc[8], sh[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    sc[q] = s.fwd[2 * s.C + c8 * 8 + q];
+    sh[q] = s.fwd[3 * s.C + c8 * 8 + q];
+  }
+  for (long long i = gtid; i < total; i += lanes) {
     const bf8 y = unpack8(s.y[i]);
     bf8 o;
     bf8 res;
     if (s.residual) res = unpack8(s.residual[i]);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      float v = y.v[q] * s.fwd[2 * s.C + c8 * 8 + q] + s.fwd[3 * s.C + c8 * 8 + q];
+      float v = y.v[q] * sc[q] + sh[q];
       if (s.residual) v += res.v[q];
       o.v[q] = rn_apply_act(v, a.act);
     }
@@ -184,7 +209,8 @@ __global__ void __launch_bounds__(TR_THREADS) bn_apply_kernel(const BnArgs a) {
   }
 }
 
-// dy = scale*(g - sum_g/n - xhat*sum_gxhat/n); dres (+)= g; block 0 also writes dgamma/dbeta
+// dy = scale*(g - sum_g/n - xhat*sum_gxhat/n); dres (+)= g; block 0 also writes dgamma/dbeta.
+// Same fixed-channel-group threading as bn_apply_kernel: 5 per-channel parameters in registers.
 __global__ void __launch_bounds__(TR_THREADS) bn_bwd_apply_kernel(const BnArgs a) {
   const BnSegDev& s = a.seg[blockIdx.y];
   const int C8 = s.C >> 3;
@@ -196,9 +222,22 @@ __global__ void __launch_bounds__(TR_THREADS) bn_bwd_apply_kernel(const BnArgs a
       if (s.dgamma) s.dgamma[c] = s.bsums[s.C + c];
     }
   }
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int c8 = (int)(i % C8);
+  const long long nthreads = (long long)gridDim.x * blockDim.x;
+  const long long lanes = nthreads / C8 * C8;
+  const long long gtid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (gtid >= lanes) return;
+  const int c8 = (int)(gtid % C8);
+  float mean[8], istd[8], sc[8], k1[8], k2[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int c = c8 * 8 + q;
+    mean[q] = s.fwd[0 * s.C + c];
+    istd[q] = s.fwd[1 * s.C + c];
+    sc[q] = s.fwd[2 * s.C + c];
+    k1[q] = s.bsums[c] * inv_n;
+    k2[q] = s.bsums[s.C + c] * inv_n;
+  }
+  for (long long i = gtid; i < total; i += lanes) {
     const bf8 y = unpack8(s.y[i]);
     const bf8 dz = unpack8(s.dz[i]);
     bf8 z;
@@ -206,10 +245,9 @@ __global__ void __launch_bounds__(TR_THREADS) bn_bwd_apply_kernel(const BnArgs a
     bf8 g, o;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const int c = c8 * 8 + q;
       g.v[q] = a.act != RN_ACT_NONE ? dz.v[q] * act_mask(z.v[q], a.act) : dz.v[q];
-      const float xh = (y.v[q] - s.fwd[0 * s.C + c]) * s.fwd[1 * s.C + c];
-      o.v[q] = s.fwd[2 * s.C + c] * (g.v[q] - s.bsums[c] * inv_n - xh * (s.bsums[s.C + c] * inv_n));
+      const float xh = (y.v[q] - mean[q]) * istd[q];
+      o.v[q] = sc[q] * (g.v[q] - k1[q] - xh * k2[q]);
     }
     s.dy[i] = pack8(o);
     if (s.dres) {
@@ -276,7 +314,7 @@ static int bn_colreduce(const rn_bn_problem* p, int mode, void* ws, size_t ws_by
   }
   hipLaunchKernelGGL(bn_colreduce_kernel, dim3(max_chunks, max_slabs, a.nseg), dim3(TR_THREADS), 0, st, a);
   RN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bn_colreduce_final_kernel, dim3((max_c + 255) / 256, a.nseg), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(bn_colreduce_final_kernel, dim3((max_c + 31) / 32, a.nseg), dim3(256), 0, st, a);
   RN_CHECK_LAUNCH();
   return RN_OK;
 }
