@@ -131,8 +131,9 @@ def run_train(args, dev, rank, world):
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
-    dom_ms = sum(a.elapsed_time(b) for a, b, _ in prof)
-    dom_flops = sum(f for _, _, f in prof)
+    dom_ms = sum(r[0].elapsed_time(r[1]) for r in prof)
+    dom_flops = sum(r[2] for r in prof)
+    dom_bytes = sum(r[3] for r in prof)
     res = {"dt": dt, "B": B, "loss": float(out["weighted-loss"].item()),
            "grad_norm": float(out["gradient-norm"].item()),
            "roofline": {"bound": "mfma", "achieved": round(dom_flops / (dom_ms * 1e-3) / 1e12, 2) if dom_ms else 0.0,
@@ -141,7 +142,8 @@ def run_train(args, dev, rank, world):
                         "traffic": None, "kernel": "conv_fwd_kernel<128,128,64,bf16> (forward + dgrad launches)",
                         "launches_per_step": len(prof) // max(args.steps, 1),
                         "avg_launch_us": round(dom_ms * 1e3 / max(len(prof), 1), 2),
-                        "algorithmic_gflop_per_launch": round(dom_flops / max(len(prof), 1) / 1e9, 3)}}
+                        "algorithmic_gflop_per_launch": round(dom_flops / max(len(prof), 1) / 1e9, 3),
+                        "algorithmic_bytes_per_launch": int(dom_bytes / max(len(prof), 1))}}
     return res, params, model, eng
 
 

@@ -71,17 +71,24 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wav
 
 // ABL: ablation mask for tools/bench_conv.py (0 in production): 1 = B tile loaded once,
 // 2 = A tile loaded once, 4 = no MFMA.
-template <int BM, int BN, int BK, bool OUT_F32, int ABL = 0>
-__global__ void __launch_bounds__(CONV_THREADS, 2) conv_fwd_kernel(const ConvArgs args) {
+// WM x WN wavefronts (64 x (BN/WN) wave tiles), STAGES LDS stages.  Two shapes are built:
+//   128 x {128,64} x {64,32}, 2x2 waves, 2 stages (64 KB LDS, 2 workgroups/CU)  — small / narrow layers
+//   256 x 128 x 64, 4x2 waves, 3 stages (144 KB LDS, 1 workgroup/CU, DMA two K-steps ahead with a
+//   counted vmcnt and a raw s_barrier so the loads of step t+1 stay in flight across the barrier)
+template <int BM, int BN, int BK, bool OUT_F32, int ABL = 0, int WM = 2, int WN = 2, int STAGES = 2>
+__global__ void __launch_bounds__(64 * WM * WN, 2) conv_fwd_kernel(const ConvArgs args) {
+  constexpr int NWAVES = WM * WN;
+  constexpr int NTHREADS = 64 * NWAVES;
   constexpr int SLOTS = BK / 8;
-  constexpr int RPI = 64 / SLOTS;              // rows per wave DMA instruction (1 KiB)
-  constexpr int A_INSTR = BM / RPI / 4;        // DMA instructions per wave for the A tile
-  constexpr int B_INSTR = BN / RPI / 4;
-  constexpr int WTM = BM / 2, WTN = BN / 2;    // wave tile
+  constexpr int RPI = 64 / SLOTS;                   // rows per wave DMA instruction (1 KiB)
+  constexpr int A_INSTR = BM / RPI / NWAVES;        // DMA instructions per wave for the A tile
+  constexpr int B_INSTR = BN / RPI / NWAVES;
+  constexpr int WTM = BM / WM, WTN = BN / WN;       // wave tile
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int KSUB = BK / 16;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
   constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+  static_assert(A_INSTR >= 1 && B_INSTR >= 1, "tile too small for the wave count");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -106,7 +113,7 @@ __global__ void __launch_bounds__(CONV_THREADS, 2) conv_fwd_kernel(const ConvArg
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wave_m = wave >> 1, wave_n = wave & 1;
+  const int wave_m = wave / WN, wave_n = wave % WN;
 
   const int R = args.R, S = args.S;
   const int H = sg.H, W = sg.W, Cin = sg.Cin, PS = sg.pix_stride;
@@ -124,7 +131,7 @@ __global__ void __launch_bounds__(CONV_THREADS, 2) conv_fwd_kernel(const ConvArg
   unsigned a_mask[A_INSTR];
 #pragma unroll
   for (int j = 0; j < A_INSTR; ++j) {
-    const int row = (j * 4 + wave) * RPI + d_row;
+    const int row = (j * NWAVES + wave) * RPI + d_row;
     const int chunk = d_pos ^ lds_swz<BK>(row);
     const int m = m0 + row;
     const int mm = m < M ? m : 0;
@@ -147,7 +154,7 @@ __global__ void __launch_bounds__(CONV_THREADS, 2) conv_fwd_kernel(const ConvArg
   unsigned b_off[B_INSTR];
 #pragma unroll
   for (int j = 0; j < B_INSTR; ++j) {
-    const int row = (j * 4 + wave) * RPI + d_row;
+    const int row = (j * NWAVES + wave) * RPI + d_row;
     const int chunk = d_pos ^ lds_swz<BK>(row);
     b_off[j] = (unsigned)(((long long)(n0 + row) * Ktot + chunk * 8) * 2);
   }
@@ -184,52 +191,122 @@ __global__ void __launch_bounds__(CONV_THREADS, 2) conv_fwd_kernel(const ConvArg
     if (!(ABL & 2) || ((tap_) == 0 && (c0_) == 0)) {                                          \
       _Pragma("unroll") for (int j = 0; j < A_INSTR; ++j) {                                   \
         const unsigned v__ = ((a_mask[j] >> (tap_)) & 1u) ? a_off[j] + tap_off__ : RN_OOB;    \
-        dma16(rs_x, st__ + (j * 4 + wave) * 1024, v__);                                       \
+        dma16(rs_x, st__ + (j * NWAVES + wave) * 1024, v__);                                       \
       }                                                                                       \
     }                                                                                         \
     const unsigned koff__ = (unsigned)(((long long)(tap_) * Cin + (c0_)) * 2);                \
     if (!(ABL & 1) || ((tap_) == 0 && (c0_) == 0)) {                                          \
       _Pragma("unroll") for (int j = 0; j < B_INSTR; ++j)                                     \
-        dma16(rs_w, st__ + A_BYTES + (j * 4 + wave) * 1024, b_off[j] + koff__);               \
+        dma16(rs_w, st__ + A_BYTES + (j * NWAVES + wave) * 1024, b_off[j] + koff__);               \
     }                                                                                         \
   } while (0)
 
-  int tap = 0, c0 = 0;
-  RN_ISSUE_TILE(0, 0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  int cur = 0;
-#pragma unroll 1
-  for (int kt = 0; kt < ksteps; ++kt) {
-    c0 += BK;
-    if (c0 >= Cin) {
-      c0 = 0;
-      ++tap;
-    }
-    if (kt + 1 < ksteps) RN_ISSUE_TILE(cur ^ 1, tap, c0);
+  int tap = 0, c0 = 0;   // coordinates of the NEXT tile to issue
+#define RN_ADVANCE()  \
+  do {                \
+    c0 += BK;         \
+    if (c0 >= Cin) {  \
+      c0 = 0;         \
+      ++tap;          \
+    }                 \
+  } while (0)
 
-    const char* base = smem + cur * STAGE_BYTES;
-#pragma unroll
-    for (int kk = 0; kk < KSUB; ++kk) {
-      bf16x8_t fa[TM], fb[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = *(const bf16x8_t*)(base + rd_a[i][kk]);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) fb[j] = *(const bf16x8_t*)(base + rd_b[j][kk]);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          if (!(ABL & 4)) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-          } else {
-            acc[i][j][0] += (float)fa[i][0] + (float)fb[j][0];
-          }
-    }
+  if (STAGES == 2) {
+    RN_ISSUE_TILE(0, 0, 0);
+    RN_ADVANCE();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    cur ^= 1;
+    int cur = 0;
+#pragma unroll 1
+    for (int kt = 0; kt < ksteps; ++kt) {
+      if (kt + 1 < ksteps) {
+        RN_ISSUE_TILE(cur ^ 1, tap, c0);
+        RN_ADVANCE();
+      }
+      const char* base = smem + cur * STAGE_BYTES;
+#pragma unroll
+      for (int kk = 0; kk < KSUB; ++kk) {
+        bf16x8_t fa[TM], fb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = *(const bf16x8_t*)(base + rd_a[i][kk]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[j] = *(const bf16x8_t*)(base + rd_b[j][kk]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            if (!(ABL & 4)) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            } else {
+              acc[i][j][0] += (float)fa[i][0] + (float)fb[j][0];
+            }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      cur ^= 1;
+    }
+  } else {
+    // ---- 3-stage ring + register double buffering -------------------------------------------------
+    // step t:  wait for every outstanding DMA (tiles <= t+1; tile t+1 had a whole step to land),
+    //          barrier, issue the DMA of tile t+2 into the stage step t-1 consumed, then issue ALL
+    //          16 ds_read_b128 of tile t+1 into the spare fragment registers and run the 16 MFMAs of
+    //          tile t from the other set.  LDS latency and the DMA both hide under the MFMAs; the
+    //          2-stage kernel above keeps only 4 LDS reads in flight per wave and is LDS-latency bound.
+    bf16x8_t fa0[TM][KSUB], fb0[TN][KSUB], fa1[TM][KSUB], fb1[TN][KSUB];
+#define RN_LOAD_FRAGS(FA, FB, stage_)                                                     \
+  do {                                                                                    \
+    const char* b__ = smem + (stage_) * STAGE_BYTES;                                      \
+    _Pragma("unroll") for (int kk = 0; kk < KSUB; ++kk) {                                 \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i) FA[i][kk] = *(const bf16x8_t*)(b__ + rd_a[i][kk]); \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) FB[j][kk] = *(const bf16x8_t*)(b__ + rd_b[j][kk]); \
+    }                                                                                     \
+  } while (0)
+#define RN_MFMA_FRAGS(FA, FB)                                                             \
+  do {                                                                                    \
+    _Pragma("unroll") for (int kk = 0; kk < KSUB; ++kk)                                   \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                      \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                    \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[i][kk], FB[j][kk], acc[i][j], 0, 0, 0); \
+  } while (0)
+#define RN_STEP(FA_CUR, FB_CUR, FA_NXT, FB_NXT)                                           \
+  do {                                                                                    \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                      \
+    __builtin_amdgcn_s_barrier();                                                         \
+    asm volatile("" ::: "memory");                                                        \
+    if (kt + 2 < ksteps) {                                                                \
+      RN_ISSUE_TILE(st2, tap, c0);                                                        \
+      RN_ADVANCE();                                                                       \
+    }                                                                                     \
+    if (kt + 1 < ksteps) RN_LOAD_FRAGS(FA_NXT, FB_NXT, st1);                              \
+    RN_MFMA_FRAGS(FA_CUR, FB_CUR);                                                        \
+    st1 = st1 == STAGES - 1 ? 0 : st1 + 1;                                                \
+    st2 = st2 == STAGES - 1 ? 0 : st2 + 1;                                                \
+    ++kt;                                                                                 \
+  } while (0)
+
+    RN_ISSUE_TILE(0, 0, 0);
+    RN_ADVANCE();
+    if (ksteps > 1) {
+      RN_ISSUE_TILE(1, tap, c0);
+      RN_ADVANCE();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    RN_LOAD_FRAGS(fa0, fb0, 0);
+    int st1 = 1, st2 = 2, kt = 0;
+#pragma unroll 1
+    while (kt < ksteps) {
+      RN_STEP(fa0, fb0, fa1, fb1);
+      if (kt < ksteps) RN_STEP(fa1, fb1, fa0, fb0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+#undef RN_STEP
+#undef RN_MFMA_FRAGS
+#undef RN_LOAD_FRAGS
   }
+#undef RN_ADVANCE
 #undef RN_ISSUE_TILE
 
   // ---- epilogue ------------------------------------------------------------------------------
@@ -257,7 +334,7 @@ __global__ void __launch_bounds__(CONV_THREADS, 2) conv_fwd_kernel(const ConvArg
   __syncthreads();
   // stage 2: row-contiguous read back, residual, activation, store
   constexpr int TPR = BN / 4;                 // threads per row (4 channels each)
-  constexpr int ROWS = CONV_THREADS / TPR;    // rows per pass
+  constexpr int ROWS = NTHREADS / TPR;        // rows per pass
   const int er = tid / TPR, ec = (tid % TPR) * 4;
   const int n = n0 + ec;
   if (n < Cout) {
@@ -293,20 +370,23 @@ __global__ void __launch_bounds__(CONV_THREADS, 2) conv_fwd_kernel(const ConvArg
 // ---- host side ---------------------------------------------------------------------------------
 extern "C" int rn_conv_cout_pad(int Cout) { return Cout <= 64 ? 64 : (int)rn_align_up((size_t)Cout, 128); }
 
-template <int BM, int BN, int BK, bool F32>
+template <int BM, int BN, int BK, bool F32, int WM = 2, int WN = 2, int STAGES = 2>
 static int launch_conv(const ConvArgs& a, hipStream_t st) {
   constexpr int stage = (BM + BN) * BK * 2;
   constexpr int epi = BM * BN * 4;
-  constexpr int lds = (2 * stage > epi) ? 2 * stage : epi;
-  auto kern = conv_fwd_kernel<BM, BN, BK, F32>;
+  constexpr int lds = (STAGES * stage > epi) ? STAGES * stage : epi;
+  auto kern = conv_fwd_kernel<BM, BN, BK, F32, 0, WM, WN, STAGES>;
   if (lds > 48 * 1024)
     RN_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  hipLaunchKernelGGL(kern, dim3(a.total_tiles), dim3(CONV_THREADS), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3(a.total_tiles), dim3(64 * WM * WN), lds, st, a);
   RN_CHECK_LAUNCH();
   return RN_OK;
 }
 
 static int g_conv_ablate = 0;
+static int g_conv_force_small = 0, g_conv_force_big = 0;
+// internal: 1 = always the 128-row kernel, 2 = always the 256-row kernel (A/B timing in tools/)
+extern "C" void rn_debug_conv_tile(int mode) { g_conv_force_small = mode == 1; g_conv_force_big = mode == 2; }
 // internal (not in rnet_hip.h): select an ablated kernel for tools/bench_conv.py
 extern "C" void rn_debug_conv_ablate(int mask) { g_conv_ablate = mask; }
 
@@ -333,6 +413,12 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
   const int cout_pad0 = rn_conv_cout_pad(p->seg[0].Cout);
   const int BN = cout_pad0 <= 64 ? 64 : 128;
   const int BK = (p->seg[0].Cin % 64 == 0) ? 64 : 32;
+  // The 256x128x64 three-stage kernel (8 waves, DMA + fragment registers double buffered) is built and
+  // tested but NOT selected by default: measured on MI355X it ties the 128x128 two-stage kernel to
+  // within 1 % on the large layers (tower conv B=32: 899 vs 889 us) and loses on mid-size ones
+  // (g2 3x3: 123 vs 106 us), i.e. the limiter is not the staging depth.
+  const bool big = g_conv_force_big && BN == 128 && BK == 64 && !g_conv_force_small;
+  const int BM = (big && BN == 128 && BK == 64) ? 256 : 128;
   int tiles = 0;
   for (int i = 0; i < p->num_segments; ++i) {
     const rn_conv_segment& s = p->seg[i];
@@ -360,12 +446,12 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
     d.tile_begin = tiles;
     d.n_tiles = cp / BN;
     d.pad_ = 0;
-    tiles += (int)rn_cdiv(M, 128) * d.n_tiles;
+    tiles += (int)rn_cdiv(M, BM) * d.n_tiles;
   }
   a.total_tiles = tiles;
   hipStream_t st = (hipStream_t)stream;
   const bool f32 = p->out_dtype == RN_DT_F32;
-  if (g_conv_ablate && BN == 128 && BK == 64 && !f32) {
+  if (g_conv_ablate && BM == 128 && BN == 128 && BK == 64 && !f32) {
     switch (g_conv_ablate) {
       case 1: return launch_ablate<1>(a, st);
       case 2: return launch_ablate<2>(a, st);
@@ -377,6 +463,8 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
       default: break;
     }
   }
+  if (BM == 256)
+    return f32 ? launch_conv<256, 128, 64, true, 4, 2, 3>(a, st) : launch_conv<256, 128, 64, false, 4, 2, 3>(a, st);
   if (BN == 128 && BK == 64) return f32 ? launch_conv<128, 128, 64, true>(a, st) : launch_conv<128, 128, 64, false>(a, st);
   if (BN == 64 && BK == 64) return f32 ? launch_conv<128, 64, 64, true>(a, st) : launch_conv<128, 64, 64, false>(a, st);
   if (BN == 128 && BK == 32) return f32 ? launch_conv<128, 128, 32, true>(a, st) : launch_conv<128, 128, 32, false>(a, st);

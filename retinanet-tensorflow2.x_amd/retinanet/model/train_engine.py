@@ -267,26 +267,31 @@ class TrainEngine:
 
     # ---- helpers to build launches ---------------------------------------------------------------------
     def _conv_meta(self, p):
-        """(algorithmic FLOPs, uses the 128x128x64 bf16-out kernel variant) of a ConvProblem."""
-        flops, dom = 0, True
+        """(algorithmic FLOPs, algorithmic HBM bytes, uses the 128x128x64 bf16-out variant) of a launch.
+        Bytes = every input pixel read once + every output written once (+ residual read) + weights."""
+        flops, byts, dom = 0, 0, True
+        osz = 4 if p.out_dtype == _C.RN_DT_F32 else 2
         for i in range(p.num_segments):
             s = p.seg[i]
             flops += 2 * s.N * s.Ho * s.Wo * p.R * p.S * s.Cin * s.Cout
+            byts += 2 * s.N * s.H * s.W * s.pix_stride + osz * s.N * s.Ho * s.Wo * s.Cout + 2 * p.R * p.S * s.Cin * s.Cout
+            if s.residual:
+                byts += 2 * s.N * s.Ho * s.Wo * s.Cout
             dom = dom and s.Cout > 64 and s.Cin % 64 == 0 and p.out_dtype == _C.RN_DT_BF16
-        return flops, dom
+        return flops, byts, dom
 
     def _launch_conv(self, p, st, what):
         """All implicit-GEMM launches (forward and dgrad) go through here so bench.py can bracket the
         dominant kernel variant with HIP events on the launch stream."""
         prof = self.conv_profile
         if prof is not None:
-            flops, dom = self._conv_meta(p)
+            flops, byts, dom = self._conv_meta(p)
             if dom:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 _C.check(self.lib.rn_conv2d_nhwc_fwd(ctypes.byref(p), st), what)
                 e1.record()
-                prof.append((e0, e1, flops))
+                prof.append((e0, e1, flops, byts))
                 return
         _C.check(self.lib.rn_conv2d_nhwc_fwd(ctypes.byref(p), st), what)
 

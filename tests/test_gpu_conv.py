@@ -111,6 +111,20 @@ def test_conv_single(cuda, case):
     _close(got, _conv_ref(s, k, stride, pad, act, out_f32), out_f32)
 
 
+@pytest.mark.parametrize("case", [c for c in CASES if c[4] > 64 and c[3] % 64 == 0],
+                         ids=lambda c: "big-" + "x".join(str(v) for v in c))
+def test_conv_big_tile_kernel(cuda, case):
+    """Same cases through the 256x128x64 three-stage kernel (normally picked only for large M)."""
+    from retinanet import _C
+    lib = _C.lib()
+    lib.rn_debug_conv_tile(2)
+    try:
+        test_conv_single(cuda, case)
+        test_conv_grouped_pyramid(cuda)
+    finally:
+        lib.rn_debug_conv_tile(0)
+
+
 def test_conv_asymmetric_weights_detect_transposes(cuda):
     """A=I style check with an asymmetric filter: channel c of the output must be input channel
     (c+1)%C shifted by one pixel — catches row/col or r/s swaps that random data would blur."""

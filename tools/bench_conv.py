@@ -32,10 +32,13 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--ablate", type=int, default=0)
+    ap.add_argument("--tile", type=int, default=0, help="1 = force 128-row kernel, 2 = force 256-row kernel")
     a = ap.parse_args()
     lib = _C.lib()
     if a.ablate:
         lib.rn_debug_conv_ablate(a.ablate)
+    if a.tile:
+        lib.rn_debug_conv_tile(a.tile)
     dev = torch.device("cuda:0")
     for name in a.preset.split(","):
         segs, k, stride, f32, use_res = PRESETS[name]
