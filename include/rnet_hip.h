@@ -138,8 +138,13 @@ int rn_detect_per_class(const float* const* class_logits, const int64_t* level_o
 size_t rn_nms_workspace_bytes(int B, int n, int K, int max_det);
 int rn_nms_per_class(const float* cand_scores, const float* cand_boxes, int B, int n, int K,
                      float iou_threshold, float score_threshold, float soft_nms_sigma, int max_det,
-                     float* det_boxes, float* det_scores, int32_t* det_classes, int32_t* valid,
-                     void* workspace, size_t workspace_bytes, void* stream);
+                     float* det_boxes, float* det_scores, int32_t* det_classes,
+                     int32_t* det_index /* i32[B,max_det] candidate row of each detection, or NULL */,
+                     int32_t* valid, void* workspace, size_t workspace_bytes, void* stream);
+
+/* a15  GenerateDetections._global_nms helper (postprocessing_ops.py:248-261): per row of
+ * scores f32[rows,K] the maximum and the FIRST argmax (tf.reduce_max / tf.argmax). */
+int rn_rowmax_argmax(const float* scores, int64_t rows, int K, float* max_out, int32_t* argmax_out, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * K1/K2 (a5,a6,a8)  tf.keras.layers.Conv2D as used by resnet.py:118-144, fpn_base.py:44-50,

@@ -431,12 +431,14 @@ struct NmsParams {
 
 __global__ void __launch_bounds__(RN_PP_THREADS)
 nms_per_class_kernel(NmsParams p, const int* __restrict__ counts, const unsigned long long* __restrict__ keys_g,
-                     BoxSrc bs, float* __restrict__ sel_scores, float4* __restrict__ sel_boxes) {
+                     BoxSrc bs, float* __restrict__ sel_scores, float4* __restrict__ sel_boxes,
+                     int* __restrict__ sel_idx) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned long long* skeys = (unsigned long long*)smem;                       // RN_SORT_CAP * 8
   float4* s_selbox = (float4*)(smem + (size_t)RN_SORT_CAP * 8);                // RN_MAX_DET * 16
   float* s_selscore = (float*)((char*)s_selbox + (size_t)RN_MAX_DET * 16);     // RN_MAX_DET * 4
-  int* s_hist = (int*)((char*)s_selscore + (size_t)RN_MAX_DET * 4);            // 256 * 4
+  int* s_selidx = (int*)((char*)s_selscore + (size_t)RN_MAX_DET * 4);          // RN_MAX_DET * 4
+  int* s_hist = (int*)((char*)s_selidx + (size_t)RN_MAX_DET * 4);              // 256 * 4
   unsigned long long* s_prefix = (unsigned long long*)((char*)s_hist + 1024);  // 8
   int* s_misc = (int*)((char*)s_prefix + 8);                                   // [0]=k scratch [1]=fill [2]=nsel
   float* s_cur = (float*)((char*)s_misc + 16);                                 // soft: RN_SORT_CAP * 4
@@ -499,6 +501,7 @@ nms_per_class_kernel(NmsParams p, const int* __restrict__ counts, const unsigned
             if (lane == j) {
               s_selbox[nsel] = box;
               s_selscore[nsel] = score;
+              s_selidx[nsel] = (int)idx;
             }
             ++nsel;
             const unsigned long long kill = __ballot((mask >> j) & 1ull);
@@ -556,6 +559,7 @@ nms_per_class_kernel(NmsParams p, const int* __restrict__ counts, const unsigned
             if (score == best) {
               s_selbox[nsel] = box;
               s_selscore[nsel] = score;
+              s_selidx[nsel] = (int)idx;
               s_cur[besti] = -1.0f;  // popped for good
             } else {
               s_cur[besti] = score > p.score_thr ? score : -1.0f;
@@ -579,14 +583,15 @@ nms_per_class_kernel(NmsParams p, const int* __restrict__ counts, const unsigned
     const bool ok = t < nsel;
     sel_scores[(long long)list * p.max_det + t] = ok ? s_selscore[t] : 0.0f;
     sel_boxes[(long long)list * p.max_det + t] = ok ? s_selbox[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+    sel_idx[(long long)list * p.max_det + t] = ok ? s_selidx[t] : 0;
   }
 }
 
 // ---- merge: top max_det over K*max_det padded class results (postprocessing_ops.py:471-490)
 __global__ void __launch_bounds__(RN_PP_THREADS)
 merge_kernel(int K, int max_det, const float* __restrict__ sel_scores, const float4* __restrict__ sel_boxes,
-             float4* __restrict__ det_boxes, float* __restrict__ det_scores, int* __restrict__ det_classes,
-             int* __restrict__ valid_out) {
+             const int* __restrict__ sel_idx, float4* __restrict__ det_boxes, float* __restrict__ det_scores,
+             int* __restrict__ det_classes, int* __restrict__ det_index, int* __restrict__ valid_out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned long long* skeys = (unsigned long long*)smem;               // RN_MAX_DET * 8
   int* s_hist = (int*)(smem + (size_t)RN_MAX_DET * 8);                 // 1024
@@ -614,6 +619,7 @@ merge_kernel(int K, int max_det, const float* __restrict__ sel_scores, const flo
     det_classes[(long long)b * max_det + t] = ok ? (int)(flat / (unsigned int)max_det) : -1;
     det_boxes[(long long)b * max_det + t] =
         ok ? sel_boxes[(long long)b * total + flat] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (det_index) det_index[(long long)b * max_det + t] = ok ? sel_idx[(long long)b * total + flat] : -1;
   }
   if (threadIdx.x == 0) valid_out[b] = valid;
 }
@@ -654,9 +660,35 @@ topk_emit_kernel(int K, int k_out, const int* __restrict__ counts, const unsigne
   }
 }
 
+// ---- max / argmax over classes per row (global NMS modes, postprocessing_ops.py:248-261) ---------
+__global__ void __launch_bounds__(RN_PP_THREADS)
+rowmax_kernel(const float* __restrict__ scores, long long rows, int K, float* __restrict__ mx, int* __restrict__ arg) {
+  for (long long r = blockIdx.x * (long long)blockDim.x + threadIdx.x; r < rows;
+       r += (long long)gridDim.x * blockDim.x) {
+    const float* p = scores + r * K;
+    float best = p[0];
+    int bi = 0;
+    for (int k = 1; k < K; ++k)
+      if (p[k] > best) {  // tf.argmax / reduce_max: first maximum
+        best = p[k];
+        bi = k;
+      }
+    mx[r] = best;
+    arg[r] = bi;
+  }
+}
+extern "C" int rn_rowmax_argmax(const float* scores, int64_t rows, int K, float* max_out, int32_t* argmax_out,
+                                void* stream) {
+  RN_CHECK_ARG(scores && max_out && argmax_out && rows > 0 && K > 0, "rn_rowmax_argmax: bad argument");
+  hipLaunchKernelGGL(rowmax_kernel, dim3(pp_blocks(rows)), dim3(RN_PP_THREADS), 0, (hipStream_t)stream, scores,
+                     (long long)rows, K, max_out, argmax_out);
+  RN_CHECK_LAUNCH();
+  return RN_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 static size_t nms_lds_bytes(int soft) {
-  size_t s = (size_t)RN_SORT_CAP * 8 + (size_t)RN_MAX_DET * 16 + (size_t)RN_MAX_DET * 4 + 1024 + 8 + 16;
+  size_t s = (size_t)RN_SORT_CAP * 8 + (size_t)RN_MAX_DET * 16 + (size_t)RN_MAX_DET * 8 + 1024 + 8 + 16;
   if (soft) s += (size_t)RN_SORT_CAP * 4 + (size_t)RN_SORT_CAP * 2;
   return rn_align_up(s, 16);
 }
@@ -666,6 +698,7 @@ struct DetectWs {
   unsigned long long* keys;
   float* sel_scores;
   float4* sel_boxes;
+  int* sel_idx;
   size_t total;
 };
 
@@ -681,6 +714,8 @@ static DetectWs detect_ws_layout(void* base, int B, long long cap, int K, int ma
   off += rn_align_up((size_t)B * K * max_det * 4, 256);
   w.sel_boxes = (float4*)(p + off);
   off += rn_align_up((size_t)B * K * max_det * 16, 256);
+  w.sel_idx = (int*)(p + off);
+  off += rn_align_up((size_t)B * K * max_det * 4, 256);
   w.total = off;
   return w;
 }
@@ -699,8 +734,8 @@ extern "C" size_t rn_topk_workspace_bytes(int B, int64_t A, int K) {
 
 static int run_nms_stage(const DetectWs& w, int B, long long cap, int K, const BoxSrc& bs, int top_k,
                          float iou_threshold, float score_threshold, float soft_nms_sigma, int max_det,
-                         float* det_boxes, float* det_scores, int32_t* det_classes, int32_t* valid,
-                         hipStream_t st) {
+                         float* det_boxes, float* det_scores, int32_t* det_classes, int32_t* det_index,
+                         int32_t* valid, hipStream_t st) {
   NmsParams p;
   p.B = B; p.K = K; p.max_det = max_det; p.top_k = top_k;
   p.soft = soft_nms_sigma > 0.0f ? 1 : 0;
@@ -714,11 +749,11 @@ static int run_nms_stage(const DetectWs& w, int B, long long cap, int K, const B
   RN_CHECK_HIP(hipFuncSetAttribute((const void*)nms_per_class_kernel,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(nms_per_class_kernel, dim3(B * K), dim3(RN_PP_THREADS), lds, st, p, w.counts, w.keys, bs,
-                     w.sel_scores, w.sel_boxes);
+                     w.sel_scores, w.sel_boxes, w.sel_idx);
   RN_CHECK_LAUNCH();
   const size_t lds_m = (size_t)RN_MAX_DET * 8 + 1024 + 8 + 16;
   hipLaunchKernelGGL(merge_kernel, dim3(B), dim3(RN_PP_THREADS), lds_m, st, K, max_det, w.sel_scores,
-                     w.sel_boxes, (float4*)det_boxes, det_scores, det_classes, valid);
+                     w.sel_boxes, w.sel_idx, (float4*)det_boxes, det_scores, det_classes, det_index, valid);
   RN_CHECK_LAUNCH();
   return RN_OK;
 }
@@ -776,13 +811,13 @@ extern "C" int rn_detect_per_class(const float* const* class_logits, const int64
   bs.base = (const float4*)boxes;
   bs.img_stride = A; bs.idx_stride = 1; bs.cls_stride = 0;
   return run_nms_stage(w, B, A, K, bs, pre_nms_top_k, iou_threshold, score_threshold, soft_nms_sigma, max_det,
-                       det_boxes, det_scores, det_classes, valid, st);
+                       det_boxes, det_scores, det_classes, nullptr, valid, st);
 }
 
 extern "C" int rn_nms_per_class(const float* cand_scores, const float* cand_boxes, int B, int n, int K,
                                 float iou_threshold, float score_threshold, float soft_nms_sigma, int max_det,
-                                float* det_boxes, float* det_scores, int32_t* det_classes, int32_t* valid,
-                                void* workspace, size_t workspace_bytes, void* stream) {
+                                float* det_boxes, float* det_scores, int32_t* det_classes, int32_t* det_index,
+                                int32_t* valid, void* workspace, size_t workspace_bytes, void* stream) {
   RN_CHECK_ARG(cand_scores && cand_boxes && det_boxes && det_scores && det_classes && valid,
                "rn_nms_per_class: null argument");
   int rc = check_nms_args("rn_nms_per_class", B, n, K, 0, soft_nms_sigma, max_det);
@@ -802,7 +837,7 @@ extern "C" int rn_nms_per_class(const float* cand_scores, const float* cand_boxe
   bs.base = (const float4*)cand_boxes;
   bs.img_stride = (long long)n * K; bs.idx_stride = K; bs.cls_stride = 1;
   return run_nms_stage(w, B, n, K, bs, 0, iou_threshold, score_threshold, soft_nms_sigma, max_det, det_boxes,
-                       det_scores, det_classes, valid, st);
+                       det_scores, det_classes, det_index, valid, st);
 }
 
 extern "C" int rn_topk_per_class(const float* scores, int B, int64_t A, int K, int top_k, float* topk_scores,

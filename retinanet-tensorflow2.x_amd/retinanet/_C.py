@@ -88,7 +88,8 @@ _SIGNATURES = {
                                     c_size_t, c_void_p]),
     "rn_nms_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "rn_nms_per_class": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_float, c_int,
-                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rn_rowmax_argmax": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "rn_conv2d_nhwc_fwd": (c_int, [POINTER(ConvProblem), c_void_p]),
     "rn_conv_cout_pad": (c_int, [c_int]),
     "rn_pack_conv_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

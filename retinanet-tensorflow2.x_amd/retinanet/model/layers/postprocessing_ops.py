@@ -91,15 +91,37 @@ class FilterTopKDetections:
     descending score, ties by ascending anchor index."""
 
     def __init__(self, top_k=100, filter_per_class=True, **kwargs):
-        if not filter_per_class:
-            raise NotImplementedError("filter_per_class=false is unused by every shipped config")
         self.top_k = top_k
+        self.filter_per_class = filter_per_class
         self._ws = None
+
+    def _filter_global(self, scores, boxes):
+        """postprocessing_ops.py:149-161: top-k over the flattened (anchor, class) scores; an anchor
+        appears once per class that made the cut (the reference gathers rows by `index // K`)."""
+        lib = _C.lib()
+        B, A, K = scores.shape
+        k = min(self.top_k, A * K)
+        flat = scores.reshape(B, A * K, 1)
+        out_s = torch.empty((B, k, 1), dtype=torch.float32, device=scores.device)
+        out_i = torch.empty((B, k, 1), dtype=torch.int32, device=scores.device)
+        need = lib.rn_topk_workspace_bytes(B, A * K, 1)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty((need,), dtype=torch.uint8, device=scores.device)
+        with torch.cuda.device(scores.device):
+            _C.check(lib.rn_topk_per_class(_C.ptr(flat), B, A * K, 1, k, _C.ptr(out_s), _C.ptr(out_i),
+                                           _C.ptr(self._ws), self._ws.numel(), _C.current_stream()),
+                     "rn_topk_per_class")
+        anchor = (out_i[:, :, 0].long() // K)
+        bi = torch.arange(B, device=scores.device)[:, None]
+        return {"scores": scores[bi, anchor].contiguous(), "boxes": boxes[bi, anchor].contiguous(),
+                "indices": out_i[:, :, 0]}
 
     def __call__(self, predictions):
         lib = _C.lib()
         scores = predictions["scores"].float().contiguous()
         boxes = predictions["boxes"].float().contiguous()
+        if not self.filter_per_class:
+            return self._filter_global(scores, boxes)
         B, A, K = scores.shape
         k = min(self.top_k, A)
         out_s = torch.empty((B, k, K), dtype=torch.float32, device=scores.device)
@@ -117,47 +139,88 @@ class FilterTopKDetections:
 
 
 class GenerateDetections:
-    """postprocessing_ops.py:176-561, per-class modes (the ones shipped configs select)."""
+    """postprocessing_ops.py:176-561.  PerClassHardNMS / PerClassSoftNMS (the modes every shipped
+    config selects), GlobalHardNMS / GlobalSoftNMS (:244-286) and CombinedNMS (:219-242).
+
+    `strict_reference=True` reproduces the reference's GlobalHardNMS quirk off-TPU: it passes
+    iou_threshold = 1.0 when sigma is 0 (:253, inverted with respect to :448), so nothing is ever
+    suppressed; the default applies the configured threshold."""
     _SUPPORTED_NMS_MODES = _SUPPORTED_NMS_MODES
 
     def __init__(self, iou_threshold=0.5, score_threshold=0.05, max_detections=100, soft_nms_sigma=None,
-                 num_classes=None, mode="CombinedNMS", **kwargs):
+                 num_classes=None, mode="CombinedNMS", strict_reference=False, **kwargs):
         if mode not in _SUPPORTED_NMS_MODES:
             raise AssertionError("Requested unsupported mode: {}, available modes are: {}".format(
                 mode, _SUPPORTED_NMS_MODES))
-        if mode not in ("PerClassHardNMS", "PerClassSoftNMS"):
-            raise NotImplementedError(f"NMS mode {mode} is not selected by any shipped config (SURVEY a15)")
         self.iou_threshold = float(iou_threshold)
         self.score_threshold = float(score_threshold)
         self.max_detections = int(max_detections)
         self.soft_nms_sigma = float(soft_nms_sigma or 0.0)
         self.num_classes = num_classes
         self.mode = mode
+        self.strict_reference = bool(strict_reference)
         self._ws = None
+        self._ws2 = None
 
     @property
     def sigma(self):
-        return self.soft_nms_sigma if self.mode == "PerClassSoftNMS" else 0.0
+        return self.soft_nms_sigma if self.mode in ("PerClassSoftNMS", "GlobalSoftNMS") else 0.0
 
-    def __call__(self, predictions):
+    def _run(self, scores, boxes, iou_thr, sigma, want_index=False):
         lib = _C.lib()
-        scores = predictions["scores"].float().contiguous()
-        boxes = predictions["boxes"].float().contiguous()
         B, n, K = scores.shape
-        if boxes.dim() == 3:
-            boxes = boxes[:, :, None, :].expand(B, n, K, 4).contiguous()
         dev = scores.device
         md = self.max_detections
         out = _alloc_detections(B, md, dev)
+        idx = torch.empty((B, md), dtype=torch.int32, device=dev) if want_index else None
         need = lib.rn_nms_workspace_bytes(B, n, K, md)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty((need,), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
-            _C.check(lib.rn_nms_per_class(_C.ptr(scores), _C.ptr(boxes), B, n, K, self.iou_threshold,
-                                          self.score_threshold, self.sigma, md, _C.ptr(out["boxes"]),
-                                          _C.ptr(out["scores"]), _C.ptr(out["classes"]),
-                                          _C.ptr(out["valid_detections"]), _C.ptr(self._ws), self._ws.numel(),
-                                          _C.current_stream()), "rn_nms_per_class")
+            _C.check(lib.rn_nms_per_class(_C.ptr(scores), _C.ptr(boxes), B, n, K, iou_thr, self.score_threshold,
+                                          sigma, md, _C.ptr(out["boxes"]), _C.ptr(out["scores"]),
+                                          _C.ptr(out["classes"]), _C.ptr(idx), _C.ptr(out["valid_detections"]),
+                                          _C.ptr(self._ws), self._ws.numel(), _C.current_stream()),
+                     "rn_nms_per_class")
+        return out, idx
+
+    def _global(self, scores, boxes):
+        lib = _C.lib()
+        if boxes.dim() != 3:
+            raise ValueError("Global NMS modes take class-agnostic boxes [B,n,4] "
+                             "(inference.filter_per_class must be false when pre_nms_top_k > 0)")
+        B, n, K = scores.shape
+        mx = torch.empty((B, n, 1), dtype=torch.float32, device=scores.device)
+        arg = torch.empty((B, n), dtype=torch.int32, device=scores.device)
+        with torch.cuda.device(scores.device):
+            _C.check(lib.rn_rowmax_argmax(_C.ptr(scores), B * n, K, _C.ptr(mx), _C.ptr(arg), _C.current_stream()),
+                     "rn_rowmax_argmax")
+        sigma = self.sigma
+        iou = self.iou_threshold
+        if not sigma and self.strict_reference:
+            iou = 1.0   # postprocessing_ops.py:253
+        out, idx = self._run(mx, boxes.reshape(B, n, 1, 4).contiguous(), iou, sigma, want_index=True)
+        cls = torch.gather(arg, 1, idx.clamp(min=0).long()).to(torch.int32)
+        out["classes"] = torch.where(idx >= 0, cls, torch.full_like(cls, -1))
+        return out
+
+    def __call__(self, predictions):
+        scores = predictions["scores"].float().contiguous()
+        boxes = predictions["boxes"].float().contiguous()
+        if self.mode in ("GlobalHardNMS", "GlobalSoftNMS"):
+            return self._global(scores, boxes)
+        B, n, K = scores.shape
+        if boxes.dim() == 3:
+            boxes = boxes[:, :, None, :].expand(B, n, K, 4).contiguous()
+        if self.mode == "CombinedNMS":
+            # tf.image.combined_non_max_suppression: per-class hard NMS (<= max_detections per class),
+            # best max_detections overall, boxes clipped, ZERO padding and float classes
+            out, _ = self._run(scores, boxes, self.iou_threshold, 0.0)
+            pad = out["scores"] < 0
+            out["scores"] = torch.where(pad, torch.zeros_like(out["scores"]), out["scores"])
+            out["classes"] = torch.where(pad, torch.zeros_like(out["classes"]), out["classes"]).float()
+            return out
+        out, _ = self._run(scores, boxes, self.iou_threshold, self.sigma)
         return out
 
 
@@ -177,8 +240,10 @@ class DetectionPostProcess:
         self._gen = GenerateDetections(iou_threshold=inf.iou_threshold, score_threshold=inf.score_threshold,
                                        max_detections=inf.max_detections, soft_nms_sigma=inf.soft_nms_sigma,
                                        num_classes=params.architecture.head.num_classes, mode=inf.mode)
-        if not inf.filter_per_class and inf.pre_nms_top_k > 0:
-            raise NotImplementedError("inference.filter_per_class=false is unused by every shipped config")
+        self._fused = inf.mode in ("PerClassHardNMS", "PerClassSoftNMS") and (inf.filter_per_class or
+                                                                                 inf.pre_nms_top_k <= 0)
+        self._filter = (FilterTopKDetections(top_k=inf.pre_nms_top_k, filter_per_class=inf.filter_per_class)
+                        if inf.pre_nms_top_k > 0 else None)
         self._top_k = int(inf.pre_nms_top_k)
         self._K = int(params.architecture.head.num_classes)
         self._ws = None
@@ -196,6 +261,17 @@ class DetectionPostProcess:
         A = offs[-1]
         dev = box_levels[0].device
         boxes = self._tb.decode(box_levels, offs, B)
+        if not self._fused:
+            # stage-by-stage path for the modes no shipped config selects (a15)
+            lib0 = _C.lib()
+            scores = torch.empty((B, A, self._K), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                _C.check(lib0.rn_sigmoid_scores(_C.ptr_array(cls_levels), _C.i64_array(offs), len(cls_levels), B,
+                                                self._K, _C.ptr(scores), _C.current_stream()), "rn_sigmoid_scores")
+            x = {"scores": scores, "boxes": boxes}
+            if self._filter is not None:
+                x = self._filter(x)
+            return self._gen(x)
         g = self._gen
         md = g.max_detections
         if self._out is None or self._out["scores"].shape[0] != B:

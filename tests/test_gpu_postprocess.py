@@ -142,3 +142,37 @@ def test_full_size_properties_b8(cuda):
     out2 = _fused(cuda, p, logits, enc, LEVELS_640)
     for k in out:
         np.testing.assert_array_equal(out[k], out2[k])
+
+
+@pytest.mark.parametrize("mode,topk,strict", [("GlobalHardNMS", -1, False), ("GlobalHardNMS", 400, True),
+                                              ("GlobalSoftNMS", 400, False), ("CombinedNMS", 300, False)])
+def test_global_and_combined_modes(cuda, mode, topk, strict):
+    """a15: the NMS modes no shipped config selects, against the oracle (bit-exact)."""
+    from retinanet.model.layers import DetectionPostProcess
+    rng = np.random.default_rng(17)
+    size, K, B = 256, 7, 2
+    p = _params(size, K, mode=mode, pre_nms_top_k=topk, filter_per_class=(mode == "CombinedNMS"), max_detections=50)
+    an = o.generate_anchors(size, size, 3, 7, p.anchor_params.areas, p.anchor_params.aspect_ratios, p.anchor_params.scales)
+    A = an.shape[0]
+    logits = rng.normal(-2.5, 1.5, (B, A, K)).astype(np.float32)
+    enc = rng.normal(0, 0.3, (B, A, 4)).astype(np.float32)
+    splits = [9216, 2304, 576, 144, 36]
+    post = DetectionPostProcess(p)
+    post._gen.strict_reference = strict
+    out = post({"class-predictions": _split(logits, splits, cuda), "box-predictions": _split(enc, splits, cuda)})
+    torch.cuda.synchronize()
+    out = {k: v.cpu().numpy() for k, v in out.items()}
+    scores, boxes = o.sigmoidf(logits), o.decode_boxes(enc, an, size, size)
+    if mode == "CombinedNMS":
+        s_k, idx = o.topk_per_class(scores, topk)
+        b_k = np.stack([boxes[b][idx[b]] for b in range(B)], axis=0)
+        wb, ws, wc, wv = o.combined_nms(s_k, b_k, 0.5, 0.05, 50)
+        assert out["classes"].dtype == np.float32
+    else:
+        if topk > 0:
+            scores, boxes = o.filter_global(scores, boxes, topk)
+        wb, ws, wc, wv = o.global_nms(scores, boxes, 0.5, 0.05, 0.5 if mode == "GlobalSoftNMS" else 0.0, 50, strict)
+    assert wv.min() > 0
+    _check(out, wb, ws, wc, wv)
+    if strict:   # the reference quirk: nothing is suppressed, the output is simply the top scores
+        assert (wv == 50).all()
