@@ -203,6 +203,7 @@ typedef struct {
   const void* dy;
   int32_t N, H, W, Cin, Ho, Wo, Cout;
   int32_t dy_pix_stride; /* elements between dy pixels; 0 = Cout (dense) */
+  int32_t x_pix_stride;  /* elements between x pixels; 0 = Cin (dense); 4 for the packed stem image */
 } rn_wgrad_segment;
 
 typedef struct {
@@ -281,8 +282,8 @@ int rn_bn_bwd_reduce(const rn_bn_problem* problem, void* workspace, size_t works
 int rn_bn_bwd_apply(const rn_bn_problem* problem, void* stream);
 
 /* backward of K6/K7/K8 */
-int rn_maxpool2d_nhwc_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int k, int Ho,
-                          int Wo, int accumulate, void* stream);
+int rn_maxpool2d_nhwc_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int k, int stride,
+                          int pad_top, int pad_left, int Ho, int Wo, int accumulate, void* stream);
 /* one level of the FPN top-down backward: din = (dout + sum2x2(din_finer)) * act'(out) */
 int rn_fpn_topdown_bwd_level(const void* dout, const void* din_finer, const void* out, void* din, int N, int H,
                              int W, int C, int act, void* stream);

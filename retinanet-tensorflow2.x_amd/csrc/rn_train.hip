@@ -465,52 +465,69 @@ extern "C" int rn_act_bwd(const void* dz, const void* z, void* dy, int64_t n, in
   return RN_OK;
 }
 
-// ---- max-pool backward, non-overlapping windows (k == stride): gradient to the FIRST maximum ---
+// ---- max-pool backward (gather form, any k / stride / TF-SAME pads): every INPUT pixel sums dy of
+// the windows that contain it and whose FIRST maximum (row-major scan, padded taps skipped) it is.
+// No atomics, deterministic; <= ceil(k/stride)^2 windows x k^2 taps of L2-resident reads per pixel.
 __global__ void __launch_bounds__(TR_THREADS)
 maxpool_bwd_kernel(const uint4* __restrict__ x, const uint4* __restrict__ dy, uint4* __restrict__ dx, int N, int H,
-                   int W, int C8, int k, int Ho, int Wo, int accumulate) {
-  const long long total = (long long)N * Ho * Wo * C8;
+                   int W, int C8, int k, int stride, int pt, int pl, int Ho, int Wo, int accumulate) {
+  const long long total = (long long)N * H * W * C8;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const int c = (int)(i % C8);
     long long t = i / C8;
-    const int ox = (int)(t % Wo);
-    t /= Wo;
-    const int oy = (int)(t % Ho);
-    const int n = (int)(t / Ho);
-    const bf8 g = unpack8(dy[i]);
-    float best[8];
-    int arg[8];
+    const int ix = (int)(t % W);
+    t /= W;
+    const int iy = (int)(t % H);
+    const int n = (int)(t / H);
+    const bf8 me = unpack8(x[i]);
+    bf8 g;
+    if (accumulate) g = unpack8(dx[i]);
+    else {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) { best[q] = -INFINITY; arg[q] = 0; }
-    for (int r = 0; r < k; ++r)
-      for (int s = 0; s < k; ++s) {
-        const bf8 v = unpack8(x[(((long long)n * H + oy * k + r) * W + ox * k + s) * C8 + c]);
+      for (int q = 0; q < 8; ++q) g.v[q] = 0.0f;
+    }
+    // windows oy with oy*stride - pt <= iy <= oy*stride - pt + k - 1
+    int oy0 = (iy + pt - (k - 1) + stride - 1) / stride;
+    if (iy + pt - (k - 1) < 0) oy0 = 0;
+    int ox0 = (ix + pl - (k - 1) + stride - 1) / stride;
+    if (ix + pl - (k - 1) < 0) ox0 = 0;
+    const int oy1 = (iy + pt) / stride, ox1 = (ix + pl) / stride;
+    for (int oy = oy0; oy <= oy1 && oy < Ho; ++oy)
+      for (int ox = ox0; ox <= ox1 && ox < Wo; ++ox) {
+        const int my_r = iy - (oy * stride - pt), my_s = ix - (ox * stride - pl);
+        bool win[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) win[q] = true;
+        for (int r = 0; r < k; ++r) {
+          const int yy = oy * stride - pt + r;
+          if ((unsigned)yy >= (unsigned)H) continue;
+          for (int s = 0; s < k; ++s) {
+            const int xx = ox * stride - pl + s;
+            if ((unsigned)xx >= (unsigned)W || (r == my_r && s == my_s)) continue;
+            const bf8 v = unpack8(x[(((long long)n * H + yy) * W + xx) * C8 + c]);
+            const bool before = r < my_r || (r == my_r && s < my_s);
+#pragma unroll
+            for (int q = 0; q < 8; ++q)   // an earlier tap wins ties, a later one must be strictly larger
+              if (before ? (v.v[q] >= me.v[q]) : (v.v[q] > me.v[q])) win[q] = false;
+          }
+        }
+        const bf8 d = unpack8(dy[(((long long)n * Ho + oy) * Wo + ox) * C8 + c]);
 #pragma unroll
         for (int q = 0; q < 8; ++q)
-          if (v.v[q] > best[q]) { best[q] = v.v[q]; arg[q] = r * k + s; }
+          if (win[q]) g.v[q] += d.v[q];
       }
-    for (int r = 0; r < k; ++r)
-      for (int s = 0; s < k; ++s) {
-        const long long o = (((long long)n * H + oy * k + r) * W + ox * k + s) * C8 + c;
-        bf8 out;
-        if (accumulate) out = unpack8(dx[o]);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const float v = arg[q] == r * k + s ? g.v[q] : 0.0f;
-          out.v[q] = accumulate ? out.v[q] + v : v;
-        }
-        dx[o] = pack8(out);
-      }
+    dx[i] = pack8(g);
   }
 }
 extern "C" int rn_maxpool2d_nhwc_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int k,
-                                     int Ho, int Wo, int accumulate, void* stream) {
-  RN_CHECK_ARG(x && dy && dx && C % 8 == 0 && k >= 1 && Ho * k <= H && Wo * k <= W && Ho * k == H && Wo * k == W,
-               "rn_maxpool2d_nhwc_bwd: only non-overlapping windows that tile the input exactly are built");
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(tr_blocks((long long)N * Ho * Wo * (C / 8))), dim3(TR_THREADS), 0,
-                     (hipStream_t)stream, (const uint4*)x, (const uint4*)dy, (uint4*)dx, N, H, W, C / 8, k, Ho,
-                     Wo, accumulate);
+                                     int stride, int pad_top, int pad_left, int Ho, int Wo, int accumulate,
+                                     void* stream) {
+  RN_CHECK_ARG(x && dy && dx && C % 8 == 0 && k >= 1 && stride >= 1 && N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0,
+               "rn_maxpool2d_nhwc_bwd: bad argument");
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(tr_blocks((long long)N * H * W * (C / 8))), dim3(TR_THREADS), 0,
+                     (hipStream_t)stream, (const uint4*)x, (const uint4*)dy, (uint4*)dx, N, H, W, C / 8, k, stride,
+                     pad_top, pad_left, Ho, Wo, accumulate);
   RN_CHECK_LAUNCH();
   return RN_OK;
 }

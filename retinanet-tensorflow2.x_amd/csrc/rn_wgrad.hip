@@ -34,7 +34,7 @@ typedef __attribute__((address_space(3))) bf16x4_t lds_b4_t;
 struct WgSegDev {
   const uint16_t* x;
   const uint16_t* dy;
-  int N, H, W, Ho, Wo, P, chunk_begin, dyS;
+  int N, H, W, Ho, Wo, P, chunk_begin, dyS, xS, pad_;
 };
 
 struct WgArgs {
@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wgrad_kernel(const WgArgs args)
   const __amdgpu_buffer_rsrc_t rs_dy =
       __builtin_amdgcn_make_buffer_rsrc((void*)sg.dy, 0, (int)((long long)sg.P * sg.dyS * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_x =
-      __builtin_amdgcn_make_buffer_rsrc((void*)sg.x, 0, (int)((long long)sg.N * H * W * Cin * 2), 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc((void*)sg.x, 0, (int)((long long)sg.N * H * W * sg.xS * 2), 0x00020000);
 
   // DMA bookkeeping: instruction j of this wave fills rows (j*4 + wave)*4 .. +3 of a 64-row tile
   const int d_row = lane >> 4, d_pos = lane & 15;
@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wgrad_kernel(const WgArgs args)
       const int iy__ = oy__ * args.sh - args.pt + r, ix__ = ox__ * args.sw - args.pl + s;         \
       const bool ok__ = in__ && (unsigned)iy__ < (unsigned)H && (unsigned)ix__ < (unsigned)W;     \
       const unsigned vb__ =                                                                       \
-          ok__ ? (unsigned)(((((long long)n__ * H + iy__) * W + ix__) * Cin + ci0 + chunk__ * 8) * 2) : WG_OOB; \
+          ok__ ? (unsigned)(((((long long)n__ * H + iy__) * W + ix__) * sg.xS + ci0 + chunk__ * 8) * 2) : WG_OOB; \
       wg_dma16(rs_x, st__ + WG_TILE_BYTES + (j * 4 + wave) * 1024, vb__);                         \
     }                                                                                             \
   } while (0)
@@ -223,7 +223,9 @@ static int wgrad_plan(const rn_wgrad_problem* p, WgArgs& a) {
     if (P <= 0 || P >= (1ll << 24)) return -1;
     const long long dyS = s.dy_pix_stride > 0 ? s.dy_pix_stride : s.Cout;
     if (dyS < s.Cout || (dyS % 4)) return -1;
-    if ((long long)s.N * s.H * s.W * s.Cin * 2 >= (1ll << 31) || P * dyS * 2 >= (1ll << 31)) return -1;
+    const long long xS = s.x_pix_stride > 0 ? s.x_pix_stride : s.Cin;
+    if (xS % 4) return -1;
+    if ((long long)s.N * s.H * s.W * xS * 2 >= (1ll << 31) || P * dyS * 2 >= (1ll << 31)) return -1;
     Ptot += P;
   }
   const int tiles = a.co_tiles * a.ci_tiles * a.R * a.S;
@@ -242,6 +244,8 @@ static int wgrad_plan(const rn_wgrad_problem* p, WgArgs& a) {
     d.P = s.N * s.Ho * s.Wo;
     d.chunk_begin = chunks;
     d.dyS = s.dy_pix_stride > 0 ? s.dy_pix_stride : s.Cout;
+    d.xS = s.x_pix_stride > 0 ? s.x_pix_stride : s.Cin;
+    d.pad_ = 0;
     chunks += (int)rn_cdiv(d.P, CH);
   }
   a.total_chunks = chunks;

@@ -38,7 +38,7 @@ class ConvProblem(Structure):
 class WgradSegment(Structure):
     _fields_ = [("x", c_void_p), ("dy", c_void_p), ("N", c_int32), ("H", c_int32), ("W", c_int32),
                 ("Cin", c_int32), ("Ho", c_int32), ("Wo", c_int32), ("Cout", c_int32),
-                ("dy_pix_stride", c_int32)]
+                ("dy_pix_stride", c_int32), ("x_pix_stride", c_int32)]
 
 
 class WgradProblem(Structure):
@@ -110,7 +110,7 @@ _SIGNATURES = {
     "rn_bn_bwd_reduce": (c_int, [POINTER(BnProblem), c_void_p, c_size_t, c_void_p]),
     "rn_bn_bwd_apply": (c_int, [POINTER(BnProblem), c_void_p]),
     "rn_maxpool2d_nhwc_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
-                                      c_int, c_int, c_void_p]),
+                                      c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rn_fpn_topdown_bwd_level": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                          c_int, c_void_p]),
     "rn_balance_features_bwd": (c_int, [_PP, _PP, _PP, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,

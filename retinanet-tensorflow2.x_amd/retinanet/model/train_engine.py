@@ -18,9 +18,9 @@ scheduled from the same static graph as the forward pass.
   * parameters, gradients, momentum and EMA live in four flat fp32 arenas (conv kernels in the
     compute layout [Cout][R][S][Cin]); the optimizer is three multi-tensor launches and also
     refreshes the bf16 compute copy of every kernel.
-Limitation (documented in DESIGN.md): the stem (7x7 conv + 3x3/2 max-pool) has no backward yet,
-so `resnet_initial` (or any pattern covering the stem) must be frozen — true for every shipped
-ImageNet-initialised ResNet config.
+The stem trains too (configs without `freeze_variables`): its weight gradient runs the same wgrad
+kernel on the packed NHWC4 image (7 row taps x 32 = 8 column taps x 4 channels), the 3x3/2 SAME
+max-pool has a gather-form backward.
 """
 from __future__ import annotations
 
@@ -87,15 +87,10 @@ class TrainEngine:
             kind = op["op"]
             if kind in ("conv", "stem"):
                 tr = self._conv_trainable(op) or bool(self._bn_trainable(op))
-                if kind == "stem" and tr:
-                    raise NotImplementedError("the stem has no backward yet: freeze it (e.g. 'resnet_initial')")
                 ins = [op["inp"]] + ([op["residual"]] if op.get("residual") else [])
                 self.requires[op["out"]] = tr or any(self.requires[i] for i in ins)
             elif kind == "maxpool":
                 self.requires[op["out"]] = self.requires[op["inp"]]
-                if self.requires[op["inp"]] and op["k"] != op["stride"]:
-                    raise NotImplementedError("overlapping max-pool backward (the stem pool) is not built: "
-                                              "freeze the stem and block_group1 ('resnet_initial')")
             elif kind == "topdown":
                 r = any(self.requires[i] for i in op["ins"])
                 for o in op["outs"]:
@@ -104,7 +99,7 @@ class TrainEngine:
                 pass
         # a conv layer is "live" when its kernel trains; mixed frozen conv / live BN is not a shipped case
         for op in g.ops:
-            if op["op"] == "conv" and op.get("bn") and self._conv_trainable(op) != bool(self._bn_trainable(op)):
+            if op["op"] in ("conv", "stem") and op.get("bn") and self._conv_trainable(op) != bool(self._bn_trainable(op)):
                 raise NotImplementedError(f"{op['conv']}: conv and its BatchNorm must be frozen together")
 
     # ---- flat parameter arenas ---------------------------------------------------------------------
@@ -121,7 +116,7 @@ class TrainEngine:
             n = v[k].numel()
             is_kernel = k.endswith("/kernel")
             bfo = -1
-            if is_kernel:
+            if is_kernel and self.g.convs[k[:-len("/kernel")]]["cin"] != 3:   # the stem has its own packed form
                 cname = k[:-len("/kernel")]
                 c = self.g.convs[cname]
                 bfo = bf_off
@@ -166,10 +161,27 @@ class TrainEngine:
         self.E.copy_(self.P)
         self.V.zero_()
         for k in self.train_names:
-            if k.endswith("/kernel"):
+            if k.endswith("/kernel") and k[:-len("/kernel")] in self.bf_off:
                 cname = k[:-len("/kernel")]
                 off, n = self.p_off[k]
                 self.Pbf[self.bf_off[cname]:self.bf_off[cname] + n].copy_(self.P[off:off + n])
+        self.refresh_stem_pack()
+
+    def _stem_op(self):
+        return next(o for o in self.g.ops if o["op"] == "stem")
+
+    def refresh_stem_pack(self):
+        """live stem: master [64][7][7][3] (compute layout) -> bf16 [64][7 rows][8 taps x 4 ch]."""
+        op = self._stem_op()
+        if not self._conv_trainable(op):
+            return
+        c = self.g.convs[op["conv"]]
+        if getattr(self, "stem_packed", None) is None:
+            self.stem_packed = torch.zeros((self.lib.rn_conv_cout_pad(c["cout"]), 7, 32), dtype=torch.bfloat16,
+                                           device=self.dev)
+        w = _ohwi_to_hwio(self._pview(op["conv"] + "/kernel").reshape(c["cout"], 7, 7, 3))
+        _C.check(self.lib.rn_pack_stem_weight(_C.ptr(w), c["cout"], _C.ptr(self.stem_packed), _C.current_stream()),
+                 "rn_pack_stem_weight")
 
     def store_to_model(self, use_ema=False):
         """flat arenas -> model.variables (executor.assign_moving_averaged_weights when use_ema)."""
@@ -196,7 +208,7 @@ class TrainEngine:
         self.Wp = self.lib.rn_stem_padded_width(W)
         self.stem_in = torch.empty((B, H + 6, self.Wp, 4), dtype=torch.bfloat16, device=dev)
         for op in self.g.ops:
-            if op["op"] == "conv" and self._bn_trainable(op):
+            if op["op"] in ("conv", "stem") and self._bn_trainable(op):
                 self.raw[op["out"]] = torch.empty_like(self.t[op["out"]])
         # balance features runs out of place in training (its backward needs the inputs)
         self.bal_out = {}
@@ -213,7 +225,9 @@ class TrainEngine:
                     if self.requires.get(i):
                         need.add(i)
             elif op["op"] in ("maxpool",) and self.requires.get(op["out"]):
-                need.update([op["out"], op["inp"]])
+                need.add(op["out"])
+                if self.requires.get(op["inp"]):
+                    need.add(op["inp"])
             elif op["op"] == "topdown":
                 for n in op["ins"] + op["outs"]:
                     if self.requires.get(n):
@@ -225,7 +239,7 @@ class TrainEngine:
             self.grad["bal:" + n] = torch.zeros_like(t)
         self.bn_state = {}
         for op in self.g.ops:
-            if op["op"] == "conv" and self._bn_trainable(op):
+            if op["op"] in ("conv", "stem") and self._bn_trainable(op):
                 bn = op["bn"]
                 self.bn_state[bn] = {"mm": self.model.variables[bn + "/moving_mean"].to(dev, torch.float32).clone(),
                                      "mv": self.model.variables[bn + "/moving_variance"].to(dev, torch.float32).clone()}
@@ -389,17 +403,38 @@ class TrainEngine:
                 pin, pimg = self.stem_in.data_ptr(), img.data_ptr()
                 self.fwd_steps.append(lambda st, pimg=pimg, pin=pin, H=H, W=W: _C.check(
                     lib.rn_pack_stem_input(pimg, B, H, W, pin, st), "rn_pack_stem_input"))
+                live = self._conv_trainable(op)
                 p = _C.ConvProblem()
                 p.R, p.S, p.stride_h, p.stride_w, p.pad_top, p.pad_left = 7, 1, 2, 2, 0, 0
-                p.act, p.out_dtype, p.num_segments = _C.ACT_IDS[op["act"]], _C.RN_DT_BF16, 1
+                p.act = _C.RN_ACT_NONE if live else _C.ACT_IDS[op["act"]]
+                p.out_dtype, p.num_segments = _C.RN_DT_BF16, 1
                 s = p.seg[0]
-                sc, sh = self.fold[op["out"]]
-                s.x, s.w, s.y = pin, self.packed_frozen[op["conv"]].data_ptr(), y.data_ptr()
-                s.scale, s.shift, s.residual = sc.data_ptr(), sh.data_ptr(), None
+                if live:
+                    s.x, s.w, s.y = pin, self.stem_packed.data_ptr(), self.raw[op["out"]].data_ptr()
+                    s.scale, s.shift, s.residual = None, None, None
+                else:
+                    sc, sh = self.fold[op["out"]]
+                    s.x, s.w, s.y = pin, self.packed_frozen[op["conv"]].data_ptr(), y.data_ptr()
+                    s.scale, s.shift, s.residual = sc.data_ptr(), sh.data_ptr(), None
                 s.N, s.H, s.W, s.Cin, s.pix_stride = B, H + 6, self.Wp, 32, 4
                 s.Ho, s.Wo, s.Cout = y.shape[1], y.shape[2], c["cout"]
                 self._keep.append(p)
-                self.fwd_steps.append(lambda st, p=p: self._launch_conv(p, st, "stem"))
+                if live:
+                    pb, sums, bsums, ws, dys = self._bn_problem([op])
+                    self.bn_groups[op["out"]] = (pb, sums, bsums, ws, dys, [op])
+                    prb = ctypes.byref(pb)
+
+                    def run_stem(st, p=p, prb=prb, ws=ws, sums=sums):
+                        self._launch_conv(p, st, "stem(train)")
+                        _C.check(lib.rn_bn_stats(prb, _C.ptr(ws), ws.numel(), st), "rn_bn_stats")
+                        if self.sync_bn:
+                            import torch.distributed as dist
+                            dist.all_reduce(sums, group=self.pg)
+                        _C.check(lib.rn_bn_finalize(prb, st), "rn_bn_finalize")
+                        _C.check(lib.rn_bn_apply(prb, st), "rn_bn_apply")
+                    self.fwd_steps.append(run_stem)
+                else:
+                    self.fwd_steps.append(lambda st, p=p: self._launch_conv(p, st, "stem"))
             elif kind == "conv":
                 grp = op.get("group")
                 if grp is not None:
@@ -495,7 +530,7 @@ class TrainEngine:
                     plan.append(("conv", [op]))
                 elif first_of_group[grp] == i:
                     plan.append(("conv", [o for o in ops if o["op"] == "conv" and o.get("group") == grp]))
-            elif op["op"] in ("maxpool", "topdown", "balance"):
+            elif op["op"] in ("maxpool", "topdown", "balance", "stem"):
                 plan.append((op["op"], op))
         # which tensor gradients get more than one contribution is decided at build time
         written = set()
@@ -515,8 +550,38 @@ class TrainEngine:
                 x, dy, dx = self.t[op["inp"]], self.grad[op["out"]], self.grad[op["inp"]]
                 acc = 0 if mark(op["inp"]) else 1
                 a = (x.data_ptr(), dy.data_ptr(), dx.data_ptr(), B, x.shape[1], x.shape[2], x.shape[3], op["k"],
-                     dy.shape[1], dy.shape[2], acc)
+                     op["stride"], op["pad_top"], op["pad_left"], dy.shape[1], dy.shape[2], acc)
                 self.bwd_steps.append(lambda st, a=a: _C.check(lib.rn_maxpool2d_nhwc_bwd(*a, st), "maxpool_bwd"))
+            elif kind == "stem":
+                op = item
+                if not self._conv_trainable(op):
+                    continue
+                pb, sums, bsums, ws, dys, _ = self.bn_groups[op["out"]]
+                pb.seg[0].dz = self.grad[op["out"]].data_ptr()
+                c = self.g.convs[op["conv"]]
+                H, W = self.t["images"].shape[1], self.t["images"].shape[2]
+                pw = _C.WgradProblem()
+                pw.R, pw.S, pw.stride_h, pw.stride_w, pw.pad_top, pw.pad_left, pw.num_segments = 7, 1, 2, 2, 0, 0, 1
+                sg = pw.seg[0]
+                sg.x, sg.dy = self.stem_in.data_ptr(), dys[0].data_ptr()
+                sg.N, sg.H, sg.W, sg.Cin, sg.Ho, sg.Wo, sg.Cout = B, H + 6, self.Wp, 32, dys[0].shape[1], dys[0].shape[2], c["cout"]
+                sg.x_pix_stride = 4
+                wsw = torch.empty((max(lib.rn_wgrad_workspace_bytes(ctypes.byref(pw)), 256),), dtype=torch.uint8,
+                                  device=self.dev)
+                dwp = torch.zeros((c["cout"], 7, 8, 4), dtype=torch.float32, device=self.dev)
+                gview = self._pview(op["conv"] + "/kernel", self.G).view(c["cout"], 7, 7, 3)
+                self._keep += [pw, wsw, dwp]
+
+                def stem_bwd(st, prb=ctypes.byref(pb), ws=ws, bsums=bsums, pw=pw, wsw=wsw, dwp=dwp, gview=gview):
+                    _C.check(lib.rn_bn_bwd_reduce(prb, _C.ptr(ws), ws.numel(), st), "rn_bn_bwd_reduce")
+                    if self.sync_bn:
+                        import torch.distributed as dist
+                        dist.all_reduce(bsums, group=self.pg)
+                    _C.check(lib.rn_bn_bwd_apply(prb, st), "rn_bn_bwd_apply")
+                    _C.check(lib.rn_conv2d_nhwc_wgrad(ctypes.byref(pw), dwp.data_ptr(), 0.0, wsw.data_ptr(),
+                                                      wsw.numel(), st), "stem wgrad")
+                    gview.copy_(dwp[:, :, :7, :3])   # [co][r][8 taps x 4 ch] -> [co][r][s][c]
+                self.bwd_steps.append(stem_bwd)
             elif kind == "topdown":
                 op = item
                 L = len(op["ins"])
@@ -736,6 +801,7 @@ class TrainEngine:
                                        self.segs_dev.data_ptr(), self.block_seg_dev.data_ptr(), self.n_blocks,
                                        lr, momentum, ema_decay if ema_decay is not None else 0.0, st),
                  "rn_optim_sgd_step")
+        self.refresh_stem_pack()
 
     def train_step(self, images, targets):
         """(images f32[B,H,W,3], targets from LabelEncoder.encode_batch) -> loss dict (device scalars)."""

@@ -204,11 +204,23 @@ def test_pool_topdown_balance_backward(cuda):
     dy = _bf(torch.randn((N, 4, 4, C), generator=g))
     xd, dyd = x.to(cuda), dy.to(cuda)
     dx = torch.empty_like(xd)
-    _C.check(lib.rn_maxpool2d_nhwc_bwd(_C.ptr(xd), _C.ptr(dyd), _C.ptr(dx), N, 8, 8, C, 2, 4, 4, 0, st))
+    _C.check(lib.rn_maxpool2d_nhwc_bwd(_C.ptr(xd), _C.ptr(dyd), _C.ptr(dx), N, 8, 8, C, 2, 2, 0, 0, 4, 4, 0, st))
     xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
     F.max_pool2d(xr, 2).backward(dy.float().permute(0, 3, 1, 2))
     torch.cuda.synchronize()
     torch.testing.assert_close(dx.float().cpu(), xr.grad.permute(0, 2, 3, 1), rtol=0, atol=0)
+    # the stem pool: 3x3 stride 2 SAME on an even size (pad 0 top/left, 1 bottom/right), overlapping
+    # windows, accumulate into an existing gradient; distinct values so the argmax is unique
+    x2 = _bf(torch.randperm(2 * 12 * 12 * 8, generator=g).float().reshape(2, 12, 12, 8) / 64.0)
+    dy2 = _bf(torch.randn((2, 6, 6, 8), generator=g))
+    base = _bf(torch.randn((2, 12, 12, 8), generator=g))
+    x2d, dy2d, dx2 = x2.to(cuda), dy2.to(cuda), base.to(cuda).clone()
+    _C.check(lib.rn_maxpool2d_nhwc_bwd(_C.ptr(x2d), _C.ptr(dy2d), _C.ptr(dx2), 2, 12, 12, 8, 3, 2, 0, 0, 6, 6, 1, st))
+    xr2 = x2.float().permute(0, 3, 1, 2).requires_grad_(True)
+    F.max_pool2d(F.pad(xr2, (0, 1, 0, 1), value=float("-inf")), 3, 2).backward(dy2.float().permute(0, 3, 1, 2))
+    torch.cuda.synchronize()
+    want2 = _bf(base.float() + xr2.grad.permute(0, 2, 3, 1)).float()
+    torch.testing.assert_close(dx2.float().cpu(), want2, rtol=1 / 128, atol=1e-2)
     # FPN top-down backward over 4 levels
     L, H0 = 4, 16
     ins = [_bf(torch.randn((N, H0 >> l, H0 >> l, C), generator=g)) for l in range(L)]

@@ -10,7 +10,7 @@ from model_ref import RefTrainer
 pytestmark = pytest.mark.gpu
 
 
-def _setup(cuda, size, B, balanced, seed=3, depth=26):
+def _setup(cuda, size, B, balanced, seed=3, depth=26, freeze=True):
     from retinanet.cfg import default_params
     from retinanet.dataloader import LabelEncoder
     from retinanet.model import ModelBuilder
@@ -39,6 +39,8 @@ def _setup(cuda, size, B, balanced, seed=3, depth=26):
     rx = [builder.FREEZE_VARS_REGEX[n] for n in p.training.freeze_variables]
     if depth == 26:   # stem + block_group1 of ResNet-26 = conv2d .. conv2d_7 (same role as 'resnet_initial')
         rx = [re.compile(r"^(conv2d|batch_normalization)(_[1-7])?/")]
+    if not freeze:    # the 30x configs train everything from scratch (training.freeze_variables: [])
+        rx = []
     eng = TrainEngine(model, B, frozen_regexes=rx)
     enc = LabelEncoder(p, device=cuda)
     rng = np.random.default_rng(seed)
@@ -70,14 +72,16 @@ def _engine_grad(eng, k):
     return got.cpu()
 
 
-@pytest.mark.parametrize("size,B,balanced", [(256, 4, True), (256, 3, False)])
-def test_backward_wiring_dense_upstream(cuda, size, B, balanced):
+@pytest.mark.parametrize("size,B,balanced,freeze", [(256, 4, True, True), (256, 3, False, True), (256, 2, True, False)])
+def test_backward_wiring_dense_upstream(cuda, size, B, balanced, freeze):
     """Whole-network backward (heads -> BalanceFeatures -> FPN -> ResNet) for a dense random
     upstream gradient on the predictions, against autograd through the bf16-emulating CPU
     restatement.  bf16 gradients through ~25 layers leave ~0.25 relative noise per tensor, so
     the criterion is direction (cosine) and norm, tensor by tensor."""
-    p, model, eng, targets, images = _setup(cuda, size, B, balanced)
+    p, model, eng, targets, images = _setup(cuda, size, B, balanced, freeze=freeze)
     ref = RefTrainer(p, model.variables, frozen_names=eng.frozen, emulate_bf16=True)
+    if not freeze:
+        assert "conv2d/kernel" in eng.train_names and "batch_normalization/gamma" in eng.train_names
     preds = eng.forward(images.to(cuda))
     g = torch.Generator().manual_seed(99)
     up = {k: {lv: torch.randn(preds[k][lv].shape, generator=g) for lv in preds[k]} for k in preds}
