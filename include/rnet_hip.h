@@ -328,6 +328,17 @@ int rn_fpn_topdown(void* const* p_in /* host array of device ptrs */, void* cons
 int rn_balance_features(void* const* p_in, void* const* p_out, int num_levels, int mid, int N, int H0, int W0,
                         int C, void* scratch, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * §8(f)-1  prepare_image / validation preprocessing
+ * (retinanet/dataloader/preprocessing_pipeline.py:96-121, retinanet/dataloader/utils.py:58-66)
+ * image f32[h,w,3] (RGB, raw pixel values) -> out f32[target_h,target_w,3]:
+ * (x/pixel_scale - mean)/stddev, TF2 bilinear resize to [scaled_h,scaled_w] (half-pixel centres),
+ * zero padding bottom/right.  scaled_h/w = round(shape * min(target/shape)) is computed by the
+ * caller exactly as the reference does in float32 (:98-101).  mean/stddev: host f32[3].
+ */
+int rn_prepare_image(const float* image, int h, int w, int scaled_h, int scaled_w, float* out, int target_h,
+                     int target_w, const float* mean, const float* stddev, float pixel_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -121,6 +121,8 @@ _SIGNATURES = {
                               c_void_p, c_size_t, c_void_p]),
     "rn_optim_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                   c_float, c_float, c_float, c_void_p]),
+    "rn_prepare_image": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, POINTER(c_float),
+                                 POINTER(c_float), c_float, c_void_p]),
     "rn_maxpool2d_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                   c_int, c_int, c_void_p]),
     "rn_fpn_topdown": (c_int, [_PP, _PP, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

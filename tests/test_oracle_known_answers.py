@@ -164,3 +164,19 @@ def test_golden_fixtures_reproduce():
             assert sorted(z.files) == sorted(arrays)
             for k in z.files:
                 np.testing.assert_array_equal(z[k], arrays[k], err_msg=f"{name}:{k}")
+
+
+def test_prepare_image_matches_torch_bilinear():
+    """Independent pin of the TF2 bilinear restatement (half-pixel centres == torch align_corners=False)."""
+    import torch.nn.functional as F
+    rng = np.random.default_rng(0)
+    for (h, w, t) in ((37, 53, 128), (480, 640, 640), (700, 500, 320)):
+        img = rng.integers(0, 256, (h, w, 3)).astype(np.float32)
+        out, sc = o.prepare_image(img, t, t, [0, 0, 0], [1, 1, 1], 1.0)
+        r = min(np.float32(t) / np.float32(h), np.float32(t) / np.float32(w))
+        sh, sw = int(np.round(np.float32(h) * r)), int(np.round(np.float32(w) * r))
+        ref = F.interpolate(torch.from_numpy(img).permute(2, 0, 1)[None], size=(sh, sw), mode="bilinear",
+                            align_corners=False, antialias=False)[0].permute(1, 2, 0).numpy()
+        np.testing.assert_allclose(out[:sh, :sw], ref, rtol=0, atol=1e-3)
+        assert (out[sh:] == 0).all() and (out[:, sw:] == 0).all() and max(sh, sw) == t
+        np.testing.assert_allclose(sc, [sh / h, sw / w], rtol=1e-6)
