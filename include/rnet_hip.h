@@ -181,6 +181,8 @@ int rn_conv2d_nhwc_fwd(const rn_conv_problem* problem /* host */, void* stream);
 /* HWIO f32 [R,S,Cin,Cout] (the Keras kernel layout, resnet.py:137-144) -> bf16
  * [Cout_pad,R,S,Cin_pad], zero padded.  Cout_pad = rn_conv_cout_pad(Cout). */
 int rn_conv_cout_pad(int Cout);
+/* channel count of the packed weights: Cin rounded up to the kernel's K step (zero columns) */
+int rn_conv_cin_pad(int Cin);
 int rn_pack_conv_weight(const float* w_hwio, int R, int S, int Cin, int Cout, int Cin_pad, void* w_packed,
                         void* stream);
 /* Stem repack: 7x7x3 HWIO -> bf16 [64][7][32] rows = (kernel row r) x (8 taps x 4 channels),
@@ -327,6 +329,36 @@ int rn_fpn_topdown(void* const* p_in /* host array of device ptrs */, void* cons
  * mid = index of the intermediate level; scratch: bf16 [N,Hmid,Wmid,C]. */
 int rn_balance_features(void* const* p_in, void* const* p_out, int num_levels, int mid, int N, int H0, int W0,
                         int C, void* scratch, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a18  EfficientNet / SeparableConv2D pieces that are not GEMMs
+ * (retinanet/model/backbone/efficientnet.py:222-265 SE, :372-380 depthwise conv;
+ *  model/neck/fpn_base.py:28-39 and model/head/detection_head.py:37-50 SeparableConv2D)
+ * Depthwise k x k conv, TF SAME pads given explicitly, y = act(dw(x)*scale[c] + shift[c]), bf16 NHWC,
+ * weights bf16 [k*k][C] (rn_pack_depthwise_weight from the Keras [k,k,C,1] f32 kernel).  Grouped.
+ */
+typedef struct {
+  const void* x;
+  const void* w;
+  void* y;
+  const float* scale;
+  const float* shift;
+  int32_t N, H, W, C, Ho, Wo;
+} rn_dw_segment;
+
+typedef struct {
+  int32_t k, stride, pad_top, pad_left, act, num_segments;
+  rn_dw_segment seg[RN_CONV_MAX_SEGMENTS];
+} rn_dw_problem;
+
+int rn_depthwise_conv2d_nhwc_fwd(const rn_dw_problem* problem /* host */, void* stream);
+int rn_pack_depthwise_weight(const float* w_kkc1, int k, int C, void* w_packed, void* stream);
+/* SE in place on x bf16 [N,HW,C]: x *= sigmoid(W2 swish(W1 mean_hw(x) + b1) + b2).
+ * w_reduce bf16 [se][C], w_expand bf16 [C][se], biases f32. */
+size_t rn_se_workspace_bytes(int N, int C);
+int rn_squeeze_excite_inplace(void* x, int N, int HW, int C, const void* w_reduce, const float* b_reduce,
+                              const void* w_expand, const float* b_expand, int se, void* workspace,
+                              size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * §8(f)-1  prepare_image / validation preprocessing

@@ -40,7 +40,7 @@ struct ConvSegDev {
   const float* shift;
   const uint16_t* residual;
   int N, H, W, Cin, pix_stride, Ho, Wo, Cout;
-  int M, tile_begin, n_tiles, pad_;
+  int M, tile_begin, n_tiles, CinP;  // CinP = Cin rounded up to the K step (weights are zero padded)
 };
 
 struct ConvArgs {
@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_fwd_kernel(const ConvArg
   const int wave_m = wave / WN, wave_n = wave % WN;
 
   const int R = args.R, S = args.S;
-  const int H = sg.H, W = sg.W, Cin = sg.Cin, PS = sg.pix_stride;
+  const int H = sg.H, W = sg.W, Cin = sg.CinP, PS = sg.pix_stride;
   const int M = sg.M;
   const int Ktot = R * S * Cin;
 
@@ -369,6 +369,8 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_fwd_kernel(const ConvArg
 
 // ---- host side ---------------------------------------------------------------------------------
 extern "C" int rn_conv_cout_pad(int Cout) { return Cout <= 64 ? 64 : (int)rn_align_up((size_t)Cout, 128); }
+// packed-weight channel count: Cin rounded up to the K step (32 below 64 channels, 64 above)
+extern "C" int rn_conv_cin_pad(int Cin) { return Cin <= 32 ? 32 : (int)rn_align_up((size_t)Cin, 64); }
 
 template <int BM, int BN, int BK, bool F32, int WM = 2, int WN = 2, int STAGES = 2>
 static int launch_conv(const ConvArgs& a, hipStream_t st) {
@@ -412,7 +414,10 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
   a.act = p->act; a.nseg = p->num_segments; a.pad_ = 0;
   const int cout_pad0 = rn_conv_cout_pad(p->seg[0].Cout);
   const int BN = cout_pad0 <= 64 ? 64 : 128;
-  const int BK = (p->seg[0].Cin % 64 == 0) ? 64 : 32;
+  // K step: 64 unless the (padded) channel count is small; Cin need only be a multiple of 8 — the
+  // tail of the last K step reads past the pixel's channels (or out of range -> zeros) and meets the
+  // zero-padded weight columns, so it contributes nothing.
+  const int BK = rn_conv_cin_pad(p->seg[0].Cin) % 64 == 0 ? 64 : 32;
   // The 256x128x64 three-stage kernel (8 waves, DMA + fragment registers double buffered) is built and
   // tested but NOT selected by default: measured on MI355X it ties the 128x128 two-stage kernel to
   // within 1 % on the large layers (tower conv B=32: 899 vs 889 us) and loses on mid-size ones
@@ -425,7 +430,8 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
     RN_CHECK_ARG(s.x && s.w && s.y, "rn_conv2d_nhwc_fwd: segment %d has a null tensor", i);
     RN_CHECK_ARG(s.N > 0 && s.H > 0 && s.W > 0 && s.Ho > 0 && s.Wo > 0 && s.Cout > 0 && s.Cin > 0,
                  "rn_conv2d_nhwc_fwd: segment %d bad shape", i);
-    RN_CHECK_ARG(s.Cin % BK == 0, "rn_conv2d_nhwc_fwd: segment %d Cin=%d not a multiple of %d", i, s.Cin, BK);
+    RN_CHECK_ARG(s.Cin % 8 == 0 && rn_conv_cin_pad(s.Cin) % BK == 0,
+                 "rn_conv2d_nhwc_fwd: segment %d Cin=%d must be a multiple of 8 (K step %d)", i, s.Cin, BK);
     RN_CHECK_ARG(s.pix_stride % 4 == 0 && s.pix_stride > 0,
                  "rn_conv2d_nhwc_fwd: segment %d pix_stride=%d must be a positive multiple of 4", i, s.pix_stride);
     RN_CHECK_ARG(s.Cout % 4 == 0, "rn_conv2d_nhwc_fwd: segment %d Cout=%d not a multiple of 4", i, s.Cout);
@@ -445,7 +451,7 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
     d.M = (int)M;
     d.tile_begin = tiles;
     d.n_tiles = cp / BN;
-    d.pad_ = 0;
+    d.CinP = rn_conv_cin_pad(s.Cin);
     tiles += (int)rn_cdiv(M, BM) * d.n_tiles;
   }
   a.total_tiles = tiles;

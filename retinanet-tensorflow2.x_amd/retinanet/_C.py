@@ -47,6 +47,16 @@ class WgradProblem(Structure):
                 ("seg", WgradSegment * RN_CONV_MAX_SEGMENTS)]
 
 
+class DwSegment(Structure):
+    _fields_ = [("x", c_void_p), ("w", c_void_p), ("y", c_void_p), ("scale", c_void_p), ("shift", c_void_p),
+                ("N", c_int32), ("H", c_int32), ("W", c_int32), ("C", c_int32), ("Ho", c_int32), ("Wo", c_int32)]
+
+
+class DwProblem(Structure):
+    _fields_ = [("k", c_int32), ("stride", c_int32), ("pad_top", c_int32), ("pad_left", c_int32), ("act", c_int32),
+                ("num_segments", c_int32), ("seg", DwSegment * RN_CONV_MAX_SEGMENTS)]
+
+
 class BnSegment(Structure):
     _fields_ = [("y", c_void_p), ("z", c_void_p), ("residual", c_void_p), ("dz", c_void_p), ("dy", c_void_p),
                 ("dres", c_void_p), ("sums", c_void_p), ("fwd", c_void_p), ("bsums", c_void_p),
@@ -92,6 +102,12 @@ _SIGNATURES = {
     "rn_rowmax_argmax": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "rn_conv2d_nhwc_fwd": (c_int, [POINTER(ConvProblem), c_void_p]),
     "rn_conv_cout_pad": (c_int, [c_int]),
+    "rn_conv_cin_pad": (c_int, [c_int]),
+    "rn_depthwise_conv2d_nhwc_fwd": (c_int, [POINTER(DwProblem), c_void_p]),
+    "rn_pack_depthwise_weight": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "rn_se_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "rn_squeeze_excite_inplace": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_int, c_void_p, c_size_t, c_void_p]),
     "rn_pack_conv_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rn_pack_stem_weight": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "rn_stem_padded_width": (c_int, [c_int]),

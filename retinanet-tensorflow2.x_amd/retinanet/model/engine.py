@@ -70,10 +70,11 @@ class InferenceEngine:
                     _C.check(lib.rn_pack_stem_weight(_C.ptr(w), c["cout"], _C.ptr(buf), st), "rn_pack_stem_weight")
                 else:
                     buf = self.packed.get(cname)
+                    cin_pad = lib.rn_conv_cin_pad(c["cin"])
                     if buf is None:
-                        buf = torch.empty((cout_pad, c["k"], c["k"], c["cin"]), dtype=torch.bfloat16,
+                        buf = torch.empty((cout_pad, c["k"], c["k"], cin_pad), dtype=torch.bfloat16,
                                           device=self.dev)
-                    _C.check(lib.rn_pack_conv_weight(_C.ptr(w), c["k"], c["k"], c["cin"], c["cout"], c["cin"],
+                    _C.check(lib.rn_pack_conv_weight(_C.ptr(w), c["k"], c["k"], c["cin"], c["cout"], cin_pad,
                                                      _C.ptr(buf), st), "rn_pack_conv_weight")
                 self.packed[cname] = buf
             # fold: y = conv*scale + shift;  BN inference: gamma*(x+bias-mean)/sqrt(var+eps)+beta

@@ -117,6 +117,9 @@ class TrainEngine:
             is_kernel = k.endswith("/kernel")
             bfo = -1
             if is_kernel and self.g.convs[k[:-len("/kernel")]]["cin"] != 3:   # the stem has its own packed form
+                if lib.rn_conv_cin_pad(self.g.convs[k[:-len("/kernel")]]["cin"]) != self.g.convs[k[:-len("/kernel")]]["cin"]:
+                    raise NotImplementedError("training needs Cin to equal its K-step padding (32 or a multiple of 64): "
+                                              "the bf16 compute copy is a plain cast of the master weights")
                 cname = k[:-len("/kernel")]
                 c = self.g.convs[cname]
                 bfo = bf_off
@@ -260,8 +263,9 @@ class TrainEngine:
                 buf = torch.empty((cp, 7, 32), dtype=torch.bfloat16, device=self.dev)
                 _C.check(lib.rn_pack_stem_weight(_C.ptr(w), c["cout"], _C.ptr(buf), st), "rn_pack_stem_weight")
             else:
-                buf = torch.empty((cp, c["k"], c["k"], c["cin"]), dtype=torch.bfloat16, device=self.dev)
-                _C.check(lib.rn_pack_conv_weight(_C.ptr(w), c["k"], c["k"], c["cin"], c["cout"], c["cin"],
+                cinp = lib.rn_conv_cin_pad(c["cin"])
+                buf = torch.empty((cp, c["k"], c["k"], cinp), dtype=torch.bfloat16, device=self.dev)
+                _C.check(lib.rn_pack_conv_weight(_C.ptr(w), c["k"], c["k"], c["cin"], c["cout"], cinp,
                                                  _C.ptr(buf), st), "rn_pack_conv_weight")
             self.packed_frozen[cname] = buf
             bias = v.get(cname + "/bias")

@@ -32,8 +32,9 @@ def _conv_gpu(cuda, segs, k, stride, pad, act, out_f32):
         x = _bf(s["x"]).to(cuda).contiguous()
         w = s["w"].to(cuda).float().contiguous()          # HWIO
         kk, _, cin, cout = w.shape
-        wp = torch.empty((lib.rn_conv_cout_pad(cout), kk, kk, cin), dtype=torch.bfloat16, device=cuda)
-        _C.check(lib.rn_pack_conv_weight(_C.ptr(w), kk, kk, cin, cout, cin, _C.ptr(wp), _C.current_stream()))
+        cinp = lib.rn_conv_cin_pad(cin)
+        wp = torch.empty((lib.rn_conv_cout_pad(cout), kk, kk, cinp), dtype=torch.bfloat16, device=cuda)
+        _C.check(lib.rn_pack_conv_weight(_C.ptr(w), kk, kk, cin, cout, cinp, _C.ptr(wp), _C.current_stream()))
         N, H, W, _ = x.shape
         Ho, Wo = (H + 2 * pad - kk) // stride + 1, (W + 2 * pad - kk) // stride + 1
         y = torch.empty((N, Ho, Wo, cout), dtype=torch.float32 if out_f32 else torch.bfloat16, device=cuda)
@@ -68,6 +69,8 @@ def _conv_ref(s, k, stride, pad, act, out_f32):
         y = F.relu(y)
     elif act == "relu6":
         y = F.relu6(y)
+    elif act == "swish":
+        y = y * torch.sigmoid(y)
     return y if out_f32 else _bf(y).float()
 
 
@@ -92,7 +95,10 @@ CASES = [
     (2, 5, 5, 256, 36, 3, 1, None, False, True),         # box prediction conv, f32 out, Cout pad 64
     (1, 10, 10, 256, 720, 3, 1, None, False, True),      # class prediction conv, 6 n-tiles
     (1, 13, 9, 192, 128, 3, 1, "relu", False, False),    # odd sizes, M tail, Cin = 3*64
-    (1, 7, 7, 96, 64, 3, 1, None, False, False),         # Cin multiple of 32 only -> BK=32 path
+    (1, 7, 7, 96, 64, 3, 1, None, False, False),         # Cin = 1.5 K steps: zero-padded weight tail
+    (2, 9, 9, 40, 144, 1, 1, "swish", False, False),     # EfficientNet widths: Cin 40 (pad 64), Cout 144
+    (1, 6, 6, 816, 136, 1, 1, None, True, False),        # MBConv project conv 816 -> 136 + skip
+    (1, 8, 8, 24, 32, 3, 1, "relu", False, False),       # Cin 24 -> BK 32
 ]
 
 
