@@ -192,6 +192,14 @@ int rn_pack_stem_weight(const float* w_hwio, int Cout, void* w_packed, void* str
  * Wp = rn_stem_padded_width(W). */
 int rn_stem_padded_width(int W);
 int rn_pack_stem_input(const float* images, int N, int H, int W, void* packed, void* stream);
+/* General form of the two calls above for any first-layer conv on 3-channel images whose kernel
+ * width S <= 8 and stride is 2 (EfficientNet Stem 3x3 s2 SAME, efficientnet.py:566-586): weights
+ * HWIO [R,S,3,Cout] -> bf16 [Cout_pad][R][8][4]; images f32 [N,H,W,3] -> bf16 [N,Hp,Wp,4] with
+ * pad_top/pad_left zero rows/cols in front, zero fill behind (Wp % 8 == 0) and a zero 4th channel.
+ * The conv is then rn_conv2d_nhwc_fwd with R=R, S=1, Cin=32, pix_stride=4, stride 2, pad 0. */
+int rn_pack_stem_weight_rs(const float* w_hwio, int R, int S, int Cout, void* w_packed, void* stream);
+int rn_pack_image_nhwc4(const float* images, int N, int H, int W, int pad_top, int pad_left, int Hp, int Wp,
+                        void* packed, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Backward of K1/K2 (the tape.gradient of executor.py:427-428 through Conv2D).

@@ -53,8 +53,8 @@ class RefModel:
         self._i = 0
 
     # ---- primitives (NCHW internally) ------------------------------------------------------------
-    def _conv(self, x, name, stride=1, pad=None, f32=False):
-        w = self.v[name + "/kernel"]  # HWIO
+    def _conv(self, x, name, stride=1, pad=None, f32=False, kernel="/kernel"):
+        w = self.v[name + kernel]  # HWIO
         k = w.shape[0]
         if pad is None:
             pad = (k - 1) // 2
@@ -64,6 +64,28 @@ class RefModel:
         wt = _r(wt, self.bf)
         b = self.v.get(name + "/bias")
         return F.conv2d(x, wt, b, stride=stride, padding=pad)
+
+    @staticmethod
+    def _same_pad(x, k, s, value=0.0):
+        """TF SAME: total = max((ceil(n/s)-1)*s + k - n, 0); the odd element goes bottom/right."""
+        H, W = x.shape[2], x.shape[3]
+        ph = max((math.ceil(H / s) - 1) * s + k - H, 0)
+        pw = max((math.ceil(W / s) - 1) * s + k - W, 0)
+        return F.pad(x, (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2), value=value)
+
+    def _depthwise(self, x, var, stride=1):
+        """tf.keras DepthwiseConv2D / the depthwise half of SeparableConv2D, padding='same', no bias."""
+        w = self.v[var]  # [k,k,C,1]
+        k, C = w.shape[0], w.shape[2]
+        wt = _r(w.permute(2, 3, 0, 1).contiguous(), self.bf)  # [C,1,k,k]
+        return F.conv2d(self._same_pad(x, k, stride), wt, None, stride=stride, groups=C)
+
+    def _cs(self, x, name, f32=False):
+        """Conv2D or SeparableConv2D, stride 1, SAME, bias (fpn_base.py:28-39, detection_head.py:37-50)."""
+        if not self.p.architecture.conv_2d.use_seperable_conv:
+            return self._conv(x, name, f32=f32)
+        y = _r(self._depthwise(x, name + "/depthwise_kernel"), self.bf)
+        return self._conv(y, name, pad=0, f32=f32, kernel="/pointwise_kernel")
 
     def _bn(self, x, name):
         g, b = self.v[name + "/gamma"], self.v[name + "/beta"]
@@ -101,7 +123,56 @@ class RefModel:
         y = self._bn(self._conv(y, c, 1), b)
         return _r(F.relu(y + sc), self.bf)
 
+    # ---- efficientnet.py:222-265 (SE), :291-482 (MBConvBlock), :566-586 (Stem), :783-855 -------------
+    def _efficientnet(self, images_nhwc):
+        name = self.p.architecture.backbone.type
+        width, depth = {"efficientnet-b0": (1.0, 1.0), "efficientnet-b1": (1.0, 1.1), "efficientnet-b2": (1.1, 1.2),
+                        "efficientnet-b3": (1.2, 1.4), "efficientnet-b4": (1.4, 1.8)}[name]
+
+        def rf(f):  # round_filters :196-211
+            f *= width
+            n = max(8, int(f + 4) // 8 * 8)
+            return int(n + 8 if n < 0.9 * f else n)
+        swish = lambda t: t * torch.sigmoid(t)
+        bnb = "tpu_batch_normalization"
+        x = _r(images_nhwc.permute(0, 3, 1, 2).contiguous(), self.bf)
+        x = self._conv(self._same_pad(x, 3, 2), name + "/stem/conv2d", 2, pad=0)
+        x = _r(swish(self._bn(x, f"{name}/stem/{self.bn_tag}")), self.bf)
+        stages = [(1, 3, 1, 1, 32, 16), (2, 3, 2, 6, 16, 24), (2, 5, 2, 6, 24, 40), (3, 3, 2, 6, 40, 80),
+                  (3, 5, 1, 6, 80, 112), (4, 5, 2, 6, 112, 192), (1, 3, 1, 6, 192, 320)]
+        blocks = []
+        for rep, k, s, e, ci, co in stages:
+            ci, co = rf(ci), rf(co)
+            for r in range(int(math.ceil(depth * rep))):
+                blocks.append((k, s if r == 0 else 1, e, ci if r == 0 else co, co))
+        red, feats = 0, {}
+        for i, (k, s, e, ci, co) in enumerate(blocks):
+            sc = f"{name}/blocks_{i}/"
+            inp, nb, nc = x, 0, 0
+            bn = lambda j: sc + (bnb if j == 0 else f"{bnb}_{j}")
+            cv = lambda j: sc + ("conv2d" if j == 0 else f"conv2d_{j}")
+            if e != 1:
+                x = _r(swish(self._bn(self._conv(x, cv(nc)), bn(nb))), self.bf)
+                nb, nc = nb + 1, nc + 1
+            x = _r(swish(self._bn(self._depthwise(x, sc + "depthwise_conv2d/depthwise_kernel", s), bn(nb))), self.bf)
+            nb += 1
+            # SE.call :252-265; under the mixed policy each op's output is a 16-bit tensor
+            se = _r(x.mean(dim=(2, 3), keepdim=True), self.bf)
+            se = _r(swish(_r(self._conv(se, sc + "se/conv2d"), self.bf)), self.bf)
+            se = _r(self._conv(se, sc + "se/conv2d_1"), self.bf)
+            x = _r(_r(torch.sigmoid(se), self.bf) * x, self.bf)
+            x = self._bn(self._conv(x, cv(nc)), bn(nb))
+            if s == 1 and ci == co:
+                x = x + inp
+            x = _r(x, self.bf)
+            if i == len(blocks) - 1 or blocks[i + 1][1] > 1:
+                red += 1
+                feats[str(red)] = x
+        return {str(l): feats[str(l)] for l in range(2, 6)}
+
     def backbone(self, images_nhwc):
+        if self.p.architecture.backbone.type.startswith("efficientnet"):
+            return self._efficientnet(images_nhwc)
         self._i = 0
         x = _r(images_nhwc.permute(0, 3, 1, 2).contiguous(), self.bf)
         c, b = self._next()
@@ -130,17 +201,17 @@ class RefModel:
         for level in range(bmax + 1, hi + 1):
             x = out[str(level - 1)]
             if level == bmax + 1:
-                x = _r(self._bn(self._conv(x, "fpn/backbone_max_level_conv_1x1"), f"fpn/backbone_max_level_{t}"),
+                x = _r(self._bn(self._cs(x, "fpn/backbone_max_level_conv_1x1"), f"fpn/backbone_max_level_{t}"),
                        self.bf)
             out[str(level)] = F.max_pool2d(x, 2)
         for level in range(lo, bmax + 1):
-            x = self._conv(out[str(level)], f"fpn/p{level}-in-channel-normalize-conv-1x1")
+            x = self._cs(out[str(level)], f"fpn/p{level}-in-channel-normalize-conv-1x1")
             out[str(level)] = _r(self._bn(x, f"fpn/p{level}-in-channel-normalize-{t}"), self.bf)
         for level in range(hi, lo, -1):
             up = F.interpolate(out[str(level)], scale_factor=2, mode="nearest")
             out[str(level - 1)] = _r(self._act(out[str(level - 1)] + up, act), self.bf)
         for level in range(lo, hi + 1):
-            x = self._conv(out[str(level)], f"fpn/p{level}-out-conv-3x3")
+            x = self._cs(out[str(level)], f"fpn/p{level}-out-conv-3x3")
             out[str(level)] = _r(self._bn(x, f"fpn/p{level}-out-{t}"), self.bf)
         return {str(l): out[str(l)] for l in range(lo, hi + 1)}
 
@@ -179,10 +250,10 @@ class RefModel:
         outs = {}
         for level, x in feats.items():
             for i in range(hd.num_convs):
-                x = self._conv(x, f"{name}/{name}-{i}-conv2d")
+                x = self._cs(x, f"{name}/{name}-{i}-conv2d")
                 x = self._bn(x, f"{name}/{name}-{i}-p{level}-{self.bn_tag}")
                 x = _r(self._act(x, act), self.bf)
-            y = self._conv(x, f"{name}/{name}-prediction-conv2d", f32=True)
+            y = self._cs(x, f"{name}/{name}-prediction-conv2d", f32=True)
             outs[level] = y.permute(0, 2, 3, 1).contiguous()  # NHWC float32
         return outs
 
@@ -220,8 +291,8 @@ class RefTrainer(RefModel):
         self.momentum = float(params.architecture.batch_norm.momentum)
         self.new_stats = {}
 
-    def _conv(self, x, name, stride=1, pad=None, f32=False):
-        y = super()._conv(x, name, stride, pad, f32)
+    def _conv(self, x, name, stride=1, pad=None, f32=False, kernel="/kernel"):
+        y = super()._conv(x, name, stride, pad, f32, kernel)
         # training materialises the pre-BN conv output as bf16 (frozen layers fold BN: no rounding;
         # the fp32 prediction convs stay fp32)
         if self.bf and not f32 and (name + "/kernel") not in self.frozen:

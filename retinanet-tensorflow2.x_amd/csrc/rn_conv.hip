@@ -508,25 +508,29 @@ extern "C" int rn_pack_conv_weight(const float* w_hwio, int R, int S, int Cin, i
   return RN_OK;
 }
 
-// stem: HWIO [7,7,3,Cout] -> [Cout_pad][7][8 taps][4 ch]; tap 7 and channel 3 are zero
-__global__ void pack_stem_weight_kernel(const float* __restrict__ w, int Cout, int Cout_pad,
+// stem: HWIO [R,S,3,Cout] (S <= 8) -> [Cout_pad][R][8 taps][4 ch]; taps >= S and channel 3 are zero
+__global__ void pack_stem_weight_kernel(const float* __restrict__ w, int R, int S, int Cout, int Cout_pad,
                                         uint16_t* __restrict__ out) {
-  const int total = Cout_pad * 7 * 32;
+  const int total = Cout_pad * R * 32;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int c = i & 3, s = (i >> 2) & 7, r = (i >> 5) % 7, o = i / (7 * 32);
+    const int c = i & 3, s = (i >> 2) & 7, r = (i >> 5) % R, o = i / (R * 32);
     float v = 0.0f;
-    if (o < Cout && c < 3 && s < 7) v = w[((r * 7 + s) * 3 + c) * Cout + o];
+    if (o < Cout && c < 3 && s < S) v = w[((r * S + s) * 3 + c) * Cout + o];
     out[i] = rn_f32_to_bf16(v);
   }
 }
 
-extern "C" int rn_pack_stem_weight(const float* w_hwio, int Cout, void* w_packed, void* stream) {
-  RN_CHECK_ARG(w_hwio && w_packed && Cout > 0, "rn_pack_stem_weight: bad argument");
+extern "C" int rn_pack_stem_weight_rs(const float* w_hwio, int R, int S, int Cout, void* w_packed, void* stream) {
+  RN_CHECK_ARG(w_hwio && w_packed && Cout > 0 && R > 0 && S > 0 && S <= 8, "rn_pack_stem_weight_rs: bad argument");
   const int Cout_pad = rn_conv_cout_pad(Cout);
-  hipLaunchKernelGGL(pack_stem_weight_kernel, dim3((Cout_pad * 7 * 32 + 255) / 256), dim3(256), 0,
-                     (hipStream_t)stream, w_hwio, Cout, Cout_pad, (uint16_t*)w_packed);
+  hipLaunchKernelGGL(pack_stem_weight_kernel, dim3((Cout_pad * R * 32 + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, w_hwio, R, S, Cout, Cout_pad, (uint16_t*)w_packed);
   RN_CHECK_LAUNCH();
   return RN_OK;
+}
+
+extern "C" int rn_pack_stem_weight(const float* w_hwio, int Cout, void* w_packed, void* stream) {
+  return rn_pack_stem_weight_rs(w_hwio, 7, 7, Cout, w_packed, stream);
 }
 
 extern "C" int rn_stem_padded_width(int W) { return (int)rn_align_up((size_t)W + 6 + 2, 8); }
@@ -534,15 +538,16 @@ extern "C" int rn_stem_padded_width(int W) { return (int)rn_align_up((size_t)W +
 // images f32 [N,H,W,3] -> bf16 [N,H+6,Wp,4], zero border of 3 (fixed_padding for k=7) and zero
 // 4th channel.  One thread per output pixel (8-byte store); reads are 12-byte pixels.
 __global__ void __launch_bounds__(256)
-pack_stem_input_kernel(const float* __restrict__ img, int N, int H, int W, int Wp, uint2* __restrict__ out) {
-  const long long total = (long long)N * (H + 6) * Wp;
+pack_stem_input_kernel(const float* __restrict__ img, int N, int H, int W, int pad_top, int pad_left, int Hp,
+                       int Wp, uint2* __restrict__ out) {
+  const long long total = (long long)N * Hp * Wp;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const int xp = (int)(i % Wp);
     const long long t = i / Wp;
-    const int yp = (int)(t % (H + 6));
-    const int n = (int)(t / (H + 6));
-    const int x = xp - 3, y = yp - 3;
+    const int yp = (int)(t % Hp);
+    const int n = (int)(t / Hp);
+    const int x = xp - pad_left, y = yp - pad_top;
     uint2 o = make_uint2(0u, 0u);
     if ((unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H) {
       const float* p = img + (((long long)n * H + y) * W + x) * 3;
@@ -553,13 +558,20 @@ pack_stem_input_kernel(const float* __restrict__ img, int N, int H, int W, int W
   }
 }
 
-extern "C" int rn_pack_stem_input(const float* images, int N, int H, int W, void* packed, void* stream) {
-  RN_CHECK_ARG(images && packed && N > 0 && H > 0 && W > 0, "rn_pack_stem_input: bad argument");
-  const int Wp = rn_stem_padded_width(W);
-  const long long total = (long long)N * (H + 6) * Wp;
+extern "C" int rn_pack_image_nhwc4(const float* images, int N, int H, int W, int pad_top, int pad_left, int Hp,
+                                   int Wp, void* packed, void* stream) {
+  RN_CHECK_ARG(images && packed && N > 0 && H > 0 && W > 0 && pad_top >= 0 && pad_left >= 0 &&
+                   Hp >= H + pad_top && Wp >= W + pad_left && Wp % 8 == 0,
+               "rn_pack_image_nhwc4: bad argument");
+  const long long total = (long long)N * Hp * Wp;
   int blocks = (int)(rn_cdiv(total, 256) < 8192 ? rn_cdiv(total, 256) : 8192);
   hipLaunchKernelGGL(pack_stem_input_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, images, N, H, W,
-                     Wp, (uint2*)packed);
+                     pad_top, pad_left, Hp, Wp, (uint2*)packed);
   RN_CHECK_LAUNCH();
   return RN_OK;
+}
+
+extern "C" int rn_pack_stem_input(const float* images, int N, int H, int W, void* packed, void* stream) {
+  RN_CHECK_ARG(images && packed && N > 0 && H > 0 && W > 0, "rn_pack_stem_input: bad argument");
+  return rn_pack_image_nhwc4(images, N, H, W, 3, 3, H + 6, rn_stem_padded_width(W), packed, stream);
 }

@@ -112,6 +112,8 @@ _SIGNATURES = {
     "rn_pack_stem_weight": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "rn_stem_padded_width": (c_int, [c_int]),
     "rn_pack_stem_input": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rn_pack_stem_weight_rs": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rn_pack_image_nhwc4": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rn_wgrad_workspace_bytes": (c_size_t, [POINTER(WgradProblem)]),
     "rn_conv2d_nhwc_wgrad": (c_int, [POINTER(WgradProblem), c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
     "rn_pack_conv_weight_dgrad": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -1,3 +1,3 @@
-from retinanet.cfg.config import AttrDict, Config, default_params
+from retinanet.cfg.config import AttrDict, Config, default_params, efficientnet_params
 
-__all__ = ["AttrDict", "Config", "default_params"]
+__all__ = ["AttrDict", "Config", "default_params", "efficientnet_params"]

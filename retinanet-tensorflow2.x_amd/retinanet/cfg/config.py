@@ -117,3 +117,19 @@ def default_params(input_size=640, batch_train=256, batch_val=8, activation="rel
                       "score_threshold": 0.05, "soft_nms_sigma": 0.5, "pre_nms_top_k": 5000,
                       "filter_per_class": True, "max_detections": 100},
     })
+
+
+def efficientnet_params(model_name="efficientnet-b3", input_size=640, filters=160, num_convs=4, activation="relu",
+                        nms_mode="PerClassSoftNMS", precision="mixed_float16", **kw):
+    """The EfficientNet + separable-conv FPN/head schema of
+    configs/v3-32/mscoco-retinanet-efficientnet-b3-896x896-30x-256.json, at BASELINE.json config 4's
+    overrides by default (640x640, soft-NMS, mixed_float16 - computed in bf16 here)."""
+    p = default_params(input_size=input_size, activation=activation, balanced=False, precision=precision,
+                       nms_mode=nms_mode, freeze=(), **kw)
+    p.experiment.name = f"mscoco-retinanet-{model_name}-{input_size}x{input_size}"
+    p.architecture.conv_2d.use_seperable_conv = True
+    p.architecture.backbone = AttrDict({"type": model_name, "checkpoint": ""})
+    p.architecture.feature_fusion.filters = filters
+    p.architecture.head.filters = filters
+    p.architecture.head.num_convs = num_convs
+    return p

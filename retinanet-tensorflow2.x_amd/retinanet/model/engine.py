@@ -45,9 +45,19 @@ class InferenceEngine:
     def _alloc(self):
         for name, (H, W, C, dt) in self.g.tensors.items():
             self.t[name] = torch.empty((self.B, H, W, C), dtype=_DT[dt], device=self.dev)
+        # first-layer conv: the image is repacked to a zero-bordered bf16 NHWC4 buffer (rn_pack_image_nhwc4)
+        stem = next(o for o in self.g.ops if o["op"] == "stem")
+        Hs, Ws = self.g.tensors[stem["out"]][:2]
+        k = stem.get("k", 7)
+        self.stem_k, self.stem_pad = k, (stem.get("pad_top", 3), stem.get("pad_left", 3))
         H, W, _, _ = self.g.tensors["images"]
-        self.Wp = self.lib.rn_stem_padded_width(W)
-        self.stem_in = torch.empty((self.B, H + 6, self.Wp, 4), dtype=torch.bfloat16, device=self.dev)
+        self.Hp = max((Hs - 1) * 2 + k, H + self.stem_pad[0])
+        self.Wp = -(-max((Ws - 1) * 2 + 8, W + self.stem_pad[1]) // 8) * 8
+        self.stem_in = torch.empty((self.B, self.Hp, self.Wp, 4), dtype=torch.bfloat16, device=self.dev)
+        se_ops = [o for o in self.g.ops if o["op"] == "se"]
+        if se_ops:
+            nbytes = max(self.lib.rn_se_workspace_bytes(self.B, self.g.ses[o["se"]]["C"]) for o in se_ops)
+            self.se_ws = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
 
     # ---- weights -----------------------------------------------------------------------------
     def load_variables(self, variables):
@@ -55,19 +65,49 @@ class InferenceEngine:
         lib = self.lib
         st = _C.current_stream()
         self.fold = getattr(self, "fold", {})
+
+        def stable(key, tensor):   # keep addresses stable for a captured graph
+            old = self.packed.get(key)
+            if old is None:
+                self.packed[key] = tensor.contiguous()
+            else:
+                old.copy_(tensor)
+
         for op in self.g.ops:
+            if op["op"] == "se":
+                name = op["se"]
+                se = self.g.ses[name]
+                f32 = lambda n: variables[name + n].to(self.dev, torch.float32)
+                stable(name + ":w1", f32("/conv2d/kernel").reshape(se["C"], se["se"]).t().to(torch.bfloat16))
+                stable(name + ":b1", f32("/conv2d/bias"))
+                stable(name + ":w2", f32("/conv2d_1/kernel").reshape(se["se"], se["C"]).t().to(torch.bfloat16))
+                stable(name + ":b2", f32("/conv2d_1/bias"))
+                continue
+            if op["op"] == "dwconv":
+                d = self.g.dws[op["dw"]]
+                w = variables[d["kvar"]].to(self.dev, torch.float32).contiguous()
+                buf = self.packed.get(op["dw"])
+                if buf is None:
+                    buf = torch.empty((d["k"] * d["k"], d["C"]), dtype=torch.bfloat16, device=self.dev)
+                _C.check(lib.rn_pack_depthwise_weight(_C.ptr(w), d["k"], d["C"], _C.ptr(buf), st),
+                         "rn_pack_depthwise_weight")
+                self.packed[op["dw"]] = buf
+                self._fold(op["out"], variables, op.get("bn"), None)
+                continue
             if op["op"] not in ("conv", "stem"):
                 continue
             cname = op["conv"]
             c = self.g.convs[cname]
-            w = variables[cname + "/kernel"].to(self.dev, torch.float32).contiguous()
+            w = variables[c.get("kvar", cname + "/kernel")].to(self.dev, torch.float32).contiguous()
             cout_pad = lib.rn_conv_cout_pad(c["cout"])
             if cname not in self.packed or True:
                 if op["op"] == "stem":
                     buf = self.packed.get(cname)
+                    k = self.stem_k
                     if buf is None:
-                        buf = torch.empty((cout_pad, 7, 32), dtype=torch.bfloat16, device=self.dev)
-                    _C.check(lib.rn_pack_stem_weight(_C.ptr(w), c["cout"], _C.ptr(buf), st), "rn_pack_stem_weight")
+                        buf = torch.empty((cout_pad, k, 32), dtype=torch.bfloat16, device=self.dev)
+                    _C.check(lib.rn_pack_stem_weight_rs(_C.ptr(w), k, k, c["cout"], _C.ptr(buf), st),
+                             "rn_pack_stem_weight_rs")
                 else:
                     buf = self.packed.get(cname)
                     cin_pad = lib.rn_conv_cin_pad(c["cin"])
@@ -77,32 +117,32 @@ class InferenceEngine:
                     _C.check(lib.rn_pack_conv_weight(_C.ptr(w), c["k"], c["k"], c["cin"], c["cout"], cin_pad,
                                                      _C.ptr(buf), st), "rn_pack_conv_weight")
                 self.packed[cname] = buf
-            # fold: y = conv*scale + shift;  BN inference: gamma*(x+bias-mean)/sqrt(var+eps)+beta
-            key = op["out"]
-            bias = variables.get(cname + "/bias")
-            bias = None if bias is None else bias.to(self.dev, torch.float32)
-            if op.get("bn"):
-                bn = op["bn"]
-                gamma = variables[bn + "/gamma"].to(self.dev, torch.float32)
-                beta = variables[bn + "/beta"].to(self.dev, torch.float32)
-                mean = variables[bn + "/moving_mean"].to(self.dev, torch.float32)
-                var = variables[bn + "/moving_variance"].to(self.dev, torch.float32)
-                scale = gamma / torch.sqrt(var + self.eps)
-                shift = beta - mean * scale
-                if bias is not None:
-                    shift = shift + bias * scale
-            else:
-                scale = None
-                shift = bias
-            old = self.fold.get(key)
-            if old is None:
-                self.fold[key] = [None if scale is None else scale.contiguous(),
-                                  None if shift is None else shift.contiguous()]
-            else:  # keep addresses stable for a captured graph
-                if scale is not None:
-                    old[0].copy_(scale)
-                if shift is not None:
-                    old[1].copy_(shift)
+            self._fold(op["out"], variables, op.get("bn"), variables.get(cname + "/bias"))
+
+    def _fold(self, key, variables, bn, bias):
+        """y = conv*scale + shift;  BN inference: gamma*(x+bias-mean)/sqrt(var+eps)+beta."""
+        bias = None if bias is None else bias.to(self.dev, torch.float32)
+        if bn:
+            gamma = variables[bn + "/gamma"].to(self.dev, torch.float32)
+            beta = variables[bn + "/beta"].to(self.dev, torch.float32)
+            mean = variables[bn + "/moving_mean"].to(self.dev, torch.float32)
+            var = variables[bn + "/moving_variance"].to(self.dev, torch.float32)
+            scale = gamma / torch.sqrt(var + self.eps)
+            shift = beta - mean * scale
+            if bias is not None:
+                shift = shift + bias * scale
+        else:
+            scale = None
+            shift = bias
+        old = self.fold.get(key)
+        if old is None:
+            self.fold[key] = [None if scale is None else scale.contiguous(),
+                              None if shift is None else shift.contiguous()]
+        else:  # keep addresses stable for a captured graph
+            if scale is not None:
+                old[0].copy_(scale)
+            if shift is not None:
+                old[1].copy_(shift)
 
     # ---- launch list -------------------------------------------------------------------------
     def _conv_segment(self, seg, op):
@@ -144,6 +184,34 @@ class InferenceEngine:
             _C.check(lib.rn_conv2d_nhwc_fwd(pref, st), f"rn_conv2d_nhwc_fwd[{name}]")
         self.steps.append((run, "conv:" + name))
 
+    def _add_dw_launch(self, ops):
+        first = ops[0]
+        d0 = self.g.dws[first["dw"]]
+        p = _C.DwProblem()
+        p.k, p.stride, p.pad_top, p.pad_left = d0["k"], d0["stride"], first["pad_top"], first["pad_left"]
+        p.act = _C.ACT_IDS[first["act"]]
+        p.num_segments = len(ops)
+        for i, op in enumerate(ops):
+            d = self.g.dws[op["dw"]]
+            if (d["k"], d["stride"], op["pad_top"], op["pad_left"], op["act"]) != \
+                    (d0["k"], d0["stride"], first["pad_top"], first["pad_left"], first["act"]):
+                raise ValueError(f"depthwise group {first.get('group')} mixes shapes")
+            x, y = self.t[op["inp"]], self.t[op["out"]]
+            scale, shift = self.fold[op["out"]]
+            s = p.seg[i]
+            s.x, s.w, s.y = x.data_ptr(), self.packed[op["dw"]].data_ptr(), y.data_ptr()
+            s.scale = scale.data_ptr() if scale is not None else None
+            s.shift = shift.data_ptr() if shift is not None else None
+            s.N, s.H, s.W, s.C, s.Ho, s.Wo = self.B, x.shape[1], x.shape[2], d["C"], y.shape[1], y.shape[2]
+        self._keep.append(p)
+        lib = self.lib
+        pref = ctypes.byref(p)
+        name = first.get("group") or first["out"]
+
+        def run(st):
+            _C.check(lib.rn_depthwise_conv2d_nhwc_fwd(pref, st), f"rn_depthwise_conv2d_nhwc_fwd[{name}]")
+        self.steps.append((run, "dwconv:" + name))
+
     def _build(self):
         lib = self.lib
         B = self.B
@@ -157,11 +225,12 @@ class InferenceEngine:
                 c = self.g.convs[op["conv"]]
                 pin, pout, pimg = self.stem_in.data_ptr(), y.data_ptr(), img.data_ptr()
 
-                def pack(st, pimg=pimg, pin=pin, H=H, W=W):
-                    _C.check(lib.rn_pack_stem_input(pimg, B, H, W, pin, st), "rn_pack_stem_input")
+                def pack(st, pimg=pimg, pin=pin, H=H, W=W, pt=self.stem_pad[0], pl=self.stem_pad[1]):
+                    _C.check(lib.rn_pack_image_nhwc4(pimg, B, H, W, pt, pl, self.Hp, self.Wp, pin, st),
+                             "rn_pack_image_nhwc4")
                 self.steps.append((pack, "pack_stem_input"))
                 p = _C.ConvProblem()
-                p.R, p.S, p.stride_h, p.stride_w, p.pad_top, p.pad_left = 7, 1, 2, 2, 0, 0
+                p.R, p.S, p.stride_h, p.stride_w, p.pad_top, p.pad_left = self.stem_k, 1, 2, 2, 0, 0
                 p.act = _C.ACT_IDS[op["act"]]
                 p.out_dtype = _C.RN_DT_BF16
                 p.num_segments = 1
@@ -169,7 +238,7 @@ class InferenceEngine:
                 scale, shift = self.fold[op["out"]]
                 s.x, s.w, s.y = pin, self.packed[op["conv"]].data_ptr(), pout
                 s.scale, s.shift, s.residual = scale.data_ptr(), shift.data_ptr(), None
-                s.N, s.H, s.W, s.Cin, s.pix_stride = B, H + 6, self.Wp, 32, 4
+                s.N, s.H, s.W, s.Cin, s.pix_stride = B, self.Hp, self.Wp, 32, 4
                 s.Ho, s.Wo, s.Cout = y.shape[1], y.shape[2], c["cout"]
                 self._keep.append(p)
                 pref = ctypes.byref(p)
@@ -184,6 +253,23 @@ class InferenceEngine:
                 elif grp not in done_groups:
                     done_groups.add(grp)
                     self._add_conv_launch([o for o in self.g.ops if o["op"] == "conv" and o.get("group") == grp])
+            elif kind == "dwconv":
+                grp = op.get("group")
+                if grp is None:
+                    self._add_dw_launch([op])
+                elif grp not in done_groups:
+                    done_groups.add(grp)
+                    self._add_dw_launch([o for o in self.g.ops if o["op"] == "dwconv" and o.get("group") == grp])
+            elif kind == "se":
+                x = self.t[op["tensor"]]
+                name, se = op["se"], self.g.ses[op["se"]]
+                args = (x.data_ptr(), B, x.shape[1] * x.shape[2], se["C"], self.packed[name + ":w1"].data_ptr(),
+                        self.packed[name + ":b1"].data_ptr(), self.packed[name + ":w2"].data_ptr(),
+                        self.packed[name + ":b2"].data_ptr(), se["se"], self.se_ws.data_ptr(), self.se_ws.numel())
+
+                def se_run(st, args=args, name=name):
+                    _C.check(lib.rn_squeeze_excite_inplace(*args, st), f"rn_squeeze_excite_inplace[{name}]")
+                self.steps.append((se_run, "se:" + op["tensor"]))
             elif kind == "maxpool":
                 x, y = self.t[op["inp"]], self.t[op["out"]]
                 args = (x.data_ptr(), y.data_ptr(), B, x.shape[1], x.shape[2], x.shape[3], op["k"], op["stride"],

@@ -33,11 +33,41 @@ class Graph:
         self.tensors[name] = (H, W, C, dtype)
         return name
 
-    def add_conv_layer(self, name, k, cin, cout, stride, bias, init, bias_init=0.0):
-        self.convs[name] = dict(k=k, cin=cin, cout=cout, stride=stride, bias=bias)
-        self.var_specs[name + "/kernel"] = dict(shape=(k, k, cin, cout), init=init)
+    def add_conv_layer(self, name, k, cin, cout, stride, bias, init, bias_init=0.0, kernel_var=None):
+        kv = kernel_var or (name + "/kernel")
+        self.convs[name] = dict(k=k, cin=cin, cout=cout, stride=stride, bias=bias, kvar=kv, bvar=name + "/bias")
+        self.var_specs[kv] = dict(shape=(k, k, cin, cout), init=init)
         if bias:
             self.var_specs[name + "/bias"] = dict(shape=(cout,), init="const", value=bias_init)
+
+    def add_dw_layer(self, name, k, C, stride, init, kernel_var=None):
+        """DepthwiseConv2D / the depthwise half of SeparableConv2D: kernel [k,k,C,1]."""
+        kv = kernel_var or (name + "/depthwise_kernel")
+        self.dws = getattr(self, "dws", OrderedDict())
+        self.dws[name] = dict(k=k, C=C, stride=stride, kvar=kv)
+        self.var_specs[kv] = dict(shape=(k, k, C, 1), init=init)
+
+    def add_se_layer(self, name, C, se):
+        self.ses = getattr(self, "ses", OrderedDict())
+        self.ses[name] = dict(C=C, se=se)
+        self.var_specs[name + "/conv2d/kernel"] = dict(shape=(1, 1, C, se), init="effnet_conv")
+        self.var_specs[name + "/conv2d/bias"] = dict(shape=(se,), init="const", value=0.0)
+        self.var_specs[name + "/conv2d_1/kernel"] = dict(shape=(1, 1, se, C), init="effnet_conv")
+        self.var_specs[name + "/conv2d_1/bias"] = dict(shape=(C,), init="const", value=0.0)
+
+    def dwconv(self, out, inp, dw, bn=None, act=None, group=None):
+        d = self.dws[dw]
+        H, W, C, _ = self.tensors[inp]
+        assert C == d["C"], (dw, C, d["C"])
+        k, s = d["k"], d["stride"]
+        Ho, Wo = -(-H // s), -(-W // s)
+        # TF SAME: total = max((Ho-1)*s + k - H, 0), before = total // 2
+        pt = max((Ho - 1) * s + k - H, 0) // 2
+        pl = max((Wo - 1) * s + k - W, 0) // 2
+        self.tensor(out, Ho, Wo, C)
+        self.ops.append(dict(op="dwconv", out=out, inp=inp, dw=dw, bn=bn, act=act, group=group, pad_top=pt,
+                             pad_left=pl))
+        return out
 
     def add_bn_layer(self, name, C, gamma_zero=False):
         self.bns[name] = dict(C=C, gamma_zero=gamma_zero)
@@ -72,14 +102,15 @@ def _conv_name(i):
 
 def build_retinanet_graph(params, sync_bn_names=False):
     arch = params.architecture
-    if "resnet" not in arch.backbone.type.lower():
-        raise NotImplementedError(f"backbone {arch.backbone.type}: only the ResNet family is built so far "
-                                  "(EfficientNet-B3 is SURVEY §8 row a18, next)")
-    depth = int(arch.backbone.depth)
-    if depth not in _RESNET_LAYERS:
-        raise ValueError(f"unsupported bottleneck ResNet depth {depth}")
-    if arch.conv_2d.use_seperable_conv:
-        raise NotImplementedError("use_seperable_conv is only used by the EfficientNet/MobileDet configs")
+    btype = arch.backbone.type.lower()
+    if "resnet" not in btype and not btype.startswith("efficientnet-b"):
+        raise NotImplementedError(f"backbone {arch.backbone.type}: the ResNet and EfficientNet-B families are built; "
+                                  "EfficientNet-lite / MobileDet are out of scope (SURVEY §2.1)")
+    if "resnet" in btype:
+        depth = int(arch.backbone.depth)
+        if depth not in _RESNET_LAYERS:
+            raise ValueError(f"unsupported bottleneck ResNet depth {depth}")
+    separable = bool(arch.conv_2d.use_seperable_conv)
     if arch.feature_fusion.type != "fpn":
         raise ValueError("{} FPN not implemented".format(arch.feature_fusion.type))
     if arch.feature_fusion.fusion_mode != "sum":
@@ -102,8 +133,12 @@ def build_retinanet_graph(params, sync_bn_names=False):
         cidx[0] += 1
         return name
 
-    # ---- ResNet (resnet.py:289-341); ResNet blocks always use ReLU (resnet.py:68-69) ---------
     g.tensor("images", H, W, 3, "f32")
+    if btype.startswith("efficientnet-b"):
+        from retinanet.model.graph_efficientnet import build_efficientnet_backbone
+        feats = build_efficientnet_backbone(g, btype, H, W, sync_bn_names)
+        return _build_fpn_and_heads(g, params, feats, act, sync_bn_names, separable)
+    # ---- ResNet (resnet.py:289-341); ResNet blocks always use ReLU (resnet.py:68-69) ---------
     c = rconv(7, 3, 64, 2)
     b = rbn(64)
     Hs, Ws = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
@@ -137,7 +172,28 @@ def build_retinanet_graph(params, sync_bn_names=False):
             x = g.conv(pre + "_out", t, c3, b3, act="relu", residual=shortcut)
             cin = 4 * filters
         feats[str(gi + 2)] = x
+    return _build_fpn_and_heads(g, params, feats, act, sync_bn_names, separable)
 
+
+def _conv_or_sep(g, separable, out, inp, name, k, cout, bias_init, init, bn, act, group, out_dtype="bf16",
+                 define=True):
+    """tf.keras.layers.Conv2D or SeparableConv2D (fpn_base.py:28-39, detection_head.py:37-50): the
+    separable form is a depthwise k x k (no bias, no activation) followed by a pointwise 1x1 + bias."""
+    cin = g.tensors[inp][2]
+    if not separable:
+        if define:
+            g.add_conv_layer(name, k, cin, cout, 1, bias=True, init=init, bias_init=bias_init)
+        return g.conv(out, inp, name, bn, act=act, group=group, out_dtype=out_dtype)
+    if define:
+        g.add_dw_layer(name + ":dw", k, cin, 1, "variance_scaling", kernel_var=name + "/depthwise_kernel")
+        g.add_conv_layer(name, 1, cin, cout, 1, bias=True, init="variance_scaling", bias_init=bias_init,
+                         kernel_var=name + "/pointwise_kernel")
+    g.dwconv(out + ":dw", inp, name + ":dw", bn=None, act=None, group=(group + ":dw") if group else None)
+    return g.conv(out, out + ":dw", name, bn, act=act, group=group, out_dtype=out_dtype, pad=0)
+
+
+def _build_fpn_and_heads(g, params, feats, act, sync_bn_names, separable):
+    arch = params.architecture
     # ---- FPN (fpn_base.py:54-71, fpn.py:81-107) ------------------------------------------------
     ff = arch.feature_fusion
     F = int(ff.filters)
@@ -145,10 +201,9 @@ def build_retinanet_graph(params, sync_bn_names=False):
     bn_tag = "sync_batch_normalization" if sync_bn_names else "batch_normalization"
     top = feats[str(bmax)]
     ctop = g.tensors[top][2]
-    g.add_conv_layer("fpn/backbone_max_level_conv_1x1", 1, ctop, F, 1, bias=True, init="variance_scaling")
     g.add_bn_layer(f"fpn/backbone_max_level_{bn_tag}", F)
-    g.conv("fpn_c6pre", top, "fpn/backbone_max_level_conv_1x1", f"fpn/backbone_max_level_{bn_tag}", act=None,
-           group="fpn_1x1")
+    _conv_or_sep(g, separable, "fpn_c6pre", top, "fpn/backbone_max_level_conv_1x1", 1, F, 0.0, "variance_scaling",
+                 f"fpn/backbone_max_level_{bn_tag}", None, None if separable else "fpn_1x1")
     prev = "fpn_c6pre"
     for level in range(bmax + 1, hi + 1):
         Hl, Wl = g.tensors[prev][0] // 2, g.tensors[prev][1] // 2
@@ -159,9 +214,9 @@ def build_retinanet_graph(params, sync_bn_names=False):
         src = feats[str(level)]
         name = f"fpn/p{level}-in-channel-normalize-conv-1x1"
         bn = f"fpn/p{level}-in-channel-normalize-{bn_tag}"
-        g.add_conv_layer(name, 1, g.tensors[src][2], F, 1, bias=True, init="variance_scaling")
         g.add_bn_layer(bn, F)
-        g.conv(f"fpn_in{level}", src, name, bn, act=None, group="fpn_1x1")
+        _conv_or_sep(g, separable, f"fpn_in{level}", src, name, 1, F, 0.0, "variance_scaling", bn, None,
+                     None if separable else "fpn_1x1")
     levels = list(range(lo, hi + 1))
     for level in levels[:-1]:
         Hl, Wl, _, _ = g.tensors[f"fpn_in{level}"]
@@ -171,10 +226,10 @@ def build_retinanet_graph(params, sync_bn_names=False):
     for level in levels:
         name = f"fpn/p{level}-out-conv-3x3"
         bn = f"fpn/p{level}-out-{bn_tag}"
-        g.add_conv_layer(name, 3, F, F, 1, bias=True, init="variance_scaling")
         g.add_bn_layer(bn, F)
         src = f"fpn_td{level}" if level != hi else f"fpn_in{hi}"
-        g.conv(f"fpn_out{level}", src, name, bn, act=None, group="fpn_out")
+        _conv_or_sep(g, separable, f"fpn_out{level}", src, name, 3, F, 0.0, "variance_scaling", bn, None,
+                     "fpn_out")
     feat = {l: f"fpn_out{l}" for l in levels}
     if ff.use_balanced_features:
         g.ops.append(dict(op="balance", tensors=[feat[l] for l in levels], mid=1))  # min_level + 1
@@ -184,26 +239,28 @@ def build_retinanet_graph(params, sync_bn_names=False):
     nconv, HF = int(hd.num_convs), int(hd.filters)
     A, K = int(hd.num_anchors), int(hd.num_classes)
     outs = {"box": {}, "class": {}}
-    for head, ofilt, bias_init in (("box-head", A * 4, 0.0),
-                                   ("class-head", A * K, -float(np.log((1 - 0.01) / 0.01)))):
+    head_init = "variance_scaling" if separable else "normal_0.01"
+    for head in ("box-head", "class-head"):
         for i in range(nconv):
-            g.add_conv_layer(f"{head}/{head}-{i}-conv2d", 3, F if i == 0 else HF, HF, 1, bias=True,
-                             init="normal_0.01")
             for level in levels:
                 g.add_bn_layer(f"{head}/{head}-{i}-p{level}-{bn_tag}", HF)
-        g.add_conv_layer(f"{head}/{head}-prediction-conv2d", 3, HF, ofilt, 1, bias=True, init="normal_0.01",
-                         bias_init=bias_init)
+    defined = set()
     for i in range(nconv):
         for head in ("box-head", "class-head"):
             for level in levels:
                 src = feat[level] if i == 0 else f"{head}_t{i - 1}_p{level}"
-                g.conv(f"{head}_t{i}_p{level}", src, f"{head}/{head}-{i}-conv2d",
-                       f"{head}/{head}-{i}-p{level}-{bn_tag}", act=act, group=f"tower{i}")
-    for head, key in (("box-head", "box"), ("class-head", "class")):
+                name = f"{head}/{head}-{i}-conv2d"
+                _conv_or_sep(g, separable, f"{head}_t{i}_p{level}", src, name, 3, HF, 0.0, head_init,
+                             f"{head}/{head}-{i}-p{level}-{bn_tag}", act, f"tower{i}", define=name not in defined)
+                defined.add(name)
+    for head, key, ofilt, bias_init in (("box-head", "box", A * 4, 0.0),
+                                       ("class-head", "class", A * K, -float(np.log((1 - 0.01) / 0.01)))):
         for level in levels:
             src = f"{head}_t{nconv - 1}_p{level}" if nconv else feat[level]
-            g.conv(f"{head}_pred_p{level}", src, f"{head}/{head}-prediction-conv2d", None, act=None,
-                   group=f"pred_{key}", out_dtype="f32")
+            name = f"{head}/{head}-prediction-conv2d"
+            _conv_or_sep(g, separable, f"{head}_pred_p{level}", src, name, 3, ofilt, bias_init, head_init, None, None,
+                         f"pred_{key}", out_dtype="f32", define=name not in defined)
+            defined.add(name)
             outs[key][str(level)] = f"{head}_pred_p{level}"
     g.outputs = {"class-predictions": outs["class"], "box-predictions": outs["box"]}
     g.levels = levels
@@ -228,6 +285,9 @@ def init_variables(graph, seed=1337, device="cpu"):
             std = math.sqrt(1.0 / fan_in) / 0.87962566103423978
             t = torch.empty(shape, dtype=torch.float32)
             torch.nn.init.trunc_normal_(t, mean=0.0, std=std, a=-2 * std, b=2 * std, generator=gen)
+        elif spec["init"] == "effnet_conv":   # efficientnet.py:116-140: N(0, sqrt(2 / fan_out))
+            fan_out = shape[0] * shape[1] * shape[3]
+            t = torch.empty(shape, dtype=torch.float32).normal_(0.0, math.sqrt(2.0 / fan_out), generator=gen)
         elif spec["init"] == "normal_0.01":
             t = torch.empty(shape, dtype=torch.float32).normal_(0.0, 0.01, generator=gen)
         else:

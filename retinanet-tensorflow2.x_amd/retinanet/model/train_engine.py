@@ -97,6 +97,9 @@ class TrainEngine:
                     self.requires[o] = r or self.requires.get(o, False)
             elif kind == "balance":
                 pass
+            else:
+                raise NotImplementedError(f"training through '{kind}' ops (EfficientNet / SeparableConv2D, SURVEY §8 "
+                                          "row a18) is not built yet: only their inference path is")
         # a conv layer is "live" when its kernel trains; mixed frozen conv / live BN is not a shipped case
         for op in g.ops:
             if op["op"] in ("conv", "stem") and op.get("bn") and self._conv_trainable(op) != bool(self._bn_trainable(op)):

@@ -54,13 +54,39 @@ def test_unsupported_configs_fail_loudly():
     from retinanet.cfg import default_params
     from retinanet.model.graph import build_retinanet_graph
     p = default_params()
-    p.architecture.backbone.type = "efficientnet-b3"
+    p.architecture.backbone.type = "efficientnet-lite3"
     with pytest.raises(NotImplementedError):
         build_retinanet_graph(p)
     p = default_params()
     p.architecture.feature_fusion.type = "bifpn"
     with pytest.raises(ValueError):
         build_retinanet_graph(p)
+
+
+def test_efficientnet_b3_graph_inventory():
+    """B3 features '2'..'5' = 32/48/136/384 channels at strides 4/8/16/32; separable
+    FPN/heads at 160 filters; Keras variable names of MBConvBlock._build (efficientnet.py:335-421)."""
+    from retinanet.cfg import efficientnet_params
+    from retinanet.model.graph import build_retinanet_graph
+    from retinanet.model.graph_efficientnet import block_table, round_filters
+    t = block_table("efficientnet-b3")
+    assert round_filters(32, 1.2) == 40 and len(t) == 26
+    assert [(b["cin"], b["cout"], b["k"], b["stride"]) for b in t[:3]] == [(40, 24, 3, 1), (24, 24, 3, 1), (24, 32, 3, 2)]
+    assert (t[-1]["cout"], t[0]["se"], t[2]["se"], t[-1]["se"]) == (384, 10, 6, 96)
+    g = build_retinanet_graph(efficientnet_params(input_size=640))
+    assert [g.tensors[n][:3] for n in ("b4_out", "b7_out", "b17_out", "b25_out")] == \
+        [(160, 160, 32), (80, 80, 48), (40, 40, 136), (20, 20, 384)]
+    for name in ("efficientnet-b3/blocks_0/tpu_batch_normalization_1/gamma",      # e1 block: 2 BNs, 1 conv
+                 "efficientnet-b3/blocks_0/conv2d/kernel",
+                 "efficientnet-b3/blocks_2/conv2d_1/kernel", "efficientnet-b3/blocks_2/tpu_batch_normalization_2/beta",
+                 "efficientnet-b3/blocks_2/depthwise_conv2d/depthwise_kernel",
+                 "efficientnet-b3/blocks_2/se/conv2d_1/bias", "efficientnet-b3/stem/conv2d/kernel",
+                 "fpn/p3-out-conv-3x3/depthwise_kernel", "fpn/p3-out-conv-3x3/pointwise_kernel",
+                 "class-head/class-head-prediction-conv2d/pointwise_kernel", "class-head/class-head-prediction-conv2d/bias"):
+        assert name in g.var_specs, name
+    assert "efficientnet-b3/blocks_0/conv2d_1/kernel" not in g.var_specs
+    assert g.var_specs["class-head/class-head-prediction-conv2d/pointwise_kernel"]["shape"] == (1, 1, 160, 720)
+    assert g.tensors[g.outputs["class-predictions"]["3"]] == (80, 80, 720, "f32")
 
 
 def test_lr_schedules_match_oracle():
