@@ -25,49 +25,7 @@
 //   * blockIdx -> tile map is XCD aware: consecutive tiles (same A rows, neighbouring n tiles)
 //     land on the same XCD's L2 (blocks are dispatched round-robin over the 8 XCDs).
 // Roofline: MFMA-bound for K >= ~512; the small-K 1x1 convs of ResNet stage 1-2 are HBM-bound.
-#include "rn_common.h"
-
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef float f32x16_t __attribute__((ext_vector_type(16)));
-
-#define CONV_THREADS 256
-
-struct ConvSegDev {
-  const uint16_t* x;
-  const uint16_t* w;
-  void* y;
-  const float* scale;
-  const float* shift;
-  const uint16_t* residual;
-  int N, H, W, Cin, pix_stride, Ho, Wo, Cout;
-  int M, tile_begin, n_tiles, CinP;  // CinP = Cin rounded up to the K step (weights are zero padded)
-};
-
-struct ConvArgs {
-  int R, S, sh, sw, pt, pl, act, nseg, total_tiles, pad_;
-  ConvSegDev seg[RN_CONV_MAX_SEGMENTS];
-};
-
-template <int BK>
-__device__ __forceinline__ int lds_swz(int row) {
-  constexpr int SLOTS = BK / 8;        // 16-byte slots per row
-  constexpr int RPB = 256 / (BK * 2);  // rows per 256-byte bank row
-  return (row / RPB) % SLOTS;
-}
-template <int BK>
-__device__ __forceinline__ int lds_slot_off(int row, int slot) {
-  return (row * (BK / 8) + (slot ^ lds_swz<BK>(row))) * 16;
-}
-
-typedef __attribute__((address_space(3))) void lds_void_t;
-
-// 16-byte buffer load straight into LDS (no VGPR round trip).  LDS address = M0 base (wave
-// uniform) + lane*16; the global source offset is per lane; out-of-range offsets write zeros.
-__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, unsigned voff) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)lds_wave_base, 16, (int)voff, 0, 0, 0);
-}
-
-#define RN_OOB 0x80000000u
+#include "rn_conv_dev.h"
 
 // ABL: ablation mask for tools/bench_conv.py (0 in production): 1 = B tile loaded once,
 // 2 = A tile loaded once, 4 = no MFMA.
@@ -211,7 +169,9 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_fwd_kernel(const ConvArg
     }                 \
   } while (0)
 
-  if (STAGES == 2) {
+  if (ABL & 32) {
+    // ablation: no main loop at all (launch + prologue + epilogue cost)
+  } else if (STAGES == 2) {
     RN_ISSUE_TILE(0, 0, 0);
     RN_ADVANCE();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -310,6 +270,17 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_fwd_kernel(const ConvArg
 #undef RN_ISSUE_TILE
 
   // ---- epilogue ------------------------------------------------------------------------------
+  if (ABL & 16) {   // ablation: no epilogue (one never-taken store keeps the accumulators alive)
+    float t = 0.0f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+    if (t == 123.456f) ((float*)sg.y)[tid] = t;
+    return;
+  }
   // stage 1: registers -> LDS fp32 [BM][BN], with the per-channel affine applied
   float* cl = (float*)smem;
   const int Cout = sg.Cout;
@@ -355,6 +326,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_fwd_kernel(const ConvArg
       v.y = rn_apply_act(v.y, args.act);
       v.z = rn_apply_act(v.z, args.act);
       v.w = rn_apply_act(v.w, args.act);
+      if ((ABL & 8) && v.x != 123.456f) continue;   // ablation: no global stores
       if (OUT_F32) {
         *(float4*)((float*)sg.y + o) = v;
       } else {
@@ -418,12 +390,18 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
   // tail of the last K step reads past the pixel's channels (or out of range -> zeros) and meets the
   // zero-padded weight columns, so it contributes nothing.
   const int BK = rn_conv_cin_pad(p->seg[0].Cin) % 64 == 0 ? 64 : 32;
-  // The 256x128x64 three-stage kernel (8 waves, DMA + fragment registers double buffered) is built and
-  // tested but NOT selected by default: measured on MI355X it ties the 128x128 two-stage kernel to
-  // within 1 % on the large layers (tower conv B=32: 899 vs 889 us) and loses on mid-size ones
-  // (g2 3x3: 123 vs 106 us), i.e. the limiter is not the staging depth.
-  const bool big = g_conv_force_big && BN == 128 && BK == 64 && !g_conv_force_small;
-  const int BM = (big && BN == 128 && BK == 64) ? 256 : 128;
+  // 256 x 256 x 32 tiles (rn_conv_big.hip) for the MFMA-bound layers: every segment at least 256 output
+  // channels wide, and enough tiles to fill the 256 CUs (one workgroup per CU) a few times over.
+  bool big = !g_conv_force_small;
+  long long tiles256 = 0;
+  for (int i = 0; i < p->num_segments && big; ++i) {
+    const rn_conv_segment& s = p->seg[i];
+    if (rn_conv_cout_pad(s.Cout) < 256 || s.Cout % 8 != 0) big = false;
+    tiles256 += rn_cdiv((long long)s.N * s.Ho * s.Wo, 256) * rn_cdiv(s.Cout, 256);
+  }
+  if (big && !g_conv_force_big && tiles256 < 384) big = false;
+  const int BM = big ? 256 : 128;
+  const int BNT = big ? 256 : BN;   // n-tile width
   int tiles = 0;
   for (int i = 0; i < p->num_segments; ++i) {
     const rn_conv_segment& s = p->seg[i];
@@ -450,7 +428,7 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
     d.Ho = s.Ho; d.Wo = s.Wo; d.Cout = s.Cout;
     d.M = (int)M;
     d.tile_begin = tiles;
-    d.n_tiles = cp / BN;
+    d.n_tiles = (int)rn_cdiv(cp, BNT);
     d.CinP = rn_conv_cin_pad(s.Cin);
     tiles += (int)rn_cdiv(M, BM) * d.n_tiles;
   }
@@ -466,11 +444,14 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
       case 5: return launch_ablate<5>(a, st);
       case 6: return launch_ablate<6>(a, st);
       case 7: return launch_ablate<7>(a, st);
+      case 8: return launch_ablate<8>(a, st);
+      case 16: return launch_ablate<16>(a, st);
+      case 32: return launch_ablate<32>(a, st);
+      case 48: return launch_ablate<48>(a, st);
       default: break;
     }
   }
-  if (BM == 256)
-    return f32 ? launch_conv<256, 128, 64, true, 4, 2, 3>(a, st) : launch_conv<256, 128, 64, false, 4, 2, 3>(a, st);
+  if (big) return rn_launch_conv_big(a, f32, st);
   if (BN == 128 && BK == 64) return f32 ? launch_conv<128, 128, 64, true>(a, st) : launch_conv<128, 128, 64, false>(a, st);
   if (BN == 64 && BK == 64) return f32 ? launch_conv<128, 64, 64, true>(a, st) : launch_conv<128, 64, 64, false>(a, st);
   if (BN == 128 && BK == 32) return f32 ? launch_conv<128, 128, 32, true>(a, st) : launch_conv<128, 128, 32, false>(a, st);

@@ -1,0 +1,52 @@
+// rn_conv_dev.h — device-side declarations shared by the implicit-GEMM conv kernels
+// (rn_conv.hip: 128-row tiles; rn_conv_big.hip: 256 x 256 tiles).
+#ifndef RN_CONV_DEV_H_
+#define RN_CONV_DEV_H_
+#include "rn_common.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+#define CONV_THREADS 256
+
+struct ConvSegDev {
+  const uint16_t* x;
+  const uint16_t* w;
+  void* y;
+  const float* scale;
+  const float* shift;
+  const uint16_t* residual;
+  int N, H, W, Cin, pix_stride, Ho, Wo, Cout;
+  int M, tile_begin, n_tiles, CinP;  // CinP = Cin rounded up to the K step (weights are zero padded)
+};
+
+struct ConvArgs {
+  int R, S, sh, sw, pt, pl, act, nseg, total_tiles, pad_;
+  ConvSegDev seg[RN_CONV_MAX_SEGMENTS];
+};
+
+template <int BK>
+__device__ __forceinline__ int lds_swz(int row) {
+  constexpr int SLOTS = BK / 8;        // 16-byte slots per row
+  constexpr int RPB = 256 / (BK * 2);  // rows per 256-byte bank row
+  return (row / RPB) % SLOTS;
+}
+template <int BK>
+__device__ __forceinline__ int lds_slot_off(int row, int slot) {
+  return (row * (BK / 8) + (slot ^ lds_swz<BK>(row))) * 16;
+}
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+// 16-byte buffer load straight into LDS (no VGPR round trip).  LDS address = M0 base (wave
+// uniform) + lane*16; the global source offset is per lane; out-of-range offsets write zeros.
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, unsigned voff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)lds_wave_base, 16, (int)voff, 0, 0, 0);
+}
+
+#define RN_OOB 0x80000000u
+
+
+// rn_conv_big.hip
+int rn_launch_conv_big(const ConvArgs& a, bool out_f32, hipStream_t st);
+#endif  // RN_CONV_DEV_H_

@@ -99,6 +99,9 @@ CASES = [
     (2, 9, 9, 40, 144, 1, 1, "swish", False, False),     # EfficientNet widths: Cin 40 (pad 64), Cout 144
     (1, 6, 6, 816, 136, 1, 1, None, True, False),        # MBConv project conv 816 -> 136 + skip
     (1, 8, 8, 24, 32, 3, 1, "relu", False, False),       # Cin 24 -> BK 32
+    (2, 24, 24, 256, 256, 3, 1, "relu", True, False),    # 4.5 M tiles of 256, residual
+    (3, 17, 19, 128, 512, 1, 1, "swish", False, False),  # 2 n-tiles of 256, M tail
+    (1, 20, 20, 256, 720, 3, 1, None, False, True),      # class prediction conv, f32 out, 3 n-tiles of 256
 ]
 
 
@@ -117,10 +120,11 @@ def test_conv_single(cuda, case):
     _close(got, _conv_ref(s, k, stride, pad, act, out_f32), out_f32)
 
 
-@pytest.mark.parametrize("case", [c for c in CASES if c[4] > 64 and c[3] % 64 == 0],
+@pytest.mark.parametrize("case", [c for c in CASES if c[4] > 128 and c[4] % 8 == 0],
                          ids=lambda c: "big-" + "x".join(str(v) for v in c))
 def test_conv_big_tile_kernel(cuda, case):
-    """Same cases through the 256x128x64 three-stage kernel (normally picked only for large M)."""
+    """Same cases through the 256x256x32 four-stage kernel (rn_conv_big.hip; normally picked only
+    when the launch has >= 384 such tiles)."""
     from retinanet import _C
     lib = _C.lib()
     lib.rn_debug_conv_tile(2)

@@ -14,6 +14,8 @@ from retinanet import _C  # noqa: E402
 PRESETS = {
     # name: (list of (H, Cin, Cout) segments, k, stride, out_f32, residual)
     "tower": ([(s, 256, 256) for s in (80, 40, 20, 10, 5)] * 2, 3, 1, False, False),
+    "tower_1x1": ([(s, 256, 256) for s in (80, 40, 20, 10, 5)] * 2, 1, 1, False, False),
+    "tower_c64": ([(s, 64, 256) for s in (80, 40, 20, 10, 5)] * 2, 1, 1, False, False),
     "pred_class": ([(s, 256, 720) for s in (80, 40, 20, 10, 5)], 3, 1, True, False),
     "g1_3x3": ([(160, 64, 64)], 3, 1, False, False),
     "g1_out": ([(160, 64, 256)], 1, 1, False, True),
@@ -32,11 +34,12 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--ablate", type=int, default=0)
-    ap.add_argument("--tile", type=int, default=0, help="1 = force 128-row kernel, 2 = force 256-row kernel")
+    ap.add_argument("--tile", type=int, default=0, help="1 = force 128-row kernel, 2 = force the 256x256 kernel")
     a = ap.parse_args()
     lib = _C.lib()
     if a.ablate:
         lib.rn_debug_conv_ablate(a.ablate)
+        lib.rn_debug_conv_big_ablate(a.ablate)
     if a.tile:
         lib.rn_debug_conv_tile(a.tile)
     dev = torch.device("cuda:0")
@@ -74,6 +77,13 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / a.iters
+        if a.ablate & 64:
+            buf = (ctypes.c_longlong * 64)()
+            lib.rn_debug_conv_big_timing(buf)
+            names = ["ds_read issue", "dma issue", "vmcnt wait", "lgkm wait", "barrier(after load)", "mfma seg",
+                     "barrier(after mfma)", "loop overhead"]
+            for w in range(8):
+                print("wave", w, " ".join(f"{names[k]}={buf[w * 8 + k]}" for k in range(8)))
         print(f"{name:12s} B={a.batch} {ms * 1e3:9.1f} us  {flops / ms / 1e9:8.1f} TFLOP/s  "
               f"{byts / ms / 1e6:8.1f} GB/s (algorithmic {byts / 1e6:.1f} MB)", flush=True)
 
