@@ -39,12 +39,13 @@ __device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 
 
 // ABL (tools/bench_conv.py --ablate, 0 in production): 1 = no DMA inside the K loop, 2 = no ds_read inside
 // the K loop, 4 = no MFMA, 8 = no epilogue.
-__device__ long long g_big_timing[8 * 8];   // [wave][phase] cycle sums of workgroup 300 (ABL & 64)
+__device__ long long g_big_timing[8 * 8 + 2];   // [wave][phase] cycle sums of workgroup 300 (ABL & 64)
 
 template <bool OUT_F32, int ABL = 0>
 __global__ void __launch_bounds__(512) conv_big_kernel(const ConvArgs args) {
   long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long t_prev = 0;
+  const long long k_c0 = (ABL & 64) ? clock64() : 0, k_w0 = (ABL & 64) ? wall_clock64() : 0;
 #define BIG_STAMP(k_)                              \
   do {                                             \
     if (ABL & 64) {                                \
@@ -120,12 +121,16 @@ __global__ void __launch_bounds__(512) conv_big_kernel(const ConvArgs args) {
   // ---- fragment read offsets ---------------------------------------------------------------------
   // row = lane&31 of a 32-row tile, 16-byte slot = 2*kk + (lane>>5), XOR-swizzled by (row/4)&3; the
   // swizzle only depends on lane&31 because every tile starts at a multiple of 16 rows.
-  const int fr = lane & 31, fh = lane >> 5;
-  const int sw = (fr >> 2) & 3;
-  const int off_p0 = (wave_m * 128 + fr) * 64 + ((0 + fh) ^ sw) * 16;            // pixels, kk = 0
-  const int off_p1 = (wave_m * 128 + fr) * 64 + ((2 + fh) ^ sw) * 16;            // pixels, kk = 1
-  const int off_w0 = A_BYTES + (wave_n * 64 + fr) * 64 + ((0 + fh) ^ sw) * 16;   // weights
-  const int off_w1 = A_BYTES + (wave_n * 64 + fr) * 64 + ((2 + fh) ^ sw) * 16;
+  int off_p0, off_w0;
+  {
+    const int fr = lane & 31, fh = lane >> 5;
+    const int sw = (fr >> 2) & 3;
+    off_p0 = (wave_m * 128 + fr) * 64 + ((0 + fh) ^ sw) * 16;            // pixels, kk = 0
+    off_w0 = A_BYTES + (wave_n * 64 + fr) * 64 + ((0 + fh) ^ sw) * 16;   // weights, kk = 0
+  }
+  // kk = 1: slot index ^ 2 = byte offset ^ 32
+#define off_p1 (off_p0 ^ 32)
+#define off_w1 (off_w0 ^ 32)
 
   f32x16_t acc[4][2];
 #pragma unroll
@@ -176,72 +181,74 @@ __global__ void __launch_bounds__(512) conv_big_kernel(const ConvArgs args) {
   } while (0)
 
   int tap = 0, c0 = 0;  // coordinates of the NEXT tile to issue
-  // group 0 (which loads in the odd slots) runs one tile further ahead than group 1, so both get
-  // four slots (two K steps) between issuing a piece and having to publish it
-  const int pre = wave_m == 0 ? (ksteps < 4 ? ksteps : 4) : (ksteps < 3 ? ksteps : 3);
+  const int pre = ksteps < 4 ? ksteps : 4;
 #pragma unroll 1
   for (int t = 0; t < pre; ++t) {
     BIG_ISSUE(t, tap, c0);
     BIG_ADVANCE();
   }
   int issued = pre;
-  {
-    // group 0 needs its pieces of tiles 0 and 1 landed, group 1 those of tile 0
-    const int pending = wave_m == 0 ? pre - 2 : pre - 1;
-    if (pending >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (pending == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
+  // tiles 0 and 1 must be complete before the first slot
+  if (pre >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (pre == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 
   // ---- ping-pong main loop ---------------------------------------------------------------------------
-  // The two waves of a SIMD (wave w and w+4: groups 0 and 1) alternate roles every half K step: one runs
-  // its 16 MFMAs back to back from registers while the other waits for its DMA pieces, issues the pieces
-  // of the tile three steps ahead and reads its 12 fragments of the next tile; two s_barriers per K step.
-  //   slot 2t  : group 0 MFMA(t)                   | group 1 LOAD(read tile t, issue tile t+3)
-  //   slot 2t+1: group 0 LOAD(read t+1, issue t+4) | group 1 MFMA(t)
-  // Tile T is read first in slot 2T-1 (group 0) and its stage was last read (tile T-4, group 1) in slot
-  // 2T-8, so group 1 issues it in slot 2T-6 and group 0 in slot 2T-7.  At the END of a load segment a
-  // wave waits for everything but the pieces of this and the previous segment (vmcnt 8) and the barrier
-  // that ends the segment publishes them: group 1's pieces of tile T in slot 2T-2, group 0's in 2T-3.
-  bf16x8_t px0[4], wt0[2], px1[4], wt1[2];
-#define BIG_LOADSEG(read_stage_)                                                              \
+  // The two waves of a SIMD (wave w and w+4: groups 0 and 1) alternate roles every half K step; two
+  // s_barriers per K step:
+  //   compute segment: the 16 MFMAs of tile t from one fragment register set, with the 12 ds_read_b128 of
+  //                    tile t+1 into the other set slotted between them (one per MFMA: the LDS latency and
+  //                    the read issue both disappear under the matrix pipe);
+  //   load segment:    issue this wave's 4 DMA pieces of tile t+4 (~100 cycles each), then wait for
+  //                    everything but the pieces of this and the previous load segment (vmcnt 8).
+  //   slot 2t  : group 0 compute(t) | group 1 load(t)        slot 2t+1: group 0 load(t) | group 1 compute(t)
+  // Tile T is read in slots 2T-2 (group 0) and 2T-1 (group 1); its stage held tile T-4, last read in slot
+  // 2T-9, so it is issued in slots 2T-8 / 2T-7 and published by the barriers that end slots 2T-4 / 2T-3:
+  // four slots (two K steps, ~1 us) of flight time for both groups.
+  // three fragment sets of 6 x ds_read_b128 (one 16-wide K slice each) rotate: while the 8 MFMAs of a
+  // slice run, the slice that will be needed two phases later streams into the free set
+  bf16x8_t fxA[4], ftA[2], fxB[4], ftB[2], fxC[4], ftC[2];
+#define BIG_LOADSEG()                                                                         \
   do {                                                                                        \
     BIG_STAMP(7);                                                                             \
-    /* fragment reads first: their LDS latency runs under the DMA issue below (the reverse    \
-       order on half of the waves measured 6 % slower) */                                     \
-    if (!(ABL & 2)) {                                                                         \
-      BIG_LOAD(px0, wt0, read_stage_, off_p0, off_w0);                                        \
-      BIG_LOAD(px1, wt1, read_stage_, off_p1, off_w1);                                        \
-    }                                                                                         \
-    BIG_STAMP(0);                                                                             \
     const bool do_issue__ = issued < ksteps && !(ABL & 1);                                    \
     if (do_issue__) {                                                                         \
       BIG_ISSUE(issued & 3, tap, c0);                                                         \
       BIG_ADVANCE();                                                                          \
     }                                                                                         \
     BIG_STAMP(1);                                                                             \
-    /* everything but the pieces of this and the previous load segment has landed: the        \
-       barrier that ends the segment publishes it */                                          \
     if (do_issue__) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                          \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                     \
     BIG_STAMP(2);                                                                             \
     ++issued;                                                                                 \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                        \
-    BIG_STAMP(3);                                                                             \
   } while (0)
-#define BIG_MFMASEG()                                                                         \
+// 8 MFMAs of slice (CX,CT) with the 6 reads of (NX,NT) slotted between them
+#define BIG_PHASE(CX, CT, NX, NT, next_stage_, offp_, offw_)                                  \
+  do {                                                                                        \
+    if (!(ABL & 2)) BIG_LOAD(NX, NT, next_stage_, offp_, offw_);                              \
+    if (!(ABL & 4)) {                                                                         \
+      BIG_MFMA(CX, CT);                                                                       \
+    } else {                                                                                  \
+      acc[0][0][0] += (float)CX[0][0] + (float)CT[0][0] + (float)CX[3][7] + (float)CT[1][7] +           \
+                      (float)CX[1][3] + (float)CX[2][5];                                      \
+    }                                                                                         \
+    if (!(ABL & 6)) {                                                                         \
+      _Pragma("unroll") for (int q__ = 0; q__ < 6; ++q__) {                                   \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                    \
+      }                                                                                       \
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                      \
+    }                                                                                         \
+  } while (0)
+// tile t lives in (X: first slice, Y: second slice), Z is free; afterwards tile t+1 lives in (Z, X)
+#define BIG_COMPUTESEG(X, XT, Y, YT, Z, ZT, next_stage_)                                      \
   do {                                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                        \
-    if (!(ABL & 4)) {                                                                         \
-      BIG_MFMA(px0, wt0);                                                                     \
-      BIG_MFMA(px1, wt1);                                                                     \
-    } else {                                                                                  \
-      acc[0][0][0] += (float)px0[0][0] + (float)wt0[0][0] + (float)px1[0][0] + (float)wt1[0][0] +       \
-                      (float)px0[3][7] + (float)wt0[1][7] + (float)px1[3][7] + (float)wt1[1][7] +       \
-                      (float)px0[1][3] + (float)px0[2][5] + (float)px1[1][3] + (float)px1[2][5];        \
-    }                                                                                         \
+    BIG_PHASE(X, XT, Z, ZT, next_stage_, off_p0, off_w0);                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+    BIG_PHASE(Y, YT, X, XT, next_stage_, off_p1, off_w1);                                     \
     __builtin_amdgcn_sched_barrier(0);                                                        \
   } while (0)
 #define BIG_BARRIER()                       \
@@ -249,40 +256,63 @@ __global__ void __launch_bounds__(512) conv_big_kernel(const ConvArgs args) {
     __builtin_amdgcn_s_barrier();           \
     asm volatile("" ::: "memory");          \
   } while (0)
+// one K step of a group-0 / group-1 wave
+#define BIG_STEP0(...)                      \
+  do {                                      \
+    BIG_COMPUTESEG(__VA_ARGS__);            \
+    BIG_STAMP(5);                           \
+    BIG_BARRIER();                          \
+    BIG_STAMP(6);                           \
+    BIG_LOADSEG();                          \
+    BIG_BARRIER();                          \
+    BIG_STAMP(4);                           \
+  } while (0)
+#define BIG_STEP1(...)                      \
+  do {                                      \
+    BIG_LOADSEG();                          \
+    BIG_BARRIER();                          \
+    BIG_STAMP(4);                           \
+    BIG_COMPUTESEG(__VA_ARGS__);            \
+    BIG_STAMP(5);                           \
+    BIG_BARRIER();                          \
+    BIG_STAMP(6);                           \
+  } while (0)
 
+  BIG_LOAD(fxA, ftA, 0, off_p0, off_w0);
+  BIG_LOAD(fxB, ftB, 0, off_p1, off_w1);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  BIG_BARRIER();   // every wave holds tile 0 in registers: its stage may be refilled from slot 0 on
   if (ABL & 64) t_prev = clock64();
-  if (wave_m == 0) {
-    BIG_LOAD(px0, wt0, 0, off_p0, off_w0);
-    BIG_LOAD(px1, wt1, 0, off_p1, off_w1);
-#pragma unroll 1
-    for (int kt = 0; kt < ksteps; ++kt) {
-      BIG_MFMASEG();
-      BIG_STAMP(5);
-      BIG_BARRIER();
-      BIG_STAMP(6);
-      BIG_LOADSEG((kt + 1) & 3);   // the last one reads a stale stage into registers nobody uses
-      BIG_BARRIER();
-      BIG_STAMP(4);
-    }
-  } else {
-#pragma unroll 1
-    for (int kt = 0; kt < ksteps; ++kt) {
-      BIG_LOADSEG(kt & 3);
-      BIG_BARRIER();
-      BIG_STAMP(4);
-      BIG_MFMASEG();
-      BIG_STAMP(5);
-      BIG_BARRIER();
-      BIG_STAMP(6);
-    }
-  }
+  // the read of tile kt+1 in the last step fetches a stale stage into registers nobody uses
+#define BIG_ROTATE(STEP)                                                                      \
+  do {                                                                                        \
+    int kt = 0;                                                                               \
+    _Pragma("unroll 1") for (; kt + 2 < ksteps; kt += 3) {                                    \
+      STEP(fxA, ftA, fxB, ftB, fxC, ftC, (kt + 1) & 3);                                       \
+      STEP(fxC, ftC, fxA, ftA, fxB, ftB, (kt + 2) & 3);                                       \
+      STEP(fxB, ftB, fxC, ftC, fxA, ftA, (kt + 3) & 3);                                       \
+    }                                                                                         \
+    if (kt < ksteps) STEP(fxA, ftA, fxB, ftB, fxC, ftC, (kt + 1) & 3);                        \
+    if (kt + 1 < ksteps) STEP(fxC, ftC, fxA, ftA, fxB, ftB, (kt + 2) & 3);                    \
+  } while (0)
+  if (wave_m == 0) BIG_ROTATE(BIG_STEP0);
+  else BIG_ROTATE(BIG_STEP1);
+#undef BIG_ROTATE
+#undef BIG_STEP1
+#undef BIG_STEP0
 #undef BIG_BARRIER
-#undef BIG_MFMASEG
+#undef BIG_COMPUTESEG
 #undef BIG_LOADSEG
   if ((ABL & 64) && blockIdx.x == 300 && lane == 0) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) g_big_timing[wave * 8 + k] = tm[k];
+    if (wave == 0) {
+      g_big_timing[64] = clock64() - k_c0;        // core cycles spent in the main loop
+      g_big_timing[65] = wall_clock64() - k_w0;   // the same interval in 100 MHz ticks
+    }
   }
+#undef off_p1
+#undef off_w1
 #undef BIG_MFMA
 #undef BIG_LOAD
 #undef BIG_ADVANCE
@@ -310,9 +340,13 @@ __global__ void __launch_bounds__(512) conv_big_kernel(const ConvArgs args) {
   const int Cout = sg.Cout;
   const int nw0 = n0 + wave_n * 64;
   char* patch = smem + wave * 8192;  // 32 pixels x 64 channels, bf16 (4 KB) or f32 (8 KB)
+  // a fresh lane id, so that nothing the epilogue needs stays live across the main loop (the loop runs
+  // at the 256-register limit of two waves per SIMD)
+  const int elane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const int fr = elane & 31, fh = elane >> 5;
   if (!OUT_F32) {
     // read-back role: 8 lanes per pixel row (16 B = 8 channels each), 8 rows per pass
-    const int rrow = lane >> 3, ru = lane & 7;
+    const int rrow = elane >> 3, ru = elane & 7;
     const int nr = nw0 + ru * 8;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -361,7 +395,7 @@ __global__ void __launch_bounds__(512) conv_big_kernel(const ConvArgs args) {
     }
   } else {
     // f32 output (prediction convs): 16 lanes per pixel row (16 B = 4 channels each), 4 rows per pass
-    const int rrow = lane >> 4, ru = lane & 15;
+    const int rrow = elane >> 4, ru = elane & 15;
     const int nr = nw0 + ru * 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -409,7 +443,7 @@ __global__ void __launch_bounds__(512) conv_big_kernel(const ConvArgs args) {
 
 // internal (tools/bench_conv.py): per-phase cycle sums recorded by the ABL=64 build
 extern "C" int rn_debug_conv_big_timing(long long* out64) {
-  return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_big_timing), sizeof(long long) * 64) == hipSuccess ? 0 : -1;
+  return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_big_timing), sizeof(long long) * 66) == hipSuccess ? 0 : -1;
 }
 
 static int g_big_ablate = 0;

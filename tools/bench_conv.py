@@ -20,6 +20,10 @@ PRESETS = {
     "g1_3x3": ([(160, 64, 64)], 3, 1, False, False),
     "g1_out": ([(160, 64, 256)], 1, 1, False, True),
     "g1_a": ([(160, 256, 64)], 1, 1, False, False),
+    "g1_sc": ([(160, 64, 256)], 1, 1, False, False),
+    "g2_out": ([(80, 128, 512)], 1, 1, False, True),
+    "g2_a": ([(80, 512, 128)], 1, 1, False, False),
+    "g3_a": ([(40, 1024, 256)], 1, 1, False, False),
     "g2_3x3": ([(80, 128, 128)], 3, 1, False, False),
     "g3_3x3": ([(40, 256, 256)], 3, 1, False, False),
     "g3_out": ([(40, 256, 1024)], 1, 1, False, True),
@@ -78,10 +82,11 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / a.iters
         if a.ablate & 64:
-            buf = (ctypes.c_longlong * 64)()
+            buf = (ctypes.c_longlong * 66)()
             lib.rn_debug_conv_big_timing(buf)
             names = ["ds_read issue", "dma issue", "vmcnt wait", "lgkm wait", "barrier(after load)", "mfma seg",
                      "barrier(after mfma)", "loop overhead"]
+            print(f"main loop: {buf[64]} core cycles in {buf[65] / 100.0:.1f} us -> {buf[64] / max(buf[65], 1) * 100:.0f} MHz")
             for w in range(8):
                 print("wave", w, " ".join(f"{names[k]}={buf[w * 8 + k]}" for k in range(8)))
         print(f"{name:12s} B={a.batch} {ms * 1e3:9.1f} us  {flops / ms / 1e9:8.1f} TFLOP/s  "
