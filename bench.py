@@ -16,9 +16,10 @@ resident in HBM -> backbone + FPN + heads -> decode + per-class top-k + NMS -> d
 which does not shard ("replicas only"), and `cpu_baseline`: the CPU restatement
 (oracle/model_ref.py, PyTorch-CPU — NOT TensorFlow) timed on the host cores.
 
-`roofline` = the dominant kernel of the timed region, conv_fwd_kernel<128,128,64,bf16> (forward
-convs and every dgrad): sum of algorithmic FLOPs of its launches / sum of their HIP-event times
-(events recorded on the launch stream inside the timed steps), against 2.5 PFLOP/s dense bf16.
+`roofline` = the dominant kernel of the timed region — whichever of conv_big_kernel<bf16> (256x256x32)
+and conv_fwd_kernel<128,128,64,bf16> (forward convs and every dgrad) took more time: sum of algorithmic
+FLOPs of its launches / sum of their HIP-event times (events recorded on the launch stream inside the
+timed steps), against 2.5 PFLOP/s dense bf16; the other one is reported under `other_conv_kernels`.
 """
 import argparse
 import json
@@ -61,17 +62,24 @@ def conv_flops(engine, step_name):
     return total
 
 
-def is_dominant_variant(engine, step_name):
-    """conv_fwd_kernel<128,128,64,bf16-out>: Cout > 64, Cin % 64 == 0, bf16 output."""
+def conv_variant(engine, step_name):
+    """Kernel the dispatcher picks for an inference conv launch: the 256x256x32 kernel (rn_conv_big.hip) or
+    conv_fwd_kernel<128,128,64> (Cout > 64, Cin % 64 == 0), bf16 output; None for the other variants."""
+    import ctypes
     g = engine.g
-    if not step_name.startswith("conv:") or step_name == "conv:stem":
-        return False
+    p = getattr(engine, "conv_problems", {}).get(step_name)
+    if p is None or step_name == "conv:stem":
+        return None
     name = step_name.split(":", 1)[1]
     for o in g.ops:
         if o["op"] == "conv" and (o.get("group") == name or o["out"] == name):
             c = g.convs[o["conv"]]
-            return c["cout"] > 64 and c["cin"] % 64 == 0 and o["out_dtype"] == "bf16"
-    return False
+            if o["out_dtype"] != "bf16":
+                return None
+            if engine.lib.rn_conv_tile_rows(ctypes.byref(p)) == 256:
+                return "conv_big_kernel<bf16> (256x256x32)"
+            return "conv_fwd_kernel<128,128,64,bf16>" if c["cout"] > 64 and c["cin"] % 64 == 0 else None
+    return None
 
 
 def synth_ground_truth(B, size, seed):
@@ -131,19 +139,27 @@ def run_train(args, dev, rank, world):
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
-    dom_ms = sum(r[0].elapsed_time(r[1]) for r in prof)
-    dom_flops = sum(r[2] for r in prof)
-    dom_bytes = sum(r[3] for r in prof)
+    # per kernel variant: [ms, flops, bytes, launches]; the dominant kernel is the one with most time
+    by_kernel = {}
+    for e0, e1, fl, by, variant in prof:
+        acc = by_kernel.setdefault(variant, [0.0, 0, 0, 0])
+        acc[0] += e0.elapsed_time(e1); acc[1] += fl; acc[2] += by; acc[3] += 1
+    dom_name = max(by_kernel, key=lambda k: by_kernel[k][0]) if by_kernel else "none"
+    dom_ms, dom_flops, dom_bytes, dom_n = by_kernel.get(dom_name, [0.0, 0, 0, 0])
     res = {"dt": dt, "B": B, "loss": float(out["weighted-loss"].item()),
            "grad_norm": float(out["gradient-norm"].item()),
            "roofline": {"bound": "mfma", "achieved": round(dom_flops / (dom_ms * 1e-3) / 1e12, 2) if dom_ms else 0.0,
                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(dom_flops / (dom_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if dom_ms else 0.0,
-                        "traffic": None, "kernel": "conv_fwd_kernel<128,128,64,bf16> (forward + dgrad launches)",
-                        "launches_per_step": len(prof) // max(args.steps, 1),
-                        "avg_launch_us": round(dom_ms * 1e3 / max(len(prof), 1), 2),
-                        "algorithmic_gflop_per_launch": round(dom_flops / max(len(prof), 1) / 1e9, 3),
-                        "algorithmic_bytes_per_launch": int(dom_bytes / max(len(prof), 1))}}
+                        "traffic": None, "kernel": dom_name + " (forward + dgrad launches)",
+                        "launches_per_step": dom_n // max(args.steps, 1),
+                        "avg_launch_us": round(dom_ms * 1e3 / max(dom_n, 1), 2),
+                        "ms_per_step": round(dom_ms / max(args.steps, 1), 3),
+                        "algorithmic_gflop_per_launch": round(dom_flops / max(dom_n, 1) / 1e9, 3),
+                        "algorithmic_bytes_per_launch": int(dom_bytes / max(dom_n, 1)),
+                        "other_conv_kernels": {k: {"ms_per_step": round(v[0] / max(args.steps, 1), 3),
+                                                   "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1) if v[0] else 0.0}
+                                               for k, v in by_kernel.items() if k != dom_name}}}
     return res, params, model, eng
 
 
@@ -165,8 +181,8 @@ def run_infer(args, dev, rank):
     infer = builder.add_post_processing_stage(model)
     engine, post = model.inference_engine(B), infer.post
     from retinanet import _C
-    dom = set(i for i, (_, n) in enumerate(engine.steps) if is_dominant_variant(engine, n))
-    dom_flops = sum(conv_flops(engine, engine.steps[i][1]) for i in dom)
+    variants = {i: conv_variant(engine, n) for i, (_, n) in enumerate(engine.steps)}
+    dom = set(i for i, v in variants.items() if v)
     ev = []
 
     def step(record):
@@ -177,7 +193,7 @@ def run_infer(args, dev, rank):
                 e0.record()
                 fn(st)
                 e1.record()
-                ev.append((e0, e1))
+                ev.append((e0, e1, i))
             else:
                 fn(st)
         return post(engine.outputs)
@@ -190,8 +206,13 @@ def run_infer(args, dev, rank):
         out = step(True)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    dom_ms = sum(a.elapsed_time(b) for a, b in ev)
-    ach = dom_flops * args.infer_steps / (dom_ms * 1e-3) / 1e12 if dom_ms else 0.0
+    by_kernel = {}
+    for a, b, i in ev:
+        acc = by_kernel.setdefault(variants[i], [0.0, 0, 0])
+        acc[0] += a.elapsed_time(b); acc[1] += conv_flops(engine, engine.steps[i][1]); acc[2] += 1
+    dom_name = max(by_kernel, key=lambda k: by_kernel[k][0]) if by_kernel else "none"
+    dom_ms, dom_fl, dom_n = by_kernel.get(dom_name, [0.0, 0, 0])
+    ach = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms else 0.0
     res = {"workload": f"ResNet50-{args.size}x{args.size} bf16 inference batch={B} (BASELINE configs[1]): forward + decode "
                        "+ per-class top-k 5000 + per-class NMS; replicas only",
            "value": round(B * args.infer_steps / dt, 2), "unit": "images/s", "ms_per_step": round(dt / args.infer_steps * 1e3, 3),
@@ -199,8 +220,12 @@ def run_infer(args, dev, rank):
            "data": "synthetic N(0,1) images, reference initialisers"
                    + (f", class logits rescaled to std {args.logit_std}" if args.logit_std > 0 else ""),
            "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(ach / PEAK_BF16_TFLOPS, 4), "kernel": "conv_fwd_kernel<128,128,64,bf16>",
-                        "launches_per_step": len(dom)}}
+                        "frac": round(ach / PEAK_BF16_TFLOPS, 4), "kernel": dom_name,
+                        "launches_per_step": dom_n // max(args.infer_steps, 1),
+                        "ms_per_step": round(dom_ms / max(args.infer_steps, 1), 3),
+                        "other_conv_kernels": {k: {"ms_per_step": round(v[0] / max(args.infer_steps, 1), 3),
+                                                   "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1) if v[0] else 0.0}
+                                               for k, v in by_kernel.items() if k != dom_name}}}
     return res, params, model
 
 
@@ -288,7 +313,9 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            line["roofline"]["traffic"] = json.load(open(tpath)).get("conv_fwd_128x128x64_bf16_bytes_per_launch")
+            key = ("conv_big_kernel_bf16_bytes_per_launch" if line["roofline"]["kernel"].startswith("conv_big")
+                   else "conv_fwd_128x128x64_bf16_bytes_per_launch")
+            line["roofline"]["traffic"] = json.load(open(tpath)).get(key)
         except Exception:
             pass
     if world == 1 and rank == 0:

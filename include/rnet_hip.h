@@ -181,6 +181,9 @@ int rn_conv2d_nhwc_fwd(const rn_conv_problem* problem /* host */, void* stream);
 /* HWIO f32 [R,S,Cin,Cout] (the Keras kernel layout, resnet.py:137-144) -> bf16
  * [Cout_pad,R,S,Cin_pad], zero padded.  Cout_pad = rn_conv_cout_pad(Cout). */
 int rn_conv_cout_pad(int Cout);
+/* M-tile height the dispatcher picks for this problem: 256 = conv_big_kernel (256x256x32, rn_conv_big.hip),
+ * 128 = conv_fwd_kernel<128,...>; 0 on a malformed problem.  For profilers (bench.py roofline). */
+int rn_conv_tile_rows(const rn_conv_problem* problem);
 /* channel count of the packed weights: Cin rounded up to the kernel's K step (zero columns) */
 int rn_conv_cin_pad(int Cin);
 int rn_pack_conv_weight(const float* w_hwio, int R, int S, int Cin, int Cout, int Cin_pad, void* w_packed,

@@ -374,6 +374,24 @@ static int launch_ablate(const ConvArgs& a, hipStream_t st) {
   return RN_OK;
 }
 
+// 256 x 256 x 32 tiles (rn_conv_big.hip) for the MFMA-bound layers: every segment at least 256 output
+// channels wide, and enough tiles to fill the 256 CUs (one workgroup per CU) a few times over.
+static bool conv_use_big(const rn_conv_problem* p) {
+  if (g_conv_force_small) return false;
+  long long tiles256 = 0;
+  for (int i = 0; i < p->num_segments; ++i) {
+    const rn_conv_segment& s = p->seg[i];
+    if (rn_conv_cout_pad(s.Cout) < 256 || s.Cout % 8 != 0) return false;
+    tiles256 += rn_cdiv((long long)s.N * s.Ho * s.Wo, 256) * rn_cdiv(s.Cout, 256);
+  }
+  return g_conv_force_big || tiles256 >= 384;
+}
+
+extern "C" int rn_conv_tile_rows(const rn_conv_problem* p) {
+  if (!p || p->num_segments < 1 || p->num_segments > RN_CONV_MAX_SEGMENTS) return 0;
+  return conv_use_big(p) ? 256 : 128;
+}
+
 extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
   RN_CHECK_ARG(p != nullptr, "rn_conv2d_nhwc_fwd: null problem");
   RN_CHECK_ARG(p->num_segments >= 1 && p->num_segments <= RN_CONV_MAX_SEGMENTS,
@@ -390,16 +408,7 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
   // tail of the last K step reads past the pixel's channels (or out of range -> zeros) and meets the
   // zero-padded weight columns, so it contributes nothing.
   const int BK = rn_conv_cin_pad(p->seg[0].Cin) % 64 == 0 ? 64 : 32;
-  // 256 x 256 x 32 tiles (rn_conv_big.hip) for the MFMA-bound layers: every segment at least 256 output
-  // channels wide, and enough tiles to fill the 256 CUs (one workgroup per CU) a few times over.
-  bool big = !g_conv_force_small;
-  long long tiles256 = 0;
-  for (int i = 0; i < p->num_segments && big; ++i) {
-    const rn_conv_segment& s = p->seg[i];
-    if (rn_conv_cout_pad(s.Cout) < 256 || s.Cout % 8 != 0) big = false;
-    tiles256 += rn_cdiv((long long)s.N * s.Ho * s.Wo, 256) * rn_cdiv(s.Cout, 256);
-  }
-  if (big && !g_conv_force_big && tiles256 < 384) big = false;
+  const bool big = conv_use_big(p);
   const int BM = big ? 256 : 128;
   const int BNT = big ? 256 : BN;   // n-tile width
   int tiles = 0;

@@ -1,23 +1,33 @@
-// rn_conv_big.hip — 256 x 256 x 32 implicit-GEMM conv tile for the MFMA-bound layers (Cout >= 256).
+// rn_conv_big.hip — persistent 256 x 256 x 32 implicit-GEMM conv kernel for layers with Cout >= 256.
 //
 // Why a second shape: the 128 x 128 tile of rn_conv.hip needs (128+128)*2 B of staged operands per
-// 2*128*128 FLOP = 64 B/clk/CU at the MFMA peak, i.e. 100 % of the vector-memory -> LDS path; measured
-// it sustains ~22 B/clk/CU and 34 % of the MFMA peak.  A 256 x 256 tile halves the
-// bytes per FLOP (32 B/clk/CU at peak) and halves the LDS-DMA instructions per MFMA.
+// 2*128*128 FLOP = 64 B/clk/CU at the MFMA peak, i.e. 100 % of the vector-memory -> LDS path, and every
+// workgroup serialises load latency -> MFMA -> epilogue -> store (~2 TB/s on the
+// HBM-bound 1x1 layers, 34 % of the MFMA peak on the 3x3 ones).  This kernel halves the staged bytes per
+// FLOP and never lets the memory pipeline drain between tiles:
 //
+//   * one workgroup per CU, persistent: workgroup b walks tiles b, b+G, b+2G, ... (XCD-aware numbering)
+//     and treats their K steps as ONE stream.  The LDS-DMA (`buffer_load ... lds`) runs 3-4 stream steps
+//     ahead in a four-stage ring (4 x 32 KB), so the first operands of the next tile land while the
+//     current tile runs its epilogue, and that tile's stores drain under the next tile's MFMAs.
 //   * 512 threads = 8 wavefronts as 2 (M) x 4 (N), wave tile 128 pixels x 64 channels = 4 x 2 MFMA
-//     32x32x16 tiles, 128 accumulator registers; two waves per SIMD interleave MFMA with the other
-//     wave's ds_read / DMA issue.
-//   * K step 32, four LDS stages of 32 KB (128 KB, one workgroup per CU): `buffer_load ... lds` DMA runs
-//     three K steps ahead behind a counted `s_waitcnt vmcnt(4)`, one raw s_barrier per K step.
-//   * fragments are software pipelined by half K step (two register sets of 6 x ds_read_b128): the
-//     reads of the next 16-wide K slice are in flight while the 8 MFMAs of the current one run.
+//     32x32x16 tiles, 128 accumulator registers.  The two waves of a SIMD (wave w and w+4) ping-pong:
+//     in every half step one runs its 16 MFMAs back to back from registers (compute segment) while the
+//     other reads its 12 fragments of the next step, issues its 4 DMA pieces and waits for older pieces
+//     (load segment); two s_barriers per K step.
+//         slot 2g  : group 0 compute(g)               | group 1 load(read g, issue g+3)
+//         slot 2g+1: group 0 load(read g+1, issue g+4) | group 1 compute(g)
+//     Stream step T is first read in slot 2T-1 and its stage was last read (step T-4) in slot 2T-8; group 1
+//     issues it in slot 2T-6, group 0 in slot 2T-7; at the END of a load segment a wave waits for everything
+//     but the pieces of this and the previous segment (vmcnt 8) and the barrier that ends the segment
+//     publishes them (group 1's pieces of T in slot 2T-2, group 0's in 2T-3): four slots of flight time.
 //   * operands are swapped (weights = MFMA A, pixels = MFMA B), so a lane's accumulator registers are
-//     4 consecutive output channels of ONE pixel: the epilogue applies scale/shift, rounds to bf16 and
-//     transposes through a per-wave 32 x 64 LDS patch with 8-byte writes, then reads 16 bytes
-//     (8 channels) per lane and stores full 128-byte rows; residual add + activation happen on the
-//     read-back side (the conv+BN value is rounded to bf16 before the add, as the reference's bf16
-//     BatchNormalization output is).  No workgroup barrier in the epilogue.
+//     4 consecutive output channels of ONE pixel.  Epilogue, per wave, no workgroup barrier: the raw
+//     accumulators are rounded to bf16 (the reference's Conv2D output under the mixed policy is a bf16
+//     tensor) and transposed through a 32 x 64 LDS patch (8-byte writes), read back 16 bytes = 8 channels
+//     per lane, then scale/shift (folded BN + bias), residual add, activation in fp32, and full 128-byte
+//     row stores.  The residual rows and the lane's 8 scale/shift values are prefetched before the
+//     transposes.  Patches live in their own 32 KB of LDS (ring 128 KB + patches 32 KB = 160 KB).
 #include "rn_conv_dev.h"
 
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
@@ -27,7 +37,8 @@ namespace {
 
 constexpr int BM = 256, BN = 256, BK = 32, NW = 8, STAGES = 4;
 constexpr int A_BYTES = BM * BK * 2, STAGE_BYTES = (BM + BN) * BK * 2;
-
+constexpr int RING_BYTES = STAGES * STAGE_BYTES, PATCH_BYTES = 4096;
+constexpr int LDS_BYTES = RING_BYTES + NW * PATCH_BYTES;
 
 __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
   f32x2_t v = {lo, hi};
@@ -37,86 +48,105 @@ __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
 __device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 
-// ABL (tools/bench_conv.py --ablate, 0 in production): 1 = no DMA inside the K loop, 2 = no ds_read inside
-// the K loop, 4 = no MFMA, 8 = no epilogue.
-__device__ long long g_big_timing[8 * 8 + 2];   // [wave][phase] cycle sums of workgroup 300 (ABL & 64)
+// XCD-aware tile numbering: virtual id v (dispatched round-robin over the 8 XCDs) -> tile, so that
+// consecutive tiles (same pixels, neighbouring channel tiles) stay on one XCD's L2
+__device__ __forceinline__ int tile_of(int v, int total) {
+  const int xcd = v & 7, slot = v >> 3;
+  const int q = total >> 3, r = total & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
 
-template <bool OUT_F32, int ABL = 0>
+template <bool OUT_F32>
 __global__ void __launch_bounds__(512) conv_big_kernel(const ConvArgs args) {
-  long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  long long t_prev = 0;
-  const long long k_c0 = (ABL & 64) ? clock64() : 0, k_w0 = (ABL & 64) ? wall_clock64() : 0;
-#define BIG_STAMP(k_)                              \
-  do {                                             \
-    if (ABL & 64) {                                \
-      const long long now__ = clock64();           \
-      tm[k_] += now__ - t_prev;                    \
-      t_prev = now__;                              \
-    }                                              \
-  } while (0)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  // ---- tile lookup (XCD-aware remap of the linear block id) ---------------------------------
-  int tile;
-  {
-    const int total = args.total_tiles;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, slot = bid >> 3;
-    const int q = total >> 3, r = total & 7;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-  }
-  int si = 0;
-#pragma unroll 1
-  for (int i = 1; i < args.nseg; ++i)
-    if (tile >= args.seg[i].tile_begin) si = i;
-  const ConvSegDev& sg = args.seg[si];
-  const int lt = tile - sg.tile_begin;
-  const int m_tile = lt / sg.n_tiles, n_tile = lt - m_tile * sg.n_tiles;
-  const int m0 = m_tile * BM, n0 = n_tile * BN;
-
+  const int total = args.total_tiles;
+  const int G = gridDim.x;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wave_m = wave >> 2, wave_n = wave & 3;
+  const int wave_m = wave >> 2, wave_n = wave & 3;   // wave_m is also the ping-pong group
+  const int R = args.R, S = args.S, RS = R * S;
 
-  const int S = args.S;
-  const int H = sg.H, W = sg.W, Cin = sg.CinP, PS = sg.pix_stride;
-  const int M = sg.M;
-  const int Ktot = args.R * S * Cin;
-  const int cout_rows = sg.Cout <= 64 ? 64 : ((sg.Cout + 127) / 128) * 128;  // rows the packed weights hold
-
-  const __amdgpu_buffer_rsrc_t rs_x =
-      __builtin_amdgcn_make_buffer_rsrc((void*)sg.x, 0, (int)((long long)sg.N * H * W * PS * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_w =
-      __builtin_amdgcn_make_buffer_rsrc((void*)sg.w, 0, (int)((long long)cout_rows * Ktot * 2), 0x00020000);
-
-  // ---- per-lane DMA bookkeeping: instruction j of this wave fills rows (j*8 + wave)*16 + lane/4 ----
-  const int d_row = lane >> 2, d_pos = lane & 3;
+  // ---- issue side: the tile whose K steps are being DMA'd -----------------------------------------
+  int i_v = blockIdx.x;           // virtual id of that tile; the stream ends when i_v >= total
+  int i_tap = 0, i_c0 = 0;        // next K step of that tile
+  int i_r = 0, i_s = 0;           // i_tap = i_r * S + i_s
+  int g_iss = 0;                  // stream steps issued by this wave
+  int i_W = 0, i_PS = 0, i_Cin = 0;
+  __amdgpu_buffer_rsrc_t rs_x, rs_w;
   unsigned a_off[2], a_mask[2], b_off[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int row = (j * NW + wave) * 16 + d_row;
-    const int chunk = d_pos ^ lds_swz<BK>(row);
-    const int m = m0 + row;
-    const int mm = m < M ? m : 0;
-    const int ox = mm % sg.Wo;
-    const int t2 = mm / sg.Wo;
-    const int oy = t2 % sg.Ho;
-    const int n = t2 / sg.Ho;
-    const int iy0 = oy * args.sh - args.pt, ix0 = ox * args.sw - args.pl;
-    a_off[j] = (unsigned)(((((long long)n * H + iy0) * W + ix0) * PS + chunk * 8) * 2);
-    unsigned mask = 0;
-    if (m < M) {
-      for (int r = 0; r < args.R; ++r)
-        for (int s = 0; s < S; ++s) {
-          const bool ok = (unsigned)(iy0 + r) < (unsigned)H && (unsigned)(ix0 + s) < (unsigned)W;
-          mask |= (ok ? 1u : 0u) << (r * S + s);
-        }
-    }
-    a_mask[j] = mask;
-    const int nrow = n0 + row;
-    b_off[j] = nrow < cout_rows ? (unsigned)(((long long)nrow * Ktot + chunk * 8) * 2) : RN_OOB;
-  }
+  const int d_row = lane >> 2, d_pos = lane & 3;   // DMA instruction j fills rows (j*8 + wave)*16 + lane/4
+
+#define BIG_SETUP_ISSUE()                                                                             \
+  do {                                                                                                \
+    const int tile__ = tile_of(i_v, total);                                                           \
+    int si__ = 0;                                                                                     \
+    _Pragma("unroll 1") for (int i = 1; i < args.nseg; ++i)                                           \
+      if (tile__ >= args.seg[i].tile_begin) si__ = i;                                                 \
+    const ConvSegDev& sg__ = args.seg[si__];                                                          \
+    const int lt__ = tile__ - sg__.tile_begin;                                                        \
+    const int mt__ = lt__ / sg__.n_tiles;                                                             \
+    const int m0__ = mt__ * BM, n0__ = (lt__ - mt__ * sg__.n_tiles) * BN;                             \
+    i_W = sg__.W; i_PS = sg__.pix_stride; i_Cin = sg__.CinP;                                          \
+    const int H__ = sg__.H, Ktot__ = RS * i_Cin;                                                      \
+    const int rows__ = sg__.Cout <= 64 ? 64 : ((sg__.Cout + 127) / 128) * 128; /* packed weight rows */ \
+    rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)sg__.x, 0,                                        \
+                                             (int)((long long)sg__.N * H__ * i_W * i_PS * 2), 0x00020000); \
+    rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)sg__.w, 0, (int)((long long)rows__ * Ktot__ * 2), \
+                                             0x00020000);                                             \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                   \
+      const int row = (j * NW + wave) * 16 + d_row;                                                   \
+      const int chunk = d_pos ^ lds_swz<BK>(row);                                                     \
+      const int m = m0__ + row;                                                                       \
+      const int mm = m < sg__.M ? m : 0;                                                              \
+      const int ox = mm % sg__.Wo;                                                                    \
+      const int t2 = mm / sg__.Wo;                                                                    \
+      const int oy = t2 % sg__.Ho;                                                                    \
+      const int n = t2 / sg__.Ho;                                                                     \
+      const int iy0 = oy * args.sh - args.pt, ix0 = ox * args.sw - args.pl;                           \
+      a_off[j] = (unsigned)(((((long long)n * H__ + iy0) * i_W + ix0) * i_PS + chunk * 8) * 2);       \
+      unsigned mask = 0;                                                                              \
+      if (m < sg__.M) {                                                                               \
+        for (int r = 0; r < R; ++r)                                                                   \
+          for (int s = 0; s < S; ++s) {                                                               \
+            const bool ok = (unsigned)(iy0 + r) < (unsigned)H__ && (unsigned)(ix0 + s) < (unsigned)i_W; \
+            mask |= (ok ? 1u : 0u) << (r * S + s);                                                    \
+          }                                                                                           \
+      }                                                                                               \
+      a_mask[j] = mask;                                                                               \
+      const int nrow = n0__ + row;                                                                    \
+      b_off[j] = nrow < rows__ ? (unsigned)(((long long)nrow * Ktot__ + chunk * 8) * 2) : RN_OOB;     \
+    }                                                                                                 \
+  } while (0)
+
+// DMA of the next stream step (4 pieces per wave); advances to the next tile when this one is done
+#define BIG_ISSUE_STEP()                                                                              \
+  do {                                                                                                \
+    const unsigned tap_off__ = (unsigned)((((long long)i_r * i_W + i_s) * i_PS + i_c0) * 2);          \
+    const unsigned koff__ = (unsigned)(((long long)i_tap * i_Cin + i_c0) * 2);                        \
+    char* st__ = smem + (g_iss & 3) * STAGE_BYTES;                                                    \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                   \
+      const unsigned v__ = ((a_mask[j] >> i_tap) & 1u) ? a_off[j] + tap_off__ : RN_OOB;               \
+      dma16(rs_x, st__ + (j * NW + wave) * 1024, v__);                                                \
+    }                                                                                                 \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                     \
+      dma16(rs_w, st__ + A_BYTES + (j * NW + wave) * 1024, b_off[j] == RN_OOB ? RN_OOB : b_off[j] + koff__); \
+    ++g_iss;                                                                                          \
+    i_c0 += BK;                                                                                       \
+    if (i_c0 >= i_Cin) {                                                                              \
+      i_c0 = 0;                                                                                       \
+      ++i_tap;                                                                                        \
+      if (++i_s == S) {                                                                               \
+        i_s = 0;                                                                                      \
+        ++i_r;                                                                                        \
+      }                                                                                               \
+      if (__builtin_expect(i_tap == RS, 0)) {                                                         \
+        i_tap = i_r = i_s = 0;                                                                        \
+        i_v += G;                                                                                     \
+        if (i_v < total) BIG_SETUP_ISSUE();                                                           \
+      }                                                                                               \
+    }                                                                                                 \
+  } while (0)
 
   // ---- fragment read offsets ---------------------------------------------------------------------
   // row = lane&31 of a 32-row tile, 16-byte slot = 2*kk + (lane>>5), XOR-swizzled by (row/4)&3; the
@@ -128,9 +158,6 @@ __global__ void __launch_bounds__(512) conv_big_kernel(const ConvArgs args) {
     off_p0 = (wave_m * 128 + fr) * 64 + ((0 + fh) ^ sw) * 16;            // pixels, kk = 0
     off_w0 = A_BYTES + (wave_n * 64 + fr) * 64 + ((0 + fh) ^ sw) * 16;   // weights, kk = 0
   }
-  // kk = 1: slot index ^ 2 = byte offset ^ 32
-#define off_p1 (off_p0 ^ 32)
-#define off_w1 (off_w0 ^ 32)
 
   f32x16_t acc[4][2];
 #pragma unroll
@@ -140,357 +167,263 @@ __global__ void __launch_bounds__(512) conv_big_kernel(const ConvArgs args) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  const int ksteps = args.R * S * (Cin / BK);
-
-#define BIG_ISSUE(stage_, tap_, c0_)                                                          \
-  do {                                                                                        \
-    const int r__ = (tap_) / S, s__ = (tap_) - r__ * S;                                       \
-    const unsigned tap_off__ = (unsigned)((((long long)r__ * W + s__) * PS + (c0_)) * 2);     \
-    const unsigned koff__ = (unsigned)(((long long)(tap_) * Cin + (c0_)) * 2);                \
-    char* st__ = smem + (stage_) * STAGE_BYTES;                                               \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                           \
-      unsigned v__ = ((a_mask[j] >> (tap_)) & 1u) ? a_off[j] + tap_off__ : RN_OOB;            \
-      if (ABL & 128) v__ = (unsigned)(m0 * 64 + (j * NW + wave) * 1024 + lane * 16) + tap_off__; \
-      dma16(rs_x, st__ + (j * NW + wave) * 1024, v__);                                        \
-    }                                                                                         \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                           \
-      unsigned v__ = b_off[j] == RN_OOB ? RN_OOB : b_off[j] + koff__;                         \
-      if (ABL & 128) v__ = (unsigned)((j * NW + wave) * 1024 + lane * 16) + koff__;           \
-      dma16(rs_w, st__ + A_BYTES + (j * NW + wave) * 1024, v__);                              \
-    }                                                                                         \
+  bf16x8_t px0[4], wt0[2], px1[4], wt1[2];   // fragments of one stream step: K slices 0..15 / 16..31
+#define BIG_READ(stage_)                                                                              \
+  do {                                                                                                \
+    const char* b__ = smem + (stage_) * STAGE_BYTES;                                                  \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) wt0[j] = *(const bf16x8_t*)(b__ + off_w0 + j * 2048); \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) px0[i] = *(const bf16x8_t*)(b__ + off_p0 + i * 2048); \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) wt1[j] = *(const bf16x8_t*)(b__ + (off_w0 ^ 32) + j * 2048); \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) px1[i] = *(const bf16x8_t*)(b__ + (off_p0 ^ 32) + i * 2048); \
   } while (0)
-#define BIG_ADVANCE()  \
-  do {                 \
-    c0 += BK;          \
-    if (c0 >= Cin) {   \
-      c0 = 0;          \
-      ++tap;           \
-    }                  \
+// load segment: fragment reads first (their LDS latency runs under the DMA issue), then this wave's
+// pieces of the stream step 3-4 ahead, then the counted wait
+#define BIG_LOADSEG(stage_)                                                                           \
+  do {                                                                                                \
+    BIG_READ(stage_);                                                                                 \
+    if (i_v < total) {                                                                                \
+      BIG_ISSUE_STEP();                                                                               \
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                \
+    } else {                                                                                          \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
+    }                                                                                                 \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
   } while (0)
-#define BIG_LOAD(PX, WT, stage_, offp_, offw_)                                                \
-  do {                                                                                        \
-    const char* b__ = smem + (stage_) * STAGE_BYTES;                                          \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) PX[i] = *(const bf16x8_t*)(b__ + (offp_) + i * 2048); \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) WT[j] = *(const bf16x8_t*)(b__ + (offw_) + j * 2048); \
-  } while (0)
-#define BIG_MFMA(PX, WT)                                                                      \
-  do {                                                                                        \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                             \
-      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                           \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WT[j], PX[i], acc[i][j], 0, 0, 0); \
-  } while (0)
-
-  int tap = 0, c0 = 0;  // coordinates of the NEXT tile to issue
-  const int pre = ksteps < 4 ? ksteps : 4;
-#pragma unroll 1
-  for (int t = 0; t < pre; ++t) {
-    BIG_ISSUE(t, tap, c0);
-    BIG_ADVANCE();
-  }
-  int issued = pre;
-  // tiles 0 and 1 must be complete before the first slot
-  if (pre >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if (pre == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-
-  // ---- ping-pong main loop ---------------------------------------------------------------------------
-  // The two waves of a SIMD (wave w and w+4: groups 0 and 1) alternate roles every half K step; two
-  // s_barriers per K step:
-  //   compute segment: the 16 MFMAs of tile t from one fragment register set, with the 12 ds_read_b128 of
-  //                    tile t+1 into the other set slotted between them (one per MFMA: the LDS latency and
-  //                    the read issue both disappear under the matrix pipe);
-  //   load segment:    issue this wave's 4 DMA pieces of tile t+4 (~100 cycles each), then wait for
-  //                    everything but the pieces of this and the previous load segment (vmcnt 8).
-  //   slot 2t  : group 0 compute(t) | group 1 load(t)        slot 2t+1: group 0 load(t) | group 1 compute(t)
-  // Tile T is read in slots 2T-2 (group 0) and 2T-1 (group 1); its stage held tile T-4, last read in slot
-  // 2T-9, so it is issued in slots 2T-8 / 2T-7 and published by the barriers that end slots 2T-4 / 2T-3:
-  // four slots (two K steps, ~1 us) of flight time for both groups.
-  // three fragment sets of 6 x ds_read_b128 (one 16-wide K slice each) rotate: while the 8 MFMAs of a
-  // slice run, the slice that will be needed two phases later streams into the free set
-  bf16x8_t fxA[4], ftA[2], fxB[4], ftB[2], fxC[4], ftC[2];
-#define BIG_LOADSEG()                                                                         \
-  do {                                                                                        \
-    BIG_STAMP(7);                                                                             \
-    const bool do_issue__ = issued < ksteps && !(ABL & 1);                                    \
-    if (do_issue__) {                                                                         \
-      BIG_ISSUE(issued & 3, tap, c0);                                                         \
-      BIG_ADVANCE();                                                                          \
-    }                                                                                         \
-    BIG_STAMP(1);                                                                             \
-    if (do_issue__) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                          \
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                     \
-    BIG_STAMP(2);                                                                             \
-    ++issued;                                                                                 \
-  } while (0)
-// 8 MFMAs of slice (CX,CT) with the 6 reads of (NX,NT) slotted between them
-#define BIG_PHASE(CX, CT, NX, NT, next_stage_, offp_, offw_)                                  \
-  do {                                                                                        \
-    if (!(ABL & 2)) BIG_LOAD(NX, NT, next_stage_, offp_, offw_);                              \
-    if (!(ABL & 4)) {                                                                         \
-      BIG_MFMA(CX, CT);                                                                       \
-    } else {                                                                                  \
-      acc[0][0][0] += (float)CX[0][0] + (float)CT[0][0] + (float)CX[3][7] + (float)CT[1][7] +           \
-                      (float)CX[1][3] + (float)CX[2][5];                                      \
-    }                                                                                         \
-    if (!(ABL & 6)) {                                                                         \
-      _Pragma("unroll") for (int q__ = 0; q__ < 6; ++q__) {                                   \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                    \
-      }                                                                                       \
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                      \
-    }                                                                                         \
-  } while (0)
-// tile t lives in (X: first slice, Y: second slice), Z is free; afterwards tile t+1 lives in (Z, X)
-#define BIG_COMPUTESEG(X, XT, Y, YT, Z, ZT, next_stage_)                                      \
-  do {                                                                                        \
-    __builtin_amdgcn_sched_barrier(0);                                                        \
-    BIG_PHASE(X, XT, Z, ZT, next_stage_, off_p0, off_w0);                                     \
-    __builtin_amdgcn_sched_barrier(0);                                                        \
-    BIG_PHASE(Y, YT, X, XT, next_stage_, off_p1, off_w1);                                     \
-    __builtin_amdgcn_sched_barrier(0);                                                        \
+#define BIG_COMPUTESEG()                                                                              \
+  do {                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                     \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                   \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt0[j], px0[i], acc[i][j], 0, 0, 0);      \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                     \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                   \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt1[j], px1[i], acc[i][j], 0, 0, 0);      \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
   } while (0)
 #define BIG_BARRIER()                       \
   do {                                      \
     __builtin_amdgcn_s_barrier();           \
     asm volatile("" ::: "memory");          \
   } while (0)
-// one K step of a group-0 / group-1 wave
-#define BIG_STEP0(...)                      \
-  do {                                      \
-    BIG_COMPUTESEG(__VA_ARGS__);            \
-    BIG_STAMP(5);                           \
-    BIG_BARRIER();                          \
-    BIG_STAMP(6);                           \
-    BIG_LOADSEG();                          \
-    BIG_BARRIER();                          \
-    BIG_STAMP(4);                           \
-  } while (0)
-#define BIG_STEP1(...)                      \
-  do {                                      \
-    BIG_LOADSEG();                          \
-    BIG_BARRIER();                          \
-    BIG_STAMP(4);                           \
-    BIG_COMPUTESEG(__VA_ARGS__);            \
-    BIG_STAMP(5);                           \
-    BIG_BARRIER();                          \
-    BIG_STAMP(6);                           \
+
+  // ---- compute side: the tile being accumulated --------------------------------------------------
+  int c_v = blockIdx.x;   // virtual id
+  int c_k = 0;            // K steps of it already accumulated
+  int c_ksteps, c_m0, c_n0, c_si;
+#define BIG_SETUP_COMPUTE()                                                                           \
+  do {                                                                                                \
+    const int tile__ = tile_of(c_v, total);                                                           \
+    c_si = 0;                                                                                         \
+    _Pragma("unroll 1") for (int i = 1; i < args.nseg; ++i)                                           \
+      if (tile__ >= args.seg[i].tile_begin) c_si = i;                                                 \
+    const ConvSegDev& sg__ = args.seg[c_si];                                                          \
+    const int lt__ = tile__ - sg__.tile_begin;                                                        \
+    const int mt__ = lt__ / sg__.n_tiles;                                                             \
+    c_m0 = mt__ * BM;                                                                                 \
+    c_n0 = (lt__ - mt__ * sg__.n_tiles) * BN;                                                         \
+    c_ksteps = RS * (sg__.CinP / BK);                                                                 \
+    c_k = 0;                                                                                          \
   } while (0)
 
-  BIG_LOAD(fxA, ftA, 0, off_p0, off_w0);
-  BIG_LOAD(fxB, ftB, 0, off_p1, off_w1);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  BIG_BARRIER();   // every wave holds tile 0 in registers: its stage may be refilled from slot 0 on
-  if (ABL & 64) t_prev = clock64();
-  // the read of tile kt+1 in the last step fetches a stale stage into registers nobody uses
-#define BIG_ROTATE(STEP)                                                                      \
-  do {                                                                                        \
-    int kt = 0;                                                                               \
-    _Pragma("unroll 1") for (; kt + 2 < ksteps; kt += 3) {                                    \
-      STEP(fxA, ftA, fxB, ftB, fxC, ftC, (kt + 1) & 3);                                       \
-      STEP(fxC, ftC, fxA, ftA, fxB, ftB, (kt + 2) & 3);                                       \
-      STEP(fxB, ftB, fxC, ftC, fxA, ftA, (kt + 3) & 3);                                       \
-    }                                                                                         \
-    if (kt < ksteps) STEP(fxA, ftA, fxB, ftB, fxC, ftC, (kt + 1) & 3);                        \
-    if (kt + 1 < ksteps) STEP(fxC, ftC, fxA, ftA, fxB, ftB, (kt + 2) & 3);                    \
-  } while (0)
-  if (wave_m == 0) BIG_ROTATE(BIG_STEP0);
-  else BIG_ROTATE(BIG_STEP1);
-#undef BIG_ROTATE
-#undef BIG_STEP1
-#undef BIG_STEP0
-#undef BIG_BARRIER
-#undef BIG_COMPUTESEG
-#undef BIG_LOADSEG
-  if ((ABL & 64) && blockIdx.x == 300 && lane == 0) {
+  // ---- epilogue of the compute-side tile (per wave; acc is cleared afterwards) --------------------
+  // acc[i][j][r]: pixel m = m0 + wave_m*128 + i*32 + (lane&31),
+  //               channel n = n0 + wave_n*64 + j*32 + 8*(r>>2) + 4*(lane>>5) + (r&3)
+  auto epilogue = [&]() __attribute__((always_inline)) {
+    const ConvSegDev& sg = args.seg[c_si];
+    const int Cout = sg.Cout, M = sg.M;
+    const int nw0 = c_n0 + wave_n * 64;
+    const int mw0 = c_m0 + wave_m * 128;
+    char* patch = smem + RING_BYTES + wave * PATCH_BYTES;
+    // a fresh lane id, so that nothing the epilogue needs stays live across the main loop
+    const int elane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int fr = elane & 31, fh = elane >> 5;
+    const int rrow = elane >> 3, ru = elane & 7;   // read-back: 8 lanes per pixel row, 8 rows per pass
+    if (!OUT_F32) {
+      // bf16 patch: 32 pixels x 64 channels (128 B rows, 16-byte units swizzled by the pixel row)
+      const int nr = nw0 + ru * 8;                 // this lane's 8 channels on the read-back side
+      const bool nok = nr < Cout;
+      float sc[8], sf[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) g_big_timing[wave * 8 + k] = tm[k];
-    if (wave == 0) {
-      g_big_timing[64] = clock64() - k_c0;        // core cycles spent in the main loop
-      g_big_timing[65] = wall_clock64() - k_w0;   // the same interval in 100 MHz ticks
-    }
+      for (int q = 0; q < 8; ++q) { sc[q] = 1.0f; sf[q] = 0.0f; }
+      if (nok && sg.scale) {
+        const float4 a = *(const float4*)(sg.scale + nr), b = *(const float4*)(sg.scale + nr + 4);
+        sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w; sc[4] = b.x; sc[5] = b.y; sc[6] = b.z; sc[7] = b.w;
+      }
+      if (nok && sg.shift) {
+        const float4 a = *(const float4*)(sg.shift + nr), b = *(const float4*)(sg.shift + nr + 4);
+        sf[0] = a.x; sf[1] = a.y; sf[2] = a.z; sf[3] = a.w; sf[4] = b.x; sf[5] = b.y; sf[6] = b.z; sf[7] = b.w;
+      }
+      const bool has_res = sg.residual != nullptr;
+      uint4 rv[2][4];
+#define BIG_RES_PREFETCH(buf_, i_)                                                                    \
+  _Pragma("unroll") for (int pass = 0; pass < 4; ++pass) {                                            \
+    const int m = mw0 + (i_) * 32 + pass * 8 + rrow;                                                  \
+    rv[buf_][pass] = make_uint4(0u, 0u, 0u, 0u);                                                      \
+    if (has_res && nok && m < M) rv[buf_][pass] = *(const uint4*)(sg.residual + (long long)m * Cout + nr); \
   }
-#undef off_p1
-#undef off_w1
-#undef BIG_MFMA
-#undef BIG_LOAD
-#undef BIG_ADVANCE
-#undef BIG_ISSUE
-
-  // every wave is done with the staging ring before it is reused as per-wave transpose patches
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-
-  if (ABL & 8) {
-    float t = 0.0f;
+      BIG_RES_PREFETCH(0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (i + 1 < 4) BIG_RES_PREFETCH((i + 1) & 1, i + 1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int nl = j * 32 + g * 8 + fh * 4;   // channel inside the wave's 64
+            uint2 pk;
+            pk.x = pack2(acc[i][j][g * 4 + 0], acc[i][j][g * 4 + 1]);
+            pk.y = pack2(acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
+            *(uint2*)(patch + fr * 128 + (((nl >> 3) ^ (fr & 7)) << 4) + (nl & 4) * 2) = pk;
+          }
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+          const int row = pass * 8 + rrow;
+          const uint4 v = *(const uint4*)(patch + row * 128 + ((ru ^ (row & 7)) << 4));
+          const int m = mw0 + i * 32 + row;
+          if (m < M && nok) {
+            const uint4 r4 = rv[i & 1][pass];
+            float f[8] = {bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y), bf_lo(v.z), bf_hi(v.z), bf_lo(v.w), bf_hi(v.w)};
+            const float rr[8] = {bf_lo(r4.x), bf_hi(r4.x), bf_lo(r4.y), bf_hi(r4.y),
+                                 bf_lo(r4.z), bf_hi(r4.z), bf_lo(r4.w), bf_hi(r4.w)};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) f[q] = rn_apply_act(f[q] * sc[q] + sf[q] + rr[q], args.act);
+            uint4 ov;
+            ov.x = pack2(f[0], f[1]); ov.y = pack2(f[2], f[3]); ov.z = pack2(f[4], f[5]); ov.w = pack2(f[6], f[7]);
+            *(uint4*)((uint16_t*)sg.y + (long long)m * Cout + nr) = ov;
+          }
+        }
+      }
+#undef BIG_RES_PREFETCH
+    } else {
+      // f32 output (prediction convs): f32 patch of 32 pixels x 32 channels per j (128 B rows)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int nr = nw0 + j * 32 + ru * 4;      // this lane's 4 channels on the read-back side
+        const bool nok = nr < Cout;
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sf = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (nok && sg.scale) sc = *(const float4*)(sg.scale + nr);
+        if (nok && sg.shift) sf = *(const float4*)(sg.shift + nr);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            float4 v;
+            v.x = acc[i][j][g * 4 + 0]; v.y = acc[i][j][g * 4 + 1]; v.z = acc[i][j][g * 4 + 2]; v.w = acc[i][j][g * 4 + 3];
+            *(float4*)(patch + fr * 128 + (((g * 2 + fh) ^ (fr & 7)) << 4)) = v;
+          }
+#pragma unroll
+          for (int pass = 0; pass < 4; ++pass) {
+            const int row = pass * 8 + rrow;
+            float4 v = *(const float4*)(patch + row * 128 + ((ru ^ (row & 7)) << 4));
+            const int m = mw0 + i * 32 + row;
+            if (m < M && nok) {
+              const long long o = (long long)m * Cout + nr;
+              v.x = v.x * sc.x + sf.x; v.y = v.y * sc.y + sf.y; v.z = v.z * sc.z + sf.z; v.w = v.w * sc.w + sf.w;
+              if (sg.residual) {
+                const uint2 r2 = *(const uint2*)(sg.residual + o);
+                v.x += bf_lo(r2.x); v.y += bf_hi(r2.x); v.z += bf_lo(r2.y); v.w += bf_hi(r2.y);
+              }
+              v.x = rn_apply_act(v.x, args.act);
+              v.y = rn_apply_act(v.y, args.act);
+              v.z = rn_apply_act(v.z, args.act);
+              v.w = rn_apply_act(v.w, args.act);
+              *(float4*)((float*)sg.y + o) = v;
+            }
+          }
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) t += acc[i][j][r];
-    if (t == 123.456f) ((float*)sg.y)[tid] = t;
-    return;
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  };
+
+  // ---- prologue ------------------------------------------------------------------------------------
+  BIG_SETUP_ISSUE();
+  BIG_SETUP_COMPUTE();
+#pragma unroll 1
+  for (int t = 0; t < 3 && i_v < total; ++t) BIG_ISSUE_STEP();
+  // stream steps 0 and 1 must be complete before the first slot
+  if (g_iss >= 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  BIG_BARRIER();
+  // pre-roll: both groups read step 0 and issue step 3; group 1 does so as its slot-0 load segment
+  BIG_LOADSEG(0);
+  if (wave_m == 1) BIG_BARRIER();
+
+  // ---- main loop over this workgroup's stream --------------------------------------------------------
+  // Separate loops per group keep the hot path straight-line (a taken branch costs ~20 cycles here).
+  // Both groups execute 2N barriers for N stream steps; a finished tile is written out in the odd slot by
+  // both (group 1 right after its MFMAs, group 0 before its load segment).
+#define BIG_TILE_END()                                       \
+  if (__builtin_expect(c_k == c_ksteps, 0)) {               \
+    epilogue();                                             \
+    if (c_v + G >= total) break;                            \
+    c_v += G;                                               \
+    BIG_SETUP_COMPUTE();                                    \
   }
-  // ---- epilogue ------------------------------------------------------------------------------
-  // acc[i][j][r]: pixel m = m0 + wave_m*128 + i*32 + (lane&31),
-  //               channel n = n0 + wave_n*64 + j*32 + 8*(r>>2) + 4*(lane>>5) + (r&3)
-  const int Cout = sg.Cout;
-  const int nw0 = n0 + wave_n * 64;
-  char* patch = smem + wave * 8192;  // 32 pixels x 64 channels, bf16 (4 KB) or f32 (8 KB)
-  // a fresh lane id, so that nothing the epilogue needs stays live across the main loop (the loop runs
-  // at the 256-register limit of two waves per SIMD)
-  const int elane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-  const int fr = elane & 31, fh = elane >> 5;
-  if (!OUT_F32) {
-    // read-back role: 8 lanes per pixel row (16 B = 8 channels each), 8 rows per pass
-    const int rrow = elane >> 3, ru = elane & 7;
-    const int nr = nw0 + ru * 8;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int nl = j * 32 + g * 8 + fh * 4;   // channel inside the wave's 64
-          const int n = nw0 + nl;
-          float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sf = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (n < Cout && !(ABL & 32)) {
-            if (sg.scale) sc = *(const float4*)(sg.scale + n);
-            if (sg.shift) sf = *(const float4*)(sg.shift + n);
-          }
-          uint2 pk;
-          pk.x = pack2(acc[i][j][g * 4 + 0] * sc.x + sf.x, acc[i][j][g * 4 + 1] * sc.y + sf.y);
-          pk.y = pack2(acc[i][j][g * 4 + 2] * sc.z + sf.z, acc[i][j][g * 4 + 3] * sc.w + sf.w);
-          // 16-byte unit (nl/8) swizzled by the pixel row; the 8-byte half stays in place
-          *(uint2*)(patch + fr * 128 + (((nl >> 3) ^ (fr & 7)) << 4) + (nl & 4) * 2) = pk;
-        }
-#pragma unroll
-      for (int pass = 0; pass < 4; ++pass) {
-        const int row = pass * 8 + rrow;
-        const uint4 v = *(const uint4*)(patch + row * 128 + ((ru ^ (row & 7)) << 4));
-        const int m = m0 + wave_m * 128 + i * 32 + row;
-        if ((ABL & 16) && v.x != 0x12345678u) continue;
-        if (m < M && nr < Cout) {
-          const long long o = (long long)m * Cout + nr;
-          float f[8] = {bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y), bf_lo(v.z), bf_hi(v.z), bf_lo(v.w), bf_hi(v.w)};
-          if (sg.residual) {
-            const uint4 rv = *(const uint4*)(sg.residual + o);
-            f[0] += bf_lo(rv.x); f[1] += bf_hi(rv.x); f[2] += bf_lo(rv.y); f[3] += bf_hi(rv.y);
-            f[4] += bf_lo(rv.z); f[5] += bf_hi(rv.z); f[6] += bf_lo(rv.w); f[7] += bf_hi(rv.w);
-          }
-          uint4 ov;
-          if (args.act == RN_ACT_NONE && !sg.residual) {
-            ov = v;
-          } else {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) f[q] = rn_apply_act(f[q], args.act);
-            ov.x = pack2(f[0], f[1]); ov.y = pack2(f[2], f[3]); ov.z = pack2(f[4], f[5]); ov.w = pack2(f[6], f[7]);
-          }
-          *(uint4*)((uint16_t*)sg.y + o) = ov;
-        }
-      }
+  int g = 0;
+  if (wave_m == 0) {
+#pragma unroll 1
+    while (true) {
+      BIG_COMPUTESEG();
+      ++c_k;
+      BIG_BARRIER();
+      BIG_TILE_END();
+      ++g;
+      BIG_LOADSEG(g & 3);   // past the end of the stream: stale reads, nothing issued
+      BIG_BARRIER();
     }
   } else {
-    // f32 output (prediction convs): 16 lanes per pixel row (16 B = 4 channels each), 4 rows per pass
-    const int rrow = elane >> 4, ru = elane & 15;
-    const int nr = nw0 + ru * 4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int nl = j * 32 + g * 8 + fh * 4;
-          const int n = nw0 + nl;
-          float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sf = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (n < Cout) {
-            if (sg.scale) sc = *(const float4*)(sg.scale + n);
-            if (sg.shift) sf = *(const float4*)(sg.shift + n);
-          }
-          float4 v;
-          v.x = acc[i][j][g * 4 + 0] * sc.x + sf.x;
-          v.y = acc[i][j][g * 4 + 1] * sc.y + sf.y;
-          v.z = acc[i][j][g * 4 + 2] * sc.z + sf.z;
-          v.w = acc[i][j][g * 4 + 3] * sc.w + sf.w;
-          *(float4*)(patch + fr * 256 + (((nl >> 2) ^ (fr & 15)) << 4)) = v;
-        }
-#pragma unroll
-      for (int pass = 0; pass < 8; ++pass) {
-        const int row = pass * 4 + rrow;
-        float4 v = *(const float4*)(patch + row * 256 + ((ru ^ (row & 15)) << 4));
-        const int m = m0 + wave_m * 128 + i * 32 + row;
-        if (m < M && nr < Cout) {
-          const long long o = (long long)m * Cout + nr;
-          if (sg.residual) {
-            const uint2 rv = *(const uint2*)(sg.residual + o);
-            v.x += bf_lo(rv.x); v.y += bf_hi(rv.x); v.z += bf_lo(rv.y); v.w += bf_hi(rv.y);
-          }
-          v.x = rn_apply_act(v.x, args.act);
-          v.y = rn_apply_act(v.y, args.act);
-          v.z = rn_apply_act(v.z, args.act);
-          v.w = rn_apply_act(v.w, args.act);
-          *(float4*)((float*)sg.y + o) = v;
-        }
-      }
+#pragma unroll 1
+    while (true) {
+      BIG_COMPUTESEG();
+      ++c_k;
+      BIG_TILE_END();
+      BIG_BARRIER();
+      ++g;
+      BIG_LOADSEG(g & 3);
+      BIG_BARRIER();
     }
   }
+#undef BIG_TILE_END
+#undef BIG_SETUP_COMPUTE
+#undef BIG_BARRIER
+#undef BIG_COMPUTESEG
+#undef BIG_LOADSEG
+#undef BIG_READ
+#undef BIG_ISSUE_STEP
+#undef BIG_SETUP_ISSUE
 }
 
 }  // namespace
 
-// internal (tools/bench_conv.py): per-phase cycle sums recorded by the ABL=64 build
-extern "C" int rn_debug_conv_big_timing(long long* out64) {
-  return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_big_timing), sizeof(long long) * 66) == hipSuccess ? 0 : -1;
-}
-
-static int g_big_ablate = 0;
-extern "C" void rn_debug_conv_big_ablate(int mask) { g_big_ablate = mask; }
-
-template <int ABL>
-static int launch_big_ablate(const ConvArgs& a, hipStream_t st) {
-  constexpr int lds = STAGES * STAGE_BYTES;
-  RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_big_kernel<false, ABL>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  hipLaunchKernelGGL((conv_big_kernel<false, ABL>), dim3(a.total_tiles), dim3(512), lds, st, a);
-  RN_CHECK_LAUNCH();
-  return RN_OK;
-}
+// internal hook kept for tools/bench_conv.py (the ablation builds were removed with the persistent rewrite)
+extern "C" void rn_debug_conv_big_ablate(int) {}
 
 int rn_launch_conv_big(const ConvArgs& a, bool out_f32, hipStream_t st) {
-  constexpr int lds = STAGES * STAGE_BYTES;
-  if (g_big_ablate && !out_f32) {
-    switch (g_big_ablate) {
-      case 1: return launch_big_ablate<1>(a, st);
-      case 2: return launch_big_ablate<2>(a, st);
-      case 3: return launch_big_ablate<3>(a, st);
-      case 4: return launch_big_ablate<4>(a, st);
-      case 7: return launch_big_ablate<7>(a, st);
-      case 8: return launch_big_ablate<8>(a, st);
-      case 11: return launch_big_ablate<11>(a, st);
-      case 12: return launch_big_ablate<12>(a, st);
-      case 16: return launch_big_ablate<16>(a, st);
-      case 32: return launch_big_ablate<32>(a, st);
-      case 48: return launch_big_ablate<48>(a, st);
-      case 64: return launch_big_ablate<64>(a, st);
-      case 192: return launch_big_ablate<192>(a, st);
-      default: break;
-    }
-  }
   static bool attr_set = false;
+  static int num_cu = 256;
   if (!attr_set) {
     RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_big_kernel<false>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_big_kernel<true>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+        prop.multiProcessorCount > 0)
+      num_cu = prop.multiProcessorCount;
     attr_set = true;
   }
+  const int grid = a.total_tiles < num_cu ? a.total_tiles : num_cu;   // one persistent workgroup per CU
   if (out_f32)
-    hipLaunchKernelGGL(conv_big_kernel<true>, dim3(a.total_tiles), dim3(512), lds, st, a);
+    hipLaunchKernelGGL(conv_big_kernel<true>, dim3(grid), dim3(512), LDS_BYTES, st, a);
   else
-    hipLaunchKernelGGL(conv_big_kernel<false>, dim3(a.total_tiles), dim3(512), lds, st, a);
+    hipLaunchKernelGGL(conv_big_kernel<false>, dim3(grid), dim3(512), LDS_BYTES, st, a);
   RN_CHECK_LAUNCH();
   return RN_OK;
 }

@@ -179,6 +179,8 @@ class InferenceEngine:
         lib = self.lib
         pref = ctypes.byref(p)
         name = first.get("group") or first["out"]
+        self.conv_problems = getattr(self, "conv_problems", {})
+        self.conv_problems["conv:" + name] = p   # for profilers: lib.rn_conv_tile_rows(byref(p))
 
         def run(st):
             _C.check(lib.rn_conv2d_nhwc_fwd(pref, st), f"rn_conv2d_nhwc_fwd[{name}]")

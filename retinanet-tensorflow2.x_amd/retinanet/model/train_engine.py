@@ -288,8 +288,9 @@ class TrainEngine:
 
     # ---- helpers to build launches ---------------------------------------------------------------------
     def _conv_meta(self, p):
-        """(algorithmic FLOPs, algorithmic HBM bytes, uses the 128x128x64 bf16-out variant) of a launch.
-        Bytes = every input pixel read once + every output written once (+ residual read) + weights."""
+        """(algorithmic FLOPs, algorithmic HBM bytes, kernel variant or None) of a launch.  Bytes = every
+        input pixel read once + every output written once (+ residual read) + weights.  Variants that
+        bench.py tracks: the 256x256x32 kernel and the 128x128x64 kernel, both with bf16 output."""
         flops, byts, dom = 0, 0, True
         osz = 4 if p.out_dtype == _C.RN_DT_F32 else 2
         for i in range(p.num_segments):
@@ -299,20 +300,25 @@ class TrainEngine:
             if s.residual:
                 byts += 2 * s.N * s.Ho * s.Wo * s.Cout
             dom = dom and s.Cout > 64 and s.Cin % 64 == 0 and p.out_dtype == _C.RN_DT_BF16
-        return flops, byts, dom
+        variant = None
+        if p.out_dtype == _C.RN_DT_BF16 and self.lib.rn_conv_tile_rows(ctypes.byref(p)) == 256:
+            variant = "conv_big_kernel<bf16> (256x256x32)"
+        elif dom:
+            variant = "conv_fwd_kernel<128,128,64,bf16>"
+        return flops, byts, variant
 
     def _launch_conv(self, p, st, what):
         """All implicit-GEMM launches (forward and dgrad) go through here so bench.py can bracket the
         dominant kernel variant with HIP events on the launch stream."""
         prof = self.conv_profile
         if prof is not None:
-            flops, byts, dom = self._conv_meta(p)
-            if dom:
+            flops, byts, variant = self._conv_meta(p)
+            if variant:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 _C.check(self.lib.rn_conv2d_nhwc_fwd(ctypes.byref(p), st), what)
                 e1.record()
-                prof.append((e0, e1, flops, byts))
+                prof.append((e0, e1, flops, byts, variant))
                 return
         _C.check(self.lib.rn_conv2d_nhwc_fwd(ctypes.byref(p), st), what)
 

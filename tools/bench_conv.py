@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--ablate", type=int, default=0)
+    ap.add_argument("--zeros", action="store_true", help="all-zero activations and weights (DVFS check: no toggling)")
     ap.add_argument("--tile", type=int, default=0, help="1 = force 128-row kernel, 2 = force the 256x256 kernel")
     a = ap.parse_args()
     lib = _C.lib()
@@ -58,6 +59,8 @@ def main():
         for i, (H, cin, cout) in enumerate(segs):
             x = torch.randn((a.batch, H, H, cin), device=dev).to(torch.bfloat16)
             w = (torch.randn((lib.rn_conv_cout_pad(cout), k, k, cin), device=dev) / (k * k * cin) ** 0.5).to(torch.bfloat16)
+            if a.zeros:
+                x.zero_(); w.zero_()
             Ho = (H + 2 * p.pad_top - k) // stride + 1
             y = torch.empty((a.batch, Ho, Ho, cout), dtype=torch.float32 if f32 else torch.bfloat16, device=dev)
             sc = torch.rand((cout,), device=dev) + 0.5
@@ -81,14 +84,6 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / a.iters
-        if a.ablate & 64:
-            buf = (ctypes.c_longlong * 66)()
-            lib.rn_debug_conv_big_timing(buf)
-            names = ["ds_read issue", "dma issue", "vmcnt wait", "lgkm wait", "barrier(after load)", "mfma seg",
-                     "barrier(after mfma)", "loop overhead"]
-            print(f"main loop: {buf[64]} core cycles in {buf[65] / 100.0:.1f} us -> {buf[64] / max(buf[65], 1) * 100:.0f} MHz")
-            for w in range(8):
-                print("wave", w, " ".join(f"{names[k]}={buf[w * 8 + k]}" for k in range(8)))
         print(f"{name:12s} B={a.batch} {ms * 1e3:9.1f} us  {flops / ms / 1e9:8.1f} TFLOP/s  "
               f"{byts / ms / 1e6:8.1f} GB/s (algorithmic {byts / 1e6:.1f} MB)", flush=True)
 
