@@ -384,7 +384,7 @@ static bool conv_use_big(const rn_conv_problem* p) {
     if (rn_conv_cout_pad(s.Cout) < 256 || s.Cout % 8 != 0) return false;
     tiles256 += rn_cdiv((long long)s.N * s.Ho * s.Wo, 256) * rn_cdiv(s.Cout, 256);
   }
-  return g_conv_force_big || tiles256 >= 384;
+  return g_conv_force_big || tiles256 >= 192;
 }
 
 extern "C" int rn_conv_tile_rows(const rn_conv_problem* p) {

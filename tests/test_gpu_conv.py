@@ -124,7 +124,7 @@ def test_conv_single(cuda, case):
                          ids=lambda c: "big-" + "x".join(str(v) for v in c))
 def test_conv_big_tile_kernel(cuda, case):
     """Same cases through the 256x256x32 four-stage kernel (rn_conv_big.hip; normally picked only
-    when the launch has >= 384 such tiles)."""
+    when the launch has >= 192 such tiles)."""
     from retinanet import _C
     lib = _C.lib()
     lib.rn_debug_conv_tile(2)
