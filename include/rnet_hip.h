@@ -190,6 +190,9 @@ int rn_pack_conv_weight(const float* w_hwio, int R, int S, int Cin, int Cout, in
                         void* stream);
 /* Stem repack: 7x7x3 HWIO -> bf16 [64][7][32] rows = (kernel row r) x (8 taps x 4 channels),
  * tap 7 and channel 3 zero, matching rn_pack_stem_input's padded NHWC4 image. */
+/* The same packing from the training engine's f32 master layout [Cout][R][S][Cin]. */
+int rn_pack_conv_weight_ohwi(const float* w_ohwi, int R, int S, int Cin, int Cout, int Cin_pad, void* w_packed,
+                             void* stream);
 int rn_pack_stem_weight(const float* w_hwio, int Cout, void* w_packed, void* stream);
 /* images f32 [N,H,W,3] -> bf16 [N,H+6,Wp,4] zero padded by 3 (fixed_padding, resnet.py:92-115),
  * Wp = rn_stem_padded_width(W). */
@@ -354,6 +357,7 @@ typedef struct {
   void* y;
   const float* scale;
   const float* shift;
+  const void* residual;  /* optional bf16 [N,Ho,Wo,C] added before the activation (gradient accumulation) */
   int32_t N, H, W, C, Ho, Wo;
 } rn_dw_segment;
 
@@ -364,12 +368,32 @@ typedef struct {
 
 int rn_depthwise_conv2d_nhwc_fwd(const rn_dw_problem* problem /* host */, void* stream);
 int rn_pack_depthwise_weight(const float* w_kkc1, int k, int C, void* w_packed, void* stream);
+/* Backward of the depthwise conv (tape.gradient through DepthwiseConv2D / SeparableConv2D, executor.py:427-428):
+ *   data gradient   = rn_depthwise_conv2d_nhwc_fwd on dy (zero-upsampled with rn_upsample_zero2x for stride 2)
+ *                     with the tap-reversed filter (rn_pack_depthwise_weight_flip from the f32 master [k*k][C]),
+ *                     stride 1, pads k-1-pad; `residual` accumulates into an already written gradient buffer;
+ *   weight gradient = rn_depthwise_conv2d_nhwc_wgrad: problem.seg[i].x = layer input, .y = dy (read only);
+ *                     dw f32 [k*k][C] (the Keras [k,k,C,1] order) summed over all segments; k in {1,3,5};
+ *                     deterministic two-stage reduction through `workspace`. */
+int rn_pack_depthwise_weight_flip(const float* w_kkc, int k, int C, void* w_packed, void* stream);
+size_t rn_depthwise_wgrad_workspace_bytes(const rn_dw_problem* problem);
+int rn_depthwise_conv2d_nhwc_wgrad(const rn_dw_problem* problem, float* dw, void* workspace, size_t workspace_bytes,
+                                   void* stream);
 /* SE in place on x bf16 [N,HW,C]: x *= sigmoid(W2 swish(W1 mean_hw(x) + b1) + b2).
  * w_reduce bf16 [se][C], w_expand bf16 [C][se], biases f32. */
 size_t rn_se_workspace_bytes(int N, int C);
 int rn_squeeze_excite_inplace(void* x, int N, int HW, int C, const void* w_reduce, const float* b_reduce,
                               const void* w_expand, const float* b_expand, int se, void* workspace,
                               size_t workspace_bytes, void* stream);
+/* Training forward (out of place; `state`, rn_se_workspace_bytes(N,C) bytes, keeps pooled / gate / h1 / a) and
+ * backward: dx = dy*gate + d(pooled)/HW (dx may alias dy), parameter gradients dw1 f32 [se][C], db1 [se],
+ * dw2 [C][se], db2 [C] overwritten. */
+int rn_squeeze_excite_fwd(const void* x, void* y, int N, int HW, int C, const void* w_reduce, const float* b_reduce,
+                          const void* w_expand, const float* b_expand, int se, void* state, size_t state_bytes,
+                          void* stream);
+int rn_squeeze_excite_bwd(const void* x, const void* dy, void* dx, int N, int HW, int C, const void* w_reduce,
+                          const void* w_expand, int se, const void* state, float* dw1, float* db1, float* dw2,
+                          float* db2, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * §8(f)-1  prepare_image / validation preprocessing

@@ -498,6 +498,33 @@ extern "C" int rn_pack_conv_weight(const float* w_hwio, int R, int S, int Cin, i
   return RN_OK;
 }
 
+// the same packing from the training engine's master layout [Cout][R][S][Cin] (f32)
+__global__ void pack_weight_ohwi_kernel(const float* __restrict__ w, int RS, int Cin, int Cout, int Cin_pad,
+                                        int Cout_pad, uint16_t* __restrict__ out) {
+  const long long total = (long long)Cout_pad * RS * Cin_pad;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cin_pad);
+    const long long t = i / Cin_pad;   // = o * RS + tap
+    float v = 0.0f;
+    if (t < (long long)Cout * RS && c < Cin) v = w[t * Cin + c];
+    out[i] = rn_f32_to_bf16(v);
+  }
+}
+
+extern "C" int rn_pack_conv_weight_ohwi(const float* w_ohwi, int R, int S, int Cin, int Cout, int Cin_pad,
+                                        void* w_packed, void* stream) {
+  RN_CHECK_ARG(w_ohwi && w_packed && R > 0 && S > 0 && Cin > 0 && Cout > 0 && Cin_pad >= Cin,
+               "rn_pack_conv_weight_ohwi: bad argument");
+  const int Cout_pad = rn_conv_cout_pad(Cout);
+  const long long total = (long long)Cout_pad * R * S * Cin_pad;
+  int blocks = (int)(rn_cdiv(total, 256) < 4096 ? rn_cdiv(total, 256) : 4096);
+  hipLaunchKernelGGL(pack_weight_ohwi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_ohwi, R * S, Cin,
+                     Cout, Cin_pad, Cout_pad, (uint16_t*)w_packed);
+  RN_CHECK_LAUNCH();
+  return RN_OK;
+}
+
 // stem: HWIO [R,S,3,Cout] (S <= 8) -> [Cout_pad][R][8 taps][4 ch]; taps >= S and channel 3 are zero
 __global__ void pack_stem_weight_kernel(const float* __restrict__ w, int R, int S, int Cout, int Cout_pad,
                                         uint16_t* __restrict__ out) {

@@ -35,7 +35,7 @@ __device__ __forceinline__ float act_exact(float v, int act) {
 }
 
 struct DwSegDev {
-  const uint4* x; const uint4* w; uint4* y; const float* scale; const float* shift;
+  const uint4* x; const uint4* w; uint4* y; const float* scale; const float* shift; const uint4* residual;
   int N, H, W, C8, Ho, Wo;
   long long begin;
 };
@@ -73,15 +73,18 @@ __global__ void __launch_bounds__(DW_THREADS) depthwise_kernel(const DwArgs a) {
         for (int q = 0; q < 8; ++q) acc[q] += xv.v[q] * wv.v[q];
       }
     }
-    bf8 o;
+    const long long oi = (((long long)n * s.Ho + oy) * s.Wo + ox) * s.C8 + c;
+    bf8 o, res;
+    if (s.residual) res = unpack8(s.residual[oi]);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       float v = acc[q];
       if (s.scale) v *= s.scale[c * 8 + q];
       if (s.shift) v += s.shift[c * 8 + q];
+      if (s.residual) v += res.v[q];
       o.v[q] = act_exact(v, a.act);
     }
-    s.y[(((long long)n * s.Ho + oy) * s.Wo + ox) * s.C8 + c] = pack8(o);
+    s.y[oi] = pack8(o);
   }
 }
 
@@ -97,6 +100,7 @@ extern "C" int rn_depthwise_conv2d_nhwc_fwd(const rn_dw_problem* p, void* stream
                  "rn_depthwise_conv2d_nhwc_fwd: segment %d bad (C %% 8 == 0)", i);
     DwSegDev& d = a.seg[i];
     d.x = (const uint4*)s.x; d.w = (const uint4*)s.w; d.y = (uint4*)s.y; d.scale = s.scale; d.shift = s.shift;
+    d.residual = (const uint4*)s.residual;
     d.N = s.N; d.H = s.H; d.W = s.W; d.C8 = s.C / 8; d.Ho = s.Ho; d.Wo = s.Wo;
     d.begin = off;
     off += (long long)s.N * s.Ho * s.Wo * (s.C / 8);
@@ -119,6 +123,174 @@ extern "C" int rn_pack_depthwise_weight(const float* w, int k, int C, void* out,
   const long long n = (long long)k * k * C;
   hipLaunchKernelGGL(pack_dw_kernel, dim3((unsigned)rn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, w, n,
                      (uint16_t*)out);
+  RN_CHECK_LAUNCH();
+  return RN_OK;
+}
+
+// master f32 [k*k][C] -> bf16 [k*k][C] with the taps reversed (the filter of the data gradient)
+__global__ void pack_dw_flip_kernel(const float* __restrict__ w, int taps, int C, uint16_t* __restrict__ out) {
+  const long long n = (long long)taps * C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int t = (int)(i / C), c = (int)(i - (long long)t * C);
+    out[i] = rn_f32_to_bf16(w[(long long)(taps - 1 - t) * C + c]);
+  }
+}
+extern "C" int rn_pack_depthwise_weight_flip(const float* w, int k, int C, void* out, void* stream) {
+  RN_CHECK_ARG(w && out && k > 0 && C > 0, "rn_pack_depthwise_weight_flip: bad argument");
+  const long long n = (long long)k * k * C;
+  hipLaunchKernelGGL(pack_dw_flip_kernel, dim3((unsigned)rn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                     k * k, C, (uint16_t*)out);
+  RN_CHECK_LAUNCH();
+  return RN_OK;
+}
+
+// ---- depthwise weight gradient --------------------------------------------------------------------
+// dW[tap][c] = sum over output pixels of dy[p][c] * x[p shifted by tap][c]; two-stage deterministic
+// reduction: (pixel chunk, channel slab) workgroups -> partials[chunk][tap][C] -> ordered sum.
+// Thread = CPT channels x one pixel lane (32 lanes), all K*K taps in registers.
+struct DwgSegDev {
+  const uint16_t* x; const uint16_t* dy;
+  int N, H, W, Ho, Wo, P, chunk_begin;
+};
+struct DwgArgs {
+  int stride, pt, pl, nseg, C, rows_per_chunk, total_chunks;
+  float* partial;
+  DwgSegDev seg[RN_CONV_MAX_SEGMENTS];
+};
+
+template <int K, int CPT>
+__global__ void __launch_bounds__(256) depthwise_wgrad_kernel(const DwgArgs a) {
+  constexpr int SLAB = 8 * CPT;   // channels per workgroup
+  const int chunk = blockIdx.x, slab = blockIdx.y;
+  int si = 0;
+  while (si + 1 < a.nseg && chunk >= a.seg[si + 1].chunk_begin) ++si;
+  const DwgSegDev& s = a.seg[si];
+  const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int c0 = slab * SLAB + cg * CPT;
+  const bool live = c0 < a.C;
+  float acc[K * K][CPT];
+#pragma unroll
+  for (int t = 0; t < K * K; ++t)
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) acc[t][q] = 0.0f;
+  const int p0 = (chunk - s.chunk_begin) * a.rows_per_chunk;
+  const int p1 = p0 + a.rows_per_chunk < s.P ? p0 + a.rows_per_chunk : s.P;
+  if (live) {
+    for (int p = p0 + rl; p < p1; p += 32) {
+      const int ox = p % s.Wo;
+      const int t2 = p / s.Wo;
+      const int oy = t2 % s.Ho;
+      const int n = t2 / s.Ho;
+      float g[CPT];
+      {
+        const uint16_t* dp = s.dy + (long long)p * a.C + c0;
+#pragma unroll
+        for (int q = 0; q < CPT; q += 2) {
+          const uint32_t u = *(const uint32_t*)(dp + q);
+          g[q] = rn_bf16_to_f32((uint16_t)(u & 0xffffu));
+          g[q + 1] = rn_bf16_to_f32((uint16_t)(u >> 16));
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < K; ++r) {
+        const int iy = oy * a.stride - a.pt + r;
+        if ((unsigned)iy >= (unsigned)s.H) continue;
+#pragma unroll
+        for (int ss = 0; ss < K; ++ss) {
+          const int ix = ox * a.stride - a.pl + ss;
+          if ((unsigned)ix >= (unsigned)s.W) continue;
+          const uint16_t* xp = s.x + (((long long)n * s.H + iy) * s.W + ix) * a.C + c0;
+#pragma unroll
+          for (int q = 0; q < CPT; q += 2) {
+            const uint32_t u = *(const uint32_t*)(xp + q);
+            acc[r * K + ss][q] += g[q] * rn_bf16_to_f32((uint16_t)(u & 0xffffu));
+            acc[r * K + ss][q + 1] += g[q + 1] * rn_bf16_to_f32((uint16_t)(u >> 16));
+          }
+        }
+      }
+    }
+  }
+  __shared__ float red[32][SLAB + 1];
+#pragma unroll 1
+  for (int t = 0; t < K * K; ++t) {
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) red[rl][cg * CPT + q] = acc[t][q];
+    __syncthreads();
+    if (threadIdx.x < SLAB) {
+      float sum = 0.0f;
+      for (int r = 0; r < 32; ++r) sum += red[r][threadIdx.x];
+      const int ch = slab * SLAB + threadIdx.x;
+      if (ch < a.C) a.partial[((long long)chunk * (K * K) + t) * a.C + ch] = sum;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(256)
+dwg_reduce_kernel(const float* __restrict__ partial, long long n, int chunks, float* __restrict__ dw) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float t = 0.0f;
+    for (int c = 0; c < chunks; ++c) t += partial[(long long)c * n + i];
+    dw[i] = t;
+  }
+}
+
+static int dwg_plan(const rn_dw_problem* p, DwgArgs& a) {
+  if (!p || p->num_segments < 1 || p->num_segments > RN_CONV_MAX_SEGMENTS) return -1;
+  if (p->k != 1 && p->k != 3 && p->k != 5) return -1;
+  a.stride = p->stride; a.pt = p->pad_top; a.pl = p->pad_left; a.nseg = p->num_segments; a.C = p->seg[0].C;
+  if (a.C % 8) return -1;
+  long long Ptot = 0;
+  for (int i = 0; i < p->num_segments; ++i) {
+    const rn_dw_segment& s = p->seg[i];
+    if (!s.x || !s.y || s.C != a.C) return -1;
+    Ptot += (long long)s.N * s.Ho * s.Wo;
+  }
+  long long rows = rn_cdiv(Ptot, 512);          // ~512 chunks over the launch
+  rows = rn_cdiv(rows, 32) * 32;
+  if (rows < 32) rows = 32;
+  a.rows_per_chunk = (int)rows;
+  int chunks = 0;
+  for (int i = 0; i < p->num_segments; ++i) {
+    const rn_dw_segment& s = p->seg[i];
+    DwgSegDev& d = a.seg[i];
+    d.x = (const uint16_t*)s.x; d.dy = (const uint16_t*)s.y;
+    d.N = s.N; d.H = s.H; d.W = s.W; d.Ho = s.Ho; d.Wo = s.Wo; d.P = s.N * s.Ho * s.Wo;
+    d.chunk_begin = chunks;
+    chunks += (int)rn_cdiv(d.P, rows);
+  }
+  a.total_chunks = chunks;
+  return 0;
+}
+
+extern "C" size_t rn_depthwise_wgrad_workspace_bytes(const rn_dw_problem* p) {
+  DwgArgs a;
+  if (dwg_plan(p, a)) return 0;
+  return (size_t)a.total_chunks * p->k * p->k * a.C * sizeof(float);
+}
+
+// problem: seg.x = layer input, seg.y = gradient wrt the layer output (read only), seg.w/scale/shift unused
+extern "C" int rn_depthwise_conv2d_nhwc_wgrad(const rn_dw_problem* p, float* dw, void* workspace,
+                                              size_t workspace_bytes, void* stream) {
+  DwgArgs a;
+  RN_CHECK_ARG(dwg_plan(p, a) == 0 && dw, "rn_depthwise_conv2d_nhwc_wgrad: bad problem (k in {1,3,5}, C %% 8 == 0)");
+  const size_t need = rn_depthwise_wgrad_workspace_bytes(p);
+  if (!workspace || workspace_bytes < need) {
+    rn_set_error("rn_depthwise_conv2d_nhwc_wgrad: workspace %zu < %zu", workspace_bytes, need);
+    return RN_ENOMEM;
+  }
+  a.partial = (float*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  if (p->k == 1)
+    hipLaunchKernelGGL((depthwise_wgrad_kernel<1, 8>), dim3(a.total_chunks, (unsigned)rn_cdiv(a.C, 64)), dim3(256), 0, st, a);
+  else if (p->k == 3)
+    hipLaunchKernelGGL((depthwise_wgrad_kernel<3, 8>), dim3(a.total_chunks, (unsigned)rn_cdiv(a.C, 64)), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((depthwise_wgrad_kernel<5, 4>), dim3(a.total_chunks, (unsigned)rn_cdiv(a.C, 32)), dim3(256), 0, st, a);
+  RN_CHECK_LAUNCH();
+  const long long n = (long long)p->k * p->k * a.C;
+  hipLaunchKernelGGL(dwg_reduce_kernel, dim3((unsigned)rn_cdiv(n, 256)), dim3(256), 0, st, (const float*)workspace, n,
+                     a.total_chunks, dw);
   RN_CHECK_LAUNCH();
   return RN_OK;
 }
@@ -155,7 +327,8 @@ se_pool_kernel(const uint4* __restrict__ x, int HW, int C8, float* __restrict__ 
 __global__ void __launch_bounds__(256)
 se_fc_kernel(const float* __restrict__ pooled, const uint16_t* __restrict__ w1 /*[se][C]*/,
              const float* __restrict__ b1, const uint16_t* __restrict__ w2 /*[C][se]*/,
-             const float* __restrict__ b2, int C, int se, float* __restrict__ gate) {
+             const float* __restrict__ b2, int C, int se, float* __restrict__ gate,
+             float* __restrict__ save_h1 /*[N][se] or null*/, float* __restrict__ save_a /*[N][se] or null*/) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sp = (float*)smem;  // [C]
   float* sh = sp + C;        // [se]
@@ -170,8 +343,10 @@ se_fc_kernel(const float* __restrict__ pooled, const uint16_t* __restrict__ w1 /
     if (lane == 0) {
       float v = acc + b1[j];
       v = rn_bf16_to_f32(rn_f32_to_bf16(v));
+      if (save_h1) save_h1[(long long)n * se + j] = v;
       v = v / (1.0f + __expf(-v));
       sh[j] = rn_bf16_to_f32(rn_f32_to_bf16(v));
+      if (save_a) save_a[(long long)n * se + j] = sh[j];
     }
   }
   __syncthreads();
@@ -186,7 +361,8 @@ se_fc_kernel(const float* __restrict__ pooled, const uint16_t* __restrict__ w1 /
 }
 
 __global__ void __launch_bounds__(DW_THREADS)
-se_gate_kernel(uint4* __restrict__ x, const float* __restrict__ gate, int HW, int C8, long long total) {
+se_gate_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, const float* __restrict__ gate, int HW, int C8,
+               long long total) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const int c = (int)(i % C8);
@@ -195,35 +371,212 @@ se_gate_kernel(uint4* __restrict__ x, const float* __restrict__ gate, int HW, in
     const float* g = gate + (n * C8 + c) * 8;
 #pragma unroll
     for (int q = 0; q < 8; ++q) v.v[q] *= g[q];
-    x[i] = pack8(v);
+    y[i] = pack8(v);
   }
 }
 
-extern "C" size_t rn_se_workspace_bytes(int N, int C) { return (size_t)N * C * 2 * sizeof(float); }
+// workspace / state layout: pooled[N][C], gate[N][C], h1[N][se], a[N][se] (se <= C), all f32
+extern "C" size_t rn_se_workspace_bytes(int N, int C) { return (size_t)N * C * 4 * sizeof(float); }
+
+static int se_forward(const void* x, void* y, int N, int HW, int C, const void* w_reduce, const float* b_reduce,
+                      const void* w_expand, const float* b_expand, int se, float* state, hipStream_t st) {
+  float* pooled = state;
+  float* gate = pooled + (size_t)N * C;
+  float* h1 = gate + (size_t)N * C;
+  float* av = h1 + (size_t)N * se;
+  hipLaunchKernelGGL(se_pool_kernel, dim3((C + 63) / 64, N), dim3(256), 0, st, (const uint4*)x, HW, C / 8, pooled);
+  RN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(se_fc_kernel, dim3(N), dim3(256), (size_t)(C + se) * 4, st, pooled, (const uint16_t*)w_reduce,
+                     b_reduce, (const uint16_t*)w_expand, b_expand, C, se, gate, h1, av);
+  RN_CHECK_LAUNCH();
+  const long long total = (long long)N * HW * (C / 8);
+  long long blocks = rn_cdiv(total, DW_THREADS);
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(se_gate_kernel, dim3((unsigned)blocks), dim3(DW_THREADS), 0, st, (const uint4*)x, (uint4*)y, gate,
+                     HW, C / 8, total);
+  RN_CHECK_LAUNCH();
+  return RN_OK;
+}
 
 extern "C" int rn_squeeze_excite_inplace(void* x, int N, int HW, int C, const void* w_reduce, const float* b_reduce,
                                          const void* w_expand, const float* b_expand, int se, void* workspace,
                                          size_t workspace_bytes, void* stream) {
-  RN_CHECK_ARG(x && w_reduce && b_reduce && w_expand && b_expand && N > 0 && HW > 0 && C % 8 == 0 && se > 0,
+  RN_CHECK_ARG(x && w_reduce && b_reduce && w_expand && b_expand && N > 0 && HW > 0 && C % 8 == 0 && se > 0 && se <= C,
                "rn_squeeze_excite_inplace: bad argument");
   if (!workspace || workspace_bytes < rn_se_workspace_bytes(N, C)) {
     rn_set_error("rn_squeeze_excite_inplace: workspace too small");
     return RN_ENOMEM;
   }
   RN_CHECK_ARG((size_t)(C + se) * 4 <= 64 * 1024, "rn_squeeze_excite_inplace: C=%d too large", C);
+  return se_forward(x, x, N, HW, C, w_reduce, b_reduce, w_expand, b_expand, se, (float*)workspace, (hipStream_t)stream);
+}
+
+// training forward: out of place (the backward needs the un-gated input), `state` (rn_se_workspace_bytes)
+// keeps pooled / gate / h1 / a for rn_squeeze_excite_bwd
+extern "C" int rn_squeeze_excite_fwd(const void* x, void* y, int N, int HW, int C, const void* w_reduce,
+                                     const float* b_reduce, const void* w_expand, const float* b_expand, int se,
+                                     void* state, size_t state_bytes, void* stream) {
+  RN_CHECK_ARG(x && y && w_reduce && b_reduce && w_expand && b_expand && N > 0 && HW > 0 && C % 8 == 0 && se > 0 &&
+                   se <= C && (size_t)(C + se) * 4 <= 64 * 1024, "rn_squeeze_excite_fwd: bad argument");
+  if (!state || state_bytes < rn_se_workspace_bytes(N, C)) {
+    rn_set_error("rn_squeeze_excite_fwd: state buffer too small");
+    return RN_ENOMEM;
+  }
+  return se_forward(x, y, N, HW, C, w_reduce, b_reduce, w_expand, b_expand, se, (float*)state, (hipStream_t)stream);
+}
+
+// ---- squeeze-and-excitation backward ------------------------------------------------------------------
+// y = x * g[n][c], g = sigmoid(h2), h2 = W2 a + b2, a = swish(h1), h1 = W1 p + b1, p = mean_hw x
+// dgate[n][c] = sum_hw dy * x
+__global__ void __launch_bounds__(256)
+se_bwd_pool_kernel(const uint4* __restrict__ x, const uint4* __restrict__ dy, int HW, int C8, float* __restrict__ dgate) {
+  const int n = blockIdx.y, slab = blockIdx.x;
+  const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int c8 = slab * 8 + cg;
+  float acc[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) acc[q] = 0.0f;
+  if (c8 < C8)
+    for (int p = rl; p < HW; p += 32) {
+      const long long o = ((long long)n * HW + p) * C8 + c8;
+      const bf8 v = unpack8(x[o]), g = unpack8(dy[o]);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] += v.v[q] * g.v[q];
+    }
+  __shared__ float red[32][65];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) red[rl][cg * 8 + q] = acc[q];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float t = 0.0f;
+    for (int r = 0; r < 32; ++r) t += red[r][threadIdx.x];
+    const int ch = slab * 64 + threadIdx.x;
+    if (ch < C8 * 8) dgate[(long long)n * C8 * 8 + ch] = t;
+  }
+}
+
+// one workgroup per image: dgate -> dh2[c], dh1[j], dp[c] (gradient wrt the pooled vector)
+__global__ void __launch_bounds__(256)
+se_bwd_fc_kernel(const float* __restrict__ state, const float* __restrict__ dgate, const uint16_t* __restrict__ w1,
+                 const uint16_t* __restrict__ w2, int N, int C, int se, float* __restrict__ dh2, float* __restrict__ dh1,
+                 float* __restrict__ dp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* s2 = (float*)smem;   // dh2 [C]
+  float* s1 = s2 + C;         // dh1 [se]
+  const int n = blockIdx.x;
+  const float* gate = state + (size_t)N * C + (size_t)n * C;
+  const float* h1 = state + (size_t)2 * N * C + (size_t)n * se;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float g = gate[c];
+    const float v = dgate[(long long)n * C + c] * g * (1.0f - g);
+    s2[c] = v;
+    dh2[(long long)n * C + c] = v;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int j = wave; j < se; j += blockDim.x / 64) {
+    float acc = 0.0f;
+    for (int c = lane; c < C; c += 64) acc += s2[c] * rn_bf16_to_f32(w2[(long long)c * se + j]);
+    acc = rn_wave_sum(acc);
+    if (lane == 0) {
+      const float u = h1[j];
+      const float sg = 1.0f / (1.0f + __expf(-u));
+      const float v = acc * (sg + u * sg * (1.0f - sg));
+      s1[j] = v;
+      dh1[(long long)n * se + j] = v;
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float acc = 0.0f;
+    for (int j = 0; j < se; ++j) acc += s1[j] * rn_bf16_to_f32(w1[(long long)j * C + c]);
+    dp[(long long)n * C + c] = acc;
+  }
+}
+
+// parameter gradients: sums over the N images (thread per element, fixed order)
+__global__ void __launch_bounds__(256)
+se_bwd_wgrad_kernel(const float* __restrict__ state, const float* __restrict__ dh2, const float* __restrict__ dh1, int N,
+                    int C, int se, float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2,
+                    float* __restrict__ db2) {
+  const float* pooled = state;
+  const float* av = state + (size_t)2 * N * C + (size_t)N * se;
+  const long long n1 = (long long)se * C;
+  const long long total = 2 * n1 + se + C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    float t = 0.0f;
+    if (i < n1) {                       // dw1[j][c]
+      const int j = (int)(i / C), c = (int)(i - (long long)j * C);
+      for (int n = 0; n < N; ++n) t += dh1[(long long)n * se + j] * pooled[(long long)n * C + c];
+      dw1[i] = t;
+    } else if (i < 2 * n1) {            // dw2[c][j]
+      const long long k = i - n1;
+      const int c = (int)(k / se), j = (int)(k - (long long)c * se);
+      for (int n = 0; n < N; ++n) t += dh2[(long long)n * C + c] * av[(long long)n * se + j];
+      dw2[k] = t;
+    } else if (i < 2 * n1 + se) {
+      const int j = (int)(i - 2 * n1);
+      for (int n = 0; n < N; ++n) t += dh1[(long long)n * se + j];
+      db1[j] = t;
+    } else {
+      const int c = (int)(i - 2 * n1 - se);
+      for (int n = 0; n < N; ++n) t += dh2[(long long)n * C + c];
+      db2[c] = t;
+    }
+  }
+}
+
+// dx = dy * g + dp / HW
+__global__ void __launch_bounds__(DW_THREADS)
+se_bwd_apply_kernel(const uint4* __restrict__ dy, uint4* __restrict__ dx, const float* __restrict__ gate,
+                    const float* __restrict__ dp, int HW, int C8, long long total) {
+  const float inv = 1.0f / (float)HW;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C8);
+    const long long n = i / ((long long)HW * C8);
+    bf8 v = unpack8(dy[i]);
+    const float* g = gate + (n * C8 + c) * 8;
+    const float* d = dp + (n * C8 + c) * 8;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v.v[q] = v.v[q] * g[q] + d[q] * inv;
+    dx[i] = pack8(v);
+  }
+}
+
+// x: the un-gated input of the forward, dy: gradient wrt the gated output, state: from rn_squeeze_excite_fwd.
+// dx may alias dy.  dw1 [se][C], db1 [se], dw2 [C][se], db2 [C] are overwritten.  workspace: rn_se_workspace_bytes.
+extern "C" int rn_squeeze_excite_bwd(const void* x, const void* dy, void* dx, int N, int HW, int C, const void* w_reduce,
+                                     const void* w_expand, int se, const void* state, float* dw1, float* db1,
+                                     float* dw2, float* db2, void* workspace, size_t workspace_bytes, void* stream) {
+  RN_CHECK_ARG(x && dy && dx && w_reduce && w_expand && state && dw1 && db1 && dw2 && db2 && N > 0 && HW > 0 &&
+                   C % 8 == 0 && se > 0 && se <= C && (size_t)(C + se) * 4 <= 64 * 1024,
+               "rn_squeeze_excite_bwd: bad argument");
+  if (!workspace || workspace_bytes < rn_se_workspace_bytes(N, C)) {
+    rn_set_error("rn_squeeze_excite_bwd: workspace too small");
+    return RN_ENOMEM;
+  }
   hipStream_t st = (hipStream_t)stream;
-  float* pooled = (float*)workspace;
-  float* gate = pooled + (size_t)N * C;
-  hipLaunchKernelGGL(se_pool_kernel, dim3((C + 63) / 64, N), dim3(256), 0, st, (const uint4*)x, HW, C / 8, pooled);
+  float* dgate = (float*)workspace;
+  float* dh2 = dgate + (size_t)N * C;
+  float* dp = dh2 + (size_t)N * C;
+  float* dh1 = dp + (size_t)N * C;
+  const float* stf = (const float*)state;
+  hipLaunchKernelGGL(se_bwd_pool_kernel, dim3((C + 63) / 64, N), dim3(256), 0, st, (const uint4*)x, (const uint4*)dy,
+                     HW, C / 8, dgate);
   RN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(se_fc_kernel, dim3(N), dim3(256), (size_t)(C + se) * 4, st, pooled, (const uint16_t*)w_reduce,
-                     b_reduce, (const uint16_t*)w_expand, b_expand, C, se, gate);
+  hipLaunchKernelGGL(se_bwd_fc_kernel, dim3(N), dim3(256), (size_t)(C + se) * 4, st, stf, dgate,
+                     (const uint16_t*)w_reduce, (const uint16_t*)w_expand, N, C, se, dh2, dh1, dp);
+  RN_CHECK_LAUNCH();
+  const long long nel = 2ll * se * C + se + C;
+  hipLaunchKernelGGL(se_bwd_wgrad_kernel, dim3((unsigned)rn_cdiv(nel, 256)), dim3(256), 0, st, stf, dh2, dh1, N, C, se,
+                     dw1, db1, dw2, db2);
   RN_CHECK_LAUNCH();
   const long long total = (long long)N * HW * (C / 8);
   long long blocks = rn_cdiv(total, DW_THREADS);
   if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(se_gate_kernel, dim3((unsigned)blocks), dim3(DW_THREADS), 0, st, (uint4*)x, gate, HW, C / 8,
-                     total);
+  hipLaunchKernelGGL(se_bwd_apply_kernel, dim3((unsigned)blocks), dim3(DW_THREADS), 0, st, (const uint4*)dy, (uint4*)dx,
+                     stf + (size_t)N * C, dp, HW, C / 8, total);
   RN_CHECK_LAUNCH();
   return RN_OK;
 }

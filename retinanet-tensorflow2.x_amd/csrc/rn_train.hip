@@ -38,6 +38,15 @@ __device__ __forceinline__ float act_mask(float z, int act) {
   if (act == RN_ACT_RELU6) return (z > 0.0f && z < 6.0f) ? 1.0f : 0.0f;
   return 1.0f;
 }
+// d act(u) / du: relu / relu6 from the stored output z, swish from the recomputed pre-activation u
+// (swish'(u) = s + u*s*(1-s), s = sigmoid(u); tf.nn.swish's registered gradient)
+__device__ __forceinline__ float act_deriv(float z, float u, int act) {
+  if (act == RN_ACT_SWISH) {
+    const float sg = 1.0f / (1.0f + __expf(-u));
+    return sg + u * sg * (1.0f - sg);
+  }
+  return act_mask(z, act);
+}
 
 static int tr_blocks(long long items, int cap = 8192) {
   long long b = rn_cdiv(items, TR_THREADS);
@@ -77,12 +86,14 @@ __global__ void __launch_bounds__(TR_THREADS) bn_colreduce_kernel(const BnArgs a
   float s0[8], s1[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) s0[q] = s1[q] = 0.0f;
-  float mean[8], istd[8];
+  float mean[8], istd[8], scq[8], shq[8];
   if (a.mode == 1 && live) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       mean[q] = s.fwd[0 * s.C + c8 * 8 + q];
       istd[q] = s.fwd[1 * s.C + c8 * 8 + q];
+      scq[q] = s.fwd[2 * s.C + c8 * 8 + q];
+      shq[q] = s.fwd[3 * s.C + c8 * 8 + q];
     }
   }
   if (live) {
@@ -101,7 +112,8 @@ __global__ void __launch_bounds__(TR_THREADS) bn_colreduce_kernel(const BnArgs a
         if (a.act != RN_ACT_NONE) z = unpack8(s.z[o]);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-          const float g = a.act != RN_ACT_NONE ? dz.v[q] * act_mask(z.v[q], a.act) : dz.v[q];
+          const float g = a.act != RN_ACT_NONE
+                              ? dz.v[q] * act_deriv(z.v[q], y.v[q] * scq[q] + shq[q], a.act) : dz.v[q];
           s0[q] += g;
           s1[q] += g * ((y.v[q] - mean[q]) * istd[q]);
         }
@@ -227,13 +239,14 @@ __global__ void __launch_bounds__(TR_THREADS) bn_bwd_apply_kernel(const BnArgs a
   const long long gtid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (gtid >= lanes) return;
   const int c8 = (int)(gtid % C8);
-  float mean[8], istd[8], sc[8], k1[8], k2[8];
+  float mean[8], istd[8], sc[8], shq[8], k1[8], k2[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     const int c = c8 * 8 + q;
     mean[q] = s.fwd[0 * s.C + c];
     istd[q] = s.fwd[1 * s.C + c];
     sc[q] = s.fwd[2 * s.C + c];
+    shq[q] = s.fwd[3 * s.C + c];
     k1[q] = s.bsums[c] * inv_n;
     k2[q] = s.bsums[s.C + c] * inv_n;
   }
@@ -245,7 +258,7 @@ __global__ void __launch_bounds__(TR_THREADS) bn_bwd_apply_kernel(const BnArgs a
     bf8 g, o;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      g.v[q] = a.act != RN_ACT_NONE ? dz.v[q] * act_mask(z.v[q], a.act) : dz.v[q];
+      g.v[q] = a.act != RN_ACT_NONE ? dz.v[q] * act_deriv(z.v[q], y.v[q] * sc[q] + shq[q], a.act) : dz.v[q];
       const float xh = (y.v[q] - mean[q]) * istd[q];
       o.v[q] = sc[q] * (g.v[q] - k1[q] - xh * k2[q]);
     }

@@ -49,6 +49,7 @@ class WgradProblem(Structure):
 
 class DwSegment(Structure):
     _fields_ = [("x", c_void_p), ("w", c_void_p), ("y", c_void_p), ("scale", c_void_p), ("shift", c_void_p),
+                ("residual", c_void_p),
                 ("N", c_int32), ("H", c_int32), ("W", c_int32), ("C", c_int32), ("Ho", c_int32), ("Wo", c_int32)]
 
 
@@ -106,6 +107,14 @@ _SIGNATURES = {
     "rn_conv_cin_pad": (c_int, [c_int]),
     "rn_depthwise_conv2d_nhwc_fwd": (c_int, [POINTER(DwProblem), c_void_p]),
     "rn_pack_depthwise_weight": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "rn_pack_depthwise_weight_flip": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "rn_depthwise_wgrad_workspace_bytes": (c_size_t, [POINTER(DwProblem)]),
+    "rn_depthwise_conv2d_nhwc_wgrad": (c_int, [POINTER(DwProblem), c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rn_squeeze_excite_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_int, c_void_p, c_size_t, c_void_p]),
+    "rn_squeeze_excite_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rn_pack_conv_weight_ohwi": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rn_se_workspace_bytes": (c_size_t, [c_int, c_int]),
     "rn_squeeze_excite_inplace": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_int, c_void_p, c_size_t, c_void_p]),

@@ -95,6 +95,105 @@ def test_squeeze_excite(cuda, N, HW, C, se):
     assert ((got - want).abs() <= 2.0 ** -8 * want.abs() + 1e-6).float().mean() > 0.97
 
 
+@pytest.mark.parametrize("N,H,W,C,k,s", [(2, 16, 16, 144, 3, 1), (2, 20, 20, 96, 5, 2), (1, 9, 7, 64, 5, 1),
+                                         (2, 12, 12, 48, 3, 2), (1, 8, 8, 160, 1, 1)])
+def test_depthwise_backward(cuda, N, H, W, C, k, s):
+    """dgrad = the forward kernel on (zero-upsampled) dy with the tap-reversed filter; wgrad = the two-stage
+    reduction kernel; both against torch autograd on the same bf16-rounded operands."""
+    from retinanet import _C
+    lib = _C.lib()
+    g = torch.Generator().manual_seed(C * k + s)
+    x = _bf(torch.randn((N, H, W, C), generator=g))
+    w = torch.randn((k, k, C, 1), generator=g) * (1.0 / k)
+    xp, pt, pl = _same(x.permute(0, 3, 1, 2), k, s)
+    xa = x.double().requires_grad_(True)
+    wa = _bf(w).double().requires_grad_(True)
+    xpa, _, _ = _same(xa.permute(0, 3, 1, 2), k, s)
+    ya = F.conv2d(xpa, wa.permute(2, 3, 0, 1), None, stride=s, groups=C).permute(0, 2, 3, 1)
+    Ho, Wo = ya.shape[1], ya.shape[2]
+    dy = _bf(torch.randn((N, Ho, Wo, C), generator=g))
+    (ya * dy.double()).sum().backward()
+    st = _C.current_stream()
+    xd, dyd = x.to(cuda, torch.bfloat16).contiguous(), dy.to(cuda, torch.bfloat16).contiguous()
+    master = w.reshape(k * k, C).to(cuda).contiguous()          # f32 master [k*k][C]
+    # ---- weight gradient
+    p = _C.DwProblem()
+    p.k, p.stride, p.pad_top, p.pad_left, p.act, p.num_segments = k, s, pt, pl, 0, 1
+    sg = p.seg[0]
+    sg.x, sg.y = xd.data_ptr(), dyd.data_ptr()
+    sg.N, sg.H, sg.W, sg.C, sg.Ho, sg.Wo = N, H, W, C, Ho, Wo
+    ws = torch.empty(max(lib.rn_depthwise_wgrad_workspace_bytes(ctypes.byref(p)), 16), dtype=torch.uint8, device=cuda)
+    dw = torch.empty((k * k, C), dtype=torch.float32, device=cuda)
+    _C.check(lib.rn_depthwise_conv2d_nhwc_wgrad(ctypes.byref(p), _C.ptr(dw), _C.ptr(ws), ws.numel(), st), "dw wgrad")
+    torch.cuda.synchronize()
+    want_dw = wa.grad.reshape(k * k, C).float()
+    torch.testing.assert_close(dw.cpu(), want_dw, rtol=2e-3, atol=2e-3 * want_dw.abs().max().item())
+    # ---- data gradient
+    wflip = torch.empty((k * k, C), dtype=torch.bfloat16, device=cuda)
+    _C.check(lib.rn_pack_depthwise_weight_flip(_C.ptr(master), k, C, _C.ptr(wflip), st), "flip")
+    src = dyd
+    if s == 2:
+        src = torch.empty((N, H, W, C), dtype=torch.bfloat16, device=cuda)
+        _C.check(lib.rn_upsample_zero2x(_C.ptr(dyd), _C.ptr(src), N, Ho, Wo, C, H, W, st), "up")
+    old = _bf(torch.randn((N, H, W, C), generator=g)).to(cuda, torch.bfloat16)   # an already written gradient
+    dx = torch.empty((N, H, W, C), dtype=torch.bfloat16, device=cuda)
+    q = _C.DwProblem()
+    q.k, q.stride, q.pad_top, q.pad_left, q.act, q.num_segments = k, 1, k - 1 - pt, k - 1 - pl, 0, 1
+    sq = q.seg[0]
+    sq.x, sq.w, sq.y, sq.residual = src.data_ptr(), wflip.data_ptr(), dx.data_ptr(), old.data_ptr()
+    sq.N, sq.H, sq.W, sq.C, sq.Ho, sq.Wo = N, H, W, C, H, W
+    _C.check(lib.rn_depthwise_conv2d_nhwc_fwd(ctypes.byref(q), st), "dw dgrad")
+    torch.cuda.synchronize()
+    want_dx = (xa.grad + old.float().cpu().double()).float()
+    got = dx.float().cpu()
+    assert ((got - want_dx).abs() <= 2.0 ** -7 * want_dx.abs().clamp_min(0.5)).all(), (got - want_dx).abs().max().item()
+
+
+@pytest.mark.parametrize("N,HW,C,se", [(4, 20 * 20, 144, 6), (3, 10 * 10, 816, 34), (2, 49, 96, 4)])
+def test_squeeze_excite_train_forward_backward(cuda, N, HW, C, se):
+    from retinanet import _C
+    lib = _C.lib()
+    g = torch.Generator().manual_seed(C + 1)
+    x = _bf(torch.randn((N, HW, C), generator=g) + 0.3)
+    w1 = _bf(torch.randn((se, C), generator=g) * (2.0 / C) ** 0.5)
+    b1 = torch.randn(se, generator=g) * 0.1
+    w2 = _bf(torch.randn((C, se), generator=g) * (2.0 / se) ** 0.5)
+    b2 = torch.randn(C, generator=g) * 0.1
+    dy = _bf(torch.randn((N, HW, C), generator=g))
+    leaves = [t.double().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    xa, w1a, b1a, w2a, b2a = leaves
+    h = xa.mean(dim=1) @ w1a.t() + b1a
+    h = h * torch.sigmoid(h)
+    gate = torch.sigmoid(h @ w2a.t() + b2a)
+    ya = xa * gate[:, None, :]
+    (ya * dy.double()).sum().backward()
+    st = _C.current_stream()
+    dev = lambda t, dt=None: t.to(cuda, dt).contiguous() if dt else t.to(cuda).contiguous()
+    xd, dyd = dev(x, torch.bfloat16), dev(dy, torch.bfloat16)
+    w1d, w2d, b1d, b2d = dev(w1, torch.bfloat16), dev(w2, torch.bfloat16), dev(b1), dev(b2)
+    nbytes = lib.rn_se_workspace_bytes(N, C)
+    state = torch.empty(nbytes, dtype=torch.uint8, device=cuda)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=cuda)
+    yd = torch.empty_like(xd)
+    _C.check(lib.rn_squeeze_excite_fwd(_C.ptr(xd), _C.ptr(yd), N, HW, C, _C.ptr(w1d), _C.ptr(b1d), _C.ptr(w2d),
+                                       _C.ptr(b2d), se, _C.ptr(state), nbytes, st), "se fwd")
+    dx = torch.empty_like(xd)
+    dw1 = torch.empty((se, C), device=cuda); db1 = torch.empty((se,), device=cuda)
+    dw2 = torch.empty((C, se), device=cuda); db2 = torch.empty((C,), device=cuda)
+    _C.check(lib.rn_squeeze_excite_bwd(_C.ptr(xd), _C.ptr(dyd), _C.ptr(dx), N, HW, C, _C.ptr(w1d), _C.ptr(w2d), se,
+                                       _C.ptr(state), _C.ptr(dw1), _C.ptr(db1), _C.ptr(dw2), _C.ptr(db2), _C.ptr(ws),
+                                       nbytes, st), "se bwd")
+    torch.cuda.synchronize()
+    torch.testing.assert_close(yd.float().cpu(), ya.detach().float(), rtol=2 ** -6, atol=1e-2)
+    # the kernel differentiates through its bf16-rounded intermediates: compare direction and size
+    for name, got, want in (("dx", dx.float().cpu(), xa.grad), ("dw1", dw1.cpu(), w1a.grad), ("db1", db1.cpu(), b1a.grad),
+                            ("dw2", dw2.cpu(), w2a.grad), ("db2", db2.cpu(), b2a.grad)):
+        a, b = got.double().reshape(-1), want.reshape(-1)
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
+        assert cos > 0.999, (name, cos)
+        assert abs(float(a.norm() / (b.norm() + 1e-30)) - 1.0) < 0.02, (name, float(a.norm() / b.norm()))
+
+
 def _randomize(model, seed):
     g = torch.Generator().manual_seed(seed)
     for k, v in model.variables.items():

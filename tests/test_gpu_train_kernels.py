@@ -141,7 +141,8 @@ def _bn_problem(cuda, segs, act, eps=1e-3, momentum=0.99, bessel=1, with_bwd=Fal
     return p, dev
 
 
-@pytest.mark.parametrize("act,use_res", [("relu", True), ("relu", False), (None, False), ("relu6", True)])
+@pytest.mark.parametrize("act,use_res", [("relu", True), ("relu", False), (None, False), ("relu6", True),
+                                         ("swish", False)])
 def test_bn_train_forward_backward(cuda, act, use_res):
     from retinanet import _C
     lib = _C.lib()
@@ -174,11 +175,15 @@ def test_bn_train_forward_backward(cuda, act, use_res):
         v = (y - mean) / torch.sqrt(var + 1e-3) * gam + bet
         if use_res:
             v = v + res
-        z = F.relu(v) if act == "relu" else (F.relu6(v) if act == "relu6" else v)
+        z = F.relu(v) if act == "relu" else (F.relu6(v) if act == "relu6" else (v * torch.sigmoid(v) if act == "swish" else v))
         torch.testing.assert_close(d["z"].float().cpu().double(), z.detach(), rtol=1 / 100, atol=2e-2)
-        # backward through the bf16-rounded z mask the kernel sees
+        # backward through the bf16-rounded z mask the kernel sees (swish: through the recomputed pre-activation)
         zk = d["z"].float().cpu().double()
-        mask = torch.ones_like(zk) if act is None else ((zk > 0) & ((zk < 6) if act == "relu6" else True)).double()
+        if act == "swish":
+            sg = torch.sigmoid(v.detach())
+            mask = sg + v.detach() * sg * (1 - sg)
+        else:
+            mask = torch.ones_like(zk) if act is None else ((zk > 0) & ((zk < 6) if act == "relu6" else True)).double()
         gz = _bf(s["dz"]).double() * mask
         (v * gz.detach()).sum().backward()
         torch.testing.assert_close(d["dy"].float().cpu().double(), y.grad, rtol=2e-2, atol=2e-2 * y.grad.abs().max().item())
