@@ -295,9 +295,13 @@ class RefTrainer(RefModel):
         y = super()._conv(x, name, stride, pad, f32, kernel)
         # training materialises the pre-BN conv output as bf16 (frozen layers fold BN: no rounding;
         # the fp32 prediction convs stay fp32)
-        if self.bf and not f32 and (name + "/kernel") not in self.frozen:
+        if self.bf and not f32 and (name + kernel) not in self.frozen:
             y = _r(y, True)
         return y
+
+    def _depthwise(self, x, var, stride=1):
+        y = super()._depthwise(x, var, stride)
+        return _r(y, True) if self.bf and var not in self.frozen else y   # raw depthwise output is a bf16 tensor
 
     def _bn(self, x, name):
         g, b = self.v[name + "/gamma"], self.v[name + "/beta"]
@@ -348,7 +352,7 @@ class RefTrainer(RefModel):
         alpha = self.p.training.weight_decay_alpha
         tot = 0.0
         for k, t in self.leaf.items():
-            if k.endswith("/kernel"):
+            if "kernel" in k.rsplit("/", 1)[-1]:   # kernel / depthwise_kernel / pointwise_kernel (executor.py:308-327)
                 tot = tot + alpha * 0.5 * (t * t).sum()   # tf.nn.l2_loss = sum(w^2)/2
         return tot
 

@@ -65,6 +65,7 @@ class TrainEngine:
         self._keep = []
         self.step_count = 0
         self.conv_profile = None
+        self._prepare_graph()
         with torch.cuda.device(self.dev):
             self._analyse()
             self._alloc_params()
@@ -74,16 +75,53 @@ class TrainEngine:
             self._build_backward()
 
     # ------------------------------------------------------------------------------------------
+    def _prepare_graph(self):
+        """Engine-local copy of the op list: squeeze-excite runs out of place in training (its backward
+        needs the un-gated input), so `se` ops get an output tensor `<t>:se` and later readers of `<t>` are
+        redirected to it.  Also classifies every variable (compute layout, weight decay)."""
+        g = self.g
+        self.tensors = dict(g.tensors)
+        self.ops = []
+        alias = {}
+        for op in g.ops:
+            o = dict(op)
+            for key in ("inp", "residual"):
+                if o.get(key) in alias:
+                    o[key] = alias[o[key]]
+            if o["op"] == "se":
+                t = o["tensor"]
+                o["inp"], o["out"] = alias.get(t, t), t + ":se"
+                self.tensors[o["out"]] = g.tensors[t]
+                alias[t] = o["out"]
+            if o["op"] in ("topdown",):
+                o["ins"] = [alias.get(n, n) for n in o["ins"]]
+            self.ops.append(o)
+        # variable name -> (kind, layer): conv / dw / se1 / se2 kernels are weight-decayed
+        # (executor.py:308-327: every trainable variable with 'kernel' in its name)
+        self.var_kind = {}
+        for cname, c in g.convs.items():
+            self.var_kind[c.get("kvar", cname + "/kernel")] = ("conv", cname)
+        for dname, d in getattr(g, "dws", {}).items():
+            self.var_kind[d["kvar"]] = ("dw", dname)
+        for sname in getattr(g, "ses", {}):
+            self.var_kind[sname + "/conv2d/kernel"] = ("se1", sname)
+            self.var_kind[sname + "/conv2d_1/kernel"] = ("se2", sname)
+
+    def _kvar(self, op):
+        if op["op"] == "dwconv":
+            return self.g.dws[op["dw"]]["kvar"]
+        c = self.g.convs[op["conv"]]
+        return c.get("kvar", op["conv"] + "/kernel")
+
     def _conv_trainable(self, op):
-        return (op["conv"] + "/kernel") not in self.frozen
+        return self._kvar(op) not in self.frozen
 
     def _bn_trainable(self, op):
         return op.get("bn") and (op["bn"] + "/gamma") not in self.frozen
 
     def _analyse(self):
-        g = self.g
         self.requires = {"images": False}
-        for op in g.ops:
+        for op in self.ops:
             kind = op["op"]
             if kind in ("conv", "stem"):
                 tr = self._conv_trainable(op) or bool(self._bn_trainable(op))
@@ -97,13 +135,21 @@ class TrainEngine:
                     self.requires[o] = r or self.requires.get(o, False)
             elif kind == "balance":
                 pass
+            elif kind == "dwconv":
+                if not self._conv_trainable(op):
+                    raise NotImplementedError("frozen depthwise layers are not a shipped configuration")
+                self.requires[op["out"]] = True
+            elif kind == "se":
+                if any((op["se"] + sfx) in self.frozen for sfx in ("/conv2d/kernel", "/conv2d_1/kernel")):
+                    raise NotImplementedError("frozen squeeze-excite layers are not a shipped configuration")
+                self.requires[op["out"]] = True
             else:
-                raise NotImplementedError(f"training through '{kind}' ops (EfficientNet / SeparableConv2D, SURVEY §8 "
-                                          "row a18) is not built yet: only their inference path is")
+                raise NotImplementedError(f"training through '{kind}' ops is not built")
         # a conv layer is "live" when its kernel trains; mixed frozen conv / live BN is not a shipped case
-        for op in g.ops:
-            if op["op"] in ("conv", "stem") and op.get("bn") and self._conv_trainable(op) != bool(self._bn_trainable(op)):
-                raise NotImplementedError(f"{op['conv']}: conv and its BatchNorm must be frozen together")
+        for op in self.ops:
+            if op["op"] in ("conv", "stem", "dwconv") and op.get("bn") and \
+                    self._conv_trainable(op) != bool(self._bn_trainable(op)):
+                raise NotImplementedError(f"{self._kvar(op)}: conv and its BatchNorm must be frozen together")
 
     # ---- flat parameter arenas ---------------------------------------------------------------------
     def _alloc_params(self):
@@ -114,23 +160,38 @@ class TrainEngine:
         self.train_names = names
         segs, block_seg = [], []
         off = bf_off = nblk = 0
-        self.p_off, self.bf_off = {}, {}
+        self.p_off, self.bf_off = {}, {}     # bf_off: conv name | "dw:<name>" | "<se>:w1" / "<se>:w2" -> offset in Pbf
+        self.fwd_packs = []                  # live convs whose Cin is not its own K-step padding: repacked per step
+        self.fwd_pack_of = {}
         for i, k in enumerate(names):
             n = v[k].numel()
-            is_kernel = k.endswith("/kernel")
+            kind, layer = self.var_kind.get(k, ("other", None))
             bfo = -1
-            if is_kernel and self.g.convs[k[:-len("/kernel")]]["cin"] != 3:   # the stem has its own packed form
-                if lib.rn_conv_cin_pad(self.g.convs[k[:-len("/kernel")]]["cin"]) != self.g.convs[k[:-len("/kernel")]]["cin"]:
-                    raise NotImplementedError("training needs Cin to equal its K-step padding (32 or a multiple of 64): "
-                                              "the bf16 compute copy is a plain cast of the master weights")
-                cname = k[:-len("/kernel")]
-                c = self.g.convs[cname]
+            if kind == "conv":
+                c = self.g.convs[layer]
+                if c["cin"] == 3:
+                    pass                                        # first-layer conv: its own packed form
+                elif lib.rn_conv_cin_pad(c["cin"]) == c["cin"]:
+                    bfo = bf_off                                # plain cast of the master = the compute layout
+                    self.bf_off[layer] = bf_off
+                    bf_off += lib.rn_conv_cout_pad(c["cout"]) * c["k"] * c["k"] * c["cin"]
+                else:
+                    cinp = lib.rn_conv_cin_pad(c["cin"])
+                    buf = torch.zeros((lib.rn_conv_cout_pad(c["cout"]), c["k"], c["k"], cinp), dtype=torch.bfloat16,
+                                      device=self.dev)
+                    self.fwd_packs.append((k, c, cinp, buf))
+                    self.fwd_pack_of[layer] = buf
+            elif kind == "dw":
                 bfo = bf_off
-                self.bf_off[cname] = bf_off
-                bf_off += lib.rn_conv_cout_pad(c["cout"]) * c["k"] * c["k"] * c["cin"]
-                bf_off = (bf_off + 7) // 8 * 8
+                self.bf_off["dw:" + layer] = bf_off
+                bf_off += n
+            elif kind in ("se1", "se2"):
+                bfo = bf_off
+                self.bf_off[layer + (":w1" if kind == "se1" else ":w2")] = bf_off
+                bf_off += n
+            bf_off = (bf_off + 7) // 8 * 8
             nb = (n + chunk - 1) // chunk
-            segs.append((off, n, 1 if is_kernel else 0, nblk, nb, 0, bfo))   # executor.py:308-327: kernels only
+            segs.append((off, n, 1 if kind != "other" else 0, nblk, nb, 0, bfo))   # executor.py:308-327: kernels only
             block_seg += [i] * nb
             self.p_off[k] = (off, n)
             off += (n + 3) // 4 * 4
@@ -141,6 +202,7 @@ class TrainEngine:
         self.V = torch.zeros_like(self.P)
         self.E = torch.zeros_like(self.P)
         self.Pbf = torch.zeros((max(bf_off, 8),), dtype=torch.bfloat16, device=self.dev)
+        self._bf_copies = [(self.p_off[k], s[6]) for k, s in zip(names, segs) if s[6] >= 0]
         seg_np = np.zeros((len(segs),), dtype=_SEG_DTYPE)
         for i, s in enumerate(segs):
             seg_np[i] = s
@@ -156,38 +218,47 @@ class TrainEngine:
         off, n = self.p_off[name]
         return (self.P if arena is None else arena)[off:off + n]
 
+    def _to_compute_layout(self, k, t):
+        kind = self.var_kind.get(k, ("other", None))[0]
+        return _hwio_to_ohwi(t) if kind in ("conv", "se1", "se2") else t
+
     def load_from_model(self):
-        """model.variables (HWIO kernels) -> flat arenas (OHWI) + bf16 compute copies."""
+        """model.variables (Keras layouts) -> flat arenas (conv / SE kernels as [Cout][R][S][Cin], depthwise
+        kernels as [k*k][C]) + bf16 compute copies."""
         v = self.model.variables
         for k in self.train_names:
-            t = v[k].to(self.dev, torch.float32)
-            if k.endswith("/kernel"):
-                t = _hwio_to_ohwi(t)
+            t = self._to_compute_layout(k, v[k].to(self.dev, torch.float32))
             self._pview(k).copy_(t.reshape(-1))
         self.E.copy_(self.P)
         self.V.zero_()
-        for k in self.train_names:
-            if k.endswith("/kernel") and k[:-len("/kernel")] in self.bf_off:
-                cname = k[:-len("/kernel")]
-                off, n = self.p_off[k]
-                self.Pbf[self.bf_off[cname]:self.bf_off[cname] + n].copy_(self.P[off:off + n])
-        self.refresh_stem_pack()
+        for (off, n), bfo in self._bf_copies:
+            self.Pbf[bfo:bfo + n].copy_(self.P[off:off + n])
+        self.refresh_packs()
 
     def _stem_op(self):
-        return next(o for o in self.g.ops if o["op"] == "stem")
+        return next(o for o in self.ops if o["op"] == "stem")
+
+    def refresh_packs(self):
+        """per-step repacks from the f32 masters: the live first-layer conv ([Cout][R][S][3] ->
+        bf16 [Cout_pad][R rows][8 taps x 4 ch]) and live convs whose Cin is zero-padded to the K step."""
+        st = _C.current_stream()
+        op = self._stem_op()
+        if self._conv_trainable(op):
+            c = self.g.convs[op["conv"]]
+            k = c["k"]
+            if getattr(self, "stem_packed", None) is None:
+                self.stem_packed = torch.zeros((self.lib.rn_conv_cout_pad(c["cout"]), k, 32), dtype=torch.bfloat16,
+                                               device=self.dev)
+            w = _ohwi_to_hwio(self._pview(self._kvar(op)).reshape(c["cout"], k, k, 3))
+            _C.check(self.lib.rn_pack_stem_weight_rs(_C.ptr(w), k, k, c["cout"], _C.ptr(self.stem_packed), st),
+                     "rn_pack_stem_weight_rs")
+        for (kname, c, cinp, buf) in self.fwd_packs:
+            off, _ = self.p_off[kname]
+            _C.check(self.lib.rn_pack_conv_weight_ohwi(self.P.data_ptr() + 4 * off, c["k"], c["k"], c["cin"], c["cout"],
+                                                       cinp, buf.data_ptr(), st), "rn_pack_conv_weight_ohwi")
 
     def refresh_stem_pack(self):
-        """live stem: master [64][7][7][3] (compute layout) -> bf16 [64][7 rows][8 taps x 4 ch]."""
-        op = self._stem_op()
-        if not self._conv_trainable(op):
-            return
-        c = self.g.convs[op["conv"]]
-        if getattr(self, "stem_packed", None) is None:
-            self.stem_packed = torch.zeros((self.lib.rn_conv_cout_pad(c["cout"]), 7, 32), dtype=torch.bfloat16,
-                                           device=self.dev)
-        w = _ohwi_to_hwio(self._pview(op["conv"] + "/kernel").reshape(c["cout"], 7, 7, 3))
-        _C.check(self.lib.rn_pack_stem_weight(_C.ptr(w), c["cout"], _C.ptr(self.stem_packed), _C.current_stream()),
-                 "rn_pack_stem_weight")
+        self.refresh_packs()
 
     def store_to_model(self, use_ema=False):
         """flat arenas -> model.variables (executor.assign_moving_averaged_weights when use_ema)."""
@@ -195,9 +266,10 @@ class TrainEngine:
         src = self.E if use_ema else self.P
         for k in self.train_names:
             t = self._pview(k, src)
-            if k.endswith("/kernel"):
-                c = self.g.convs[k[:-len("/kernel")]]
-                t = _ohwi_to_hwio(t.reshape(c["cout"], c["k"], c["k"], c["cin"]))
+            kind = self.var_kind.get(k, ("other", None))[0]
+            if kind in ("conv", "se1", "se2"):
+                kh, kw, ci, co = v[k].shape
+                t = _ohwi_to_hwio(t.reshape(co, kh, kw, ci))
             v[k].copy_(t.reshape(v[k].shape))
         for bn, d in self.bn_state.items():
             v[bn + "/moving_mean"].copy_(d["mm"])
@@ -208,24 +280,39 @@ class TrainEngine:
     def _alloc_tensors(self):
         B, dev = self.B, self.dev
         self.t, self.raw, self.grad = {}, {}, {}
-        for name, (H, W, C, dt) in self.g.tensors.items():
+        for name, (H, W, C, dt) in self.tensors.items():
             self.t[name] = torch.empty((B, H, W, C), dtype=_DT[dt], device=dev)
-        H, W, _, _ = self.g.tensors["images"]
-        self.Wp = self.lib.rn_stem_padded_width(W)
-        self.stem_in = torch.empty((B, H + 6, self.Wp, 4), dtype=torch.bfloat16, device=dev)
-        for op in self.g.ops:
-            if op["op"] in ("conv", "stem") and self._bn_trainable(op):
+        # first-layer conv: zero-bordered bf16 NHWC4 copy of the image (rn_pack_image_nhwc4)
+        stem = self._stem_op()
+        Hs, Ws = self.tensors[stem["out"]][:2]
+        self.stem_k = stem.get("k", 7)
+        self.stem_pad = (stem.get("pad_top", 3), stem.get("pad_left", 3))
+        H, W, _, _ = self.tensors["images"]
+        self.Hp = max((Hs - 1) * 2 + self.stem_k, H + self.stem_pad[0])
+        self.Wp = -(-max((Ws - 1) * 2 + 8, W + self.stem_pad[1]) // 8) * 8
+        self.stem_in = torch.empty((B, self.Hp, self.Wp, 4), dtype=torch.bfloat16, device=dev)
+        for op in self.ops:
+            if op["op"] in ("conv", "stem", "dwconv") and self._bn_trainable(op):
                 self.raw[op["out"]] = torch.empty_like(self.t[op["out"]])
+        # squeeze-excite: saved forward state per op + one shared workspace
+        self.se_state = {}
+        se_bytes = 0
+        for op in self.ops:
+            if op["op"] == "se":
+                nb = self.lib.rn_se_workspace_bytes(B, self.g.ses[op["se"]]["C"])
+                self.se_state[op["out"]] = torch.empty((nb,), dtype=torch.uint8, device=dev)
+                se_bytes = max(se_bytes, nb)
+        self.se_ws = torch.empty((max(se_bytes, 16),), dtype=torch.uint8, device=dev)
         # balance features runs out of place in training (its backward needs the inputs)
         self.bal_out = {}
-        for op in self.g.ops:
+        for op in self.ops:
             if op["op"] == "balance":
                 for n in op["tensors"]:
                     self.bal_out[n] = torch.empty_like(self.t[n])
         # gradient buffers (bf16) for every tensor that needs one
         need = set()
-        for op in self.g.ops:
-            if op["op"] == "conv" and self.requires.get(op["out"]):
+        for op in self.ops:
+            if op["op"] in ("conv", "dwconv", "se") and self.requires.get(op["out"]):
                 need.add(op["out"])
                 for i in [op["inp"]] + ([op["residual"]] if op.get("residual") else []):
                     if self.requires.get(i):
@@ -239,13 +326,13 @@ class TrainEngine:
                     if self.requires.get(n):
                         need.add(n)
         for n in need:
-            H, W, C, _ = self.g.tensors[n]
+            H, W, C, _ = self.tensors[n]
             self.grad[n] = torch.zeros((B, H, W, C), dtype=torch.bfloat16, device=dev)
         for n, t in self.bal_out.items():
             self.grad["bal:" + n] = torch.zeros_like(t)
         self.bn_state = {}
-        for op in self.g.ops:
-            if op["op"] in ("conv", "stem") and self._bn_trainable(op):
+        for op in self.ops:
+            if op["op"] in ("conv", "stem", "dwconv") and self._bn_trainable(op):
                 bn = op["bn"]
                 self.bn_state[bn] = {"mm": self.model.variables[bn + "/moving_mean"].to(dev, torch.float32).clone(),
                                      "mv": self.model.variables[bn + "/moving_variance"].to(dev, torch.float32).clone()}
@@ -255,16 +342,17 @@ class TrainEngine:
         lib, v = self.lib, self.model.variables
         st = _C.current_stream()
         self.fold, self.packed_frozen = {}, {}
-        for op in self.g.ops:
+        for op in self.ops:
             if op["op"] not in ("conv", "stem") or self._conv_trainable(op):
                 continue
             cname = op["conv"]
             c = self.g.convs[cname]
-            w = v[cname + "/kernel"].to(self.dev, torch.float32).contiguous()
+            w = v[self._kvar(op)].to(self.dev, torch.float32).contiguous()
             cp = lib.rn_conv_cout_pad(c["cout"])
             if op["op"] == "stem":
-                buf = torch.empty((cp, 7, 32), dtype=torch.bfloat16, device=self.dev)
-                _C.check(lib.rn_pack_stem_weight(_C.ptr(w), c["cout"], _C.ptr(buf), st), "rn_pack_stem_weight")
+                buf = torch.empty((cp, c["k"], 32), dtype=torch.bfloat16, device=self.dev)
+                _C.check(lib.rn_pack_stem_weight_rs(_C.ptr(w), c["k"], c["k"], c["cout"], _C.ptr(buf), st),
+                         "rn_pack_stem_weight_rs")
             else:
                 cinp = lib.rn_conv_cin_pad(c["cin"])
                 buf = torch.empty((cp, c["k"], c["k"], cinp), dtype=torch.bfloat16, device=self.dev)
@@ -325,6 +413,8 @@ class TrainEngine:
     def _weight_ptr(self, cname):
         if cname in self.packed_frozen:
             return self.packed_frozen[cname].data_ptr()
+        if cname in self.fwd_pack_of:
+            return self.fwd_pack_of[cname].data_ptr()
         return self.Pbf.data_ptr() + 2 * self.bf_off[cname]
 
     def _conv_problem(self, ops, dst_of, raw_mode):
@@ -340,7 +430,7 @@ class TrainEngine:
         p.num_segments = len(ops)
         for i, op in enumerate(ops):
             c = self.g.convs[op["conv"]]
-            x, y = self.t[op["inp"]] if op["inp"] not in self.bal_src else self.bal_src[op["inp"]], dst_of(op)
+            x, y = self._src(op["inp"]), dst_of(op)
             s = p.seg[i]
             s.x, s.w, s.y = x.data_ptr(), self._weight_ptr(op["conv"]), y.data_ptr()
             if raw_mode:
@@ -361,20 +451,39 @@ class TrainEngine:
         self._keep.append(p)
         return p
 
+    def _dw_problem(self, ops, dst_of):
+        """forward depthwise launch over `ops` writing the raw (pre-BN) or final output; bf16 weights are
+        the plain-cast copies of the [k*k][C] masters."""
+        d0 = self.g.dws[ops[0]["dw"]]
+        p = _C.DwProblem()
+        p.k, p.stride, p.pad_top, p.pad_left = d0["k"], d0["stride"], ops[0]["pad_top"], ops[0]["pad_left"]
+        p.act, p.num_segments = _C.RN_ACT_NONE, len(ops)
+        for i, op in enumerate(ops):
+            d = self.g.dws[op["dw"]]
+            if (d["k"], d["stride"], op["pad_top"], op["pad_left"]) != (p.k, p.stride, p.pad_top, p.pad_left):
+                raise ValueError("depthwise group mixes shapes")
+            x, y = self._src(op["inp"]), dst_of(op)
+            s = p.seg[i]
+            s.x, s.w, s.y = x.data_ptr(), self.Pbf.data_ptr() + 2 * self.bf_off["dw:" + op["dw"]], y.data_ptr()
+            s.scale, s.shift, s.residual = None, None, None
+            s.N, s.H, s.W, s.C, s.Ho, s.Wo = self.B, x.shape[1], x.shape[2], d["C"], y.shape[1], y.shape[2]
+        self._keep.append(p)
+        return p
+
     def _bn_problem(self, ops):
         p = _C.BnProblem()
         p.num_segments = len(ops)
         p.act = _C.ACT_IDS[ops[0]["act"]]
         p.bessel = 0 if self.sync_bn else 1
         p.eps, p.momentum, p.count_scale = self.eps, self.momentum_bn, float(self.world if self.sync_bn else 1)
-        csum = sum(self.g.convs[o["conv"]]["cout"] for o in ops)
+        csum = sum(self.tensors[o["out"]][2] for o in ops)
         sums = torch.zeros((2 * csum,), dtype=torch.float32, device=self.dev)
         bsums = torch.zeros((2 * csum,), dtype=torch.float32, device=self.dev)
         fwd = torch.zeros((4 * csum,), dtype=torch.float32, device=self.dev)
         off = 0
         dys = []
         for i, op in enumerate(ops):
-            C = self.g.convs[op["conv"]]["cout"]
+            C = self.tensors[op["out"]][2]
             bn = op["bn"]
             y, z = self.raw[op["out"]], self.t[op["out"]]
             dy = torch.empty_like(y)
@@ -407,7 +516,7 @@ class TrainEngine:
         self.bn_groups = {}   # first op out -> (problem, sums, bsums, ws, dys, ops)
         self.bal_src = {}     # tensor name -> balance output tensor (consumers read the balanced copy)
         done = set()
-        for op in self.g.ops:
+        for op in self.ops:
             kind = op["op"]
             if kind == "stem":
                 img, y = self.t["images"], self.t[op["out"]]
@@ -415,10 +524,11 @@ class TrainEngine:
                 c = self.g.convs[op["conv"]]
                 pin, pimg = self.stem_in.data_ptr(), img.data_ptr()
                 self.fwd_steps.append(lambda st, pimg=pimg, pin=pin, H=H, W=W: _C.check(
-                    lib.rn_pack_stem_input(pimg, B, H, W, pin, st), "rn_pack_stem_input"))
+                    lib.rn_pack_image_nhwc4(pimg, B, H, W, self.stem_pad[0], self.stem_pad[1], self.Hp, self.Wp, pin, st),
+                    "rn_pack_image_nhwc4"))
                 live = self._conv_trainable(op)
                 p = _C.ConvProblem()
-                p.R, p.S, p.stride_h, p.stride_w, p.pad_top, p.pad_left = 7, 1, 2, 2, 0, 0
+                p.R, p.S, p.stride_h, p.stride_w, p.pad_top, p.pad_left = self.stem_k, 1, 2, 2, 0, 0
                 p.act = _C.RN_ACT_NONE if live else _C.ACT_IDS[op["act"]]
                 p.out_dtype, p.num_segments = _C.RN_DT_BF16, 1
                 s = p.seg[0]
@@ -429,7 +539,7 @@ class TrainEngine:
                     sc, sh = self.fold[op["out"]]
                     s.x, s.w, s.y = pin, self.packed_frozen[op["conv"]].data_ptr(), y.data_ptr()
                     s.scale, s.shift, s.residual = sc.data_ptr(), sh.data_ptr(), None
-                s.N, s.H, s.W, s.Cin, s.pix_stride = B, H + 6, self.Wp, 32, 4
+                s.N, s.H, s.W, s.Cin, s.pix_stride = B, self.Hp, self.Wp, 32, 4
                 s.Ho, s.Wo, s.Cout = y.shape[1], y.shape[2], c["cout"]
                 self._keep.append(p)
                 if live:
@@ -454,7 +564,7 @@ class TrainEngine:
                     if grp in done:
                         continue
                     done.add(grp)
-                    ops = [o for o in self.g.ops if o["op"] == "conv" and o.get("group") == grp]
+                    ops = [o for o in self.ops if o["op"] == "conv" and o.get("group") == grp]
                 else:
                     ops = [op]
                 live_bn = bool(self._bn_trainable(ops[0]))
@@ -478,6 +588,46 @@ class TrainEngine:
                 else:
                     pc = self._conv_problem(ops, lambda o: self.t[o["out"]], raw_mode=False)
                     self.fwd_steps.append(lambda st, pc=pc: self._launch_conv(pc, st, "conv"))
+            elif kind == "dwconv":
+                grp = op.get("group")
+                if grp is not None:
+                    if grp in done:
+                        continue
+                    done.add(grp)
+                    ops = [o for o in self.ops if o["op"] == "dwconv" and o.get("group") == grp]
+                else:
+                    ops = [op]
+                live_bn = bool(self._bn_trainable(ops[0]))
+                pd = self._dw_problem(ops, (lambda o: self.raw[o["out"]]) if live_bn else (lambda o: self.t[o["out"]]))
+                prd = ctypes.byref(pd)
+                if live_bn:
+                    pb, sums, bsums, ws, dys = self._bn_problem(ops)
+                    self.bn_groups[ops[0]["out"]] = (pb, sums, bsums, ws, dys, ops)
+                    prb = ctypes.byref(pb)
+
+                    def run_dw(st, prd=prd, prb=prb, ws=ws, sums=sums):
+                        _C.check(lib.rn_depthwise_conv2d_nhwc_fwd(prd, st), "depthwise(train)")
+                        _C.check(lib.rn_bn_stats(prb, _C.ptr(ws), ws.numel(), st), "rn_bn_stats")
+                        if self.sync_bn:
+                            import torch.distributed as dist
+                            dist.all_reduce(sums, group=self.pg)
+                        _C.check(lib.rn_bn_finalize(prb, st), "rn_bn_finalize")
+                        _C.check(lib.rn_bn_apply(prb, st), "rn_bn_apply")
+                    self.fwd_steps.append(run_dw)
+                else:
+                    if ops[0].get("act") not in (None, "none"):
+                        raise NotImplementedError("depthwise conv with an activation but no BatchNorm")
+                    self.fwd_steps.append(lambda st, prd=prd: _C.check(lib.rn_depthwise_conv2d_nhwc_fwd(prd, st),
+                                                                       "depthwise"))
+            elif kind == "se":
+                x, y = self.t[op["inp"]], self.t[op["out"]]
+                name, se = op["se"], self.g.ses[op["se"]]
+                state = self.se_state[op["out"]]
+                a = (x.data_ptr(), y.data_ptr(), B, x.shape[1] * x.shape[2], se["C"],
+                     self.Pbf.data_ptr() + 2 * self.bf_off[name + ":w1"], self._pview(name + "/conv2d/bias").data_ptr(),
+                     self.Pbf.data_ptr() + 2 * self.bf_off[name + ":w2"], self._pview(name + "/conv2d_1/bias").data_ptr(),
+                     se["se"], state.data_ptr(), state.numel())
+                self.fwd_steps.append(lambda st, a=a: _C.check(lib.rn_squeeze_excite_fwd(*a, st), "rn_squeeze_excite_fwd"))
             elif kind == "maxpool":
                 x, y = self.t[op["inp"]], self.t[op["out"]]
                 args = (x.data_ptr(), y.data_ptr(), B, x.shape[1], x.shape[2], x.shape[3], op["k"], op["stride"],
@@ -510,9 +660,9 @@ class TrainEngine:
     def _rebuild_consumers_of_balanced(self):
         # the graph lists `balance` before the heads, so bal_src was already populated when the tower
         # groups were built (ops are visited in order); nothing to do.  Kept as an assertion.
-        order = [o["op"] for o in self.g.ops]
+        order = [o["op"] for o in self.ops]
         bi = order.index("balance")
-        for o in self.g.ops[:bi]:
+        for o in self.ops[:bi]:
             if o["op"] == "conv":
                 assert o["inp"] not in self.bal_src
 
@@ -528,22 +678,23 @@ class TrainEngine:
         self.bwd_steps = []
         self.grad_init = {}       # tensor -> runtime flag "gradient buffer already written this step"
         self.dgrad_packs = []     # (master offset, conv dims, packed buffer)
-        ops = self.g.ops
+        ops = self.ops
+        self.dw_flip_packs = []   # (master offset, k, C, packed bf16 tap-reversed filter)
         first_of_group, seen = {}, set()
         for i, op in enumerate(ops):
-            if op["op"] == "conv" and op.get("group") and op["group"] not in seen:
-                seen.add(op["group"])
-                first_of_group[op["group"]] = i
+            if op["op"] in ("conv", "dwconv") and op.get("group") and (op["op"], op["group"]) not in seen:
+                seen.add((op["op"], op["group"]))
+                first_of_group[(op["op"], op["group"])] = i
         plan = []
         for i in range(len(ops) - 1, -1, -1):
             op = ops[i]
-            if op["op"] == "conv":
+            if op["op"] in ("conv", "dwconv"):
                 grp = op.get("group")
                 if grp is None:
-                    plan.append(("conv", [op]))
-                elif first_of_group[grp] == i:
-                    plan.append(("conv", [o for o in ops if o["op"] == "conv" and o.get("group") == grp]))
-            elif op["op"] in ("maxpool", "topdown", "balance", "stem"):
+                    plan.append((op["op"], [op]))
+                elif first_of_group[(op["op"], grp)] == i:
+                    plan.append((op["op"], [o for o in ops if o["op"] == op["op"] and o.get("group") == grp]))
+            elif op["op"] in ("maxpool", "topdown", "balance", "stem", "se"):
                 plan.append((op["op"], op))
         # which tensor gradients get more than one contribution is decided at build time
         written = set()
@@ -556,6 +707,21 @@ class TrainEngine:
         for kind, item in plan:
             if kind == "conv":
                 self._plan_conv_backward(item, mark)
+            elif kind == "dwconv":
+                self._plan_dw_backward(item, mark)
+            elif kind == "se":
+                op = item
+                x, dy, dx = self.t[op["inp"]], self.grad[op["out"]], self.grad[op["inp"]]
+                mark(op["inp"])
+                name, se = op["se"], self.g.ses[op["se"]]
+                a = (x.data_ptr(), dy.data_ptr(), dx.data_ptr(), B, x.shape[1] * x.shape[2], se["C"],
+                     self.Pbf.data_ptr() + 2 * self.bf_off[name + ":w1"],
+                     self.Pbf.data_ptr() + 2 * self.bf_off[name + ":w2"], se["se"], self.se_state[op["out"]].data_ptr(),
+                     self._pview(name + "/conv2d/kernel", self.G).data_ptr(),
+                     self._pview(name + "/conv2d/bias", self.G).data_ptr(),
+                     self._pview(name + "/conv2d_1/kernel", self.G).data_ptr(),
+                     self._pview(name + "/conv2d_1/bias", self.G).data_ptr(), self.se_ws.data_ptr(), self.se_ws.numel())
+                self.bwd_steps.append(lambda st, a=a: _C.check(lib.rn_squeeze_excite_bwd(*a, st), "rn_squeeze_excite_bwd"))
             elif kind == "maxpool":
                 op = item
                 if not self.requires.get(op["inp"]):
@@ -574,18 +740,19 @@ class TrainEngine:
                 c = self.g.convs[op["conv"]]
                 H, W = self.t["images"].shape[1], self.t["images"].shape[2]
                 pw = _C.WgradProblem()
-                pw.R, pw.S, pw.stride_h, pw.stride_w, pw.pad_top, pw.pad_left, pw.num_segments = 7, 1, 2, 2, 0, 0, 1
+                k = self.stem_k
+                pw.R, pw.S, pw.stride_h, pw.stride_w, pw.pad_top, pw.pad_left, pw.num_segments = k, 1, 2, 2, 0, 0, 1
                 sg = pw.seg[0]
                 sg.x, sg.dy = self.stem_in.data_ptr(), dys[0].data_ptr()
-                sg.N, sg.H, sg.W, sg.Cin, sg.Ho, sg.Wo, sg.Cout = B, H + 6, self.Wp, 32, dys[0].shape[1], dys[0].shape[2], c["cout"]
+                sg.N, sg.H, sg.W, sg.Cin, sg.Ho, sg.Wo, sg.Cout = B, self.Hp, self.Wp, 32, dys[0].shape[1], dys[0].shape[2], c["cout"]
                 sg.x_pix_stride = 4
                 wsw = torch.empty((max(lib.rn_wgrad_workspace_bytes(ctypes.byref(pw)), 256),), dtype=torch.uint8,
                                   device=self.dev)
-                dwp = torch.zeros((c["cout"], 7, 8, 4), dtype=torch.float32, device=self.dev)
-                gview = self._pview(op["conv"] + "/kernel", self.G).view(c["cout"], 7, 7, 3)
+                dwp = torch.zeros((c["cout"], k, 8, 4), dtype=torch.float32, device=self.dev)
+                gview = self._pview(self._kvar(op), self.G).view(c["cout"], k, k, 3)
                 self._keep += [pw, wsw, dwp]
 
-                def stem_bwd(st, prb=ctypes.byref(pb), ws=ws, bsums=bsums, pw=pw, wsw=wsw, dwp=dwp, gview=gview):
+                def stem_bwd(st, prb=ctypes.byref(pb), ws=ws, bsums=bsums, pw=pw, wsw=wsw, dwp=dwp, gview=gview, k=k):
                     _C.check(lib.rn_bn_bwd_reduce(prb, _C.ptr(ws), ws.numel(), st), "rn_bn_bwd_reduce")
                     if self.sync_bn:
                         import torch.distributed as dist
@@ -593,7 +760,7 @@ class TrainEngine:
                     _C.check(lib.rn_bn_bwd_apply(prb, st), "rn_bn_bwd_apply")
                     _C.check(lib.rn_conv2d_nhwc_wgrad(ctypes.byref(pw), dwp.data_ptr(), 0.0, wsw.data_ptr(),
                                                       wsw.numel(), st), "stem wgrad")
-                    gview.copy_(dwp[:, :, :7, :3])   # [co][r][8 taps x 4 ch] -> [co][r][s][c]
+                    gview.copy_(dwp[:, :, :k, :3])   # [co][r][8 taps x 4 ch] -> [co][r][s][c]
                 self.bwd_steps.append(stem_bwd)
             elif kind == "topdown":
                 op = item
@@ -687,7 +854,7 @@ class TrainEngine:
                 s.dy_pix_stride = dy.shape[3]
             ws = torch.empty((max(lib.rn_wgrad_workspace_bytes(ctypes.byref(p)), 256),), dtype=torch.uint8,
                              device=self.dev)
-            dw = self._pview(cname + "/kernel", self.G)
+            dw = self._pview(c.get("kvar", cname + "/kernel"), self.G)
             self._keep += [p, ws]
             a = (ctypes.byref(p), dw.data_ptr(), 0.0, ws.data_ptr(), ws.numel())
             self.bwd_steps.append(lambda st, a=a: _C.check(lib.rn_conv2d_nhwc_wgrad(*a, st), "rn_conv2d_nhwc_wgrad"))
@@ -726,6 +893,97 @@ class TrainEngine:
         for sub in launches:
             self._plan_dgrad_launch(sub, dy_of, mark, packs)
 
+    def _plan_dw_backward(self, ops, mark):
+        """depthwise conv (+BN+act) backward: BN backward -> dy; weight gradient (summed over the levels of a
+        shared separable conv); data gradient = the forward kernel on (zero-upsampled) dy with the
+        tap-reversed filter, accumulating into gradient buffers that already hold a contribution."""
+        lib, B = self.lib, self.B
+        live_bn = bool(self._bn_trainable(ops[0]))
+        if live_bn:
+            pb, sums, bsums, ws, dys, _ = self.bn_groups[ops[0]["out"]]
+            for i, op in enumerate(ops):
+                pb.seg[i].dz = self.grad[op["out"]].data_ptr()
+            prb = ctypes.byref(pb)
+
+            def run(st, prb=prb, ws=ws, bsums=bsums):
+                _C.check(lib.rn_bn_bwd_reduce(prb, _C.ptr(ws), ws.numel(), st), "rn_bn_bwd_reduce")
+                if self.sync_bn:
+                    import torch.distributed as dist
+                    dist.all_reduce(bsums, group=self.pg)
+                _C.check(lib.rn_bn_bwd_apply(prb, st), "rn_bn_bwd_apply")
+            self.bwd_steps.append(run)
+            dy_of = {op["out"]: dys[i] for i, op in enumerate(ops)}
+        else:
+            dy_of = {op["out"]: self.grad[op["out"]] for op in ops}
+        by_layer = {}
+        for op in ops:
+            by_layer.setdefault(op["dw"], []).append(op)
+        for dname, dops in by_layer.items():
+            d = self.g.dws[dname]
+            p = _C.DwProblem()
+            p.k, p.stride, p.pad_top, p.pad_left, p.act = d["k"], d["stride"], dops[0]["pad_top"], dops[0]["pad_left"], 0
+            p.num_segments = len(dops)
+            for i, op in enumerate(dops):
+                x, dy = self._src(op["inp"]), dy_of[op["out"]]
+                s = p.seg[i]
+                s.x, s.y = x.data_ptr(), dy.data_ptr()
+                s.N, s.H, s.W, s.C, s.Ho, s.Wo = B, x.shape[1], x.shape[2], d["C"], dy.shape[1], dy.shape[2]
+            ws = torch.empty((max(lib.rn_depthwise_wgrad_workspace_bytes(ctypes.byref(p)), 256),), dtype=torch.uint8,
+                             device=self.dev)
+            self._keep += [p, ws]
+            a = (ctypes.byref(p), self._pview(d["kvar"], self.G).data_ptr(), ws.data_ptr(), ws.numel())
+            self.bwd_steps.append(lambda st, a=a: _C.check(lib.rn_depthwise_conv2d_nhwc_wgrad(*a, st), "dw wgrad"))
+        need = [op for op in ops if self.requires.get(op["inp"])]
+        launches = []
+        for op in need:
+            for sub in launches:
+                if all(o["inp"] != op["inp"] for o in sub):
+                    sub.append(op)
+                    break
+            else:
+                launches.append([op])
+        flips = {}
+        for sub in launches:
+            d0 = self.g.dws[sub[0]["dw"]]
+            k, stride = d0["k"], d0["stride"]
+            p = _C.DwProblem()
+            p.k, p.stride, p.act, p.num_segments = k, 1, 0, len(sub)
+            p.pad_top, p.pad_left = k - 1 - sub[0]["pad_top"], k - 1 - sub[0]["pad_left"]
+            ups = []
+            for i, op in enumerate(sub):
+                d = self.g.dws[op["dw"]]
+                if op["dw"] not in flips:
+                    buf = torch.empty((k * k, d["C"]), dtype=torch.bfloat16, device=self.dev)
+                    flips[op["dw"]] = buf
+                    off, _ = self.p_off[d["kvar"]]
+                    self.dw_flip_packs.append((self.P.data_ptr() + 4 * off, k, d["C"], buf))
+                dy = dy_of[op["out"]]
+                x = self._src(op["inp"])
+                H, W = x.shape[1], x.shape[2]
+                if stride == 2:
+                    up = torch.empty((B, H, W, d["C"]), dtype=torch.bfloat16, device=self.dev)
+                    ups.append((dy.data_ptr(), up.data_ptr(), B, dy.shape[1], dy.shape[2], d["C"], H, W))
+                    self._keep.append(up)
+                    src = up
+                elif stride == 1:
+                    src = dy
+                else:
+                    raise NotImplementedError("stride > 2")
+                gbuf = self._gradbuf(op["inp"])
+                first = mark(op["inp"] if op["inp"] not in self.bal_src else "bal:" + op["inp"])
+                s = p.seg[i]
+                s.x, s.w, s.y = src.data_ptr(), flips[op["dw"]].data_ptr(), gbuf.data_ptr()
+                s.scale, s.shift = None, None
+                s.residual = None if first else gbuf.data_ptr()
+                s.N, s.H, s.W, s.C, s.Ho, s.Wo = B, H, W, d["C"], H, W
+            self._keep.append(p)
+
+            def dgrad(st, p=p, ups=ups):
+                for u in ups:
+                    _C.check(lib.rn_upsample_zero2x(*u, st), "rn_upsample_zero2x")
+                _C.check(lib.rn_depthwise_conv2d_nhwc_fwd(ctypes.byref(p), st), "dw dgrad")
+            self.bwd_steps.append(dgrad)
+
     def _plan_dgrad_launch(self, need, dy_of, mark, packs):
         lib, B = self.lib, self.B
         c0 = self.g.convs[need[0]["conv"]]
@@ -740,11 +998,12 @@ class TrainEngine:
             c = self.g.convs[op["conv"]]
             dy = dy_of[op["out"]]
             cw = dy.shape[3]
+            cwp = lib.rn_conv_cin_pad(cw)     # K of the dgrad GEMM, zero padded in the packed weights only
             if op["conv"] not in packs:
-                buf = torch.empty((lib.rn_conv_cout_pad(c["cin"]), k, k, cw), dtype=torch.bfloat16, device=self.dev)
+                buf = torch.empty((lib.rn_conv_cout_pad(c["cin"]), k, k, cwp), dtype=torch.bfloat16, device=self.dev)
                 packs[op["conv"]] = buf
-                off, _ = self.p_off[op["conv"] + "/kernel"]
-                self.dgrad_packs.append((self.P.data_ptr() + 4 * off, k, c["cin"], c["cout"], cw, buf))
+                off, _ = self.p_off[c.get("kvar", op["conv"] + "/kernel")]
+                self.dgrad_packs.append((self.P.data_ptr() + 4 * off, k, c["cin"], c["cout"], cwp, buf))
             x = self._src(op["inp"])
             H, W = x.shape[1], x.shape[2]
             if stride == 2:
@@ -777,6 +1036,8 @@ class TrainEngine:
         lib = self.lib
         for (mptr, k, cin, cout, cw, buf) in self.dgrad_packs:
             _C.check(lib.rn_pack_conv_weight_dgrad(mptr, k, k, cin, cout, cw, buf.data_ptr(), st), "pack dgrad")
+        for (mptr, k, C, buf) in self.dw_flip_packs:
+            _C.check(lib.rn_pack_depthwise_weight_flip(mptr, k, C, buf.data_ptr(), st), "pack dw flip")
 
     def forward(self, images):
         st = _C.current_stream()
