@@ -334,3 +334,45 @@ def test_efficientnet_backward_wiring(cuda, name, size, B):
     assert by["class-head/class-head-prediction-conv2d/pointwise_kernel"] > 0.995
     assert by["box-head/box-head-prediction-conv2d/depthwise_kernel"] > 0.99
     assert by[name + "/stem/conv2d/kernel"] > 0.85
+
+
+def test_efficientnet_train_steps_reduce_loss(cuda):
+    """Full training steps (encode -> forward -> loss -> backward -> clip -> SGD/EMA) on a fixed batch:
+    the loss must fall, every parameter tensor must move, and the compute copies must track the masters."""
+    from make_golden import synth_gt
+    from retinanet.cfg import efficientnet_params
+    from retinanet.dataloader import LabelEncoder
+    from retinanet.model import ModelBuilder
+    from retinanet.model.train_engine import TrainEngine
+    size, B = 256, 4
+    p = efficientnet_params("efficientnet-b0", input_size=size)
+    p.architecture.batch_norm.use_sync = False
+    builder = ModelBuilder(p, "train", device=cuda, seed=11)
+    model = builder()
+    eng = TrainEngine(model, B, frozen_regexes=[])
+    enc = LabelEncoder(p, device=cuda)
+    rng = np.random.default_rng(11)
+    gts = [synth_gt(rng, int(rng.integers(2, 9)), size) for _ in range(B)]
+    Gmax = max(x[0].shape[0] for x in gts)
+    gb, gc, cnt = np.zeros([B, Gmax, 4], np.float32), np.zeros([B, Gmax], np.float32), np.zeros([B], np.int32)
+    for i, (b, c) in enumerate(gts):
+        gb[i, :len(b)], gc[i, :len(c)], cnt[i] = b, c, len(b)
+    targets = enc.encode_batch(torch.from_numpy(gb), torch.from_numpy(gc), torch.from_numpy(cnt))
+    images = torch.randn((B, size, size, 3), generator=torch.Generator().manual_seed(11)).to(cuda)
+    w0 = eng.P.clone()
+    losses = []
+    model.optimizer.lr = lambda step: 0.01      # the schedule's warm-up start is too small to see in 12 steps
+    for _ in range(12):
+        out = eng.train_step(images, targets)
+        losses.append(float(out["weighted-loss"].item()))
+    torch.cuda.synchronize()
+    assert all(np.isfinite(losses)), losses
+    assert losses[-1] < 0.8 * losses[0], losses
+    moved = [(k, float((eng._pview(k) - w0[eng.p_off[k][0]:eng.p_off[k][0] + eng.p_off[k][1]]).abs().max()))
+             for k in eng.train_names]
+    # every kernel must move (BatchNorm parameters of the 1x1 / 2x2 pyramid levels see gradients below the
+    # fp32 resolution of gamma = 1 at this learning rate)
+    still = [k for k, d in moved if d == 0.0 and "kernel" in k.rsplit("/", 1)[-1]]
+    assert not still, still[:10]
+    for (off, n), bfo in eng._bf_copies:   # bf16 compute copies follow the f32 masters
+        torch.testing.assert_close(eng.Pbf[bfo:bfo + n].float(), eng.P[off:off + n].to(torch.bfloat16).float(), rtol=0, atol=0)
