@@ -253,7 +253,7 @@ int rn_act_bwd(const void* dz, const void* z, void* dy, int64_t n, int act, void
  *   rn_bn_stats        y -> sums[2][C] = (sum, sum of squares) of THIS rank's pixels
  *   (SyncBN: the caller all-reduces `sums` over ranks and sets count_scale = replicas)
  *   rn_bn_finalize     sums -> fwd[4][C] = (mean, invstd, scale, shift); moving stats update
- *   rn_bn_apply        z = act(y*scale + shift + residual)
+ *   rn_bn_apply        z = act((y*scale + shift) [* sample_scale[n]] + residual)
  *   rn_bn_bwd_reduce   dz, z, y -> bsums[2][C] = (sum g, sum g*xhat), g = dz*act'(z)
  *   (SyncBN: all-reduce `bsums`)
  *   rn_bn_bwd_apply    dy = scale*(g - sum_g/n - xhat*sum_gxhat/n); dres (+)= g; dgamma, dbeta
@@ -278,6 +278,11 @@ typedef struct {
   int64_t P;
   int32_t C;
   int32_t dres_accumulate;
+  /* drop_connect / stochastic depth (backbone/efficientnet.py:97-113): optional f32 [P / rows_per_sample]
+   * per-image factors (0 or 1/survival_prob) applied to the BatchNorm output BEFORE the residual add:
+   * z = act((y*scale + shift) * m[n] + residual); the backward scales the BN branch by m[n], dres is not. */
+  const float* sample_scale;
+  int64_t rows_per_sample;
 } rn_bn_segment;
 
 typedef struct {

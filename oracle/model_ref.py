@@ -163,6 +163,9 @@ class RefModel:
             x = _r(_r(torch.sigmoid(se), self.bf) * x, self.bf)
             x = self._bn(self._conv(x, cv(nc)), bn(nb))
             if s == 1 and ci == co:
+                m = getattr(self, "drop_connect_factors", {}).get(i)   # training: per-image 0 or 1/survival_prob
+                if m is not None:
+                    x = x * m.to(x.dtype)[:, None, None, None]
                 x = x + inp
             x = _r(x, self.bf)
             if i == len(blocks) - 1 or blocks[i + 1][1] > 1:

@@ -61,6 +61,7 @@ struct BnSegDev {
   const float* gamma; const float* beta; float* moving_mean; float* moving_var; float* dgamma; float* dbeta;
   long long P;
   int C, dres_accumulate, chunks, rows_per_chunk;
+  const float* sample_scale; long long rows_per_sample;
 };
 struct BnArgs {
   int nseg, act, bessel, mode;
@@ -112,8 +113,9 @@ __global__ void __launch_bounds__(TR_THREADS) bn_colreduce_kernel(const BnArgs a
         if (a.act != RN_ACT_NONE) z = unpack8(s.z[o]);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-          const float g = a.act != RN_ACT_NONE
-                              ? dz.v[q] * act_deriv(z.v[q], y.v[q] * scq[q] + shq[q], a.act) : dz.v[q];
+          float g = a.act != RN_ACT_NONE
+                        ? dz.v[q] * act_deriv(z.v[q], y.v[q] * scq[q] + shq[q], a.act) : dz.v[q];
+          if (s.sample_scale) g *= s.sample_scale[(int)r / (int)s.rows_per_sample];
           s0[q] += g;
           s1[q] += g * ((y.v[q] - mean[q]) * istd[q]);
         }
@@ -211,9 +213,10 @@ __global__ void __launch_bounds__(TR_THREADS) bn_apply_kernel(const BnArgs a) {
     bf8 o;
     bf8 res;
     if (s.residual) res = unpack8(s.residual[i]);
+    const float m = s.sample_scale ? s.sample_scale[(int)(i / C8) / (int)s.rows_per_sample] : 1.0f;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      float v = y.v[q] * sc[q] + sh[q];
+      float v = (y.v[q] * sc[q] + sh[q]) * m;
       if (s.residual) v += res.v[q];
       o.v[q] = rn_apply_act(v, a.act);
     }
@@ -255,12 +258,13 @@ __global__ void __launch_bounds__(TR_THREADS) bn_bwd_apply_kernel(const BnArgs a
     const bf8 dz = unpack8(s.dz[i]);
     bf8 z;
     if (a.act != RN_ACT_NONE) z = unpack8(s.z[i]);
+    const float m = s.sample_scale ? s.sample_scale[(int)(i / C8) / (int)s.rows_per_sample] : 1.0f;
     bf8 g, o;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       g.v[q] = a.act != RN_ACT_NONE ? dz.v[q] * act_deriv(z.v[q], y.v[q] * sc[q] + shq[q], a.act) : dz.v[q];
       const float xh = (y.v[q] - mean[q]) * istd[q];
-      o.v[q] = sc[q] * (g.v[q] - k1[q] - xh * k2[q]);
+      o.v[q] = sc[q] * (g.v[q] * m - k1[q] - xh * k2[q]);
     }
     s.dy[i] = pack8(o);
     if (s.dres) {
@@ -288,6 +292,8 @@ static int bn_fill(const rn_bn_problem* p, BnArgs& a, int need_ws) {
     d.sums = s.sums; d.fwd = s.fwd; d.bsums = s.bsums; d.gamma = s.gamma; d.beta = s.beta;
     d.moving_mean = s.moving_mean; d.moving_var = s.moving_var; d.dgamma = s.dgamma; d.dbeta = s.dbeta;
     d.P = s.P; d.C = s.C; d.dres_accumulate = s.dres_accumulate;
+    d.sample_scale = s.sample_scale; d.rows_per_sample = s.rows_per_sample > 0 ? s.rows_per_sample : 1;
+    if (s.sample_scale && p->act == RN_ACT_SWISH) return -1;   // swish' is recomputed without the factor
     long long rpc = rn_cdiv(rn_cdiv(s.P, 256), 32) * 32;  // <= 256 chunks, multiple of 32 rows
     if (rpc < 32) rpc = 32;
     d.rows_per_chunk = (int)rpc;

@@ -63,7 +63,7 @@ class BnSegment(Structure):
                 ("dres", c_void_p), ("sums", c_void_p), ("fwd", c_void_p), ("bsums", c_void_p),
                 ("gamma", c_void_p), ("beta", c_void_p), ("moving_mean", c_void_p), ("moving_var", c_void_p),
                 ("dgamma", c_void_p), ("dbeta", c_void_p), ("P", c_int64), ("C", c_int32),
-                ("dres_accumulate", c_int32)]
+                ("dres_accumulate", c_int32), ("sample_scale", c_void_p), ("rows_per_sample", c_int64)]
 
 
 class BnProblem(Structure):

@@ -5,8 +5,10 @@ Mirrors what retinanet/model/backbone/efficientnet.py builds for `features_only=
 `Stem` :566-586, block strings :82-90, `round_filters`/`round_repeats` :196-219) and returns the
 '2'..'5' feature map names (`EfficientNet.__init__` :1033-1036: reduction_2..reduction_5).
 
-Inference only for now: drop_connect (:97-113) is the identity when training=False, and the
-classification Head (:589-673) is never built into the detector.  Variable names follow the
+drop_connect (:97-113) is the identity when training=False; in training the project conv of every
+skip block carries its `survival` probability and the TrainEngine applies a per-image 0 / (1/p) factor to
+the BatchNorm output before the residual add.  The classification Head (:589-673) is never built into
+the detector.  Variable names follow the
 Keras scopes `<model>/stem/...`, `<model>/blocks_<i>/...` with the conv2d / tpu_batch_normalization
 counters of `MBConvBlock._build` (:335-421).
 """
@@ -24,6 +26,9 @@ _PARAMS = {  # efficientnet.py:48-62: (width_coefficient, depth_coefficient)
 _BLOCKS = [(1, 3, 1, 1, 32, 16, 0.25), (2, 3, 2, 6, 16, 24, 0.25), (2, 5, 2, 6, 24, 40, 0.25),
            (3, 3, 2, 6, 40, 80, 0.25), (3, 5, 1, 6, 80, 112, 0.25), (4, 5, 2, 6, 112, 192, 0.25),
            (1, 3, 1, 6, 192, 320, 0.25)]
+
+
+SURVIVAL_PROB = 0.8   # efficientnet.py:940 (`survival_prob=0.8` for every efficientnet-b* / lite model)
 
 
 def round_filters(filters, width, divisor=8):
@@ -105,6 +110,9 @@ def build_efficientnet_backbone(g, model_name, H, W, sync_bn_names=False):
         g.add_bn_layer(bn, b["cout"])
         skip = inp if (b["stride"] == 1 and b["cin"] == b["cout"]) else None
         x = g.conv(f"b{i}_out", x, cn, bn, act=None, residual=skip)
+        if skip is not None:
+            # drop_connect in training (:97-113, :824-827): survival_prob 0.8 scaled linearly with the block index
+            g.ops[-1]["survival"] = 1.0 - (1.0 - SURVIVAL_PROB) * float(i) / len(blocks)
         # efficientnet.py:814-817: a block is a reduction point when it is the last one or the next
         # block strides
         if i == len(blocks) - 1 or blocks[i + 1]["stride"] > 1:

@@ -65,6 +65,11 @@ class TrainEngine:
         self._keep = []
         self.step_count = 0
         self.conv_profile = None
+        self.drop_connect = True     # stochastic depth of the EfficientNet skip blocks (efficientnet.py:97-113)
+        self.dc_masks = {}           # project conv output -> (f32[B] factors, survival_prob)
+        self.dc_all = self.dc_p = None
+        self.dc_generator = torch.Generator(device=self.dev)
+        self.dc_generator.manual_seed(1337)
         self._prepare_graph()
         with torch.cuda.device(self.dev):
             self._analyse()
@@ -503,6 +508,16 @@ class TrainEngine:
             s.dgamma = self._pview(bn + "/gamma", self.G).data_ptr()
             s.dbeta = self._pview(bn + "/beta", self.G).data_ptr()
             s.P, s.C, s.dres_accumulate = y.shape[0] * y.shape[1] * y.shape[2], C, 0
+            if op.get("survival") is not None and self.drop_connect:
+                if self.dc_all is None:     # one [blocks, B] tensor so that a step draws every factor at once
+                    nsurv = sum(1 for o in self.ops if o.get("survival") is not None)
+                    self.dc_all = torch.ones((nsurv, self.B), dtype=torch.float32, device=self.dev)
+                    self.dc_p = torch.ones((nsurv, 1), dtype=torch.float32, device=self.dev)
+                j = len(self.dc_masks)
+                m = self.dc_all[j]
+                self.dc_p[j, 0] = float(op["survival"])
+                self.dc_masks[op["out"]] = (m, float(op["survival"]))
+                s.sample_scale, s.rows_per_sample = m.data_ptr(), y.shape[1] * y.shape[2]
             off += C
         ws = torch.empty((max(self.lib.rn_bn_workspace_bytes(ctypes.byref(p)), 256),), dtype=torch.uint8,
                          device=self.dev)
@@ -1039,8 +1054,15 @@ class TrainEngine:
         for (mptr, k, C, buf) in self.dw_flip_packs:
             _C.check(lib.rn_pack_depthwise_weight_flip(mptr, k, C, buf.data_ptr(), st), "pack dw flip")
 
-    def forward(self, images):
+    def draw_drop_connect(self):
+        """binary = floor(survival_prob + U[0,1)); factor = binary / survival_prob, per image (:107-112)."""
+        u = torch.rand(self.dc_all.shape, generator=self.dc_generator, device=self.dev, dtype=torch.float32)
+        torch.div(torch.floor(u.add_(self.dc_p)), self.dc_p, out=self.dc_all)
+
+    def forward(self, images, draw=True):
         st = _C.current_stream()
+        if draw and self.dc_masks:
+            self.draw_drop_connect()
         if images.data_ptr() != self.t["images"].data_ptr():
             self.t["images"].copy_(images, non_blocking=True)
         for fn in self.fwd_steps:

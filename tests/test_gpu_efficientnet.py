@@ -277,7 +277,7 @@ def _engine_grad(eng, k):
 def test_efficientnet_backward_wiring(cuda, name, size, B):
     """Whole-network backward (separable heads -> separable FPN -> MBConv backbone incl. the 3x3 stem) for a
     dense random upstream gradient, against autograd through the bf16-emulating CPU restatement: direction
-    and norm tensor by tensor (drop_connect disabled: survival_prob is treated as 1)."""
+    and norm tensor by tensor, with fixed drop_connect factors (some blocks dropped per image)."""
     from model_ref import RefTrainer
     from retinanet.cfg import efficientnet_params
     from retinanet.model import ModelBuilder
@@ -299,7 +299,13 @@ def test_efficientnet_backward_wiring(cuda, name, size, B):
     eng = TrainEngine(model, B, frozen_regexes=[])
     ref = RefTrainer(p, model.variables, frozen_names=eng.frozen, emulate_bf16=True)
     images = torch.randn((B, size, size, 3), generator=g)
-    preds = eng.forward(images.to(cuda))
+    # drop_connect: fix the per-image factors (one block dropped for image 0, one for image 1) and hand the
+    # same factors to the restatement
+    assert len(eng.dc_masks) == 9 and all(0.8 <= sp < 1.0 for _, sp in eng.dc_masks.values())
+    for j, (out, (m, sp)) in enumerate(sorted(eng.dc_masks.items(), key=lambda kv: int(kv[0][1:].split("_")[0]))):
+        m.copy_(torch.tensor([0.0 if (j % 4 == b) else 1.0 / sp for b in range(B)]))
+    ref.drop_connect_factors = {int(out[1:].split("_")[0]): m.cpu().double() for out, (m, sp) in eng.dc_masks.items()}
+    preds = eng.forward(images.to(cuda), draw=False)
     up = {k: {lv: torch.randn(preds[k][lv].shape, generator=g) for lv in preds[k]} for k in preds}
     eng.backward({k: {lv: t.to(cuda) for lv, t in d.items()} for k, d in up.items()})
     torch.cuda.synchronize()
@@ -329,7 +335,9 @@ def test_efficientnet_backward_wiring(cuda, name, size, B):
     # batch 2): ~0.1 relative noise per tensor in the backbone, ~0.03 in the FPN / heads
     assert sig[0][0] > 0.70, sig[:8]   # the squeeze-excite reduce kernels (small gradients) are the noisiest
     assert np.median(cos) > 0.88, np.median(cos)
-    assert np.median(np.abs(ratios - 1)) < 0.08 and np.abs(ratios - 1).max() < 0.4, (ratios.min(), ratios.max())
+    assert np.median(np.abs(ratios - 1)) < 0.08, np.median(np.abs(ratios - 1))
+    strong = [r for r in sig if r[2] >= med]     # tensors with at least the median gradient norm
+    assert max(abs(r[1] - 1) for r in strong) < 0.25, sorted(strong, key=lambda r: -abs(r[1] - 1))[:6]
     by = {r[3]: r[0] for r in rows}
     assert by["class-head/class-head-prediction-conv2d/pointwise_kernel"] > 0.995
     assert by["box-head/box-head-prediction-conv2d/depthwise_kernel"] > 0.99
@@ -367,7 +375,9 @@ def test_efficientnet_train_steps_reduce_loss(cuda):
         losses.append(float(out["weighted-loss"].item()))
     torch.cuda.synchronize()
     assert all(np.isfinite(losses)), losses
-    assert losses[-1] < 0.8 * losses[0], losses
+    # stochastic depth is active (random per-image block drops): the fall is noisier than without it
+    assert len(eng.dc_masks) == 9
+    assert np.mean(losses[-3:]) < 0.97 * np.mean(losses[:3]), losses
     moved = [(k, float((eng._pview(k) - w0[eng.p_off[k][0]:eng.p_off[k][0] + eng.p_off[k][1]]).abs().max()))
              for k in eng.train_names]
     # every kernel must move (BatchNorm parameters of the 1x1 / 2x2 pyramid levels see gradients below the
