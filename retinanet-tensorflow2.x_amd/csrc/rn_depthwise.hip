@@ -51,13 +51,13 @@ __global__ void __launch_bounds__(DW_THREADS) depthwise_kernel(const DwArgs a) {
     int si = 0;
     while (si + 1 < a.nseg && i >= a.seg[si + 1].begin) ++si;
     const DwSegDev& s = a.seg[si];
-    long long t = i - s.begin;
-    const int c = (int)(t % s.C8);
-    t /= s.C8;
-    const int ox = (int)(t % s.Wo);
-    t /= s.Wo;
-    const int oy = (int)(t % s.Ho);
-    const int n = (int)(t / s.Ho);
+    unsigned t = (unsigned)(i - s.begin);          // < 2^31 per segment (host check)
+    const int c = (int)(t % (unsigned)s.C8);
+    t /= (unsigned)s.C8;
+    const int ox = (int)(t % (unsigned)s.Wo);
+    t /= (unsigned)s.Wo;
+    const int oy = (int)(t % (unsigned)s.Ho);
+    const int n = (int)(t / (unsigned)s.Ho);
     float acc[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) acc[q] = 0.0f;
@@ -103,6 +103,8 @@ extern "C" int rn_depthwise_conv2d_nhwc_fwd(const rn_dw_problem* p, void* stream
     d.residual = (const uint4*)s.residual;
     d.N = s.N; d.H = s.H; d.W = s.W; d.C8 = s.C / 8; d.Ho = s.Ho; d.Wo = s.Wo;
     d.begin = off;
+    RN_CHECK_ARG((long long)s.N * s.Ho * s.Wo * (s.C / 8) < (1ll << 31) && (long long)s.N * s.H * s.W * (s.C / 8) < (1ll << 31),
+                 "rn_depthwise_conv2d_nhwc_fwd: segment %d too large", i);
     off += (long long)s.N * s.Ho * s.Wo * (s.C / 8);
   }
   a.total = off;
@@ -158,6 +160,22 @@ struct DwgArgs {
   DwgSegDev seg[RN_CONV_MAX_SEGMENTS];
 };
 
+// CPT consecutive bf16 channels with ONE 16-byte (CPT = 8) or 8-byte (CPT = 4) load
+template <int CPT>
+__device__ __forceinline__ void dwg_load(const uint16_t* p, float* v) {
+  if (CPT == 8) {
+    const uint4 u = *(const uint4*)p;
+    v[0] = rn_bf16_to_f32((uint16_t)(u.x & 0xffffu)); v[1] = rn_bf16_to_f32((uint16_t)(u.x >> 16));
+    v[2] = rn_bf16_to_f32((uint16_t)(u.y & 0xffffu)); v[3] = rn_bf16_to_f32((uint16_t)(u.y >> 16));
+    v[4] = rn_bf16_to_f32((uint16_t)(u.z & 0xffffu)); v[5] = rn_bf16_to_f32((uint16_t)(u.z >> 16));
+    v[6] = rn_bf16_to_f32((uint16_t)(u.w & 0xffffu)); v[7] = rn_bf16_to_f32((uint16_t)(u.w >> 16));
+  } else {
+    const uint2 u = *(const uint2*)p;
+    v[0] = rn_bf16_to_f32((uint16_t)(u.x & 0xffffu)); v[1] = rn_bf16_to_f32((uint16_t)(u.x >> 16));
+    v[2] = rn_bf16_to_f32((uint16_t)(u.y & 0xffffu)); v[3] = rn_bf16_to_f32((uint16_t)(u.y >> 16));
+  }
+}
+
 template <int K, int CPT>
 __global__ void __launch_bounds__(256) depthwise_wgrad_kernel(const DwgArgs a) {
   constexpr int SLAB = 8 * CPT;   // channels per workgroup
@@ -182,15 +200,7 @@ __global__ void __launch_bounds__(256) depthwise_wgrad_kernel(const DwgArgs a) {
       const int oy = t2 % s.Ho;
       const int n = t2 / s.Ho;
       float g[CPT];
-      {
-        const uint16_t* dp = s.dy + (long long)p * a.C + c0;
-#pragma unroll
-        for (int q = 0; q < CPT; q += 2) {
-          const uint32_t u = *(const uint32_t*)(dp + q);
-          g[q] = rn_bf16_to_f32((uint16_t)(u & 0xffffu));
-          g[q + 1] = rn_bf16_to_f32((uint16_t)(u >> 16));
-        }
-      }
+      dwg_load<CPT>(s.dy + (long long)p * a.C + c0, g);
 #pragma unroll
       for (int r = 0; r < K; ++r) {
         const int iy = oy * a.stride - a.pt + r;
@@ -199,13 +209,10 @@ __global__ void __launch_bounds__(256) depthwise_wgrad_kernel(const DwgArgs a) {
         for (int ss = 0; ss < K; ++ss) {
           const int ix = ox * a.stride - a.pl + ss;
           if ((unsigned)ix >= (unsigned)s.W) continue;
-          const uint16_t* xp = s.x + (((long long)n * s.H + iy) * s.W + ix) * a.C + c0;
+          float xv[CPT];
+          dwg_load<CPT>(s.x + (((long long)n * s.H + iy) * s.W + ix) * a.C + c0, xv);
 #pragma unroll
-          for (int q = 0; q < CPT; q += 2) {
-            const uint32_t u = *(const uint32_t*)(xp + q);
-            acc[r * K + ss][q] += g[q] * rn_bf16_to_f32((uint16_t)(u & 0xffffu));
-            acc[r * K + ss][q + 1] += g[q + 1] * rn_bf16_to_f32((uint16_t)(u >> 16));
-          }
+          for (int q = 0; q < CPT; ++q) acc[r * K + ss][q] += g[q] * xv[q];
         }
       }
     }
@@ -297,16 +304,20 @@ extern "C" int rn_depthwise_conv2d_nhwc_wgrad(const rn_dw_problem* p, float* dw,
 
 // ---- squeeze-and-excitation --------------------------------------------------------------------
 // pooled[n][c] = bf16(mean over H*W)  (tf.reduce_mean on a bf16 tensor yields bf16)
+// grid (channel slabs, N, HW chunks): partial[chunk][n][c] = sum over the chunk's pixels (deterministic);
+// se_pool_final_kernel adds the chunks in order, divides and rounds.
 __global__ void __launch_bounds__(256)
-se_pool_kernel(const uint4* __restrict__ x, int HW, int C8, float* __restrict__ pooled) {
+se_pool_kernel(const uint4* __restrict__ x, int HW, int C8, int rows_per_chunk, float* __restrict__ partial) {
   const int n = blockIdx.y, slab = blockIdx.x;  // 8 channel groups (64 channels) per block
   const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
   const int c8 = slab * 8 + cg;
+  const int p0 = blockIdx.z * rows_per_chunk;
+  const int p1 = p0 + rows_per_chunk < HW ? p0 + rows_per_chunk : HW;
   float acc[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) acc[q] = 0.0f;
   if (c8 < C8)
-    for (int p = rl; p < HW; p += 32) {
+    for (int p = p0 + rl; p < p1; p += 32) {
       const bf8 v = unpack8(x[((long long)n * HW + p) * C8 + c8]);
 #pragma unroll
       for (int q = 0; q < 8; ++q) acc[q] += v.v[q];
@@ -319,8 +330,30 @@ se_pool_kernel(const uint4* __restrict__ x, int HW, int C8, float* __restrict__ 
     float t = 0.0f;
     for (int r = 0; r < 32; ++r) t += red[r][threadIdx.x];
     const int ch = slab * 64 + threadIdx.x;
-    if (ch < C8 * 8) pooled[(long long)n * C8 * 8 + ch] = rn_bf16_to_f32(rn_f32_to_bf16(t / (float)HW));
+    if (ch < C8 * 8) partial[((long long)blockIdx.z * gridDim.y + n) * C8 * 8 + ch] = t;
   }
+}
+
+// out[i] = round_bf16?(scale * sum over chunks of partial[chunk][i])
+__global__ void __launch_bounds__(256)
+se_pool_final_kernel(const float* __restrict__ partial, long long n, int chunks, float scale, int round_bf16,
+                     float* __restrict__ out) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float t = 0.0f;
+    for (int c = 0; c < chunks; ++c) t += partial[(long long)c * n + i];
+    t *= scale;
+    out[i] = round_bf16 ? rn_bf16_to_f32(rn_f32_to_bf16(t)) : t;
+  }
+}
+
+static int se_chunks(int HW, int* rows_per_chunk) {
+  int chunks = (HW + 1023) / 1024;            // >= 1024 pixels per chunk
+  if (chunks > 32) chunks = 32;
+  if (chunks < 1) chunks = 1;
+  int rows = (HW + chunks - 1) / chunks;
+  rows = (rows + 31) / 32 * 32;
+  *rows_per_chunk = rows;
+  return (HW + rows - 1) / rows;
 }
 
 // gate[n][c] = bf16(sigmoid(W2 . bf16(swish(W1 . pooled + b1)) + b2)); one workgroup per image
@@ -376,7 +409,8 @@ se_gate_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, const float* 
 }
 
 // workspace / state layout: pooled[N][C], gate[N][C], h1[N][se], a[N][se] (se <= C), all f32
-extern "C" size_t rn_se_workspace_bytes(int N, int C) { return (size_t)N * C * 4 * sizeof(float); }
+// + 32 chunk partials [32][N][C] behind the four [N][C]-sized arrays
+extern "C" size_t rn_se_workspace_bytes(int N, int C) { return (size_t)N * C * (4 + 32) * sizeof(float); }
 
 static int se_forward(const void* x, void* y, int N, int HW, int C, const void* w_reduce, const float* b_reduce,
                       const void* w_expand, const float* b_expand, int se, float* state, hipStream_t st) {
@@ -384,8 +418,18 @@ static int se_forward(const void* x, void* y, int N, int HW, int C, const void* 
   float* gate = pooled + (size_t)N * C;
   float* h1 = gate + (size_t)N * C;
   float* av = h1 + (size_t)N * se;
-  hipLaunchKernelGGL(se_pool_kernel, dim3((C + 63) / 64, N), dim3(256), 0, st, (const uint4*)x, HW, C / 8, pooled);
-  RN_CHECK_LAUNCH();
+  {
+    int rows = 0;
+    const int chunks = se_chunks(HW, &rows);
+    float* partial = state + (size_t)N * C * 4;
+    hipLaunchKernelGGL(se_pool_kernel, dim3((C + 63) / 64, N, chunks), dim3(256), 0, st, (const uint4*)x, HW, C / 8,
+                       rows, partial);
+    RN_CHECK_LAUNCH();
+    const long long nel = (long long)N * C;
+    hipLaunchKernelGGL(se_pool_final_kernel, dim3((unsigned)rn_cdiv(nel, 256)), dim3(256), 0, st, partial, nel, chunks,
+                       1.0f / (float)HW, 1, pooled);
+    RN_CHECK_LAUNCH();
+  }
   hipLaunchKernelGGL(se_fc_kernel, dim3(N), dim3(256), (size_t)(C + se) * 4, st, pooled, (const uint16_t*)w_reduce,
                      b_reduce, (const uint16_t*)w_expand, b_expand, C, se, gate, h1, av);
   RN_CHECK_LAUNCH();
@@ -429,15 +473,18 @@ extern "C" int rn_squeeze_excite_fwd(const void* x, void* y, int N, int HW, int 
 // y = x * g[n][c], g = sigmoid(h2), h2 = W2 a + b2, a = swish(h1), h1 = W1 p + b1, p = mean_hw x
 // dgate[n][c] = sum_hw dy * x
 __global__ void __launch_bounds__(256)
-se_bwd_pool_kernel(const uint4* __restrict__ x, const uint4* __restrict__ dy, int HW, int C8, float* __restrict__ dgate) {
+se_bwd_pool_kernel(const uint4* __restrict__ x, const uint4* __restrict__ dy, int HW, int C8, int rows_per_chunk,
+                   float* __restrict__ partial) {
   const int n = blockIdx.y, slab = blockIdx.x;
   const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
   const int c8 = slab * 8 + cg;
+  const int p0 = blockIdx.z * rows_per_chunk;
+  const int p1 = p0 + rows_per_chunk < HW ? p0 + rows_per_chunk : HW;
   float acc[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) acc[q] = 0.0f;
   if (c8 < C8)
-    for (int p = rl; p < HW; p += 32) {
+    for (int p = p0 + rl; p < p1; p += 32) {
       const long long o = ((long long)n * HW + p) * C8 + c8;
       const bf8 v = unpack8(x[o]), g = unpack8(dy[o]);
 #pragma unroll
@@ -451,7 +498,7 @@ se_bwd_pool_kernel(const uint4* __restrict__ x, const uint4* __restrict__ dy, in
     float t = 0.0f;
     for (int r = 0; r < 32; ++r) t += red[r][threadIdx.x];
     const int ch = slab * 64 + threadIdx.x;
-    if (ch < C8 * 8) dgate[(long long)n * C8 * 8 + ch] = t;
+    if (ch < C8 * 8) partial[((long long)blockIdx.z * gridDim.y + n) * C8 * 8 + ch] = t;
   }
 }
 
@@ -562,9 +609,18 @@ extern "C" int rn_squeeze_excite_bwd(const void* x, const void* dy, void* dx, in
   float* dp = dh2 + (size_t)N * C;
   float* dh1 = dp + (size_t)N * C;
   const float* stf = (const float*)state;
-  hipLaunchKernelGGL(se_bwd_pool_kernel, dim3((C + 63) / 64, N), dim3(256), 0, st, (const uint4*)x, (const uint4*)dy,
-                     HW, C / 8, dgate);
-  RN_CHECK_LAUNCH();
+  {
+    int rows = 0;
+    const int chunks = se_chunks(HW, &rows);
+    float* partial = (float*)workspace + (size_t)N * C * 4;
+    hipLaunchKernelGGL(se_bwd_pool_kernel, dim3((C + 63) / 64, N, chunks), dim3(256), 0, st, (const uint4*)x,
+                       (const uint4*)dy, HW, C / 8, rows, partial);
+    RN_CHECK_LAUNCH();
+    const long long nel = (long long)N * C;
+    hipLaunchKernelGGL(se_pool_final_kernel, dim3((unsigned)rn_cdiv(nel, 256)), dim3(256), 0, st, partial, nel, chunks,
+                       1.0f, 0, dgate);
+    RN_CHECK_LAUNCH();
+  }
   hipLaunchKernelGGL(se_bwd_fc_kernel, dim3(N), dim3(256), (size_t)(C + se) * 4, st, stf, dgate,
                      (const uint16_t*)w_reduce, (const uint16_t*)w_expand, N, C, se, dh2, dh1, dp);
   RN_CHECK_LAUNCH();
