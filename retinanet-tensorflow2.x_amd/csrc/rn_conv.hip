@@ -376,6 +376,9 @@ static int launch_ablate(const ConvArgs& a, hipStream_t st) {
 
 // 256 x 256 x 32 tiles (rn_conv_big.hip) for the MFMA-bound layers: every segment at least 256 output
 // channels wide, and enough tiles to fill the 256 CUs (one workgroup per CU) a few times over.
+static long long g_conv_big_min_tiles = 192;
+extern "C" void rn_debug_conv_big_min_tiles(int n) { g_conv_big_min_tiles = n; }   // tools/: A/B timing
+
 static bool conv_use_big(const rn_conv_problem* p) {
   if (g_conv_force_small) return false;
   long long tiles256 = 0;
@@ -384,7 +387,7 @@ static bool conv_use_big(const rn_conv_problem* p) {
     if (rn_conv_cout_pad(s.Cout) < 256 || s.Cout % 8 != 0) return false;
     tiles256 += rn_cdiv((long long)s.N * s.Ho * s.Wo, 256) * rn_cdiv(s.Cout, 256);
   }
-  return g_conv_force_big || tiles256 >= 192;
+  return g_conv_force_big || tiles256 >= g_conv_big_min_tiles;
 }
 
 extern "C" int rn_conv_tile_rows(const rn_conv_problem* p) {

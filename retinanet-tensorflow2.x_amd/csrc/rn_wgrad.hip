@@ -206,6 +206,11 @@ wgrad_reduce_kernel(const float4* __restrict__ ws, long long n4, int chunks, flo
   }
 }
 
+// workgroups a launch aims for (2 per CU x 256 CUs x a few rounds); fewer = fewer split-K partials to
+// write and reduce, more = better balance.  Tunable from tools/ for A/B timing.
+static int g_wgrad_target_blocks = 1024;
+extern "C" void rn_debug_wgrad_target_blocks(int n) { if (n > 0) g_wgrad_target_blocks = n; }
+
 static int wgrad_plan(const rn_wgrad_problem* p, WgArgs& a) {
   if (!p || p->num_segments < 1 || p->num_segments > RN_CONV_MAX_SEGMENTS) return -1;
   if (p->R < 1 || p->S < 1 || p->stride_h < 1 || p->stride_w < 1) return -1;
@@ -229,7 +234,7 @@ static int wgrad_plan(const rn_wgrad_problem* p, WgArgs& a) {
     Ptot += P;
   }
   const int tiles = a.co_tiles * a.ci_tiles * a.R * a.S;
-  long long target = rn_cdiv(2048, tiles);
+  long long target = rn_cdiv(g_wgrad_target_blocks, tiles);
   if (target < 1) target = 1;
   if (target > 256) target = 256;
   long long CH = rn_cdiv(rn_cdiv(Ptot, target), WG_BK) * WG_BK;

@@ -27,12 +27,20 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--big-min-tiles", type=int, default=0, help="override the 256x256 kernel's minimum tile count")
+    ap.add_argument("--wgrad-blocks", type=int, default=0, help="override the wgrad split-K target workgroup count")
     a = ap.parse_args()
     from retinanet.cfg import default_params
     from retinanet.dataloader import LabelEncoder
     from retinanet.model import ModelBuilder
     from retinanet.model.train_engine import TrainEngine
     dev = torch.device("cuda:0")
+    if a.big_min_tiles:
+        from retinanet import _C
+        _C.lib().rn_debug_conv_big_min_tiles(a.big_min_tiles)
+    if a.wgrad_blocks:
+        from retinanet import _C
+        _C.lib().rn_debug_wgrad_target_blocks(a.wgrad_blocks)
     p = default_params(input_size=a.size)
     b = ModelBuilder(p, "train", device=dev)
     model = b()
