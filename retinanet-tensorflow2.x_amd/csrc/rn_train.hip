@@ -139,17 +139,18 @@ __global__ void __launch_bounds__(TR_THREADS) bn_colreduce_kernel(const BnArgs a
 }
 
 // stage 2 of the column reductions: out[which][c] = sum over chunks.  32 channels x 8 chunk lanes
-// per workgroup: lane j adds chunks j, j+8, ... in order (double), the 8 lane sums are then added
-// in lane order — a fixed association, so the result is deterministic.
-__global__ void __launch_bounds__(256) bn_colreduce_final_kernel(const BnArgs a) {
+// per workgroup (32 channels x 32 lanes): lane j adds chunks j, j+32, ... in order (double), the 32 lane
+// sums are then added in lane order — a fixed association, so the result is deterministic.  (With 8 lanes
+// the 32-deep dependent load chain made each of the ~115 launches per step take ~12 us.)
+__global__ void __launch_bounds__(1024) bn_colreduce_final_kernel(const BnArgs a) {
   const BnSegDev& s = a.seg[blockIdx.y];
-  __shared__ double red[2][8][33];
+  __shared__ double red[2][32][33];
   const int cl = threadIdx.x & 31, lane = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   double t0 = 0.0, t1 = 0.0;
   if (c < s.C) {
     const float* p = a.ws + a.ws_off[blockIdx.y];
-    for (int k = lane; k < s.chunks; k += 8) {
+    for (int k = lane; k < s.chunks; k += 32) {
       t0 += (double)p[((long long)k * 2 + 0) * s.C + c];
       t1 += (double)p[((long long)k * 2 + 1) * s.C + c];
     }
@@ -162,7 +163,7 @@ __global__ void __launch_bounds__(256) bn_colreduce_final_kernel(const BnArgs a)
     const int cc = blockIdx.x * 32 + cl;
     if (cc < s.C) {
       double t = 0.0;
-      for (int j = 0; j < 8; ++j) t += red[which][j][cl];
+      for (int j = 0; j < 32; ++j) t += red[which][j][cl];
       float* out = a.mode == 0 ? s.sums : s.bsums;
       out[which * s.C + cc] = (float)t;
     }
@@ -333,7 +334,7 @@ static int bn_colreduce(const rn_bn_problem* p, int mode, void* ws, size_t ws_by
   }
   hipLaunchKernelGGL(bn_colreduce_kernel, dim3(max_chunks, max_slabs, a.nseg), dim3(TR_THREADS), 0, st, a);
   RN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bn_colreduce_final_kernel, dim3((max_c + 31) / 32, a.nseg), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(bn_colreduce_final_kernel, dim3((max_c + 31) / 32, a.nseg), dim3(1024), 0, st, a);
   RN_CHECK_LAUNCH();
   return RN_OK;
 }

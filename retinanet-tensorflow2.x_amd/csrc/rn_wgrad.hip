@@ -39,6 +39,7 @@ struct WgSegDev {
 
 struct WgArgs {
   int R, S, sh, sw, pt, pl, nseg, total_chunks, CH, co_tiles, ci_tiles, Cin, Cout, pad_;
+  int co_groups, gco;   // the co tiles are walked in `co_groups` groups of `gco`
   float* ws;
   WgSegDev seg[RN_CONV_MAX_SEGMENTS];
 };
@@ -70,21 +71,26 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wgrad_kernel(const WgArgs args)
   // each XCD a contiguous range of logical ids with the tile index fastest — every (co, ci, tap)
   // tile of one pixel chunk then runs on the same XCD and re-reads that chunk's x / dy rows from its
   // L2 instead of HBM (first version: 2.7 TB/s of fetch traffic, each chunk pulled by all 8 XCDs).
-  const int tiles_per_tap = args.co_tiles * args.ci_tiles;
+  // A pixel chunk's tiles only share L2 lines while they walk the chunk in lockstep, i.e. while they are
+  // all resident at once: an XCD holds 64 workgroups, so launches with more tiles per chunk (class prediction
+  // conv: 6 x 2 x 9 = 108) go through the chunk in `co_groups` passes of <= 64 tiles (464 -> ~900 TFLOP/s).
+  const int tiles_per_tap = args.gco * args.ci_tiles;
   const int tiles_all = tiles_per_tap * args.R * args.S;
   int logical;
   {
-    const int total = tiles_all * args.total_chunks;
+    const int total = tiles_all * args.total_chunks * args.co_groups;
     const int bid = blockIdx.x;
     const int xcd = bid & 7, slot = bid >> 3;
     const int q = total >> 3, rr = total & 7;
     logical = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + slot;
   }
-  const int chunk = logical / tiles_all;
-  const int tile_id = logical - chunk * tiles_all;
+  const int vchunk = logical / tiles_all;
+  const int chunk = vchunk / args.co_groups, cgp = vchunk - chunk * args.co_groups;
+  const int tile_id = logical - vchunk * tiles_all;
   const int tap = tile_id / tiles_per_tap;
   const int tt = tile_id - tap * tiles_per_tap;
-  const int co_t = tt / args.ci_tiles, ci_t = tt - co_t * args.ci_tiles;
+  const int co_t = cgp * args.gco + tt / args.ci_tiles, ci_t = tt % args.ci_tiles;
+  if (co_t >= args.co_tiles) return;   // padding of the last group (whole workgroup, before any barrier)
   const int co0 = co_t * 128, ci0 = ci_t * 128;
   const int r = tap / args.S, s = tap - r * args.S;
   int si = 0;
@@ -234,6 +240,10 @@ static int wgrad_plan(const rn_wgrad_problem* p, WgArgs& a) {
     Ptot += P;
   }
   const int tiles = a.co_tiles * a.ci_tiles * a.R * a.S;
+  a.co_groups = (int)rn_cdiv(tiles, 64);
+  if (a.co_groups > a.co_tiles) a.co_groups = a.co_tiles;
+  a.gco = (int)rn_cdiv(a.co_tiles, a.co_groups);
+  a.co_groups = (int)rn_cdiv(a.co_tiles, a.gco);
   long long target = rn_cdiv(g_wgrad_target_blocks, tiles);
   if (target < 1) target = 1;
   if (target > 256) target = 256;
@@ -278,7 +288,7 @@ extern "C" int rn_conv2d_nhwc_wgrad(const rn_wgrad_problem* p, float* dw, float 
   hipStream_t st = (hipStream_t)stream;
   const int lds = 4 * WG_TILE_BYTES;
   RN_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  dim3 grid((unsigned)(a.co_tiles * a.ci_tiles * a.R * a.S * a.total_chunks));
+  dim3 grid((unsigned)(a.gco * a.ci_tiles * a.R * a.S * a.co_groups * a.total_chunks));
   hipLaunchKernelGGL(wgrad_kernel, grid, dim3(WG_THREADS), lds, st, a);
   RN_CHECK_LAUNCH();
   const long long n = (long long)a.Cout * a.R * a.S * a.Cin;

@@ -27,8 +27,9 @@ def _ws(nbytes, dev):
     ([(1, 16, 128, 256)], 3, 2),
     ([(2, 8, 256, 36)], 3, 1),                                   # box prediction conv (Cout tail)
     ([(2, s, 256, 256) for s in (8, 4, 2, 1)], 3, 1),            # shared head conv over a pyramid
-    ([(1, 10, 192, 720)], 3, 1),                                 # Cin tail tile, 6 co tiles
-], ids=["3x3", "1x1", "3x3s2", "pred36", "pyramid", "cin192_720"])
+    ([(1, 10, 192, 720)], 3, 1),                                 # Cin tail tile, 6 co tiles (2 lockstep groups)
+    ([(1, 6, 256, 640)], 3, 1),                                  # 5 co tiles in groups of 3 + 2 (padding tile)
+], ids=["3x3", "1x1", "3x3s2", "pred36", "pyramid", "cin192_720", "co640"])
 def test_wgrad(cuda, shape):
     from retinanet import _C
     lib = _C.lib()
