@@ -152,18 +152,22 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wgrad_kernel(const WgArgs args)
       const int chunk__ = d_pos ^ ((row__ & 3) << 2);                                             \
       const int p__ = (p0_) + row__;                                                              \
       const bool in__ = p__ < p_end;                                                              \
-      const unsigned va__ = in__ ? (unsigned)(((long long)p__ * sg.dyS + co0 + chunk__ * 8) * 2) : WG_OOB; \
+      const unsigned va__ = in__ ? (__umul24((unsigned)p__, (unsigned)sg.dyS) + co0 + chunk__ * 8) * 2u : WG_OOB; \
       wg_dma16(rs_dy, st__ + (j * 4 + wave) * 1024, va__);                                        \
       const int iy__ = r_oy[j] * args.sh - args.pt + r, ix__ = r_ox[j] * args.sw - args.pl + s;   \
       const bool ok__ = in__ && (unsigned)iy__ < (unsigned)H && (unsigned)ix__ < (unsigned)W;     \
-      const unsigned vb__ =                                                                       \
-          ok__ ? (unsigned)(((((long long)r_n[j] * H + iy__) * W + ix__) * sg.xS + ci0 + chunk__ * 8) * 2) : WG_OOB; \
+      /* 24-bit multiplies (full rate): every factor is < 2^24 (host check), the byte offset < 2^31 */ \
+      const unsigned pix__ = __umul24(__umul24((unsigned)r_n[j], (unsigned)H) + (unsigned)iy__, (unsigned)W) + (unsigned)ix__; \
+      const unsigned vb__ = ok__ ? (__umul24(pix__, (unsigned)sg.xS) + ci0 + chunk__ * 8) * 2u : WG_OOB; \
       wg_dma16(rs_x, st__ + WG_TILE_BYTES + (j * 4 + wave) * 1024, vb__);                         \
       /* advance this row by one K step */                                                        \
       int ox__ = r_ox[j] + adv_r, oy__ = r_oy[j] + adv_qr, n__ = r_n[j] + adv_qn;                 \
-      if (ox__ >= Wo) { ox__ -= Wo; ++oy__; }                                                     \
-      if (oy__ >= Ho) { oy__ -= Ho; ++n__; }                                                      \
-      if (oy__ >= Ho) { oy__ -= Ho; ++n__; }                                                      \
+      const int c1__ = ox__ >= Wo;                                                                \
+      ox__ -= c1__ ? Wo : 0; oy__ += c1__;                                                        \
+      const int c2__ = oy__ >= Ho;                                                                \
+      oy__ -= c2__ ? Ho : 0; n__ += c2__;                                                         \
+      const int c3__ = oy__ >= Ho;                                                                \
+      oy__ -= c3__ ? Ho : 0; n__ += c3__;                                                         \
       r_ox[j] = ox__; r_oy[j] = oy__; r_n[j] = n__;                                               \
     }                                                                                             \
   } while (0)
@@ -254,6 +258,7 @@ static int wgrad_plan(const rn_wgrad_problem* p, WgArgs& a) {
     const long long xS = s.x_pix_stride > 0 ? s.x_pix_stride : s.Cin;
     if (xS % 4) return -1;
     if ((long long)s.N * s.H * s.W * xS * 2 >= (1ll << 31) || P * dyS * 2 >= (1ll << 31)) return -1;
+    if ((long long)s.N * s.H * s.W >= (1ll << 24) || xS >= (1 << 24) || dyS >= (1 << 24)) return -1;   // 24-bit multiplies
     Ptot += P;
   }
   const int tiles = a.co_tiles * a.ci_tiles * a.R * a.S;

@@ -10,7 +10,8 @@ import os
 from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librnet_hip.so")
+# RNET_HIP_LIB: alternative build of the same ABI (A/B timing of kernel variants on one GPU box)
+LIB_PATH = os.environ.get("RNET_HIP_LIB") or os.path.join(_HERE, "librnet_hip.so")
 
 RN_DT_F32, RN_DT_BF16 = 0, 1
 RN_ACT_NONE, RN_ACT_RELU, RN_ACT_RELU6, RN_ACT_SWISH = 0, 1, 2, 3
