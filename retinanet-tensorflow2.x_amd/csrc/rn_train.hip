@@ -38,6 +38,17 @@ __device__ __forceinline__ float act_mask(float z, int act) {
   if (act == RN_ACT_RELU6) return (z > 0.0f && z < 6.0f) ? 1.0f : 0.0f;
   return 1.0f;
 }
+// relu / relu6 pass-through mask from the pre-activation u = y*scale + shift (layers without a residual
+// input): tf.nn.relu / relu6 gradients gate on the op's bf16 INPUT, i.e. on round_bf16(u) — so the stored
+// output z does not have to be read back (saves one tensor read in each of the two backward passes).
+__device__ __forceinline__ float act_mask_u(float u, int act) {
+  if (act == RN_ACT_RELU) return u > 0.0f ? 1.0f : 0.0f;      // rounding to bf16 never changes the sign
+  if (act == RN_ACT_RELU6) {
+    const float ub = (float)(__bf16)u;                         // v_cvt_pk_bf16_f32 (RNE)
+    return (ub > 0.0f && ub < 6.0f) ? 1.0f : 0.0f;
+  }
+  return 1.0f;
+}
 // d act(u) / du: relu / relu6 from the stored output z, swish from the recomputed pre-activation u
 // (swish'(u) = s + u*s*(1-s), s = sigmoid(u); tf.nn.swish's registered gradient)
 __device__ __forceinline__ float act_deriv(float z, float u, int act) {
@@ -109,12 +120,14 @@ __global__ void __launch_bounds__(TR_THREADS) bn_colreduce_kernel(const BnArgs a
         }
       } else {
         const bf8 dz = unpack8(s.dz[o]);
+        const bool from_u = !s.residual && (a.act == RN_ACT_RELU || a.act == RN_ACT_RELU6);
         bf8 z;
-        if (a.act != RN_ACT_NONE) z = unpack8(s.z[o]);
+        if (a.act != RN_ACT_NONE && !from_u) z = unpack8(s.z[o]);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-          float g = a.act != RN_ACT_NONE
-                        ? dz.v[q] * act_deriv(z.v[q], y.v[q] * scq[q] + shq[q], a.act) : dz.v[q];
+          const float u = y.v[q] * scq[q] + shq[q];
+          float g = a.act == RN_ACT_NONE ? dz.v[q]
+                    : dz.v[q] * (from_u ? act_mask_u(u, a.act) : act_deriv(z.v[q], u, a.act));
           if (s.sample_scale) g *= s.sample_scale[(int)r / (int)s.rows_per_sample];
           s0[q] += g;
           s1[q] += g * ((y.v[q] - mean[q]) * istd[q]);
@@ -257,13 +270,16 @@ __global__ void __launch_bounds__(TR_THREADS) bn_bwd_apply_kernel(const BnArgs a
   for (long long i = gtid; i < total; i += lanes) {
     const bf8 y = unpack8(s.y[i]);
     const bf8 dz = unpack8(s.dz[i]);
+    const bool from_u = !s.residual && (a.act == RN_ACT_RELU || a.act == RN_ACT_RELU6);
     bf8 z;
-    if (a.act != RN_ACT_NONE) z = unpack8(s.z[i]);
+    if (a.act != RN_ACT_NONE && !from_u) z = unpack8(s.z[i]);
     const float m = s.sample_scale ? s.sample_scale[(int)(i / C8) / (int)s.rows_per_sample] : 1.0f;
     bf8 g, o;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      g.v[q] = a.act != RN_ACT_NONE ? dz.v[q] * act_deriv(z.v[q], y.v[q] * sc[q] + shq[q], a.act) : dz.v[q];
+      const float u = y.v[q] * sc[q] + shq[q];
+      g.v[q] = a.act == RN_ACT_NONE ? dz.v[q]
+               : dz.v[q] * (from_u ? act_mask_u(u, a.act) : act_deriv(z.v[q], u, a.act));
       const float xh = (y.v[q] - mean[q]) * istd[q];
       o.v[q] = sc[q] * (g.v[q] * m - k1[q] - xh * k2[q]);
     }

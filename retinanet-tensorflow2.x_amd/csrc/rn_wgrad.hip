@@ -18,31 +18,7 @@
 //     partial tile to the workspace, a second kernel adds the chunks in index order
 //     (deterministic; no float atomics).
 // MFMA-bound for large layers; the partial-tile traffic is chunks * |W| * 4 B.
-#include "rn_common.h"
-
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
-typedef float f32x16_t __attribute__((ext_vector_type(16)));
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(3))) bf16x4_t lds_b4_t;
-
-#define WG_THREADS 256
-#define WG_BK 64
-#define WG_TILE_BYTES (WG_BK * 256)
-#define WG_OOB 0x80000000u
-
-struct WgSegDev {
-  const uint16_t* x;
-  const uint16_t* dy;
-  int N, H, W, Ho, Wo, P, chunk_begin, dyS, xS, pad_;
-};
-
-struct WgArgs {
-  int R, S, sh, sw, pt, pl, nseg, total_chunks, CH, co_tiles, ci_tiles, Cin, Cout, pad_;
-  int co_groups, gco;   // the co tiles are walked in `co_groups` groups of `gco`
-  float* ws;
-  WgSegDev seg[RN_CONV_MAX_SEGMENTS];
-};
+#include "rn_wgrad_dev.h"
 
 __device__ __forceinline__ void wg_dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, unsigned voff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)lds_wave_base, 16, (int)voff, 0, 0, 0);
@@ -236,6 +212,8 @@ wgrad_reduce_kernel(const float4* __restrict__ ws, long long n4, int chunks, flo
 // workgroups a launch aims for (2 per CU x 256 CUs x a few rounds); fewer = fewer split-K partials to
 // write and reduce, more = better balance.  Tunable from tools/ for A/B timing.
 static int g_wgrad_target_blocks = 1024;
+static int g_wgrad_force_small = 0;
+extern "C" void rn_debug_wgrad_force_small(int on) { g_wgrad_force_small = on; }
 extern "C" void rn_debug_wgrad_target_blocks(int n) { if (n > 0) g_wgrad_target_blocks = n; }
 
 static int wgrad_plan(const rn_wgrad_problem* p, WgArgs& a) {
@@ -287,6 +265,8 @@ static int wgrad_plan(const rn_wgrad_problem* p, WgArgs& a) {
   }
   a.total_chunks = chunks;
   a.pad_ = 0;
+  // large layers: 256 x 256 per-tap tiles on the ping-pong kernel (rn_wgrad_big.hip); pad_ = 1 marks the choice
+  if (!g_wgrad_force_small && rn_wgrad_big_plan(p, a)) a.pad_ = 1;
   return 0;
 }
 
@@ -308,6 +288,17 @@ extern "C" int rn_conv2d_nhwc_wgrad(const rn_wgrad_problem* p, float* dw, float 
   }
   a.ws = (float*)workspace;
   hipStream_t st = (hipStream_t)stream;
+  if (a.pad_ == 1) {
+    const int rc = rn_launch_wgrad_big(a, st);
+    if (rc != RN_OK) return rc;
+    const long long nb = (long long)a.Cout * a.R * a.S * a.Cin;
+    const long long nb4 = nb / 4;
+    int blocksb = (int)(rn_cdiv(nb4, 256) < 2048 ? rn_cdiv(nb4, 256) : 2048);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocksb), dim3(256), 0, st, (const float4*)workspace, nb4,
+                       a.total_chunks, (float4*)dw, beta);
+    RN_CHECK_LAUNCH();
+    return RN_OK;
+  }
   const int lds = 4 * WG_TILE_BYTES;
   RN_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   dim3 grid((unsigned)(a.gco * a.ci_tiles * a.R * a.S * a.co_groups * a.total_chunks));

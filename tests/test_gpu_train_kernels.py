@@ -29,11 +29,19 @@ def _ws(nbytes, dev):
     ([(2, s, 256, 256) for s in (8, 4, 2, 1)], 3, 1),            # shared head conv over a pyramid
     ([(1, 10, 192, 720)], 3, 1),                                 # Cin tail tile, 6 co tiles (2 lockstep groups)
     ([(1, 6, 256, 640)], 3, 1),                                  # 5 co tiles in groups of 3 + 2 (padding tile)
-], ids=["3x3", "1x1", "3x3s2", "pred36", "pyramid", "cin192_720", "co640"])
-def test_wgrad(cuda, shape):
+    ([(2, s, 256, 256) for s in (80, 40, 20, 10, 5)], 3, 1),     # 256x256-tile kernel: shared head conv, 5 levels
+    ([(2, 64, 256, 720)], 3, 1),                                 # 256x256-tile kernel: 3 co tiles, Cout tail
+    ([(3, 48, 512, 256)], 1, 1),                                 # 256x256-tile kernel: 1x1, 2 ci tiles
+    ([(2, 96, 256, 512)], 3, 2),                                 # 256x256-tile kernel: stride 2
+], ids=["3x3", "1x1", "3x3s2", "pred36", "pyramid", "cin192_720", "co640", "big_pyramid", "big_720", "big_1x1",
+        "big_s2"])
+def test_wgrad(cuda, shape, request):
     from retinanet import _C
     lib = _C.lib()
     segs, k, stride = shape
+    big = request.node.callspec.id.startswith("big_")
+    lib.rn_debug_wgrad_big_min_pixels(1 if big else 16384)   # the big_* cases must run the 256x256-tile kernel
+    request.addfinalizer(lambda: lib.rn_debug_wgrad_big_min_pixels(16384))
     g = torch.Generator().manual_seed(len(segs) * 100 + k + stride)
     pad = (k - 1) // 2
     cin, cout = segs[0][2], segs[0][3]
