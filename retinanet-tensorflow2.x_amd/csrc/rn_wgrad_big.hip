@@ -266,12 +266,21 @@ bool rn_wgrad_big_plan(const rn_wgrad_problem* p, WgArgs& a) {
   a.ci_tiles = ci_tiles;
   a.co_groups = 1;
   a.gco = co_tiles;
-  long long target = rn_cdiv(448, tiles);       // ~1.75 workgroups per CU-slot (one workgroup per CU)
+  // one workgroup per CU (128 KB of LDS): aim for at most two full rounds of the 256 CUs.  Segments
+  // (pyramid levels) are chunked separately, so the rounding is settled by growing the chunk.
+  long long target = 512 / tiles;
   if (target < 1) target = 1;
   long long CH = rn_cdiv(rn_cdiv(Ptot, target), BK) * BK;
   if (CH < 4 * BK) CH = 4 * BK;
-  a.CH = (int)CH;
   int chunks = 0;
+  for (int it = 0; it < 16; ++it) {
+    chunks = 0;
+    for (int i = 0; i < p->num_segments; ++i) chunks += (int)rn_cdiv(a.seg[i].P, CH);
+    if ((long long)chunks * tiles <= 512 || chunks <= 1) break;
+    CH += BK * rn_cdiv(CH / BK, 16);    // +6 % per iteration
+  }
+  a.CH = (int)CH;
+  chunks = 0;
   for (int i = 0; i < p->num_segments; ++i) {
     WgSegDev& d = a.seg[i];
     d.chunk_begin = chunks;
