@@ -251,6 +251,8 @@ __global__ void __launch_bounds__(512) wgrad_big_kernel(const WgArgs args) {
 
 }  // namespace
 
+static long long g_big_target_blocks = 256;   // one round of the 256 CUs: fewest split-K partials
+extern "C" void rn_debug_wgrad_big_target_blocks(int n) { g_big_target_blocks = n; }
 static long long g_big_min_pixels = 16384;
 extern "C" void rn_debug_wgrad_big_min_pixels(int n) { g_big_min_pixels = n; }   // tests: force the big kernel
 
@@ -266,9 +268,9 @@ bool rn_wgrad_big_plan(const rn_wgrad_problem* p, WgArgs& a) {
   a.ci_tiles = ci_tiles;
   a.co_groups = 1;
   a.gco = co_tiles;
-  // one workgroup per CU (128 KB of LDS): aim for at most two full rounds of the 256 CUs.  Segments
+  // one workgroup per CU (128 KB of LDS): aim for one full round of the 256 CUs.  Segments
   // (pyramid levels) are chunked separately, so the rounding is settled by growing the chunk.
-  long long target = 512 / tiles;
+  long long target = g_big_target_blocks / tiles;
   if (target < 1) target = 1;
   long long CH = rn_cdiv(rn_cdiv(Ptot, target), BK) * BK;
   if (CH < 4 * BK) CH = 4 * BK;
@@ -276,7 +278,7 @@ bool rn_wgrad_big_plan(const rn_wgrad_problem* p, WgArgs& a) {
   for (int it = 0; it < 16; ++it) {
     chunks = 0;
     for (int i = 0; i < p->num_segments; ++i) chunks += (int)rn_cdiv(a.seg[i].P, CH);
-    if ((long long)chunks * tiles <= 512 || chunks <= 1) break;
+    if ((long long)chunks * tiles <= g_big_target_blocks || chunks <= 1) break;
     CH += BK * rn_cdiv(CH / BK, 16);    // +6 % per iteration
   }
   a.CH = (int)CH;

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--big-min-tiles", type=int, default=0, help="override the 256x256 kernel's minimum tile count")
+    ap.add_argument("--wgrad-big-blocks", type=int, default=0)
     ap.add_argument("--wgrad-blocks", type=int, default=0, help="override the wgrad split-K target workgroup count")
     a = ap.parse_args()
     from retinanet.cfg import default_params
@@ -38,6 +39,9 @@ def main():
     if a.big_min_tiles:
         from retinanet import _C
         _C.lib().rn_debug_conv_big_min_tiles(a.big_min_tiles)
+    if a.wgrad_big_blocks:
+        from retinanet import _C
+        _C.lib().rn_debug_wgrad_big_target_blocks(a.wgrad_big_blocks)
     if a.wgrad_blocks:
         from retinanet import _C
         _C.lib().rn_debug_wgrad_target_blocks(a.wgrad_blocks)
