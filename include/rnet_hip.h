@@ -411,6 +411,18 @@ int rn_squeeze_excite_bwd(const void* x, const void* dy, void* dx, int N, int HW
 int rn_prepare_image(const float* image, int h, int w, int scaled_h, int scaled_w, float* out, int target_h,
                      int target_w, const float* mean, const float* stddev, float pixel_scale, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * §8(f)-2  COCOEvaluator.accumulate_results  (retinanet/eval/coco_evaluator.py:95-134)
+ * boxes f32[B,D,4] (x1,y1,x2,y2 as produced by the serving signature), classes i32[B,D], valid i32[B],
+ * resize_scale f32[B,2] (the `resize_scale` of preprocessing_pipeline.py:96-121) ->
+ * out_bbox i32[B,D,4] = (x, y, w, h) after `boxes /= tile(resize_scale / input_shape, 2)` and int32 truncation,
+ * out_category i32[B,D] = class_lut[class] (sorted-name -> original COCO id, :39-52, 89-93) or the class itself
+ * when class_lut is NULL; slots >= valid[b] get bbox 0 and category -1.
+ */
+int rn_coco_accumulate(const float* boxes, const int32_t* classes, const int32_t* valid, const float* resize_scale,
+                       float input_h, float input_w, const int32_t* class_lut, int num_classes, int B, int D,
+                       int rescale, int32_t* out_bbox, int32_t* out_category, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

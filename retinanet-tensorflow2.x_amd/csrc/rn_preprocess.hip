@@ -66,3 +66,45 @@ extern "C" int rn_prepare_image(const float* image, int h, int w, int scaled_h, 
   RN_CHECK_LAUNCH();
   return RN_OK;
 }
+
+
+// ---- (f)-2  COCOEvaluator.accumulate_results (retinanet/eval/coco_evaluator.py:95-134) ----------------
+// boxes /= tile(resize_scale / input_shape, 2); int32 truncation; (x1,y1,x2,y2) -> (x,y,w,h) on the truncated
+// values; class id through the sorted-name lookup table.  One thread per detection slot.
+__global__ void __launch_bounds__(256)
+coco_accumulate_kernel(const float4* __restrict__ boxes, const int* __restrict__ classes, const int* __restrict__ valid,
+                       const float2* __restrict__ resize_scale, float in_h, float in_w, const int* __restrict__ lut,
+                       int num_classes, int B, int D, int rescale, int4* __restrict__ out_bbox,
+                       int* __restrict__ out_cat) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * D) return;
+  const int b = i / D, d = i - b * D;
+  if (d >= valid[b]) {
+    out_bbox[i] = make_int4(0, 0, 0, 0);
+    out_cat[i] = -1;
+    return;
+  }
+  float4 v = boxes[i];
+  if (rescale) {
+    const float2 rs = resize_scale[b];
+    const float s0 = rs.x / in_h, s1 = rs.y / in_w;   // resize_scales[i] / self._input_shape  (:118)
+    v.x = v.x / s0; v.y = v.y / s1; v.z = v.z / s0; v.w = v.w / s1;   // tiled x2 (:119-122)
+  }
+  const int x1 = (int)v.x, y1 = (int)v.y, x2 = (int)v.z, y2 = (int)v.w;   // np.int32(): truncation (:124)
+  out_bbox[i] = make_int4(x1, y1, x2 - x1, y2 - y1);                          // :125
+  const int c = classes[i];
+  out_cat[i] = (lut && c >= 0 && c < num_classes) ? lut[c] : c;
+}
+
+extern "C" int rn_coco_accumulate(const float* boxes, const int32_t* classes, const int32_t* valid,
+                                  const float* resize_scale, float input_h, float input_w, const int32_t* class_lut,
+                                  int num_classes, int B, int D, int rescale, int32_t* out_bbox, int32_t* out_category,
+                                  void* stream) {
+  RN_CHECK_ARG(boxes && classes && valid && out_bbox && out_category && B > 0 && D > 0 && (!rescale || resize_scale) &&
+                   input_h > 0 && input_w > 0, "rn_coco_accumulate: bad argument");
+  hipLaunchKernelGGL(coco_accumulate_kernel, dim3((B * D + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     (const float4*)boxes, classes, valid, (const float2*)resize_scale, input_h, input_w, class_lut,
+                     num_classes, B, D, rescale, (int4*)out_bbox, out_category);
+  RN_CHECK_LAUNCH();
+  return RN_OK;
+}

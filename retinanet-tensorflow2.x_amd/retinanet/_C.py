@@ -115,6 +115,8 @@ _SIGNATURES = {
                                       c_int, c_void_p, c_size_t, c_void_p]),
     "rn_squeeze_excite_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rn_coco_accumulate": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_int, c_int, c_int,
+                                   c_int, c_void_p, c_void_p, c_void_p]),
     "rn_pack_conv_weight_ohwi": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rn_se_workspace_bytes": (c_size_t, [c_int, c_int]),
     "rn_squeeze_excite_inplace": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
