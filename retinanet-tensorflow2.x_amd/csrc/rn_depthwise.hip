@@ -45,52 +45,88 @@ struct DwArgs {
   DwSegDev seg[RN_CONV_MAX_SEGMENTS];
 };
 
-__global__ void __launch_bounds__(DW_THREADS) depthwise_kernel(const DwArgs a) {
+// Strip kernel: one thread = T = 4 consecutive output pixels of one row x 8 channels.  Per filter row the
+// (T-1)*stride + K input vectors are loaded once (all in flight together) and reused by every tap that
+// touches them: K*((T-1)*S+K) 16-byte loads per strip instead of T*K*K, fully unrolled.  (The first version
+// looped over the taps with data-dependent `continue`s: one L1/L2 round trip after the other, ~10x off HBM.)
+template <int K, int S>
+__global__ void __launch_bounds__(DW_THREADS) depthwise_strip_kernel(const DwArgs a) {
+  constexpr int T = 4;
+  constexpr int WIN = (T - 1) * S + K;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < a.total;
        i += (long long)gridDim.x * blockDim.x) {
     int si = 0;
     while (si + 1 < a.nseg && i >= a.seg[si + 1].begin) ++si;
     const DwSegDev& s = a.seg[si];
+    const unsigned strips = (unsigned)(s.Wo + T - 1) / T;
     unsigned t = (unsigned)(i - s.begin);          // < 2^31 per segment (host check)
     const int c = (int)(t % (unsigned)s.C8);
     t /= (unsigned)s.C8;
-    const int ox = (int)(t % (unsigned)s.Wo);
-    t /= (unsigned)s.Wo;
+    const int ox0 = (int)(t % strips) * T;
+    t /= strips;
     const int oy = (int)(t % (unsigned)s.Ho);
     const int n = (int)(t / (unsigned)s.Ho);
-    float acc[8];
+    float acc[T][8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) acc[q] = 0.0f;
-    for (int r = 0; r < a.k; ++r) {
-      const int iy = oy * a.stride - a.pt + r;
-      if ((unsigned)iy >= (unsigned)s.H) continue;
-      for (int ss = 0; ss < a.k; ++ss) {
-        const int ix = ox * a.stride - a.pl + ss;
-        if ((unsigned)ix >= (unsigned)s.W) continue;
-        const bf8 xv = unpack8(s.x[(((long long)n * s.H + iy) * s.W + ix) * s.C8 + c]);
-        const bf8 wv = unpack8(s.w[(long long)(r * a.k + ss) * s.C8 + c]);
+    for (int tt = 0; tt < T; ++tt)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) acc[q] += xv.v[q] * wv.v[q];
+      for (int q = 0; q < 8; ++q) acc[tt][q] = 0.0f;
+    const int ix0 = ox0 * S - a.pl;
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+      const int iy = oy * S - a.pt + r;
+      const bool rowok = (unsigned)iy < (unsigned)s.H;
+      const uint4* xrow = s.x + ((long long)n * s.H + (rowok ? iy : 0)) * s.W * s.C8 + c;
+      uint4 win[WIN];
+#pragma unroll
+      for (int j = 0; j < WIN; ++j) {
+        const int ix = ix0 + j;
+        win[j] = (rowok && (unsigned)ix < (unsigned)s.W) ? xrow[(long long)ix * s.C8] : make_uint4(0u, 0u, 0u, 0u);
+      }
+      uint4 wr[K];
+#pragma unroll
+      for (int ss = 0; ss < K; ++ss) wr[ss] = s.w[(long long)(r * K + ss) * s.C8 + c];
+#pragma unroll
+      for (int j = 0; j < WIN; ++j) {
+        const bf8 xv = unpack8(win[j]);
+#pragma unroll
+        for (int tt = 0; tt < T; ++tt) {
+          const int ss = j - tt * S;          // compile-time after unrolling
+          if (ss >= 0 && ss < K) {
+            const bf8 wv = unpack8(wr[ss]);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[tt][q] += xv.v[q] * wv.v[q];
+          }
+        }
       }
     }
-    const long long oi = (((long long)n * s.Ho + oy) * s.Wo + ox) * s.C8 + c;
-    bf8 o, res;
-    if (s.residual) res = unpack8(s.residual[oi]);
+    float sc[8], sh[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      float v = acc[q];
-      if (s.scale) v *= s.scale[c * 8 + q];
-      if (s.shift) v += s.shift[c * 8 + q];
-      if (s.residual) v += res.v[q];
-      o.v[q] = act_exact(v, a.act);
+      sc[q] = s.scale ? s.scale[c * 8 + q] : 1.0f;
+      sh[q] = s.shift ? s.shift[c * 8 + q] : 0.0f;
     }
-    s.y[oi] = pack8(o);
+#pragma unroll
+    for (int tt = 0; tt < T; ++tt) {
+      if (ox0 + tt >= s.Wo) break;
+      const long long oi = (((long long)n * s.Ho + oy) * s.Wo + ox0 + tt) * s.C8 + c;
+      bf8 o, res;
+      if (s.residual) res = unpack8(s.residual[oi]);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        float v = acc[tt][q] * sc[q] + sh[q];
+        if (s.residual) v += res.v[q];
+        o.v[q] = act_exact(v, a.act);
+      }
+      s.y[oi] = pack8(o);
+    }
   }
 }
 
 extern "C" int rn_depthwise_conv2d_nhwc_fwd(const rn_dw_problem* p, void* stream) {
-  RN_CHECK_ARG(p && p->num_segments >= 1 && p->num_segments <= RN_CONV_MAX_SEGMENTS && p->k >= 1 && p->stride >= 1,
-               "rn_depthwise_conv2d_nhwc_fwd: bad problem");
+  RN_CHECK_ARG(p && p->num_segments >= 1 && p->num_segments <= RN_CONV_MAX_SEGMENTS &&
+                   (p->k == 1 || p->k == 3 || p->k == 5) && (p->stride == 1 || p->stride == 2),
+               "rn_depthwise_conv2d_nhwc_fwd: bad problem (k in {1,3,5}, stride in {1,2})");
   DwArgs a;
   a.k = p->k; a.stride = p->stride; a.pt = p->pad_top; a.pl = p->pad_left; a.act = p->act; a.nseg = p->num_segments;
   long long off = 0;
@@ -105,12 +141,22 @@ extern "C" int rn_depthwise_conv2d_nhwc_fwd(const rn_dw_problem* p, void* stream
     d.begin = off;
     RN_CHECK_ARG((long long)s.N * s.Ho * s.Wo * (s.C / 8) < (1ll << 31) && (long long)s.N * s.H * s.W * (s.C / 8) < (1ll << 31),
                  "rn_depthwise_conv2d_nhwc_fwd: segment %d too large", i);
-    off += (long long)s.N * s.Ho * s.Wo * (s.C / 8);
+    off += (long long)s.N * s.Ho * ((s.Wo + 3) / 4) * (s.C / 8);   // work items: 4-pixel strips x 8-channel groups
   }
   a.total = off;
   long long blocks = rn_cdiv(off, DW_THREADS);
-  if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(depthwise_kernel, dim3((unsigned)blocks), dim3(DW_THREADS), 0, (hipStream_t)stream, a);
+  if (blocks > 32768) blocks = 32768;
+  const dim3 grid((unsigned)blocks), block(DW_THREADS);
+  hipStream_t st = (hipStream_t)stream;
+  const int key = p->k * 10 + p->stride;
+  switch (key) {
+    case 11: hipLaunchKernelGGL((depthwise_strip_kernel<1, 1>), grid, block, 0, st, a); break;
+    case 12: hipLaunchKernelGGL((depthwise_strip_kernel<1, 2>), grid, block, 0, st, a); break;
+    case 31: hipLaunchKernelGGL((depthwise_strip_kernel<3, 1>), grid, block, 0, st, a); break;
+    case 32: hipLaunchKernelGGL((depthwise_strip_kernel<3, 2>), grid, block, 0, st, a); break;
+    case 51: hipLaunchKernelGGL((depthwise_strip_kernel<5, 1>), grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL((depthwise_strip_kernel<5, 2>), grid, block, 0, st, a); break;
+  }
   RN_CHECK_LAUNCH();
   return RN_OK;
 }
@@ -176,9 +222,14 @@ __device__ __forceinline__ void dwg_load(const uint16_t* p, float* v) {
   }
 }
 
-template <int K, int CPT>
+// Work item = one strip of T = 4 consecutive output pixels of an image row; a chunk = rows_per_chunk items.
+// Per filter row the strip's (T-1)*S + K input vectors are loaded once and feed every (pixel, tap) pair that
+// touches them (the first version re-read x for each of the K*K taps: L2-bandwidth bound).
+template <int K, int CPT, int S>
 __global__ void __launch_bounds__(256) depthwise_wgrad_kernel(const DwgArgs a) {
   constexpr int SLAB = 8 * CPT;   // channels per workgroup
+  constexpr int T = 4;
+  constexpr int WIN = (T - 1) * S + K;
   const int chunk = blockIdx.x, slab = blockIdx.y;
   int si = 0;
   while (si + 1 < a.nseg && chunk >= a.seg[si + 1].chunk_begin) ++si;
@@ -191,28 +242,50 @@ __global__ void __launch_bounds__(256) depthwise_wgrad_kernel(const DwgArgs a) {
   for (int t = 0; t < K * K; ++t)
 #pragma unroll
     for (int q = 0; q < CPT; ++q) acc[t][q] = 0.0f;
-  const int p0 = (chunk - s.chunk_begin) * a.rows_per_chunk;
-  const int p1 = p0 + a.rows_per_chunk < s.P ? p0 + a.rows_per_chunk : s.P;
+  const int strips = (s.Wo + T - 1) / T;
+  const int items = s.N * s.Ho * strips;           // s.P holds the item count of the segment
+  const int i0 = (chunk - s.chunk_begin) * a.rows_per_chunk;
+  const int i1 = i0 + a.rows_per_chunk < items ? i0 + a.rows_per_chunk : items;
   if (live) {
-    for (int p = p0 + rl; p < p1; p += 32) {
-      const int ox = p % s.Wo;
-      const int t2 = p / s.Wo;
+    for (int it = i0 + rl; it < i1; it += 32) {
+      const int ox0 = (it % strips) * T;
+      const int t2 = it / strips;
       const int oy = t2 % s.Ho;
       const int n = t2 / s.Ho;
-      float g[CPT];
-      dwg_load<CPT>(s.dy + (long long)p * a.C + c0, g);
+      float g[T][CPT];
+#pragma unroll
+      for (int tt = 0; tt < T; ++tt) {
+        if (ox0 + tt < s.Wo) {
+          dwg_load<CPT>(s.dy + (((long long)n * s.Ho + oy) * s.Wo + ox0 + tt) * a.C + c0, g[tt]);
+        } else {
+#pragma unroll
+          for (int q = 0; q < CPT; ++q) g[tt][q] = 0.0f;
+        }
+      }
+      const int ix0 = ox0 * S - a.pl;
 #pragma unroll
       for (int r = 0; r < K; ++r) {
-        const int iy = oy * a.stride - a.pt + r;
+        const int iy = oy * S - a.pt + r;
         if ((unsigned)iy >= (unsigned)s.H) continue;
+        const uint16_t* xrow = s.x + (((long long)n * s.H + iy) * s.W) * a.C + c0;
 #pragma unroll
-        for (int ss = 0; ss < K; ++ss) {
-          const int ix = ox * a.stride - a.pl + ss;
-          if ((unsigned)ix >= (unsigned)s.W) continue;
+        for (int j = 0; j < WIN; ++j) {
+          const int ix = ix0 + j;
           float xv[CPT];
-          dwg_load<CPT>(s.x + (((long long)n * s.H + iy) * s.W + ix) * a.C + c0, xv);
+          if ((unsigned)ix < (unsigned)s.W) {
+            dwg_load<CPT>(xrow + (long long)ix * a.C, xv);
+          } else {
 #pragma unroll
-          for (int q = 0; q < CPT; ++q) acc[r * K + ss][q] += g[q] * xv[q];
+            for (int q = 0; q < CPT; ++q) xv[q] = 0.0f;
+          }
+#pragma unroll
+          for (int tt = 0; tt < T; ++tt) {
+            const int ss = j - tt * S;     // compile-time after unrolling
+            if (ss >= 0 && ss < K) {
+#pragma unroll
+              for (int q = 0; q < CPT; ++q) acc[r * K + ss][q] += g[tt][q] * xv[q];
+            }
+          }
         }
       }
     }
@@ -247,11 +320,12 @@ static int dwg_plan(const rn_dw_problem* p, DwgArgs& a) {
   if (p->k != 1 && p->k != 3 && p->k != 5) return -1;
   a.stride = p->stride; a.pt = p->pad_top; a.pl = p->pad_left; a.nseg = p->num_segments; a.C = p->seg[0].C;
   if (a.C % 8) return -1;
-  long long Ptot = 0;
+  if (p->stride != 1 && p->stride != 2) return -1;
+  long long Ptot = 0;                            // work items: 4-pixel strips of output rows
   for (int i = 0; i < p->num_segments; ++i) {
     const rn_dw_segment& s = p->seg[i];
     if (!s.x || !s.y || s.C != a.C) return -1;
-    Ptot += (long long)s.N * s.Ho * s.Wo;
+    Ptot += (long long)s.N * s.Ho * ((s.Wo + 3) / 4);
   }
   long long rows = rn_cdiv(Ptot, 512);          // ~512 chunks over the launch
   rows = rn_cdiv(rows, 32) * 32;
@@ -262,7 +336,7 @@ static int dwg_plan(const rn_dw_problem* p, DwgArgs& a) {
     const rn_dw_segment& s = p->seg[i];
     DwgSegDev& d = a.seg[i];
     d.x = (const uint16_t*)s.x; d.dy = (const uint16_t*)s.y;
-    d.N = s.N; d.H = s.H; d.W = s.W; d.Ho = s.Ho; d.Wo = s.Wo; d.P = s.N * s.Ho * s.Wo;
+    d.N = s.N; d.H = s.H; d.W = s.W; d.Ho = s.Ho; d.Wo = s.Wo; d.P = s.N * s.Ho * ((s.Wo + 3) / 4);
     d.chunk_begin = chunks;
     chunks += (int)rn_cdiv(d.P, rows);
   }
@@ -288,12 +362,15 @@ extern "C" int rn_depthwise_conv2d_nhwc_wgrad(const rn_dw_problem* p, float* dw,
   }
   a.partial = (float*)workspace;
   hipStream_t st = (hipStream_t)stream;
-  if (p->k == 1)
-    hipLaunchKernelGGL((depthwise_wgrad_kernel<1, 8>), dim3(a.total_chunks, (unsigned)rn_cdiv(a.C, 64)), dim3(256), 0, st, a);
-  else if (p->k == 3)
-    hipLaunchKernelGGL((depthwise_wgrad_kernel<3, 8>), dim3(a.total_chunks, (unsigned)rn_cdiv(a.C, 64)), dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL((depthwise_wgrad_kernel<5, 4>), dim3(a.total_chunks, (unsigned)rn_cdiv(a.C, 32)), dim3(256), 0, st, a);
+  const dim3 g8(a.total_chunks, (unsigned)rn_cdiv(a.C, 64)), g4(a.total_chunks, (unsigned)rn_cdiv(a.C, 32)), blk(256);
+  switch (p->k * 10 + p->stride) {
+    case 11: hipLaunchKernelGGL((depthwise_wgrad_kernel<1, 8, 1>), g8, blk, 0, st, a); break;
+    case 12: hipLaunchKernelGGL((depthwise_wgrad_kernel<1, 8, 2>), g8, blk, 0, st, a); break;
+    case 31: hipLaunchKernelGGL((depthwise_wgrad_kernel<3, 8, 1>), g8, blk, 0, st, a); break;
+    case 32: hipLaunchKernelGGL((depthwise_wgrad_kernel<3, 8, 2>), g8, blk, 0, st, a); break;
+    case 51: hipLaunchKernelGGL((depthwise_wgrad_kernel<5, 4, 1>), g4, blk, 0, st, a); break;
+    default: hipLaunchKernelGGL((depthwise_wgrad_kernel<5, 4, 2>), g4, blk, 0, st, a); break;
+  }
   RN_CHECK_LAUNCH();
   const long long n = (long long)p->k * p->k * a.C;
   hipLaunchKernelGGL(dwg_reduce_kernel, dim3((unsigned)rn_cdiv(n, 256)), dim3(256), 0, st, (const float*)workspace, n,
