@@ -433,41 +433,44 @@ static int se_chunks(int HW, int* rows_per_chunk) {
   return (HW + rows - 1) / rows;
 }
 
-// gate[n][c] = bf16(sigmoid(W2 . bf16(swish(W1 . pooled + b1)) + b2)); one workgroup per image
+// gate[n][c] = bf16(sigmoid(W2 . bf16(swish(W1 . pooled + b1)) + b2)) in two launches that fill the chip
+// (the first version ran one workgroup per image: 32 workgroups, up to 0.4 ms per call):
+//   se_fc1: one wavefront per (image, reduced channel j): h1 = bf16(W1[j] . pooled[n] + b1[j]), a = bf16(swish(h1))
+//   se_fc2: one thread per (image, channel c): gate = bf16(sigmoid(bf16(W2[c] . a[n] + b2[c])))
 __global__ void __launch_bounds__(256)
-se_fc_kernel(const float* __restrict__ pooled, const uint16_t* __restrict__ w1 /*[se][C]*/,
-             const float* __restrict__ b1, const uint16_t* __restrict__ w2 /*[C][se]*/,
-             const float* __restrict__ b2, int C, int se, float* __restrict__ gate,
-             float* __restrict__ save_h1 /*[N][se] or null*/, float* __restrict__ save_a /*[N][se] or null*/) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* sp = (float*)smem;  // [C]
-  float* sh = sp + C;        // [se]
-  const int n = blockIdx.x;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) sp[c] = pooled[(long long)n * C + c];
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int j = wave; j < se; j += blockDim.x / 64) {
-    float acc = 0.0f;
-    for (int c = lane; c < C; c += 64) acc += sp[c] * rn_bf16_to_f32(w1[(long long)j * C + c]);
-    acc = rn_wave_sum(acc);
-    if (lane == 0) {
-      float v = acc + b1[j];
-      v = rn_bf16_to_f32(rn_f32_to_bf16(v));
-      if (save_h1) save_h1[(long long)n * se + j] = v;
-      v = v / (1.0f + __expf(-v));
-      sh[j] = rn_bf16_to_f32(rn_f32_to_bf16(v));
-      if (save_a) save_a[(long long)n * se + j] = sh[j];
-    }
+se_fc1_kernel(const float* __restrict__ pooled, const uint16_t* __restrict__ w1 /*[se][C]*/,
+              const float* __restrict__ b1, int N, int C, int se, float* __restrict__ h1 /*[N][se]*/,
+              float* __restrict__ av /*[N][se]*/) {
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);   // (n, j)
+  if (item >= N * se) return;
+  const int n = item / se, j = item - n * se;
+  const float* p = pooled + (long long)n * C;
+  const uint16_t* w = w1 + (long long)j * C;
+  float acc = 0.0f;
+  for (int c = lane; c < C; c += 64) acc += p[c] * rn_bf16_to_f32(w[c]);
+  acc = rn_wave_sum(acc);
+  if (lane == 0) {
+    float v = rn_bf16_to_f32(rn_f32_to_bf16(acc + b1[j]));
+    h1[item] = v;
+    v = v / (1.0f + __expf(-v));
+    av[item] = rn_bf16_to_f32(rn_f32_to_bf16(v));
   }
-  __syncthreads();
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float acc = 0.0f;
-    for (int j = 0; j < se; ++j) acc += sh[j] * rn_bf16_to_f32(w2[(long long)c * se + j]);
-    float v = acc + b2[c];
-    v = rn_bf16_to_f32(rn_f32_to_bf16(v));
-    v = 1.0f / (1.0f + __expf(-v));
-    gate[(long long)n * C + c] = rn_bf16_to_f32(rn_f32_to_bf16(v));
-  }
+}
+
+__global__ void __launch_bounds__(256)
+se_fc2_kernel(const float* __restrict__ av /*[N][se]*/, const uint16_t* __restrict__ w2 /*[C][se]*/,
+              const float* __restrict__ b2, int N, int C, int se, float* __restrict__ gate /*[N][C]*/) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * C) return;
+  const int n = i / C, c = i - n * C;
+  const float* a = av + (long long)n * se;
+  const uint16_t* w = w2 + (long long)c * se;
+  float acc = 0.0f;
+  for (int j = 0; j < se; ++j) acc += a[j] * rn_bf16_to_f32(w[j]);
+  float v = rn_bf16_to_f32(rn_f32_to_bf16(acc + b2[c]));
+  v = 1.0f / (1.0f + __expf(-v));
+  gate[i] = rn_bf16_to_f32(rn_f32_to_bf16(v));
 }
 
 __global__ void __launch_bounds__(DW_THREADS)
@@ -507,8 +510,11 @@ static int se_forward(const void* x, void* y, int N, int HW, int C, const void* 
                        1.0f / (float)HW, 1, pooled);
     RN_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(se_fc_kernel, dim3(N), dim3(256), (size_t)(C + se) * 4, st, pooled, (const uint16_t*)w_reduce,
-                     b_reduce, (const uint16_t*)w_expand, b_expand, C, se, gate, h1, av);
+  hipLaunchKernelGGL(se_fc1_kernel, dim3((unsigned)rn_cdiv((long long)N * se, 4)), dim3(256), 0, st, pooled,
+                     (const uint16_t*)w_reduce, b_reduce, N, C, se, h1, av);
+  RN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(se_fc2_kernel, dim3((unsigned)rn_cdiv((long long)N * C, 256)), dim3(256), 0, st, av,
+                     (const uint16_t*)w_expand, b_expand, N, C, se, gate);
   RN_CHECK_LAUNCH();
   const long long total = (long long)N * HW * (C / 8);
   long long blocks = rn_cdiv(total, DW_THREADS);
@@ -579,43 +585,41 @@ se_bwd_pool_kernel(const uint4* __restrict__ x, const uint4* __restrict__ dy, in
   }
 }
 
-// one workgroup per image: dgate -> dh2[c], dh1[j], dp[c] (gradient wrt the pooled vector)
+// dgate -> dh2[n][c] (thread per element), dh1[n][j] (wavefront per element), dp[n][c] (thread per element)
 __global__ void __launch_bounds__(256)
-se_bwd_fc_kernel(const float* __restrict__ state, const float* __restrict__ dgate, const uint16_t* __restrict__ w1,
-                 const uint16_t* __restrict__ w2, int N, int C, int se, float* __restrict__ dh2, float* __restrict__ dh1,
+se_bwd_dh2_kernel(const float* __restrict__ state, const float* __restrict__ dgate, int N, int C,
+                  float* __restrict__ dh2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * C) return;
+  const float g = state[(size_t)N * C + i];
+  dh2[i] = dgate[i] * g * (1.0f - g);
+}
+__global__ void __launch_bounds__(256)
+se_bwd_dh1_kernel(const float* __restrict__ state, const float* __restrict__ dh2, const uint16_t* __restrict__ w2,
+                  int N, int C, int se, float* __restrict__ dh1) {
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);   // (n, j)
+  if (item >= N * se) return;
+  const int n = item / se, j = item - n * se;
+  const float* d = dh2 + (long long)n * C;
+  float acc = 0.0f;
+  for (int c = lane; c < C; c += 64) acc += d[c] * rn_bf16_to_f32(w2[(long long)c * se + j]);
+  acc = rn_wave_sum(acc);
+  if (lane == 0) {
+    const float u = state[(size_t)2 * N * C + item];   // h1
+    const float sg = 1.0f / (1.0f + __expf(-u));
+    dh1[item] = acc * (sg + u * sg * (1.0f - sg));
+  }
+}
+__global__ void __launch_bounds__(256)
+se_bwd_dp_kernel(const float* __restrict__ dh1, const uint16_t* __restrict__ w1, int N, int C, int se,
                  float* __restrict__ dp) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* s2 = (float*)smem;   // dh2 [C]
-  float* s1 = s2 + C;         // dh1 [se]
-  const int n = blockIdx.x;
-  const float* gate = state + (size_t)N * C + (size_t)n * C;
-  const float* h1 = state + (size_t)2 * N * C + (size_t)n * se;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    const float g = gate[c];
-    const float v = dgate[(long long)n * C + c] * g * (1.0f - g);
-    s2[c] = v;
-    dh2[(long long)n * C + c] = v;
-  }
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int j = wave; j < se; j += blockDim.x / 64) {
-    float acc = 0.0f;
-    for (int c = lane; c < C; c += 64) acc += s2[c] * rn_bf16_to_f32(w2[(long long)c * se + j]);
-    acc = rn_wave_sum(acc);
-    if (lane == 0) {
-      const float u = h1[j];
-      const float sg = 1.0f / (1.0f + __expf(-u));
-      const float v = acc * (sg + u * sg * (1.0f - sg));
-      s1[j] = v;
-      dh1[(long long)n * se + j] = v;
-    }
-  }
-  __syncthreads();
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float acc = 0.0f;
-    for (int j = 0; j < se; ++j) acc += s1[j] * rn_bf16_to_f32(w1[(long long)j * C + c]);
-    dp[(long long)n * C + c] = acc;
-  }
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * C) return;
+  const int n = i / C, c = i - n * C;
+  float acc = 0.0f;
+  for (int j = 0; j < se; ++j) acc += dh1[(long long)n * se + j] * rn_bf16_to_f32(w1[(long long)j * C + c]);
+  dp[i] = acc;
 }
 
 // parameter gradients: sums over the N images (thread per element, fixed order)
@@ -698,8 +702,13 @@ extern "C" int rn_squeeze_excite_bwd(const void* x, const void* dy, void* dx, in
                        1.0f, 0, dgate);
     RN_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(se_bwd_fc_kernel, dim3(N), dim3(256), (size_t)(C + se) * 4, st, stf, dgate,
-                     (const uint16_t*)w_reduce, (const uint16_t*)w_expand, N, C, se, dh2, dh1, dp);
+  const unsigned bnc = (unsigned)rn_cdiv((long long)N * C, 256);
+  hipLaunchKernelGGL(se_bwd_dh2_kernel, dim3(bnc), dim3(256), 0, st, stf, dgate, N, C, dh2);
+  RN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(se_bwd_dh1_kernel, dim3((unsigned)rn_cdiv((long long)N * se, 4)), dim3(256), 0, st, stf, dh2,
+                     (const uint16_t*)w_expand, N, C, se, dh1);
+  RN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(se_bwd_dp_kernel, dim3(bnc), dim3(256), 0, st, dh1, (const uint16_t*)w_reduce, N, C, se, dp);
   RN_CHECK_LAUNCH();
   const long long nel = 2ll * se * C + se + C;
   hipLaunchKernelGGL(se_bwd_wgrad_kernel, dim3((unsigned)rn_cdiv(nel, 256)), dim3(256), 0, st, stf, dh2, dh1, N, C, se,

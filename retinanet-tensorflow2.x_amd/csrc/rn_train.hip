@@ -311,7 +311,10 @@ static int bn_fill(const rn_bn_problem* p, BnArgs& a, int need_ws) {
     d.P = s.P; d.C = s.C; d.dres_accumulate = s.dres_accumulate;
     d.sample_scale = s.sample_scale; d.rows_per_sample = s.rows_per_sample > 0 ? s.rows_per_sample : 1;
     if (s.sample_scale && p->act == RN_ACT_SWISH) return -1;   // swish' is recomputed without the factor
-    long long rpc = rn_cdiv(rn_cdiv(s.P, 256), 32) * 32;  // <= 256 chunks, multiple of 32 rows
+    // ~2048 workgroups per segment over (row chunks x 64-channel slabs): narrow layers (EfficientNet: 24..144
+    // channels = 1..3 slabs) get more row chunks, so the reduction still fills the chip
+    const long long want_chunks = 2048 / rn_cdiv(s.C, 64) < 256 ? 256 : 2048 / rn_cdiv(s.C, 64);
+    long long rpc = rn_cdiv(rn_cdiv(s.P, want_chunks), 32) * 32;  // multiple of 32 rows
     if (rpc < 32) rpc = 32;
     d.rows_per_chunk = (int)rpc;
     d.chunks = (int)rn_cdiv(s.P, rpc);
