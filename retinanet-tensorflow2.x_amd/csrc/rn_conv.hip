@@ -8,15 +8,18 @@
 // prepacked weight [Cout_pad][R*S*Cin] (k contiguous), accumulation fp32 on
 // v_mfma_f32_32x32x16_bf16.
 //
-// Workgroup = 256 threads = 4 wavefronts (2x2), tile BM x BN x BK = 128 x {128,64} x {64,32}.
-//   * global -> registers -> LDS staging, double buffered, ONE barrier per K step: the loads of
-//     step t+1 are issued before the MFMAs of step t and written to the other LDS buffer after
-//     them, so HBM/L2 latency hides under the matrix pipe.
+// This file: host entry points, weight / image packing, and the 128-row kernel — workgroup = 256 threads =
+// 4 wavefronts (2x2), tile BM x BN x BK = 128 x {128,64} x {64,32} — that serves the narrow layers and the
+// small launches; layers with Cout >= 256 and enough tiles go to the persistent 256 x 256 x 32 kernel in
+// rn_conv_big.hip (conv_use_big below).
+//   * staging by `buffer_load ... lds` DMA (16 B per lane, no VGPR round trip), two LDS stages, ONE
+//     barrier per K step: the DMA of step t+1 is issued before the MFMAs of step t.
 //   * LDS tiles are [rows][BK] bf16 with the 16-byte slot index XOR-swizzled by
-//     (row / rows_per_256B) so the ds_read_b128 fragment reads (one row per lane, same k slot)
-//     hit 16 distinct 16-byte slots of the 256-byte bank row: conflict free.
+//     (row / rows_per_256B) — applied to the DMA's per-lane source chunk and to the ds_read_b128
+//     fragment address — so the fragment reads (one row per lane, same k slot) hit 16 distinct
+//     16-byte slots of the 256-byte bank row: conflict free.
 //   * padding / image borders / M tail: per-row tap-validity bitmask computed once per tile;
-//     invalid 16-byte pieces are zero-filled in registers.
+//     invalid pieces get an out-of-range buffer offset, which the hardware zero-fills.
 //   * epilogue: acc*scale[c]+shift[c] staged through LDS as fp32 [BM][BN] (reusing the A/B
 //     buffers), then read back row-contiguous: + residual, activation, convert, 8/16-byte
 //     coalesced stores.  BN(+bias) folding makes Conv+BN+ReLU(+add) one kernel at inference.
@@ -29,10 +32,8 @@
 
 // ABL: ablation mask for tools/bench_conv.py (0 in production): 1 = B tile loaded once,
 // 2 = A tile loaded once, 4 = no MFMA.
-// WM x WN wavefronts (64 x (BN/WN) wave tiles), STAGES LDS stages.  Two shapes are built:
-//   128 x {128,64} x {64,32}, 2x2 waves, 2 stages (64 KB LDS, 2 workgroups/CU)  — small / narrow layers
-//   256 x 128 x 64, 4x2 waves, 3 stages (144 KB LDS, 1 workgroup/CU, DMA two K-steps ahead with a
-//   counted vmcnt and a raw s_barrier so the loads of step t+1 stay in flight across the barrier)
+// WM x WN wavefronts (64 x (BN/WN) wave tiles), two LDS stages: 128 x {128,64} x {64,32}, 2x2 waves
+// (64 KB LDS, 2 workgroups/CU) for the narrow / small launches; the wide layers go to rn_conv_big.hip.
 template <int BM, int BN, int BK, bool OUT_F32, int ABL = 0, int WM = 2, int WN = 2, int STAGES = 2>
 __global__ void __launch_bounds__(64 * WM * WN, 2) conv_fwd_kernel(const ConvArgs args) {
   constexpr int NWAVES = WM * WN;
@@ -205,66 +206,6 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_fwd_kernel(const ConvArg
       __syncthreads();
       cur ^= 1;
     }
-  } else {
-    // ---- 3-stage ring + register double buffering -------------------------------------------------
-    // step t:  wait for every outstanding DMA (tiles <= t+1; tile t+1 had a whole step to land),
-    //          barrier, issue the DMA of tile t+2 into the stage step t-1 consumed, then issue ALL
-    //          16 ds_read_b128 of tile t+1 into the spare fragment registers and run the 16 MFMAs of
-    //          tile t from the other set.  LDS latency and the DMA both hide under the MFMAs; the
-    //          2-stage kernel above keeps only 4 LDS reads in flight per wave and is LDS-latency bound.
-    bf16x8_t fa0[TM][KSUB], fb0[TN][KSUB], fa1[TM][KSUB], fb1[TN][KSUB];
-#define RN_LOAD_FRAGS(FA, FB, stage_)                                                     \
-  do {                                                                                    \
-    const char* b__ = smem + (stage_) * STAGE_BYTES;                                      \
-    _Pragma("unroll") for (int kk = 0; kk < KSUB; ++kk) {                                 \
-      _Pragma("unroll") for (int i = 0; i < TM; ++i) FA[i][kk] = *(const bf16x8_t*)(b__ + rd_a[i][kk]); \
-      _Pragma("unroll") for (int j = 0; j < TN; ++j) FB[j][kk] = *(const bf16x8_t*)(b__ + rd_b[j][kk]); \
-    }                                                                                     \
-  } while (0)
-#define RN_MFMA_FRAGS(FA, FB)                                                             \
-  do {                                                                                    \
-    _Pragma("unroll") for (int kk = 0; kk < KSUB; ++kk)                                   \
-      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                      \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                    \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[i][kk], FB[j][kk], acc[i][j], 0, 0, 0); \
-  } while (0)
-#define RN_STEP(FA_CUR, FB_CUR, FA_NXT, FB_NXT)                                           \
-  do {                                                                                    \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                      \
-    __builtin_amdgcn_s_barrier();                                                         \
-    asm volatile("" ::: "memory");                                                        \
-    if (kt + 2 < ksteps) {                                                                \
-      RN_ISSUE_TILE(st2, tap, c0);                                                        \
-      RN_ADVANCE();                                                                       \
-    }                                                                                     \
-    if (kt + 1 < ksteps) RN_LOAD_FRAGS(FA_NXT, FB_NXT, st1);                              \
-    RN_MFMA_FRAGS(FA_CUR, FB_CUR);                                                        \
-    st1 = st1 == STAGES - 1 ? 0 : st1 + 1;                                                \
-    st2 = st2 == STAGES - 1 ? 0 : st2 + 1;                                                \
-    ++kt;                                                                                 \
-  } while (0)
-
-    RN_ISSUE_TILE(0, 0, 0);
-    RN_ADVANCE();
-    if (ksteps > 1) {
-      RN_ISSUE_TILE(1, tap, c0);
-      RN_ADVANCE();
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    RN_LOAD_FRAGS(fa0, fb0, 0);
-    int st1 = 1, st2 = 2, kt = 0;
-#pragma unroll 1
-    while (kt < ksteps) {
-      RN_STEP(fa0, fb0, fa1, fb1);
-      if (kt < ksteps) RN_STEP(fa1, fb1, fa0, fb0);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __syncthreads();
-#undef RN_STEP
-#undef RN_MFMA_FRAGS
-#undef RN_LOAD_FRAGS
   }
 #undef RN_ADVANCE
 #undef RN_ISSUE_TILE
