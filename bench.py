@@ -294,11 +294,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # RNET_BENCH_ONE_DEVICE=1: functional check of the N>1 code path on a single-GPU box — every rank uses
+    # cuda:0 and the collectives go through gloo (RCCL refuses two ranks on one device).  Not a measurement.
+    one_device = os.environ.get("RNET_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if one_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     train, p_train, m_train, eng = run_train(args, dev, rank, world)
     B = train["B"]
