@@ -166,6 +166,12 @@ typedef struct {
   const float* shift;   /* f32[Cout] or NULL (=0) */
   const void* residual; /* bf16 [N,Ho,Wo,Cout] or NULL */
   int32_t N, H, W, Cin, pix_stride, Ho, Wo, Cout;
+  /* optional: BatchNorm forward statistics fused into the epilogue.  When the launch runs on the 256-row
+   * kernel (rn_conv_tile_rows() == 256) and this is non-NULL, every 128-pixel row block b of the output
+   * writes its per-channel partial sums of the STORED bf16 values: bn_partial[(b*2 + 0)*Cout + c] = sum,
+   * [(b*2 + 1)*Cout + c] = sum of squares, b = 0 .. 2*ceil(N*Ho*Wo/256)-1 — the stage-1 layout of rn_bn_stats
+   * (rn_bn_segment.ext_chunks).  Ignored by the 128-row kernel. */
+  float* bn_partial;
 } rn_conv_segment;
 
 typedef struct {
@@ -283,6 +289,11 @@ typedef struct {
    * z = act((y*scale + shift) * m[n] + residual); the backward scales the BN branch by m[n], dres is not. */
   const float* sample_scale;
   int64_t rows_per_sample;
+  /* > 0: the stage-1 partial sums of rn_bn_stats were already written by the producing convolution
+   * (rn_conv_segment.bn_partial) as `ext_chunks` row blocks at workspace + rn_bn_partial_offset_bytes(); rn_bn_stats
+   * then only runs the ordered final reduction.  All segments of a problem must agree. */
+  int32_t ext_chunks;
+  int32_t pad_;
 } rn_bn_segment;
 
 typedef struct {
@@ -296,6 +307,7 @@ typedef struct {
 } rn_bn_problem;
 
 size_t rn_bn_workspace_bytes(const rn_bn_problem* problem /* host */);
+size_t rn_bn_partial_offset_bytes(const rn_bn_problem* problem, int segment);   /* forward-stats partials in the workspace */
 int rn_bn_stats(const rn_bn_problem* problem, void* workspace, size_t workspace_bytes, void* stream);
 int rn_bn_finalize(const rn_bn_problem* problem, void* stream);
 int rn_bn_apply(const rn_bn_problem* problem, void* stream);

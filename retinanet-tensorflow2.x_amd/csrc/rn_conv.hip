@@ -377,6 +377,7 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
     ConvSegDev& d = a.seg[i];
     d.x = (const uint16_t*)s.x; d.w = (const uint16_t*)s.w; d.y = s.y;
     d.scale = s.scale; d.shift = s.shift; d.residual = (const uint16_t*)s.residual;
+    d.bn_partial = s.bn_partial;
     d.N = s.N; d.H = s.H; d.W = s.W; d.Cin = s.Cin; d.pix_stride = s.pix_stride;
     d.Ho = s.Ho; d.Wo = s.Wo; d.Cout = s.Cout;
     d.M = (int)M;

@@ -254,6 +254,11 @@ __global__ void __launch_bounds__(512) conv_big_kernel(const ConvArgs args) {
         sf[0] = a.x; sf[1] = a.y; sf[2] = a.z; sf[3] = a.w; sf[4] = b.x; sf[5] = b.y; sf[6] = b.z; sf[7] = b.w;
       }
       const bool has_res = sg.residual != nullptr;
+      // fused BatchNorm forward statistics (training, raw conv output): per-lane sums of the stored values
+      const bool stats = sg.bn_partial != nullptr;
+      float st0[8], st1[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) st0[q] = st1[q] = 0.0f;
       uint4 rv[2][4];
 #define BIG_RES_PREFETCH(buf_, i_)                                                                    \
   _Pragma("unroll") for (int pass = 0; pass < 4; ++pass) {                                            \
@@ -290,7 +295,32 @@ __global__ void __launch_bounds__(512) conv_big_kernel(const ConvArgs args) {
             uint4 ov;
             ov.x = pack2(f[0], f[1]); ov.y = pack2(f[2], f[3]); ov.z = pack2(f[4], f[5]); ov.w = pack2(f[6], f[7]);
             *(uint4*)((uint16_t*)sg.y + (long long)m * Cout + nr) = ov;
+            if (stats) {
+              const float w[8] = {bf_lo(ov.x), bf_hi(ov.x), bf_lo(ov.y), bf_hi(ov.y),
+                                  bf_lo(ov.z), bf_hi(ov.z), bf_lo(ov.w), bf_hi(ov.w)};
+#pragma unroll
+              for (int q = 0; q < 8; ++q) { st0[q] += w[q]; st1[q] += w[q] * w[q]; }
+            }
           }
+        }
+      }
+      if (stats) {
+        // sum over the 8 row lanes that share this lane's channels (lane bits 3..5), then lanes 0-7 write the
+        // wave's 128-pixel row block: chunk = m_tile * 2 + wave_m, layout [chunk][2][Cout]
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+#pragma unroll
+          for (int o = 8; o < 64; o <<= 1) {
+            st0[q] += __shfl_xor(st0[q], o, 64);
+            st1[q] += __shfl_xor(st1[q], o, 64);
+          }
+        }
+        if (rrow == 0 && nok) {
+          float* dst = sg.bn_partial + ((long long)(c_m0 / BM) * 2 + wave_m) * 2 * Cout + nr;
+          *(float4*)(dst) = make_float4(st0[0], st0[1], st0[2], st0[3]);
+          *(float4*)(dst + 4) = make_float4(st0[4], st0[5], st0[6], st0[7]);
+          *(float4*)(dst + Cout) = make_float4(st1[0], st1[1], st1[2], st1[3]);
+          *(float4*)(dst + Cout + 4) = make_float4(st1[4], st1[5], st1[6], st1[7]);
         }
       }
 #undef BIG_RES_PREFETCH

@@ -295,7 +295,8 @@ __global__ void __launch_bounds__(TR_THREADS) bn_bwd_apply_kernel(const BnArgs a
   }
 }
 
-static int bn_fill(const rn_bn_problem* p, BnArgs& a, int need_ws) {
+// mode 0 (forward statistics) honours rn_bn_segment.ext_chunks: stage-1 partials written by the conv epilogue
+static int bn_fill(const rn_bn_problem* p, BnArgs& a, int need_ws, int mode = 1) {
   if (!p || p->num_segments < 1 || p->num_segments > RN_CONV_MAX_SEGMENTS) return -1;
   a.nseg = p->num_segments; a.act = p->act; a.bessel = p->bessel; a.mode = 0;
   a.eps = p->eps; a.momentum = p->momentum; a.count_scale = p->count_scale > 0 ? p->count_scale : 1.0f;
@@ -318,6 +319,7 @@ static int bn_fill(const rn_bn_problem* p, BnArgs& a, int need_ws) {
     if (rpc < 32) rpc = 32;
     d.rows_per_chunk = (int)rpc;
     d.chunks = (int)rn_cdiv(s.P, rpc);
+    if (mode == 0 && s.ext_chunks > 0) d.chunks = s.ext_chunks;
     a.ws_off[i] = off;
     off += (long long)d.chunks * 2 * s.C;
   }
@@ -326,16 +328,30 @@ static int bn_fill(const rn_bn_problem* p, BnArgs& a, int need_ws) {
 }
 
 extern "C" size_t rn_bn_workspace_bytes(const rn_bn_problem* p) {
+  size_t need = 0;
+  for (int mode = 0; mode < 2; ++mode) {     // forward (possibly external partials) and backward chunking
+    BnArgs a;
+    if (bn_fill(p, a, 1, mode)) return 0;
+    const BnSegDev& l = a.seg[a.nseg - 1];
+    const size_t b = (size_t)(a.ws_off[a.nseg - 1] + (long long)l.chunks * 2 * l.C) * sizeof(float);
+    if (b > need) need = b;
+  }
+  return need;
+}
+
+extern "C" size_t rn_bn_partial_offset_bytes(const rn_bn_problem* p, int segment) {
   BnArgs a;
-  if (bn_fill(p, a, 1)) return 0;
-  const BnSegDev& l = a.seg[a.nseg - 1];
-  return (size_t)(a.ws_off[a.nseg - 1] + (long long)l.chunks * 2 * l.C) * sizeof(float);
+  if (bn_fill(p, a, 1, 0) || segment < 0 || segment >= a.nseg) return 0;
+  return (size_t)a.ws_off[segment] * sizeof(float);
 }
 
 static int bn_colreduce(const rn_bn_problem* p, int mode, void* ws, size_t ws_bytes, hipStream_t st,
                         const char* fn) {
   BnArgs a;
-  RN_CHECK_ARG(bn_fill(p, a, 1) == 0, "%s: bad problem (C %% 8 == 0, 1..10 segments)", fn);
+  RN_CHECK_ARG(bn_fill(p, a, 1, mode) == 0, "%s: bad problem (C %% 8 == 0, 1..10 segments)", fn);
+  int n_ext = 0;
+  for (int i = 0; i < p->num_segments; ++i) n_ext += (mode == 0 && p->seg[i].ext_chunks > 0) ? 1 : 0;
+  RN_CHECK_ARG(n_ext == 0 || n_ext == p->num_segments, "%s: ext_chunks must be set on all segments or none", fn);
   if (!ws || ws_bytes < rn_bn_workspace_bytes(p)) {
     rn_set_error("%s: workspace too small", fn);
     return RN_ENOMEM;
@@ -351,8 +367,10 @@ static int bn_colreduce(const rn_bn_problem* p, int mode, void* ws, size_t ws_by
     if ((s.C + 63) / 64 > max_slabs) max_slabs = (s.C + 63) / 64;
     if (s.C > max_c) max_c = s.C;
   }
-  hipLaunchKernelGGL(bn_colreduce_kernel, dim3(max_chunks, max_slabs, a.nseg), dim3(TR_THREADS), 0, st, a);
-  RN_CHECK_LAUNCH();
+  if (n_ext == 0) {   // otherwise the producing convolution already wrote the stage-1 partials
+    hipLaunchKernelGGL(bn_colreduce_kernel, dim3(max_chunks, max_slabs, a.nseg), dim3(TR_THREADS), 0, st, a);
+    RN_CHECK_LAUNCH();
+  }
   hipLaunchKernelGGL(bn_colreduce_final_kernel, dim3((max_c + 31) / 32, a.nseg), dim3(1024), 0, st, a);
   RN_CHECK_LAUNCH();
   return RN_OK;

@@ -27,7 +27,7 @@ class RnetError(RuntimeError):
 class ConvSegment(Structure):
     _fields_ = [("x", c_void_p), ("w", c_void_p), ("y", c_void_p), ("scale", c_void_p), ("shift", c_void_p),
                 ("residual", c_void_p), ("N", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32),
-                ("pix_stride", c_int32), ("Ho", c_int32), ("Wo", c_int32), ("Cout", c_int32)]
+                ("pix_stride", c_int32), ("Ho", c_int32), ("Wo", c_int32), ("Cout", c_int32), ("bn_partial", c_void_p)]
 
 
 class ConvProblem(Structure):
@@ -64,7 +64,8 @@ class BnSegment(Structure):
                 ("dres", c_void_p), ("sums", c_void_p), ("fwd", c_void_p), ("bsums", c_void_p),
                 ("gamma", c_void_p), ("beta", c_void_p), ("moving_mean", c_void_p), ("moving_var", c_void_p),
                 ("dgamma", c_void_p), ("dbeta", c_void_p), ("P", c_int64), ("C", c_int32),
-                ("dres_accumulate", c_int32), ("sample_scale", c_void_p), ("rows_per_sample", c_int64)]
+                ("dres_accumulate", c_int32), ("sample_scale", c_void_p), ("rows_per_sample", c_int64),
+                ("ext_chunks", c_int32), ("pad_", c_int32)]
 
 
 class BnProblem(Structure):
@@ -135,6 +136,7 @@ _SIGNATURES = {
     "rn_cast_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "rn_act_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "rn_bn_workspace_bytes": (c_size_t, [POINTER(BnProblem)]),
+    "rn_bn_partial_offset_bytes": (c_size_t, [POINTER(BnProblem), c_int]),
     "rn_bn_stats": (c_int, [POINTER(BnProblem), c_void_p, c_size_t, c_void_p]),
     "rn_bn_finalize": (c_int, [POINTER(BnProblem), c_void_p]),
     "rn_bn_apply": (c_int, [POINTER(BnProblem), c_void_p]),

@@ -26,6 +26,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 
 import numpy as np
 import torch
@@ -65,6 +66,7 @@ class TrainEngine:
         self._keep = []
         self.step_count = 0
         self.conv_profile = None
+        self.fuse_bn_stats = os.environ.get("RNET_FUSE_BN_STATS", "1") != "0"   # conv epilogue writes BN partial sums
         self.drop_connect = True     # stochastic depth of the EfficientNet skip blocks (efficientnet.py:97-113)
         self.dc_masks = {}           # project conv output -> (f32[B] factors, survival_prob)
         self.dc_all = self.dc_p = None
@@ -475,7 +477,10 @@ class TrainEngine:
         self._keep.append(p)
         return p
 
-    def _bn_problem(self, ops):
+    def _bn_problem(self, ops, conv_problem=None):
+        """BatchNorm problem over `ops`.  With `conv_problem` (the launch that produces the raw outputs): when the
+        dispatcher runs it on the 256-row kernel, the forward statistics' stage-1 partial sums are written by the
+        conv epilogue (rn_conv_segment.bn_partial) and rn_bn_stats only does the final ordered reduction."""
         p = _C.BnProblem()
         p.num_segments = len(ops)
         p.act = _C.ACT_IDS[ops[0]["act"]]
@@ -519,8 +524,16 @@ class TrainEngine:
                 self.dc_masks[op["out"]] = (m, float(op["survival"]))
                 s.sample_scale, s.rows_per_sample = m.data_ptr(), y.shape[1] * y.shape[2]
             off += C
+        fused = (conv_problem is not None and self.fuse_bn_stats and conv_problem.out_dtype == _C.RN_DT_BF16
+                 and self.lib.rn_conv_tile_rows(ctypes.byref(conv_problem)) == 256)
+        if fused:
+            for i in range(len(ops)):
+                p.seg[i].ext_chunks = 2 * ((p.seg[i].P + 255) // 256)
         ws = torch.empty((max(self.lib.rn_bn_workspace_bytes(ctypes.byref(p)), 256),), dtype=torch.uint8,
                          device=self.dev)
+        if fused:
+            for i in range(len(ops)):
+                conv_problem.seg[i].bn_partial = ws.data_ptr() + self.lib.rn_bn_partial_offset_bytes(ctypes.byref(p), i)
         self._keep += [p, sums, bsums, fwd, ws] + dys
         return p, sums, bsums, ws, dys
 
@@ -587,7 +600,7 @@ class TrainEngine:
                     raise NotImplementedError("a conv group mixes frozen and live BatchNorm")
                 if live_bn:
                     pc = self._conv_problem(ops, lambda o: self.raw[o["out"]], raw_mode=True)
-                    pb, sums, bsums, ws, dys = self._bn_problem(ops)
+                    pb, sums, bsums, ws, dys = self._bn_problem(ops, conv_problem=pc)
                     self.bn_groups[ops[0]["out"]] = (pb, sums, bsums, ws, dys, ops)
                     prb = ctypes.byref(pb)
 

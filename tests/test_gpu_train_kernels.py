@@ -207,6 +207,63 @@ def test_bn_train_forward_backward(cuda, act, use_res):
         torch.testing.assert_close(d["moving_var"].cpu().double(), mv, rtol=1e-5, atol=1e-5)
 
 
+def test_bn_forward_stats_fused_into_conv_epilogue(cuda):
+    """rn_conv_segment.bn_partial + rn_bn_segment.ext_chunks: the 256-row conv kernel writes the per-128-row partial
+    sums, rn_bn_stats only runs the final reduction.  Must give the statistics of the unfused path on the same
+    stored bf16 output (fp32 summation order differs), including pixel tails and a channel tail (Cout 320)."""
+    from retinanet import _C
+    lib = _C.lib()
+    g = torch.Generator().manual_seed(23)
+    shapes = [(2, 19, 21, 128, 256), (1, 16, 16, 128, 320), (3, 7, 5, 128, 512)]   # N, H, W, Cin, Cout
+    pc = _C.ConvProblem()
+    pc.R = pc.S = 1
+    pc.stride_h = pc.stride_w = 1
+    pc.pad_top = pc.pad_left = 0
+    pc.act, pc.out_dtype, pc.num_segments = _C.RN_ACT_NONE, _C.RN_DT_BF16, len(shapes)
+    keep, ys, segs = [], [], []
+    for i, (N, H, W, cin, cout) in enumerate(shapes):
+        x = _bf(torch.randn((N, H, W, cin), generator=g)).to(cuda)
+        w = (torch.randn((1, 1, cin, cout), generator=g) / 8 + 0.02).to(cuda).contiguous()
+        wp = torch.empty((lib.rn_conv_cout_pad(cout), 1, 1, cin), dtype=torch.bfloat16, device=cuda)
+        _C.check(lib.rn_pack_conv_weight(_C.ptr(w), 1, 1, cin, cout, cin, _C.ptr(wp), _C.current_stream()))
+        y = torch.empty((N, H, W, cout), dtype=torch.bfloat16, device=cuda)
+        s = pc.seg[i]
+        s.x, s.w, s.y, s.scale, s.shift, s.residual = x.data_ptr(), wp.data_ptr(), y.data_ptr(), None, None, None
+        s.N, s.H, s.W, s.Cin, s.pix_stride, s.Ho, s.Wo, s.Cout = N, H, W, cin, cin, H, W, cout
+        keep += [x, w, wp]
+        ys.append(y)
+        segs.append({"y": torch.zeros((N, H, W, cout)), "gamma": torch.ones((cout,)), "beta": torch.zeros((cout,)),
+                     "moving_mean": torch.zeros((cout,)), "moving_var": torch.ones((cout,))})
+    st = _C.current_stream()
+    lib.rn_debug_conv_tile(2)
+    try:
+        assert lib.rn_conv_tile_rows(ctypes.byref(pc)) == 256
+        sums = {}
+        for fused in (False, True):
+            p, dev = _bn_problem(cuda, segs, None)
+            for i, y in enumerate(ys):
+                p.seg[i].y = y.data_ptr()
+                if fused:
+                    p.seg[i].ext_chunks = 2 * ((p.seg[i].P + 255) // 256)
+            ws = _ws(lib.rn_bn_workspace_bytes(ctypes.byref(p)), cuda)
+            ws.fill_(0x7f)    # stale bytes must not leak into the sums
+            for i in range(len(ys)):
+                pc.seg[i].bn_partial = (ws.data_ptr() + lib.rn_bn_partial_offset_bytes(ctypes.byref(p), i)) if fused else None
+                ys[i].zero_()
+            _C.check(lib.rn_conv2d_nhwc_fwd(ctypes.byref(pc), st))
+            _C.check(lib.rn_bn_stats(ctypes.byref(p), _C.ptr(ws), ws.numel(), st))
+            torch.cuda.synchronize()
+            sums[fused] = [d["sums"].cpu().double() for d in dev]
+    finally:
+        lib.rn_debug_conv_tile(0)
+    for i, y in enumerate(ys):
+        yd = y.float().cpu().double().reshape(-1, y.shape[-1])
+        want = torch.stack([yd.sum(0), (yd * yd).sum(0)])
+        tol = 1e-5 * want[1].abs().max().item()
+        torch.testing.assert_close(sums[False][i], want, rtol=1e-5, atol=tol)
+        torch.testing.assert_close(sums[True][i], want, rtol=1e-5, atol=tol)
+
+
 def test_pool_topdown_balance_backward(cuda):
     from retinanet import _C
     lib = _C.lib()
