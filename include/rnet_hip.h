@@ -435,6 +435,47 @@ int rn_coco_accumulate(const float* boxes, const int32_t* classes, const int32_t
                        float input_h, float input_w, const int32_t* class_lut, int num_classes, int B, int D,
                        int rescale, int32_t* out_bbox, int32_t* out_category, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * §8(f)-4  TFRecord input format — HOST functions (every pointer below is host memory; no HIP call)
+ * Replaces what tf.data.TFRecordDataset (retinanet/dataloader/input_pipeline.py:60-68) and
+ * tf.io.parse_single_example (retinanet/dataloader/tfrecord_parser.py:4-41) do for the reference, and
+ * tf.io.TFRecordWriter / tf.train.Example.SerializeToString (retinanet/dataset_utils/tfrecord_writer.py:27-57).
+ *
+ * Framing of one record: u64le length | u32le masked_crc32c(length bytes) | payload | u32le masked_crc32c(payload),
+ * masked = rotr(crc, 15) + 0xa282ead8, crc = CRC-32C (Castagnoli, reflected 0x82F63B78).
+ */
+uint32_t rn_crc32c(const void* data, size_t nbytes);
+uint32_t rn_crc32c_masked(const void* data, size_t nbytes);
+/* Walk a buffer of whole records.  Fills payload_offsets/lengths (relative to buf) for at most max_records
+ * records, returns how many were found (>= 0) and the bytes they cover in *consumed (a truncated trailing
+ * record is not an error when allow_partial_tail != 0: it is left unconsumed, like a reader that refills its
+ * buffer).  verify_crc != 0 checks both checksums.  Negative rn_status on corruption (TF: DataLossError). */
+long long rn_tfrecord_scan(const uint8_t* buf, size_t nbytes, uint64_t* payload_offsets, uint64_t* payload_lengths,
+                           long long max_records, int verify_crc, int allow_partial_tail, size_t* consumed);
+/* Frame one payload into out (capacity >= nbytes + 16); returns the bytes written. */
+size_t rn_tfrecord_frame(const uint8_t* payload, size_t nbytes, uint8_t* out);
+
+/* One parsed tf.train.Example with the reference's feature set (tfrecord_parser.py:5-13). */
+typedef struct {
+  uint64_t image_offset, image_length; /* the 'image' bytes inside the record (FixedLenFeature [], string) */
+  int64_t image_id;                    /* 'image_id' (FixedLenFeature [], int64) */
+  int32_t n_xmins, n_ymins, n_xmaxs, n_ymaxs, n_classes; /* VarLenFeature lengths (0 when absent) */
+  int32_t pad_;
+} rn_example_info;
+/* Parses the protobuf wire format of Example{features=1{map<string,Feature> feature=1}} (packed and unpacked
+ * repeated scalars, any key order, the last duplicate key wins).  Box coordinates / classes are copied into the
+ * caller's arrays (each of `capacity` elements; pass capacity 0 and NULL arrays to only count).  Errors like
+ * parse_single_example: RN_EINVAL when 'image' or 'image_id' is missing, has another dtype or not exactly
+ * one value, when a VarLen feature has another dtype, or on malformed wire data; RN_ENOMEM when a list is longer
+ * than capacity (info is still filled with the needed lengths). */
+int rn_example_parse(const uint8_t* record, size_t nbytes, rn_example_info* info, float* xmins, float* ymins,
+                     float* xmaxs, float* ymaxs, int64_t* classes, int capacity);
+/* Serialises the Example of TFrecordWriter._make_example (tfrecord_writer.py:27-44); boxes f32[n_boxes,4] =
+ * (xmin, ymin, xmax, ymax) rows.  Feature keys are written in sorted order, repeated scalars packed.
+ * Returns the size (call with out == NULL to size the buffer), or 0 when capacity is too small. */
+size_t rn_example_serialize(const uint8_t* image, size_t image_bytes, int64_t image_id, const float* boxes,
+                            int n_boxes, const int64_t* classes, int n_classes, uint8_t* out, size_t capacity);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,7 +7,8 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p)
+from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_longlong, c_size_t, c_uint32,
+                    c_uint64, c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RNET_HIP_LIB: alternative build of the same ABI (A/B timing of kernel variants on one GPU box)
@@ -22,6 +23,12 @@ ACT_IDS = {None: RN_ACT_NONE, "none": RN_ACT_NONE, "relu": RN_ACT_RELU, "relu6":
 
 class RnetError(RuntimeError):
     pass
+
+
+class ExampleInfo(Structure):   # rn_example_info
+    _fields_ = [("image_offset", c_uint64), ("image_length", c_uint64), ("image_id", c_int64),
+                ("n_xmins", c_int32), ("n_ymins", c_int32), ("n_xmaxs", c_int32), ("n_ymaxs", c_int32),
+                ("n_classes", c_int32), ("pad_", c_int32)]
 
 
 class ConvSegment(Structure):
@@ -160,6 +167,16 @@ _SIGNATURES = {
                                   c_int, c_int, c_void_p]),
     "rn_fpn_topdown": (c_int, [_PP, _PP, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rn_balance_features": (c_int, [_PP, _PP, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    # host functions (TFRecord input format)
+    "rn_crc32c": (c_uint32, [c_void_p, c_size_t]),
+    "rn_crc32c_masked": (c_uint32, [c_void_p, c_size_t]),
+    "rn_tfrecord_scan": (c_longlong, [c_void_p, c_size_t, c_void_p, c_void_p, c_longlong, c_int, c_int,
+                                      POINTER(c_size_t)]),
+    "rn_tfrecord_frame": (c_size_t, [c_void_p, c_size_t, c_void_p]),
+    "rn_example_parse": (c_int, [c_void_p, c_size_t, POINTER(ExampleInfo), c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_int]),
+    "rn_example_serialize": (c_size_t, [c_void_p, c_size_t, c_int64, c_void_p, c_int, c_void_p, c_int, c_void_p,
+                                        c_size_t]),
 }
 
 _lib = None

@@ -111,8 +111,13 @@ def default_params(input_size=640, batch_train=256, batch_val=8, activation="rel
                           "scales": [1, 1.2599210498948732, 1.5874010519681994]},
         "encoder_params": {"match_iou": 0.5, "ignore_iou": 0.5, "box_variance": [0.1, 0.1, 0.2, 0.2],
                            "scale_box_targets": False},
-        "dataloader_params": {"preprocessing": {"mean": [0.485, 0.456, 0.406],
-                                                "stddev": [0.229, 0.224, 0.225], "pixel_scale": 255.0}},
+        "dataloader_params": {"tfrecords": {"train": "coco_remapped_tfrecords/train*",
+                                            "val": "coco_remapped_tfrecords/val*"},
+                              "augmentations": {"use_augmentation": True, "horizontal_flip": True,
+                                                "scale_jitter": {"min_scale": 0.1, "max_scale": 2.0}},
+                              "preprocessing": {"mean": [0.485, 0.456, 0.406],
+                                                "stddev": [0.229, 0.224, 0.225], "pixel_scale": 255.0},
+                              "shuffle_buffer_size": 1024},
         "inference": {"batch_size": inference_batch, "mode": nms_mode, "iou_threshold": 0.5,
                       "score_threshold": 0.05, "soft_nms_sigma": 0.5, "pre_nms_top_k": 5000,
                       "filter_per_class": True, "max_detections": 100},
