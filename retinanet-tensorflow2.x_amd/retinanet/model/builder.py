@@ -16,6 +16,7 @@ import logging
 import re
 from collections import OrderedDict
 
+import numpy as np
 import torch
 
 from retinanet.dataloader.anchor_generator import AnchorBoxGenerator
@@ -37,6 +38,7 @@ class RetinaNetModel:
         self.optimizer = None
         self._engines = {}
         self._frozen = set()
+        self.loaded_extras = {}
 
     # -- Keras-like surface used by the reference's Executor (executor.py:119,144,244,259,543) --
     @property
@@ -59,13 +61,32 @@ class RetinaNetModel:
             v.copy_(torch.as_tensor(w).reshape(v.shape))
         self._refresh()
 
-    def save_weights(self, path):
-        from safetensors.torch import save_file
-        save_file({k: v.detach().cpu().contiguous() for k, v in self.variables.items()}, path)
+    def save_weights(self, path, slots=None, extra=None):
+        """`<path>.index` + `<path>.data-00000-of-00001` in TensorFlow's checkpoint format (what the reference's
+        `model.save_weights`, executor.py:652-654, writes; see retinanet/tf_checkpoint.py), plus the `checkpoint`
+        state file `latest_checkpoint` reads.  `slots`: optional {(variable, slot): array} optimizer state
+        (TrainEngine.optimizer_slots()).  A path ending in `.safetensors` writes one safetensors file instead."""
+        if str(path).endswith(".safetensors"):
+            from safetensors.torch import save_file
+            save_file({k: v.detach().cpu().contiguous() for k, v in self.variables.items()}, path)
+            return
+        from retinanet import tf_checkpoint
+        arrays = {k: v.detach().cpu().numpy() for k, v in self.variables.items()}
+        arrays.update(extra or {})            # e.g. the optimizer's step counter
+        tf_checkpoint.save_weights(path, arrays, slots)
 
     def load_weights(self, path, by_name=True, skip_mismatch=False):
-        from safetensors.torch import load_file
-        loaded = load_file(path)
+        """Loads a TensorFlow checkpoint prefix (variables matched through the object graph's full names) or a
+        `.safetensors` file.  Returns the optimizer slots found in the checkpoint ({} for safetensors)."""
+        slots = {}
+        if str(path).endswith(".safetensors"):
+            from safetensors.torch import load_file
+            loaded = load_file(path)
+        else:
+            from retinanet import tf_checkpoint
+            arrays, slots = tf_checkpoint.load_weights(path)
+            loaded = {k: torch.from_numpy(np.ascontiguousarray(a)) for k, a in arrays.items()}
+            self.loaded_extras = {k: a for k, a in arrays.items() if k not in self.variables}
         for k, v in self.variables.items():
             if k not in loaded:
                 if skip_mismatch:
@@ -77,6 +98,7 @@ class RetinaNetModel:
                 raise ValueError(f"{k}: shape {tuple(loaded[k].shape)} != {tuple(v.shape)}")
             v.copy_(loaded[k])
         self._refresh()
+        return slots
 
     def summary(self, print_fn=print):
         n = sum(v.numel() for k, v in self.variables.items() if self.graph.var_specs[k].get("trainable", True))

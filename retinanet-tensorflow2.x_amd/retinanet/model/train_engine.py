@@ -267,17 +267,62 @@ class TrainEngine:
     def refresh_stem_pack(self):
         self.refresh_packs()
 
+    def _keras_layout(self, k, arena):
+        """Variable `k` of a flat arena in the layout Keras holds it (conv / SE kernels HWIO)."""
+        v = self.model.variables[k]
+        t = self._pview(k, arena)
+        if self.var_kind.get(k, ("other", None))[0] in ("conv", "se1", "se2"):
+            kh, kw, ci, co = v.shape
+            t = _ohwi_to_hwio(t.reshape(co, kh, kw, ci))
+        return t.reshape(v.shape)
+
+    def optimizer_slots(self):
+        """{(variable, slot): f32 array}: the SGD `momentum` accumulators and the moving-average `average` copies
+        (optimizers/builder.py:27-71 — what `save_weights` stores next to the weights for a resume)."""
+        out = {}
+        for k in self.train_names:
+            out[(k, "momentum")] = self._keras_layout(k, self.V).detach().cpu().numpy().copy()
+            out[(k, "average")] = self._keras_layout(k, self.E).detach().cpu().numpy().copy()
+        return out
+
+    def load_optimizer_slots(self, slots):
+        """Inverse of `optimizer_slots`; variables without a stored slot keep their current state."""
+        for (k, slot), arr in slots.items():
+            if k not in self.p_off or slot not in ("momentum", "average"):
+                continue
+            t = self._to_compute_layout(k, torch.as_tensor(np.asarray(arr), dtype=torch.float32).to(self.dev))
+            self._pview(k, self.V if slot == "momentum" else self.E).copy_(t.reshape(-1))
+
+    def save_checkpoint(self, prefix):
+        """Weights + BN moving statistics + optimizer slots (`momentum`, `average`) + the step counter, in
+        TensorFlow's checkpoint format (what executor.py:652-654 / 695-697 write through `model.save_weights`)."""
+        with torch.cuda.device(self.dev):
+            self.store_to_model(use_ema=False)
+            torch.cuda.synchronize()
+        self.model.save_weights(prefix, slots=self.optimizer_slots(),
+                                extra={"SGD/iter": np.asarray(self.step_count, dtype=np.int64)})
+
+    def restore_checkpoint(self, prefix):
+        """executor.py:221-244: load the latest weights and continue from their step."""
+        with torch.cuda.device(self.dev):
+            slots = self.model.load_weights(prefix)
+            self.load_from_model()
+            for bn, d in self.bn_state.items():
+                d["mm"].copy_(self.model.variables[bn + "/moving_mean"])
+                d["mv"].copy_(self.model.variables[bn + "/moving_variance"])
+            self._fold_frozen()
+            self.load_optimizer_slots(slots)
+            it = self.model.loaded_extras.get("SGD/iter")
+            self.step_count = int(it) if it is not None else 0
+            if self.model.optimizer is not None:
+                self.model.optimizer.iterations = self.step_count
+
     def store_to_model(self, use_ema=False):
         """flat arenas -> model.variables (executor.assign_moving_averaged_weights when use_ema)."""
         v = self.model.variables
         src = self.E if use_ema else self.P
         for k in self.train_names:
-            t = self._pview(k, src)
-            kind = self.var_kind.get(k, ("other", None))[0]
-            if kind in ("conv", "se1", "se2"):
-                kh, kw, ci, co = v[k].shape
-                t = _ohwi_to_hwio(t.reshape(co, kh, kw, ci))
-            v[k].copy_(t.reshape(v[k].shape))
+            v[k].copy_(self._keras_layout(k, src))
         for bn, d in self.bn_state.items():
             v[bn + "/moving_mean"].copy_(d["mm"])
             v[bn + "/moving_variance"].copy_(d["mv"])
@@ -348,6 +393,7 @@ class TrainEngine:
         """inference-mode scale/shift + packed weights for frozen conv(+BN) layers."""
         lib, v = self.lib, self.model.variables
         st = _C.current_stream()
+        old_fold, old_packed = getattr(self, "fold", None), getattr(self, "packed_frozen", None)
         self.fold, self.packed_frozen = {}, {}
         for op in self.ops:
             if op["op"] not in ("conv", "stem") or self._conv_trainable(op):
@@ -380,6 +426,15 @@ class TrainEngine:
             elif bias is not None:
                 shift = bias.to(self.dev).float().contiguous()
             self.fold[op["out"]] = (scale, shift)
+        if old_fold is not None:
+            # a refold after a restore: the launch descriptors hold the first buffers' addresses -> copy in place
+            for k, buf in self.packed_frozen.items():
+                old_packed[k].copy_(buf)
+            for k, (scale, shift) in self.fold.items():
+                for dst, src in zip(old_fold[k], (scale, shift)):
+                    if dst is not None:
+                        dst.copy_(src)
+            self.fold, self.packed_frozen = old_fold, old_packed
 
     # ---- helpers to build launches ---------------------------------------------------------------------
     def _conv_meta(self, p):
