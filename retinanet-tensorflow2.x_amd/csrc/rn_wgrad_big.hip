@@ -16,6 +16,12 @@
 //     out-of-range buffer offset (hardware zero fill).
 // One workgroup = one (co tile, ci tile, tap, pixel chunk); partial tiles go to the same workspace layout as
 // rn_wgrad.hip and are summed by its deterministic reduce kernel.
+#include <algorithm>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
 #include "rn_wgrad_dev.h"
 
 namespace {
@@ -252,7 +258,8 @@ __global__ void __launch_bounds__(512) wgrad_big_kernel(const WgArgs args) {
 }  // namespace
 
 static long long g_big_target_blocks = 256;   // one round of the 256 CUs: fewest split-K partials
-extern "C" void rn_debug_wgrad_big_target_blocks(int n) { g_big_target_blocks = n; }
+static bool g_big_target_user = false;          // set by the debug override: no candidate search
+extern "C" void rn_debug_wgrad_big_target_blocks(int n) { g_big_target_blocks = n; g_big_target_user = true; }
 static long long g_big_min_pixels = 16384;
 extern "C" void rn_debug_wgrad_big_min_pixels(int n) { g_big_min_pixels = n; }   // tests: force the big kernel
 
@@ -268,21 +275,74 @@ bool rn_wgrad_big_plan(const rn_wgrad_problem* p, WgArgs& a) {
   a.ci_tiles = ci_tiles;
   a.co_groups = 1;
   a.gco = co_tiles;
-  // one workgroup per CU (128 KB of LDS): aim for one full round of the 256 CUs.  Segments
-  // (pyramid levels) are chunked separately, so the rounding is settled by growing the chunk.
-  long long target = g_big_target_blocks / tiles;
-  if (target < 1) target = 1;
-  long long CH = rn_cdiv(rn_cdiv(Ptot, target), BK) * BK;
-  if (CH < 4 * BK) CH = 4 * BK;
-  int chunks = 0;
-  for (int it = 0; it < 16; ++it) {
-    chunks = 0;
-    for (int i = 0; i < p->num_segments; ++i) chunks += (int)rn_cdiv(a.seg[i].P, CH);
-    if ((long long)chunks * tiles <= g_big_target_blocks || chunks <= 1) break;
-    CH += BK * rn_cdiv(CH / BK, 16);    // +6 % per iteration
+  // One workgroup per CU (128 KB of LDS).  Candidates: chunk lengths that give about 1, 1.5, 2 and 3 rounds of
+  // the 256 CUs; segments (pyramid levels) are chunked separately, so each candidate grows its chunk until the
+  // workgroup count fits.  The kernel hands XCD x a contiguous range of (chunk, tile) ids, and a launch whose
+  // tile count does not divide the 32 CUs of an XCD (27 tiles for 256 -> 720) leaves one round badly filled:
+  // the candidates are priced with a greedy simulation of that mapping (per-workgroup cost = K steps + a
+  // fixed prologue / epilogue / partial-tile cost) and the cheapest wins.  Plans are cached per shape.
+  long long CH = 0;
+  {
+    static std::mutex mu;
+    static std::unordered_map<std::string, long long> cache;
+    std::string key((const char*)&g_big_target_blocks, sizeof(g_big_target_blocks));
+    key.push_back(g_big_target_user ? 1 : 0);
+    const int dims[4] = {a.R * 16 + a.S, a.Cin, a.Cout, p->num_segments};
+    key.append((const char*)dims, sizeof(dims));
+    for (int i = 0; i < p->num_segments; ++i) key.append((const char*)&a.seg[i].P, sizeof(a.seg[i].P));
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) {
+      CH = it->second;
+    } else {
+      const int mult_x2[4] = {2, 3, 4, 6};
+      const int ncand = g_big_target_user ? 1 : 4;
+      double best = 0;
+      for (int c = 0; c < ncand; ++c) {
+        const long long blocks = (long long)g_big_target_blocks * mult_x2[c] / 2;
+        long long target = blocks / tiles;
+        if (target < 1) target = 1;
+        long long ch = rn_cdiv(rn_cdiv(Ptot, target), BK) * BK;
+        if (ch < 4 * BK) ch = 4 * BK;
+        int chunks = 0;
+        for (int it2 = 0; it2 < 16; ++it2) {
+          chunks = 0;
+          for (int i = 0; i < p->num_segments; ++i) chunks += (int)rn_cdiv(a.seg[i].P, ch);
+          if ((long long)chunks * tiles <= blocks || chunks <= 1) break;
+          ch += BK * rn_cdiv(ch / BK, 16);    // +6 % per iteration
+        }
+        // greedy schedule of the kernel's XCD mapping: workgroup `logical` = chunk * tiles + tile
+        const long long total = (long long)chunks * tiles;
+        std::vector<int> steps;   // K steps of every chunk
+        for (int i = 0; i < p->num_segments; ++i)
+          for (long long b = 0; b < a.seg[i].P; b += ch)
+            steps.push_back((int)rn_cdiv(std::min<long long>(ch, a.seg[i].P - b), BK));
+        const double fixed = 30.0;   // prologue + epilogue + partial tile write, in K steps
+        double makespan = 0;
+        const long long q = total >> 3, rr = total & 7;
+        long long begin = 0;
+        for (int x = 0; x < 8; ++x) {
+          const long long n = q + (x < rr ? 1 : 0);
+          double cu[32];
+          for (int k = 0; k < 32; ++k) cu[k] = 0;
+          for (long long l = begin; l < begin + n; ++l) {
+            int k0 = 0;
+            for (int k = 1; k < 32; ++k) if (cu[k] < cu[k0]) k0 = k;
+            cu[k0] += steps[(size_t)(l / tiles)] + fixed;
+          }
+          for (int k = 0; k < 32; ++k) makespan = std::max(makespan, cu[k]);
+          begin += n;
+        }
+        if (c == 0 || makespan < best * 0.97) {   // more workgroups only for a clear gain
+          best = makespan;
+          CH = ch;
+        }
+      }
+      cache.emplace(key, CH);
+    }
   }
   a.CH = (int)CH;
-  chunks = 0;
+  int chunks = 0;
   for (int i = 0; i < p->num_segments; ++i) {
     WgSegDev& d = a.seg[i];
     d.chunk_begin = chunks;
