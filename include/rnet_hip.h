@@ -190,6 +190,10 @@ int rn_conv_cout_pad(int Cout);
 /* M-tile height the dispatcher picks for this problem: 256 = conv_big_kernel (256x256x32, rn_conv_big.hip),
  * 128 = conv_fwd_kernel<128,...>; 0 on a malformed problem.  For profilers (bench.py roofline). */
 int rn_conv_tile_rows(const rn_conv_problem* problem);
+/* Which kernel rn_conv2d_nhwc_fwd runs for `problem`: 0 = 128-row tiles (conv_fwd_kernel), 1 = conv_big_kernel
+ * (256 x 256 x 32, persistent), 2 = conv_halo_kernel (256 x 256 x 32 for 3x3 / stride 1 / pad 1: pixels staged
+ * once per channel chunk as a halo patch).  Profiling / bench bookkeeping only. */
+int rn_conv_kernel_id(const rn_conv_problem* problem);
 /* channel count of the packed weights: Cin rounded up to the kernel's K step (zero columns) */
 int rn_conv_cin_pad(int Cin);
 int rn_pack_conv_weight(const float* w_hwio, int R, int S, int Cin, int Cout, int Cin_pad, void* w_packed,

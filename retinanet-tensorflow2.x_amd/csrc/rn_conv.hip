@@ -28,6 +28,10 @@
 //   * blockIdx -> tile map is XCD aware: consecutive tiles (same A rows, neighbouring n tiles)
 //     land on the same XCD's L2 (blocks are dispatched round-robin over the 8 XCDs).
 // Roofline: MFMA-bound for K >= ~512; the small-K 1x1 convs of ResNet stage 1-2 are HBM-bound.
+#include <map>
+#include <mutex>
+#include <tuple>
+
 #include "rn_conv_dev.h"
 
 // ABL: ablation mask for tools/bench_conv.py (0 in production): 1 = B tile loaded once,
@@ -331,6 +335,39 @@ static bool conv_use_big(const rn_conv_problem* p) {
   return g_conv_force_big || tiles256 >= g_conv_big_min_tiles;
 }
 
+// 3x3 / stride 1 / pad 1 launches of the 256-row class go to the halo kernel (rn_conv_halo.hip) when every
+// segment's worst tile fits its patch buffer.
+static int g_conv_halo = 1;
+extern "C" void rn_debug_conv_halo(int on) { g_conv_halo = on; }   // tools/, tests: A/B against conv_big_kernel
+
+static bool conv_use_halo(const rn_conv_problem* p) {
+  if (!g_conv_halo || !conv_use_big(p)) return false;
+  if (p->R != 3 || p->S != 3 || p->stride_h != 1 || p->stride_w != 1 || p->pad_top != 1 || p->pad_left != 1)
+    return false;
+  static std::mutex mu;
+  static std::map<std::tuple<int, int, int>, int> patch_px;   // (N, H, W) -> worst patch, computed once
+  for (int i = 0; i < p->num_segments; ++i) {
+    const rn_conv_segment& s = p->seg[i];
+    if (s.Ho != s.H || s.Wo != s.W || s.Cin % 32 != 0) return false;
+    int px;
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      auto key = std::make_tuple(s.N, s.H, s.W);
+      auto it = patch_px.find(key);
+      if (it == patch_px.end()) it = patch_px.emplace(key, rn_conv_halo_patch_pixels(s.N, s.H, s.W)).first;
+      px = it->second;
+    }
+    if (px > rn_conv_halo_capacity()) return false;
+  }
+  return true;
+}
+
+/* 0: 128-row kernel, 1: conv_big_kernel, 2: conv_halo_kernel */
+extern "C" int rn_conv_kernel_id(const rn_conv_problem* p) {
+  if (!p || p->num_segments < 1 || p->num_segments > RN_CONV_MAX_SEGMENTS) return -1;
+  return conv_use_halo(p) ? 2 : (conv_use_big(p) ? 1 : 0);
+}
+
 extern "C" int rn_conv_tile_rows(const rn_conv_problem* p) {
   if (!p || p->num_segments < 1 || p->num_segments > RN_CONV_MAX_SEGMENTS) return 0;
   return conv_use_big(p) ? 256 : 128;
@@ -405,7 +442,7 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
       default: break;
     }
   }
-  if (big) return rn_launch_conv_big(a, f32, st);
+  if (big) return conv_use_halo(p) ? rn_launch_conv_halo(a, f32, st) : rn_launch_conv_big(a, f32, st);
   if (BN == 128 && BK == 64) return f32 ? launch_conv<128, 128, 64, true>(a, st) : launch_conv<128, 128, 64, false>(a, st);
   if (BN == 64 && BK == 64) return f32 ? launch_conv<128, 64, 64, true>(a, st) : launch_conv<128, 64, 64, false>(a, st);
   if (BN == 128 && BK == 32) return f32 ? launch_conv<128, 128, 32, true>(a, st) : launch_conv<128, 128, 32, false>(a, st);

@@ -1,0 +1,178 @@
+// rn_conv_big_epi.h — per-wave epilogue shared by the 256 x 256 kernels (rn_conv_big.hip, rn_conv_halo.hip).
+// Wave (wave_m, wave_n) of the 2 x 4 grid owns 128 pixels x 64 channels as 4 x 2 MFMA 32x32 accumulators:
+//   acc[i][j][r]: pixel m = m0 + wave_m*128 + i*32 + (lane&31),
+//                 channel n = n0 + wave_n*64 + j*32 + 8*(r>>2) + 4*(lane>>5) + (r&3)
+// (weights = MFMA A, pixels = MFMA B, so a lane's registers are 4 consecutive channels of ONE pixel).
+// bf16 output: raw accumulators rounded to bf16 (the reference's Conv2D output under the mixed policy is a bf16
+// tensor), transposed through a 32 x 64 LDS patch (8-byte writes), read back 16 bytes = 8 channels per lane, then
+// scale/shift (folded BN + bias), residual add, activation in fp32, full 128-byte row stores; optional fused
+// BatchNorm forward statistics of the stored values.  f32 output: 32 x 32 f32 patches per j.  `patch` is this
+// wave's 4 KB of LDS; no workgroup barrier.  Clears acc.
+#ifndef RN_CONV_BIG_EPI_H_
+#define RN_CONV_BIG_EPI_H_
+#include "rn_conv_dev.h"
+
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+  f32x2_t v = {lo, hi};
+  bf16x2_t b = __builtin_convertvector(v, bf16x2_t);  // v_cvt_pk_bf16_f32: RNE, like rn_f32_to_bf16
+  return __builtin_bit_cast(uint32_t, b);
+}
+__device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+
+// XCD-aware tile numbering: virtual id v (dispatched round-robin over the 8 XCDs) -> tile, so that
+// consecutive tiles (same pixels, neighbouring channel tiles) stay on one XCD's L2
+__device__ __forceinline__ int tile_of(int v, int total) {
+  const int xcd = v & 7, slot = v >> 3;
+  const int q = total >> 3, r = total & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
+template <bool OUT_F32>
+__device__ __forceinline__ void big_epilogue(f32x16_t (&acc)[4][2], const ConvArgs& args, int c_si, int c_m0,
+                                             int c_n0, int wave, char* patch) {
+  const int wave_m = wave >> 2, wave_n = wave & 3;
+  const ConvSegDev& sg = args.seg[c_si];
+  const int Cout = sg.Cout, M = sg.M;
+  const int nw0 = c_n0 + wave_n * 64;
+  const int mw0 = c_m0 + wave_m * 128;
+  // a fresh lane id, so that nothing the epilogue needs stays live across the main loop
+  const int elane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const int fr = elane & 31, fh = elane >> 5;
+  const int rrow = elane >> 3, ru = elane & 7;   // read-back: 8 lanes per pixel row, 8 rows per pass
+  if (!OUT_F32) {
+    // bf16 patch: 32 pixels x 64 channels (128 B rows, 16-byte units swizzled by the pixel row)
+    const int nr = nw0 + ru * 8;                 // this lane's 8 channels on the read-back side
+    const bool nok = nr < Cout;
+    float sc[8], sf[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { sc[q] = 1.0f; sf[q] = 0.0f; }
+    if (nok && sg.scale) {
+      const float4 a = *(const float4*)(sg.scale + nr), b = *(const float4*)(sg.scale + nr + 4);
+      sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w; sc[4] = b.x; sc[5] = b.y; sc[6] = b.z; sc[7] = b.w;
+    }
+    if (nok && sg.shift) {
+      const float4 a = *(const float4*)(sg.shift + nr), b = *(const float4*)(sg.shift + nr + 4);
+      sf[0] = a.x; sf[1] = a.y; sf[2] = a.z; sf[3] = a.w; sf[4] = b.x; sf[5] = b.y; sf[6] = b.z; sf[7] = b.w;
+    }
+    const bool has_res = sg.residual != nullptr;
+    // fused BatchNorm forward statistics (training, raw conv output): per-lane sums of the stored values
+    const bool stats = sg.bn_partial != nullptr;
+    float st0[8], st1[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) st0[q] = st1[q] = 0.0f;
+    uint4 rv[2][4];
+#define BIG_RES_PREFETCH(buf_, i_)                                                                    \
+_Pragma("unroll") for (int pass = 0; pass < 4; ++pass) {                                            \
+  const int m = mw0 + (i_) * 32 + pass * 8 + rrow;                                                  \
+  rv[buf_][pass] = make_uint4(0u, 0u, 0u, 0u);                                                      \
+  if (has_res && nok && m < M) rv[buf_][pass] = *(const uint4*)(sg.residual + (long long)m * Cout + nr); \
+}
+    BIG_RES_PREFETCH(0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i + 1 < 4) BIG_RES_PREFETCH((i + 1) & 1, i + 1);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int nl = j * 32 + g * 8 + fh * 4;   // channel inside the wave's 64
+          uint2 pk;
+          pk.x = pack2(acc[i][j][g * 4 + 0], acc[i][j][g * 4 + 1]);
+          pk.y = pack2(acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
+          *(uint2*)(patch + fr * 128 + (((nl >> 3) ^ (fr & 7)) << 4) + (nl & 4) * 2) = pk;
+        }
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int row = pass * 8 + rrow;
+        const uint4 v = *(const uint4*)(patch + row * 128 + ((ru ^ (row & 7)) << 4));
+        const int m = mw0 + i * 32 + row;
+        if (m < M && nok) {
+          const uint4 r4 = rv[i & 1][pass];
+          float f[8] = {bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y), bf_lo(v.z), bf_hi(v.z), bf_lo(v.w), bf_hi(v.w)};
+          const float rr[8] = {bf_lo(r4.x), bf_hi(r4.x), bf_lo(r4.y), bf_hi(r4.y),
+                               bf_lo(r4.z), bf_hi(r4.z), bf_lo(r4.w), bf_hi(r4.w)};
+#pragma unroll
+          for (int q = 0; q < 8; ++q) f[q] = rn_apply_act(f[q] * sc[q] + sf[q] + rr[q], args.act);
+          uint4 ov;
+          ov.x = pack2(f[0], f[1]); ov.y = pack2(f[2], f[3]); ov.z = pack2(f[4], f[5]); ov.w = pack2(f[6], f[7]);
+          *(uint4*)((uint16_t*)sg.y + (long long)m * Cout + nr) = ov;
+          if (stats) {
+            const float w[8] = {bf_lo(ov.x), bf_hi(ov.x), bf_lo(ov.y), bf_hi(ov.y),
+                                bf_lo(ov.z), bf_hi(ov.z), bf_lo(ov.w), bf_hi(ov.w)};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { st0[q] += w[q]; st1[q] += w[q] * w[q]; }
+          }
+        }
+      }
+    }
+    if (stats) {
+      // sum over the 8 row lanes that share this lane's channels (lane bits 3..5), then lanes 0-7 write the
+      // wave's 128-pixel row block: chunk = m_tile * 2 + wave_m, layout [chunk][2][Cout]
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) {
+          st0[q] += __shfl_xor(st0[q], o, 64);
+          st1[q] += __shfl_xor(st1[q], o, 64);
+        }
+      }
+      if (rrow == 0 && nok) {
+        float* dst = sg.bn_partial + ((long long)(c_m0 / 256) * 2 + wave_m) * 2 * Cout + nr;
+        *(float4*)(dst) = make_float4(st0[0], st0[1], st0[2], st0[3]);
+        *(float4*)(dst + 4) = make_float4(st0[4], st0[5], st0[6], st0[7]);
+        *(float4*)(dst + Cout) = make_float4(st1[0], st1[1], st1[2], st1[3]);
+        *(float4*)(dst + Cout + 4) = make_float4(st1[4], st1[5], st1[6], st1[7]);
+      }
+    }
+#undef BIG_RES_PREFETCH
+  } else {
+    // f32 output (prediction convs): f32 patch of 32 pixels x 32 channels per j (128 B rows)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int nr = nw0 + j * 32 + ru * 4;      // this lane's 4 channels on the read-back side
+      const bool nok = nr < Cout;
+      float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sf = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (nok && sg.scale) sc = *(const float4*)(sg.scale + nr);
+      if (nok && sg.shift) sf = *(const float4*)(sg.shift + nr);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float4 v;
+          v.x = acc[i][j][g * 4 + 0]; v.y = acc[i][j][g * 4 + 1]; v.z = acc[i][j][g * 4 + 2]; v.w = acc[i][j][g * 4 + 3];
+          *(float4*)(patch + fr * 128 + (((g * 2 + fh) ^ (fr & 7)) << 4)) = v;
+        }
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+          const int row = pass * 8 + rrow;
+          float4 v = *(const float4*)(patch + row * 128 + ((ru ^ (row & 7)) << 4));
+          const int m = mw0 + i * 32 + row;
+          if (m < M && nok) {
+            const long long o = (long long)m * Cout + nr;
+            v.x = v.x * sc.x + sf.x; v.y = v.y * sc.y + sf.y; v.z = v.z * sc.z + sf.z; v.w = v.w * sc.w + sf.w;
+            if (sg.residual) {
+              const uint2 r2 = *(const uint2*)(sg.residual + o);
+              v.x += bf_lo(r2.x); v.y += bf_hi(r2.x); v.z += bf_lo(r2.y); v.w += bf_hi(r2.y);
+            }
+            v.x = rn_apply_act(v.x, args.act);
+            v.y = rn_apply_act(v.y, args.act);
+            v.z = rn_apply_act(v.z, args.act);
+            v.w = rn_apply_act(v.w, args.act);
+            *(float4*)((float*)sg.y + o) = v;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+}
+#endif  // RN_CONV_BIG_EPI_H_

@@ -50,4 +50,8 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wav
 
 // rn_conv_big.hip
 int rn_launch_conv_big(const ConvArgs& a, bool out_f32, hipStream_t st);
+// rn_conv_halo.hip (3x3 / stride 1 / pad 1)
+int rn_launch_conv_halo(const ConvArgs& a, bool out_f32, hipStream_t st);
+int rn_conv_halo_patch_pixels(int N, int H, int W);
+int rn_conv_halo_capacity();
 #endif  // RN_CONV_DEV_H_

@@ -1,0 +1,395 @@
+// rn_conv_halo.hip — persistent 256 x 256 x 32 kernel for 3x3 / stride 1 / pad 1 convolutions with
+// Cout >= 256 (head towers, class prediction, FPN output convs, ResNet stage 3/4 3x3, and their data gradients).
+//
+// conv_big_kernel (rn_conv_big.hip) stages 16 KB of pixels + 16 KB of weights per K step, and for a 3x3 filter
+// eight of the nine pixel tiles of a channel chunk are the ninth one shifted by a pixel: the LDS-DMA path
+// (~45 B/clk/CU, ~100 issue cycles per 1 KB instruction) carries the same bytes nine times and bounds the
+// kernel at ~1000 TFLOP/s.  Here the K loop runs chunk-major (32 input channels, then the 9 taps) and the pixels
+// of a chunk are staged ONCE, as the halo patch the tile's 256 output pixels need:
+//
+//   * patch = the input rows from one above the tile's first pixel row to one below its last, with ONE zero
+//     column between consecutive rows and ONE zero row between consecutive images (and above the first / below
+//     the last): "padded global row" G = n*(H+1) + iy + 1, row stride W+1, patch order
+//     p = (G - G0)*(W+1) + ix + 1, 64 B per pixel.  Output pixel m, tap (r,s) reads patch pixel
+//     base(m) + r*(W+1) + s: the pixel right of a row's last one IS the zero pixel left of the next row, the
+//     row below an image's last one IS the zero row above the next image; borders are ordinary zero pixels
+//     (written by the DMA's out-of-range zero fill), there are no per-tap masks, a tap is a uniform offset.
+//     Capacity 640 pixels = 40 KB (a 256-pixel tile of an 80 x 80 level that straddles two images needs
+//     7 rows x 81 + 1 = 568), two patches (the next chunk's lands while this one is used) + a four-stage ring
+//     of 16 KB weight tiles + a 10 KB table of per-thread source offsets = 154 KB.  Staged bytes per K step:
+//     16 KB + ~4 KB instead of 32 KB.
+//   * per wave and K step: 2 weight pieces, and in steps 1..5 of a chunk one piece of the next chunk's patch
+//     (5 x 8 waves x 1 KB = 40 KB), against 4 pieces before.  The nine taps are unrolled, so the counted
+//     `s_waitcnt vmcnt` of each load segment is a constant (everything but the last two segments' pieces).
+//   * same two-group ping-pong, barriers, XCD-aware persistent tile walk and per-wave epilogue as
+//     conv_big_kernel; the epilogue's 32 KB of transpose patches alias the pixel patch of the tile's last chunk,
+//     which is dead by then (the next DMA into it is issued two barriers later).
+#include "rn_conv_big_epi.h"
+
+// HALO_ABLATE (probe builds only, tools/probes/build_halo_ablate.sh): 1 = no counted vmcnt wait, 2 = no DMA issue,
+// 4 = no fragment reads, 8 = no MFMAs — wrong results, timing only
+#ifndef HALO_ABLATE
+#define HALO_ABLATE 0
+#endif
+
+#ifdef HALO_PROF   // probe builds: core clock (clock64) and 100 MHz wall clock at the start / end of workgroup 0
+__device__ unsigned long long g_halo_clk[4];
+extern "C" int rn_debug_halo_clocks(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_halo_clk), sizeof(g_halo_clk)) == hipSuccess ? 0 : -3;
+}
+#endif
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 32, NW = 8;
+constexpr int PIX_PX = 640, PIX_BYTES = PIX_PX * 64;     // one halo patch (40 KB)
+constexpr int PIECES = PIX_PX / 16 / NW;                 // 5 patch DMA pieces per wave per chunk
+constexpr int W_STAGE = BN * BK * 2;                     // 16 KB of weights per K step
+constexpr int W_RING = 2 * PIX_BYTES;
+constexpr int PA_TABLE = W_RING + 4 * W_STAGE;           // per-thread source offsets of the patch pieces
+constexpr int LDS_BYTES = PA_TABLE + PIECES * 512 * 4;   // 80 + 64 + 10 = 154 KB
+
+template <bool OUT_F32>
+__global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int total = args.total_tiles;
+  const int G = gridDim.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_m = wave >> 2, wave_n = wave & 3;   // wave_m is also the ping-pong group
+
+  // ---- issue side, pixels: the chunk whose patch is being DMA'd (one chunk ahead of the weights' chunk) ----
+  int p_v = blockIdx.x;        // virtual tile id; exhausted when >= total
+  int p_chunk = 0, p_nch = 0;  // chunk of that tile / its chunk count
+  int p_par = 0;               // patch buffer it goes to
+  __amdgpu_buffer_rsrc_t rs_x;
+  // byte offset of this lane's 16 bytes of piece j at chunk 0 (or RN_OOB): kept in LDS, one dword per (j, thread)
+  // The table address is rebuilt from a fresh lane id at every use (volatile: not hoisted), so that no
+  // per-thread address stays live across the epilogue — the allocator would spill it and reload it, with an
+  // `s_waitcnt vmcnt(0)`, in every load segment.
+#define HALO_LANE(dst_) asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(dst_))
+#define HALO_PA_AT(j_, ln_) (*(unsigned*)(smem + PA_TABLE + (j_) * 2048 + wave * 256 + (ln_) * 4))
+
+#define HALO_SETUP_PIX()                                                                              \
+  do {                                                                                                \
+    const int tile__ = tile_of(p_v, total);                                                           \
+    int si__ = 0;                                                                                     \
+    _Pragma("unroll 1") for (int i = 1; i < args.nseg; ++i)                                           \
+      if (tile__ >= args.seg[i].tile_begin) si__ = i;                                                 \
+    const ConvSegDev& sg__ = args.seg[si__];                                                          \
+    const int lt__ = tile__ - sg__.tile_begin;                                                        \
+    const int m0__ = (lt__ / sg__.n_tiles) * BM;                                                      \
+    const int H__ = sg__.H, W__ = sg__.W, PS__ = sg__.pix_stride, W1__ = W__ + 1, H1__ = H__ + 1;     \
+    const int HW__ = H__ * W__;                                                                       \
+    p_nch = sg__.CinP / BK;                                                                           \
+    rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)sg__.x, 0,                                        \
+                                             (int)((long long)sg__.N * HW__ * PS__ * 2), 0x00020000); \
+    const int ml__ = (m0__ + BM - 1 < sg__.M ? m0__ + BM - 1 : sg__.M - 1);                           \
+    const int nf__ = m0__ / HW__, nl__ = ml__ / HW__;                                                 \
+    const int Gf__ = nf__ * H1__ + (m0__ - nf__ * HW__) / W__ + 1;   /* padded row of the first pixel */ \
+    const int Gl__ = nl__ * H1__ + (ml__ - nl__ * HW__) / W__ + 1;                                    \
+    const int plast__ = (Gl__ - Gf__ + 3) * W1__;   /* last patch pixel: the zero right of the last row */ \
+    unsigned ln__;                                                                                    \
+    HALO_LANE(ln__);                                                                                  \
+    _Pragma("unroll") for (int j = 0; j < PIECES; ++j) {                                              \
+      const int p = (j * NW + wave) * 16 + (int)(ln__ >> 2);                                          \
+      const int chunk = (int)(ln__ & 3) ^ ((p >> 2) & 3);                                             \
+      const int prow = p / W1__, pcol = p - prow * W1__;                                              \
+      const int Gp = Gf__ - 1 + prow;                                                                 \
+      const int n = Gp / H1__;                                                                        \
+      const int iy = Gp - n * H1__ - 1, ix = pcol - 1;                                                \
+      const bool ok = (unsigned)iy < (unsigned)H__ && (unsigned)ix < (unsigned)W__ && p < plast__ &&  \
+                      n < sg__.N;                                                                     \
+      HALO_PA_AT(j, ln__) = ok ? (unsigned)(((((long long)n * H__ + iy) * W__ + ix) * PS__ + chunk * 8) * 2) : RN_OOB; \
+    }                                                                                                 \
+  } while (0)
+
+// one piece of the next chunk's patch (piece index compile time); after the last piece the stream advances
+#define HALO_ISSUE_PIX(j_, pa_)                                                                       \
+  do {                                                                                                \
+    const unsigned v__ = (pa_) == RN_OOB ? RN_OOB : (pa_) + (unsigned)(p_chunk * (BK * 2));           \
+    if (!(HALO_ABLATE & 2)) dma16(rs_x, smem + p_par * PIX_BYTES + ((j_) * NW + wave) * 1024, v__);   \
+    if ((j_) == PIECES - 1 && p_v < total) {                                                          \
+      p_par ^= 1;                                                                                     \
+      if (++p_chunk == p_nch) {                                                                       \
+        p_chunk = 0;                                                                                  \
+        p_v += G;                                                                                     \
+        if (p_v < total) {                                                                            \
+          HALO_SETUP_PIX();                                                                           \
+        } else {  /* end of the stream: the remaining pieces are zero fills into the dead buffer */   \
+          unsigned ln2__;                                                                             \
+          HALO_LANE(ln2__);                                                                           \
+          _Pragma("unroll") for (int q = 0; q < PIECES; ++q) HALO_PA_AT(q, ln2__) = RN_OOB;           \
+        }                                                                                             \
+      }                                                                                               \
+    }                                                                                                 \
+  } while (0)
+
+  // ---- issue side, weights: the tile / chunk / tap whose 16 KB are being DMA'd (3 steps ahead) -------------
+  int w_v = blockIdx.x;
+  int w_chunk = 0, w_nch = 0;
+  __amdgpu_buffer_rsrc_t rs_w;
+  unsigned b_off;              // piece 0 (rows wave*16 + lane/4 of the tile); piece 1 is 128 rows further
+  unsigned w_step1 = 0;        // byte distance of piece 1, or RN_OOB when those rows are past the packed weights
+  const int d_row = lane >> 2, d_pos = lane & 3;   // weight piece j fills rows (j*8 + wave)*16 + lane/4
+
+#define HALO_SETUP_W()                                                                                \
+  do {                                                                                                \
+    const int tile__ = tile_of(w_v, total);                                                           \
+    int si__ = 0;                                                                                     \
+    _Pragma("unroll 1") for (int i = 1; i < args.nseg; ++i)                                           \
+      if (tile__ >= args.seg[i].tile_begin) si__ = i;                                                 \
+    const ConvSegDev& sg__ = args.seg[si__];                                                          \
+    const int lt__ = tile__ - sg__.tile_begin;                                                        \
+    const int n0__ = (lt__ - (lt__ / sg__.n_tiles) * sg__.n_tiles) * BN;                              \
+    w_nch = sg__.CinP / BK;                                                                           \
+    const int Ktot__ = 9 * sg__.CinP;                                                                 \
+    const int rows__ = ((sg__.Cout + 127) / 128) * 128; /* packed weight rows */                      \
+    rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)sg__.w, 0, (int)((long long)rows__ * Ktot__ * 2), \
+                                             0x00020000);                                             \
+    {                                                                                                 \
+      const int row = wave * 16 + d_row;   /* piece 1: row + 128, same swizzle (128 % 16 == 0) */      \
+      const int chunk = d_pos ^ lds_swz<BK>(row);                                                     \
+      b_off = (unsigned)(((long long)(n0__ + row) * Ktot__ + chunk * 8) * 2);                         \
+      /* rows__ is a multiple of 128 and n0 < rows__: piece 0 is always inside, piece 1 as a whole or not */ \
+      w_step1 = n0__ + 128 < rows__ ? (unsigned)(128 * Ktot__ * 2) : RN_OOB;                          \
+    }                                                                                                 \
+  } while (0)
+
+// the two weight pieces of the next stream step, tap compile time
+#define HALO_ISSUE_W(tap_, ahead_)                                                                          \
+  do {                                                                                                \
+    const unsigned koff__ = (unsigned)(((tap_) * w_nch + w_chunk) * (BK * 2));                        \
+    char* st__ = smem + W_RING + ((g + (ahead_)) & 3) * W_STAGE;                                      \
+    if (!(HALO_ABLATE & 2)) {                                                                         \
+      dma16(rs_w, st__ + wave * 1024, b_off + koff__);                                                \
+      dma16(rs_w, st__ + (NW + wave) * 1024, w_step1 == RN_OOB ? RN_OOB : b_off + koff__ + w_step1);  \
+    }                                                                                                 \
+    if ((tap_) == 8) {                                                                                \
+      if (++w_chunk == w_nch) {                                                                       \
+        w_chunk = 0;                                                                                  \
+        w_v += G;                                                                                     \
+        if (w_v < total) HALO_SETUP_W();                                                              \
+      }                                                                                               \
+    }                                                                                                 \
+  } while (0)
+
+  // ---- compute side: the tile being accumulated ---------------------------------------------------------
+  int c_v = blockIdx.x;
+  int c_chunk = 0, c_nch = 0, c_par = 0;
+  int c_m0 = 0, c_n0 = 0, c_si = 0, c_W1 = 0;
+  int base[4];   // patch pixel of this lane's 4 fragment rows (output pixel at tap (0,0))
+  const int fr = lane & 31, fh = lane >> 5;
+
+#define HALO_SETUP_COMPUTE()                                                                          \
+  do {                                                                                                \
+    const int tile__ = tile_of(c_v, total);                                                           \
+    c_si = 0;                                                                                         \
+    _Pragma("unroll 1") for (int i = 1; i < args.nseg; ++i)                                           \
+      if (tile__ >= args.seg[i].tile_begin) c_si = i;                                                 \
+    const ConvSegDev& sg__ = args.seg[c_si];                                                          \
+    const int lt__ = tile__ - sg__.tile_begin;                                                        \
+    const int mt__ = lt__ / sg__.n_tiles;                                                             \
+    c_m0 = mt__ * BM;                                                                                 \
+    c_n0 = (lt__ - mt__ * sg__.n_tiles) * BN;                                                         \
+    c_nch = sg__.CinP / BK;                                                                           \
+    c_chunk = 0;                                                                                      \
+    const int H__ = sg__.H, W__ = sg__.W, H1__ = H__ + 1, HW__ = H__ * W__;                           \
+    c_W1 = W__ + 1;                                                                                   \
+    const int nf__ = c_m0 / HW__;                                                                     \
+    const int Gf__ = nf__ * H1__ + (c_m0 - nf__ * HW__) / W__ + 1;                                    \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
+      int m = c_m0 + wave_m * 128 + i * 32 + fr;                                                      \
+      m = m < sg__.M ? m : sg__.M - 1;                                                                \
+      const int n = m / HW__;                                                                         \
+      const int rem = m - n * HW__;                                                                   \
+      const int oy = rem / W__, ox = rem - oy * W__;                                                  \
+      base[i] = (n * H1__ + oy + 1 - Gf__) * c_W1 + ox;                                               \
+    }                                                                                                 \
+  } while (0)
+
+  // weights: row = lane&31 of a 32-row tile, 16-byte slot = 2*kk + (lane>>5), XOR-swizzled by (row/4)&3
+  const int off_w0 = (wave_n * 64 + fr) * 64 + ((fh ^ ((fr >> 2) & 3)) << 4);
+
+  f32x16_t acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  bf16x8_t px0[4], wt0[2], px1[4], wt1[2];   // fragments of one stream step: K slices 0..15 / 16..31
+  int g = 0;                                  // stream step whose fragments are in registers
+// fragments of stream step g, tap compile time: weights from ring stage g&3, pixels from the current patch
+#define HALO_READ(tap_)                                                                               \
+  do {                                                                                                \
+    const char* wb__ = smem + W_RING + (g & 3) * W_STAGE + off_w0;                                    \
+    const char* wb1__ = smem + W_RING + (g & 3) * W_STAGE + (off_w0 ^ 32);                            \
+    const char* pb__ = smem + c_par * PIX_BYTES;                                                      \
+    const int dt__ = ((tap_) / 3) * c_W1 + ((tap_) % 3);                                              \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) wt0[j] = *(const bf16x8_t*)(wb__ + j * 2048);       \
+    int po__[4];                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
+      const int p = base[i] + dt__;                                                                   \
+      po__[i] = p * 64 + ((fh ^ ((p >> 2) & 3)) << 4);                                                \
+      px0[i] = *(const bf16x8_t*)(pb__ + po__[i]);                                                    \
+    }                                                                                                 \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) wt1[j] = *(const bf16x8_t*)(wb1__ + j * 2048);      \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) px1[i] = *(const bf16x8_t*)(pb__ + (po__[i] ^ 32)); \
+  } while (0)
+// load segment for the step with tap `tap_`: fragment reads first (their LDS latency runs under the DMA issue),
+// then this wave's pieces — weights of the step 3 ahead and, in taps 1..6, one piece of the next chunk's patch —
+// then the counted wait: everything but the pieces of this and the previous segment
+#define HALO_LOADSEG(tap_)                                                                            \
+  do {                                                                                                \
+    unsigned pa__ = RN_OOB;                                                                           \
+    if ((tap_) >= 1 && (tap_) <= PIECES) {                                                            \
+      unsigned ln__;                                                                                  \
+      HALO_LANE(ln__);                                                                                \
+      pa__ = HALO_PA_AT((tap_) - 1, ln__);                                                            \
+    }                                                                                                 \
+    if (!(HALO_ABLATE & 4)) HALO_READ(tap_);                                                          \
+    if (w_v < total) {                                                                                \
+      HALO_ISSUE_W(((tap_) + 3) % 9, 3);                                                               \
+      if ((tap_) >= 1 && (tap_) <= PIECES) HALO_ISSUE_PIX((tap_) - 1, pa__);                          \
+      constexpr int now__ = ((tap_) >= 1 && (tap_) <= PIECES) ? 3 : 2;                                \
+      constexpr int prev__ = (((tap_) + 8) % 9 >= 1 && ((tap_) + 8) % 9 <= PIECES) ? 3 : 2;           \
+      if (HALO_ABLATE & 3) {                                                                          \
+      } else if (now__ + prev__ == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                \
+      else if (now__ + prev__ == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");                  \
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                           \
+    } else {                                                                                          \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
+    }                                                                                                 \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
+  } while (0)
+#define HALO_COMPUTESEG()                                                                             \
+  do {                                                                                                \
+    if (HALO_ABLATE & 8) break;                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                     \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                   \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt0[j], px0[i], acc[i][j], 0, 0, 0);      \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                     \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                   \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt1[j], px1[i], acc[i][j], 0, 0, 0);      \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+  } while (0)
+#define HALO_BARRIER()                      \
+  do {                                      \
+    __builtin_amdgcn_s_barrier();           \
+    asm volatile("" ::: "memory");          \
+  } while (0)
+
+#ifdef HALO_PROF
+  if (blockIdx.x == 0 && tid == 0) { g_halo_clk[0] = clock64(); g_halo_clk[1] = wall_clock64(); }
+#endif
+  // ---- prologue -------------------------------------------------------------------------------------------
+  HALO_SETUP_PIX();
+  HALO_SETUP_W();
+  HALO_SETUP_COMPUTE();
+  // patch of chunk 0 (5 pieces), then the weights of stream steps 0, 1, 2
+  {
+    unsigned pa0[PIECES];
+    unsigned ln0;
+    HALO_LANE(ln0);
+#pragma unroll
+    for (int j = 0; j < PIECES; ++j) pa0[j] = HALO_PA_AT(j, ln0);
+    HALO_ISSUE_PIX(0, pa0[0]); HALO_ISSUE_PIX(1, pa0[1]); HALO_ISSUE_PIX(2, pa0[2]); HALO_ISSUE_PIX(3, pa0[3]);
+    HALO_ISSUE_PIX(4, pa0[4]);
+  }
+  HALO_ISSUE_W(0, 0); HALO_ISSUE_W(1, 1); HALO_ISSUE_W(2, 2);
+  asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // the patch and steps 0, 1 have landed
+  HALO_BARRIER();
+  // pre-roll: both groups read step 0 and issue step 3; group 1 does so as its slot-0 load segment
+  HALO_LOADSEG(0);
+  if (wave_m == 1) HALO_BARRIER();
+
+  // ---- main loop: nine taps per pass, separate straight-line loops per group --------------------------------
+  // slot 2g: group 0 compute(g) | group 1 load(read g, issue g+3); slot 2g+1: group 0 load(read g+1, issue g+4)
+  // | group 1 compute(g).  A finished tile is written out in the odd slot by both groups (group 1 right after
+  // its MFMAs, group 0 before its load segment).
+#define HALO_CHUNK_END()                                                                  \
+  c_par ^= 1;                                                                             \
+  if (__builtin_expect(++c_chunk == c_nch, 0)) {                                          \
+    big_epilogue<OUT_F32>(acc, args, c_si, c_m0, c_n0, wave,                              \
+                          smem + (c_par ^ 1) * PIX_BYTES + wave * 4096 /* 32 KB of the dead 40 KB patch */);                  \
+    if (c_v + G >= total) break;                                                          \
+    c_v += G;                                                                             \
+    HALO_SETUP_COMPUTE();                                                                 \
+  }
+#define HALO_STEP0(next_tap_)                 \
+  HALO_COMPUTESEG();                          \
+  HALO_BARRIER();                             \
+  if ((next_tap_) == 0) { HALO_CHUNK_END() }  \
+  ++g;                                        \
+  HALO_LOADSEG(next_tap_);                    \
+  HALO_BARRIER();
+#define HALO_STEP1(next_tap_)                 \
+  HALO_COMPUTESEG();                          \
+  if ((next_tap_) == 0) { HALO_CHUNK_END() }  \
+  HALO_BARRIER();                             \
+  ++g;                                        \
+  HALO_LOADSEG(next_tap_);                    \
+  HALO_BARRIER();
+  if (wave_m == 0) {
+#pragma unroll 1
+    while (true) {
+      HALO_STEP0(1) HALO_STEP0(2) HALO_STEP0(3) HALO_STEP0(4) HALO_STEP0(5) HALO_STEP0(6) HALO_STEP0(7)
+      HALO_STEP0(8) HALO_STEP0(0)
+    }
+  } else {
+#pragma unroll 1
+    while (true) {
+      HALO_STEP1(1) HALO_STEP1(2) HALO_STEP1(3) HALO_STEP1(4) HALO_STEP1(5) HALO_STEP1(6) HALO_STEP1(7)
+      HALO_STEP1(8) HALO_STEP1(0)
+    }
+  }
+#ifdef HALO_PROF
+  if (blockIdx.x == 0 && tid == 0) { g_halo_clk[2] = clock64(); g_halo_clk[3] = wall_clock64(); }
+#endif
+}
+
+}  // namespace
+
+int rn_launch_conv_halo(const ConvArgs& a, bool out_f32, hipStream_t st) {
+  static bool attr_set = false;
+  static int num_cu = 256;
+  if (!attr_set) {
+    RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<false>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<true>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+        prop.multiProcessorCount > 0)
+      num_cu = prop.multiProcessorCount;
+    attr_set = true;
+  }
+  const int grid = a.total_tiles < num_cu ? a.total_tiles : num_cu;   // one persistent workgroup per CU
+  if (out_f32)
+    hipLaunchKernelGGL(conv_halo_kernel<true>, dim3(grid), dim3(512), LDS_BYTES, st, a);
+  else
+    hipLaunchKernelGGL(conv_halo_kernel<false>, dim3(grid), dim3(512), LDS_BYTES, st, a);
+  RN_CHECK_LAUNCH();
+  return RN_OK;
+}
+
+// patch pixels the worst tile of an [N, H, W] tensor needs (rows from one above its first pixel row to one below
+// its last in the shared-pad numbering, W + 1 apart, + the closing zero pixel); the caller compares it with the
+// kernel's capacity
+int rn_conv_halo_patch_pixels(int N, int H, int W) {
+  const long long M = (long long)N * H * W, HW = (long long)H * W;
+  long long worst = 0;
+  for (long long m0 = 0; m0 < M; m0 += BM) {
+    const long long ml = m0 + BM - 1 < M ? m0 + BM - 1 : M - 1;
+    const long long nf = m0 / HW, nl = ml / HW;
+    const long long Gf = nf * (H + 1) + (m0 - nf * HW) / W + 1, Gl = nl * (H + 1) + (ml - nl * HW) / W + 1;
+    worst = worst > Gl - Gf + 3 ? worst : Gl - Gf + 3;
+  }
+  return (int)(worst * (W + 1) + 1);
+}
+int rn_conv_halo_capacity() { return PIX_PX; }

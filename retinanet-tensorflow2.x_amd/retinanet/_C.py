@@ -113,6 +113,7 @@ _SIGNATURES = {
     "rn_conv2d_nhwc_fwd": (c_int, [POINTER(ConvProblem), c_void_p]),
     "rn_conv_cout_pad": (c_int, [c_int]),
     "rn_conv_tile_rows": (c_int, [POINTER(ConvProblem)]),
+    "rn_conv_kernel_id": (c_int, [POINTER(ConvProblem)]),
     "rn_conv_cin_pad": (c_int, [c_int]),
     "rn_depthwise_conv2d_nhwc_fwd": (c_int, [POINTER(DwProblem), c_void_p]),
     "rn_pack_depthwise_weight": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),

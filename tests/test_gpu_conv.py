@@ -135,6 +135,79 @@ def test_conv_big_tile_kernel(cuda, case):
         lib.rn_debug_conv_tile(0)
 
 
+HALO_CASES = [
+    # N, H, W, Cin, Cout, act, residual, out_f32   (3x3 / stride 1 / pad 1, through conv_halo_kernel)
+    (2, 24, 24, 256, 256, "relu", True, False),     # tiles 2 and 4 straddle the two images
+    (1, 80, 80, 64, 256, "relu", False, False),     # widest level: 4 rows + halo per tile, 2 channel chunks
+    (3, 5, 5, 256, 256, None, False, False),        # one tile over three tiny images (many pad rows)
+    (7, 10, 10, 128, 320, "relu6", False, False),   # Cout tail: second n-tile has 64 live channels
+    (1, 20, 20, 256, 720, None, False, True),       # class prediction conv, f32 out
+    (2, 13, 9, 96, 512, "swish", True, False),      # odd sizes, Cin = 3 chunks, M tail
+    (40, 3, 3, 32, 256, None, False, False),        # single chunk; 28 images per tile
+    (1, 40, 40, 512, 512, "relu", False, False),    # ResNet stage-3 shape, 16 chunks
+    (2, 1, 7, 64, 256, None, False, False),         # H = 1: every tap row but the middle one is padding
+    (2, 6, 1, 64, 256, None, False, False),         # W = 1
+]
+
+
+@pytest.mark.parametrize("case", HALO_CASES, ids=lambda c: "halo-" + "x".join(str(v) for v in c))
+def test_conv_halo_kernel(cuda, case):
+    """3x3 / stride 1 / pad 1 with Cout >= 256 through the halo-patch kernel (rn_conv_halo.hip), against the
+    float64 reference and against conv_big_kernel on the same inputs (same products, other summation order)."""
+    from retinanet import _C
+    lib = _C.lib()
+    N, H, W, Cin, Cout, act, use_res, out_f32 = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    s = {"x": torch.randn((N, H, W, Cin), generator=g),
+         "w": torch.randn((3, 3, Cin, Cout), generator=g) / math.sqrt(9 * Cin),
+         "scale": torch.rand((Cout,), generator=g) + 0.5, "shift": torch.randn((Cout,), generator=g) * 0.1}
+    if use_res:
+        s["residual"] = torch.randn((N, H, W, Cout), generator=g)
+    lib.rn_debug_conv_tile(2)
+    try:
+        p = _C.ConvProblem()
+        p.R = p.S = 3
+        p.stride_h = p.stride_w = p.pad_top = p.pad_left = 1
+        p.out_dtype, p.num_segments = (_C.RN_DT_F32 if out_f32 else _C.RN_DT_BF16), 1
+        sg = p.seg[0]
+        sg.N, sg.H, sg.W, sg.Cin, sg.pix_stride, sg.Ho, sg.Wo, sg.Cout = N, H, W, Cin, Cin, H, W, Cout
+        assert lib.rn_conv_kernel_id(ctypes.byref(p)) == 2
+        got = _conv_gpu(cuda, [s], 3, 1, 1, act, out_f32)[0]
+        lib.rn_debug_conv_halo(0)
+        assert lib.rn_conv_kernel_id(ctypes.byref(p)) == 1
+        big = _conv_gpu(cuda, [s], 3, 1, 1, act, out_f32)[0]
+    finally:
+        lib.rn_debug_conv_halo(1)
+        lib.rn_debug_conv_tile(0)
+    want = _conv_ref(s, 3, 1, 1, act, out_f32)
+    _close(got, want, out_f32)
+    scale = want.abs().max().item() + 1e-6
+    # bf16 outputs may differ by one rounding step where the fp32 sums straddle a rounding boundary
+    torch.testing.assert_close(got, big, rtol=1.0 / 128 if not out_f32 else 1e-4, atol=scale * (1 / 256 if not out_f32 else 1e-5))
+    if not out_f32:
+        assert (got != big).float().mean().item() < 0.02
+
+
+def test_conv_halo_asymmetric_weights(cuda):
+    """Exact shift test through the halo kernel: output channel c = input channel (c+1)%C read through tap
+    (r=0, s=2), i.e. pixel (y-1, x+1); borders must be exact zeros."""
+    from retinanet import _C
+    lib = _C.lib()
+    C = 256
+    x = (torch.arange(2 * 9 * 11 * C, dtype=torch.float32).reshape(2, 9, 11, C) * 7) % 61
+    w = torch.zeros((3, 3, C, C))
+    for c in range(C):
+        w[0, 2, (c + 1) % C, c] = 1.0
+    lib.rn_debug_conv_tile(2)
+    try:
+        got = _conv_gpu(cuda, [{"x": x, "w": w}], 3, 1, 1, None, True)[0]
+    finally:
+        lib.rn_debug_conv_tile(0)
+    want = torch.zeros_like(got)
+    want[:, 1:, :-1, :] = torch.roll(x, -1, dims=3)[:, :-1, 1:, :]
+    torch.testing.assert_close(got, want, rtol=0, atol=0)
+
+
 def test_conv_asymmetric_weights_detect_transposes(cuda):
     """A=I style check with an asymmetric filter: channel c of the output must be input channel
     (c+1)%C shifted by one pixel — catches row/col or r/s swaps that random data would blur."""

@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--ablate", type=int, default=0)
     ap.add_argument("--zeros", action="store_true", help="all-zero activations and weights (DVFS check: no toggling)")
+    ap.add_argument("--no-halo", action="store_true", help="3x3 launches on conv_big_kernel instead of conv_halo_kernel")
     ap.add_argument("--tile", type=int, default=0, help="1 = force 128-row kernel, 2 = force the 256x256 kernel")
     a = ap.parse_args()
     lib = _C.lib()
@@ -47,6 +48,8 @@ def main():
         lib.rn_debug_conv_big_ablate(a.ablate)
     if a.tile:
         lib.rn_debug_conv_tile(a.tile)
+    if a.no_halo:
+        lib.rn_debug_conv_halo(0)
     dev = torch.device("cuda:0")
     for name in a.preset.split(","):
         segs, k, stride, f32, use_res = PRESETS[name]
@@ -84,6 +87,11 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / a.iters
+        if hasattr(lib, "rn_debug_halo_clocks"):     # probe builds: core clock of workgroup 0 during the last launch
+            clk = (ctypes.c_ulonglong * 4)()
+            if lib.rn_debug_halo_clocks(clk) == 0 and clk[3] > clk[1]:
+                cyc, wall = clk[2] - clk[0], (clk[3] - clk[1]) / 100.0   # wall clock ticks at 100 MHz -> us
+                print(f"  workgroup 0: {cyc} core cycles in {wall:.1f} us -> {cyc / wall / 1e3:.3f} GHz")
         print(f"{name:12s} B={a.batch} {ms * 1e3:9.1f} us  {flops / ms / 1e9:8.1f} TFLOP/s  "
               f"{byts / ms / 1e6:8.1f} GB/s (algorithmic {byts / 1e6:.1f} MB)", flush=True)
 
