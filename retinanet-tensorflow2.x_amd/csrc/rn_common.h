@@ -43,13 +43,26 @@ __device__ __forceinline__ uint32_t rn_pack_bf16x2(float lo, float hi) {
   return (uint32_t)rn_f32_to_bf16(lo) | ((uint32_t)rn_f32_to_bf16(hi) << 16);
 }
 
-__device__ __forceinline__ float rn_apply_act(float v, int act) {
-  switch (act) {
-    case RN_ACT_RELU: return fmaxf(v, 0.0f);
-    case RN_ACT_RELU6: return fminf(fmaxf(v, 0.0f), 6.0f);
-    case RN_ACT_SWISH: return v / (1.0f + __expf(-v));
-    default: return v;
+// Activation of N values with a wave-uniform selector.  One branch per CALL (not per element: a `switch` inside an
+// unrolled element loop compiles to a chain of scalar compares and taken branches per element — measured 25 000
+// cycles per 256 x 256 tile epilogue against ~4 000 for the arithmetic): swish behind one uniform branch, identity
+// returns at once, relu / relu6 are max(v, 0) then min(v, 6 or +inf).
+template <int N>
+__device__ __forceinline__ void rn_apply_act_n(float (&f)[N], int act) {
+  if (act == RN_ACT_SWISH) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) f[q] = f[q] / (1.0f + __expf(-f[q]));
+    return;
   }
+  if (act == RN_ACT_NONE) return;
+  const float hi = act == RN_ACT_RELU6 ? 6.0f : __builtin_huge_valf();
+#pragma unroll
+  for (int q = 0; q < N; ++q) f[q] = fminf(fmaxf(f[q], 0.0f), hi);
+}
+__device__ __forceinline__ float rn_apply_act(float v, int act) {
+  float f[1] = {v};
+  rn_apply_act_n<1>(f, act);
+  return f[0];
 }
 
 // 64-wide wavefront reductions

@@ -267,10 +267,11 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_fwd_kernel(const ConvArg
         v.z += rn_bf16_to_f32((uint16_t)(rv.y & 0xffffu));
         v.w += rn_bf16_to_f32((uint16_t)(rv.y >> 16));
       }
-      v.x = rn_apply_act(v.x, args.act);
-      v.y = rn_apply_act(v.y, args.act);
-      v.z = rn_apply_act(v.z, args.act);
-      v.w = rn_apply_act(v.w, args.act);
+      {
+        float f4[4] = {v.x, v.y, v.z, v.w};
+        rn_apply_act_n<4>(f4, args.act);
+        v = make_float4(f4[0], f4[1], f4[2], f4[3]);
+      }
       if ((ABL & 8) && v.x != 123.456f) continue;   // ablation: no global stores
       if (OUT_F32) {
         *(float4*)((float*)sg.y + o) = v;
@@ -337,6 +338,8 @@ static bool conv_use_big(const rn_conv_problem* p) {
 
 // 3x3 / stride 1 / pad 1 launches of the 256-row class go to the halo kernel (rn_conv_halo.hip) when every
 // segment's worst tile fits its patch buffer.
+static int g_conv_stagger = 0;   // start stagger of the persistent 3x3 kernel, in units of 64 cycles per phase
+extern "C" void rn_debug_conv_stagger(int units) { g_conv_stagger = units; }
 static int g_conv_halo = 1;
 extern "C" void rn_debug_conv_halo(int on) { g_conv_halo = on; }   // tools/, tests: A/B against conv_big_kernel
 
@@ -349,6 +352,7 @@ static bool conv_use_halo(const rn_conv_problem* p) {
   for (int i = 0; i < p->num_segments; ++i) {
     const rn_conv_segment& s = p->seg[i];
     if (s.Ho != s.H || s.Wo != s.W || s.Cin % 32 != 0) return false;
+    if ((long long)s.N * s.H * s.W >= (1ll << 22)) return false;   // the kernel's float-reciprocal divisions
     int px;
     {
       std::lock_guard<std::mutex> lock(mu);
@@ -442,7 +446,16 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
       default: break;
     }
   }
-  if (big) return conv_use_halo(p) ? rn_launch_conv_halo(a, f32, st) : rn_launch_conv_big(a, f32, st);
+  if (big && conv_use_halo(p)) {
+    a.pad_ = g_conv_stagger;
+    return rn_launch_conv_halo(a, f32, st);
+  }
+  if (big) {
+    a.pad_ = 1;   // float-reciprocal index arithmetic in the tile set-up, valid while every M < 2^22
+    for (int i = 0; i < a.nseg; ++i)
+      if (a.seg[i].M >= (1 << 22)) a.pad_ = 0;
+    return rn_launch_conv_big(a, f32, st);
+  }
   if (BN == 128 && BK == 64) return f32 ? launch_conv<128, 128, 64, true>(a, st) : launch_conv<128, 128, 64, false>(a, st);
   if (BN == 64 && BK == 64) return f32 ? launch_conv<128, 64, 64, true>(a, st) : launch_conv<128, 64, 64, false>(a, st);
   if (BN == 128 && BK == 32) return f32 ? launch_conv<128, 128, 32, true>(a, st) : launch_conv<128, 128, 32, false>(a, st);

@@ -37,7 +37,7 @@ constexpr int A_BYTES = BM * BK * 2, STAGE_BYTES = (BM + BN) * BK * 2;
 constexpr int RING_BYTES = STAGES * STAGE_BYTES, PATCH_BYTES = 4096;
 constexpr int LDS_BYTES = RING_BYTES + NW * PATCH_BYTES;
 
-template <bool OUT_F32>
+template <bool OUT_F32, bool HAS_RES>
 __global__ void __launch_bounds__(512) conv_big_kernel(const ConvArgs args) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int total = args.total_tiles;
@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(512) conv_big_kernel(const ConvArgs args) {
       if (tile__ >= args.seg[i].tile_begin) si__ = i;                                                 \
     const ConvSegDev& sg__ = args.seg[si__];                                                          \
     const int lt__ = tile__ - sg__.tile_begin;                                                        \
-    const int mt__ = lt__ / sg__.n_tiles;                                                             \
+    const int mt__ = rn_fdiv(lt__, sg__.n_tiles, __frcp_rn((float)sg__.n_tiles)); /* < 2^22 tiles */  \
     const int m0__ = mt__ * BM, n0__ = (lt__ - mt__ * sg__.n_tiles) * BN;                             \
     i_W = sg__.W; i_PS = sg__.pix_stride; i_Cin = sg__.CinP;                                          \
     const int H__ = sg__.H, Ktot__ = RS * i_Cin;                                                      \
@@ -75,15 +75,24 @@ __global__ void __launch_bounds__(512) conv_big_kernel(const ConvArgs args) {
                                              (int)((long long)sg__.N * H__ * i_W * i_PS * 2), 0x00020000); \
     rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)sg__.w, 0, (int)((long long)rows__ * Ktot__ * 2), \
                                              0x00020000);                                             \
+    const float rWo__ = __frcp_rn((float)sg__.Wo), rHo__ = __frcp_rn((float)sg__.Ho);                 \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                   \
       const int row = (j * NW + wave) * 16 + d_row;                                                   \
       const int chunk = d_pos ^ lds_swz<BK>(row);                                                     \
       const int m = m0__ + row;                                                                       \
       const int mm = m < sg__.M ? m : 0;                                                              \
-      const int ox = mm % sg__.Wo;                                                                    \
-      const int t2 = mm / sg__.Wo;                                                                    \
-      const int oy = t2 % sg__.Ho;                                                                    \
-      const int n = t2 / sg__.Ho;                                                                     \
+      int ox, oy, n;                                                                                  \
+      if (args.pad_) {   /* every M < 2^22: float-reciprocal division (~8 VALU instead of ~45 each) */ \
+        const int t2 = rn_fdiv(mm, sg__.Wo, rWo__);                                                   \
+        ox = mm - t2 * sg__.Wo;                                                                       \
+        n = rn_fdiv(t2, sg__.Ho, rHo__);                                                              \
+        oy = t2 - n * sg__.Ho;                                                                        \
+      } else {                                                                                        \
+        ox = mm % sg__.Wo;                                                                            \
+        const int t2 = mm / sg__.Wo;                                                                  \
+        oy = t2 % sg__.Ho;                                                                            \
+        n = t2 / sg__.Ho;                                                                             \
+      }                                                                                               \
       const int iy0 = oy * args.sh - args.pt, ix0 = ox * args.sw - args.pl;                           \
       a_off[j] = (unsigned)(((((long long)n * H__ + iy0) * i_W + ix0) * i_PS + chunk * 8) * 2);       \
       unsigned mask = 0;                                                                              \
@@ -199,7 +208,7 @@ __global__ void __launch_bounds__(512) conv_big_kernel(const ConvArgs args) {
       if (tile__ >= args.seg[i].tile_begin) c_si = i;                                                 \
     const ConvSegDev& sg__ = args.seg[c_si];                                                          \
     const int lt__ = tile__ - sg__.tile_begin;                                                        \
-    const int mt__ = lt__ / sg__.n_tiles;                                                             \
+    const int mt__ = rn_fdiv(lt__, sg__.n_tiles, __frcp_rn((float)sg__.n_tiles)); /* < 2^22 tiles */  \
     c_m0 = mt__ * BM;                                                                                 \
     c_n0 = (lt__ - mt__ * sg__.n_tiles) * BN;                                                         \
     c_ksteps = RS * (sg__.CinP / BK);                                                                 \
@@ -208,7 +217,7 @@ __global__ void __launch_bounds__(512) conv_big_kernel(const ConvArgs args) {
 
   // ---- epilogue of the compute-side tile (per wave; acc is cleared afterwards) --------------------
   auto epilogue = [&]() __attribute__((always_inline)) {
-    big_epilogue<OUT_F32>(acc, args, c_si, c_m0, c_n0, wave, smem + RING_BYTES + wave * PATCH_BYTES);
+    big_epilogue<OUT_F32, HAS_RES>(acc, args, c_si, c_m0, c_n0, wave, smem + RING_BYTES + wave * PATCH_BYTES);
   };
 
   // ---- prologue ------------------------------------------------------------------------------------
@@ -278,9 +287,13 @@ int rn_launch_conv_big(const ConvArgs& a, bool out_f32, hipStream_t st) {
   static bool attr_set = false;
   static int num_cu = 256;
   if (!attr_set) {
-    RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_big_kernel<false>,
+    RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_big_kernel<false, false>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_big_kernel<true>,
+    RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_big_kernel<false, true>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_big_kernel<true, false>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_big_kernel<true, true>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     int dev = 0;
     hipDeviceProp_t prop;
@@ -290,10 +303,16 @@ int rn_launch_conv_big(const ConvArgs& a, bool out_f32, hipStream_t st) {
     attr_set = true;
   }
   const int grid = a.total_tiles < num_cu ? a.total_tiles : num_cu;   // one persistent workgroup per CU
-  if (out_f32)
-    hipLaunchKernelGGL(conv_big_kernel<true>, dim3(grid), dim3(512), LDS_BYTES, st, a);
-  else
-    hipLaunchKernelGGL(conv_big_kernel<false>, dim3(grid), dim3(512), LDS_BYTES, st, a);
+  bool has_res = false;   // one residual input anywhere -> the variant that carries the residual path
+  for (int i = 0; i < a.nseg; ++i) has_res = has_res || a.seg[i].residual != nullptr;
+  const dim3 g3(grid), b3(512);
+  if (out_f32) {
+    if (has_res) hipLaunchKernelGGL((conv_big_kernel<true, true>), g3, b3, LDS_BYTES, st, a);
+    else hipLaunchKernelGGL((conv_big_kernel<true, false>), g3, b3, LDS_BYTES, st, a);
+  } else {
+    if (has_res) hipLaunchKernelGGL((conv_big_kernel<false, true>), g3, b3, LDS_BYTES, st, a);
+    else hipLaunchKernelGGL((conv_big_kernel<false, false>), g3, b3, LDS_BYTES, st, a);
+  }
   RN_CHECK_LAUNCH();
   return RN_OK;
 }

@@ -12,6 +12,19 @@
 #define RN_CONV_BIG_EPI_H_
 #include "rn_conv_dev.h"
 
+#ifdef HALO_PROF   // probe builds (tools/probes/build_halo_ablate.sh): cycle stamps of workgroup 0, thread 0
+__device__ unsigned long long g_halo_clk[32];
+#define EPI_STAMP(k_) if (blockIdx.x == 0 && threadIdx.x == 0 && g_halo_clk[k_] == 0) g_halo_clk[k_] = clock64();
+#else
+#define EPI_STAMP(k_)
+#endif
+
+#ifdef HALO_ABLATE
+#define EPI_ABLATE HALO_ABLATE   // probe builds: 16 = (almost) no output stores
+#else
+#define EPI_ABLATE 0
+#endif
+
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
@@ -20,8 +33,25 @@ __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
   bf16x2_t b = __builtin_convertvector(v, bf16x2_t);  // v_cvt_pk_bf16_f32: RNE, like rn_f32_to_bf16
   return __builtin_bit_cast(uint32_t, b);
 }
+typedef short i16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2_t, a), __builtin_bit_cast(i16x2_t, b)));
+}
+__device__ __forceinline__ uint32_t pk_min_i16(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(i16x2_t, a), __builtin_bit_cast(i16x2_t, b)));
+}
 __device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+
+// a / b for 0 <= a < 2^22, b > 0, through the float reciprocal (rcp_b ~ 1 / b): the estimate is off by at most
+// one, fixed up with the exact remainder — ~8 VALU instructions against ~45 for the compiler's integer division.
+// The tile set-up code of the persistent kernels runs a few dozen of these per lane per tile, on all eight waves.
+__device__ __forceinline__ int rn_fdiv(int a, int b, float rcp_b) {
+  int q = (int)((float)a * rcp_b);
+  const int r = a - q * b;
+  q += (r >= b ? 1 : 0) - (r < 0 ? 1 : 0);
+  return q;
+}
 
 // XCD-aware tile numbering: virtual id v (dispatched round-robin over the 8 XCDs) -> tile, so that
 // consecutive tiles (same pixels, neighbouring channel tiles) stay on one XCD's L2
@@ -31,7 +61,11 @@ __device__ __forceinline__ int tile_of(int v, int total) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
 }
 
-template <bool OUT_F32>
+// HAS_RES = false compiles the residual input out: the prefetched residual rows are global loads, and the waits
+// the compiler puts in front of their uses also wait for the stores issued before them (loads and stores share
+// vmcnt and retire in order) — with the loads merely predicated off, every 32-pixel block of a tile would still
+// wait for the previous block's stores to reach L2 (measured: 25 000 cycles per tile epilogue instead of ~5 000).
+template <bool OUT_F32, bool HAS_RES>
 __device__ __forceinline__ void big_epilogue(f32x16_t (&acc)[4][2], const ConvArgs& args, int c_si, int c_m0,
                                              int c_n0, int wave, char* patch) {
   const int wave_m = wave >> 2, wave_n = wave & 3;
@@ -58,15 +92,28 @@ __device__ __forceinline__ void big_epilogue(f32x16_t (&acc)[4][2], const ConvAr
       const float4 a = *(const float4*)(sg.shift + nr), b = *(const float4*)(sg.shift + nr + 4);
       sf[0] = a.x; sf[1] = a.y; sf[2] = a.z; sf[3] = a.w; sf[4] = b.x; sf[5] = b.y; sf[6] = b.z; sf[7] = b.w;
     }
-    const bool has_res = sg.residual != nullptr;
+    // Take the scale / shift registers through an empty asm: the compiler has to wait for these (conditional)
+    // loads HERE.  Left to the first real use it re-waits inside every predicated store block further down, and a
+    // vmcnt wait there also waits for the stores issued before it (loads and stores retire in order): each
+    // 8-row pass then costs a full store round trip to L2 (measured ~3 000 cycles per 32-pixel block).
+#pragma unroll
+    for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(sc[q]), "+v"(sf[q]));
+    EPI_STAMP(12);
+    const bool has_res = HAS_RES && sg.residual != nullptr;
     // fused BatchNorm forward statistics (training, raw conv output): per-lane sums of the stored values
     const bool stats = sg.bn_partial != nullptr;
     float st0[8], st1[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) st0[q] = st1[q] = 0.0f;
-    uint4 rv[2][4];
+    // this lane's output address at (block 0, pass 0); blocks / passes are uniform multiples of a row further on
+    char* const ybase = (char*)sg.y + ((long long)(mw0 + rrow) * Cout + nr) * 2;
+    const long long row_bytes = (long long)Cout * 2;
+    const int act = args.act;
+    const bool clamp_lo = act == RN_ACT_RELU || act == RN_ACT_RELU6, clamp_hi = act == RN_ACT_RELU6;
+    const bool plain = !sg.scale && !sg.shift && !has_res && act == RN_ACT_NONE;
+    uint4 rv[2][HAS_RES ? 4 : 1];
 #define BIG_RES_PREFETCH(buf_, i_)                                                                    \
-_Pragma("unroll") for (int pass = 0; pass < 4; ++pass) {                                            \
+_Pragma("unroll") for (int pass = 0; pass < (HAS_RES ? 4 : 0); ++pass) {                            \
   const int m = mw0 + (i_) * 32 + pass * 8 + rrow;                                                  \
   rv[buf_][pass] = make_uint4(0u, 0u, 0u, 0u);                                                      \
   if (has_res && nok && m < M) rv[buf_][pass] = *(const uint4*)(sg.residual + (long long)m * Cout + nr); \
@@ -74,6 +121,7 @@ _Pragma("unroll") for (int pass = 0; pass < 4; ++pass) {                        
     BIG_RES_PREFETCH(0, 0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+      EPI_STAMP(13 + 2 * i);
       if (i + 1 < 4) BIG_RES_PREFETCH((i + 1) & 1, i + 1);
 #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -85,21 +133,49 @@ _Pragma("unroll") for (int pass = 0; pass < 4; ++pass) {                        
           pk.y = pack2(acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
           *(uint2*)(patch + fr * 128 + (((nl >> 3) ^ (fr & 7)) << 4) + (nl & 4) * 2) = pk;
         }
+      EPI_STAMP(14 + 2 * i);
+      // read the block's four 8-row passes back before touching any of them: one LDS round trip per block instead
+      // of four dependent ones (each pass used to wait for its own read, then for a scalar reload of the output
+      // pointer, before its store could issue: ~600 cycles per pass of pure latency, 16 passes per tile)
+      uint4 vb[4];
 #pragma unroll
       for (int pass = 0; pass < 4; ++pass) {
         const int row = pass * 8 + rrow;
-        const uint4 v = *(const uint4*)(patch + row * 128 + ((ru ^ (row & 7)) << 4));
+        vb[pass] = *(const uint4*)(patch + row * 128 + ((ru ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int row = pass * 8 + rrow;
+        const uint4 v = vb[pass];
         const int m = mw0 + i * 32 + row;
         if (m < M && nok) {
-          const uint4 r4 = rv[i & 1][pass];
-          float f[8] = {bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y), bf_lo(v.z), bf_hi(v.z), bf_lo(v.w), bf_hi(v.w)};
-          const float rr[8] = {bf_lo(r4.x), bf_hi(r4.x), bf_lo(r4.y), bf_hi(r4.y),
-                               bf_lo(r4.z), bf_hi(r4.z), bf_lo(r4.w), bf_hi(r4.w)};
-#pragma unroll
-          for (int q = 0; q < 8; ++q) f[q] = rn_apply_act(f[q] * sc[q] + sf[q] + rr[q], args.act);
           uint4 ov;
-          ov.x = pack2(f[0], f[1]); ov.y = pack2(f[2], f[3]); ov.z = pack2(f[4], f[5]); ov.w = pack2(f[6], f[7]);
-          *(uint4*)((uint16_t*)sg.y + (long long)m * Cout + nr) = ov;
+          if (plain) {
+            ov = v;   // raw conv output (training: BatchNorm follows): the transposed bf16 rows are the result
+          } else {
+            const uint4 r4 = HAS_RES ? rv[i & 1][HAS_RES ? pass : 0] : make_uint4(0u, 0u, 0u, 0u);
+            float f[8] = {bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y), bf_lo(v.z), bf_hi(v.z), bf_lo(v.w), bf_hi(v.w)};
+            const float rr[8] = {bf_lo(r4.x), bf_hi(r4.x), bf_lo(r4.y), bf_hi(r4.y),
+                                 bf_lo(r4.z), bf_hi(r4.z), bf_lo(r4.w), bf_hi(r4.w)};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) f[q] = f[q] * sc[q] + sf[q] + rr[q];
+            if (act == RN_ACT_SWISH) {
+#pragma unroll
+              for (int q = 0; q < 8; ++q) f[q] = f[q] / (1.0f + __expf(-f[q]));
+            }
+            ov.x = pack2(f[0], f[1]); ov.y = pack2(f[2], f[3]); ov.z = pack2(f[4], f[5]); ov.w = pack2(f[6], f[7]);
+            // relu / relu6 on the packed bf16 pairs: rounding is monotonic and 0 and 6 are bf16 values, so
+            // act(round(x)) == round(act(x)); as signed 16-bit integers every negative bf16 is below 0 and
+            // positive ones order like their values (one v_pk_max_i16 / v_pk_min_i16 per two outputs)
+            if (clamp_lo) {
+              ov.x = pk_max_i16(ov.x, 0u); ov.y = pk_max_i16(ov.y, 0u); ov.z = pk_max_i16(ov.z, 0u); ov.w = pk_max_i16(ov.w, 0u);
+            }
+            if (clamp_hi) {
+              ov.x = pk_min_i16(ov.x, 0x40c040c0u); ov.y = pk_min_i16(ov.y, 0x40c040c0u);
+              ov.z = pk_min_i16(ov.z, 0x40c040c0u); ov.w = pk_min_i16(ov.w, 0x40c040c0u);
+            }
+          }
+          if (!(EPI_ABLATE & 16) || ov.x == 0x12345678u) *(uint4*)(ybase + (long long)(i * 32 + pass * 8) * row_bytes) = ov;
           if (stats) {
             const float w[8] = {bf_lo(ov.x), bf_hi(ov.x), bf_lo(ov.y), bf_hi(ov.y),
                                 bf_lo(ov.z), bf_hi(ov.z), bf_lo(ov.w), bf_hi(ov.w)};
@@ -109,6 +185,7 @@ _Pragma("unroll") for (int pass = 0; pass < 4; ++pass) {                        
         }
       }
     }
+    EPI_STAMP(21);
     if (stats) {
       // sum over the 8 row lanes that share this lane's channels (lane bits 3..5), then lanes 0-7 write the
       // wave's 128-pixel row block: chunk = m_tile * 2 + wave_m, layout [chunk][2][Cout]
@@ -138,6 +215,7 @@ _Pragma("unroll") for (int pass = 0; pass < 4; ++pass) {                        
       float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sf = make_float4(0.f, 0.f, 0.f, 0.f);
       if (nok && sg.scale) sc = *(const float4*)(sg.scale + nr);
       if (nok && sg.shift) sf = *(const float4*)(sg.shift + nr);
+      asm volatile("" : "+v"(sc.x), "+v"(sc.y), "+v"(sc.z), "+v"(sc.w), "+v"(sf.x), "+v"(sf.y), "+v"(sf.z), "+v"(sf.w));
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -158,10 +236,11 @@ _Pragma("unroll") for (int pass = 0; pass < 4; ++pass) {                        
               const uint2 r2 = *(const uint2*)(sg.residual + o);
               v.x += bf_lo(r2.x); v.y += bf_hi(r2.x); v.z += bf_lo(r2.y); v.w += bf_hi(r2.y);
             }
-            v.x = rn_apply_act(v.x, args.act);
-            v.y = rn_apply_act(v.y, args.act);
-            v.z = rn_apply_act(v.z, args.act);
-            v.w = rn_apply_act(v.w, args.act);
+            {
+              float f4[4] = {v.x, v.y, v.z, v.w};
+              rn_apply_act_n<4>(f4, args.act);
+              v = make_float4(f4[0], f4[1], f4[2], f4[3]);
+            }
             *(float4*)((float*)sg.y + o) = v;
           }
         }

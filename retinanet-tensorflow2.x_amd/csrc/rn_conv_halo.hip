@@ -15,8 +15,8 @@
 //     row below an image's last one IS the zero row above the next image; borders are ordinary zero pixels
 //     (written by the DMA's out-of-range zero fill), there are no per-tap masks, a tap is a uniform offset.
 //     Capacity 640 pixels = 40 KB (a 256-pixel tile of an 80 x 80 level that straddles two images needs
-//     7 rows x 81 + 1 = 568), two patches (the next chunk's lands while this one is used) + a four-stage ring
-//     of 16 KB weight tiles + a 10 KB table of per-thread source offsets = 154 KB.  Staged bytes per K step:
+//     7 rows x 81 + 1 = 568), two patches (the next chunk's lands while this one is used) + a three-stage ring
+//     of 16 KB weight tiles + a 10 KB table of per-thread source offsets = 138 KB.  Staged bytes per K step:
 //     16 KB + ~4 KB instead of 32 KB.
 //   * per wave and K step: 2 weight pieces, and in steps 1..5 of a chunk one piece of the next chunk's patch
 //     (5 x 8 waves x 1 KB = 40 KB), against 4 pieces before.  The nine taps are unrolled, so the counted
@@ -31,9 +31,10 @@
 #ifndef HALO_ABLATE
 #define HALO_ABLATE 0
 #endif
+static int g_halo_grid = 0;
+extern "C" void rn_debug_conv_halo_grid(int n) { g_halo_grid = n; }   // tools/: fewer persistent workgroups than CUs
 
 #ifdef HALO_PROF   // probe builds: core clock (clock64) and 100 MHz wall clock at the start / end of workgroup 0
-__device__ unsigned long long g_halo_clk[4];
 extern "C" int rn_debug_halo_clocks(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_halo_clk), sizeof(g_halo_clk)) == hipSuccess ? 0 : -3;
 }
@@ -44,12 +45,14 @@ namespace {
 constexpr int BM = 256, BN = 256, BK = 32, NW = 8;
 constexpr int PIX_PX = 640, PIX_BYTES = PIX_PX * 64;     // one halo patch (40 KB)
 constexpr int PIECES = PIX_PX / 16 / NW;                 // 5 patch DMA pieces per wave per chunk
+constexpr int PLANE = PIX_PX * 16;                       // the patch is 4 planes [16-byte channel slot][pixel]
 constexpr int W_STAGE = BN * BK * 2;                     // 16 KB of weights per K step
+constexpr int W_STAGES = 3;                              // 9 taps = 3 x 3: the ring stage of a tap is tap % 3
 constexpr int W_RING = 2 * PIX_BYTES;
-constexpr int PA_TABLE = W_RING + 4 * W_STAGE;           // per-thread source offsets of the patch pieces
-constexpr int LDS_BYTES = PA_TABLE + PIECES * 512 * 4;   // 80 + 64 + 10 = 154 KB
+constexpr int PA_TABLE = W_RING + W_STAGES * W_STAGE;    // per-thread source offsets of the patch pieces
+constexpr int LDS_BYTES = PA_TABLE + PIECES * 512 * 4;   // 80 + 48 + 10 = 138 KB
 
-template <bool OUT_F32>
+template <bool OUT_F32, bool HAS_RES>
 __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int total = args.total_tiles;
@@ -79,29 +82,31 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
       if (tile__ >= args.seg[i].tile_begin) si__ = i;                                                 \
     const ConvSegDev& sg__ = args.seg[si__];                                                          \
     const int lt__ = tile__ - sg__.tile_begin;                                                        \
-    const int m0__ = (lt__ / sg__.n_tiles) * BM;                                                      \
+    const int m0__ = rn_fdiv(lt__, sg__.n_tiles, __frcp_rn((float)sg__.n_tiles)) * BM;                \
     const int H__ = sg__.H, W__ = sg__.W, PS__ = sg__.pix_stride, W1__ = W__ + 1, H1__ = H__ + 1;     \
     const int HW__ = H__ * W__;                                                                       \
     p_nch = sg__.CinP / BK;                                                                           \
     rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)sg__.x, 0,                                        \
                                              (int)((long long)sg__.N * HW__ * PS__ * 2), 0x00020000); \
     const int ml__ = (m0__ + BM - 1 < sg__.M ? m0__ + BM - 1 : sg__.M - 1);                           \
-    const int nf__ = m0__ / HW__, nl__ = ml__ / HW__;                                                 \
-    const int Gf__ = nf__ * H1__ + (m0__ - nf__ * HW__) / W__ + 1;   /* padded row of the first pixel */ \
-    const int Gl__ = nl__ * H1__ + (ml__ - nl__ * HW__) / W__ + 1;                                    \
+    const float rHW__ = __frcp_rn((float)HW__), rW__ = __frcp_rn((float)W__);                         \
+    const float rW1__ = __frcp_rn((float)W1__), rH1__ = __frcp_rn((float)H1__);                       \
+    const int nf__ = rn_fdiv(m0__, HW__, rHW__), nl__ = rn_fdiv(ml__, HW__, rHW__);                   \
+    const int Gf__ = nf__ * H1__ + rn_fdiv(m0__ - nf__ * HW__, W__, rW__) + 1;   /* padded row of the first pixel */ \
+    const int Gl__ = nl__ * H1__ + rn_fdiv(ml__ - nl__ * HW__, W__, rW__) + 1;                        \
     const int plast__ = (Gl__ - Gf__ + 3) * W1__;   /* last patch pixel: the zero right of the last row */ \
     unsigned ln__;                                                                                    \
     HALO_LANE(ln__);                                                                                  \
+    /* piece j of wave w = plane (w & 3), pixel block 2j + (w >> 2): 64 consecutive patch pixels, one per lane */ \
     _Pragma("unroll") for (int j = 0; j < PIECES; ++j) {                                              \
-      const int p = (j * NW + wave) * 16 + (int)(ln__ >> 2);                                          \
-      const int chunk = (int)(ln__ & 3) ^ ((p >> 2) & 3);                                             \
-      const int prow = p / W1__, pcol = p - prow * W1__;                                              \
+      const int p = (2 * j + (wave >> 2)) * 64 + (int)ln__;                                           \
+      const int prow = rn_fdiv(p, W1__, rW1__), pcol = p - prow * W1__;                               \
       const int Gp = Gf__ - 1 + prow;                                                                 \
-      const int n = Gp / H1__;                                                                        \
+      const int n = rn_fdiv(Gp, H1__, rH1__);                                                         \
       const int iy = Gp - n * H1__ - 1, ix = pcol - 1;                                                \
       const bool ok = (unsigned)iy < (unsigned)H__ && (unsigned)ix < (unsigned)W__ && p < plast__ &&  \
                       n < sg__.N;                                                                     \
-      HALO_PA_AT(j, ln__) = ok ? (unsigned)(((((long long)n * H__ + iy) * W__ + ix) * PS__ + chunk * 8) * 2) : RN_OOB; \
+      HALO_PA_AT(j, ln__) = ok ? (unsigned)(((((long long)n * H__ + iy) * W__ + ix) * PS__ + (wave & 3) * 8) * 2) : RN_OOB; \
     }                                                                                                 \
   } while (0)
 
@@ -109,7 +114,8 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
 #define HALO_ISSUE_PIX(j_, pa_)                                                                       \
   do {                                                                                                \
     const unsigned v__ = (pa_) == RN_OOB ? RN_OOB : (pa_) + (unsigned)(p_chunk * (BK * 2));           \
-    if (!(HALO_ABLATE & 2)) dma16(rs_x, smem + p_par * PIX_BYTES + ((j_) * NW + wave) * 1024, v__);   \
+    if (!(HALO_ABLATE & 2))                                                                           \
+      dma16(rs_x, smem + p_par * PIX_BYTES + (wave & 3) * PLANE + (2 * (j_) + (wave >> 2)) * 1024, v__); \
     if ((j_) == PIECES - 1 && p_v < total) {                                                          \
       p_par ^= 1;                                                                                     \
       if (++p_chunk == p_nch) {                                                                       \
@@ -132,7 +138,7 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
   __amdgpu_buffer_rsrc_t rs_w;
   unsigned b_off;              // piece 0 (rows wave*16 + lane/4 of the tile); piece 1 is 128 rows further
   unsigned w_step1 = 0;        // byte distance of piece 1, or RN_OOB when those rows are past the packed weights
-  const int d_row = lane >> 2, d_pos = lane & 3;   // weight piece j fills rows (j*8 + wave)*16 + lane/4
+  // (weight piece j fills rows (j*8 + wave)*16 + lane/4 of the stage, 16-byte slot lane%4)
 
 #define HALO_SETUP_W()                                                                                \
   do {                                                                                                \
@@ -142,15 +148,17 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
       if (tile__ >= args.seg[i].tile_begin) si__ = i;                                                 \
     const ConvSegDev& sg__ = args.seg[si__];                                                          \
     const int lt__ = tile__ - sg__.tile_begin;                                                        \
-    const int n0__ = (lt__ - (lt__ / sg__.n_tiles) * sg__.n_tiles) * BN;                              \
+    const int n0__ = (lt__ - rn_fdiv(lt__, sg__.n_tiles, __frcp_rn((float)sg__.n_tiles)) * sg__.n_tiles) * BN; \
     w_nch = sg__.CinP / BK;                                                                           \
     const int Ktot__ = 9 * sg__.CinP;                                                                 \
     const int rows__ = ((sg__.Cout + 127) / 128) * 128; /* packed weight rows */                      \
     rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)sg__.w, 0, (int)((long long)rows__ * Ktot__ * 2), \
                                              0x00020000);                                             \
     {                                                                                                 \
-      const int row = wave * 16 + d_row;   /* piece 1: row + 128, same swizzle (128 % 16 == 0) */      \
-      const int chunk = d_pos ^ lds_swz<BK>(row);                                                     \
+      unsigned lw__;                                                                                  \
+      HALO_LANE(lw__);                                                                                \
+      const int row = wave * 16 + (int)(lw__ >> 2);   /* piece 1: row + 128, same swizzle */           \
+      const int chunk = (int)(lw__ & 3) ^ lds_swz<BK>(row);                                           \
       b_off = (unsigned)(((long long)(n0__ + row) * Ktot__ + chunk * 8) * 2);                         \
       /* rows__ is a multiple of 128 and n0 < rows__: piece 0 is always inside, piece 1 as a whole or not */ \
       w_step1 = n0__ + 128 < rows__ ? (unsigned)(128 * Ktot__ * 2) : RN_OOB;                          \
@@ -158,10 +166,10 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
   } while (0)
 
 // the two weight pieces of the next stream step, tap compile time
-#define HALO_ISSUE_W(tap_, ahead_)                                                                          \
+#define HALO_ISSUE_W(tap_)                                                                            \
   do {                                                                                                \
     const unsigned koff__ = (unsigned)(((tap_) * w_nch + w_chunk) * (BK * 2));                        \
-    char* st__ = smem + W_RING + ((g + (ahead_)) & 3) * W_STAGE;                                      \
+    char* st__ = smem + W_RING + ((tap_) % 3) * W_STAGE;                                              \
     if (!(HALO_ABLATE & 2)) {                                                                         \
       dma16(rs_w, st__ + wave * 1024, b_off + koff__);                                                \
       dma16(rs_w, st__ + (NW + wave) * 1024, w_step1 == RN_OOB ? RN_OOB : b_off + koff__ + w_step1);  \
@@ -179,8 +187,18 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
   int c_v = blockIdx.x;
   int c_chunk = 0, c_nch = 0, c_par = 0;
   int c_m0 = 0, c_n0 = 0, c_si = 0, c_W1 = 0;
-  int base[4];   // patch pixel of this lane's 4 fragment rows (output pixel at tap (0,0))
-  const int fr = lane & 31, fh = lane >> 5;
+  int base[4];   // LDS byte offset (inside a patch) of this lane's 16 bytes of its 4 fragment rows at tap (0,0)
+  // weights: row = lane&31 of a 32-row tile, 16-byte slot = 2*kk + (lane>>5), XOR-swizzled by (row/4)&3.
+  // Rebuilt from a fresh lane id after every epilogue so that it is not live (and spilled) across it.
+  int off_w0;
+#define HALO_LANE_CONSTS()                                                                            \
+  do {                                                                                                \
+    unsigned lc__;                                                                                    \
+    HALO_LANE(lc__);                                                                                  \
+    const int fr__ = (int)(lc__ & 31), fh__ = (int)(lc__ >> 5);                                       \
+    off_w0 = (wave_n * 64 + fr__) * 64 + ((fh__ ^ ((fr__ >> 2) & 3)) << 4);                           \
+  } while (0)
+  HALO_LANE_CONSTS();
 
 #define HALO_SETUP_COMPUTE()                                                                          \
   do {                                                                                                \
@@ -190,27 +208,28 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
       if (tile__ >= args.seg[i].tile_begin) c_si = i;                                                 \
     const ConvSegDev& sg__ = args.seg[c_si];                                                          \
     const int lt__ = tile__ - sg__.tile_begin;                                                        \
-    const int mt__ = lt__ / sg__.n_tiles;                                                             \
+    const int mt__ = rn_fdiv(lt__, sg__.n_tiles, __frcp_rn((float)sg__.n_tiles));                     \
     c_m0 = mt__ * BM;                                                                                 \
     c_n0 = (lt__ - mt__ * sg__.n_tiles) * BN;                                                         \
     c_nch = sg__.CinP / BK;                                                                           \
     c_chunk = 0;                                                                                      \
     const int H__ = sg__.H, W__ = sg__.W, H1__ = H__ + 1, HW__ = H__ * W__;                           \
     c_W1 = W__ + 1;                                                                                   \
-    const int nf__ = c_m0 / HW__;                                                                     \
-    const int Gf__ = nf__ * H1__ + (c_m0 - nf__ * HW__) / W__ + 1;                                    \
+    const float rHW__ = __frcp_rn((float)HW__), rW__ = __frcp_rn((float)W__);                         \
+    const int nf__ = rn_fdiv(c_m0, HW__, rHW__);                                                      \
+    const int Gf__ = nf__ * H1__ + rn_fdiv(c_m0 - nf__ * HW__, W__, rW__) + 1;                        \
+    unsigned lq__;                                                                                    \
+    HALO_LANE(lq__);                                                                                  \
+    const int fr = (int)(lq__ & 31), fh = (int)(lq__ >> 5);                                           \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
       int m = c_m0 + wave_m * 128 + i * 32 + fr;                                                      \
       m = m < sg__.M ? m : sg__.M - 1;                                                                \
-      const int n = m / HW__;                                                                         \
+      const int n = rn_fdiv(m, HW__, rHW__);                                                          \
       const int rem = m - n * HW__;                                                                   \
-      const int oy = rem / W__, ox = rem - oy * W__;                                                  \
-      base[i] = (n * H1__ + oy + 1 - Gf__) * c_W1 + ox;                                               \
+      const int oy = rn_fdiv(rem, W__, rW__), ox = rem - oy * W__;                                    \
+      base[i] = ((n * H1__ + oy + 1 - Gf__) * c_W1 + ox) * 16 + fh * PLANE;                           \
     }                                                                                                 \
   } while (0)
-
-  // weights: row = lane&31 of a 32-row tile, 16-byte slot = 2*kk + (lane>>5), XOR-swizzled by (row/4)&3
-  const int off_w0 = (wave_n * 64 + fr) * 64 + ((fh ^ ((fr >> 2) & 3)) << 4);
 
   f32x16_t acc[4][2];
 #pragma unroll
@@ -221,47 +240,39 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
   bf16x8_t px0[4], wt0[2], px1[4], wt1[2];   // fragments of one stream step: K slices 0..15 / 16..31
-  int g = 0;                                  // stream step whose fragments are in registers
-// fragments of stream step g, tap compile time: weights from ring stage g&3, pixels from the current patch
+  unsigned pa_next = RN_OOB;                  // source offset of the patch piece the next load segment issues
+// fragments of the step with tap `tap_` (compile time): weights from ring stage tap % 3, pixels from the current
+// patch: plane (2*kk + lane/32), pixel base + r*(W+1) + s — one VALU add per fragment, kk = 1 is an immediate
 #define HALO_READ(tap_)                                                                               \
   do {                                                                                                \
-    const char* wb__ = smem + W_RING + (g & 3) * W_STAGE + off_w0;                                    \
-    const char* wb1__ = smem + W_RING + (g & 3) * W_STAGE + (off_w0 ^ 32);                            \
-    const char* pb__ = smem + c_par * PIX_BYTES;                                                      \
-    const int dt__ = ((tap_) / 3) * c_W1 + ((tap_) % 3);                                              \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) wt0[j] = *(const bf16x8_t*)(wb__ + j * 2048);       \
-    int po__[4];                                                                                      \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
-      const int p = base[i] + dt__;                                                                   \
-      po__[i] = p * 64 + ((fh ^ ((p >> 2) & 3)) << 4);                                                \
-      px0[i] = *(const bf16x8_t*)(pb__ + po__[i]);                                                    \
-    }                                                                                                 \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) wt1[j] = *(const bf16x8_t*)(wb1__ + j * 2048);      \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) px1[i] = *(const bf16x8_t*)(pb__ + (po__[i] ^ 32)); \
+    const char* wb__ = smem + W_RING + ((tap_) % 3) * W_STAGE;                                        \
+    const char* pb__ = smem + c_par * PIX_BYTES + (((tap_) / 3) * c_W1 + ((tap_) % 3)) * 16;          \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) wt0[j] = *(const bf16x8_t*)(wb__ + off_w0 + j * 2048); \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) px0[i] = *(const bf16x8_t*)(pb__ + base[i]);        \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) wt1[j] = *(const bf16x8_t*)(wb__ + (off_w0 ^ 32) + j * 2048); \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) px1[i] = *(const bf16x8_t*)(pb__ + base[i] + 2 * PLANE); \
   } while (0)
 // load segment for the step with tap `tap_`: fragment reads first (their LDS latency runs under the DMA issue),
-// then this wave's pieces — weights of the step 3 ahead and, in taps 1..6, one piece of the next chunk's patch —
-// then the counted wait: everything but the pieces of this and the previous segment
+// then this wave's pieces — weights of the step 2 ahead and, in taps 1..5, one piece of the next chunk's patch
+// (its source offset was fetched from the LDS table one segment earlier) — then the counted wait: everything
+// but this segment's own pieces
 #define HALO_LOADSEG(tap_)                                                                            \
   do {                                                                                                \
-    unsigned pa__ = RN_OOB;                                                                           \
-    if ((tap_) >= 1 && (tap_) <= PIECES) {                                                            \
-      unsigned ln__;                                                                                  \
-      HALO_LANE(ln__);                                                                                \
-      pa__ = HALO_PA_AT((tap_) - 1, ln__);                                                            \
-    }                                                                                                 \
     if (!(HALO_ABLATE & 4)) HALO_READ(tap_);                                                          \
+    constexpr bool pix__ = (tap_) >= 1 && (tap_) <= PIECES;                                           \
     if (w_v < total) {                                                                                \
-      HALO_ISSUE_W(((tap_) + 3) % 9, 3);                                                               \
-      if ((tap_) >= 1 && (tap_) <= PIECES) HALO_ISSUE_PIX((tap_) - 1, pa__);                          \
-      constexpr int now__ = ((tap_) >= 1 && (tap_) <= PIECES) ? 3 : 2;                                \
-      constexpr int prev__ = (((tap_) + 8) % 9 >= 1 && ((tap_) + 8) % 9 <= PIECES) ? 3 : 2;           \
+      HALO_ISSUE_W(((tap_) + 2) % 9);                                                                 \
+      if (pix__) HALO_ISSUE_PIX((tap_) - 1, pa_next);                                                 \
       if (HALO_ABLATE & 3) {                                                                          \
-      } else if (now__ + prev__ == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                \
-      else if (now__ + prev__ == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");                  \
-      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                           \
+      } else if (pix__) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                              \
+      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                           \
     } else {                                                                                          \
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
+    }                                                                                                 \
+    if ((tap_) < PIECES) {   /* the offset the next segment's patch piece needs */                    \
+      unsigned ln__;                                                                                  \
+      HALO_LANE(ln__);                                                                                \
+      pa_next = HALO_PA_AT((tap_), ln__);                                                             \
     }                                                                                                 \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
   } while (0)
@@ -283,14 +294,24 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
     asm volatile("" ::: "memory");          \
   } while (0)
 
+  // Start stagger.  Every workgroup walks tiles of the same length, so without it all 256 CUs reach their
+  // epilogues together: 256 x 128 KB of stores hit L2 / HBM as one burst every tile period, the store queues back
+  // up and each epilogue takes as long as the whole burst needs to drain (measured 23 000 cycles against
+  // ~5 000 alone) with the MFMA pipes idle.  A one-off start delay of (16 phases) x args.pad_ x 64 cycles
+  // spreads the epilogues over the burst's length for the rest of the launch.
+  if (args.pad_ > 0) {
+    const int phase = (blockIdx.x * 5) & 15;
+#pragma unroll 1
+    for (int k = 0; k < phase * args.pad_; ++k) __builtin_amdgcn_s_sleep(1);
+  }
 #ifdef HALO_PROF
-  if (blockIdx.x == 0 && tid == 0) { g_halo_clk[0] = clock64(); g_halo_clk[1] = wall_clock64(); }
+  if (blockIdx.x == 0 && tid == 0) { g_halo_clk[0] = clock64(); g_halo_clk[1] = wall_clock64(); for (int q = 8; q < 32; ++q) g_halo_clk[q] = 0; }
 #endif
   // ---- prologue -------------------------------------------------------------------------------------------
   HALO_SETUP_PIX();
   HALO_SETUP_W();
   HALO_SETUP_COMPUTE();
-  // patch of chunk 0 (5 pieces), then the weights of stream steps 0, 1, 2
+  // patch of chunk 0 (5 pieces), then the weights of stream steps 0 and 1
   {
     unsigned pa0[PIECES];
     unsigned ln0;
@@ -300,10 +321,10 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
     HALO_ISSUE_PIX(0, pa0[0]); HALO_ISSUE_PIX(1, pa0[1]); HALO_ISSUE_PIX(2, pa0[2]); HALO_ISSUE_PIX(3, pa0[3]);
     HALO_ISSUE_PIX(4, pa0[4]);
   }
-  HALO_ISSUE_W(0, 0); HALO_ISSUE_W(1, 1); HALO_ISSUE_W(2, 2);
-  asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // the patch and steps 0, 1 have landed
+  HALO_ISSUE_W(0); HALO_ISSUE_W(1);
+  asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // the patch and step 0 have landed
   HALO_BARRIER();
-  // pre-roll: both groups read step 0 and issue step 3; group 1 does so as its slot-0 load segment
+  // pre-roll: both groups read step 0 and issue step 2; group 1 does so as its slot-0 load segment
   HALO_LOADSEG(0);
   if (wave_m == 1) HALO_BARRIER();
 
@@ -314,29 +335,50 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
 #define HALO_CHUNK_END()                                                                  \
   c_par ^= 1;                                                                             \
   if (__builtin_expect(++c_chunk == c_nch, 0)) {                                          \
-    big_epilogue<OUT_F32>(acc, args, c_si, c_m0, c_n0, wave,                              \
-                          smem + (c_par ^ 1) * PIX_BYTES + wave * 4096 /* 32 KB of the dead 40 KB patch */);                  \
+    HALO_EPI_PROBE(8);                                                                    \
+    big_epilogue<OUT_F32, HAS_RES>(acc, args, c_si, c_m0, c_n0, wave,                              \
+                          smem + (c_par ^ 1) * PIX_BYTES + wave * 4096 /* 32 KB of the dead 40 KB patch */); \
+    HALO_EPI_PROBE(9);                                                                    \
     if (c_v + G >= total) break;                                                          \
     c_v += G;                                                                             \
+    HALO_LANE_CONSTS();                                                                   \
     HALO_SETUP_COMPUTE();                                                                 \
   }
 #define HALO_STEP0(next_tap_)                 \
   HALO_COMPUTESEG();                          \
   HALO_BARRIER();                             \
   if ((next_tap_) == 0) { HALO_CHUNK_END() }  \
-  ++g;                                        \
   HALO_LOADSEG(next_tap_);                    \
+  if ((next_tap_) == 0) { HALO_EPI_PROBE2() }  \
   HALO_BARRIER();
 #define HALO_STEP1(next_tap_)                 \
   HALO_COMPUTESEG();                          \
   if ((next_tap_) == 0) { HALO_CHUNK_END() }  \
   HALO_BARRIER();                             \
-  ++g;                                        \
   HALO_LOADSEG(next_tap_);                    \
   HALO_BARRIER();
+#ifdef HALO_PROF
+#define HALO_EPI_PROBE(k_) if (blockIdx.x == 0 && tid == 0 && g_halo_clk[k_] == 0) g_halo_clk[k_] = clock64();
+#else
+#define HALO_EPI_PROBE(k_)
+#endif
+#ifdef HALO_PROF
+#define HALO_EPI_PROBE2() if (blockIdx.x == 0 && tid == 0 && g_halo_clk[9] != 0 && g_halo_clk[10] == 0) g_halo_clk[10] = clock64();
+#else
+#define HALO_EPI_PROBE2()
+#endif
+#ifdef HALO_PROF
+  int pass_ = 0;
+#define HALO_PASS_PROBE() \
+  if (blockIdx.x == 0 && tid == 0 && pass_ >= 2 && pass_ < 6) g_halo_clk[2 + pass_] = clock64(); \
+  ++pass_;
+#else
+#define HALO_PASS_PROBE()
+#endif
   if (wave_m == 0) {
 #pragma unroll 1
     while (true) {
+      HALO_PASS_PROBE()
       HALO_STEP0(1) HALO_STEP0(2) HALO_STEP0(3) HALO_STEP0(4) HALO_STEP0(5) HALO_STEP0(6) HALO_STEP0(7)
       HALO_STEP0(8) HALO_STEP0(0)
     }
@@ -358,9 +400,13 @@ int rn_launch_conv_halo(const ConvArgs& a, bool out_f32, hipStream_t st) {
   static bool attr_set = false;
   static int num_cu = 256;
   if (!attr_set) {
-    RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<false>,
+    RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<false, false>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<true>,
+    RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<false, true>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<true, false>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<true, true>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     int dev = 0;
     hipDeviceProp_t prop;
@@ -369,11 +415,18 @@ int rn_launch_conv_halo(const ConvArgs& a, bool out_f32, hipStream_t st) {
       num_cu = prop.multiProcessorCount;
     attr_set = true;
   }
-  const int grid = a.total_tiles < num_cu ? a.total_tiles : num_cu;   // one persistent workgroup per CU
-  if (out_f32)
-    hipLaunchKernelGGL(conv_halo_kernel<true>, dim3(grid), dim3(512), LDS_BYTES, st, a);
-  else
-    hipLaunchKernelGGL(conv_halo_kernel<false>, dim3(grid), dim3(512), LDS_BYTES, st, a);
+  int grid = a.total_tiles < num_cu ? a.total_tiles : num_cu;   // one persistent workgroup per CU
+  if (g_halo_grid > 0 && g_halo_grid < grid) grid = g_halo_grid;
+  bool has_res = false;   // one residual input anywhere -> the variant that carries the residual path
+  for (int i = 0; i < a.nseg; ++i) has_res = has_res || a.seg[i].residual != nullptr;
+  const dim3 g3(grid), b3(512);
+  if (out_f32) {
+    if (has_res) hipLaunchKernelGGL((conv_halo_kernel<true, true>), g3, b3, LDS_BYTES, st, a);
+    else hipLaunchKernelGGL((conv_halo_kernel<true, false>), g3, b3, LDS_BYTES, st, a);
+  } else {
+    if (has_res) hipLaunchKernelGGL((conv_halo_kernel<false, true>), g3, b3, LDS_BYTES, st, a);
+    else hipLaunchKernelGGL((conv_halo_kernel<false, false>), g3, b3, LDS_BYTES, st, a);
+  }
   RN_CHECK_LAUNCH();
   return RN_OK;
 }

@@ -115,7 +115,8 @@ __global__ void __launch_bounds__(POOL_THREADS) fpn_topdown_kernel(Pyramid p) {
       const bf8 u = unpack8(p.in[k][(((long long)n * Hk) + (y >> (k - l))) * Wk * p.C8 +
                                    (long long)(x >> (k - l)) * p.C8 + c]);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) v.v[q] = rn_apply_act(u.v[q] + v.v[q], p.act);
+      for (int q = 0; q < 8; ++q) v.v[q] = u.v[q] + v.v[q];
+      rn_apply_act_n<8>(v.v, p.act);
       round8(v);
     }
     p.out[l][(((long long)n * Hl) + y) * Wl * p.C8 + (long long)x * p.C8 + c] = pack8(v);

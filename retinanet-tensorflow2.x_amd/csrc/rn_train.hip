@@ -232,8 +232,9 @@ __global__ void __launch_bounds__(TR_THREADS) bn_apply_kernel(const BnArgs a) {
     for (int q = 0; q < 8; ++q) {
       float v = (y.v[q] * sc[q] + sh[q]) * m;
       if (s.residual) v += res.v[q];
-      o.v[q] = rn_apply_act(v, a.act);
+      o.v[q] = v;
     }
+    rn_apply_act_n<8>(o.v, a.act);
     s.z[i] = pack8(o);
   }
 }

@@ -39,6 +39,9 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--ablate", type=int, default=0)
     ap.add_argument("--zeros", action="store_true", help="all-zero activations and weights (DVFS check: no toggling)")
+    ap.add_argument("--stagger", type=int, default=-1, help="start stagger of conv_halo_kernel, 64-cycle units per phase")
+    ap.add_argument("--halo-grid", type=int, default=0, help="limit conv_halo_kernel to this many workgroups")
+    ap.add_argument("--raw", action="store_true", help="no scale / shift / activation (the training forward's raw conv output)")
     ap.add_argument("--no-halo", action="store_true", help="3x3 launches on conv_big_kernel instead of conv_halo_kernel")
     ap.add_argument("--tile", type=int, default=0, help="1 = force 128-row kernel, 2 = force the 256x256 kernel")
     a = ap.parse_args()
@@ -50,6 +53,10 @@ def main():
         lib.rn_debug_conv_tile(a.tile)
     if a.no_halo:
         lib.rn_debug_conv_halo(0)
+    if a.halo_grid:
+        lib.rn_debug_conv_halo_grid(a.halo_grid)
+    if a.stagger >= 0:
+        lib.rn_debug_conv_stagger(a.stagger)
     dev = torch.device("cuda:0")
     for name in a.preset.split(","):
         segs, k, stride, f32, use_res = PRESETS[name]
@@ -57,7 +64,7 @@ def main():
         p.R = p.S = k
         p.stride_h = p.stride_w = stride
         p.pad_top = p.pad_left = (k - 1) // 2
-        p.act, p.out_dtype, p.num_segments = _C.RN_ACT_RELU, (_C.RN_DT_F32 if f32 else _C.RN_DT_BF16), len(segs)
+        p.act, p.out_dtype, p.num_segments = (_C.RN_ACT_NONE if a.raw else _C.RN_ACT_RELU), (_C.RN_DT_F32 if f32 else _C.RN_DT_BF16), len(segs)
         keep, flops, byts = [], 0, 0
         for i, (H, cin, cout) in enumerate(segs):
             x = torch.randn((a.batch, H, H, cin), device=dev).to(torch.bfloat16)
@@ -71,6 +78,8 @@ def main():
             res = torch.randn((a.batch, Ho, Ho, cout), device=dev).to(torch.bfloat16) if use_res else None
             s = p.seg[i]
             s.x, s.w, s.y, s.scale, s.shift = x.data_ptr(), w.data_ptr(), y.data_ptr(), sc.data_ptr(), sh.data_ptr()
+            if a.raw:
+                s.scale, s.shift = None, None
             s.residual = res.data_ptr() if use_res else None
             s.N, s.H, s.W, s.Cin, s.pix_stride, s.Ho, s.Wo, s.Cout = a.batch, H, H, cin, cin, Ho, Ho, cout
             keep += [x, w, y, sc, sh, res]
@@ -88,10 +97,14 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / a.iters
         if hasattr(lib, "rn_debug_halo_clocks"):     # probe builds: core clock of workgroup 0 during the last launch
-            clk = (ctypes.c_ulonglong * 4)()
+            clk = (ctypes.c_ulonglong * 32)()
             if lib.rn_debug_halo_clocks(clk) == 0 and clk[3] > clk[1]:
                 cyc, wall = clk[2] - clk[0], (clk[3] - clk[1]) / 100.0   # wall clock ticks at 100 MHz -> us
-                print(f"  workgroup 0: {cyc} core cycles in {wall:.1f} us -> {cyc / wall / 1e3:.3f} GHz")
+                print(f"  workgroup 0: {cyc} core cycles in {wall:.1f} us -> {cyc / wall / 1e3:.3f} GHz; "
+                      f"cycles per slot in passes 2-4 of tile 0: {[round((clk[5 + i] - clk[4 + i]) / 18) for i in range(3)]}; "
+                      f"first epilogue {clk[9] - clk[8]} cycles, + next load segment {clk[10] - clk[9]}; "
+                      f"inside (entry, then per 32-pixel block: transposes | read-back + stores): "
+                      f"{[int(clk[k + 1] - clk[k]) for k in range(12, 21)]}")
         print(f"{name:12s} B={a.batch} {ms * 1e3:9.1f} us  {flops / ms / 1e9:8.1f} TFLOP/s  "
               f"{byts / ms / 1e6:8.1f} GB/s (algorithmic {byts / 1e6:.1f} MB)", flush=True)
 
