@@ -59,6 +59,47 @@ __device__ __forceinline__ float act_deriv(float z, float u, int act) {
   return act_mask(z, act);
 }
 
+// How the BatchNorm backward kernels turn dz into g = dz * act'(.): decided on the host once per launch and
+// compiled in (a runtime `act` / `residual` test inside the unrolled 8-channel loops becomes a chain of scalar
+// compares and branches PER ELEMENT — the passes are then issue-bound, not HBM-bound).
+enum { G_GENERIC = 0, G_NONE = 1, G_U_RELU = 2, G_U_RELU6 = 3, G_Z_RELU = 4, G_Z_RELU6 = 5, G_SWISH = 6 };
+template <int G>
+__device__ __forceinline__ float grad_gate(float dz, float z, float u, int act, bool from_u) {
+  if (G == G_NONE) return dz;
+  if (G == G_U_RELU) return u > 0.0f ? dz : 0.0f;               // rounding to bf16 never changes the sign
+  if (G == G_U_RELU6) {
+    const float ub = (float)(__bf16)u;                           // the op's bf16 input (see act_mask_u)
+    return (ub > 0.0f && ub < 6.0f) ? dz : 0.0f;
+  }
+  if (G == G_Z_RELU) return z > 0.0f ? dz : 0.0f;
+  if (G == G_Z_RELU6) return (z > 0.0f && z < 6.0f) ? dz : 0.0f;
+  if (G == G_SWISH) {
+    const float sg = 1.0f / (1.0f + __expf(-u));
+    return dz * (sg + u * sg * (1.0f - sg));
+  }
+  return act == RN_ACT_NONE ? dz : dz * (from_u ? act_mask_u(u, act) : act_deriv(z, u, act));
+}
+// the gate mode of a problem: one mode when every segment agrees on "has a residual input", else generic
+static int bn_gate_mode(const rn_bn_problem* p) {
+  if (p->act == RN_ACT_NONE) return G_NONE;
+  if (p->act == RN_ACT_SWISH) return G_SWISH;
+  int with_res = 0;
+  for (int i = 0; i < p->num_segments; ++i) with_res += p->seg[i].residual ? 1 : 0;
+  if (with_res != 0 && with_res != p->num_segments) return G_GENERIC;
+  if (with_res == 0) return p->act == RN_ACT_RELU ? G_U_RELU : (p->act == RN_ACT_RELU6 ? G_U_RELU6 : G_GENERIC);
+  return p->act == RN_ACT_RELU ? G_Z_RELU : (p->act == RN_ACT_RELU6 ? G_Z_RELU6 : G_GENERIC);
+}
+#define BN_DISPATCH_GATE(mode_, CALL_)                  \
+  switch (mode_) {                                      \
+    case G_NONE: CALL_(G_NONE); break;                  \
+    case G_U_RELU: CALL_(G_U_RELU); break;              \
+    case G_U_RELU6: CALL_(G_U_RELU6); break;            \
+    case G_Z_RELU: CALL_(G_Z_RELU); break;              \
+    case G_Z_RELU6: CALL_(G_Z_RELU6); break;            \
+    case G_SWISH: CALL_(G_SWISH); break;                \
+    default: CALL_(G_GENERIC); break;                   \
+  }
+
 static int tr_blocks(long long items, int cap = 8192) {
   long long b = rn_cdiv(items, TR_THREADS);
   if (b > cap) b = cap;
@@ -83,6 +124,7 @@ struct BnArgs {
 };
 
 // mode 0: (sum y, sum y^2); mode 1: (sum g, sum g*xhat), g = dz*mask(z), xhat = (y-mean)*invstd
+template <int G>   // G < 0: mode 0 (forward statistics); else the gradient gate of mode 1
 __global__ void __launch_bounds__(TR_THREADS) bn_colreduce_kernel(const BnArgs a) {
   const BnSegDev& s = a.seg[blockIdx.z];
   const int chunk = blockIdx.x;
@@ -99,7 +141,7 @@ __global__ void __launch_bounds__(TR_THREADS) bn_colreduce_kernel(const BnArgs a
 #pragma unroll
   for (int q = 0; q < 8; ++q) s0[q] = s1[q] = 0.0f;
   float mean[8], istd[8], scq[8], shq[8];
-  if (a.mode == 1 && live) {
+  if (G >= 0 && live) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       mean[q] = s.fwd[0 * s.C + c8 * 8 + q];
@@ -112,7 +154,7 @@ __global__ void __launch_bounds__(TR_THREADS) bn_colreduce_kernel(const BnArgs a
     for (long long r = r0 + rl; r < r1; r += 32) {
       const long long o = r * C8 + c8;
       const bf8 y = unpack8(s.y[o]);
-      if (a.mode == 0) {
+      if (G < 0) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           s0[q] += y.v[q];
@@ -121,14 +163,15 @@ __global__ void __launch_bounds__(TR_THREADS) bn_colreduce_kernel(const BnArgs a
       } else {
         const bf8 dz = unpack8(s.dz[o]);
         const bool from_u = !s.residual && (a.act == RN_ACT_RELU || a.act == RN_ACT_RELU6);
+        constexpr bool need_z = G == G_Z_RELU || G == G_Z_RELU6 || G == G_GENERIC;
         bf8 z;
-        if (a.act != RN_ACT_NONE && !from_u) z = unpack8(s.z[o]);
+        if (need_z && (G != G_GENERIC || (a.act != RN_ACT_NONE && !from_u))) z = unpack8(s.z[o]);
+        float m = 1.0f;
+        if (s.sample_scale) m = s.sample_scale[(int)r / (int)s.rows_per_sample];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           const float u = y.v[q] * scq[q] + shq[q];
-          float g = a.act == RN_ACT_NONE ? dz.v[q]
-                    : dz.v[q] * (from_u ? act_mask_u(u, a.act) : act_deriv(z.v[q], u, a.act));
-          if (s.sample_scale) g *= s.sample_scale[(int)r / (int)s.rows_per_sample];
+          const float g = grad_gate<G < 0 ? 0 : G>(dz.v[q], z.v[q], u, a.act, from_u) * m;
           s0[q] += g;
           s1[q] += g * ((y.v[q] - mean[q]) * istd[q]);
         }
@@ -241,6 +284,7 @@ __global__ void __launch_bounds__(TR_THREADS) bn_apply_kernel(const BnArgs a) {
 
 // dy = scale*(g - sum_g/n - xhat*sum_gxhat/n); dres (+)= g; block 0 also writes dgamma/dbeta.
 // Same fixed-channel-group threading as bn_apply_kernel: 5 per-channel parameters in registers.
+template <int G>
 __global__ void __launch_bounds__(TR_THREADS) bn_bwd_apply_kernel(const BnArgs a) {
   const BnSegDev& s = a.seg[blockIdx.y];
   const int C8 = s.C >> 3;
@@ -272,15 +316,15 @@ __global__ void __launch_bounds__(TR_THREADS) bn_bwd_apply_kernel(const BnArgs a
     const bf8 y = unpack8(s.y[i]);
     const bf8 dz = unpack8(s.dz[i]);
     const bool from_u = !s.residual && (a.act == RN_ACT_RELU || a.act == RN_ACT_RELU6);
+    constexpr bool need_z = G == G_Z_RELU || G == G_Z_RELU6 || G == G_GENERIC;
     bf8 z;
-    if (a.act != RN_ACT_NONE && !from_u) z = unpack8(s.z[i]);
+    if (need_z && (G != G_GENERIC || (a.act != RN_ACT_NONE && !from_u))) z = unpack8(s.z[i]);
     const float m = s.sample_scale ? s.sample_scale[(int)(i / C8) / (int)s.rows_per_sample] : 1.0f;
     bf8 g, o;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const float u = y.v[q] * sc[q] + shq[q];
-      g.v[q] = a.act == RN_ACT_NONE ? dz.v[q]
-               : dz.v[q] * (from_u ? act_mask_u(u, a.act) : act_deriv(z.v[q], u, a.act));
+      g.v[q] = grad_gate<G>(dz.v[q], z.v[q], u, a.act, from_u);
       const float xh = (y.v[q] - mean[q]) * istd[q];
       o.v[q] = sc[q] * (g.v[q] * m - k1[q] - xh * k2[q]);
     }
@@ -369,7 +413,14 @@ static int bn_colreduce(const rn_bn_problem* p, int mode, void* ws, size_t ws_by
     if (s.C > max_c) max_c = s.C;
   }
   if (n_ext == 0) {   // otherwise the producing convolution already wrote the stage-1 partials
-    hipLaunchKernelGGL(bn_colreduce_kernel, dim3(max_chunks, max_slabs, a.nseg), dim3(TR_THREADS), 0, st, a);
+    const dim3 grid(max_chunks, max_slabs, a.nseg), block(TR_THREADS);
+    if (mode == 0) {
+      hipLaunchKernelGGL(bn_colreduce_kernel<-1>, grid, block, 0, st, a);
+    } else {
+#define BN_CALL_(G_) hipLaunchKernelGGL(bn_colreduce_kernel<G_>, grid, block, 0, st, a)
+      BN_DISPATCH_GATE(bn_gate_mode(p), BN_CALL_)
+#undef BN_CALL_
+    }
     RN_CHECK_LAUNCH();
   }
   hipLaunchKernelGGL(bn_colreduce_final_kernel, dim3((max_c + 31) / 32, a.nseg), dim3(1024), 0, st, a);
@@ -422,8 +473,12 @@ extern "C" int rn_bn_bwd_apply(const rn_bn_problem* p, void* stream) {
     const long long t = a.seg[i].P * (a.seg[i].C / 8);
     if (t > mx) mx = t;
   }
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(tr_blocks(mx, 4096), a.nseg), dim3(TR_THREADS), 0,
-                     (hipStream_t)stream, a);
+  {
+    const dim3 grid(tr_blocks(mx, 4096), a.nseg), block(TR_THREADS);
+#define BN_CALL_(G_) hipLaunchKernelGGL(bn_bwd_apply_kernel<G_>, grid, block, 0, (hipStream_t)stream, a)
+    BN_DISPATCH_GATE(bn_gate_mode(p), BN_CALL_)
+#undef BN_CALL_
+  }
   RN_CHECK_LAUNCH();
   return RN_OK;
 }
