@@ -63,8 +63,9 @@ def conv_flops(engine, step_name):
 
 
 def conv_variant(engine, step_name):
-    """Kernel the dispatcher picks for an inference conv launch: the 256x256x32 kernel (rn_conv_big.hip) or
-    conv_fwd_kernel<128,128,64> (Cout > 64, Cin % 64 == 0), bf16 output; None for the other variants."""
+    """Kernel the dispatcher picks for an inference conv launch (named like its device symbol): conv_halo_kernel /
+    conv_big_kernel <f32 out, residual> or conv_fwd_kernel<128,128,64> (Cout > 64, Cin % 64 == 0), bf16 output;
+    None for the other variants."""
     import ctypes
     g = engine.g
     p = getattr(engine, "conv_problems", {}).get(step_name)
@@ -76,8 +77,12 @@ def conv_variant(engine, step_name):
             c = g.convs[o["conv"]]
             if o["out_dtype"] != "bf16":
                 return None
-            if engine.lib.rn_conv_tile_rows(ctypes.byref(p)) == 256:
-                return "conv_big_kernel<bf16> (256x256x32)"
+            kid = engine.lib.rn_conv_kernel_id(ctypes.byref(p))
+            res = "true" if any(p.seg[i].residual for i in range(p.num_segments)) else "false"
+            if kid == 2:
+                return f"conv_halo_kernel<false, {res}> (256x256x32, 3x3 halo patch)"
+            if kid == 1:
+                return f"conv_big_kernel<false, {res}> (256x256x32)"
             return "conv_fwd_kernel<128,128,64,bf16>" if c["cout"] > 64 and c["cin"] % 64 == 0 else None
     return None
 
@@ -330,9 +335,11 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            key = ("conv_big_kernel_bf16_bytes_per_launch" if line["roofline"]["kernel"].startswith("conv_big")
-                   else "conv_fwd_128x128x64_bf16_bytes_per_launch")
-            line["roofline"]["traffic"] = json.load(open(tpath)).get(key)
+            # profiles/traffic.json (tools/summarize_profiles.py): per device symbol, HBM bytes per launch from the
+            # FETCH_SIZE / WRITE_SIZE passes of the same bench command
+            sym = line["roofline"]["kernel"].split(" (")[0]
+            ent = json.load(open(tpath)).get("kernels", {}).get(sym)
+            line["roofline"]["traffic"] = ent.get("bytes_per_launch") if ent else None
         except Exception:
             pass
     if world == 1 and rank == 0:

@@ -450,9 +450,15 @@ class TrainEngine:
             if s.residual:
                 byts += 2 * s.N * s.Ho * s.Wo * s.Cout
             dom = dom and s.Cout > 64 and s.Cin % 64 == 0 and p.out_dtype == _C.RN_DT_BF16
+        # one name per device symbol, so that a bench line and a rocprof kernel-stats row can be matched
         variant = None
-        if p.out_dtype == _C.RN_DT_BF16 and self.lib.rn_conv_tile_rows(ctypes.byref(p)) == 256:
-            variant = "conv_big_kernel<bf16> (256x256x32)"
+        kid = self.lib.rn_conv_kernel_id(ctypes.byref(p))
+        has_res = any(p.seg[i].residual for i in range(p.num_segments))
+        tmpl = f"<{'true' if p.out_dtype == _C.RN_DT_F32 else 'false'}, {'true' if has_res else 'false'}>"
+        if kid == 2:
+            variant = "conv_halo_kernel" + tmpl + " (256x256x32, 3x3 halo patch)"
+        elif kid == 1:
+            variant = "conv_big_kernel" + tmpl + " (256x256x32)"
         elif dom:
             variant = "conv_fwd_kernel<128,128,64,bf16>"
         return flops, byts, variant
