@@ -51,6 +51,12 @@ __device__ __forceinline__ bf16x8_t frag_read(const char* p) {   // p: rows r0 (
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+// LINEAR: stride 1, output size == input size, symmetric padding (every 1x1 / 3x3 layer of the network): the input
+// pixel of output pixel p at tap (r, s) is p + (r - pt)*W + (s - pl), so both operands' source offsets advance by a
+// constant per K step and only (ox, oy) are tracked, for the border test of the shifted taps — 17 VALU per DMA row
+// pair instead of ~45 (the load segment of this kernel is instruction-issue bound: ~230 instructions per K step
+// against 16 MFMAs).
+template <bool LINEAR>
 __global__ void __launch_bounds__(512) wgrad_big_kernel(const WgArgs args) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // (chunk, tile) from the block id: tiles of one pixel chunk are consecutive on one XCD (they walk the
@@ -121,11 +127,41 @@ __global__ void __launch_bounds__(512) wgrad_big_kernel(const WgArgs args) {
 
   const int ksteps = (p_end - p_begin + BK - 1) / BK;
   int g_iss = 0;   // K steps issued by this wave
+  // LINEAR state: byte offsets of this lane's two rows in dy and x (out of range for good where the channel chunk
+  // is), the taps' forbidden output row / column (-1: none)
+  unsigned l_dy[2], l_x[2];
+  const int y_bad = r < args.pt ? 0 : (r > args.pt ? Ho - 1 : -1), x_bad = s < args.pl ? 0 : (s > args.pl ? Wo - 1 : -1);
+  if (LINEAR) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int p0 = p_begin + row_lo + 16 * j;
+      l_dy[j] = a_ch == WG_OOB ? WG_OOB : (unsigned)((p0 * sg.dyS + (int)a_ch) * 2);
+      // the shifted pixel of a valid tap is inside the same image; invalid ones are masked at issue
+      l_x[j] = b_ch == WG_OOB ? WG_OOB : (unsigned)(((p0 + (r - args.pt) * W + (s - args.pl)) * sg.xS + (int)b_ch) * 2);
+    }
+  }
+  const unsigned l_dy_step = (unsigned)(BK * sg.dyS * 2), l_x_step = (unsigned)(BK * sg.xS * 2);
 
 #define WGB_ISSUE()                                                                               \
   do {                                                                                            \
     char* st__ = smem + (g_iss & 3) * STAGE_BYTES;                                                \
     const int pb__ = p_begin + g_iss * BK;                                                        \
+    if (LINEAR) {                                                                                 \
+      const int left__ = p_end - pb__;   /* rows of this step that are inside the chunk */         \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                             \
+        const bool in__ = row_lo + 16 * j < left__;                                               \
+        dma16(rs_dy, st__ + (wave + 8 * j) * 1024, in__ ? l_dy[j] : WG_OOB);                      \
+        const bool ok__ = in__ && r_oy[j] != y_bad && r_ox[j] != x_bad;                           \
+        dma16(rs_x, st__ + OP_BYTES + (wave + 8 * j) * 1024, ok__ ? l_x[j] : WG_OOB);             \
+        l_dy[j] += l_dy_step;                                                                     \
+        l_x[j] += l_x_step;                                                                       \
+        int ox__ = r_ox[j] + adv_r, oy__ = r_oy[j] + adv_qr;                                      \
+        const int c1__ = ox__ >= Wo;                                                              \
+        ox__ -= c1__ ? Wo : 0; oy__ += c1__;                                                      \
+        oy__ -= oy__ >= Ho ? Ho : 0;                                                              \
+        r_ox[j] = ox__; r_oy[j] = oy__;                                                           \
+      }                                                                                           \
+    } else {                                                                                      \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                               \
       const int p__ = pb__ + row_lo + 16 * j;                                                     \
       const bool in__ = p__ < p_end;                                                              \
@@ -145,6 +181,7 @@ __global__ void __launch_bounds__(512) wgrad_big_kernel(const WgArgs args) {
       const int c3__ = oy__ >= Ho;                                                                \
       oy__ -= c3__ ? Ho : 0; n__ += c3__;                                                         \
       r_ox[j] = ox__; r_oy[j] = oy__; r_n[j] = n__;                                               \
+    }                                                                                             \
     }                                                                                             \
     ++g_iss;                                                                                      \
   } while (0)
@@ -206,10 +243,11 @@ __global__ void __launch_bounds__(512) wgrad_big_kernel(const WgArgs args) {
   if (g_iss >= 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   WGB_BARRIER();
-  WGB_LOADSEG(0);
-  if (wave_m == 1) WGB_BARRIER();
   int g = 0;
+  // (the pre-roll load segment is written out in both branches: each loop then gets its fragment registers from
+  // its own dominating block — with one shared pre-roll the second loop copied all 48 of them every K step)
   if (wave_m == 0) {
+    WGB_LOADSEG(0);
 #pragma unroll 1
     while (true) {
       WGB_COMPUTESEG();
@@ -218,12 +256,17 @@ __global__ void __launch_bounds__(512) wgrad_big_kernel(const WgArgs args) {
       WGB_LOADSEG(g & 3);
       WGB_BARRIER();
     }
+    WGB_BARRIER();   // pairs with group 1's last one
   } else {
+    WGB_LOADSEG(0);
+    WGB_BARRIER();
+    // same loop shape as group 0 (break AFTER the barrier): with the break in front of it the compiler double
+    // buffered the 48 fragment registers and copied them back every K step (50 v_mov per iteration)
 #pragma unroll 1
     while (true) {
       WGB_COMPUTESEG();
-      if (++g == ksteps) break;
       WGB_BARRIER();
+      if (++g == ksteps) break;
       WGB_LOADSEG(g & 3);
       WGB_BARRIER();
     }
@@ -355,12 +398,21 @@ bool rn_wgrad_big_plan(const rn_wgrad_problem* p, WgArgs& a) {
 int rn_launch_wgrad_big(const WgArgs& a, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    RN_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+    RN_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_big_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     LDS_BYTES));
+    RN_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_big_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      LDS_BYTES));
     attr_set = true;
   }
+  bool linear = a.sh == 1 && a.sw == 1 && a.pt == (a.R - 1) / 2 && a.pl == (a.S - 1) / 2 && (a.R & 1) && (a.S & 1);
+  for (int i = 0; i < a.nseg; ++i) {
+    const WgSegDev& s = a.seg[i];
+    linear = linear && s.Ho == s.H && s.Wo == s.W &&
+             (long long)s.N * s.H * s.W * (s.xS > s.dyS ? s.xS : s.dyS) * 2 < (1ll << 31) - (1ll << 24);
+  }
   dim3 grid((unsigned)(a.co_tiles * a.ci_tiles * a.R * a.S * a.total_chunks));
-  hipLaunchKernelGGL(wgrad_big_kernel, grid, dim3(512), LDS_BYTES, st, a);
+  if (linear) hipLaunchKernelGGL(wgrad_big_kernel<true>, grid, dim3(512), LDS_BYTES, st, a);
+  else hipLaunchKernelGGL(wgrad_big_kernel<false>, grid, dim3(512), LDS_BYTES, st, a);
   RN_CHECK_LAUNCH();
   return RN_OK;
 }
