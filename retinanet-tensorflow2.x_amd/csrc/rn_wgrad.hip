@@ -41,6 +41,8 @@ __device__ __forceinline__ bf16x8_t wg_frag(const char* tile, int kb, int lane, 
   return r;
 }
 
+// LINEAR: see wgrad_big_kernel — stride 1, same-size, symmetric padding: constant source-offset advance per K step
+template <bool LINEAR>
 __global__ void __launch_bounds__(WG_THREADS, 2) wgrad_kernel(const WgArgs args) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (A 16K + B 16K)
   // XCD-aware block -> (chunk, tile) map: blocks are dispatched round-robin over the 8 XCDs, so give
@@ -120,9 +122,39 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wgrad_kernel(const WgArgs args)
   const int adv_q = WG_BK / Wo, adv_r = WG_BK - adv_q * Wo;      // 64 pixels = adv_q rows + adv_r columns
   const int adv_qn = adv_q / Ho, adv_qr = adv_q - adv_qn * Ho;   //            = adv_qn images + adv_qr rows + ...
 
+  unsigned l_dy[4], l_x[4];
+  const int y_bad = r < args.pt ? 0 : (r > args.pt ? Ho - 1 : -1), x_bad = s < args.pl ? 0 : (s > args.pl ? Wo - 1 : -1);
+  if (LINEAR) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = (j * 4 + wave) * 4 + d_row;
+      const int chunkc = d_pos ^ ((row & 3) << 2);
+      const int p0 = p_begin + row;
+      l_dy[j] = (unsigned)((p0 * sg.dyS + co0 + chunkc * 8) * 2);
+      l_x[j] = (unsigned)(((p0 + (r - args.pt) * W + (s - args.pl)) * sg.xS + ci0 + chunkc * 8) * 2);
+    }
+  }
+  const unsigned l_dy_step = (unsigned)(WG_BK * sg.dyS * 2), l_x_step = (unsigned)(WG_BK * sg.xS * 2);
+
 #define WG_ISSUE(buf, p0_)                                                                        \
   do {                                                                                            \
     char* st__ = smem + (buf) * (2 * WG_TILE_BYTES);                                              \
+    if (LINEAR) {                                                                                 \
+      const int left__ = p_end - (p0_);                                                           \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                             \
+        const bool in__ = (j * 4 + wave) * 4 + d_row < left__;                                    \
+        wg_dma16(rs_dy, st__ + (j * 4 + wave) * 1024, in__ ? l_dy[j] : WG_OOB);                   \
+        const bool ok__ = in__ && r_oy[j] != y_bad && r_ox[j] != x_bad;                           \
+        wg_dma16(rs_x, st__ + WG_TILE_BYTES + (j * 4 + wave) * 1024, ok__ ? l_x[j] : WG_OOB);     \
+        l_dy[j] += l_dy_step;                                                                     \
+        l_x[j] += l_x_step;                                                                       \
+        int ox__ = r_ox[j] + adv_r, oy__ = r_oy[j] + adv_qr;                                      \
+        const int c1__ = ox__ >= Wo;                                                              \
+        ox__ -= c1__ ? Wo : 0; oy__ += c1__;                                                      \
+        oy__ -= oy__ >= Ho ? Ho : 0;                                                              \
+        r_ox[j] = ox__; r_oy[j] = oy__;                                                           \
+      }                                                                                           \
+    } else                                                                                        \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
       const int row__ = (j * 4 + wave) * 4 + d_row;                                               \
       const int chunk__ = d_pos ^ ((row__ & 3) << 2);                                             \
@@ -300,9 +332,17 @@ extern "C" int rn_conv2d_nhwc_wgrad(const rn_wgrad_problem* p, float* dw, float 
     return RN_OK;
   }
   const int lds = 4 * WG_TILE_BYTES;
-  RN_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  RN_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  RN_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   dim3 grid((unsigned)(a.gco * a.ci_tiles * a.R * a.S * a.co_groups * a.total_chunks));
-  hipLaunchKernelGGL(wgrad_kernel, grid, dim3(WG_THREADS), lds, st, a);
+  bool linear = a.sh == 1 && a.sw == 1 && a.pt == (a.R - 1) / 2 && a.pl == (a.S - 1) / 2 && (a.R & 1) && (a.S & 1);
+  for (int i = 0; i < a.nseg; ++i) {
+    const WgSegDev& s = a.seg[i];
+    linear = linear && s.Ho == s.H && s.Wo == s.W &&
+             (long long)s.N * s.H * s.W * (s.xS > s.dyS ? s.xS : s.dyS) * 2 < (1ll << 31) - (1ll << 24);
+  }
+  if (linear) hipLaunchKernelGGL(wgrad_kernel<true>, grid, dim3(WG_THREADS), lds, st, a);
+  else hipLaunchKernelGGL(wgrad_kernel<false>, grid, dim3(WG_THREADS), lds, st, a);
   RN_CHECK_LAUNCH();
   const long long n = (long long)a.Cout * a.R * a.S * a.Cin;
   const long long n4 = n / 4;
