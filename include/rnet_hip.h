@@ -247,6 +247,14 @@ int rn_conv2d_nhwc_wgrad(const rn_wgrad_problem* problem /* host */, float* dw, 
  * rn_upsample_zero2x first.  w_ohwi is the f32 master in compute layout [Cout][R][S][Cin]. */
 int rn_pack_conv_weight_dgrad(const float* w_ohwi, int R, int S, int Cin, int Cout, int Cout_pad, void* w_packed,
                               void* stream);
+/* the same for many layers in one launch (host array of descriptors; any n, chunked by RN_DGRAD_PACK_MAX) */
+#define RN_DGRAD_PACK_MAX 64
+typedef struct {
+  const float* w_ohwi; /* f32 master [Cout][R][S][Cin] */
+  void* w_packed;      /* bf16 [cout_pad(Cin)][R][S][Cout_pad] */
+  int32_t R, S, Cin, Cout, Cout_pad, pad_;
+} rn_dgrad_pack;
+int rn_pack_conv_weight_dgrad_batch(const rn_dgrad_pack* items /* host */, int n, void* stream);
 /* f32 [P,C] -> bf16 [P,Cpad], zero padded channels (dy of the 36/720-channel prediction convs is
  * padded to a multiple of 64 so it can be the K dimension of the dgrad GEMM) */
 int rn_cast_pad_f32_to_bf16(const float* x, void* y, int64_t P, int C, int Cpad, void* stream);
@@ -313,6 +321,9 @@ typedef struct {
 size_t rn_bn_workspace_bytes(const rn_bn_problem* problem /* host */);
 size_t rn_bn_partial_offset_bytes(const rn_bn_problem* problem, int segment);   /* forward-stats partials in the workspace */
 int rn_bn_stats(const rn_bn_problem* problem, void* workspace, size_t workspace_bytes, void* stream);
+/* rn_bn_stats + rn_bn_finalize in one call for single-replica BatchNorm (no all-reduce between them): the final
+ * reduction kernel finishes each channel with the finalize arithmetic — same values, one launch less per layer */
+int rn_bn_stats_finalize(const rn_bn_problem* problem, void* workspace, size_t workspace_bytes, void* stream);
 int rn_bn_finalize(const rn_bn_problem* problem, void* stream);
 int rn_bn_apply(const rn_bn_problem* problem, void* stream);
 int rn_bn_bwd_reduce(const rn_bn_problem* problem, void* workspace, size_t workspace_bytes, void* stream);

@@ -175,6 +175,53 @@ pack_dgrad_kernel(const float* __restrict__ w, int R, int S, int Cin, int Cout, 
     out[i] = rn_f32_to_bf16(v);
   }
 }
+// every trainable conv's dgrad weights in one launch (one grid row per layer): the training step repacks ~60
+// layers after each optimizer step, and 60 launches of a few microseconds each are mostly launch latency
+struct DgradPackArgs {
+  int n;
+  rn_dgrad_pack item[RN_DGRAD_PACK_MAX];
+};
+__global__ void __launch_bounds__(256) pack_dgrad_batch_kernel(const DgradPackArgs a) {
+  const rn_dgrad_pack& it = a.item[blockIdx.y];
+  const int R = it.R, S = it.S, Cin = it.Cin, Cout = it.Cout, Cout_pad = it.Cout_pad;
+  const int Cin_pad = Cin <= 64 ? 64 : ((Cin + 127) / 128) * 128;   // rn_conv_cout_pad(Cin)
+  const long long total = (long long)Cin_pad * R * S * Cout_pad;
+  const float* __restrict__ w = it.w_ohwi;
+  uint16_t* __restrict__ out = (uint16_t*)it.w_packed;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int co = (int)(i % Cout_pad);
+    long long t = i / Cout_pad;
+    const int s = (int)(t % S);
+    t /= S;
+    const int r = (int)(t % R);
+    const int ci = (int)(t / R);
+    float v = 0.0f;
+    if (ci < Cin && co < Cout) v = w[(((long long)co * R + (R - 1 - r)) * S + (S - 1 - s)) * Cin + ci];
+    out[i] = rn_f32_to_bf16(v);
+  }
+}
+extern "C" int rn_pack_conv_weight_dgrad_batch(const rn_dgrad_pack* items, int n, void* stream) {
+  RN_CHECK_ARG(items && n >= 0, "rn_pack_conv_weight_dgrad_batch: bad argument");
+  for (int base = 0; base < n; base += RN_DGRAD_PACK_MAX) {
+    DgradPackArgs a;
+    a.n = n - base < RN_DGRAD_PACK_MAX ? n - base : RN_DGRAD_PACK_MAX;
+    long long most = 0;
+    for (int i = 0; i < a.n; ++i) {
+      const rn_dgrad_pack& it = items[base + i];
+      RN_CHECK_ARG(it.w_ohwi && it.w_packed && it.R > 0 && it.S > 0 && it.Cin > 0 && it.Cout > 0 &&
+                       it.Cout_pad >= it.Cout, "rn_pack_conv_weight_dgrad_batch: bad item %d", base + i);
+      a.item[i] = it;
+      const long long total = (long long)rn_conv_cout_pad(it.Cin) * it.R * it.S * it.Cout_pad;
+      if (total > most) most = total;
+    }
+    const int bx = (int)(rn_cdiv(most, 256) < 256 ? rn_cdiv(most, 256) : 256);
+    hipLaunchKernelGGL(pack_dgrad_batch_kernel, dim3(bx, a.n), dim3(256), 0, (hipStream_t)stream, a);
+    RN_CHECK_LAUNCH();
+  }
+  return RN_OK;
+}
+
 extern "C" int rn_pack_conv_weight_dgrad(const float* w_ohwi, int R, int S, int Cin, int Cout, int Cout_pad,
                                          void* out, void* stream) {
   RN_CHECK_ARG(w_ohwi && out && R > 0 && S > 0 && Cin > 0 && Cout > 0 && Cout_pad >= Cout,

@@ -116,7 +116,7 @@ struct BnSegDev {
   const float* sample_scale; long long rows_per_sample;
 };
 struct BnArgs {
-  int nseg, act, bessel, mode;
+  int nseg, act, bessel, mode, fuse_finalize;
   float eps, momentum, count_scale;
   float* ws;           // partials: [seg][chunk][2][C] laid out with ws_off
   long long ws_off[RN_CONV_MAX_SEGMENTS];
@@ -198,6 +198,25 @@ __global__ void __launch_bounds__(TR_THREADS) bn_colreduce_kernel(const BnArgs a
 // per workgroup (32 channels x 32 lanes): lane j adds chunks j, j+32, ... in order (double), the 32 lane
 // sums are then added in lane order — a fixed association, so the result is deterministic.  (With 8 lanes
 // the 32-deep dependent load chain made each of the ~115 launches per step take ~12 us.)
+// forward finalize of one channel: sums (local or all-reduced) -> mean, invstd, scale, shift; moving stats
+__device__ __forceinline__ void bn_finalize_channel(const BnArgs& a, const BnSegDev& s, int c, double sum, double sumsq) {
+  const double n = (double)s.P * (double)a.count_scale;
+  const double mean = sum / n;
+  double var = sumsq / n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float istd = (float)(1.0 / sqrt(var + (double)a.eps));
+  const float sc = s.gamma[c] * istd;
+  s.fwd[0 * s.C + c] = (float)mean;
+  s.fwd[1 * s.C + c] = istd;
+  s.fwd[2 * s.C + c] = sc;
+  s.fwd[3 * s.C + c] = s.beta[c] - (float)mean * sc;
+  if (s.moving_mean) {
+    const double vm = a.bessel && n > 1.0 ? var * n / (n - 1.0) : var;
+    s.moving_mean[c] = s.moving_mean[c] * a.momentum + (float)mean * (1.0f - a.momentum);
+    s.moving_var[c] = s.moving_var[c] * a.momentum + (float)vm * (1.0f - a.momentum);
+  }
+}
+
 __global__ void __launch_bounds__(1024) bn_colreduce_final_kernel(const BnArgs a) {
   const BnSegDev& s = a.seg[blockIdx.y];
   __shared__ double red[2][32][33];
@@ -222,30 +241,20 @@ __global__ void __launch_bounds__(1024) bn_colreduce_final_kernel(const BnArgs a
       for (int j = 0; j < 32; ++j) t += red[which][j][cl];
       float* out = a.mode == 0 ? s.sums : s.bsums;
       out[which * s.C + cc] = (float)t;
+      red[which][0][cl] = (double)(float)t;   // for the fused finalize below (same value the unfused path reads)
     }
+  }
+  if (a.fuse_finalize) {   // single-replica BatchNorm: bn_finalize_kernel's arithmetic without a second launch
+    __syncthreads();
+    if (threadIdx.x < 32 && c < s.C) bn_finalize_channel(a, s, c, red[0][0][cl], red[1][0][cl]);
   }
 }
 
-// forward finalize: sums (local or all-reduced) -> mean, invstd, scale, shift; moving stats
 __global__ void bn_finalize_kernel(const BnArgs a) {
   const BnSegDev& s = a.seg[blockIdx.y];
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= s.C) return;
-  const double n = (double)s.P * (double)a.count_scale;
-  const double mean = (double)s.sums[c] / n;
-  double var = (double)s.sums[s.C + c] / n - mean * mean;
-  if (var < 0.0) var = 0.0;
-  const float istd = (float)(1.0 / sqrt(var + (double)a.eps));
-  const float sc = s.gamma[c] * istd;
-  s.fwd[0 * s.C + c] = (float)mean;
-  s.fwd[1 * s.C + c] = istd;
-  s.fwd[2 * s.C + c] = sc;
-  s.fwd[3 * s.C + c] = s.beta[c] - (float)mean * sc;
-  if (s.moving_mean) {
-    const double vm = a.bessel && n > 1.0 ? var * n / (n - 1.0) : var;
-    s.moving_mean[c] = s.moving_mean[c] * a.momentum + (float)mean * (1.0f - a.momentum);
-    s.moving_var[c] = s.moving_var[c] * a.momentum + (float)vm * (1.0f - a.momentum);
-  }
+  bn_finalize_channel(a, s, c, (double)s.sums[c], (double)s.sums[s.C + c]);
 }
 
 // z = act(y*scale + shift + residual).  The grid-stride is rounded to a multiple of C/8 so a
@@ -343,7 +352,7 @@ __global__ void __launch_bounds__(TR_THREADS) bn_bwd_apply_kernel(const BnArgs a
 // mode 0 (forward statistics) honours rn_bn_segment.ext_chunks: stage-1 partials written by the conv epilogue
 static int bn_fill(const rn_bn_problem* p, BnArgs& a, int need_ws, int mode = 1) {
   if (!p || p->num_segments < 1 || p->num_segments > RN_CONV_MAX_SEGMENTS) return -1;
-  a.nseg = p->num_segments; a.act = p->act; a.bessel = p->bessel; a.mode = 0;
+  a.nseg = p->num_segments; a.act = p->act; a.bessel = p->bessel; a.mode = 0; a.fuse_finalize = 0;
   a.eps = p->eps; a.momentum = p->momentum; a.count_scale = p->count_scale > 0 ? p->count_scale : 1.0f;
   long long off = 0;
   for (int i = 0; i < p->num_segments; ++i) {
@@ -391,7 +400,7 @@ extern "C" size_t rn_bn_partial_offset_bytes(const rn_bn_problem* p, int segment
 }
 
 static int bn_colreduce(const rn_bn_problem* p, int mode, void* ws, size_t ws_bytes, hipStream_t st,
-                        const char* fn) {
+                        const char* fn, int fuse_finalize = 0) {
   BnArgs a;
   RN_CHECK_ARG(bn_fill(p, a, 1, mode) == 0, "%s: bad problem (C %% 8 == 0, 1..10 segments)", fn);
   int n_ext = 0;
@@ -402,6 +411,10 @@ static int bn_colreduce(const rn_bn_problem* p, int mode, void* ws, size_t ws_by
     return RN_ENOMEM;
   }
   a.mode = mode;
+  a.fuse_finalize = fuse_finalize;
+  if (fuse_finalize)
+    for (int i = 0; i < a.nseg; ++i)
+      RN_CHECK_ARG(a.seg[i].fwd && a.seg[i].gamma && a.seg[i].beta, "%s: null tensor", fn);
   a.ws = (float*)ws;
   int max_chunks = 0, max_slabs = 0, max_c = 0;
   for (int i = 0; i < a.nseg; ++i) {
@@ -430,6 +443,9 @@ static int bn_colreduce(const rn_bn_problem* p, int mode, void* ws, size_t ws_by
 
 extern "C" int rn_bn_stats(const rn_bn_problem* p, void* ws, size_t ws_bytes, void* stream) {
   return bn_colreduce(p, 0, ws, ws_bytes, (hipStream_t)stream, "rn_bn_stats");
+}
+extern "C" int rn_bn_stats_finalize(const rn_bn_problem* p, void* ws, size_t ws_bytes, void* stream) {
+  return bn_colreduce(p, 0, ws, ws_bytes, (hipStream_t)stream, "rn_bn_stats_finalize", 1);
 }
 extern "C" int rn_bn_bwd_reduce(const rn_bn_problem* p, void* ws, size_t ws_bytes, void* stream) {
   return bn_colreduce(p, 1, ws, ws_bytes, (hipStream_t)stream, "rn_bn_bwd_reduce");

@@ -25,6 +25,11 @@ class RnetError(RuntimeError):
     pass
 
 
+class DgradPack(Structure):   # rn_dgrad_pack
+    _fields_ = [("w_ohwi", c_void_p), ("w_packed", c_void_p), ("R", c_int32), ("S", c_int32), ("Cin", c_int32),
+                ("Cout", c_int32), ("Cout_pad", c_int32), ("pad_", c_int32)]
+
+
 class ExampleInfo(Structure):   # rn_example_info
     _fields_ = [("image_offset", c_uint64), ("image_length", c_uint64), ("image_id", c_int64),
                 ("n_xmins", c_int32), ("n_ymins", c_int32), ("n_xmaxs", c_int32), ("n_ymaxs", c_int32),
@@ -139,6 +144,7 @@ _SIGNATURES = {
     "rn_wgrad_workspace_bytes": (c_size_t, [POINTER(WgradProblem)]),
     "rn_conv2d_nhwc_wgrad": (c_int, [POINTER(WgradProblem), c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
     "rn_pack_conv_weight_dgrad": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rn_pack_conv_weight_dgrad_batch": (c_int, [POINTER(DgradPack), c_int, c_void_p]),
     "rn_cast_pad_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "rn_upsample_zero2x": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rn_cast_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
@@ -146,6 +152,7 @@ _SIGNATURES = {
     "rn_bn_workspace_bytes": (c_size_t, [POINTER(BnProblem)]),
     "rn_bn_partial_offset_bytes": (c_size_t, [POINTER(BnProblem), c_int]),
     "rn_bn_stats": (c_int, [POINTER(BnProblem), c_void_p, c_size_t, c_void_p]),
+    "rn_bn_stats_finalize": (c_int, [POINTER(BnProblem), c_void_p, c_size_t, c_void_p]),
     "rn_bn_finalize": (c_int, [POINTER(BnProblem), c_void_p]),
     "rn_bn_apply": (c_int, [POINTER(BnProblem), c_void_p]),
     "rn_bn_bwd_reduce": (c_int, [POINTER(BnProblem), c_void_p, c_size_t, c_void_p]),

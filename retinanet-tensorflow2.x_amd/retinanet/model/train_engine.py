@@ -538,6 +538,19 @@ class TrainEngine:
         self._keep.append(p)
         return p
 
+    def _bn_stats_finalize(self, prb, ws, sums, st):
+        """Batch statistics -> (mean, invstd, scale, shift) + moving statistics.  One replica: the final reduction
+        kernel also finalizes; SyncBN: the [2][C] sums are all-reduced between the two."""
+        lib = self.lib
+        if not self.sync_bn and os.environ.get("RNET_FUSE_BN_FINALIZE", "1") != "0":
+            _C.check(lib.rn_bn_stats_finalize(prb, _C.ptr(ws), ws.numel(), st), "rn_bn_stats_finalize")
+            return
+        _C.check(lib.rn_bn_stats(prb, _C.ptr(ws), ws.numel(), st), "rn_bn_stats")
+        if self.sync_bn:
+            import torch.distributed as dist
+            dist.all_reduce(sums, group=self.pg)
+        _C.check(lib.rn_bn_finalize(prb, st), "rn_bn_finalize")
+
     def _bn_problem(self, ops, conv_problem=None):
         """BatchNorm problem over `ops`.  With `conv_problem` (the launch that produces the raw outputs): when the
         dispatcher runs it on the 256-row kernel, the forward statistics' stage-1 partial sums are written by the
@@ -638,11 +651,7 @@ class TrainEngine:
 
                     def run_stem(st, p=p, prb=prb, ws=ws, sums=sums):
                         self._launch_conv(p, st, "stem(train)")
-                        _C.check(lib.rn_bn_stats(prb, _C.ptr(ws), ws.numel(), st), "rn_bn_stats")
-                        if self.sync_bn:
-                            import torch.distributed as dist
-                            dist.all_reduce(sums, group=self.pg)
-                        _C.check(lib.rn_bn_finalize(prb, st), "rn_bn_finalize")
+                        self._bn_stats_finalize(prb, ws, sums, st)
                         _C.check(lib.rn_bn_apply(prb, st), "rn_bn_apply")
                     self.fwd_steps.append(run_stem)
                 else:
@@ -667,11 +676,7 @@ class TrainEngine:
 
                     def run(st, pc=pc, prb=prb, ws=ws, sums=sums):
                         self._launch_conv(pc, st, "conv(train)")
-                        _C.check(lib.rn_bn_stats(prb, _C.ptr(ws), ws.numel(), st), "rn_bn_stats")
-                        if self.sync_bn:
-                            import torch.distributed as dist
-                            dist.all_reduce(sums, group=self.pg)
-                        _C.check(lib.rn_bn_finalize(prb, st), "rn_bn_finalize")
+                        self._bn_stats_finalize(prb, ws, sums, st)
                         _C.check(lib.rn_bn_apply(prb, st), "rn_bn_apply")
                     self.fwd_steps.append(run)
                 else:
@@ -696,11 +701,7 @@ class TrainEngine:
 
                     def run_dw(st, prd=prd, prb=prb, ws=ws, sums=sums):
                         _C.check(lib.rn_depthwise_conv2d_nhwc_fwd(prd, st), "depthwise(train)")
-                        _C.check(lib.rn_bn_stats(prb, _C.ptr(ws), ws.numel(), st), "rn_bn_stats")
-                        if self.sync_bn:
-                            import torch.distributed as dist
-                            dist.all_reduce(sums, group=self.pg)
-                        _C.check(lib.rn_bn_finalize(prb, st), "rn_bn_finalize")
+                        self._bn_stats_finalize(prb, ws, sums, st)
                         _C.check(lib.rn_bn_apply(prb, st), "rn_bn_apply")
                     self.fwd_steps.append(run_dw)
                 else:
@@ -1123,8 +1124,18 @@ class TrainEngine:
     # ---- one training step -----------------------------------------------------------------------------
     def refresh_dgrad_weights(self, st):
         lib = self.lib
-        for (mptr, k, cin, cout, cw, buf) in self.dgrad_packs:
-            _C.check(lib.rn_pack_conv_weight_dgrad(mptr, k, k, cin, cout, cw, buf.data_ptr(), st), "pack dgrad")
+        if self.dgrad_packs and os.environ.get("RNET_BATCH_DGRAD_PACK", "1") == "0":   # A/B switch (tools/)
+            for (mptr, k, cin, cout, cw, buf) in self.dgrad_packs:
+                _C.check(lib.rn_pack_conv_weight_dgrad(mptr, k, k, cin, cout, cw, buf.data_ptr(), st), "pack dgrad")
+        elif self.dgrad_packs:
+            if getattr(self, "_dgrad_pack_items", None) is None:   # descriptors are static: build them once
+                arr = (_C.DgradPack * len(self.dgrad_packs))()
+                for i, (mptr, k, cin, cout, cw, buf) in enumerate(self.dgrad_packs):
+                    arr[i].w_ohwi, arr[i].w_packed = mptr, buf.data_ptr()
+                    arr[i].R, arr[i].S, arr[i].Cin, arr[i].Cout, arr[i].Cout_pad = k, k, cin, cout, cw
+                self._dgrad_pack_items = arr
+            _C.check(lib.rn_pack_conv_weight_dgrad_batch(self._dgrad_pack_items, len(self.dgrad_packs), st),
+                     "pack dgrad")
         for (mptr, k, C, buf) in self.dw_flip_packs:
             _C.check(lib.rn_pack_depthwise_weight_flip(mptr, k, C, buf.data_ptr(), st), "pack dw flip")
 

@@ -167,8 +167,11 @@ def test_bn_train_forward_backward(cuda, act, use_res):
     p, dev = _bn_problem(cuda, segs, act)
     ws = _ws(lib.rn_bn_workspace_bytes(ctypes.byref(p)), cuda)
     st = _C.current_stream()
-    _C.check(lib.rn_bn_stats(ctypes.byref(p), _C.ptr(ws), ws.numel(), st))
-    _C.check(lib.rn_bn_finalize(ctypes.byref(p), st))
+    if use_res:   # the two forms of the forward statistics must agree: separate calls / fused finalize
+        _C.check(lib.rn_bn_stats(ctypes.byref(p), _C.ptr(ws), ws.numel(), st))
+        _C.check(lib.rn_bn_finalize(ctypes.byref(p), st))
+    else:
+        _C.check(lib.rn_bn_stats_finalize(ctypes.byref(p), _C.ptr(ws), ws.numel(), st))
     _C.check(lib.rn_bn_apply(ctypes.byref(p), st))
     _C.check(lib.rn_bn_bwd_reduce(ctypes.byref(p), _C.ptr(ws), ws.numel(), st))
     _C.check(lib.rn_bn_bwd_apply(ctypes.byref(p), st))
