@@ -59,16 +59,18 @@ focal_kernel(LossLevels lv, int B, int K, long long A, const float* __restrict__
        i += (long long)gridDim.x * blockDim.x) {
     int l = 0;
     while (l + 1 < lv.num_levels && i >= lv.vbeg[l + 1]) ++l;
-    const long long local = i - lv.vbeg[l];
-    const long long n_l = lv.off[l + 1] - lv.off[l];
-    const long long row = local / KV;  // b * n_l + j
-    const int kv = (int)(local - row * KV);
-    const long long b = row / n_l;
-    const long long j = row - b * n_l;
-    const float ct = class_targets[b * A + lv.off[l] + j];
+    // 32-bit index arithmetic inside a level (the launcher checks B * n_l * K / V < 2^32): the 64-bit divisions
+    // this replaced cost ~120 VALU instructions each, per 4 logits — the kernel was division-bound, not HBM-bound
+    const unsigned local = (unsigned)(i - lv.vbeg[l]);
+    const unsigned n_l = (unsigned)(lv.off[l + 1] - lv.off[l]);
+    const unsigned row = local / (unsigned)KV;  // b * n_l + j
+    const int kv = (int)(local - row * (unsigned)KV);
+    const unsigned b = row / n_l;
+    const unsigned j = row - b * n_l;
+    const float ct = class_targets[(long long)b * A + lv.off[l] + j];
     const bool ignore = (ct == -2.0f);
     const int cls = (int)ct;
-    const float* src = lv.cls[l] + row * K + (long long)kv * V;
+    const float* src = lv.cls[l] + (long long)row * K + (long long)kv * V;
     float x[V], g[V];
     if (V == 4) {
       const float4 v = *(const float4*)src;
@@ -85,7 +87,7 @@ focal_kernel(LossLevels lv, int B, int K, long long A, const float* __restrict__
       g[u] = gr * gs;
     }
     if (write_grad) {
-      float* dst = lv.dcls[l] + row * K + (long long)kv * V;
+      float* dst = lv.dcls[l] + (long long)row * K + (long long)kv * V;
       if (V == 4) *(float4*)dst = make_float4(g[0], g[1 % V], g[2 % V], g[3 % V]);
       else dst[0] = g[0];
     }
@@ -215,6 +217,8 @@ extern "C" int rn_retinanet_loss_fwd_bwd(const float* const* class_logits, const
   hipStream_t st = (hipStream_t)stream;
   double* cls_part = (double*)workspace;
   double* box_part = cls_part + 2048;
+  for (int l = 0; l < num_levels; ++l)
+    RN_CHECK_ARG(lv.vbeg[l + 1] - lv.vbeg[l] < (1ll << 32), "rn_retinanet_loss: level %d has >= 2^32 logit vectors", l);
   const int nb_cls = loss_blocks(lv.vbeg[num_levels]);
   const int nb_box = loss_blocks((long long)B * A);
   if (V == 4)
