@@ -338,8 +338,6 @@ static bool conv_use_big(const rn_conv_problem* p) {
 
 // 3x3 / stride 1 / pad 1 launches of the 256-row class go to the halo kernel (rn_conv_halo.hip) when every
 // segment's worst tile fits its patch buffer.
-static int g_conv_stagger = 0;   // start stagger of the persistent 3x3 kernel, in units of 64 cycles per phase
-extern "C" void rn_debug_conv_stagger(int units) { g_conv_stagger = units; }
 static int g_conv_halo = 1;
 extern "C" void rn_debug_conv_halo(int on) { g_conv_halo = on; }   // tools/, tests: A/B against conv_big_kernel
 
@@ -446,10 +444,7 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
       default: break;
     }
   }
-  if (big && conv_use_halo(p)) {
-    a.pad_ = g_conv_stagger;
-    return rn_launch_conv_halo(a, f32, st);
-  }
+  if (big && conv_use_halo(p)) return rn_launch_conv_halo(a, f32, st);
   if (big) {
     a.pad_ = 1;   // float-reciprocal index arithmetic in the tile set-up, valid while every M < 2^22
     for (int i = 0; i < a.nseg; ++i)

@@ -14,7 +14,8 @@
 
 #ifdef HALO_PROF   // probe builds (tools/probes/build_halo_ablate.sh): cycle stamps of workgroup 0, thread 0
 __device__ unsigned long long g_halo_clk[32];
-#define EPI_STAMP(k_) if (blockIdx.x == 0 && threadIdx.x == 0 && g_halo_clk[k_] == 0) g_halo_clk[k_] = clock64();
+// (unconditional store, no read-back: a load here would wait, through vmcnt, for every store issued before it)
+#define EPI_STAMP(k_) if (blockIdx.x == 0 && threadIdx.x == 0) g_halo_clk[k_] = clock64();
 #else
 #define EPI_STAMP(k_)
 #endif

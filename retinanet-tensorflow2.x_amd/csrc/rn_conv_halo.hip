@@ -294,16 +294,6 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
     asm volatile("" ::: "memory");          \
   } while (0)
 
-  // Start stagger.  Every workgroup walks tiles of the same length, so without it all 256 CUs reach their
-  // epilogues together: 256 x 128 KB of stores hit L2 / HBM as one burst every tile period, the store queues back
-  // up and each epilogue takes as long as the whole burst needs to drain (measured 23 000 cycles against
-  // ~5 000 alone) with the MFMA pipes idle.  A one-off start delay of (16 phases) x args.pad_ x 64 cycles
-  // spreads the epilogues over the burst's length for the rest of the launch.
-  if (args.pad_ > 0) {
-    const int phase = (blockIdx.x * 5) & 15;
-#pragma unroll 1
-    for (int k = 0; k < phase * args.pad_; ++k) __builtin_amdgcn_s_sleep(1);
-  }
 #ifdef HALO_PROF
   if (blockIdx.x == 0 && tid == 0) { g_halo_clk[0] = clock64(); g_halo_clk[1] = wall_clock64(); for (int q = 8; q < 32; ++q) g_halo_clk[q] = 0; }
 #endif
@@ -358,12 +348,12 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
   HALO_LOADSEG(next_tap_);                    \
   HALO_BARRIER();
 #ifdef HALO_PROF
-#define HALO_EPI_PROBE(k_) if (blockIdx.x == 0 && tid == 0 && g_halo_clk[k_] == 0) g_halo_clk[k_] = clock64();
+#define HALO_EPI_PROBE(k_) if (blockIdx.x == 0 && tid == 0) g_halo_clk[k_] = clock64();
 #else
 #define HALO_EPI_PROBE(k_)
 #endif
 #ifdef HALO_PROF
-#define HALO_EPI_PROBE2() if (blockIdx.x == 0 && tid == 0 && g_halo_clk[9] != 0 && g_halo_clk[10] == 0) g_halo_clk[10] = clock64();
+#define HALO_EPI_PROBE2() if (blockIdx.x == 0 && tid == 0) g_halo_clk[10] = clock64();
 #else
 #define HALO_EPI_PROBE2()
 #endif

@@ -39,7 +39,6 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--ablate", type=int, default=0)
     ap.add_argument("--zeros", action="store_true", help="all-zero activations and weights (DVFS check: no toggling)")
-    ap.add_argument("--stagger", type=int, default=-1, help="start stagger of conv_halo_kernel, 64-cycle units per phase")
     ap.add_argument("--halo-grid", type=int, default=0, help="limit conv_halo_kernel to this many workgroups")
     ap.add_argument("--raw", action="store_true", help="no scale / shift / activation (the training forward's raw conv output)")
     ap.add_argument("--no-halo", action="store_true", help="3x3 launches on conv_big_kernel instead of conv_halo_kernel")
@@ -55,8 +54,6 @@ def main():
         lib.rn_debug_conv_halo(0)
     if a.halo_grid:
         lib.rn_debug_conv_halo_grid(a.halo_grid)
-    if a.stagger >= 0:
-        lib.rn_debug_conv_stagger(a.stagger)
     dev = torch.device("cuda:0")
     for name in a.preset.split(","):
         segs, k, stride, f32, use_res = PRESETS[name]
