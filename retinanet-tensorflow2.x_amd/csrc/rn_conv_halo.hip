@@ -329,10 +329,12 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
     big_epilogue<OUT_F32, HAS_RES>(acc, args, c_si, c_m0, c_n0, wave,                              \
                           smem + (c_par ^ 1) * PIX_BYTES + wave * 4096 /* 32 KB of the dead 40 KB patch */); \
     HALO_EPI_PROBE(9);                                                                    \
+    HALO_EPI_COUNT();                                                                     \
     if (c_v + G >= total) break;                                                          \
     c_v += G;                                                                             \
     HALO_LANE_CONSTS();                                                                   \
     HALO_SETUP_COMPUTE();                                                                 \
+    HALO_EPI_PROBE_AT(11, 2);                                                             \
   }
 #define HALO_STEP0(next_tap_)                 \
   HALO_COMPUTESEG();                          \
@@ -348,19 +350,25 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
   HALO_LOADSEG(next_tap_);                    \
   HALO_BARRIER();
 #ifdef HALO_PROF
-#define HALO_EPI_PROBE(k_) if (blockIdx.x == 0 && tid == 0) g_halo_clk[k_] = clock64();
+#define HALO_EPI_COUNT() ++epi_
+#define HALO_EPI_PROBE_AT(k_, e_) if (blockIdx.x == 0 && tid == 0 && epi_ == (e_)) g_halo_clk[k_] = clock64();
+#define HALO_EPI_PROBE(k_) if (blockIdx.x == 0 && tid == 0 && epi_ == 1) g_halo_clk[k_] = clock64();
 #else
+#define HALO_EPI_COUNT()
+#define HALO_EPI_PROBE_AT(k_, e_)
 #define HALO_EPI_PROBE(k_)
 #endif
 #ifdef HALO_PROF
-#define HALO_EPI_PROBE2() if (blockIdx.x == 0 && tid == 0) g_halo_clk[10] = clock64();
+#define HALO_EPI_PROBE2() if (blockIdx.x == 0 && tid == 0 && epi_ == 2) g_halo_clk[10] = clock64();
 #else
 #define HALO_EPI_PROBE2()
 #endif
 #ifdef HALO_PROF
-  int pass_ = 0;
+  int g_pass_after_ = 0;
+  int pass_ = 0, epi_ = 0;   // stamps of the SECOND tile of workgroup 0
 #define HALO_PASS_PROBE() \
   if (blockIdx.x == 0 && tid == 0 && pass_ >= 2 && pass_ < 6) g_halo_clk[2 + pass_] = clock64(); \
+  if (blockIdx.x == 0 && tid == 0 && epi_ == 2 && g_pass_after_ < 4) g_halo_clk[24 + g_pass_after_++] = clock64(); \
   ++pass_;
 #else
 #define HALO_PASS_PROBE()
