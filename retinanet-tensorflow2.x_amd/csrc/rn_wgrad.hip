@@ -224,20 +224,40 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wgrad_kernel(const WgArgs args)
     }
 }
 
+// Ordered split-K reduction: dw[i] = sum_c ws[c][i] (+ beta * dw[i]).  256 threads = 64 float4 columns x 4 chunk
+// lanes: lane q sums chunks q, q+4, q+8, ... (independent loads, a quarter of the serial chain of the one-thread-per
+// -column form, which was latency bound at ~22 us per launch), then the four partial sums are added in lane order —
+// a fixed tree, so the result does not depend on the launch geometry.
 __global__ void __launch_bounds__(256)
 wgrad_reduce_kernel(const float4* __restrict__ ws, long long n4, int chunks, float4* __restrict__ dw, float beta) {
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
-       i += (long long)gridDim.x * blockDim.x) {
+  __shared__ float4 part[4][64];
+  const int col = threadIdx.x & 63, q = threadIdx.x >> 6;
+  for (long long base = blockIdx.x * 64ll; base < n4; base += (long long)gridDim.x * 64) {
+    const long long i = base + col;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int c = 0; c < chunks; ++c) {
-      const float4 v = ws[(long long)c * n4 + i];
-      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    if (i < n4) {
+#pragma unroll 4
+      for (int c = q; c < chunks; c += 4) {
+        const float4 v = ws[(long long)c * n4 + i];
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+      }
     }
-    if (beta != 0.0f) {
-      const float4 o = dw[i];
-      a.x += beta * o.x; a.y += beta * o.y; a.z += beta * o.z; a.w += beta * o.w;
+    part[q][col] = a;
+    __syncthreads();
+    if (q == 0 && i < n4) {
+      float4 r = part[0][col];
+#pragma unroll
+      for (int k = 1; k < 4; ++k) {
+        const float4 v = part[k][col];
+        r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w;
+      }
+      if (beta != 0.0f) {
+        const float4 o = dw[i];
+        r.x += beta * o.x; r.y += beta * o.y; r.z += beta * o.z; r.w += beta * o.w;
+      }
+      dw[i] = r;
     }
-    dw[i] = a;
+    __syncthreads();
   }
 }
 
@@ -325,7 +345,7 @@ extern "C" int rn_conv2d_nhwc_wgrad(const rn_wgrad_problem* p, float* dw, float 
     if (rc != RN_OK) return rc;
     const long long nb = (long long)a.Cout * a.R * a.S * a.Cin;
     const long long nb4 = nb / 4;
-    int blocksb = (int)(rn_cdiv(nb4, 256) < 2048 ? rn_cdiv(nb4, 256) : 2048);
+    int blocksb = (int)(rn_cdiv(nb4, 64) < 4096 ? rn_cdiv(nb4, 64) : 4096);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocksb), dim3(256), 0, st, (const float4*)workspace, nb4,
                        a.total_chunks, (float4*)dw, beta);
     RN_CHECK_LAUNCH();
@@ -346,7 +366,7 @@ extern "C" int rn_conv2d_nhwc_wgrad(const rn_wgrad_problem* p, float* dw, float 
   RN_CHECK_LAUNCH();
   const long long n = (long long)a.Cout * a.R * a.S * a.Cin;
   const long long n4 = n / 4;
-  int blocks = (int)(rn_cdiv(n4, 256) < 2048 ? rn_cdiv(n4, 256) : 2048);
+  int blocks = (int)(rn_cdiv(n4, 64) < 4096 ? rn_cdiv(n4, 64) : 4096);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)workspace, n4,
                      a.total_chunks, (float4*)dw, beta);
   RN_CHECK_LAUNCH();
