@@ -217,15 +217,18 @@ __device__ __forceinline__ void bn_finalize_channel(const BnArgs& a, const BnSeg
   }
 }
 
+// 1024 threads = 16 channels x 64 chunk lanes (the 32 x 32 form spent most of its ~9 us per launch in 50-deep serial
+// load chains on 8 workgroups); every lane sums its chunks in double, the 64 lane sums are added in lane order
 __global__ void __launch_bounds__(1024) bn_colreduce_final_kernel(const BnArgs a) {
   const BnSegDev& s = a.seg[blockIdx.y];
-  __shared__ double red[2][32][33];
-  const int cl = threadIdx.x & 31, lane = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  __shared__ double red[2][64][17];
+  const int cl = threadIdx.x & 15, lane = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   double t0 = 0.0, t1 = 0.0;
   if (c < s.C) {
     const float* p = a.ws + a.ws_off[blockIdx.y];
-    for (int k = lane; k < s.chunks; k += 32) {
+#pragma unroll 4
+    for (int k = lane; k < s.chunks; k += 64) {
       t0 += (double)p[((long long)k * 2 + 0) * s.C + c];
       t1 += (double)p[((long long)k * 2 + 1) * s.C + c];
     }
@@ -233,12 +236,12 @@ __global__ void __launch_bounds__(1024) bn_colreduce_final_kernel(const BnArgs a
   red[0][lane][cl] = t0;
   red[1][lane][cl] = t1;
   __syncthreads();
-  if (threadIdx.x < 64) {
-    const int which = threadIdx.x >> 5;
-    const int cc = blockIdx.x * 32 + cl;
+  if (threadIdx.x < 32) {
+    const int which = threadIdx.x >> 4;
+    const int cc = blockIdx.x * 16 + cl;
     if (cc < s.C) {
       double t = 0.0;
-      for (int j = 0; j < 32; ++j) t += red[which][j][cl];
+      for (int j = 0; j < 64; ++j) t += red[which][j][cl];
       float* out = a.mode == 0 ? s.sums : s.bsums;
       out[which * s.C + cc] = (float)t;
       red[which][0][cl] = (double)(float)t;   // for the fused finalize below (same value the unfused path reads)
@@ -246,7 +249,7 @@ __global__ void __launch_bounds__(1024) bn_colreduce_final_kernel(const BnArgs a
   }
   if (a.fuse_finalize) {   // single-replica BatchNorm: bn_finalize_kernel's arithmetic without a second launch
     __syncthreads();
-    if (threadIdx.x < 32 && c < s.C) bn_finalize_channel(a, s, c, red[0][0][cl], red[1][0][cl]);
+    if (threadIdx.x < 16 && c < s.C) bn_finalize_channel(a, s, c, red[0][0][cl], red[1][0][cl]);
   }
 }
 
@@ -436,7 +439,7 @@ static int bn_colreduce(const rn_bn_problem* p, int mode, void* ws, size_t ws_by
     }
     RN_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(bn_colreduce_final_kernel, dim3((max_c + 31) / 32, a.nseg), dim3(1024), 0, st, a);
+  hipLaunchKernelGGL(bn_colreduce_final_kernel, dim3((max_c + 15) / 16, a.nseg), dim3(1024), 0, st, a);
   RN_CHECK_LAUNCH();
   return RN_OK;
 }
