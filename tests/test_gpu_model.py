@@ -51,6 +51,19 @@ def test_forward_matches_cpu_restatement(cuda, size, balanced, act):
             assert err.mean().item() <= 0.01 * scale + 1e-4, (key, lv, err.mean().item(), scale)
 
 
+def test_forward_through_the_persistent_kernels(cuda):
+    """The same network with every eligible layer forced onto the 256 x 256 persistent kernels (conv_big_kernel,
+    and conv_halo_kernel for the 3x3 / stride 1 layers) — at test sizes the dispatcher would otherwise keep the
+    128-row kernel, so this is the whole-network parity check of the kernels the full-size bench runs on."""
+    from retinanet import _C
+    lib = _C.lib()
+    lib.rn_debug_conv_tile(2)
+    try:
+        test_forward_matches_cpu_restatement(cuda, 256, True, "relu")
+    finally:
+        lib.rn_debug_conv_tile(0)
+
+
 def test_serving_path_end_to_end(cuda):
     """images -> boxes/scores/classes/valid (model/builder.py:153-190): run the HIP
     post-process and the oracle post-process on the SAME HIP head outputs -> bit-exact; and the

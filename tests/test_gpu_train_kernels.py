@@ -210,7 +210,8 @@ def test_bn_train_forward_backward(cuda, act, use_res):
         torch.testing.assert_close(d["moving_var"].cpu().double(), mv, rtol=1e-5, atol=1e-5)
 
 
-def test_bn_forward_stats_fused_into_conv_epilogue(cuda):
+@pytest.mark.parametrize("k", [1, 3])
+def test_bn_forward_stats_fused_into_conv_epilogue(cuda, k):
     """rn_conv_segment.bn_partial + rn_bn_segment.ext_chunks: the 256-row conv kernel writes the per-128-row partial
     sums, rn_bn_stats only runs the final reduction.  Must give the statistics of the unfused path on the same
     stored bf16 output (fp32 summation order differs), including pixel tails and a channel tail (Cout 320)."""
@@ -219,16 +220,16 @@ def test_bn_forward_stats_fused_into_conv_epilogue(cuda):
     g = torch.Generator().manual_seed(23)
     shapes = [(2, 19, 21, 128, 256), (1, 16, 16, 128, 320), (3, 7, 5, 128, 512)]   # N, H, W, Cin, Cout
     pc = _C.ConvProblem()
-    pc.R = pc.S = 1
+    pc.R = pc.S = k            # k = 3: the halo-patch kernel (rn_conv_halo.hip), same epilogue
     pc.stride_h = pc.stride_w = 1
-    pc.pad_top = pc.pad_left = 0
+    pc.pad_top = pc.pad_left = (k - 1) // 2
     pc.act, pc.out_dtype, pc.num_segments = _C.RN_ACT_NONE, _C.RN_DT_BF16, len(shapes)
     keep, ys, segs = [], [], []
     for i, (N, H, W, cin, cout) in enumerate(shapes):
         x = _bf(torch.randn((N, H, W, cin), generator=g)).to(cuda)
-        w = (torch.randn((1, 1, cin, cout), generator=g) / 8 + 0.02).to(cuda).contiguous()
-        wp = torch.empty((lib.rn_conv_cout_pad(cout), 1, 1, cin), dtype=torch.bfloat16, device=cuda)
-        _C.check(lib.rn_pack_conv_weight(_C.ptr(w), 1, 1, cin, cout, cin, _C.ptr(wp), _C.current_stream()))
+        w = (torch.randn((k, k, cin, cout), generator=g) / (8 * k) + 0.02 / k).to(cuda).contiguous()
+        wp = torch.empty((lib.rn_conv_cout_pad(cout), k, k, cin), dtype=torch.bfloat16, device=cuda)
+        _C.check(lib.rn_pack_conv_weight(_C.ptr(w), k, k, cin, cout, cin, _C.ptr(wp), _C.current_stream()))
         y = torch.empty((N, H, W, cout), dtype=torch.bfloat16, device=cuda)
         s = pc.seg[i]
         s.x, s.w, s.y, s.scale, s.shift, s.residual = x.data_ptr(), wp.data_ptr(), y.data_ptr(), None, None, None
@@ -241,6 +242,7 @@ def test_bn_forward_stats_fused_into_conv_epilogue(cuda):
     lib.rn_debug_conv_tile(2)
     try:
         assert lib.rn_conv_tile_rows(ctypes.byref(pc)) == 256
+        assert lib.rn_conv_kernel_id(ctypes.byref(pc)) == (2 if k == 3 else 1)
         sums = {}
         for fused in (False, True):
             p, dev = _bn_problem(cuda, segs, None)

@@ -73,7 +73,7 @@ def _engine_grad(eng, k):
 
 
 @pytest.mark.parametrize("size,B,balanced,freeze", [(256, 4, True, True), (256, 3, False, True), (256, 2, True, False)])
-def test_backward_wiring_dense_upstream(cuda, size, B, balanced, freeze):
+def test_backward_wiring_dense_upstream(cuda, size, B, balanced, freeze, min_cos=None, med_cos=None):
     """Whole-network backward (heads -> BalanceFeatures -> FPN -> ResNet) for a dense random
     upstream gradient on the predictions, against autograd through the bf16-emulating CPU
     restatement.  bf16 gradients through ~25 layers leave ~0.25 relative noise per tensor, so
@@ -102,14 +102,35 @@ def test_backward_wiring_dense_upstream(cuda, size, B, balanced, freeze):
         rows.append((_cos(got, want), got.double().norm().item() / (want.norm().item() + 1e-30), k))
     rows.sort()
     small = size < 200   # 1x1 / 2x2 pyramid levels: BatchNorm over a handful of samples is noisier
-    assert rows[0][0] > (0.80 if small else 0.90), rows[:5]
-    assert np.median([r[0] for r in rows]) > (0.93 if small else 0.955), np.median([r[0] for r in rows])
+    assert rows[0][0] > (min_cos if min_cos else (0.80 if small else 0.90)), rows[:5]
+    assert np.median([r[0] for r in rows]) > (med_cos if med_cos else (0.93 if small else 0.955)), np.median([r[0] for r in rows])
     ratios = np.array([r[1] for r in rows])
     assert np.median(np.abs(ratios - 1)) < 0.03 and np.abs(ratios - 1).max() < 0.35, (ratios.min(), ratios.max())
     # the layers next to the loss see almost no accumulated rounding noise
     last = {r[2]: r[0] for r in rows}
     assert last["class-head/class-head-prediction-conv2d/kernel"] > 0.995
     assert last["box-head/box-head-prediction-conv2d/kernel"] > 0.995
+
+
+def test_backward_wiring_through_the_persistent_kernels(cuda):
+    """The same whole-network backward with every eligible layer forced onto the 256-wide persistent kernels
+    (conv_big / conv_halo for forward and data gradients, their fused BatchNorm statistics, wgrad_big for the
+    weight gradients) — the kernels the full-size training bench runs on, which the dispatcher would not pick at
+    test sizes."""
+    from retinanet import _C
+    lib = _C.lib()
+    lib.rn_debug_conv_tile(2)
+    lib.rn_debug_wgrad_big_min_pixels(1)
+    try:
+        # The 256-row kernels round the accumulator to bf16 BEFORE scale / shift / residual (TensorFlow's separate
+        # Conv2D and BiasAdd / BatchNorm / Add ops each materialise a bf16 tensor); the 128-row kernel and the
+        # oracle apply them in fp32 and round once.  Measured against the oracle (tools/debug_persistent_parity.py):
+        # forward relative error 0.030 -> 0.061, gradient cosine median 0.972 -> 0.941, minimum 0.944 -> 0.886;
+        # wgrad_big alone changes nothing.
+        test_backward_wiring_dense_upstream(cuda, 256, 4, True, True, min_cos=0.85, med_cos=0.92)
+    finally:
+        lib.rn_debug_conv_tile(0)
+        lib.rn_debug_wgrad_big_min_pixels(16384)
 
 
 def test_train_step_losses_and_optimizer_arithmetic(cuda):
