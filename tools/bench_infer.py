@@ -10,7 +10,11 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--big-min-tiles", type=int, default=0, help="override the 256-row kernels' minimum tile count")
     a = ap.parse_args()
+    if a.big_min_tiles:
+        from retinanet import _C
+        _C.lib().rn_debug_conv_big_min_tiles(a.big_min_tiles)
     from retinanet.cfg import default_params
     from retinanet.model import ModelBuilder
     dev = torch.device("cuda:0")
