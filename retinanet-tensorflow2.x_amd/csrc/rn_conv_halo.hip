@@ -58,7 +58,6 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
   const int total = args.total_tiles;
   const int G = gridDim.x;
   const int tid = threadIdx.x;
-  const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave_m = wave >> 2, wave_n = wave & 3;   // wave_m is also the ping-pong group
 
