@@ -128,3 +128,32 @@ def test_val_batches(cuda, params, tmp_path):
             np.testing.assert_array_equal(b["resize_scale"][j].numpy(), scale)
             seen.append(image_id)
     assert sorted(seen) == sorted(by_id)
+
+
+def test_training_steps_from_tfrecords(cuda, params, tmp_path):
+    """The whole chain on real files: TFRecord shards -> InputPipeline (parse, augment, batch, GPU label encoding)
+    -> TrainEngine.train_step.  Losses must be finite and fall over a few steps on the repeated tiny dataset."""
+    from retinanet.dataloader.input_pipeline import InputPipeline
+    from retinanet.model import ModelBuilder
+    from retinanet.model.train_engine import TrainEngine
+    from retinanet.optimizers import build_optimizer
+    samples = _samples(6, seed=21)
+    _write(tmp_path, "train", samples, 2)
+    aug = {"use_augmentation": True, "horizontal_flip": True, "scale_jitter": {"min_scale": 0.8, "max_scale": 1.25}}
+    p = _params(params, tmp_path, 128, aug, 2)
+    p.architecture.batch_norm.use_sync = False
+    p.architecture.backbone.depth = 26
+    p.training.optimizer.lr_params.warmup_learning_rate = 0.01
+    p.training.optimizer.lr_params.initial_learning_rate = 0.02
+    builder = ModelBuilder(p, "train", device=cuda, seed=3)
+    model = builder()
+    model.optimizer = build_optimizer(p.training.optimizer, p.training.train_steps, p.floatx.precision)
+    eng = TrainEngine(model, 2, frozen_regexes=[])
+    pipe = InputPipeline("train", p, False, 1, device=cuda)
+    it = pipe()
+    losses = []
+    for _ in range(12):
+        images, targets = next(it)
+        losses.append(eng.train_step(images, targets)["weighted-loss"].item())
+    assert all(np.isfinite(losses)), losses
+    assert np.mean(losses[-3:]) < np.mean(losses[:3]), losses
