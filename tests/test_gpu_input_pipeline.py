@@ -157,3 +157,42 @@ def test_training_steps_from_tfrecords(cuda, params, tmp_path):
         losses.append(eng.train_step(images, targets)["weighted-loss"].item())
     assert all(np.isfinite(losses)), losses
     assert np.mean(losses[-3:]) < np.mean(losses[:3]), losses
+
+
+def test_eval_chain_from_tfrecords(cuda, params, tmp_path):
+    """executor._eval_step + COCOEvaluator on real files: val TFRecords -> InputPipeline('val') -> serving model ->
+    COCOEvaluator.accumulate_results: one detection list per image id, boxes in ORIGINAL-image pixels (the
+    resize_scale of the pipeline undone, int32 truncation), bit-exact against the oracle's accumulation."""
+    from retinanet.dataloader.input_pipeline import InputPipeline
+    from retinanet.eval import COCOEvaluator
+    from retinanet.model import ModelBuilder
+    samples = _samples(5, seed=31)
+    _write(tmp_path, "val", samples, 1)
+    p = _params(params, tmp_path, 128, {"use_augmentation": False}, 2)
+    p.inference.score_threshold = 0.005
+    b = ModelBuilder(p, "val", device=cuda, seed=4)
+    model = b()
+    infer = {bs: b.add_post_processing_stage(model) for bs in (1, 2)}
+    ev = COCOEvaluator([128, 128], categories=[{"id": i + 1, "name": f"c{i:02d}"} for i in range(80)],
+                       remap_class_ids=True)
+    hw = {s[3]: s[0].shape[:2] for s in samples}
+    seen = []
+    for batch in InputPipeline("val", p, False, 1, device=cuda)():
+        det = infer[int(batch["image"].shape[0])](batch["image"])
+        res = {"image_id": batch["image_id"].numpy(), "resize_scale": batch["resize_scale"].numpy(), "detections": det}
+        n0 = len(ev.processed_detections)
+        ev.accumulate_results(res)
+        valid = det["valid_detections"].cpu().numpy()
+        wb, wc = o.coco_accumulate(det["boxes"].cpu().numpy(), det["classes"].cpu().numpy(), valid,
+                                   batch["resize_scale"].numpy(), (128, 128), class_lut=ev._lut)
+        k = n0
+        for i, image_id in enumerate(batch["image_id"].tolist()):
+            seen.append(image_id)
+            for d in range(int(valid[i])):
+                r = ev.processed_detections[k]
+                k += 1
+                assert r["image_id"] == image_id and r["bbox"] == wb[i, d].tolist() and r["category_id"] == int(wc[i, d])
+                h, w = hw[image_id]
+                assert -2 <= r["bbox"][0] <= w + 2 and -2 <= r["bbox"][1] <= h + 2   # original-image pixels
+        assert k == len(ev.processed_detections)
+    assert sorted(seen) == sorted(hw)
