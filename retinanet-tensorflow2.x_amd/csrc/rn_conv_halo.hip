@@ -50,7 +50,51 @@ constexpr int W_STAGE = BN * BK * 2;                     // 16 KB of weights per
 constexpr int W_STAGES = 3;                              // 9 taps = 3 x 3: the ring stage of a tap is tap % 3
 constexpr int W_RING = 2 * PIX_BYTES;
 constexpr int PA_TABLE = W_RING + W_STAGES * W_STAGE;    // per-thread source offsets of the patch pieces
-constexpr int LDS_BYTES = PA_TABLE + PIECES * 512 * 4;   // 80 + 48 + 10 = 138 KB
+constexpr int SEG_TABLE = PA_TABLE + PIECES * 512 * 4;   // segment descriptors the tile set-ups need (see HaloSeg)
+constexpr int LDS_BYTES = SEG_TABLE + 16 * 4 + RN_CONV_MAX_SEGMENTS * 64;   // 80 + 48 + 10 + <1 = 139 KB
+
+// What the three tile set-ups read of a segment, copied into LDS once per kernel: reading ConvArgs through the
+// scalar cache cost each set-up a chain of dependent s_loads (the segment search alone one per segment) — measured
+// ~5 000 cycles per set-up, three set-ups per tile.  From LDS it is one round of broadcast reads.
+struct HaloSeg {
+  const uint16_t* x;
+  const uint16_t* w;
+  int N, H, W, pix_stride, Cout, M, tile_begin, n_tiles, CinP;
+};
+// layout: 16 dwords of tile_begin (INT_MAX past the last segment), then 16 dwords per segment
+__device__ __forceinline__ void halo_seg_table_fill(char* smem, const ConvArgs& args, int tid) {
+  int* tb = (int*)(smem + SEG_TABLE);
+  if (tid < 16) tb[tid] = tid < args.nseg ? args.seg[tid < RN_CONV_MAX_SEGMENTS ? tid : 0].tile_begin : 0x7fffffff;
+  if (tid < args.nseg) {
+    const ConvSegDev& g = args.seg[tid];
+    unsigned* d = (unsigned*)(smem + SEG_TABLE + 64 + tid * 64);
+    const unsigned long long px = (unsigned long long)g.x, pw = (unsigned long long)g.w;
+    d[0] = (unsigned)px; d[1] = (unsigned)(px >> 32); d[2] = (unsigned)pw; d[3] = (unsigned)(pw >> 32);
+    d[4] = g.N; d[5] = g.H; d[6] = g.W; d[7] = g.pix_stride;
+    d[8] = g.Cout; d[9] = g.M; d[10] = g.tile_begin; d[11] = g.n_tiles;
+    d[12] = g.CinP; d[13] = 0; d[14] = 0; d[15] = 0;
+  }
+}
+__device__ __forceinline__ int halo_seg_of_tile(const char* smem, int tile) {
+  const int4* tb = (const int4*)(smem + SEG_TABLE);
+  const int4 a = tb[0], b = tb[1], c = tb[2];
+  int si = (tile >= a.y) + (tile >= a.z) + (tile >= a.w) + (tile >= b.x) + (tile >= b.y) + (tile >= b.z) +
+           (tile >= b.w) + (tile >= c.x) + (tile >= c.y);
+  return __builtin_amdgcn_readfirstlane(si);
+}
+__device__ __forceinline__ HaloSeg halo_seg(const char* smem, int si) {
+  const uint4* d = (const uint4*)(smem + SEG_TABLE + 64 + si * 64);
+  const uint4 q0 = d[0], q1 = d[1], q2 = d[2], q3 = d[3];
+  HaloSeg g;
+#define HALO_U(v_) ((unsigned)__builtin_amdgcn_readfirstlane((int)(v_)))
+  g.x = (const uint16_t*)(((unsigned long long)HALO_U(q0.y) << 32) | HALO_U(q0.x));
+  g.w = (const uint16_t*)(((unsigned long long)HALO_U(q0.w) << 32) | HALO_U(q0.z));
+  g.N = (int)HALO_U(q1.x); g.H = (int)HALO_U(q1.y); g.W = (int)HALO_U(q1.z); g.pix_stride = (int)HALO_U(q1.w);
+  g.Cout = (int)HALO_U(q2.x); g.M = (int)HALO_U(q2.y); g.tile_begin = (int)HALO_U(q2.z); g.n_tiles = (int)HALO_U(q2.w);
+  g.CinP = (int)HALO_U(q3.x);
+#undef HALO_U
+  return g;
+}
 
 template <bool OUT_F32, bool HAS_RES>
 __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
@@ -76,10 +120,8 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
 #define HALO_SETUP_PIX()                                                                              \
   do {                                                                                                \
     const int tile__ = tile_of(p_v, total);                                                           \
-    int si__ = 0;                                                                                     \
-    _Pragma("unroll 1") for (int i = 1; i < args.nseg; ++i)                                           \
-      if (tile__ >= args.seg[i].tile_begin) si__ = i;                                                 \
-    const ConvSegDev& sg__ = args.seg[si__];                                                          \
+    const int si__ = halo_seg_of_tile(smem, tile__);                                                  \
+    const HaloSeg sg__ = halo_seg(smem, si__);                                                        \
     const int lt__ = tile__ - sg__.tile_begin;                                                        \
     const int m0__ = rn_fdiv(lt__, sg__.n_tiles, __frcp_rn((float)sg__.n_tiles)) * BM;                \
     const int H__ = sg__.H, W__ = sg__.W, PS__ = sg__.pix_stride, W1__ = W__ + 1, H1__ = H__ + 1;     \
@@ -142,10 +184,8 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
 #define HALO_SETUP_W()                                                                                \
   do {                                                                                                \
     const int tile__ = tile_of(w_v, total);                                                           \
-    int si__ = 0;                                                                                     \
-    _Pragma("unroll 1") for (int i = 1; i < args.nseg; ++i)                                           \
-      if (tile__ >= args.seg[i].tile_begin) si__ = i;                                                 \
-    const ConvSegDev& sg__ = args.seg[si__];                                                          \
+    const int si__ = halo_seg_of_tile(smem, tile__);                                                  \
+    const HaloSeg sg__ = halo_seg(smem, si__);                                                        \
     const int lt__ = tile__ - sg__.tile_begin;                                                        \
     const int n0__ = (lt__ - rn_fdiv(lt__, sg__.n_tiles, __frcp_rn((float)sg__.n_tiles)) * sg__.n_tiles) * BN; \
     w_nch = sg__.CinP / BK;                                                                           \
@@ -202,10 +242,8 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
 #define HALO_SETUP_COMPUTE()                                                                          \
   do {                                                                                                \
     const int tile__ = tile_of(c_v, total);                                                           \
-    c_si = 0;                                                                                         \
-    _Pragma("unroll 1") for (int i = 1; i < args.nseg; ++i)                                           \
-      if (tile__ >= args.seg[i].tile_begin) c_si = i;                                                 \
-    const ConvSegDev& sg__ = args.seg[c_si];                                                          \
+    c_si = halo_seg_of_tile(smem, tile__);                                                            \
+    const HaloSeg sg__ = halo_seg(smem, c_si);                                                        \
     const int lt__ = tile__ - sg__.tile_begin;                                                        \
     const int mt__ = rn_fdiv(lt__, sg__.n_tiles, __frcp_rn((float)sg__.n_tiles));                     \
     c_m0 = mt__ * BM;                                                                                 \
@@ -297,6 +335,8 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
   if (blockIdx.x == 0 && tid == 0) { g_halo_clk[0] = clock64(); g_halo_clk[1] = wall_clock64(); for (int q = 8; q < 32; ++q) g_halo_clk[q] = 0; }
 #endif
   // ---- prologue -------------------------------------------------------------------------------------------
+  halo_seg_table_fill(smem, args, tid);
+  __syncthreads();
   HALO_SETUP_PIX();
   HALO_SETUP_W();
   HALO_SETUP_COMPUTE();
@@ -367,7 +407,7 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
   int pass_ = 0, epi_ = 0;   // stamps of the SECOND tile of workgroup 0
 #define HALO_PASS_PROBE() \
   if (blockIdx.x == 0 && tid == 0 && pass_ >= 2 && pass_ < 6) g_halo_clk[2 + pass_] = clock64(); \
-  if (blockIdx.x == 0 && tid == 0 && epi_ == 2 && g_pass_after_ < 4) g_halo_clk[24 + g_pass_after_++] = clock64(); \
+  if (blockIdx.x == 0 && tid == 0 && pass_ < 10) g_halo_clk[22 + pass_] = clock64(); \
   ++pass_;
 #else
 #define HALO_PASS_PROBE()

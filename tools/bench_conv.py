@@ -100,7 +100,7 @@ def main():
                 print(f"  workgroup 0: {cyc} core cycles in {wall:.1f} us -> {cyc / wall / 1e3:.3f} GHz; "
                       f"cycles per slot in passes 2-4 of tile 0: {[round((clk[5 + i] - clk[4 + i]) / 18) for i in range(3)]}; "
                       f"2nd tile: epilogue {clk[9] - clk[8]} cycles, + set-up {int(clk[11]) - int(clk[9])}, + load segment {int(clk[10]) - int(clk[11])}, "
-                      f"then to the starts of the next passes {[int(clk[24 + i]) - int(clk[10]) for i in range(4)]}; "
+                      f"cycles per slot in passes 0..8 of the first tile (the 9th is the next tile's first): {[round((int(clk[23 + i]) - int(clk[22 + i])) / 18) for i in range(9)]}; "
                       f"inside (entry, then per 32-pixel block: transposes | read-back + stores): "
                       f"{[int(clk[k + 1] - clk[k]) for k in range(12, 21)]}")
         print(f"{name:12s} B={a.batch} {ms * 1e3:9.1f} us  {flops / ms / 1e9:8.1f} TFLOP/s  "
