@@ -375,18 +375,16 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
     HALO_SETUP_COMPUTE();                                                                 \
     HALO_EPI_PROBE_AT(11, 2);                                                             \
   }
-#define HALO_STEP0(next_tap_)                 \
-  HALO_COMPUTESEG();                          \
-  HALO_BARRIER();                             \
-  if ((next_tap_) == 0) { HALO_CHUNK_END() }  \
-  HALO_LOADSEG(next_tap_);                    \
-  if ((next_tap_) == 0) { HALO_EPI_PROBE2() }  \
-  HALO_BARRIER();
-#define HALO_STEP1(next_tap_)                 \
-  HALO_COMPUTESEG();                          \
-  if ((next_tap_) == 0) { HALO_CHUNK_END() }  \
-  HALO_BARRIER();                             \
-  HALO_LOADSEG(next_tap_);                    \
+// One loop body for both groups (the barrier that follows the compute segment sits before the tile-end work for
+// group 0 and after it for group 1): two uniform branches per K step, but half the code — the kernel is larger
+// than the instruction cache, and every tile's epilogue / set-up code is fetched again.
+#define HALO_STEP(next_tap_)                     \
+  HALO_COMPUTESEG();                             \
+  if (wave_m == 0) HALO_BARRIER();               \
+  if ((next_tap_) == 0) { HALO_CHUNK_END() }     \
+  if (wave_m == 1) HALO_BARRIER();               \
+  HALO_LOADSEG(next_tap_);                       \
+  if ((next_tap_) == 0) { HALO_EPI_PROBE2() }    \
   HALO_BARRIER();
 #ifdef HALO_PROF
 #define HALO_EPI_COUNT() ++epi_
@@ -412,19 +410,11 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
 #else
 #define HALO_PASS_PROBE()
 #endif
-  if (wave_m == 0) {
 #pragma unroll 1
-    while (true) {
-      HALO_PASS_PROBE()
-      HALO_STEP0(1) HALO_STEP0(2) HALO_STEP0(3) HALO_STEP0(4) HALO_STEP0(5) HALO_STEP0(6) HALO_STEP0(7)
-      HALO_STEP0(8) HALO_STEP0(0)
-    }
-  } else {
-#pragma unroll 1
-    while (true) {
-      HALO_STEP1(1) HALO_STEP1(2) HALO_STEP1(3) HALO_STEP1(4) HALO_STEP1(5) HALO_STEP1(6) HALO_STEP1(7)
-      HALO_STEP1(8) HALO_STEP1(0)
-    }
+  while (true) {
+    HALO_PASS_PROBE()
+    HALO_STEP(1) HALO_STEP(2) HALO_STEP(3) HALO_STEP(4) HALO_STEP(5) HALO_STEP(6) HALO_STEP(7)
+    HALO_STEP(8) HALO_STEP(0)
   }
 #ifdef HALO_PROF
   if (blockIdx.x == 0 && tid == 0) { g_halo_clk[2] = clock64(); g_halo_clk[3] = wall_clock64(); }
