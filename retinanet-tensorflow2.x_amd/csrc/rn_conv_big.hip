@@ -234,8 +234,8 @@ __global__ void __launch_bounds__(512) conv_big_kernel(const ConvArgs args) {
   if (wave_m == 1) BIG_BARRIER();
 
   // ---- main loop over this workgroup's stream --------------------------------------------------------
-  // Separate loops per group keep the hot path straight-line (a taken branch costs ~20 cycles here).
-  // Both groups execute 2N barriers for N stream steps; a finished tile is written out in the odd slot by
+  // One loop for both groups (two uniform branches around the barriers; two straight-line copies made the
+  // kernel larger than the instruction cache and cost registers).  Both groups execute 2N barriers for N stream steps; a finished tile is written out in the odd slot by
   // both (group 1 right after its MFMAs, group 0 before its load segment).
 #define BIG_TILE_END()                                       \
   if (__builtin_expect(c_k == c_ksteps, 0)) {               \
@@ -245,28 +245,16 @@ __global__ void __launch_bounds__(512) conv_big_kernel(const ConvArgs args) {
     BIG_SETUP_COMPUTE();                                    \
   }
   int g = 0;
-  if (wave_m == 0) {
 #pragma unroll 1
-    while (true) {
-      BIG_COMPUTESEG();
-      ++c_k;
-      BIG_BARRIER();
-      BIG_TILE_END();
-      ++g;
-      BIG_LOADSEG(g & 3);   // past the end of the stream: stale reads, nothing issued
-      BIG_BARRIER();
-    }
-  } else {
-#pragma unroll 1
-    while (true) {
-      BIG_COMPUTESEG();
-      ++c_k;
-      BIG_TILE_END();
-      BIG_BARRIER();
-      ++g;
-      BIG_LOADSEG(g & 3);
-      BIG_BARRIER();
-    }
+  while (true) {
+    BIG_COMPUTESEG();
+    ++c_k;
+    if (wave_m == 0) BIG_BARRIER();
+    BIG_TILE_END();
+    if (wave_m == 1) BIG_BARRIER();
+    ++g;
+    BIG_LOADSEG(g & 3);   // past the end of the stream: stale reads, nothing issued
+    BIG_BARRIER();
   }
 #undef BIG_TILE_END
 #undef BIG_SETUP_COMPUTE

@@ -244,33 +244,18 @@ __global__ void __launch_bounds__(512) wgrad_big_kernel(const WgArgs args) {
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   WGB_BARRIER();
   int g = 0;
-  // (the pre-roll load segment is written out in both branches: each loop then gets its fragment registers from
-  // its own dominating block — with one shared pre-roll the second loop copied all 48 of them every K step)
-  if (wave_m == 0) {
-    WGB_LOADSEG(0);
+  // one loop for both groups: group 1 runs one barrier ahead, group 0 closes with the matching one
+  WGB_LOADSEG(0);
+  if (wave_m == 1) WGB_BARRIER();
 #pragma unroll 1
-    while (true) {
-      WGB_COMPUTESEG();
-      WGB_BARRIER();
-      if (++g == ksteps) break;
-      WGB_LOADSEG(g & 3);
-      WGB_BARRIER();
-    }
-    WGB_BARRIER();   // pairs with group 1's last one
-  } else {
-    WGB_LOADSEG(0);
+  while (true) {
+    WGB_COMPUTESEG();
     WGB_BARRIER();
-    // same loop shape as group 0 (break AFTER the barrier): with the break in front of it the compiler double
-    // buffered the 48 fragment registers and copied them back every K step (50 v_mov per iteration)
-#pragma unroll 1
-    while (true) {
-      WGB_COMPUTESEG();
-      WGB_BARRIER();
-      if (++g == ksteps) break;
-      WGB_LOADSEG(g & 3);
-      WGB_BARRIER();
-    }
+    if (++g == ksteps) break;
+    WGB_LOADSEG(g & 3);
+    WGB_BARRIER();
   }
+  if (wave_m == 0) WGB_BARRIER();
 #undef WGB_BARRIER
 #undef WGB_COMPUTESEG
 #undef WGB_LOADSEG
