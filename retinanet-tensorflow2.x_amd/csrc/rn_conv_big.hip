@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(512) conv_big_kernel(const ConvArgs args) {
     c_k = 0;                                                                                          \
   } while (0)
 
-  // ---- epilogue of the compute-side tile (per wave; acc is cleared afterwards) --------------------
+  // ---- epilogue of the compute-side tile (per wave; acc is re-initialised for the next tile afterwards) --------------------
   auto epilogue = [&]() __attribute__((always_inline)) {
     big_epilogue<OUT_F32, HAS_RES>(acc, args, c_si, c_m0, c_n0, wave, smem + RING_BYTES + wave * PATCH_BYTES);
   };
@@ -223,6 +223,7 @@ __global__ void __launch_bounds__(512) conv_big_kernel(const ConvArgs args) {
   // ---- prologue ------------------------------------------------------------------------------------
   BIG_SETUP_ISSUE();
   BIG_SETUP_COMPUTE();
+  big_acc_init<OUT_F32, HAS_RES>(acc, args, c_si, c_n0, wave);
 #pragma unroll 1
   for (int t = 0; t < 3 && i_v < total; ++t) BIG_ISSUE_STEP();
   // stream steps 0 and 1 must be complete before the first slot
@@ -243,6 +244,7 @@ __global__ void __launch_bounds__(512) conv_big_kernel(const ConvArgs args) {
     if (c_v + G >= total) break;                            \
     c_v += G;                                               \
     BIG_SETUP_COMPUTE();                                    \
+    big_acc_init<OUT_F32, HAS_RES>(acc, args, c_si, c_n0, wave); \
   }
   int g = 0;
 #pragma unroll 1
@@ -271,6 +273,7 @@ __global__ void __launch_bounds__(512) conv_big_kernel(const ConvArgs args) {
 // internal hook kept for tools/bench_conv.py (the ablation builds were removed with the persistent rewrite)
 extern "C" void rn_debug_conv_big_ablate(int) {}
 
+extern int g_halo_grid;
 int rn_launch_conv_big(const ConvArgs& a, bool out_f32, hipStream_t st) {
   static bool attr_set = false;
   static int num_cu = 256;
@@ -290,7 +293,8 @@ int rn_launch_conv_big(const ConvArgs& a, bool out_f32, hipStream_t st) {
       num_cu = prop.multiProcessorCount;
     attr_set = true;
   }
-  const int grid = a.total_tiles < num_cu ? a.total_tiles : num_cu;   // one persistent workgroup per CU
+  int grid = a.total_tiles < num_cu ? a.total_tiles : num_cu;   // one persistent workgroup per CU
+  if (g_halo_grid > 0 && g_halo_grid < grid) grid = g_halo_grid;     // rn_debug_conv_halo_grid (tests, tools)
   bool has_res = false;   // one residual input anywhere -> the variant that carries the residual path
   for (int i = 0; i < a.nseg; ++i) has_res = has_res || a.seg[i].residual != nullptr;
   const dim3 g3(grid), b3(512);

@@ -7,13 +7,13 @@
 // tensor), transposed through a 32 x 64 LDS patch (8-byte writes), read back 16 bytes = 8 channels per lane, then
 // scale/shift (folded BN + bias), residual add, activation in fp32, full 128-byte row stores; optional fused
 // BatchNorm forward statistics of the stored values.  f32 output: 32 x 32 f32 patches per j.  `patch` is this
-// wave's 4 KB of LDS; no workgroup barrier.  Clears acc.
+// wave's 4 KB of LDS; no workgroup barrier.  The caller re-initialises acc for its next tile (big_acc_init).
 #ifndef RN_CONV_BIG_EPI_H_
 #define RN_CONV_BIG_EPI_H_
 #include "rn_conv_dev.h"
 
 #ifdef HALO_PROF   // probe builds (tools/probes/build_halo_ablate.sh): cycle stamps of workgroup 0, thread 0
-__device__ unsigned long long g_halo_clk[32];
+__device__ unsigned long long g_halo_clk[48];
 // (unconditional store, no read-back: a load here would wait, through vmcnt, for every store issued before it)
 #define EPI_STAMP(k_) if (blockIdx.x == 0 && threadIdx.x == 0) g_halo_clk[k_] = clock64();
 #else
@@ -62,6 +62,55 @@ __device__ __forceinline__ int tile_of(int v, int total) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
 }
 
+// Shift-only layers (bias + none / relu / relu6, bf16 output, no residual: the head towers): the bias is the
+// accumulators' initial value, so the epilogue rounds acc + bias to bf16 ONCE (like the reference's fp32 BiasAdd
+// followed by the cast) and needs no fp32 pass over the transposed rows — relu / relu6 act on the packed bf16.
+template <bool OUT_F32, bool HAS_RES>
+__device__ __forceinline__ bool big_bias_in_acc(const ConvArgs& args, const ConvSegDev& sg) {
+  // (compiled out of the residual variants: their launches carry folded-BatchNorm scales anyway, and the extra
+  // code cost the <false, true> kernel 6 %)
+  if (OUT_F32 || HAS_RES) return false;
+  return sg.shift != nullptr && sg.scale == nullptr &&
+         (args.act == RN_ACT_NONE || args.act == RN_ACT_RELU || args.act == RN_ACT_RELU6);
+}
+// accumulators of a new tile: zero, or the bias of the lane's channels (see the layout at the top).  The 64
+// floats of the wave come through the scalar cache (uniform address, constant address space): no vector memory
+// operation, so the counted vmcnt waits of the DMA stream are not disturbed.
+template <bool OUT_F32, bool HAS_RES>
+__device__ __forceinline__ void big_acc_init(f32x16_t (&acc)[4][2], const ConvArgs& args, int c_si, int c_n0, int wave) {
+  const ConvSegDev& sg = args.seg[c_si];
+  if (big_bias_in_acc<OUT_F32, HAS_RES>(args, sg)) {
+    typedef const float __attribute__((address_space(4))) cfloat;
+    const cfloat* b = (const cfloat*)(unsigned long long)sg.shift;
+    const int nw0 = c_n0 + (wave & 3) * 64;
+    const int Cout = sg.Cout;
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const bool hi = lane >= 32;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        int c0 = nw0 + j * 32 + g * 8;               // 8 channels: lanes 0-31 hold c0..c0+3, lanes 32-63 c0+4..c0+7
+        c0 = c0 + 8 <= Cout ? c0 : Cout - 8;         // groups past Cout are never stored: read valid memory
+        c0 = c0 < 0 ? 0 : c0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float lo_v = b[c0 + q], hi_v = b[c0 + 4 + q];
+          const float v = hi ? hi_v : lo_v;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[i][j][g * 4 + q] = v;
+        }
+      }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  }
+}
+
 // HAS_RES = false compiles the residual input out: the prefetched residual rows are global loads, and the waits
 // the compiler puts in front of their uses also wait for the stores issued before them (loads and stores share
 // vmcnt and retire in order) — with the loads merely predicated off, every 32-pixel block of a tile would still
@@ -89,7 +138,8 @@ __device__ __forceinline__ void big_epilogue(f32x16_t (&acc)[4][2], const ConvAr
       const float4 a = *(const float4*)(sg.scale + nr), b = *(const float4*)(sg.scale + nr + 4);
       sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w; sc[4] = b.x; sc[5] = b.y; sc[6] = b.z; sc[7] = b.w;
     }
-    if (nok && sg.shift) {
+    const bool bias_acc = big_bias_in_acc<OUT_F32, HAS_RES>(args, sg);   // the shift is already in acc
+    if (nok && sg.shift && !bias_acc) {
       const float4 a = *(const float4*)(sg.shift + nr), b = *(const float4*)(sg.shift + nr + 4);
       sf[0] = a.x; sf[1] = a.y; sf[2] = a.z; sf[3] = a.w; sf[4] = b.x; sf[5] = b.y; sf[6] = b.z; sf[7] = b.w;
     }
@@ -111,7 +161,7 @@ __device__ __forceinline__ void big_epilogue(f32x16_t (&acc)[4][2], const ConvAr
     const long long row_bytes = (long long)Cout * 2;
     const int act = args.act;
     const bool clamp_lo = act == RN_ACT_RELU || act == RN_ACT_RELU6, clamp_hi = act == RN_ACT_RELU6;
-    const bool plain = !sg.scale && !sg.shift && !has_res && act == RN_ACT_NONE;
+    const bool plain = (!sg.scale && !sg.shift && !has_res && act == RN_ACT_NONE) || bias_acc;
     uint4 rv[2][HAS_RES ? 4 : 1];
 #define BIG_RES_PREFETCH(buf_, i_)                                                                    \
 _Pragma("unroll") for (int pass = 0; pass < (HAS_RES ? 4 : 0); ++pass) {                            \
@@ -152,7 +202,16 @@ _Pragma("unroll") for (int pass = 0; pass < (HAS_RES ? 4 : 0); ++pass) {        
         if (m < M && nok) {
           uint4 ov;
           if (plain) {
-            ov = v;   // raw conv output (training: BatchNorm follows): the transposed bf16 rows are the result
+            // raw conv output (training: BatchNorm follows) or bias-initialised accumulators: the transposed
+            // bf16 rows are the result, up to relu / relu6 on the packed pairs (see below)
+            ov = v;
+            if (clamp_lo) {
+              ov.x = pk_max_i16(ov.x, 0u); ov.y = pk_max_i16(ov.y, 0u); ov.z = pk_max_i16(ov.z, 0u); ov.w = pk_max_i16(ov.w, 0u);
+            }
+            if (clamp_hi) {
+              ov.x = pk_min_i16(ov.x, 0x40c040c0u); ov.y = pk_min_i16(ov.y, 0x40c040c0u);
+              ov.z = pk_min_i16(ov.z, 0x40c040c0u); ov.w = pk_min_i16(ov.w, 0x40c040c0u);
+            }
           } else {
             const uint4 r4 = HAS_RES ? rv[i & 1][HAS_RES ? pass : 0] : make_uint4(0u, 0u, 0u, 0u);
             float f[8] = {bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y), bf_lo(v.z), bf_hi(v.z), bf_lo(v.w), bf_hi(v.w)};
@@ -248,11 +307,5 @@ _Pragma("unroll") for (int pass = 0; pass < (HAS_RES ? 4 : 0); ++pass) {        
       }
     }
   }
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 }
 #endif  // RN_CONV_BIG_EPI_H_

@@ -31,8 +31,8 @@
 #ifndef HALO_ABLATE
 #define HALO_ABLATE 0
 #endif
-static int g_halo_grid = 0;
-extern "C" void rn_debug_conv_halo_grid(int n) { g_halo_grid = n; }   // tools/: fewer persistent workgroups than CUs
+int g_halo_grid = 0;   // also honoured by conv_big_kernel's launcher
+extern "C" void rn_debug_conv_halo_grid(int n) { g_halo_grid = n; }   // tools/, tests: fewer persistent workgroups than CUs
 
 #ifdef HALO_PROF   // probe builds: core clock (clock64) and 100 MHz wall clock at the start / end of workgroup 0
 extern "C" int rn_debug_halo_clocks(unsigned long long* out) {
@@ -106,6 +106,9 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
   const int wave_m = wave >> 2, wave_n = wave & 3;   // wave_m is also the ping-pong group
 
   // ---- issue side, pixels: the chunk whose patch is being DMA'd (one chunk ahead of the weights' chunk) ----
+#ifdef HALO_PROF
+  int stamp_n_[4] = {0, 0, 0, 0};
+#endif
   int p_v = blockIdx.x;        // virtual tile id; exhausted when >= total
   int p_chunk = 0, p_nch = 0;  // chunk of that tile / its chunk count
   int p_par = 0;               // patch buffer it goes to
@@ -114,6 +117,11 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
   // The table address is rebuilt from a fresh lane id at every use (volatile: not hoisted), so that no
   // per-thread address stays live across the epilogue — the allocator would spill it and reload it, with an
   // `s_waitcnt vmcnt(0)`, in every load segment.
+#ifdef HALO_PROF   // clock stamps around the first in-loop pixel / weight set-up of workgroup 0, wave 0
+#define HALO_SETUP_STAMP(k_) if (blockIdx.x == 0 && tid == 0 && stamp_n_[(k_) - 32]++ == 0) g_halo_clk[k_] = clock64();
+#else
+#define HALO_SETUP_STAMP(k_)
+#endif
 #define HALO_LANE(dst_) asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(dst_))
 #define HALO_PA_AT(j_, ln_) (*(unsigned*)(smem + PA_TABLE + (j_) * 2048 + wave * 256 + (ln_) * 4))
 
@@ -163,7 +171,9 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
         p_chunk = 0;                                                                                  \
         p_v += G;                                                                                     \
         if (p_v < total) {                                                                            \
+          HALO_SETUP_STAMP(32);                                                                       \
           HALO_SETUP_PIX();                                                                           \
+          HALO_SETUP_STAMP(33);                                                                       \
         } else {  /* end of the stream: the remaining pieces are zero fills into the dead buffer */   \
           unsigned ln2__;                                                                             \
           HALO_LANE(ln2__);                                                                           \
@@ -217,7 +227,7 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
       if (++w_chunk == w_nch) {                                                                       \
         w_chunk = 0;                                                                                  \
         w_v += G;                                                                                     \
-        if (w_v < total) HALO_SETUP_W();                                                              \
+        if (w_v < total) { HALO_SETUP_STAMP(34); HALO_SETUP_W(); HALO_SETUP_STAMP(35); }              \
       }                                                                                               \
     }                                                                                                 \
   } while (0)
@@ -332,7 +342,7 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
   } while (0)
 
 #ifdef HALO_PROF
-  if (blockIdx.x == 0 && tid == 0) { g_halo_clk[0] = clock64(); g_halo_clk[1] = wall_clock64(); for (int q = 8; q < 32; ++q) g_halo_clk[q] = 0; }
+  if (blockIdx.x == 0 && tid == 0) { g_halo_clk[0] = clock64(); g_halo_clk[1] = wall_clock64(); for (int q = 8; q < 48; ++q) g_halo_clk[q] = 0; }
 #endif
   // ---- prologue -------------------------------------------------------------------------------------------
   halo_seg_table_fill(smem, args, tid);
@@ -340,6 +350,7 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
   HALO_SETUP_PIX();
   HALO_SETUP_W();
   HALO_SETUP_COMPUTE();
+  big_acc_init<OUT_F32, HAS_RES>(acc, args, c_si, c_n0, wave);
   // patch of chunk 0 (5 pieces), then the weights of stream steps 0 and 1
   {
     unsigned pa0[PIECES];
@@ -357,7 +368,7 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
   HALO_LOADSEG(0);
   if (wave_m == 1) HALO_BARRIER();
 
-  // ---- main loop: nine taps per pass, separate straight-line loops per group --------------------------------
+  // ---- main loop: nine taps per pass, one loop body for both groups --------------------------------------------
   // slot 2g: group 0 compute(g) | group 1 load(read g, issue g+3); slot 2g+1: group 0 load(read g+1, issue g+4)
   // | group 1 compute(g).  A finished tile is written out in the odd slot by both groups (group 1 right after
   // its MFMAs, group 0 before its load segment).
@@ -373,6 +384,7 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
     c_v += G;                                                                             \
     HALO_LANE_CONSTS();                                                                   \
     HALO_SETUP_COMPUTE();                                                                 \
+    big_acc_init<OUT_F32, HAS_RES>(acc, args, c_si, c_n0, wave);                          \
     HALO_EPI_PROBE_AT(11, 2);                                                             \
   }
 // One loop body for both groups (the barrier that follows the compute segment sits before the tile-end work for

@@ -188,6 +188,43 @@ def test_conv_halo_kernel(cuda, case):
         assert (got != big).float().mean().item() < 0.02
 
 
+BIAS_CASES = [
+    # N, H, W, Cin, Cout, k, act, persistent workgroups (0 = one per CU)
+    (2, 24, 24, 64, 256, 3, "relu", 0),
+    (2, 24, 24, 64, 256, 3, "relu", 2),      # 5 tiles over 2 workgroups: accumulators re-initialised in the loop
+    (7, 10, 10, 128, 320, 3, "relu6", 3),    # Cout tail: the second n-tile has 64 live channels
+    (1, 20, 20, 64, 720, 3, None, 2),        # three n-tiles, the last with 208 live channels
+    (3, 17, 19, 128, 512, 1, "relu", 3),     # 1x1 on conv_big_kernel, two n-tiles, M tail
+    (1, 20, 20, 256, 264, 1, None, 0),       # Cout = 264: one live 8-channel group in the second n-tile
+]
+
+
+@pytest.mark.parametrize("case", BIAS_CASES, ids=lambda c: "bias-" + "x".join(str(v) for v in c))
+def test_conv_bias_only_rounds_once(cuda, case):
+    """Shift-only layers (bias + none / relu / relu6) on the 256-row kernels start their accumulators at the bias
+    (rn_conv_big_epi.h big_acc_init), so the output is bf16(act(sum + bias)) with ONE rounding, like the reference's
+    fp32 BiasAdd + cast: against the float64 restatement at most a sliver of the outputs may sit one bf16 step off
+    (fp32 summation order), far fewer than the double rounding of the scale / shift path produces."""
+    from retinanet import _C
+    lib = _C.lib()
+    N, H, W, Cin, Cout, k, act, grid = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    s = {"x": torch.randn((N, H, W, Cin), generator=g),
+         "w": torch.randn((k, k, Cin, Cout), generator=g) / math.sqrt(k * k * Cin),
+         "shift": torch.randn((Cout,), generator=g)}
+    pad = (k - 1) // 2
+    lib.rn_debug_conv_tile(2)
+    lib.rn_debug_conv_halo_grid(grid)
+    try:
+        got = _conv_gpu(cuda, [s], k, 1, pad, act, False)[0]
+    finally:
+        lib.rn_debug_conv_halo_grid(0)
+        lib.rn_debug_conv_tile(0)
+    want = _conv_ref(s, k, 1, pad, act, False)
+    _close(got, want, False)
+    assert (got != want).float().mean().item() < 2e-3
+
+
 def test_conv_halo_asymmetric_weights(cuda):
     """Exact shift test through the halo kernel: output channel c = input channel (c+1)%C read through tap
     (r=0, s=2), i.e. pixel (y-1, x+1); borders must be exact zeros."""

@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--zeros", action="store_true", help="all-zero activations and weights (DVFS check: no toggling)")
     ap.add_argument("--halo-grid", type=int, default=0, help="limit conv_halo_kernel to this many workgroups")
     ap.add_argument("--raw", action="store_true", help="no scale / shift / activation (the training forward's raw conv output)")
+    ap.add_argument("--bias", action="store_true", help="shift only (bias + relu: the head towers)")
     ap.add_argument("--no-halo", action="store_true", help="3x3 launches on conv_big_kernel instead of conv_halo_kernel")
     ap.add_argument("--tile", type=int, default=0, help="1 = force 128-row kernel, 2 = force the 256x256 kernel")
     a = ap.parse_args()
@@ -77,6 +78,8 @@ def main():
             s.x, s.w, s.y, s.scale, s.shift = x.data_ptr(), w.data_ptr(), y.data_ptr(), sc.data_ptr(), sh.data_ptr()
             if a.raw:
                 s.scale, s.shift = None, None
+            if a.bias:
+                s.scale = None
             s.residual = res.data_ptr() if use_res else None
             s.N, s.H, s.W, s.Cin, s.pix_stride, s.Ho, s.Wo, s.Cout = a.batch, H, H, cin, cin, Ho, Ho, cout
             keep += [x, w, y, sc, sh, res]
@@ -94,7 +97,7 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / a.iters
         if hasattr(lib, "rn_debug_halo_clocks"):     # probe builds: core clock of workgroup 0 during the last launch
-            clk = (ctypes.c_ulonglong * 32)()
+            clk = (ctypes.c_ulonglong * 48)()
             if lib.rn_debug_halo_clocks(clk) == 0 and clk[3] > clk[1]:
                 cyc, wall = clk[2] - clk[0], (clk[3] - clk[1]) / 100.0   # wall clock ticks at 100 MHz -> us
                 print(f"  workgroup 0: {cyc} core cycles in {wall:.1f} us -> {cyc / wall / 1e3:.3f} GHz; "
@@ -102,7 +105,8 @@ def main():
                       f"2nd tile: epilogue {clk[9] - clk[8]} cycles, + set-up {int(clk[11]) - int(clk[9])}, + load segment {int(clk[10]) - int(clk[11])}, "
                       f"cycles per slot in passes 0..8 of the first tile (the 9th is the next tile's first): {[round((int(clk[23 + i]) - int(clk[22 + i])) / 18) for i in range(9)]}; "
                       f"inside (entry, then per 32-pixel block: transposes | read-back + stores): "
-                      f"{[int(clk[k + 1] - clk[k]) for k in range(12, 21)]}")
+                      f"{[int(clk[k + 1] - clk[k]) for k in range(12, 21)]}; first in-loop pixel set-up "
+                      f"{int(clk[33]) - int(clk[32])} cycles, weight set-up {int(clk[35]) - int(clk[34])}")
         print(f"{name:12s} B={a.batch} {ms * 1e3:9.1f} us  {flops / ms / 1e9:8.1f} TFLOP/s  "
               f"{byts / ms / 1e6:8.1f} GB/s (algorithmic {byts / 1e6:.1f} MB)", flush=True)
 
