@@ -67,6 +67,10 @@ class TrainEngine:
         self.step_count = 0
         self.conv_profile = None
         self.fuse_bn_stats = os.environ.get("RNET_FUSE_BN_STATS", "1") != "0"   # conv epilogue writes BN partial sums
+        # weight / bias gradient launches on a second HIP stream: nothing in the backward pass reads them, so they
+        # run beside the data-gradient chain (MFMA-bound wgrad next to the HBM-bound BatchNorm backward kernels)
+        self.side_stream_on = os.environ.get("RNET_WGRAD_STREAM", "1") != "0"
+        self._side_stream = None
         self.drop_connect = True     # stochastic depth of the EfficientNet skip blocks (efficientnet.py:97-113)
         self.dc_masks = {}           # project conv output -> (f32[B] factors, survival_prob)
         self.dc_all = self.dc_p = None
@@ -947,7 +951,8 @@ class TrainEngine:
             dw = self._pview(c.get("kvar", cname + "/kernel"), self.G)
             self._keep += [p, ws]
             a = (ctypes.byref(p), dw.data_ptr(), 0.0, ws.data_ptr(), ws.numel())
-            self.bwd_steps.append(lambda st, a=a: _C.check(lib.rn_conv2d_nhwc_wgrad(*a, st), "rn_conv2d_nhwc_wgrad"))
+            self.bwd_steps.append(self._side(lambda st, a=a: _C.check(lib.rn_conv2d_nhwc_wgrad(*a, st),
+                                                                     "rn_conv2d_nhwc_wgrad")))
             if c["bias"]:
                 # bias gradient = column sums of dy over every segment (two-stage reduction kernel)
                 pb2 = _C.BnProblem()
@@ -967,7 +972,7 @@ class TrainEngine:
                 def bias_grad(st, pr=ctypes.byref(pb2), ws2=ws2, bs=bs, db=db, n=c["cout"]):
                     _C.check(lib.rn_bn_stats(pr, _C.ptr(ws2), ws2.numel(), st), "bias colsum")
                     torch.sum(bs[:, 0, :n], dim=0, out=db)
-                self.bwd_steps.append(bias_grad)
+                self.bwd_steps.append(self._side(bias_grad))
         # (c) data gradients.  Segments of one launch must write distinct gradient buffers (both
         # heads read the same pyramid level): split the group into launches with unique inputs.
         need = [op for op in ops if self.requires.get(op["inp"])]
@@ -1022,7 +1027,8 @@ class TrainEngine:
                              device=self.dev)
             self._keep += [p, ws]
             a = (ctypes.byref(p), self._pview(d["kvar"], self.G).data_ptr(), ws.data_ptr(), ws.numel())
-            self.bwd_steps.append(lambda st, a=a: _C.check(lib.rn_depthwise_conv2d_nhwc_wgrad(*a, st), "dw wgrad"))
+            self.bwd_steps.append(self._side(lambda st, a=a: _C.check(lib.rn_depthwise_conv2d_nhwc_wgrad(*a, st),
+                                                                     "dw wgrad")))
         need = [op for op in ops if self.requires.get(op["inp"])]
         launches = []
         for op in need:
@@ -1154,6 +1160,12 @@ class TrainEngine:
             fn(st)
         return self.outputs
 
+    @staticmethod
+    def _side(fn):
+        """marks a backward step whose results only the optimizer reads (weight / bias gradients)"""
+        fn.side = True
+        return fn
+
     def backward(self, loss_grads):
         """loss_grads: RetinaNetLoss.grads (f32, per level) -> parameter gradients in self.G."""
         lib, st = self.lib, _C.current_stream()
@@ -1165,8 +1177,33 @@ class TrainEngine:
                 _C.check(lib.rn_cast_pad_f32_to_bf16(gsrc.data_ptr(), dst.data_ptr(), gsrc.numel() // C, C,
                                                      dst.shape[3], st), "cast")
         self.refresh_dgrad_weights(st)
-        for fn in self.bwd_steps:
-            fn(st)
+        if not self.side_stream_on:
+            for fn in self.bwd_steps:
+                fn(st)
+            return
+        # two streams: a side step waits (event) for everything the main stream has enqueued so far — its inputs
+        # dy / x are complete at that point and are not written again before the join below — and the main stream
+        # carries on with the data gradients; the optimizer (clip: global norm over every gradient) follows the join
+        main = torch.cuda.current_stream(self.dev)
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(self.dev)
+            self._side_events = [torch.cuda.Event() for _ in self.bwd_steps]
+        side = self._side_stream
+        sst = ctypes.c_void_p(side.cuda_stream)
+        fresh = False            # the side stream already waits for the newest main-stream work
+        for i, fn in enumerate(self.bwd_steps):
+            if getattr(fn, "side", False):
+                if not fresh:
+                    ev = self._side_events[i]
+                    ev.record(main)
+                    side.wait_event(ev)
+                    fresh = True
+                with torch.cuda.stream(side):
+                    fn(sst)
+            else:
+                fn(st)
+                fresh = False
+        main.wait_stream(side)
 
     def optimizer_step(self, lr, momentum, clipnorm, wd_alpha, ema_decay):
         lib, st = self.lib, _C.current_stream()

@@ -133,6 +133,32 @@ def test_backward_wiring_through_the_persistent_kernels(cuda):
         lib.rn_debug_wgrad_big_min_pixels(16384)
 
 
+def test_two_stream_backward_is_bit_identical(cuda):
+    """TrainEngine.backward runs the weight / bias gradient launches on a second HIP stream (RNET_WGRAD_STREAM,
+    default on).  Every kernel is deterministic, so the gradient buffer must equal the one-stream order's bit for
+    bit — a race on dy, a saved activation or a workspace would show up as a difference."""
+    p, model, eng, targets, images = _setup(cuda, 256, 4, True, freeze=True)
+    assert eng.side_stream_on
+    assert any(getattr(fn, "side", False) for fn in eng.bwd_steps)
+    preds = eng.forward(images.to(cuda))
+    g = torch.Generator().manual_seed(99)
+    up = {k: {lv: torch.randn(preds[k][lv].shape, generator=g).to(cuda) for lv in preds[k]} for k in preds}
+    grads = []
+    try:
+        for two_streams in (False, True, True, False, True):
+            eng.side_stream_on = two_streams
+            eng.G.zero_()
+            eng.forward(images.to(cuda), draw=False)
+            eng.backward(up)
+            torch.cuda.synchronize()
+            grads.append(eng.G.clone())
+    finally:
+        eng.side_stream_on = True
+    assert int((grads[0] != 0).sum()) > grads[0].numel() // 2
+    for i in range(1, len(grads)):
+        assert torch.equal(grads[0], grads[i]), f"run {i} differs from the one-stream gradients"
+
+
 def test_train_step_losses_and_optimizer_arithmetic(cuda):
     """One full step with the real loss: loss values against the restatement, then the optimizer
     stages re-derived in float64 from the engine's own raw gradients (executor.py:401-407,
