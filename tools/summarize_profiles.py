@@ -1,6 +1,8 @@
 """Turns the raw rocprofv3 output of tools/run_profiles.sh (gpurun_out/prof/...) into the files kept under profiles/:
 
   profiles/<round>_bench_train_b32_kernel_stats.csv      kernel-trace --stats of the training bench command
+  profiles/<round>_bench_train_b32_one_stream_kernel_stats.csv  the same with RNET_WGRAD_STREAM=0 (one-stream backward:
+                                                         kernel durations with the chip to themselves)
   profiles/<round>_bench_train1_infer30_kernel_stats.csv the same for the default bench command (train + inference)
   profiles/<round>_pmc_train_b32_per_kernel.csv          per kernel and counter: dispatches, mean, sum
   profiles/traffic.json                                  per kernel: HBM bytes per launch (FETCH_SIZE x2 per the gfx950
@@ -37,6 +39,7 @@ def main():
     a = ap.parse_args()
     out = os.path.join(ROOT, "profiles")
     for sub, dst in (("train", f"{a.round}_bench_train_b32_kernel_stats.csv"),
+                     ("train1s", f"{a.round}_bench_train_b32_one_stream_kernel_stats.csv"),
                      ("infer", f"{a.round}_bench_train1_infer30_kernel_stats.csv")):
         f = newest(os.path.join(a.src, sub, "**", "*kernel_stats.csv"))
         if f:
@@ -56,7 +59,7 @@ def main():
                 v = per[k][c]
                 fo.write(f'"{k}",{c},{len(v)},{sum(v) / len(v)},{sum(v)}\n')
     traffic = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / {SQ_VALU_MFMA_BUSY_CYCLES,SQ_BUSY_CU_CYCLES,GRBM_GUI_ACTIVE} in "
-                       "three separate passes over `bench.py --steps 2 --warmup 1 --no-infer --no-cpu-baseline` (training "
+                       "three separate passes over `RNET_WGRAD_STREAM=0 bench.py --steps 2 --warmup 1 --no-infer --no-cpu-baseline` (training "
                        "step, B=32), tools/run_profiles.sh + tools/summarize_profiles.py; means over the launches of each "
                        "kernel; FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md (128-B requests "
                        "tallied at 64 B), WRITE_SIZE uncalibrated; counter units KB -> bytes (x1000)",
