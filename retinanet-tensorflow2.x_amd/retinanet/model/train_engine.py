@@ -628,10 +628,11 @@ class TrainEngine:
                 img, y = self.t["images"], self.t[op["out"]]
                 H, W = img.shape[1], img.shape[2]
                 c = self.g.convs[op["conv"]]
-                pin, pimg = self.stem_in.data_ptr(), img.data_ptr()
-                self.fwd_steps.append(lambda st, pimg=pimg, pin=pin, H=H, W=W: _C.check(
-                    lib.rn_pack_image_nhwc4(pimg, B, H, W, self.stem_pad[0], self.stem_pad[1], self.Hp, self.Wp, pin, st),
-                    "rn_pack_image_nhwc4"))
+                pin = self.stem_in.data_ptr()
+                self._images_ptr = img.data_ptr()   # forward() points this at the caller's batch when it can be read in place
+                self.fwd_steps.append(lambda st, pin=pin, H=H, W=W: _C.check(
+                    lib.rn_pack_image_nhwc4(self._images_ptr, B, H, W, self.stem_pad[0], self.stem_pad[1], self.Hp, self.Wp,
+                                            pin, st), "rn_pack_image_nhwc4"))
                 live = self._conv_trainable(op)
                 p = _C.ConvProblem()
                 p.R, p.S, p.stride_h, p.stride_w, p.pad_top, p.pad_left = self.stem_k, 1, 2, 2, 0, 0
@@ -1154,8 +1155,16 @@ class TrainEngine:
         st = _C.current_stream()
         if draw and self.dc_masks:
             self.draw_drop_connect()
-        if images.data_ptr() != self.t["images"].data_ptr():
-            self.t["images"].copy_(images, non_blocking=True)
+        own = self.t["images"]
+        if (images.device == own.device and images.dtype == own.dtype and images.shape == own.shape
+                and images.is_contiguous()):
+            # the only reader is the NHWC4 packing kernel at the head of the launch list: read the batch where it is
+            # (a 157 MB device copy per step at 640x640x32 otherwise)
+            self._images_ref = images
+            self._images_ptr = images.data_ptr()
+        else:
+            own.copy_(images, non_blocking=True)
+            self._images_ptr = own.data_ptr()
         for fn in self.fwd_steps:
             fn(st)
         return self.outputs
