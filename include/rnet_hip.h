@@ -166,11 +166,12 @@ typedef struct {
   const float* shift;   /* f32[Cout] or NULL (=0) */
   const void* residual; /* bf16 [N,Ho,Wo,Cout] or NULL */
   int32_t N, H, W, Cin, pix_stride, Ho, Wo, Cout;
-  /* optional: BatchNorm forward statistics fused into the epilogue.  When the launch runs on the 256-row
-   * kernel (rn_conv_tile_rows() == 256) and this is non-NULL, every 128-pixel row block b of the output
-   * writes its per-channel partial sums of the STORED bf16 values: bn_partial[(b*2 + 0)*Cout + c] = sum,
-   * [(b*2 + 1)*Cout + c] = sum of squares, b = 0 .. 2*ceil(N*Ho*Wo/256)-1 — the stage-1 layout of rn_bn_stats
-   * (rn_bn_segment.ext_chunks).  Ignored by the 128-row kernel. */
+  /* optional: BatchNorm forward statistics fused into the epilogue (bf16 outputs).  When this is non-NULL, every
+   * 128-pixel row block b of the output writes its per-channel partial sums of the STORED bf16 values:
+   * bn_partial[(b*2 + 0)*Cout + c] = sum, [(b*2 + 1)*Cout + c] = sum of squares — the stage-1 layout of
+   * rn_bn_stats (rn_bn_segment.ext_chunks).  Blocks written: b = 0 .. 2*ceil(N*Ho*Wo/256)-1 when the launch runs on
+   * the 256-row kernels (rn_conv_tile_rows() == 256), b = 0 .. ceil(N*Ho*Wo/128)-1 on the 128-row kernel: set
+   * ext_chunks accordingly. */
   float* bn_partial;
 } rn_conv_segment;
 

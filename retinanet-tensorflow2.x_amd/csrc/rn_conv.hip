@@ -253,6 +253,10 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_fwd_kernel(const ConvArg
   constexpr int ROWS = NTHREADS / TPR;        // rows per pass
   const int er = tid / TPR, ec = (tid % TPR) * 4;
   const int n = n0 + ec;
+  // fused BatchNorm forward statistics (rn_conv_segment.bn_partial): sums of the STORED bf16 values of this
+  // thread's 4 channels over its rows; reduced over the workgroup's 128 rows below
+  const bool stats = !OUT_F32 && sg.bn_partial != nullptr;
+  float st0[4] = {0.f, 0.f, 0.f, 0.f}, st1[4] = {0.f, 0.f, 0.f, 0.f};
   if (n < Cout) {
 #pragma unroll 4
     for (int rr = er; rr < BM; rr += ROWS) {
@@ -280,7 +284,31 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_fwd_kernel(const ConvArg
         pk.x = rn_pack_bf16x2(v.x, v.y);
         pk.y = rn_pack_bf16x2(v.z, v.w);
         *(uint2*)((uint16_t*)sg.y + o) = pk;
+        if (stats) {
+          const float w4[4] = {__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xffff0000u),
+                               __uint_as_float(pk.y << 16), __uint_as_float(pk.y & 0xffff0000u)};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { st0[q] += w4[q]; st1[q] += w4[q] * w4[q]; }
+        }
       }
+    }
+  }
+  if (stats) {   // uniform per workgroup (one segment per tile)
+    __syncthreads();                       // every thread is done reading cl
+    float* red = cl;                       // [2][ROWS][BN]
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      red[er * BN + ec + q] = st0[q];
+      red[(ROWS + er) * BN + ec + q] = st1[q];
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < Cout) {     // fixed order over the ROWS row lanes: deterministic
+      float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) { s0 += red[r * BN + tid]; s1 += red[(ROWS + r) * BN + tid]; }
+      float* dst = sg.bn_partial + (long long)(m0 / BM) * 2 * Cout + n0 + tid;
+      dst[0] = s0;
+      dst[Cout] = s1;
     }
   }
 }

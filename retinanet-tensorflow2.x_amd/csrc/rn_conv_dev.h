@@ -16,7 +16,7 @@ struct ConvSegDev {
   const float* scale;
   const float* shift;
   const uint16_t* residual;
-  float* bn_partial;   // fused BatchNorm forward statistics (256-row kernel only), or null
+  float* bn_partial;   // fused BatchNorm forward statistics (bf16 outputs), or null
   int N, H, W, Cin, pix_stride, Ho, Wo, Cout;
   int M, tile_begin, n_tiles, CinP;  // CinP = Cin rounded up to the K step (weights are zero padded)
 };

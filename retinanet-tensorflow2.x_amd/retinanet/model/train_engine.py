@@ -556,9 +556,9 @@ class TrainEngine:
         _C.check(lib.rn_bn_finalize(prb, st), "rn_bn_finalize")
 
     def _bn_problem(self, ops, conv_problem=None):
-        """BatchNorm problem over `ops`.  With `conv_problem` (the launch that produces the raw outputs): when the
-        dispatcher runs it on the 256-row kernel, the forward statistics' stage-1 partial sums are written by the
-        conv epilogue (rn_conv_segment.bn_partial) and rn_bn_stats only does the final ordered reduction."""
+        """BatchNorm problem over `ops`.  With `conv_problem` (the launch that produces the raw outputs): the forward
+        statistics' stage-1 partial sums are written by the conv epilogue (rn_conv_segment.bn_partial, one row per
+        128 output pixels) and rn_bn_stats only does the final ordered reduction."""
         p = _C.BnProblem()
         p.num_segments = len(ops)
         p.act = _C.ACT_IDS[ops[0]["act"]]
@@ -602,11 +602,12 @@ class TrainEngine:
                 self.dc_masks[op["out"]] = (m, float(op["survival"]))
                 s.sample_scale, s.rows_per_sample = m.data_ptr(), y.shape[1] * y.shape[2]
             off += C
-        fused = (conv_problem is not None and self.fuse_bn_stats and conv_problem.out_dtype == _C.RN_DT_BF16
-                 and self.lib.rn_conv_tile_rows(ctypes.byref(conv_problem)) == 256)
+        fused = conv_problem is not None and self.fuse_bn_stats and conv_problem.out_dtype == _C.RN_DT_BF16
         if fused:
+            rows = self.lib.rn_conv_tile_rows(ctypes.byref(conv_problem))   # the kernel the dispatcher will run
             for i in range(len(ops)):
-                p.seg[i].ext_chunks = 2 * ((p.seg[i].P + 255) // 256)
+                P = p.seg[i].P
+                p.seg[i].ext_chunks = 2 * ((P + 255) // 256) if rows == 256 else (P + 127) // 128
         ws = torch.empty((max(self.lib.rn_bn_workspace_bytes(ctypes.byref(p)), 256),), dtype=torch.uint8,
                          device=self.dev)
         if fused:

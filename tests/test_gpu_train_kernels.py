@@ -210,8 +210,8 @@ def test_bn_train_forward_backward(cuda, act, use_res):
         torch.testing.assert_close(d["moving_var"].cpu().double(), mv, rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("k", [1, 3])
-def test_bn_forward_stats_fused_into_conv_epilogue(cuda, k):
+@pytest.mark.parametrize("k,tile", [(1, 2), (3, 2), (1, 1), (3, 1)])
+def test_bn_forward_stats_fused_into_conv_epilogue(cuda, k, tile):
     """rn_conv_segment.bn_partial + rn_bn_segment.ext_chunks: the 256-row conv kernel writes the per-128-row partial
     sums, rn_bn_stats only runs the final reduction.  Must give the statistics of the unfused path on the same
     stored bf16 output (fp32 summation order differs), including pixel tails and a channel tail (Cout 320)."""
@@ -239,17 +239,20 @@ def test_bn_forward_stats_fused_into_conv_epilogue(cuda, k):
         segs.append({"y": torch.zeros((N, H, W, cout)), "gamma": torch.ones((cout,)), "beta": torch.zeros((cout,)),
                      "moving_mean": torch.zeros((cout,)), "moving_var": torch.ones((cout,))})
     st = _C.current_stream()
-    lib.rn_debug_conv_tile(2)
+    lib.rn_debug_conv_tile(tile)       # 2: the 256-row kernels, 1: the 128-row kernel (one partial row per tile)
     try:
-        assert lib.rn_conv_tile_rows(ctypes.byref(pc)) == 256
-        assert lib.rn_conv_kernel_id(ctypes.byref(pc)) == (2 if k == 3 else 1)
+        rows = lib.rn_conv_tile_rows(ctypes.byref(pc))
+        assert rows == (256 if tile == 2 else 128)
+        if tile == 2:
+            assert lib.rn_conv_kernel_id(ctypes.byref(pc)) == (2 if k == 3 else 1)
         sums = {}
         for fused in (False, True):
             p, dev = _bn_problem(cuda, segs, None)
             for i, y in enumerate(ys):
                 p.seg[i].y = y.data_ptr()
                 if fused:
-                    p.seg[i].ext_chunks = 2 * ((p.seg[i].P + 255) // 256)
+                    P = p.seg[i].P
+                    p.seg[i].ext_chunks = 2 * ((P + 255) // 256) if rows == 256 else (P + 127) // 128
             ws = _ws(lib.rn_bn_workspace_bytes(ctypes.byref(p)), cuda)
             ws.fill_(0x7f)    # stale bytes must not leak into the sums
             for i in range(len(ys)):
