@@ -89,6 +89,18 @@ int rn_retinanet_loss_fwd_bwd(const float* const* class_logits, const float* con
                               float alpha, float gamma, float label_smoothing, float delta,
                               float box_loss_weight, float class_loss_weight, float grad_scale, float* losses,
                               void* workspace, size_t workspace_bytes, void* stream);
+/* Same losses; the gradients are written as bf16 (round to nearest even of the same fp32 values) straight into the
+ * NHWC tensors the prediction convs' backward pass reads: d_class_bf16[l] bf16[B*H_l*W_l][class_pix_stride] with the
+ * anchors_per_location*K live channels in front (the pad channels are not touched), d_box_bf16[l] likewise with
+ * anchors_per_location*4.  Saves the fp32 gradient round trip of executor.py:427 (tape.gradient keeps fp32). */
+int rn_retinanet_loss_fwd_bwd_bf16(const float* const* class_logits, const float* const* box_preds,
+                                   void* const* d_class_bf16, void* const* d_box_bf16, int class_pix_stride,
+                                   int box_pix_stride, int anchors_per_location, const int64_t* level_offsets,
+                                   int num_levels, int B, int K, const float* class_targets,
+                                   const float* box_targets, const float* normalizer, float alpha, float gamma,
+                                   float label_smoothing, float delta, float box_loss_weight,
+                                   float class_loss_weight, float grad_scale, float* losses, void* workspace,
+                                   size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * a11+a12  FuseDetections + TransformBoxesAndScores

@@ -24,6 +24,11 @@ struct LossLevels {
   const float* box[RN_LOSS_MAX_LEVELS];
   float* dcls[RN_LOSS_MAX_LEVELS];
   float* dbox[RN_LOSS_MAX_LEVELS];
+  // write_grad == 2: gradients as bf16 straight into the padded NHWC dy tensors of the prediction convs'
+  // backward pass ([B*H*W][stride] with the level's na*K / na*4 live channels in front)
+  uint16_t* dcls16[RN_LOSS_MAX_LEVELS];
+  uint16_t* dbox16[RN_LOSS_MAX_LEVELS];
+  int cls_stride16, box_stride16, na;
   long long off[RN_LOSS_MAX_LEVELS + 1];   // anchor boundaries
   long long vbeg[RN_LOSS_MAX_LEVELS + 1];  // prefix of B*n_l*(K/V) work items
 };
@@ -110,10 +115,16 @@ focal_kernel(LossLevels lv, int B, int K, long long A, const float* __restrict__
       acc += lo;
       g[u] = gr * gs;
     }
-    if (write_grad) {
+    if (write_grad == 1) {
       float* dst = lv.dcls[l] + (long long)row * K + (long long)kv * V;
       if (V == 4) *(float4*)dst = make_float4(g[0], g[1 % V], g[2 % V], g[3 % V]);
       else dst[0] = g[0];
+    } else if (write_grad == 2) {
+      const unsigned pix = row / (unsigned)lv.na;                // rows are (image, anchor): na anchors per pixel
+      const unsigned ch = (row - pix * (unsigned)lv.na) * (unsigned)K + (unsigned)(kv * V);
+      uint16_t* dst = lv.dcls16[l] + (long long)pix * lv.cls_stride16 + ch;
+      if (V == 4) *(uint2*)dst = make_uint2(rn_pack_bf16x2(g[0], g[1 % V]), rn_pack_bf16x2(g[2 % V], g[3 % V]));
+      else dst[0] = rn_f32_to_bf16(g[0]);
     }
   }
   __shared__ double sred[RN_LOSS_THREADS / 64];
@@ -158,7 +169,14 @@ huber_kernel(LossLevels lv, int B, long long A, const float4* __restrict__ box_t
       acc += lo;
       gv[c] = gr * gs;
     }
-    if (write_grad) ((float4*)lv.dbox[l])[row] = make_float4(gv[0], gv[1], gv[2], gv[3]);
+    if (write_grad == 1) {
+      ((float4*)lv.dbox[l])[row] = make_float4(gv[0], gv[1], gv[2], gv[3]);
+    } else if (write_grad == 2) {
+      const long long pix = row / lv.na;
+      const int ch = (int)(row - pix * lv.na) * 4;
+      *(uint2*)(lv.dbox16[l] + pix * lv.box_stride16 + ch) =
+          make_uint2(rn_pack_bf16x2(gv[0], gv[1]), rn_pack_bf16x2(gv[2], gv[3]));
+    }
   }
   __shared__ double sred[RN_LOSS_THREADS / 64];
   double d = rn_wave_sum_d((double)acc);
@@ -204,14 +222,15 @@ extern "C" size_t rn_loss_workspace_bytes(int B, int64_t A, int K) {
   return 2 * 2048 * sizeof(double);
 }
 
-extern "C" int rn_retinanet_loss_fwd_bwd(const float* const* class_logits, const float* const* box_preds,
-                                         float* const* d_class_logits, float* const* d_box_preds,
-                                         const int64_t* level_offsets, int num_levels, int B, int K,
-                                         const float* class_targets, const float* box_targets,
-                                         const float* normalizer, float alpha, float gamma,
-                                         float label_smoothing, float delta, float box_loss_weight,
-                                         float class_loss_weight, float grad_scale, float* losses,
-                                         void* workspace, size_t workspace_bytes, void* stream) {
+static int loss_launch(const float* const* class_logits, const float* const* box_preds,
+                       float* const* d_class_logits, float* const* d_box_preds, void* const* d_class_bf16,
+                       void* const* d_box_bf16, int class_pix_stride, int box_pix_stride, int anchors_per_location,
+                       const int64_t* level_offsets, int num_levels, int B, int K,
+                       const float* class_targets, const float* box_targets,
+                       const float* normalizer, float alpha, float gamma,
+                       float label_smoothing, float delta, float box_loss_weight,
+                       float class_loss_weight, float grad_scale, float* losses,
+                       void* workspace, size_t workspace_bytes, void* stream) {
   RN_CHECK_ARG(class_logits && box_preds && level_offsets && class_targets && box_targets && normalizer && losses,
                "rn_retinanet_loss_fwd_bwd: null argument");
   RN_CHECK_ARG(num_levels >= 1 && num_levels <= RN_LOSS_MAX_LEVELS && B > 0 && K > 0,
@@ -221,16 +240,29 @@ extern "C" int rn_retinanet_loss_fwd_bwd(const float* const* class_logits, const
     return RN_ENOMEM;
   }
   const int V = (K % 4 == 0) ? 4 : 1;
-  const int write_grad = (d_class_logits && d_box_preds) ? 1 : 0;
+  const int write_grad = (d_class_bf16 && d_box_bf16) ? 2 : (d_class_logits && d_box_preds) ? 1 : 0;
   LossLevels lv;
+  lv.cls_stride16 = class_pix_stride; lv.box_stride16 = box_pix_stride; lv.na = anchors_per_location;
+  if (write_grad == 2) {
+    RN_CHECK_ARG(anchors_per_location > 0 && class_pix_stride >= anchors_per_location * K &&
+                 box_pix_stride >= anchors_per_location * 4 && class_pix_stride % 4 == 0 && box_pix_stride % 4 == 0,
+                 "rn_retinanet_loss_fwd_bwd_bf16: bad strides %d / %d for %d anchors per location", class_pix_stride,
+                 box_pix_stride, anchors_per_location);
+  }
   lv.num_levels = num_levels;
   lv.off[0] = level_offsets[0];
   lv.vbeg[0] = 0;
   for (int l = 0; l < num_levels; ++l) {
     lv.cls[l] = class_logits[l];
     lv.box[l] = box_preds[l];
-    lv.dcls[l] = write_grad ? d_class_logits[l] : nullptr;
-    lv.dbox[l] = write_grad ? d_box_preds[l] : nullptr;
+    lv.dcls[l] = write_grad == 1 ? d_class_logits[l] : nullptr;
+    lv.dbox[l] = write_grad == 1 ? d_box_preds[l] : nullptr;
+    lv.dcls16[l] = write_grad == 2 ? (uint16_t*)d_class_bf16[l] : nullptr;
+    lv.dbox16[l] = write_grad == 2 ? (uint16_t*)d_box_bf16[l] : nullptr;
+    if (write_grad == 2)
+      RN_CHECK_ARG(lv.dcls16[l] && lv.dbox16[l] && (level_offsets[l + 1] - level_offsets[l]) % anchors_per_location == 0,
+                   "rn_retinanet_loss_fwd_bwd_bf16: level %d: null output or anchors not a multiple of %d", l,
+                   anchors_per_location);
     lv.off[l + 1] = level_offsets[l + 1];
     const long long n_l = level_offsets[l + 1] - level_offsets[l];
     RN_CHECK_ARG(n_l > 0, "rn_retinanet_loss_fwd_bwd: empty level %d", l);
@@ -262,4 +294,33 @@ extern "C" int rn_retinanet_loss_fwd_bwd(const float* const* class_logits, const
                      box_loss_weight, class_loss_weight, losses);
   RN_CHECK_LAUNCH();
   return RN_OK;
+}
+
+extern "C" int rn_retinanet_loss_fwd_bwd(const float* const* class_logits, const float* const* box_preds,
+                                         float* const* d_class_logits, float* const* d_box_preds,
+                                         const int64_t* level_offsets, int num_levels, int B, int K,
+                                         const float* class_targets, const float* box_targets,
+                                         const float* normalizer, float alpha, float gamma,
+                                         float label_smoothing, float delta, float box_loss_weight,
+                                         float class_loss_weight, float grad_scale, float* losses,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+  return loss_launch(class_logits, box_preds, d_class_logits, d_box_preds, nullptr, nullptr, 0, 0, 0, level_offsets,
+                     num_levels, B, K, class_targets, box_targets, normalizer, alpha, gamma, label_smoothing, delta,
+                     box_loss_weight, class_loss_weight, grad_scale, losses, workspace, workspace_bytes, stream);
+}
+
+extern "C" int rn_retinanet_loss_fwd_bwd_bf16(const float* const* class_logits, const float* const* box_preds,
+                                              void* const* d_class_bf16, void* const* d_box_bf16,
+                                              int class_pix_stride, int box_pix_stride, int anchors_per_location,
+                                              const int64_t* level_offsets, int num_levels, int B, int K,
+                                              const float* class_targets, const float* box_targets,
+                                              const float* normalizer, float alpha, float gamma,
+                                              float label_smoothing, float delta, float box_loss_weight,
+                                              float class_loss_weight, float grad_scale, float* losses,
+                                              void* workspace, size_t workspace_bytes, void* stream) {
+  RN_CHECK_ARG(d_class_bf16 && d_box_bf16, "rn_retinanet_loss_fwd_bwd_bf16: null gradient outputs");
+  return loss_launch(class_logits, box_preds, nullptr, nullptr, d_class_bf16, d_box_bf16, class_pix_stride,
+                     box_pix_stride, anchors_per_location, level_offsets, num_levels, B, K, class_targets, box_targets,
+                     normalizer, alpha, gamma, label_smoothing, delta, box_loss_weight, class_loss_weight, grad_scale,
+                     losses, workspace, workspace_bytes, stream);
 }

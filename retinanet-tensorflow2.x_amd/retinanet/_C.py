@@ -101,6 +101,9 @@ _SIGNATURES = {
     "rn_retinanet_loss_fwd_bwd": (c_int, [_PP, _PP, _PP, _PP, POINTER(c_int64), c_int, c_int, c_int, c_void_p,
                                           c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_float,
                                           c_float, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rn_retinanet_loss_fwd_bwd_bf16": (c_int, [_PP, _PP, _PP, _PP, c_int, c_int, c_int, POINTER(c_int64), c_int, c_int,
+                                               c_int, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
+                                               c_float, c_float, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
     "rn_decode_boxes": (c_int, [_PP, POINTER(c_int64), c_int, c_int, c_void_p, POINTER(c_float), c_float,
                                 c_float, c_void_p, c_void_p]),
     "rn_sigmoid_scores": (c_int, [_PP, POINTER(c_int64), c_int, c_int, c_int, c_void_p, c_void_p]),

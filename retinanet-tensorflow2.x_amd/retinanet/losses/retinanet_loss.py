@@ -39,7 +39,10 @@ class RetinaNetLoss:
             return dist.get_world_size(self._pg)
         return 1
 
-    def __call__(self, targets, predictions, compute_grads=True, grad_scale=None):
+    def __call__(self, targets, predictions, compute_grads=True, grad_scale=None, grads_bf16=None):
+        """grads_bf16 = {"class-predictions": {level: bf16[B,H,W,stride]}, "box-predictions": {...}}: write the
+        gradients as bf16 into these (channel-padded) tensors instead of fp32 `self.grads` — the training engine
+        passes the dy tensors of the prediction convs, so no fp32 gradient is materialised."""
         lib = _C.lib()
         cls_pred = predictions["class-predictions"]
         box_pred = predictions["box-predictions"]
@@ -68,8 +71,9 @@ class RetinaNetLoss:
             bl.append(b)
         if offs[-1] != cls_t.shape[1]:
             raise ValueError(f"predictions cover {offs[-1]} anchors, targets {cls_t.shape[1]}")
-        dcl = [torch.empty_like(c) for c in cl] if compute_grads else None
-        dbl = [torch.empty_like(b) for b in bl] if compute_grads else None
+        bf16_out = compute_grads and grads_bf16 is not None
+        dcl = [torch.empty_like(c) for c in cl] if compute_grads and not bf16_out else None
+        dbl = [torch.empty_like(b) for b in bl] if compute_grads and not bf16_out else None
         need = lib.rn_loss_workspace_bytes(B, offs[-1], K)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty((need,), dtype=torch.uint8, device=dev)
@@ -77,13 +81,31 @@ class RetinaNetLoss:
         if grad_scale is None:
             grad_scale = 1.0 / R  # per_replica_loss = total / replicas  (executor.py:421)
         with torch.cuda.device(dev):
-            _C.check(lib.rn_retinanet_loss_fwd_bwd(
-                _C.ptr_array(cl), _C.ptr_array(bl), _C.ptr_array(dcl), _C.ptr_array(dbl),
-                _C.i64_array(offs), len(levels), B, K, _C.ptr(cls_t), _C.ptr(box_t), _C.ptr(normalizer),
-                self._alpha, self._gamma, self._label_smoothing, self._delta, self._box_loss_weight,
-                self._class_loss_weight, float(grad_scale), _C.ptr(out), _C.ptr(self._ws), self._ws.numel(),
-                _C.current_stream()), "rn_retinanet_loss_fwd_bwd")
-        if compute_grads:
+            if bf16_out:
+                gc = [grads_bf16["class-predictions"][lv] for lv in levels]
+                gb = [grads_bf16["box-predictions"][lv] for lv in levels]
+                na = cl[0].shape[-1] // K
+                for c, b, tc, tb in zip(cl, bl, gc, gb):
+                    if (tc.dtype != torch.bfloat16 or tb.dtype != torch.bfloat16 or not tc.is_contiguous()
+                            or not tb.is_contiguous() or tc.shape[:-1] != c.shape[:-1] or tb.shape[:-1] != b.shape[:-1]
+                            or tc.shape[-1] != gc[0].shape[-1] or tb.shape[-1] != gb[0].shape[-1]):
+                        raise ValueError("grads_bf16 tensors must be contiguous bf16 [B,H,W,stride] like the predictions")
+                _C.check(lib.rn_retinanet_loss_fwd_bwd_bf16(
+                    _C.ptr_array(cl), _C.ptr_array(bl), _C.ptr_array(gc), _C.ptr_array(gb), gc[0].shape[-1],
+                    gb[0].shape[-1], na, _C.i64_array(offs), len(levels), B, K, _C.ptr(cls_t), _C.ptr(box_t),
+                    _C.ptr(normalizer), self._alpha, self._gamma, self._label_smoothing, self._delta,
+                    self._box_loss_weight, self._class_loss_weight, float(grad_scale), _C.ptr(out), _C.ptr(self._ws),
+                    self._ws.numel(), _C.current_stream()), "rn_retinanet_loss_fwd_bwd_bf16")
+            else:
+                _C.check(lib.rn_retinanet_loss_fwd_bwd(
+                    _C.ptr_array(cl), _C.ptr_array(bl), _C.ptr_array(dcl), _C.ptr_array(dbl),
+                    _C.i64_array(offs), len(levels), B, K, _C.ptr(cls_t), _C.ptr(box_t), _C.ptr(normalizer),
+                    self._alpha, self._gamma, self._label_smoothing, self._delta, self._box_loss_weight,
+                    self._class_loss_weight, float(grad_scale), _C.ptr(out), _C.ptr(self._ws), self._ws.numel(),
+                    _C.current_stream()), "rn_retinanet_loss_fwd_bwd")
+        if bf16_out:
+            self.grads = None
+        elif compute_grads:
             self.grads = {"class-predictions": dict(zip(levels, dcl)), "box-predictions": dict(zip(levels, dbl))}
         return {"box-loss": out[0], "class-loss": out[1], "weighted-loss": out[2],
                 "num-anchors-matched": out[3], "iou-prediction-loss": 0.0}

@@ -1176,16 +1176,27 @@ class TrainEngine:
         fn.side = True
         return fn
 
+    def loss_grad_buffers(self):
+        """The dy tensors of the prediction convs (bf16 [B,H,W,padded channels]) keyed like the predictions: handed to
+        RetinaNetLoss(grads_bf16=...) so that the loss kernels write the upstream gradients where backward() reads
+        them (pad channels stay zero from allocation)."""
+        if getattr(self, "_loss_dy", None) is None:
+            self._loss_dy = {k: {lv: self.dy_of[name] for lv, name in self.g.outputs[k].items()}
+                             for k in ("class-predictions", "box-predictions")}
+        return self._loss_dy
+
     def backward(self, loss_grads):
-        """loss_grads: RetinaNetLoss.grads (f32, per level) -> parameter gradients in self.G."""
+        """loss_grads: RetinaNetLoss.grads (f32, per level), or None when the loss wrote loss_grad_buffers()
+        -> parameter gradients in self.G."""
         lib, st = self.lib, _C.current_stream()
-        for key, okey in (("class-predictions", "class-predictions"), ("box-predictions", "box-predictions")):
-            for lv, name in self.g.outputs[okey].items():
-                gsrc = loss_grads[key][lv]
-                dst = self.dy_of[name]
-                C = gsrc.shape[-1]
-                _C.check(lib.rn_cast_pad_f32_to_bf16(gsrc.data_ptr(), dst.data_ptr(), gsrc.numel() // C, C,
-                                                     dst.shape[3], st), "cast")
+        if loss_grads is not None:   # None: the loss kernels already wrote bf16 into loss_grad_buffers()
+            for key, okey in (("class-predictions", "class-predictions"), ("box-predictions", "box-predictions")):
+                for lv, name in self.g.outputs[okey].items():
+                    gsrc = loss_grads[key][lv]
+                    dst = self.dy_of[name]
+                    C = gsrc.shape[-1]
+                    _C.check(lib.rn_cast_pad_f32_to_bf16(gsrc.data_ptr(), dst.data_ptr(), gsrc.numel() // C, C,
+                                                         dst.shape[3], st), "cast")
         self.refresh_dgrad_weights(st)
         if not self.side_stream_on:
             for fn in self.bwd_steps:
@@ -1237,8 +1248,9 @@ class TrainEngine:
         opt = self.model.optimizer
         with torch.cuda.device(self.dev):
             preds = self.forward(images)
-            loss = self.model.loss(targets, preds, compute_grads=True, grad_scale=1.0 / self.world)
-            self.backward(self.model.loss.grads)
+            loss = self.model.loss(targets, preds, compute_grads=True, grad_scale=1.0 / self.world,
+                                   grads_bf16=self.loss_grad_buffers())
+            self.backward(None)
             step = self.step_count
             self.optimizer_step(opt.lr(step), opt.momentum, opt.clipnorm,
                                 cfg.weight_decay_alpha if cfg.use_weight_decay else 0.0,

@@ -84,3 +84,42 @@ def test_fresh_head_all_background(cuda):
                        np.zeros([B, A, 4], np.float32), 0.0, K, [57600, 14400, 3600, 900, 225])
     assert out["class-loss"] == pytest.approx(A * K * 7.537751890126e-06, rel=2e-5)
     assert out["box-loss"] == 0.0 and (db == 0).all()
+
+
+def test_loss_bf16_gradient_outputs_match_the_cast(cuda):
+    """rn_retinanet_loss_fwd_bwd_bf16 writes the gradients as bf16 into channel-padded NHWC tensors (the dy tensors of
+    the prediction convs): same losses, and bit for bit the round-to-nearest-even cast of the fp32 gradients; the
+    pad channels are left alone."""
+    from retinanet.cfg import default_params
+    from retinanet.losses import RetinaNetLoss
+    K, na, B = 8, 3, 2
+    sizes = [(8, 8), (4, 4), (2, 2)]
+    g = torch.Generator().manual_seed(5)
+    loss = RetinaNetLoss(K, default_params().loss)
+    preds = {"class-predictions": {}, "box-predictions": {}}
+    for i, (h, w) in enumerate(sizes):
+        preds["class-predictions"][str(3 + i)] = (torch.randn((B, h, w, na * K), generator=g) * 2 - 2).to(cuda)
+        preds["box-predictions"][str(3 + i)] = torch.randn((B, h, w, na * 4), generator=g).to(cuda)
+    A = sum(h * w * na for h, w in sizes)
+    cls_t = torch.randint(-2, K, (B, A), generator=g).float()
+    box_t = torch.randn((B, A, 4), generator=g) * (cls_t >= 0).float()[..., None]
+    targets = {"num-positives": torch.tensor([float((cls_t >= 0).sum()), 0.0], device=cuda),
+               "_flat": {"class-targets": cls_t.to(cuda), "box-targets": box_t.to(cuda)}}
+    out32 = loss(targets, preds)
+    g32 = loss.grads
+    cs, bs = 32, 16     # padded channel strides (24 / 12 live)
+    bufs = {"class-predictions": {lv: torch.full((B, h, w, cs), 7.0, dtype=torch.bfloat16, device=cuda)
+                                  for lv, (h, w) in zip("345", sizes)},
+            "box-predictions": {lv: torch.full((B, h, w, bs), 7.0, dtype=torch.bfloat16, device=cuda)
+                                for lv, (h, w) in zip("345", sizes)}}
+    out16 = loss(targets, preds, grads_bf16=bufs)
+    torch.cuda.synchronize()
+    assert loss.grads is None
+    for k in ("box-loss", "class-loss", "weighted-loss"):
+        assert out32[k].item() == out16[k].item()
+    for key, live in (("class-predictions", na * K), ("box-predictions", na * 4)):
+        for lv in "345":
+            got = bufs[key][lv]
+            assert torch.equal(got[..., :live], g32[key][lv].to(torch.bfloat16))
+            assert bool((got[..., live:] == 7.0).all())
+    assert float(g32["class-predictions"]["3"].abs().max()) > 0
