@@ -273,6 +273,10 @@ int rn_pack_conv_weight_dgrad_batch(const rn_dgrad_pack* items /* host */, int n
 int rn_cast_pad_f32_to_bf16(const float* x, void* y, int64_t P, int C, int Cpad, void* stream);
 /* y[n,2h,2w,:] = x[n,h,w,:], zero elsewhere; bf16 NHWC */
 int rn_upsample_zero2x(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, void* stream);
+/* y[n,2h,2w,:] (+)= x[n,h,w,:], bf16: accumulate = 0 is rn_upsample_zero2x (zeros at the other positions),
+ * accumulate = 1 adds in fp32 and rounds once, touching only the even positions.  Data gradient of a 1x1 / stride-2
+ * convolution (the ResNet projection shortcuts): the GEMM runs on dy at the low resolution. */
+int rn_scatter_add2x(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, int accumulate, void* stream);
 int rn_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
 /* dy = dz * act'(z) for a layer with an activation but no BatchNorm in front */
 int rn_act_bwd(const void* dz, const void* z, void* dy, int64_t n, int act, void* stream);

@@ -589,6 +589,39 @@ extern "C" int rn_upsample_zero2x(const void* x, void* y, int N, int H, int W, i
   return RN_OK;
 }
 
+// ---- y[n,2h,2w,:] += x[n,h,w,:] (fp32 add, one rounding): the data gradient of a 1x1 / stride-2 convolution
+// only has values at the even positions, so its GEMM runs at the low resolution and this scatters the result
+__global__ void __launch_bounds__(TR_THREADS)
+scatter_add2x_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int N, int H, int W, int C8, int Ho, int Wo) {
+  const long long total = (long long)N * H * W * C8;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C8);
+    long long t = i / C8;
+    const int w = (int)(t % W);
+    t /= W;
+    const int h = (int)(t % H);
+    const int n = (int)(t / H);
+    if (2 * h >= Ho || 2 * w >= Wo) continue;
+    const long long o = (((long long)n * Ho + 2 * h) * Wo + 2 * w) * C8 + c;
+    const bf8 a = unpack8(x[i]), b = unpack8(y[o]);
+    bf8 r;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) r.v[q] = a.v[q] + b.v[q];
+    y[o] = pack8(r);
+  }
+}
+extern "C" int rn_scatter_add2x(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, int accumulate,
+                                void* stream) {
+  RN_CHECK_ARG(x && y && N > 0 && H > 0 && W > 0 && C % 8 == 0 && Ho >= 2 * H - 1 && Wo >= 2 * W - 1,
+               "rn_scatter_add2x: bad argument");
+  if (!accumulate) return rn_upsample_zero2x(x, y, N, H, W, C, Ho, Wo, stream);   // first writer: zeros elsewhere
+  hipLaunchKernelGGL(scatter_add2x_kernel, dim3(tr_blocks((long long)N * H * W * (C / 8))), dim3(TR_THREADS), 0,
+                     (hipStream_t)stream, (const uint4*)x, (uint4*)y, N, H, W, C / 8, Ho, Wo);
+  RN_CHECK_LAUNCH();
+  return RN_OK;
+}
+
 extern "C" int rn_act_bwd(const void* dz, const void* z, void* dy, int64_t n, int act, void* stream) {
   RN_CHECK_ARG(dz && z && dy && n > 0 && n % 8 == 0, "rn_act_bwd: bad argument");
   hipLaunchKernelGGL(act_bwd_kernel, dim3(tr_blocks(n / 8)), dim3(TR_THREADS), 0, (hipStream_t)stream,

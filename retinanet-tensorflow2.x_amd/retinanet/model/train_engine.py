@@ -1092,6 +1092,10 @@ class TrainEngine:
         p.pad_top = p.pad_left = k - 1 - need[0]["pad"]
         p.act, p.out_dtype, p.num_segments = _C.RN_ACT_NONE, _C.RN_DT_BF16, len(need)
         ups = []
+        # 1x1 / stride 2 (projection shortcuts): dx is non-zero only at the even positions, so the GEMM runs on dy
+        # as it is (a quarter of the pixels of the zero-upsampled form) and rn_scatter_add2x puts the rows in place
+        lowres = k == 1 and stride == 2 and need[0]["pad"] == 0 and os.environ.get("RNET_DGRAD_LOWRES", "1") != "0"
+        scatters = []
         for i, op in enumerate(need):
             c = self.g.convs[op["conv"]]
             dy = dy_of[op["out"]]
@@ -1104,6 +1108,19 @@ class TrainEngine:
                 self.dgrad_packs.append((self.P.data_ptr() + 4 * off, k, c["cin"], c["cout"], cwp, buf))
             x = self._src(op["inp"])
             H, W = x.shape[1], x.shape[2]
+            if lowres:
+                gbuf = self._gradbuf(op["inp"])
+                first = mark(op["inp"] if op["inp"] not in self.bal_src else "bal:" + op["inp"])
+                tmp = torch.empty((B, dy.shape[1], dy.shape[2], c["cin"]), dtype=torch.bfloat16, device=self.dev)
+                self._keep.append(tmp)
+                scatters.append((tmp.data_ptr(), gbuf.data_ptr(), B, dy.shape[1], dy.shape[2], c["cin"], H, W,
+                                 0 if first else 1))
+                s = p.seg[i]
+                s.x, s.w, s.y = dy.data_ptr(), packs[op["conv"]].data_ptr(), tmp.data_ptr()
+                s.scale, s.shift, s.residual = None, None, None
+                s.N, s.H, s.W, s.Cin, s.pix_stride = B, dy.shape[1], dy.shape[2], cw, cw
+                s.Ho, s.Wo, s.Cout = dy.shape[1], dy.shape[2], c["cin"]
+                continue
             if stride == 2:
                 up = torch.empty((B, H, W, cw), dtype=torch.bfloat16, device=self.dev)
                 ups.append((dy.data_ptr(), up.data_ptr(), B, dy.shape[1], dy.shape[2], cw, H, W))
@@ -1123,10 +1140,12 @@ class TrainEngine:
             s.Ho, s.Wo, s.Cout = H, W, c["cin"]
         self._keep.append(p)
 
-        def dgrad(st, p=p, ups=ups):
+        def dgrad(st, p=p, ups=ups, scatters=scatters):
             for u in ups:
                 _C.check(lib.rn_upsample_zero2x(*u, st), "rn_upsample_zero2x")
             self._launch_conv(p, st, "dgrad")
+            for sc in scatters:
+                _C.check(lib.rn_scatter_add2x(*sc, st), "rn_scatter_add2x")
         self.bwd_steps.append(dgrad)
 
     # ---- one training step -----------------------------------------------------------------------------

@@ -407,3 +407,22 @@ def test_optimizer_step(cuda):
         got = bf[offs[i]:offs[i] + n].float().cpu()
         want = w2[offs[i]:offs[i] + n].float().to(torch.bfloat16).float() if wd[i] else torch.zeros(n)
         torch.testing.assert_close(got, want, rtol=1 / 128, atol=1e-3)
+
+
+@pytest.mark.parametrize("N,H,W,C,Ho,Wo", [(2, 5, 7, 16, 10, 14), (1, 4, 3, 64, 7, 5), (3, 8, 8, 8, 16, 16)])
+def test_scatter_add2x(cuda, N, H, W, C, Ho, Wo):
+    """rn_scatter_add2x: y[n,2h,2w,:] (+)= x[n,h,w,:] — the placement step of the low-resolution data gradient of a
+    1x1 / stride-2 convolution; fp32 add with one rounding, the other positions untouched (accumulate) or zero."""
+    from retinanet import _C
+    lib = _C.lib()
+    g = torch.Generator().manual_seed(N * 100 + C)
+    x = _bf(torch.randn((N, H, W, C), generator=g))
+    y0 = _bf(torch.randn((N, Ho, Wo, C), generator=g))
+    for acc in (0, 1):
+        xd, yd = x.to(cuda), y0.clone().to(cuda)
+        _C.check(lib.rn_scatter_add2x(_C.ptr(xd), _C.ptr(yd), N, H, W, C, Ho, Wo, acc, _C.current_stream()))
+        torch.cuda.synchronize()
+        want = y0.float().clone() if acc else torch.zeros((N, Ho, Wo, C))
+        hh, ww = (Ho + 1) // 2, (Wo + 1) // 2
+        want[:, ::2, ::2, :] += x.float()[:, :hh, :ww, :]
+        assert torch.equal(yd.float().cpu(), want.to(torch.bfloat16).float())
