@@ -182,7 +182,11 @@ _Pragma("unroll") for (int pass = 0; pass < (HAS_RES ? 4 : 0); ++pass) {        
           uint2 pk;
           pk.x = pack2(acc[i][j][g * 4 + 0], acc[i][j][g * 4 + 1]);
           pk.y = pack2(acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
-          *(uint2*)(patch + fr * 128 + (((nl >> 3) ^ (fr & 7)) << 4) + (nl & 4) * 2) = pk;
+          // ds_write_b64 is serviced in contiguous 16-lane groups over a 128-byte bank row: rows fr and fr + 8 share
+          // the 16-byte unit (same fr & 7), so the 8-byte half is flipped for rows 8-15 / 24-31 — 16 distinct 8-byte
+          // chunks per group instead of a 2-way conflict (SQ_LDS_BANK_CONFLICT was 18-25 % of the LDS cycles of the
+          // short-K 1x1 launches); the read-back swaps the halves back for odd passes
+          *(uint2*)(patch + fr * 128 + (((nl >> 3) ^ (fr & 7)) << 4) + ((((nl >> 2) ^ (fr >> 3)) & 1) << 3)) = pk;
         }
       EPI_STAMP(14 + 2 * i);
       // read the block's four 8-row passes back before touching any of them: one LDS round trip per block instead
@@ -192,7 +196,8 @@ _Pragma("unroll") for (int pass = 0; pass < (HAS_RES ? 4 : 0); ++pass) {        
 #pragma unroll
       for (int pass = 0; pass < 4; ++pass) {
         const int row = pass * 8 + rrow;
-        vb[pass] = *(const uint4*)(patch + row * 128 + ((ru ^ (row & 7)) << 4));
+        const uint4 t = *(const uint4*)(patch + row * 128 + ((ru ^ (row & 7)) << 4));
+        vb[pass] = (pass & 1) ? make_uint4(t.z, t.w, t.x, t.y) : t;   // rows 8-15 / 24-31: halves were flipped
       }
 #pragma unroll
       for (int pass = 0; pass < 4; ++pass) {
