@@ -165,14 +165,28 @@ int rn_rowmax_argmax(const float* scores, int64_t rows, int K, float* max_out, i
  * One launch runs up to RN_CONV_MAX_SEGMENTS independent problems that share kernel size,
  * stride and Cout tile shape (e.g. the five pyramid levels of one shared head conv, or the
  * FPN's per-level 3x3 convs).  Activations NHWC bf16; weights PREPACKED bf16
- * [Cout_pad][R][S][Cin] (rn_pack_conv_weight); accumulation fp32; epilogue
- * y = act(acc*scale[c] + shift[c] + residual) written as bf16 or f32.
+ * [Cout_pad][R][S][w_terms*Cin_pad] (rn_pack_conv_weight / rn_pack_conv_weight_split); accumulation fp32.
+ *
+ * Epilogue = the reference's layer sequence under the mixed_bfloat16 policy (__main__.py:76-77): every Keras
+ * layer output (Conv2D incl. its bias, BatchNormalization, the residual `+`) is a bf16 TENSOR, so with
+ * rb(v) = round-to-nearest-even to bf16:
+ *   bf16 output:  t = acc + bias[c]                               (Conv2D + BiasAdd, fp32 inside the layer)
+ *                 if scale/shift or residual given:  t = rb(t)    (the Conv2D layer's output tensor)
+ *                 if scale/shift given:  t = t*scale[c] + shift[c];  if residual given: t = rb(t)   (BatchNorm output)
+ *                 if residual given:     t = t + residual
+ *                 y = rb(act(rb'(t)))    rb' = rb for swish (the Add / BatchNorm output feeds tf.nn.swish), identity else
+ *   f32 output (the dtype=float32 prediction convs, detection_head.py:80-88): y = act((acc + bias)*scale + shift
+ *                 + residual), no intermediate rounding.
+ * w_terms (0/1 = plain): the f32 weights are carried as w_terms bf16 planes stacked along Cin
+ * (w = w_hi + w_lo [+ w_lo2]); the kernel walks the same input channels once per plane, so a bf16 activation times
+ * an f32 weight is accumulated to 16 (24) weight mantissa bits in fp32 — how the f32 prediction convs keep their
+ * f32 kernels on a bf16 MFMA.
  */
 #define RN_CONV_MAX_SEGMENTS 10
 
 typedef struct {
   const void* x;        /* bf16 [N,H,W,pix_stride] (pix_stride >= Cin elements between pixels) */
-  const void* w;        /* bf16 [Cout_pad, R, S, Cin] */
+  const void* w;        /* bf16 [Cout_pad, R, S, w_terms*Cin_pad] */
   void* y;              /* bf16 or f32 [N,Ho,Wo,Cout] */
   const float* scale;   /* f32[Cout] or NULL (=1) */
   const float* shift;   /* f32[Cout] or NULL (=0) */
@@ -185,6 +199,9 @@ typedef struct {
    * the 256-row kernels (rn_conv_tile_rows() == 256), b = 0 .. ceil(N*Ho*Wo/128)-1 on the 128-row kernel: set
    * ext_chunks accordingly. */
   float* bn_partial;
+  const float* bias;    /* f32[Cout] or NULL: the Conv2D layer's bias, added to the fp32 accumulator */
+  int32_t w_terms;      /* 0 or 1: plain bf16 weights; 2 / 3: split-bf16 planes along Cin (see above) */
+  int32_t pad_;
 } rn_conv_segment;
 
 typedef struct {
@@ -211,6 +228,11 @@ int rn_conv_kernel_id(const rn_conv_problem* problem);
 int rn_conv_cin_pad(int Cin);
 int rn_pack_conv_weight(const float* w_hwio, int R, int S, int Cin, int Cout, int Cin_pad, void* w_packed,
                         void* stream);
+/* Split-bf16 packing for rn_conv_segment.w_terms = terms (2 or 3): plane 0 = rb(w), plane t = rb(w - sum of the
+ * planes before it); bf16 [Cout_pad][R][S][terms][Cin_pad].  layout_ohwi = 0: w is HWIO (Keras), 1: [Cout][R][S][Cin]
+ * (the training engine's master layout). */
+int rn_pack_conv_weight_split(const float* w, int layout_ohwi, int R, int S, int Cin, int Cout, int Cin_pad, int terms,
+                              void* w_packed, void* stream);
 /* Stem repack: 7x7x3 HWIO -> bf16 [64][7][32] rows = (kernel row r) x (8 taps x 4 channels),
  * tap 7 and channel 3 zero, matching rn_pack_stem_input's padded NHWC4 image. */
 /* The same packing from the training engine's f32 master layout [Cout][R][S][Cin]. */
@@ -288,10 +310,14 @@ int rn_act_bwd(const void* dz, const void* z, void* dy, int64_t n, int act, void
  *   rn_bn_stats        y -> sums[2][C] = (sum, sum of squares) of THIS rank's pixels
  *   (SyncBN: the caller all-reduces `sums` over ranks and sets count_scale = replicas)
  *   rn_bn_finalize     sums -> fwd[4][C] = (mean, invstd, scale, shift); moving stats update
- *   rn_bn_apply        z = act((y*scale + shift) [* sample_scale[n]] + residual)
- *   rn_bn_bwd_reduce   dz, z, y -> bsums[2][C] = (sum g, sum g*xhat), g = dz*act'(z)
- *   (SyncBN: all-reduce `bsums`)
- *   rn_bn_bwd_apply    dy = scale*(g - sum_g/n - xhat*sum_gxhat/n); dres (+)= g; dgamma, dbeta
+ *   rn_bn_apply        z = act((y*scale + shift) [* sample_scale[n]] + residual); the BatchNorm output, the
+ *                      drop_connect output and (in front of swish) the residual sum are rounded to bf16 where the
+ *                      reference holds a bf16 tensor between two layers (see rn_conv_segment)
+ *   rn_bn_bwd_reduce   dz, z, y -> bsums[2][C] = (sum g, sum g*xhat), g = dz*act'(z); also dbeta = bsums[0],
+ *                      dgamma = bsums[1]: the gamma / beta gradients are THIS replica's sums
+ *   (SyncBN: all-reduce `bsums` — after rn_bn_bwd_reduce, so dgamma / dbeta stay local like tf.gradients leaves them
+ *    until the optimizer's cross-replica sum)
+ *   rn_bn_bwd_apply    dy = scale*(g - sum_g/n - xhat*sum_gxhat/n); dres (+)= g
  * All tensors bf16 [P,C] (P = N*H*W), per-channel arrays f32.
  */
 typedef struct {

@@ -7,10 +7,14 @@ bottom/right, BatchNormalization inference = gamma*(x-mean)/sqrt(var+eps)+beta.
 
 Written independently of retinanet-tensorflow2.x_amd/retinanet/model/graph.py (it walks the
 reference's builder order itself), so agreement also checks the product's graph wiring.
-`emulate_bf16=True` rounds weights and every layer output to bfloat16 where the Keras
-mixed_bfloat16 policy would (layer outputs are bf16, variables are cast at use, the two
-prediction convs run in float32: detection_head.py:87), which lets the HIP path be compared
-with a tight tolerance.  Also the cpu_baseline leg of bench.py.
+`emulate_bf16=True` rounds weights and every LAYER output to bfloat16 where the Keras
+mixed_bfloat16 policy (__main__.py:76-77) makes it a bf16 tensor: the output of Conv2D /
+DepthwiseConv2D (conv + bias: one layer, one rounding), of BatchNormalization, of the residual
+`+` (resnet.py:248) / FeatureFusion Add, of drop_connect, of the activation; variables are cast
+at use.  The two prediction convs are built with dtype=float32 (detection_head.py:80-88): their
+input is cast UP, their kernel and bias stay float32, nothing is rounded.  With the rounding
+points shared, the HIP path differs from this file only by fp32 summation order.
+Also the cpu_baseline leg of bench.py.
 """
 from __future__ import annotations
 
@@ -59,11 +63,11 @@ class RefModel:
         if pad is None:
             pad = (k - 1) // 2
         wt = w.permute(3, 2, 0, 1).contiguous()  # OIHW
-        # weights are rounded to bf16 on the GPU path for every conv, the fp32-labelled
-        # prediction convs included (documented deviation: DESIGN.md "prediction convs")
-        wt = _r(wt, self.bf)
         b = self.v.get(name + "/bias")
-        return F.conv2d(x, wt, b, stride=stride, padding=pad)
+        if f32:   # layer dtype float32 (detection_head.py:80-88): f32 kernel, f32 output, no rounding
+            return F.conv2d(x, wt, b, stride=stride, padding=pad)
+        # compute dtype bf16: kernel cast at use, fp32 accumulate, + bias, the layer's output is a bf16 tensor
+        return _r(F.conv2d(x, _r(wt, self.bf), b, stride=stride, padding=pad), self.bf)
 
     @staticmethod
     def _same_pad(x, k, s, value=0.0):
@@ -73,25 +77,27 @@ class RefModel:
         pw = max((math.ceil(W / s) - 1) * s + k - W, 0)
         return F.pad(x, (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2), value=value)
 
-    def _depthwise(self, x, var, stride=1):
+    def _depthwise(self, x, var, stride=1, f32=False):
         """tf.keras DepthwiseConv2D / the depthwise half of SeparableConv2D, padding='same', no bias."""
         w = self.v[var]  # [k,k,C,1]
         k, C = w.shape[0], w.shape[2]
-        wt = _r(w.permute(2, 3, 0, 1).contiguous(), self.bf)  # [C,1,k,k]
-        return F.conv2d(self._same_pad(x, k, stride), wt, None, stride=stride, groups=C)
+        wt = w.permute(2, 3, 0, 1).contiguous()  # [C,1,k,k]
+        if f32:   # inside a dtype=float32 SeparableConv2D (the prediction layers): nothing is rounded
+            return F.conv2d(self._same_pad(x, k, stride), wt, None, stride=stride, groups=C)
+        return _r(F.conv2d(self._same_pad(x, k, stride), _r(wt, self.bf), None, stride=stride, groups=C), self.bf)
 
     def _cs(self, x, name, f32=False):
         """Conv2D or SeparableConv2D, stride 1, SAME, bias (fpn_base.py:28-39, detection_head.py:37-50)."""
         if not self.p.architecture.conv_2d.use_seperable_conv:
             return self._conv(x, name, f32=f32)
-        y = _r(self._depthwise(x, name + "/depthwise_kernel"), self.bf)
+        y = self._depthwise(x, name + "/depthwise_kernel", f32=f32)
         return self._conv(y, name, pad=0, f32=f32, kernel="/pointwise_kernel")
 
     def _bn(self, x, name):
         g, b = self.v[name + "/gamma"], self.v[name + "/beta"]
         m, var = self.v[name + "/moving_mean"], self.v[name + "/moving_variance"]
         s = g / torch.sqrt(var + self.eps)
-        return x * s[None, :, None, None] + (b - m * s)[None, :, None, None]
+        return _r(x * s[None, :, None, None] + (b - m * s)[None, :, None, None], self.bf)
 
     def _act(self, x, kind):
         if kind == "relu":
@@ -121,7 +127,7 @@ class RefModel:
         y = _r(F.relu(self._bn(self._conv(y, c, stride, pad=1), b)), self.bf)
         c, b = self._next()
         y = self._bn(self._conv(y, c, 1), b)
-        return _r(F.relu(y + sc), self.bf)
+        return F.relu(_r(y + sc, self.bf))
 
     # ---- efficientnet.py:222-265 (SE), :291-482 (MBConvBlock), :566-586 (Stem), :783-855 -------------
     def _efficientnet(self, images_nhwc):
@@ -133,7 +139,7 @@ class RefModel:
             f *= width
             n = max(8, int(f + 4) // 8 * 8)
             return int(n + 8 if n < 0.9 * f else n)
-        swish = lambda t: t * torch.sigmoid(t)
+        swish = lambda t: t * torch.sigmoid(t)   # on the bf16 tensor the layer in front of it returned
         bnb = "tpu_batch_normalization"
         x = _r(images_nhwc.permute(0, 3, 1, 2).contiguous(), self.bf)
         x = self._conv(self._same_pad(x, 3, 2), name + "/stem/conv2d", 2, pad=0)
@@ -165,9 +171,8 @@ class RefModel:
             if s == 1 and ci == co:
                 m = getattr(self, "drop_connect_factors", {}).get(i)   # training: per-image 0 or 1/survival_prob
                 if m is not None:
-                    x = x * m.to(x.dtype)[:, None, None, None]
-                x = x + inp
-            x = _r(x, self.bf)
+                    x = _r(x * m.to(x.dtype)[:, None, None, None], self.bf)
+                x = _r(x + inp, self.bf)
             if i == len(blocks) - 1 or blocks[i + 1][1] > 1:
                 red += 1
                 feats[str(red)] = x
@@ -294,18 +299,6 @@ class RefTrainer(RefModel):
         self.momentum = float(params.architecture.batch_norm.momentum)
         self.new_stats = {}
 
-    def _conv(self, x, name, stride=1, pad=None, f32=False, kernel="/kernel"):
-        y = super()._conv(x, name, stride, pad, f32, kernel)
-        # training materialises the pre-BN conv output as bf16 (frozen layers fold BN: no rounding;
-        # the fp32 prediction convs stay fp32)
-        if self.bf and not f32 and (name + kernel) not in self.frozen:
-            y = _r(y, True)
-        return y
-
-    def _depthwise(self, x, var, stride=1):
-        y = super()._depthwise(x, var, stride)
-        return _r(y, True) if self.bf and var not in self.frozen else y   # raw depthwise output is a bf16 tensor
-
     def _bn(self, x, name):
         g, b = self.v[name + "/gamma"], self.v[name + "/beta"]
         if (name + "/gamma") in self.frozen:  # layer.trainable=False -> inference mode
@@ -318,7 +311,7 @@ class RefTrainer(RefModel):
         self.new_stats[name + "/moving_variance"] = (self.v[name + "/moving_variance"] * self.momentum
                                                      + var.detach() * n / (n - 1) * (1 - self.momentum))
         xh = (x - mean[None, :, None, None]) / torch.sqrt(var + self.eps)[None, :, None, None]
-        return xh * g[None, :, None, None] + b[None, :, None, None]
+        return _r(xh * g[None, :, None, None] + b[None, :, None, None], self.bf)
 
     def forward_train(self, images_nhwc):
         feats = self.fpn(self.backbone(images_nhwc.to(self.dtype)))

@@ -39,6 +39,8 @@ __device__ __forceinline__ uint16_t rn_f32_to_bf16(float f) {
   u += 0x7fffu + ((u >> 16) & 1u);
   return (uint16_t)(u >> 16);
 }
+// round to bf16 and back: where the reference materialises a bf16 tensor between two layers
+__device__ __forceinline__ float rn_rb(float v) { return rn_bf16_to_f32(rn_f32_to_bf16(v)); }
 __device__ __forceinline__ uint32_t rn_pack_bf16x2(float lo, float hi) {
   return (uint32_t)rn_f32_to_bf16(lo) | ((uint32_t)rn_f32_to_bf16(hi) << 16);
 }

@@ -82,6 +82,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_fwd_kernel(const ConvArg
   const int H = sg.H, W = sg.W, Cin = sg.CinP, PS = sg.pix_stride;
   const int M = sg.M;
   const int Ktot = R * S * Cin;
+  const int cwrap = sg.cwrap;   // split-bf16 weight planes: the input channels repeat every cwrap
 
   const __amdgpu_buffer_rsrc_t rs_x =
       __builtin_amdgcn_make_buffer_rsrc((void*)sg.x, 0, (int)((long long)sg.N * H * W * PS * 2), 0x00020000);
@@ -149,7 +150,8 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_fwd_kernel(const ConvArg
 #define RN_ISSUE_TILE(buf, tap_, c0_)                                                         \
   do {                                                                                        \
     const int r__ = (tap_) / S, s__ = (tap_) - r__ * S;                                       \
-    const unsigned tap_off__ = (unsigned)((((long long)r__ * W + s__) * PS + (c0_)) * 2);     \
+    const int cw__ = (c0_) < cwrap ? (c0_) : ((c0_) < 2 * cwrap ? (c0_) - cwrap : (c0_) - 2 * cwrap);   \
+    const unsigned tap_off__ = (unsigned)((((long long)r__ * W + s__) * PS + cw__) * 2);      \
     char* st__ = smem + (buf) * STAGE_BYTES;                                                  \
     if (!(ABL & 2) || ((tap_) == 0 && (c0_) == 0)) {                                          \
       _Pragma("unroll") for (int j = 0; j < A_INSTR; ++j) {                                   \
@@ -226,24 +228,34 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_fwd_kernel(const ConvArg
     if (t == 123.456f) ((float*)sg.y)[tid] = t;
     return;
   }
-  // stage 1: registers -> LDS fp32 [BM][BN], with the per-channel affine applied
+  // stage 1: registers -> LDS fp32 [BM][BN]: conv (+bias) output and BatchNorm affine, each rounded to bf16 where
+  // the reference holds a bf16 tensor between two layers (rnet_hip.h, rn_conv_segment)
   float* cl = (float*)smem;
   const int Cout = sg.Cout;
+  const bool affine = sg.scale != nullptr || sg.shift != nullptr;
+  const bool has_res = sg.residual != nullptr;
+  const bool round1 = !OUT_F32 && (affine || has_res);
+  const bool round2 = !OUT_F32 && affine && has_res;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int nl = wave_n * WTN + j * 32 + (lane & 31);
     const int n = n0 + nl;
-    float sc = 1.0f, sf = 0.0f;
+    float sc = 1.0f, sf = 0.0f, bs = 0.0f;
     if (n < Cout) {
       if (sg.scale) sc = sg.scale[n];
       if (sg.shift) sf = sg.shift[n];
+      if (sg.bias) bs = sg.bias[n];
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ml = wave_m * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        cl[ml * BN + nl] = acc[i][j][r] * sc + sf;
+        float t = acc[i][j][r] + bs;
+        if (round1) t = rn_rb(t);
+        if (affine) t = t * sc + sf;
+        if (round2) t = rn_rb(t);
+        cl[ml * BN + nl] = t;
       }
     }
   }
@@ -273,6 +285,10 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_fwd_kernel(const ConvArg
       }
       {
         float f4[4] = {v.x, v.y, v.z, v.w};
+        if (!OUT_F32 && args.act == RN_ACT_SWISH) {   // tf.nn.swish reads the layer output as a bf16 tensor
+#pragma unroll
+          for (int q = 0; q < 4; ++q) f4[q] = rn_rb(f4[q]);
+        }
         rn_apply_act_n<4>(f4, args.act);
         v = make_float4(f4[0], f4[1], f4[2], f4[3]);
       }
@@ -359,6 +375,7 @@ static bool conv_use_big(const rn_conv_problem* p) {
   for (int i = 0; i < p->num_segments; ++i) {
     const rn_conv_segment& s = p->seg[i];
     if (rn_conv_cout_pad(s.Cout) < 256 || s.Cout % 8 != 0) return false;
+    if (s.bias && s.residual) return false;   // the residual variants of the 256-row kernels carry no bias path
     tiles256 += rn_cdiv((long long)s.N * s.Ho * s.Wo, 256) * rn_cdiv(s.Cout, 256);
   }
   return g_conv_force_big || tiles256 >= g_conv_big_min_tiles;
@@ -445,12 +462,17 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
     d.x = (const uint16_t*)s.x; d.w = (const uint16_t*)s.w; d.y = s.y;
     d.scale = s.scale; d.shift = s.shift; d.residual = (const uint16_t*)s.residual;
     d.bn_partial = s.bn_partial;
+    d.bias = s.bias;
     d.N = s.N; d.H = s.H; d.W = s.W; d.Cin = s.Cin; d.pix_stride = s.pix_stride;
     d.Ho = s.Ho; d.Wo = s.Wo; d.Cout = s.Cout;
     d.M = (int)M;
     d.tile_begin = tiles;
     d.n_tiles = (int)rn_cdiv(cp, BNT);
-    d.CinP = rn_conv_cin_pad(s.Cin);
+    const int terms = s.w_terms > 1 ? s.w_terms : 1;
+    RN_CHECK_ARG(terms <= 3, "rn_conv2d_nhwc_fwd: segment %d w_terms=%d (1..3)", i, s.w_terms);
+    d.cwrap = rn_conv_cin_pad(s.Cin);
+    d.CinP = terms * d.cwrap;
+    d.pad2_ = 0;
     tiles += (int)rn_cdiv(M, BM) * d.n_tiles;
   }
   a.total_tiles = tiles;
@@ -539,6 +561,40 @@ extern "C" int rn_pack_conv_weight_ohwi(const float* w_ohwi, int R, int S, int C
   int blocks = (int)(rn_cdiv(total, 256) < 4096 ? rn_cdiv(total, 256) : 4096);
   hipLaunchKernelGGL(pack_weight_ohwi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_ohwi, R * S, Cin,
                      Cout, Cin_pad, Cout_pad, (uint16_t*)w_packed);
+  RN_CHECK_LAUNCH();
+  return RN_OK;
+}
+
+// split-bf16 planes of an f32 kernel (rn_conv_segment.w_terms): [Cout_pad][R*S][terms][Cin_pad], plane 0 = rb(w),
+// plane t = rb(w - planes before it) — x (a bf16 tensor) times the f32 weight, to 16 / 24 weight mantissa bits
+__global__ void pack_weight_split_kernel(const float* __restrict__ w, int ohwi, int RS, int Cin, int Cout, int Cin_pad,
+                                         int Cout_pad, int terms, uint16_t* __restrict__ out) {
+  const long long total = (long long)Cout_pad * RS * Cin_pad;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cin_pad);
+    const long long t = i / Cin_pad;   // = o * RS + tap
+    const int tap = (int)(t % RS), o = (int)(t / RS);
+    float v = 0.0f;
+    if (o < Cout && c < Cin) v = ohwi ? w[t * Cin + c] : w[((long long)tap * Cin + c) * Cout + o];
+    uint16_t* dst = out + (t * terms) * Cin_pad + c;
+    for (int k = 0; k < terms; ++k) {
+      const uint16_t b = rn_f32_to_bf16(v);
+      dst[(long long)k * Cin_pad] = b;
+      v -= rn_bf16_to_f32(b);   // exact: the residual of a round-to-nearest is representable in fp32
+    }
+  }
+}
+
+extern "C" int rn_pack_conv_weight_split(const float* w, int layout_ohwi, int R, int S, int Cin, int Cout, int Cin_pad,
+                                         int terms, void* w_packed, void* stream) {
+  RN_CHECK_ARG(w && w_packed && R > 0 && S > 0 && Cin > 0 && Cout > 0 && Cin_pad >= Cin && terms >= 1 && terms <= 3,
+               "rn_pack_conv_weight_split: bad argument");
+  const int Cout_pad = rn_conv_cout_pad(Cout);
+  const long long total = (long long)Cout_pad * R * S * Cin_pad;
+  int blocks = (int)(rn_cdiv(total, 256) < 4096 ? rn_cdiv(total, 256) : 4096);
+  hipLaunchKernelGGL(pack_weight_split_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, layout_ohwi, R * S,
+                     Cin, Cout, Cin_pad, Cout_pad, terms, (uint16_t*)w_packed);
   RN_CHECK_LAUNCH();
   return RN_OK;
 }

@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(512) conv_big_kernel(const ConvArgs args) {
   int i_tap = 0, i_c0 = 0;        // next K step of that tile
   int i_r = 0, i_s = 0;           // i_tap = i_r * S + i_s
   int g_iss = 0;                  // stream steps issued by this wave
-  int i_W = 0, i_PS = 0, i_Cin = 0;
+  int i_W = 0, i_PS = 0, i_Cin = 0, i_cw = 0;   // i_cw: input channels wrap (split-bf16 weight planes)
   __amdgpu_buffer_rsrc_t rs_x, rs_w;
   unsigned a_off[2], a_mask[2], b_off[2];
   const int d_row = lane >> 2, d_pos = lane & 3;   // DMA instruction j fills rows (j*8 + wave)*16 + lane/4
@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(512) conv_big_kernel(const ConvArgs args) {
     const int lt__ = tile__ - sg__.tile_begin;                                                        \
     const int mt__ = rn_fdiv(lt__, sg__.n_tiles, __frcp_rn((float)sg__.n_tiles)); /* < 2^22 tiles */  \
     const int m0__ = mt__ * BM, n0__ = (lt__ - mt__ * sg__.n_tiles) * BN;                             \
-    i_W = sg__.W; i_PS = sg__.pix_stride; i_Cin = sg__.CinP;                                          \
+    i_W = sg__.W; i_PS = sg__.pix_stride; i_Cin = sg__.CinP; i_cw = sg__.cwrap;                       \
     const int H__ = sg__.H, Ktot__ = RS * i_Cin;                                                      \
     const int rows__ = sg__.Cout <= 64 ? 64 : ((sg__.Cout + 127) / 128) * 128; /* packed weight rows */ \
     rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)sg__.x, 0,                                        \
@@ -112,7 +112,8 @@ __global__ void __launch_bounds__(512) conv_big_kernel(const ConvArgs args) {
 // DMA of the next stream step (4 pieces per wave); advances to the next tile when this one is done
 #define BIG_ISSUE_STEP()                                                                              \
   do {                                                                                                \
-    const unsigned tap_off__ = (unsigned)((((long long)i_r * i_W + i_s) * i_PS + i_c0) * 2);          \
+    const int cw__ = i_c0 < i_cw ? i_c0 : (i_c0 < 2 * i_cw ? i_c0 - i_cw : i_c0 - 2 * i_cw);          \
+    const unsigned tap_off__ = (unsigned)((((long long)i_r * i_W + i_s) * i_PS + cw__) * 2);          \
     const unsigned koff__ = (unsigned)(((long long)i_tap * i_Cin + i_c0) * 2);                        \
     char* st__ = smem + (g_iss & 3) * STAGE_BYTES;                                                    \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                   \

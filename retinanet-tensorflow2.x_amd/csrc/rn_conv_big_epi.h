@@ -5,8 +5,8 @@
 // (weights = MFMA A, pixels = MFMA B, so a lane's registers are 4 consecutive channels of ONE pixel).
 // bf16 output: raw accumulators rounded to bf16 (the reference's Conv2D output under the mixed policy is a bf16
 // tensor), transposed through a 32 x 64 LDS patch (8-byte writes), read back 16 bytes = 8 channels per lane, then
-// scale/shift (folded BN + bias), residual add, activation in fp32, full 128-byte row stores; optional fused
-// BatchNorm forward statistics of the stored values.  f32 output: 32 x 32 f32 patches per j.  `patch` is this
+// BatchNorm scale/shift (-> bf16), residual add (-> bf16), activation, full 128-byte row stores (the rounding
+// points of rnet_hip.h's rn_conv_segment); optional fused BatchNorm forward statistics of the stored values.  f32 output: 32 x 32 f32 patches per j.  `patch` is this
 // wave's 4 KB of LDS; no workgroup barrier.  The caller re-initialises acc for its next tile (big_acc_init).
 #ifndef RN_CONV_BIG_EPI_H_
 #define RN_CONV_BIG_EPI_H_
@@ -62,16 +62,15 @@ __device__ __forceinline__ int tile_of(int v, int total) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
 }
 
-// Shift-only layers (bias + none / relu / relu6, bf16 output, no residual: the head towers): the bias is the
-// accumulators' initial value, so the epilogue rounds acc + bias to bf16 ONCE (like the reference's fp32 BiasAdd
-// followed by the cast) and needs no fp32 pass over the transposed rows — relu / relu6 act on the packed bf16.
+// The Conv2D layer's bias is the accumulators' initial value, so the epilogue rounds acc + bias to bf16 ONCE (the
+// layer's output tensor: fp32 BiasAdd inside the layer, then the cast) and bias-only layers (the head towers) need
+// no fp32 pass over the transposed rows — relu / relu6 act on the packed bf16.
 template <bool OUT_F32, bool HAS_RES>
 __device__ __forceinline__ bool big_bias_in_acc(const ConvArgs& args, const ConvSegDev& sg) {
-  // (compiled out of the residual variants: their launches carry folded-BatchNorm scales anyway, and the extra
-  // code cost the <false, true> kernel 6 %)
-  if (OUT_F32 || HAS_RES) return false;
-  return sg.shift != nullptr && sg.scale == nullptr &&
-         (args.act == RN_ACT_NONE || args.act == RN_ACT_RELU || args.act == RN_ACT_RELU6);
+  // (compiled out of the residual variants: no layer of the reference has both a bias and a residual input — the
+  // dispatcher keeps such launches on the 128-row kernel — and the extra code cost the <false, true> kernel 6 %)
+  if (HAS_RES) return false;
+  return sg.bias != nullptr;
 }
 // accumulators of a new tile: zero, or the bias of the lane's channels (see the layout at the top).  The 64
 // floats of the wave come through the scalar cache (uniform address, constant address space): no vector memory
@@ -81,7 +80,7 @@ __device__ __forceinline__ void big_acc_init(f32x16_t (&acc)[4][2], const ConvAr
   const ConvSegDev& sg = args.seg[c_si];
   if (big_bias_in_acc<OUT_F32, HAS_RES>(args, sg)) {
     typedef const float __attribute__((address_space(4))) cfloat;
-    const cfloat* b = (const cfloat*)(unsigned long long)sg.shift;
+    const cfloat* b = (const cfloat*)(unsigned long long)sg.bias;
     const int nw0 = c_n0 + (wave & 3) * 64;
     const int Cout = sg.Cout;
     const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -138,8 +137,7 @@ __device__ __forceinline__ void big_epilogue(f32x16_t (&acc)[4][2], const ConvAr
       const float4 a = *(const float4*)(sg.scale + nr), b = *(const float4*)(sg.scale + nr + 4);
       sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w; sc[4] = b.x; sc[5] = b.y; sc[6] = b.z; sc[7] = b.w;
     }
-    const bool bias_acc = big_bias_in_acc<OUT_F32, HAS_RES>(args, sg);   // the shift is already in acc
-    if (nok && sg.shift && !bias_acc) {
+    if (nok && sg.shift) {
       const float4 a = *(const float4*)(sg.shift + nr), b = *(const float4*)(sg.shift + nr + 4);
       sf[0] = a.x; sf[1] = a.y; sf[2] = a.z; sf[3] = a.w; sf[4] = b.x; sf[5] = b.y; sf[6] = b.z; sf[7] = b.w;
     }
@@ -161,7 +159,10 @@ __device__ __forceinline__ void big_epilogue(f32x16_t (&acc)[4][2], const ConvAr
     const long long row_bytes = (long long)Cout * 2;
     const int act = args.act;
     const bool clamp_lo = act == RN_ACT_RELU || act == RN_ACT_RELU6, clamp_hi = act == RN_ACT_RELU6;
-    const bool plain = (!sg.scale && !sg.shift && !has_res && act == RN_ACT_NONE) || bias_acc;
+    const bool affine = sg.scale != nullptr || sg.shift != nullptr;
+    // conv (+bias) output only: the transposed bf16 rows are the result, up to relu / relu6 on the packed pairs
+    const bool plain = !affine && !has_res && act != RN_ACT_SWISH;
+    const bool round2 = affine && has_res;   // the BatchNorm output is a bf16 tensor before the residual add
     uint4 rv[2][HAS_RES ? 4 : 1];
 #define BIG_RES_PREFETCH(buf_, i_)                                                                    \
 _Pragma("unroll") for (int pass = 0; pass < (HAS_RES ? 4 : 0); ++pass) {                            \
@@ -222,11 +223,21 @@ _Pragma("unroll") for (int pass = 0; pass < (HAS_RES ? 4 : 0); ++pass) {        
             float f[8] = {bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y), bf_lo(v.z), bf_hi(v.z), bf_lo(v.w), bf_hi(v.w)};
             const float rr[8] = {bf_lo(r4.x), bf_hi(r4.x), bf_lo(r4.y), bf_hi(r4.y),
                                  bf_lo(r4.z), bf_hi(r4.z), bf_lo(r4.w), bf_hi(r4.w)};
+            // f = the Conv2D layer's bf16 output; BatchNorm affine -> bf16 tensor -> residual add -> bf16 tensor
 #pragma unroll
-            for (int q = 0; q < 8; ++q) f[q] = f[q] * sc[q] + sf[q] + rr[q];
+            for (int q = 0; q < 8; ++q) f[q] = f[q] * sc[q] + sf[q];
+            if (round2) {
+#pragma unroll
+              for (int q = 0; q < 8; q += 2) {   // v_cvt_pk_bf16_f32 (RNE) and back
+                const uint32_t pq = pack2(f[q], f[q + 1]);
+                f[q] = bf_lo(pq); f[q + 1] = bf_hi(pq);
+              }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) f[q] += rr[q];
             if (act == RN_ACT_SWISH) {
 #pragma unroll
-              for (int q = 0; q < 8; ++q) f[q] = f[q] / (1.0f + __expf(-f[q]));
+              for (int q = 0; q < 8; ++q) { const float u = rn_rb(f[q]); f[q] = u / (1.0f + __expf(-u)); }
             }
             ov.x = pack2(f[0], f[1]); ov.y = pack2(f[2], f[3]); ov.z = pack2(f[4], f[5]); ov.w = pack2(f[6], f[7]);
             // relu / relu6 on the packed bf16 pairs: rounding is monotonic and 0 and 6 are bf16 values, so

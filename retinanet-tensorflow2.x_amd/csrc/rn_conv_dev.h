@@ -17,9 +17,12 @@ struct ConvSegDev {
   const float* shift;
   const uint16_t* residual;
   float* bn_partial;   // fused BatchNorm forward statistics (bf16 outputs), or null
+  const float* bias;   // Conv2D bias, added to the fp32 accumulator (rnet_hip.h: epilogue)
   int N, H, W, Cin, pix_stride, Ho, Wo, Cout;
-  int M, tile_begin, n_tiles, CinP;  // CinP = Cin rounded up to the K step (weights are zero padded)
+  int M, tile_begin, n_tiles, CinP;  // CinP = K extent per tap = w_terms * (Cin rounded up to the K step)
+  int cwrap, pad2_;                  // input channels wrap at cwrap (= CinP / w_terms): split-bf16 weight planes
 };
+
 
 struct ConvArgs {
   int R, S, sh, sw, pt, pl, act, nseg, total_tiles, pad_;

@@ -59,7 +59,7 @@ constexpr int LDS_BYTES = SEG_TABLE + 16 * 4 + RN_CONV_MAX_SEGMENTS * 64;   // 8
 struct HaloSeg {
   const uint16_t* x;
   const uint16_t* w;
-  int N, H, W, pix_stride, Cout, M, tile_begin, n_tiles, CinP;
+  int N, H, W, pix_stride, Cout, M, tile_begin, n_tiles, CinP, cwrap;
 };
 // layout: 16 dwords of tile_begin (INT_MAX past the last segment), then 16 dwords per segment
 __device__ __forceinline__ void halo_seg_table_fill(char* smem, const ConvArgs& args, int tid) {
@@ -72,7 +72,7 @@ __device__ __forceinline__ void halo_seg_table_fill(char* smem, const ConvArgs& 
     d[0] = (unsigned)px; d[1] = (unsigned)(px >> 32); d[2] = (unsigned)pw; d[3] = (unsigned)(pw >> 32);
     d[4] = g.N; d[5] = g.H; d[6] = g.W; d[7] = g.pix_stride;
     d[8] = g.Cout; d[9] = g.M; d[10] = g.tile_begin; d[11] = g.n_tiles;
-    d[12] = g.CinP; d[13] = 0; d[14] = 0; d[15] = 0;
+    d[12] = g.CinP; d[13] = g.cwrap; d[14] = 0; d[15] = 0;
   }
 }
 __device__ __forceinline__ int halo_seg_of_tile(const char* smem, int tile) {
@@ -91,7 +91,7 @@ __device__ __forceinline__ HaloSeg halo_seg(const char* smem, int si) {
   g.w = (const uint16_t*)(((unsigned long long)HALO_U(q0.w) << 32) | HALO_U(q0.z));
   g.N = (int)HALO_U(q1.x); g.H = (int)HALO_U(q1.y); g.W = (int)HALO_U(q1.z); g.pix_stride = (int)HALO_U(q1.w);
   g.Cout = (int)HALO_U(q2.x); g.M = (int)HALO_U(q2.y); g.tile_begin = (int)HALO_U(q2.z); g.n_tiles = (int)HALO_U(q2.w);
-  g.CinP = (int)HALO_U(q3.x);
+  g.CinP = (int)HALO_U(q3.x); g.cwrap = (int)HALO_U(q3.y);
 #undef HALO_U
   return g;
 }
@@ -111,6 +111,7 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
 #endif
   int p_v = blockIdx.x;        // virtual tile id; exhausted when >= total
   int p_chunk = 0, p_nch = 0;  // chunk of that tile / its chunk count
+  int p_wrap = 0;              // input channel chunks before they repeat (split-bf16 weight planes)
   int p_par = 0;               // patch buffer it goes to
   __amdgpu_buffer_rsrc_t rs_x;
   // byte offset of this lane's 16 bytes of piece j at chunk 0 (or RN_OOB): kept in LDS, one dword per (j, thread)
@@ -135,6 +136,7 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
     const int H__ = sg__.H, W__ = sg__.W, PS__ = sg__.pix_stride, W1__ = W__ + 1, H1__ = H__ + 1;     \
     const int HW__ = H__ * W__;                                                                       \
     p_nch = sg__.CinP / BK;                                                                           \
+    p_wrap = sg__.cwrap / BK;                                                                         \
     rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)sg__.x, 0,                                        \
                                              (int)((long long)sg__.N * HW__ * PS__ * 2), 0x00020000); \
     const int ml__ = (m0__ + BM - 1 < sg__.M ? m0__ + BM - 1 : sg__.M - 1);                           \
@@ -162,7 +164,8 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
 // one piece of the next chunk's patch (piece index compile time); after the last piece the stream advances
 #define HALO_ISSUE_PIX(j_, pa_)                                                                       \
   do {                                                                                                \
-    const unsigned v__ = (pa_) == RN_OOB ? RN_OOB : (pa_) + (unsigned)(p_chunk * (BK * 2));           \
+    const int pc__ = p_chunk < p_wrap ? p_chunk : (p_chunk < 2 * p_wrap ? p_chunk - p_wrap : p_chunk - 2 * p_wrap); \
+    const unsigned v__ = (pa_) == RN_OOB ? RN_OOB : (pa_) + (unsigned)(pc__ * (BK * 2));              \
     if (!(HALO_ABLATE & 2))                                                                           \
       dma16(rs_x, smem + p_par * PIX_BYTES + (wave & 3) * PLANE + (2 * (j_) + (wave >> 2)) * 1024, v__); \
     if ((j_) == PIECES - 1 && p_v < total) {                                                          \

@@ -244,6 +244,12 @@ __global__ void __launch_bounds__(1024) bn_colreduce_final_kernel(const BnArgs a
       for (int j = 0; j < 64; ++j) t += red[which][j][cl];
       float* out = a.mode == 0 ? s.sums : s.bsums;
       out[which * s.C + cc] = (float)t;
+      // gamma / beta gradients are THIS replica's sums (tf.gradients of SyncBatchNormalization: only the
+      // optimizer's all-reduce makes them global) — written here, before the caller all-reduces bsums
+      if (a.mode == 1) {
+        float* gp = which == 0 ? s.dbeta : s.dgamma;
+        if (gp) gp[cc] = (float)t;
+      }
       red[which][0][cl] = (double)(float)t;   // for the fused finalize below (same value the unfused path reads)
     }
   }
@@ -260,8 +266,10 @@ __global__ void bn_finalize_kernel(const BnArgs a) {
   bn_finalize_channel(a, s, c, (double)s.sums[c], (double)s.sums[s.C + c]);
 }
 
-// z = act(y*scale + shift + residual).  The grid-stride is rounded to a multiple of C/8 so a
-// thread keeps ONE 8-channel group for all its rows and holds that group's scale/shift in registers.
+// z = act(y*scale + shift + residual), with a bf16 tensor where the reference has one between two layers: the
+// BatchNorm output (when something other than relu / relu6 follows it), the drop_connect output, the residual sum
+// in front of tf.nn.swish.  The grid-stride is rounded to a multiple of C/8 so a thread keeps ONE 8-channel group
+// for all its rows and holds that group's scale/shift in registers.
 __global__ void __launch_bounds__(TR_THREADS) bn_apply_kernel(const BnArgs a) {
   const BnSegDev& s = a.seg[blockIdx.y];
   const int C8 = s.C >> 3;
@@ -283,10 +291,17 @@ __global__ void __launch_bounds__(TR_THREADS) bn_apply_kernel(const BnArgs a) {
     bf8 res;
     if (s.residual) res = unpack8(s.residual[i]);
     const float m = s.sample_scale ? s.sample_scale[(int)(i / C8) / (int)s.rows_per_sample] : 1.0f;
+    const bool swish = a.act == RN_ACT_SWISH;
+    const bool r1 = s.residual != nullptr || s.sample_scale != nullptr || swish;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      float v = (y.v[q] * sc[q] + sh[q]) * m;
-      if (s.residual) v += res.v[q];
+      float v = y.v[q] * sc[q] + sh[q];
+      if (r1) v = rn_rb(v);
+      if (s.sample_scale) v = rn_rb(v * m);
+      if (s.residual) {
+        v += res.v[q];
+        if (swish) v = rn_rb(v);
+      }
       o.v[q] = v;
     }
     rn_apply_act_n<8>(o.v, a.act);
@@ -294,7 +309,7 @@ __global__ void __launch_bounds__(TR_THREADS) bn_apply_kernel(const BnArgs a) {
   }
 }
 
-// dy = scale*(g - sum_g/n - xhat*sum_gxhat/n); dres (+)= g; block 0 also writes dgamma/dbeta.
+// dy = scale*(g - sum_g/n - xhat*sum_gxhat/n); dres (+)= g  (dgamma / dbeta: written by the backward reduction).
 // Same fixed-channel-group threading as bn_apply_kernel: 5 per-channel parameters in registers.
 template <int G>
 __global__ void __launch_bounds__(TR_THREADS) bn_bwd_apply_kernel(const BnArgs a) {
@@ -302,12 +317,6 @@ __global__ void __launch_bounds__(TR_THREADS) bn_bwd_apply_kernel(const BnArgs a
   const int C8 = s.C >> 3;
   const long long total = s.P * C8;
   const float inv_n = (float)(1.0 / ((double)s.P * (double)a.count_scale));
-  if (blockIdx.x == 0) {
-    for (int c = threadIdx.x; c < s.C; c += blockDim.x) {
-      if (s.dbeta) s.dbeta[c] = s.bsums[c];
-      if (s.dgamma) s.dgamma[c] = s.bsums[s.C + c];
-    }
-  }
   const long long nthreads = (long long)gridDim.x * blockDim.x;
   const long long lanes = nthreads / C8 * C8;
   const long long gtid = blockIdx.x * (long long)blockDim.x + threadIdx.x;

@@ -17,6 +17,9 @@ LIB_PATH = os.environ.get("RNET_HIP_LIB") or os.path.join(_HERE, "librnet_hip.so
 RN_DT_F32, RN_DT_BF16 = 0, 1
 RN_ACT_NONE, RN_ACT_RELU, RN_ACT_RELU6, RN_ACT_SWISH = 0, 1, 2, 3
 RN_CONV_MAX_SEGMENTS = 10
+ABI_VERSION = 2
+# f32 kernels of the dtype=float32 prediction convs (detection_head.py:80-88) as split-bf16 planes (rn_conv_segment.w_terms)
+PRED_W_TERMS = int(os.environ.get("RNET_PRED_W_TERMS", "2"))
 ACT_IDS = {None: RN_ACT_NONE, "none": RN_ACT_NONE, "relu": RN_ACT_RELU, "relu6": RN_ACT_RELU6,
            "swish": RN_ACT_SWISH}
 
@@ -39,7 +42,8 @@ class ExampleInfo(Structure):   # rn_example_info
 class ConvSegment(Structure):
     _fields_ = [("x", c_void_p), ("w", c_void_p), ("y", c_void_p), ("scale", c_void_p), ("shift", c_void_p),
                 ("residual", c_void_p), ("N", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32),
-                ("pix_stride", c_int32), ("Ho", c_int32), ("Wo", c_int32), ("Cout", c_int32), ("bn_partial", c_void_p)]
+                ("pix_stride", c_int32), ("Ho", c_int32), ("Wo", c_int32), ("Cout", c_int32), ("bn_partial", c_void_p),
+                ("bias", c_void_p), ("w_terms", c_int32), ("pad_", c_int32)]
 
 
 class ConvProblem(Structure):
@@ -139,6 +143,8 @@ _SIGNATURES = {
     "rn_squeeze_excite_inplace": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_int, c_void_p, c_size_t, c_void_p]),
     "rn_pack_conv_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rn_pack_conv_weight_split": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                          c_void_p]),
     "rn_pack_stem_weight": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "rn_stem_padded_width": (c_int, [c_int]),
     "rn_pack_stem_input": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
@@ -211,6 +217,8 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
+        if handle.rn_abi_version() != ABI_VERSION:
+            raise RnetError(f"{LIB_PATH}: ABI version {handle.rn_abi_version()}, this binding needs {ABI_VERSION}: rebuild")
         _lib = handle
     return _lib
 

@@ -3,8 +3,8 @@
 `InferenceEngine` is the MI355X replacement of `model(images, training=False)` for the Keras
 model the reference builds (retinanet/model/builder.py:94-106): weights are packed once to the
 MFMA-friendly bf16 [Cout][R][S][Cin] layout, BatchNorm (inference mode: moving statistics) and
-conv bias are folded into a per-channel scale/shift applied in the conv epilogue together with
-the activation and the residual add, all activations live in buffers allocated once, and the
+conv bias are applied in the conv epilogue together with the activation and the residual add (rounded to bf16
+where the reference holds a bf16 tensor between two layers: rnet_hip.h, rn_conv_segment), all activations live in buffers allocated once, and the
 launch list is fixed — so the whole forward pass can be captured in a HIP graph
 (`capture_graph=True`) and replayed with one host call instead of ~70.
 """
@@ -111,17 +111,29 @@ class InferenceEngine:
                 else:
                     buf = self.packed.get(cname)
                     cin_pad = lib.rn_conv_cin_pad(c["cin"])
+                    terms = self._w_terms(op)
                     if buf is None:
-                        buf = torch.empty((cout_pad, c["k"], c["k"], cin_pad), dtype=torch.bfloat16,
+                        buf = torch.empty((cout_pad, c["k"], c["k"], terms * cin_pad), dtype=torch.bfloat16,
                                           device=self.dev)
-                    _C.check(lib.rn_pack_conv_weight(_C.ptr(w), c["k"], c["k"], c["cin"], c["cout"], cin_pad,
-                                                     _C.ptr(buf), st), "rn_pack_conv_weight")
+                    if terms > 1:   # f32 layer (detection_head.py:80-88): its f32 kernel as split-bf16 planes
+                        _C.check(lib.rn_pack_conv_weight_split(_C.ptr(w), 0, c["k"], c["k"], c["cin"], c["cout"], cin_pad,
+                                                               terms, _C.ptr(buf), st), "rn_pack_conv_weight_split")
+                    else:
+                        _C.check(lib.rn_pack_conv_weight(_C.ptr(w), c["k"], c["k"], c["cin"], c["cout"], cin_pad,
+                                                         _C.ptr(buf), st), "rn_pack_conv_weight")
                 self.packed[cname] = buf
             self._fold(op["out"], variables, op.get("bn"), variables.get(cname + "/bias"))
 
+    def _w_terms(self, op):
+        """split-bf16 weight planes of the dtype=float32 prediction convs (rn_conv_segment.w_terms); 1 elsewhere"""
+        return _C.PRED_W_TERMS if op.get("out_dtype") == "f32" and op["op"] == "conv" else 1
+
     def _fold(self, key, variables, bn, bias):
-        """y = conv*scale + shift;  BN inference: gamma*(x+bias-mean)/sqrt(var+eps)+beta."""
+        """(scale, shift, bias) of the conv epilogue: the Conv2D layer's bias stays separate (it is added before the
+        layer's output is rounded to bf16), BN inference = x*scale + shift with scale = gamma/sqrt(var+eps),
+        shift = beta - mean*scale."""
         bias = None if bias is None else bias.to(self.dev, torch.float32)
+        scale = shift = None
         if bn:
             gamma = variables[bn + "/gamma"].to(self.dev, torch.float32)
             beta = variables[bn + "/beta"].to(self.dev, torch.float32)
@@ -129,31 +141,27 @@ class InferenceEngine:
             var = variables[bn + "/moving_variance"].to(self.dev, torch.float32)
             scale = gamma / torch.sqrt(var + self.eps)
             shift = beta - mean * scale
-            if bias is not None:
-                shift = shift + bias * scale
-        else:
-            scale = None
-            shift = bias
+        new = (scale, shift, bias)
         old = self.fold.get(key)
         if old is None:
-            self.fold[key] = [None if scale is None else scale.contiguous(),
-                              None if shift is None else shift.contiguous()]
+            self.fold[key] = [None if t is None else t.contiguous() for t in new]
         else:  # keep addresses stable for a captured graph
-            if scale is not None:
-                old[0].copy_(scale)
-            if shift is not None:
-                old[1].copy_(shift)
+            for dst, src in zip(old, new):
+                if src is not None:
+                    dst.copy_(src)
 
     # ---- launch list -------------------------------------------------------------------------
     def _conv_segment(self, seg, op):
         c = self.g.convs[op["conv"]]
         x, y = self.t[op["inp"]], self.t[op["out"]]
-        scale, shift = self.fold[op["out"]]
+        scale, shift, bias = self.fold[op["out"]]
         seg.x = x.data_ptr()
         seg.w = self.packed[op["conv"]].data_ptr()
         seg.y = y.data_ptr()
         seg.scale = scale.data_ptr() if scale is not None else None
         seg.shift = shift.data_ptr() if shift is not None else None
+        seg.bias = bias.data_ptr() if bias is not None else None
+        seg.w_terms = self._w_terms(op)
         seg.residual = self.t[op["residual"]].data_ptr() if op.get("residual") else None
         seg.N, seg.H, seg.W, seg.Cin = self.B, x.shape[1], x.shape[2], c["cin"]
         seg.pix_stride = x.shape[3]
@@ -199,7 +207,7 @@ class InferenceEngine:
                     (d0["k"], d0["stride"], first["pad_top"], first["pad_left"], first["act"]):
                 raise ValueError(f"depthwise group {first.get('group')} mixes shapes")
             x, y = self.t[op["inp"]], self.t[op["out"]]
-            scale, shift = self.fold[op["out"]]
+            scale, shift, _ = self.fold[op["out"]]
             s = p.seg[i]
             s.x, s.w, s.y = x.data_ptr(), self.packed[op["dw"]].data_ptr(), y.data_ptr()
             s.scale = scale.data_ptr() if scale is not None else None
@@ -237,7 +245,7 @@ class InferenceEngine:
                 p.out_dtype = _C.RN_DT_BF16
                 p.num_segments = 1
                 s = p.seg[0]
-                scale, shift = self.fold[op["out"]]
+                scale, shift, _ = self.fold[op["out"]]
                 s.x, s.w, s.y = pin, self.packed[op["conv"]].data_ptr(), pout
                 s.scale, s.shift, s.residual = scale.data_ptr(), shift.data_ptr(), None
                 s.N, s.H, s.W, s.Cin, s.pix_stride = B, self.Hp, self.Wp, 32, 4

@@ -174,6 +174,9 @@ class TrainEngine:
         self.p_off, self.bf_off = {}, {}     # bf_off: conv name | "dw:<name>" | "<se>:w1" / "<se>:w2" -> offset in Pbf
         self.fwd_packs = []                  # live convs whose Cin is not its own K-step padding: repacked per step
         self.fwd_pack_of = {}
+        self.split_packs = []                # live f32 convs (prediction layers): split-bf16 planes, repacked per step
+        self.split_pack_of = {}
+        f32_convs = {o["conv"] for o in self.ops if o["op"] == "conv" and o.get("out_dtype") == "f32"}
         for i, k in enumerate(names):
             n = v[k].numel()
             kind, layer = self.var_kind.get(k, ("other", None))
@@ -182,6 +185,12 @@ class TrainEngine:
                 c = self.g.convs[layer]
                 if c["cin"] == 3:
                     pass                                        # first-layer conv: its own packed form
+                elif layer in f32_convs and _C.PRED_W_TERMS > 1:
+                    cinp = lib.rn_conv_cin_pad(c["cin"])        # detection_head.py:80-88: the layer keeps its f32 kernel
+                    buf = torch.zeros((lib.rn_conv_cout_pad(c["cout"]), c["k"], c["k"], _C.PRED_W_TERMS * cinp),
+                                      dtype=torch.bfloat16, device=self.dev)
+                    self.split_packs.append((k, c, cinp, buf))
+                    self.split_pack_of[layer] = buf
                 elif lib.rn_conv_cin_pad(c["cin"]) == c["cin"]:
                     bfo = bf_off                                # plain cast of the master = the compute layout
                     self.bf_off[layer] = bf_off
@@ -267,6 +276,11 @@ class TrainEngine:
             off, _ = self.p_off[kname]
             _C.check(self.lib.rn_pack_conv_weight_ohwi(self.P.data_ptr() + 4 * off, c["k"], c["k"], c["cin"], c["cout"],
                                                        cinp, buf.data_ptr(), st), "rn_pack_conv_weight_ohwi")
+        for (kname, c, cinp, buf) in self.split_packs:
+            off, _ = self.p_off[kname]
+            _C.check(self.lib.rn_pack_conv_weight_split(self.P.data_ptr() + 4 * off, 1, c["k"], c["k"], c["cin"],
+                                                        c["cout"], cinp, _C.PRED_W_TERMS, buf.data_ptr(), st),
+                     "rn_pack_conv_weight_split")
 
     def refresh_stem_pack(self):
         self.refresh_packs()
@@ -423,19 +437,16 @@ class TrainEngine:
                 gmm, bta = v[bn + "/gamma"].to(self.dev).float(), v[bn + "/beta"].to(self.dev).float()
                 mean, var = v[bn + "/moving_mean"].to(self.dev).float(), v[bn + "/moving_variance"].to(self.dev).float()
                 scale = (gmm / torch.sqrt(var + self.eps)).contiguous()
-                shift = bta - mean * scale
-                if bias is not None:
-                    shift = shift + bias.to(self.dev).float() * scale
-                shift = shift.contiguous()
-            elif bias is not None:
-                shift = bias.to(self.dev).float().contiguous()
-            self.fold[op["out"]] = (scale, shift)
+                shift = (bta - mean * scale).contiguous()
+            # the Conv2D bias stays separate: it is added before the layer's output is rounded (rn_conv_segment)
+            bias = None if bias is None else bias.to(self.dev).float().contiguous()
+            self.fold[op["out"]] = (scale, shift, bias)
         if old_fold is not None:
             # a refold after a restore: the launch descriptors hold the first buffers' addresses -> copy in place
             for k, buf in self.packed_frozen.items():
                 old_packed[k].copy_(buf)
-            for k, (scale, shift) in self.fold.items():
-                for dst, src in zip(old_fold[k], (scale, shift)):
+            for k, new3 in self.fold.items():
+                for dst, src in zip(old_fold[k], new3):
                     if dst is not None:
                         dst.copy_(src)
             self.fold, self.packed_frozen = old_fold, old_packed
@@ -487,6 +498,8 @@ class TrainEngine:
             return self.packed_frozen[cname].data_ptr()
         if cname in self.fwd_pack_of:
             return self.fwd_pack_of[cname].data_ptr()
+        if cname in self.split_pack_of:
+            return self.split_pack_of[cname].data_ptr()
         return self.Pbf.data_ptr() + 2 * self.bf_off[cname]
 
     def _conv_problem(self, ops, dst_of, raw_mode):
@@ -505,19 +518,17 @@ class TrainEngine:
             x, y = self._src(op["inp"]), dst_of(op)
             s = p.seg[i]
             s.x, s.w, s.y = x.data_ptr(), self._weight_ptr(op["conv"]), y.data_ptr()
-            if raw_mode:
-                s.scale = None
-                s.shift = (self._pview(op["conv"] + "/bias").data_ptr() if c["bias"] else None)
-                s.residual = None
+            s.scale = s.shift = s.bias = s.residual = None
+            if raw_mode or self._conv_trainable(op):   # raw pre-BN output, or a live conv without BN (prediction convs)
+                s.bias = self._pview(op["conv"] + "/bias").data_ptr() if c["bias"] else None
             else:
-                if self._conv_trainable(op):      # live conv without BN (prediction convs)
-                    s.scale = None
-                    s.shift = (self._pview(op["conv"] + "/bias").data_ptr() if c["bias"] else None)
-                else:
-                    sc, sh = self.fold[op["out"]]
-                    s.scale = sc.data_ptr() if sc is not None else None
-                    s.shift = sh.data_ptr() if sh is not None else None
+                sc, sh, bs = self.fold[op["out"]]
+                s.scale = sc.data_ptr() if sc is not None else None
+                s.shift = sh.data_ptr() if sh is not None else None
+                s.bias = bs.data_ptr() if bs is not None else None
+            if not raw_mode:
                 s.residual = self.t[op["residual"]].data_ptr() if op.get("residual") else None
+            s.w_terms = _C.PRED_W_TERMS if op["conv"] in self.split_pack_of else 1
             s.N, s.H, s.W, s.Cin, s.pix_stride = self.B, x.shape[1], x.shape[2], c["cin"], x.shape[3]
             s.Ho, s.Wo, s.Cout = y.shape[1], y.shape[2], c["cout"]
         self._keep.append(p)
@@ -644,7 +655,7 @@ class TrainEngine:
                     s.x, s.w, s.y = pin, self.stem_packed.data_ptr(), self.raw[op["out"]].data_ptr()
                     s.scale, s.shift, s.residual = None, None, None
                 else:
-                    sc, sh = self.fold[op["out"]]
+                    sc, sh, _ = self.fold[op["out"]]
                     s.x, s.w, s.y = pin, self.packed_frozen[op["conv"]].data_ptr(), y.data_ptr()
                     s.scale, s.shift, s.residual = sc.data_ptr(), sh.data_ptr(), None
                 s.N, s.H, s.W, s.Cin, s.pix_stride = B, self.Hp, self.Wp, 32, 4

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     lib = _C.lib()
     for name in _declared():
         assert hasattr(lib, name), name
-    assert lib.rn_abi_version() == 1
+    assert lib.rn_abi_version() == _C.ABI_VERSION
 
 
 def test_product_never_imports_oracle():

@@ -1,9 +1,11 @@
-"""GPU parity: K1/K2 implicit-GEMM conv (+ folded BN / bias / residual / activation) and the
-pooling / FPN / BalanceFeatures kernels against a plain PyTorch-CPU float32 reference on the
-same bf16-rounded inputs.  Tolerance: fp32 accumulation-order noise plus one bf16 rounding of
-the output (2^-8 relative)."""
+"""GPU parity: K1/K2 implicit-GEMM conv (+ bias / folded BN / residual / activation, with a bf16 tensor where the
+reference has one between two layers: include/rnet_hip.h rn_conv_segment) and the pooling / FPN / BalanceFeatures
+kernels against a float64 PyTorch-CPU restatement on the same bf16-rounded inputs.  Because the rounding points
+are shared, the only difference left is fp32 summation order: an output may sit ONE bf16 step off where the sum
+straddles a rounding boundary (rtol 2^-7), and only a small fraction of the outputs may."""
 import ctypes
 import math
+import zlib
 
 import numpy as np
 import pytest
@@ -15,6 +17,11 @@ pytestmark = pytest.mark.gpu
 
 def _bf(x):
     return x.to(torch.bfloat16)
+
+
+def _seed(case):
+    """reproducible across processes (hash() of a tuple with strings is salted per process)"""
+    return zlib.crc32(repr(case).encode()) % (2 ** 31)
 
 
 def _conv_gpu(cuda, segs, k, stride, pad, act, out_f32):
@@ -33,22 +40,30 @@ def _conv_gpu(cuda, segs, k, stride, pad, act, out_f32):
         w = s["w"].to(cuda).float().contiguous()          # HWIO
         kk, _, cin, cout = w.shape
         cinp = lib.rn_conv_cin_pad(cin)
-        wp = torch.empty((lib.rn_conv_cout_pad(cout), kk, kk, cinp), dtype=torch.bfloat16, device=cuda)
-        _C.check(lib.rn_pack_conv_weight(_C.ptr(w), kk, kk, cin, cout, cinp, _C.ptr(wp), _C.current_stream()))
+        terms = int(s.get("w_terms", 1))
+        wp = torch.empty((lib.rn_conv_cout_pad(cout), kk, kk, terms * cinp), dtype=torch.bfloat16, device=cuda)
+        if terms > 1:
+            _C.check(lib.rn_pack_conv_weight_split(_C.ptr(w), 0, kk, kk, cin, cout, cinp, terms, _C.ptr(wp),
+                                                   _C.current_stream()))
+        else:
+            _C.check(lib.rn_pack_conv_weight(_C.ptr(w), kk, kk, cin, cout, cinp, _C.ptr(wp), _C.current_stream()))
         N, H, W, _ = x.shape
         Ho, Wo = (H + 2 * pad - kk) // stride + 1, (W + 2 * pad - kk) // stride + 1
         y = torch.empty((N, Ho, Wo, cout), dtype=torch.float32 if out_f32 else torch.bfloat16, device=cuda)
-        sc = s.get("scale"); sh = s.get("shift"); res = s.get("residual")
+        sc = s.get("scale"); sh = s.get("shift"); res = s.get("residual"); bs = s.get("bias")
         sc = None if sc is None else sc.to(cuda).float().contiguous()
         sh = None if sh is None else sh.to(cuda).float().contiguous()
+        bs = None if bs is None else bs.to(cuda).float().contiguous()
         res = None if res is None else _bf(res).to(cuda).contiguous()
         g = p.seg[i]
         g.x, g.w, g.y = x.data_ptr(), wp.data_ptr(), y.data_ptr()
         g.scale = sc.data_ptr() if sc is not None else None
         g.shift = sh.data_ptr() if sh is not None else None
         g.residual = res.data_ptr() if res is not None else None
+        g.bias = bs.data_ptr() if bs is not None else None
+        g.w_terms = terms
         g.N, g.H, g.W, g.Cin, g.pix_stride, g.Ho, g.Wo, g.Cout = N, H, W, cin, cin, Ho, Wo, cout
-        keep += [x, wp, sc, sh, res]
+        keep += [x, wp, sc, sh, res, bs]
         outs.append(y)
     _C.check(lib.rn_conv2d_nhwc_fwd(ctypes.byref(p), _C.current_stream()), "conv")
     torch.cuda.synchronize()
@@ -56,22 +71,34 @@ def _conv_gpu(cuda, segs, k, stride, pad, act, out_f32):
 
 
 def _conv_ref(s, k, stride, pad, act, out_f32):
-    x = _bf(s["x"]).float().permute(0, 3, 1, 2)
-    w = _bf(s["w"]).float().permute(3, 2, 0, 1)
-    y = F.conv2d(x.double(), w.double(), stride=stride, padding=pad).float().permute(0, 2, 3, 1)
+    """include/rnet_hip.h rn_conv_segment: bf16 output = Conv2D(+bias) -> bf16 -> BatchNorm affine -> bf16 ->
+    residual add -> bf16 -> activation; f32 output (a dtype=float32 layer): f32 weights, no rounding."""
+    rb = (lambda t: t) if out_f32 else (lambda t: _bf(t.float()).double())
+    x = _bf(s["x"]).double().permute(0, 3, 1, 2)
+    w = s["w"].double() if s.get("w_terms", 1) == 3 else _bf(s["w"]).double()
+    if s.get("w_terms", 1) == 2:
+        w = w + _bf(s["w"] - _bf(s["w"]).float()).double()
+    y = F.conv2d(x, w.permute(3, 2, 0, 1), stride=stride, padding=pad).permute(0, 2, 3, 1)
+    if s.get("bias") is not None:
+        y = y + s["bias"].double()
+    affine = s.get("scale") is not None or s.get("shift") is not None
+    res = s.get("residual")
+    if affine or res is not None:
+        y = rb(y)
     if s.get("scale") is not None:
-        y = y * s["scale"]
+        y = y * s["scale"].double()
     if s.get("shift") is not None:
-        y = y + s["shift"]
-    if s.get("residual") is not None:
-        y = y + _bf(s["residual"]).float()
+        y = y + s["shift"].double()
+    if res is not None:
+        y = (rb(y) if affine else y) + _bf(res).double()
     if act == "relu":
         y = F.relu(y)
     elif act == "relu6":
         y = F.relu6(y)
     elif act == "swish":
+        y = rb(y)
         y = y * torch.sigmoid(y)
-    return y if out_f32 else _bf(y).float()
+    return y.float() if out_f32 else _bf(y.float()).float()
 
 
 def _close(got, want, out_f32):
@@ -81,6 +108,9 @@ def _close(got, want, out_f32):
     else:
         torch.testing.assert_close(got, want, rtol=1.0 / 128, atol=scale / 256)
         assert (got - want).abs().mean().item() <= 2e-3 * scale
+        # shared rounding points: all that is left is fp32 summation order flipping a rounding here and there
+        # (an intermediate bf16 step shows up amplified by the BatchNorm scale in the few outputs it hits)
+        assert (got != want).float().mean().item() < 0.03
 
 
 CASES = [
@@ -108,7 +138,7 @@ CASES = [
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(str(v) for v in c))
 def test_conv_single(cuda, case):
     N, H, W, Cin, Cout, k, stride, act, use_res, out_f32 = case
-    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    g = torch.Generator().manual_seed(_seed(case))
     pad = (k - 1) // 2
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     s = {"x": torch.randn((N, H, W, Cin), generator=g),
@@ -157,7 +187,7 @@ def test_conv_halo_kernel(cuda, case):
     from retinanet import _C
     lib = _C.lib()
     N, H, W, Cin, Cout, act, use_res, out_f32 = case
-    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    g = torch.Generator().manual_seed(_seed(case))
     s = {"x": torch.randn((N, H, W, Cin), generator=g),
          "w": torch.randn((3, 3, Cin, Cout), generator=g) / math.sqrt(9 * Cin),
          "scale": torch.rand((Cout,), generator=g) + 0.5, "shift": torch.randn((Cout,), generator=g) * 0.1}
@@ -201,17 +231,17 @@ BIAS_CASES = [
 
 @pytest.mark.parametrize("case", BIAS_CASES, ids=lambda c: "bias-" + "x".join(str(v) for v in c))
 def test_conv_bias_only_rounds_once(cuda, case):
-    """Shift-only layers (bias + none / relu / relu6) on the 256-row kernels start their accumulators at the bias
-    (rn_conv_big_epi.h big_acc_init), so the output is bf16(act(sum + bias)) with ONE rounding, like the reference's
-    fp32 BiasAdd + cast: against the float64 restatement at most a sliver of the outputs may sit one bf16 step off
-    (fp32 summation order), far fewer than the double rounding of the scale / shift path produces."""
+    """Conv2D + bias on the 256-row kernels: the accumulators start at the bias (rn_conv_big_epi.h big_acc_init), so
+    the layer's output is bf16(act(sum + bias)) with ONE rounding (fp32 BiasAdd inside the layer, then the cast):
+    against the float64 restatement at most a sliver of the outputs may sit one bf16 step off (fp32 summation
+    order)."""
     from retinanet import _C
     lib = _C.lib()
     N, H, W, Cin, Cout, k, act, grid = case
-    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    g = torch.Generator().manual_seed(_seed(case))
     s = {"x": torch.randn((N, H, W, Cin), generator=g),
          "w": torch.randn((k, k, Cin, Cout), generator=g) / math.sqrt(k * k * Cin),
-         "shift": torch.randn((Cout,), generator=g)}
+         "bias": torch.randn((Cout,), generator=g)}
     pad = (k - 1) // 2
     lib.rn_debug_conv_tile(2)
     lib.rn_debug_conv_halo_grid(grid)
@@ -223,6 +253,91 @@ def test_conv_bias_only_rounds_once(cuda, case):
     want = _conv_ref(s, k, 1, pad, act, False)
     _close(got, want, False)
     assert (got != want).float().mean().item() < 2e-3
+
+
+LAYER_CASES = [
+    # N, H, W, Cin, Cout, k, act, residual, kernel (0 = 128-row, 1 = conv_big, 2 = conv_halo)
+    (2, 20, 20, 256, 256, 3, None, False, 0),     # FPN output conv: Conv2D + bias -> bf16 -> BatchNorm -> bf16
+    (2, 20, 20, 256, 256, 3, None, False, 2),
+    (2, 20, 20, 512, 256, 1, None, False, 1),     # FPN lateral 1x1 + bias + BN
+    (2, 20, 20, 256, 256, 3, "relu", False, 2),   # head tower at inference: conv + bias, BN, relu
+    (2, 12, 12, 64, 256, 1, "relu", True, 0),     # bias AND residual: stays on the 128-row kernel
+]
+
+
+@pytest.mark.parametrize("case", LAYER_CASES, ids=lambda c: "layer-" + "x".join(str(v) for v in c))
+def test_conv_bias_then_batchnorm_rounding_points(cuda, case):
+    """Conv2D(+bias) -> BatchNormalization (-> + residual) as ONE launch: bias before the first rounding, scale /
+    shift after it, the residual after the second — on every kernel the dispatcher can pick."""
+    from retinanet import _C
+    lib = _C.lib()
+    N, H, W, Cin, Cout, k, act, use_res, kid = case
+    g = torch.Generator().manual_seed(_seed(case))
+    s = {"x": torch.randn((N, H, W, Cin), generator=g),
+         "w": torch.randn((k, k, Cin, Cout), generator=g) / math.sqrt(k * k * Cin),
+         "bias": torch.randn((Cout,), generator=g),
+         "scale": torch.rand((Cout,), generator=g) + 0.5, "shift": torch.randn((Cout,), generator=g) * 0.1}
+    if use_res:
+        s["residual"] = torch.randn((N, H, W, Cout), generator=g)
+    pad = (k - 1) // 2
+    lib.rn_debug_conv_tile(2 if kid else 1)
+    try:
+        got = _conv_gpu(cuda, [s], k, 1, pad, act, False)[0]
+    finally:
+        lib.rn_debug_conv_tile(0)
+    _close(got, _conv_ref(s, k, 1, pad, act, False), False)
+
+
+SPLIT_CASES = [
+    # N, H, W, Cin, Cout, k, terms, kernel (0 = 128-row, 1 = conv_big, 2 = conv_halo)
+    (2, 5, 5, 256, 36, 3, 2, 0),         # box prediction conv
+    (1, 10, 10, 256, 720, 3, 2, 0),      # class prediction conv on the 128-row kernel (small launch)
+    (1, 20, 20, 256, 720, 3, 2, 2),      # ... on the halo kernel (what batch 8 / 32 at 640 x 640 runs)
+    (1, 20, 20, 256, 720, 3, 3, 2),
+    (1, 20, 20, 256, 720, 3, 2, 1),      # ... on conv_big_kernel (halo switched off)
+    (2, 16, 16, 160, 720, 1, 2, 1),      # pointwise half of a separable prediction conv (EfficientNet-B3 widths)
+    (2, 16, 16, 160, 36, 1, 3, 0),
+]
+
+
+@pytest.mark.parametrize("case", SPLIT_CASES, ids=lambda c: "split-" + "x".join(str(v) for v in c))
+def test_conv_f32_weights_as_split_bf16_planes(cuda, case):
+    """The dtype=float32 prediction convs (detection_head.py:80-88): bf16 activations x f32 kernel + f32 bias,
+    f32 accumulate, f32 out.  With rn_conv_segment.w_terms the kernel is carried as 2 (3) bf16 planes: against the
+    float64 product with the SAME planes only fp32 summation order is left (<= 2e-5 of the output range); against
+    the product with the untouched f32 kernel the 2-plane form is within 2^-16 per weight (<= 3e-5), the 3-plane
+    form exact to fp32.  One plane (plain bf16 weights, what round 1 shipped) is ~1e-3 off: measured below."""
+    from retinanet import _C
+    lib = _C.lib()
+    N, H, W, Cin, Cout, k, terms, kid = case
+    g = torch.Generator().manual_seed(_seed(case))
+    s = {"x": torch.randn((N, H, W, Cin), generator=g).relu(),          # tower outputs are post-ReLU
+         "w": torch.randn((k, k, Cin, Cout), generator=g) * 0.01,      # RandomNormal(0.01), detection_head.py:40-43
+         "bias": torch.full((Cout,), -4.59512), "w_terms": terms}
+    pad = (k - 1) // 2
+    lib.rn_debug_conv_tile(2 if kid else 1)
+    lib.rn_debug_conv_halo(1 if kid == 2 else 0)
+    try:
+        p = _C.ConvProblem()
+        p.R = p.S = k
+        p.stride_h = p.stride_w = 1
+        p.pad_top = p.pad_left = pad
+        p.out_dtype, p.num_segments = _C.RN_DT_F32, 1
+        sg = p.seg[0]
+        sg.N, sg.H, sg.W, sg.Cin, sg.pix_stride, sg.Ho, sg.Wo, sg.Cout = N, H, W, Cin, Cin, H, W, Cout
+        assert lib.rn_conv_kernel_id(ctypes.byref(p)) == kid
+        got = _conv_gpu(cuda, [s], k, 1, pad, None, True)[0]
+        one = _conv_gpu(cuda, [dict(s, w_terms=1)], k, 1, pad, None, True)[0]
+    finally:
+        lib.rn_debug_conv_halo(1)
+        lib.rn_debug_conv_tile(0)
+    same_planes = _conv_ref(s, k, 1, pad, None, True)
+    exact = _conv_ref(dict(s, w_terms=3), k, 1, pad, None, True)
+    spread = (exact + 4.59512).abs().max().item()       # range of the logits around the bias
+    assert (got - same_planes).abs().max().item() <= 2e-5 * spread
+    assert (got - exact).abs().max().item() <= 3e-5 * spread
+    # what the split buys: plain bf16 weights are two orders of magnitude further from the f32 layer
+    assert (one - exact).abs().max().item() > 10 * (got - exact).abs().max().item()
 
 
 def test_conv_halo_asymmetric_weights(cuda):

@@ -78,8 +78,8 @@ def main():
             s.x, s.w, s.y, s.scale, s.shift = x.data_ptr(), w.data_ptr(), y.data_ptr(), sc.data_ptr(), sh.data_ptr()
             if a.raw:
                 s.scale, s.shift = None, None
-            if a.bias:
-                s.scale = None
+            if a.bias:   # Conv2D + bias (the head towers): the bias is the accumulators' initial value
+                s.scale, s.shift, s.bias = None, None, sh.data_ptr()
             s.residual = res.data_ptr() if use_res else None
             s.N, s.H, s.W, s.Cin, s.pix_stride, s.Ho, s.Wo, s.Cout = a.batch, H, H, cin, cin, Ho, Ho, cout
             keep += [x, w, y, sc, sh, res]
