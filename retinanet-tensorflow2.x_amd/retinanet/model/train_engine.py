@@ -64,6 +64,7 @@ class TrainEngine:
             if any(rx.search(k) for rx in frozen_regexes):
                 self.frozen.add(k)
         self._keep = []
+        self.conv_launches = []   # (name, rn_conv_problem) of every implicit-GEMM launch: lib.rn_conv_kernel_id(byref(p))
         self.step_count = 0
         self.conv_profile = None
         self.fuse_bn_stats = os.environ.get("RNET_FUSE_BN_STATS", "1") != "0"   # conv epilogue writes BN partial sums
@@ -532,6 +533,7 @@ class TrainEngine:
             s.N, s.H, s.W, s.Cin, s.pix_stride = self.B, x.shape[1], x.shape[2], c["cin"], x.shape[3]
             s.Ho, s.Wo, s.Cout = y.shape[1], y.shape[2], c["cout"]
         self._keep.append(p)
+        self.conv_launches.append(("fwd:" + (first.get("group") or first["out"]), p))
         return p
 
     def _dw_problem(self, ops, dst_of):
@@ -1150,6 +1152,7 @@ class TrainEngine:
             s.N, s.H, s.W, s.Cin, s.pix_stride = B, src.shape[1], src.shape[2], cw, cw
             s.Ho, s.Wo, s.Cout = H, W, c["cin"]
         self._keep.append(p)
+        self.conv_launches.append(("dgrad:" + (need[0].get("group") or need[0]["out"]), p))
 
         def dgrad(st, p=p, ups=ups, scatters=scatters):
             for u in ups:

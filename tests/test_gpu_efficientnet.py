@@ -36,9 +36,11 @@ def test_depthwise_conv(cuda, N, H, W, C, k, s, act):
     scale = torch.rand(C, generator=g) + 0.5
     shift = torch.randn(C, generator=g) * 0.1
     xp, pt, pl = _same(x.permute(0, 3, 1, 2), k, s)
-    want = F.conv2d(xp, _bf(w).permute(2, 3, 0, 1).contiguous(), None, stride=s, groups=C)
+    # bf16 tensors between the layers (include/rnet_hip.h): DepthwiseConv2D output, BatchNorm output in front of swish
+    want = _bf(F.conv2d(xp, _bf(w).permute(2, 3, 0, 1).contiguous(), None, stride=s, groups=C))
     want = want * scale[None, :, None, None] + shift[None, :, None, None]
     if act == "swish":
+        want = _bf(want)
         want = want * torch.sigmoid(want)
     elif act == "relu":
         want = F.relu(want)
@@ -273,12 +275,18 @@ def _engine_grad(eng, k):
     return got.reshape(shape).cpu()
 
 
-@pytest.mark.parametrize("name,size,B", [("efficientnet-b0", 256, 2)])
-def test_efficientnet_backward_wiring(cuda, name, size, B):
-    """Whole-network backward (separable heads -> separable FPN -> MBConv backbone incl. the 3x3 stem) for a
-    dense random upstream gradient, against autograd through the bf16-emulating CPU restatement: direction
-    and norm tensor by tensor, with fixed drop_connect factors (some blocks dropped per image)."""
+@pytest.mark.parametrize("name,size,B,upstream", [("efficientnet-b0", 256, 2, "dense"),
+                                                  ("efficientnet-b3", 640, 4, "loss")],
+                         ids=["b0-256-dense-upstream", "config4-b3-640-b4-train-step"])
+def test_efficientnet_backward_wiring(cuda, name, size, B, upstream):
+    """Whole-network backward (separable heads -> separable FPN -> MBConv backbone incl. the 3x3 stem) against
+    autograd through the bf16-emulating CPU restatement: direction and norm tensor by tensor, with fixed
+    drop_connect factors (some blocks dropped per image).  `dense`: a dense random upstream gradient on the
+    predictions; `loss`: BASELINE configs[4] at full size (EfficientNet-B3, 640 x 640, a shard of 4 images) with
+    the real targets and RetinaNetLoss — losses compared too."""
+    from make_golden import synth_gt
     from model_ref import RefTrainer
+    from retinanet.dataloader import LabelEncoder
     from retinanet.cfg import efficientnet_params
     from retinanet.model import ModelBuilder
     from retinanet.model.train_engine import TrainEngine
@@ -301,20 +309,41 @@ def test_efficientnet_backward_wiring(cuda, name, size, B):
     images = torch.randn((B, size, size, 3), generator=g)
     # drop_connect: fix the per-image factors (one block dropped for image 0, one for image 1) and hand the
     # same factors to the restatement
-    assert len(eng.dc_masks) == 9 and all(0.8 <= sp < 1.0 for _, sp in eng.dc_masks.values())
+    # skip blocks: 9 of EfficientNet-B0's 16, 19 of B3's 26 (efficientnet.py:824-827)
+    assert len(eng.dc_masks) == {"efficientnet-b0": 9, "efficientnet-b3": 19}[name]
+    assert all(0.8 <= sp < 1.0 for _, sp in eng.dc_masks.values())
     for j, (out, (m, sp)) in enumerate(sorted(eng.dc_masks.items(), key=lambda kv: int(kv[0][1:].split("_")[0]))):
         m.copy_(torch.tensor([0.0 if (j % 4 == b) else 1.0 / sp for b in range(B)]))
     ref.drop_connect_factors = {int(out[1:].split("_")[0]): m.cpu().double() for out, (m, sp) in eng.dc_masks.items()}
     preds = eng.forward(images.to(cuda), draw=False)
-    up = {k: {lv: torch.randn(preds[k][lv].shape, generator=g) for lv in preds[k]} for k in preds}
-    eng.backward({k: {lv: t.to(cuda) for lv, t in d.items()} for k, d in up.items()})
+    if upstream == "dense":
+        up = {k: {lv: torch.randn(preds[k][lv].shape, generator=g) for lv in preds[k]} for k in preds}
+        eng.backward({k: {lv: t.to(cuda) for lv, t in d.items()} for k, d in up.items()})
+    else:
+        enc = LabelEncoder(p, device=cuda)
+        rng = np.random.default_rng(5)
+        gts = [synth_gt(rng, int(rng.integers(2, 9)), size) for _ in range(B)]
+        Gmax = max(x[0].shape[0] for x in gts)
+        gb, gc, cnt = np.zeros([B, Gmax, 4], np.float32), np.zeros([B, Gmax], np.float32), np.zeros([B], np.int32)
+        for i, (b, c) in enumerate(gts):
+            gb[i, :len(b)], gc[i, :len(c)], cnt[i] = b, c, len(b)
+        targets = enc.encode_batch(torch.from_numpy(gb), torch.from_numpy(gc), torch.from_numpy(cnt))
+        loss = model.loss(targets, preds, compute_grads=True, grad_scale=1.0)
+        eng.backward(model.loss.grads)
     torch.cuda.synchronize()
     rp = ref.forward_train(images)
-    for k in up:
-        for lv in up[k]:
+    for k in rp:
+        for lv in rp[k]:
             a, b = preds[k][lv].float().cpu().double().reshape(-1), rp[k][lv].detach().reshape(-1)
             assert ((a - b).norm() / (b.norm() + 1e-30)).item() < 0.15, (k, lv)
-    sum((rp[k][lv] * up[k][lv].double()).sum() for k in up for lv in up[k]).backward()
+    if upstream == "dense":
+        sum((rp[k][lv] * up[k][lv].double()).sum() for k in up for lv in up[k]).backward()
+    else:
+        rl = ref.loss(rp, targets["_flat"]["class-targets"].cpu().numpy(), targets["_flat"]["box-targets"].cpu().numpy(),
+                      float(targets["num-positives"].sum().item()))
+        for k in ("box-loss", "class-loss", "weighted-loss"):
+            assert loss[k].item() == pytest.approx(float(rl[k].detach()), rel=0.03), k
+        rl["weighted-loss"].backward()
     assert set(eng.train_names) == set(ref.leaf)
     rows = []
     for k in eng.train_names:
