@@ -387,18 +387,39 @@ int rn_balance_features_bwd(void* const* dout, void* const* in, void* const* din
  * over flat f32 arenas.  segs_dev: device array of {i64 offset, i64 size, i32 weight_decay,
  * i32 block_begin, i32 nblocks, i32 pad, i64 bf16_offset}; block_seg_dev: device i32[num_blocks]
  * (block -> segment), blocks of rn_optim_chunk() elements.
- *   rn_optim_clip      g += wd_coeff*w (decayed tensors); per-tensor clip_by_norm then
- *                      clip_by_global_norm; metrics f32[4] = {norm after, norm before, factor}
- *   rn_optim_sgd_step  v = m v - lr g; w += v; ema -= (1-d)(ema - w); bf16 copy of w
+ *   rn_optim_clip      g *= grad_unscale (LossScaleOptimizer.get_unscaled_gradients, executor.py:429-430; 1 = off);
+ *                      g += wd_coeff*w (decayed tensors); per-tensor clip_by_norm then clip_by_global_norm;
+ *                      metrics f32[8] = {norm after, norm before, global factor, l2-regularization =
+ *                      wd_alpha * sum ||w||^2 / 2 over the decayed tensors (executor.py:296-299), 1 if any clip
+ *                      factor != 1, 1 if the gradient norm is not finite, -, -}
+ *   rn_optim_clip_prepare / _factors / _apply: the three stages on their own.  The data-parallel step launches the
+ *                      gradient all-reduce bucket by bucket while the backward pass is still running, on UNclipped
+ *                      gradients (the clip factors need every gradient): `prepare` runs per bucket (blocks
+ *                      [block_begin, block_begin + block_count)), `factors` once at the end and also writes
+ *                      flags[0] = "a factor != 1 on this rank", flags[1] = "not finite" (slots that ride in the
+ *                      last bucket's all-reduce); if some rank's clip fired, `apply` with correction != NULL writes
+ *                      (factor - 1) * g, which is all-reduced and added — the sum then equals the reference's
+ *                      clip-then-all-reduce order (executor.py:432-437).
+ *   rn_optim_sgd_step  v = m v - lr g; w += v (or w += m v - lr g with the new v: nesterov); ema -= (1-d)(ema - w);
+ *                      bf16 copy of w.  skip_flag (device f32, may be NULL): non-zero = drop the step
+ *                      (LossScaleOptimizer.apply_gradients with non-finite gradients).
  */
 int rn_optim_chunk(void);
 size_t rn_optim_workspace_bytes(int num_blocks, int num_segments);
 int rn_optim_clip(float* grads, const float* params, const void* segs_dev, int num_segments,
-                  const int32_t* block_seg_dev, int num_blocks, float wd_coeff, float clipnorm, float* metrics,
-                  void* workspace, size_t workspace_bytes, void* stream);
+                  const int32_t* block_seg_dev, int num_blocks, float wd_coeff, float wd_alpha, float grad_unscale,
+                  float clipnorm, float* metrics, void* workspace, size_t workspace_bytes, void* stream);
+int rn_optim_clip_prepare(float* grads, const float* params, const void* segs_dev, const int32_t* block_seg_dev,
+                          int num_blocks, int block_begin, int block_count, float wd_coeff, float grad_unscale,
+                          float* local_copy /* same layout as grads, or NULL: keeps this rank's gradients */,
+                          void* workspace, size_t workspace_bytes, void* stream);
+int rn_optim_clip_factors(const void* segs_dev, int num_segments, int num_blocks, float clipnorm, float wd_alpha,
+                          float* metrics, float* flags, void* workspace, size_t workspace_bytes, void* stream);
+int rn_optim_clip_apply(float* grads, float* correction, const void* segs_dev, const int32_t* block_seg_dev,
+                        int num_blocks, void* workspace, size_t workspace_bytes, void* stream);
 int rn_optim_sgd_step(float* params, const float* grads, float* momentum_buf, float* ema, void* params_bf16,
                       const void* segs_dev, const int32_t* block_seg_dev, int num_blocks, float lr, float momentum,
-                      float ema_decay, void* stream);
+                      float ema_decay, int nesterov, const float* skip_flag, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * K6  tf.keras.layers.MaxPool2D  (resnet.py:304-307 3x3 s2 SAME; fpn_base.py:25-26,68 2x2 s2)

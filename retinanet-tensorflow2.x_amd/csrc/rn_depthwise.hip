@@ -115,13 +115,12 @@ __global__ void __launch_bounds__(DW_THREADS) depthwise_strip_kernel(const DwArg
       bf8 o, res;
       if (s.residual) res = unpack8(s.residual[oi]);
       // bf16 tensors where the reference has them: DepthwiseConv2D output, BatchNorm output in front of swish
-      // (rnet_hip.h, rn_conv_segment); the accumulate form (data gradients) adds into the rounded conv output
+      // (rnet_hip.h, rn_conv_segment); the accumulate form (data gradients: no affine) adds in fp32, one rounding
       const bool affine = s.scale != nullptr || s.shift != nullptr;
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         float v = acc[tt][q];
-        if (affine || s.residual) v = rn_rb(v);
-        if (affine) v = v * sc[q] + sh[q];
+        if (affine) v = rn_rb(v) * sc[q] + sh[q];
         if (s.residual) v = (affine ? rn_rb(v) : v) + res.v[q];
         if (a.act == RN_ACT_SWISH) v = rn_rb(v);
         o.v[q] = act_exact(v, a.act);

@@ -18,59 +18,86 @@
 
 struct OptSeg { long long offset, size; int wd, block_begin, nblocks, pad_; long long bf16_offset; };
 
+// partial[b] = sum of squares of the block's (unscaled, weight-decayed) gradients; partial_w[b] = sum of squares of
+// its weights when the tensor is weight-decayed (the l2-regularization term the reference logs, executor.py:296-299)
 __global__ void __launch_bounds__(OPT_THREADS)
 optim_sqnorm_kernel(float* __restrict__ g, const float* __restrict__ w, const OptSeg* __restrict__ segs,
-                    const int* __restrict__ block_seg, float wdc, double* __restrict__ partial) {
-  const int si = block_seg[blockIdx.x];
+                    const int* __restrict__ block_seg, int block0, float wdc, float unscale,
+                    double* __restrict__ partial, double* __restrict__ partial_w, float* __restrict__ local_copy) {
+  const int blk = block0 + blockIdx.x;
+  const int si = block_seg[blk];
   const OptSeg s = segs[si];
-  const long long b0 = (long long)(blockIdx.x - s.block_begin) * OPT_CHUNK;
+  const long long b0 = (long long)(blk - s.block_begin) * OPT_CHUNK;
   long long b1 = b0 + OPT_CHUNK;
   if (b1 > s.size) b1 = s.size;
-  float acc = 0.0f;
+  float acc = 0.0f, accw = 0.0f;
+  const bool touch = s.wd || unscale != 1.0f;
   for (long long i = b0 + threadIdx.x; i < b1; i += OPT_THREADS) {
-    float v = g[s.offset + i];
+    float v = g[s.offset + i] * unscale;   // LossScaleOptimizer.get_unscaled_gradients (executor.py:429-430)
     if (s.wd) {
-      v += wdc * w[s.offset + i];
-      g[s.offset + i] = v;
+      const float wv = w[s.offset + i];
+      v += wdc * wv;
+      accw += wv * wv;
     }
+    if (touch) g[s.offset + i] = v;
+    if (local_copy) local_copy[s.offset + i] = v;   // this rank's gradient, kept for the clip correction
     acc += v * v;
   }
-  __shared__ double red[OPT_THREADS / 64];
-  const double d = rn_wave_sum_d((double)acc);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+  __shared__ double red[2][OPT_THREADS / 64];
+  const double d = rn_wave_sum_d((double)acc), dw = rn_wave_sum_d((double)accw);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = d; red[1][threadIdx.x >> 6] = dw; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    double t = 0.0;
-    for (int k = 0; k < OPT_THREADS / 64; ++k) t += red[k];
-    partial[blockIdx.x] = t;
+    double t = 0.0, tw = 0.0;
+    for (int k = 0; k < OPT_THREADS / 64; ++k) { t += red[0][k]; tw += red[1][k]; }
+    partial[blk] = t;
+    partial_w[blk] = tw;
   }
 }
 
+// metrics f32[8]: [0] global norm after clipping, [1] before the global clip, [2] the global factor,
+// [3] l2-regularization = alpha * sum over decayed tensors of ||w||^2 / 2, [4] 1 if any per-tensor or the global
+// factor != 1 on this rank ("the clip fired"), [5] 1 if the gradient norm is not finite (LossScaleOptimizer skips
+// the step).  flags (optional, device f32[2]): [0] += metrics[4], [1] += metrics[5] — the slots that ride in the
+// last gradient bucket of the overlapped all-reduce.
 __global__ void __launch_bounds__(256)
-optim_factors_kernel(const OptSeg* __restrict__ segs, int nseg, const double* __restrict__ partial, float clip,
-                     float* __restrict__ factor, float* __restrict__ metrics) {
-  __shared__ double s_sq[256];
-  double local = 0.0;
+optim_factors_kernel(const OptSeg* __restrict__ segs, int nseg, const double* __restrict__ partial,
+                     const double* __restrict__ partial_w, float clip, float wd_alpha, float* __restrict__ factor,
+                     float* __restrict__ metrics, float* __restrict__ flags) {
+  __shared__ double s_sq[256], s_w[256];
+  __shared__ int s_fired[256];
+  double local = 0.0, localw = 0.0;
+  int fired = 0;
   for (int t = threadIdx.x; t < nseg; t += blockDim.x) {
     const OptSeg s = segs[t];
-    double sq = 0.0;
-    for (int b = 0; b < s.nblocks; ++b) sq += partial[s.block_begin + b];
+    double sq = 0.0, sw = 0.0;
+    for (int b = 0; b < s.nblocks; ++b) { sq += partial[s.block_begin + b]; sw += partial_w[s.block_begin + b]; }
     const float norm = (float)sqrt(sq);
     const float f = clip > 0.0f ? clip / fmaxf(norm, clip) : 1.0f;  // tf.clip_by_norm
     factor[t] = f;
+    fired |= f != 1.0f;
     const float cn = norm * f;
     local += (double)cn * (double)cn;
+    localw += sw;
   }
   s_sq[threadIdx.x] = local;
+  s_w[threadIdx.x] = localw;
+  s_fired[threadIdx.x] = fired;
   __syncthreads();
   if (threadIdx.x == 0) {
-    double tot = 0.0;
-    for (int k = 0; k < 256; ++k) tot += s_sq[k];
+    double tot = 0.0, totw = 0.0;
+    int any = 0;
+    for (int k = 0; k < 256; ++k) { tot += s_sq[k]; totw += s_w[k]; any |= s_fired[k]; }
     const float gn = (float)sqrt(tot);
     const float F = clip > 0.0f ? clip / fmaxf(gn, clip) : 1.0f;    // tf.clip_by_global_norm
+    const bool finite = gn == gn && gn <= 3.0e38f;
     metrics[0] = gn * F;  // global norm of the clipped gradients (executor.py:440 multiplies by R)
     metrics[1] = gn;      // before the global clip
     metrics[2] = F;
+    metrics[3] = (float)(0.5 * (double)wd_alpha * totw);
+    metrics[4] = (any || F != 1.0f) ? 1.0f : 0.0f;
+    metrics[5] = finite ? 0.0f : 1.0f;
+    if (flags) { flags[0] = metrics[4]; flags[1] = metrics[5]; }
     s_sq[0] = (double)F;
   }
   __syncthreads();
@@ -78,23 +105,33 @@ optim_factors_kernel(const OptSeg* __restrict__ segs, int nseg, const double* __
   for (int t = threadIdx.x; t < nseg; t += blockDim.x) factor[t] *= F;
 }
 
+// g <- g * factor[tensor] in place (out == nullptr), or out <- (factor[tensor] - 1) * g: the correction this rank
+// owes an all-reduce that already summed its UNclipped gradients (the optimistic-clip overlap, see rn_optim_clip_*)
 __global__ void __launch_bounds__(OPT_THREADS)
-optim_scale_kernel(float* __restrict__ g, const OptSeg* __restrict__ segs, const int* __restrict__ block_seg,
-                   const float* __restrict__ factor) {
+optim_scale_kernel(float* __restrict__ g, float* __restrict__ out, const OptSeg* __restrict__ segs,
+                   const int* __restrict__ block_seg, const float* __restrict__ factor) {
   const int si = block_seg[blockIdx.x];
   const OptSeg s = segs[si];
   const float f = factor[si];
-  if (f == 1.0f) return;
+  if (f == 1.0f && !out) return;
   const long long b0 = (long long)(blockIdx.x - s.block_begin) * OPT_CHUNK;
   long long b1 = b0 + OPT_CHUNK;
   if (b1 > s.size) b1 = s.size;
-  for (long long i = b0 + threadIdx.x; i < b1; i += OPT_THREADS) g[s.offset + i] *= f;
+  if (out) {
+    const float c = f - 1.0f;
+    for (long long i = b0 + threadIdx.x; i < b1; i += OPT_THREADS) out[s.offset + i] = c * g[s.offset + i];
+  } else {
+    for (long long i = b0 + threadIdx.x; i < b1; i += OPT_THREADS) g[s.offset + i] *= f;
+  }
 }
 
 __global__ void __launch_bounds__(OPT_THREADS)
 optim_sgd_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ v, float* __restrict__ ema,
                  uint16_t* __restrict__ wbf16, const OptSeg* __restrict__ segs, const int* __restrict__ block_seg,
-                 float lr, float momentum, float ema_decay, int use_ema) {
+                 float lr, float momentum, float ema_decay, int use_ema, int nesterov,
+                 const float* __restrict__ skip_flag) {
+  // LossScaleOptimizer.apply_gradients: a step whose gradients are not finite on ANY replica is dropped
+  if (skip_flag && skip_flag[0] != 0.0f) return;
   const int si = block_seg[blockIdx.x];
   const OptSeg s = segs[si];
   const long long b0 = (long long)(blockIdx.x - s.block_begin) * OPT_CHUNK;
@@ -103,7 +140,8 @@ optim_sgd_kernel(float* __restrict__ w, const float* __restrict__ g, float* __re
   for (long long i = b0 + threadIdx.x; i < b1; i += OPT_THREADS) {
     const long long o = s.offset + i;
     const float vel = momentum * v[o] - lr * g[o];
-    const float nw = w[o] + vel;
+    // Keras SGD: w += v  (momentum), or w += momentum * v - lr * g with the NEW v (nesterov=True)
+    const float nw = w[o] + (nesterov ? momentum * vel - lr * g[o] : vel);
     v[o] = vel;
     w[o] = nw;
     if (use_ema) {
@@ -115,43 +153,93 @@ optim_sgd_kernel(float* __restrict__ w, const float* __restrict__ g, float* __re
 }
 
 extern "C" size_t rn_optim_workspace_bytes(int num_blocks, int num_segments) {
-  return rn_align_up((size_t)num_blocks * sizeof(double), 256) + rn_align_up((size_t)num_segments * sizeof(float), 256) + 256;
+  return 2 * rn_align_up((size_t)num_blocks * sizeof(double), 256) + rn_align_up((size_t)num_segments * sizeof(float), 256) + 256;
 }
 extern "C" int rn_optim_chunk(void) { return OPT_CHUNK; }
 
-extern "C" int rn_optim_clip(float* grads, const float* params, const void* segs_dev, int num_segments,
-                             const int32_t* block_seg_dev, int num_blocks, float wd_coeff, float clipnorm,
-                             float* metrics /* dev f32[4] */, void* workspace, size_t workspace_bytes,
-                             void* stream) {
-  RN_CHECK_ARG(grads && params && segs_dev && block_seg_dev && metrics && num_segments > 0 && num_blocks > 0,
-               "rn_optim_clip: bad argument");
-  if (!workspace || workspace_bytes < rn_optim_workspace_bytes(num_blocks, num_segments)) {
-    rn_set_error("rn_optim_clip: workspace too small");
+struct OptWs { double* partial; double* partial_w; float* factor; };
+static OptWs opt_ws(void* workspace, int num_blocks) {
+  OptWs w;
+  const size_t pb = rn_align_up((size_t)num_blocks * sizeof(double), 256);
+  w.partial = (double*)workspace;
+  w.partial_w = (double*)((char*)workspace + pb);
+  w.factor = (float*)((char*)workspace + 2 * pb);
+  return w;
+}
+
+// Stage 1 over blocks [block_begin, block_begin + block_count): unscale, weight decay, per-block sums of squares.
+// The overlapped all-reduce runs it bucket by bucket as the backward pass completes the buckets.
+extern "C" int rn_optim_clip_prepare(float* grads, const float* params, const void* segs_dev,
+                                     const int32_t* block_seg_dev, int num_blocks, int block_begin, int block_count,
+                                     float wd_coeff, float grad_unscale, float* local_copy, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  RN_CHECK_ARG(grads && params && segs_dev && block_seg_dev && num_blocks > 0 && block_begin >= 0 && block_count >= 0 &&
+                   block_begin + block_count <= num_blocks, "rn_optim_clip_prepare: bad argument");
+  if (!workspace || workspace_bytes < rn_optim_workspace_bytes(num_blocks, 1)) {
+    rn_set_error("rn_optim_clip_prepare: workspace too small");
     return RN_ENOMEM;
   }
-  double* partial = (double*)workspace;
-  float* factor = (float*)((char*)workspace + rn_align_up((size_t)num_blocks * sizeof(double), 256));
-  hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(optim_sqnorm_kernel, dim3(num_blocks), dim3(OPT_THREADS), 0, st, grads, params,
-                     (const OptSeg*)segs_dev, block_seg_dev, wd_coeff, partial);
-  RN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(optim_factors_kernel, dim3(1), dim3(256), 0, st, (const OptSeg*)segs_dev, num_segments,
-                     partial, clipnorm, factor, metrics);
-  RN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(optim_scale_kernel, dim3(num_blocks), dim3(OPT_THREADS), 0, st, grads,
-                     (const OptSeg*)segs_dev, block_seg_dev, factor);
+  if (block_count == 0) return RN_OK;
+  const OptWs w = opt_ws(workspace, num_blocks);
+  hipLaunchKernelGGL(optim_sqnorm_kernel, dim3(block_count), dim3(OPT_THREADS), 0, (hipStream_t)stream, grads, params,
+                     (const OptSeg*)segs_dev, block_seg_dev, block_begin, wd_coeff, grad_unscale, w.partial, w.partial_w,
+                     local_copy);
   RN_CHECK_LAUNCH();
   return RN_OK;
 }
 
+// Stage 2: per-tensor and global clip factors from the block sums (+ the l2 metric, the "fired" / "not finite" flags)
+extern "C" int rn_optim_clip_factors(const void* segs_dev, int num_segments, int num_blocks, float clipnorm,
+                                     float wd_alpha, float* metrics, float* flags, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  RN_CHECK_ARG(segs_dev && metrics && num_segments > 0 && num_blocks > 0, "rn_optim_clip_factors: bad argument");
+  if (!workspace || workspace_bytes < rn_optim_workspace_bytes(num_blocks, num_segments)) {
+    rn_set_error("rn_optim_clip_factors: workspace too small");
+    return RN_ENOMEM;
+  }
+  const OptWs w = opt_ws(workspace, num_blocks);
+  hipLaunchKernelGGL(optim_factors_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const OptSeg*)segs_dev,
+                     num_segments, w.partial, w.partial_w, clipnorm, wd_alpha, w.factor, metrics, flags);
+  RN_CHECK_LAUNCH();
+  return RN_OK;
+}
+
+// Stage 3: grads <- grads * factor in place (correction == NULL), or correction <- (factor - 1) * grads
+extern "C" int rn_optim_clip_apply(float* grads, float* correction, const void* segs_dev,
+                                   const int32_t* block_seg_dev, int num_blocks, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+  RN_CHECK_ARG(grads && segs_dev && block_seg_dev && num_blocks > 0 && workspace, "rn_optim_clip_apply: bad argument");
+  const OptWs w = opt_ws(workspace, num_blocks);
+  hipLaunchKernelGGL(optim_scale_kernel, dim3(num_blocks), dim3(OPT_THREADS), 0, (hipStream_t)stream, grads, correction,
+                     (const OptSeg*)segs_dev, block_seg_dev, w.factor);
+  RN_CHECK_LAUNCH();
+  return RN_OK;
+}
+
+extern "C" int rn_optim_clip(float* grads, const float* params, const void* segs_dev, int num_segments,
+                             const int32_t* block_seg_dev, int num_blocks, float wd_coeff, float wd_alpha,
+                             float grad_unscale, float clipnorm, float* metrics /* dev f32[8] */, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+  RN_CHECK_ARG(grads && params && segs_dev && block_seg_dev && metrics && num_segments > 0 && num_blocks > 0,
+               "rn_optim_clip: bad argument");
+  int rc = rn_optim_clip_prepare(grads, params, segs_dev, block_seg_dev, num_blocks, 0, num_blocks, wd_coeff,
+                                 grad_unscale, nullptr, workspace, workspace_bytes, stream);
+  if (rc) return rc;
+  rc = rn_optim_clip_factors(segs_dev, num_segments, num_blocks, clipnorm, wd_alpha, metrics, nullptr, workspace,
+                             workspace_bytes, stream);
+  if (rc) return rc;
+  return rn_optim_clip_apply(grads, nullptr, segs_dev, block_seg_dev, num_blocks, workspace, workspace_bytes, stream);
+}
+
 extern "C" int rn_optim_sgd_step(float* params, const float* grads, float* momentum_buf, float* ema,
                                  void* params_bf16, const void* segs_dev, const int32_t* block_seg_dev,
-                                 int num_blocks, float lr, float momentum, float ema_decay, void* stream) {
+                                 int num_blocks, float lr, float momentum, float ema_decay, int nesterov,
+                                 const float* skip_flag, void* stream) {
   RN_CHECK_ARG(params && grads && momentum_buf && segs_dev && block_seg_dev && num_blocks > 0,
                "rn_optim_sgd_step: bad argument");
   hipLaunchKernelGGL(optim_sgd_kernel, dim3(num_blocks), dim3(OPT_THREADS), 0, (hipStream_t)stream, params, grads,
                      momentum_buf, ema, (uint16_t*)params_bf16, (const OptSeg*)segs_dev, block_seg_dev, lr, momentum,
-                     ema_decay, ema ? 1 : 0);
+                     ema_decay, ema ? 1 : 0, nesterov, skip_flag);
   RN_CHECK_LAUNCH();
   return RN_OK;
 }

@@ -175,10 +175,15 @@ _SIGNATURES = {
                                         c_int, c_void_p]),
     "rn_optim_chunk": (c_int, []),
     "rn_optim_workspace_bytes": (c_size_t, [c_int, c_int]),
-    "rn_optim_clip": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_float, c_float, c_void_p,
-                              c_void_p, c_size_t, c_void_p]),
+    "rn_optim_clip": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_float, c_float, c_float, c_float,
+                              c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rn_optim_clip_prepare": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float,
+                                      c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rn_optim_clip_factors": (c_int, [c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_size_t,
+                                      c_void_p]),
+    "rn_optim_clip_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "rn_optim_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                                  c_float, c_float, c_float, c_void_p]),
+                                  c_float, c_float, c_float, c_int, c_void_p, c_void_p]),
     "rn_prepare_image": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, POINTER(c_float),
                                  POINTER(c_float), c_float, c_void_p]),
     "rn_maxpool2d_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

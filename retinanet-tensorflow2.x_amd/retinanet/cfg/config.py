@@ -96,6 +96,7 @@ def default_params(input_size=640, batch_train=256, batch_val=8, activation="rel
             "strategy": {"type": strategy, "name": ""},
             "restore_checkpoint": False, "freeze_variables": list(freeze),
             "train_steps": 16875, "validation_samples": 4952, "validation_freq": -1,
+            "annotation_file_path": "./instances_val2017.json", "remap_class_ids": True,
             "steps_per_execution": 128, "save_every": 2560,
             "recovery": {"use_inflection_detector": False, "metric_key": "l2-regularization",
                          "threshold": 0.05, "max_trials": 10},

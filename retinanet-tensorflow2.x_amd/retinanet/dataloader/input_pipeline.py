@@ -3,13 +3,20 @@
 
 Same stages in the same order:
   glob (sorted, like tf.io.gfile.glob) -> file shuffle (seed 1337, reshuffled every epoch) -> shard by input
-  pipeline (`files[id::n]`, only when `is_multi_host`) -> repeat (train) -> deterministic interleave
+  pipeline (`files[id::n]`) -> repeat (train) -> deterministic interleave
   (cycle_length = number of CPU cores as AUTOTUNE picks, block_length 1) of TFRecordDataset -> [train] shuffle buffer
   -> map(parse_example + preprocessing) -> batch (train: drop_remainder; val: keep) -> encode.
 What differs by design: the label encoding is not mapped per sample on the host but done once per batch on the GPU
 (`LabelEncoder.encode_batch`: two HBM-bound launches for the whole batch), so a train batch is
 `(images f32[B,H,W,3] cuda, targets)` with `targets` = the reference's dict per level with a leading batch axis;
 random draws come from numpy Generators seeded with `_RANDOM_SEED` (TensorFlow's streams are not reproducible here).
+
+Sharding: the reference shards files and divides the batch only when `is_multi_host` (:44-47) because on ONE host a
+single process drives every GPU and MirroredStrategy splits the global batch.  This build runs one PROCESS per GPU, so
+every rank is an input pipeline of its own: whenever the `input_context` says there is more than one pipeline the
+files are sharded (`files[id::n]`, the FILE shuffle keeps the common seed so that the shards stay disjoint), the batch
+size is the per-replica one, and the shuffle-buffer / augmentation seeds are offset by the pipeline id — with or
+without `is_multi_host`.
 """
 from __future__ import annotations
 
@@ -116,8 +123,11 @@ class InputPipeline:
         logging.info("Found %d %s tfrecords matching %s", len(matched), self.run_mode, self.tfrecord_files)
         if not matched:
             raise FileNotFoundError(f"no tfrecords match {self.tfrecord_files}")
-        rng = np.random.default_rng(InputPipeline._RANDOM_SEED)
-        sharded = self.is_multi_host and input_context is not None
+        rng = np.random.default_rng(InputPipeline._RANDOM_SEED)   # common to all ranks: disjoint shards of ONE order
+        sharded = input_context is not None and input_context.num_input_pipelines > 1
+        if sharded and len(matched) < input_context.num_input_pipelines:
+            raise ValueError(f"{len(matched)} tfrecord files cannot be sharded over "
+                             f"{input_context.num_input_pipelines} input pipelines")
 
         def epochs():
             while True:
@@ -136,12 +146,17 @@ class InputPipeline:
 
     def __call__(self, input_context=None):
         batch_size = self.batch_size
-        if self.is_multi_host and input_context is not None:
+        pid = 0
+        if input_context is not None and input_context.num_replicas_in_sync > 1:
             batch_size = input_context.get_per_replica_batch_size(self.batch_size)
+            pid = int(input_context.input_pipeline_id)
         records = self._records(input_context)
         if self.run_mode == "val":
             return self._val_batches(records, batch_size)
-        records = shuffle_buffer(records, self.shuffle_buffer_size, np.random.default_rng(InputPipeline._RANDOM_SEED + 1))
+        # per-pipeline streams: ranks must not draw the same shuffle order / flips / scale jitter
+        self.preprocessing_pipeline.rng = np.random.default_rng([InputPipeline._RANDOM_SEED + 2, pid])
+        records = shuffle_buffer(records, self.shuffle_buffer_size,
+                                 np.random.default_rng([InputPipeline._RANDOM_SEED + 1, pid]))
         return self._train_batches(records, batch_size)
 
     def _val_batches(self, records, batch_size):

@@ -119,3 +119,25 @@ def build_efficientnet_backbone(g, model_name, H, W, sync_bn_names=False):
             ridx += 1
             reductions[ridx] = x
     return {str(l): reductions[l] for l in range(2, 6)}
+
+
+class EfficientNet:
+    """`EfficientNet(input_shape, model_name, checkpoint, normalization_op_params, override_params)`
+    (efficientnet.py:1003-1040): features '2'..'5' = reduction_2..reduction_5."""
+
+    def __init__(self, input_shape, model_name, checkpoint="", normalization_op_params=None, override_params=None):
+        if not model_name.startswith("efficientnet-b"):
+            raise NotImplementedError(f"backbone {model_name}: the EfficientNet-B family is built; EfficientNet-lite "
+                                      "is out of scope (SURVEY §2.1)")
+        if override_params:
+            raise NotImplementedError("efficientnet override_params are unused by every shipped config")
+        self.input_shape, self.model_name, self.checkpoint = list(input_shape), model_name, checkpoint
+        self._sync_names = bool((normalization_op_params or {}).get("sync_names", False))
+        self.name = model_name
+
+    def __call__(self, images):
+        from retinanet.model.graph import Sym
+        g = images.graph
+        H, W, _, _ = g.tensors[images.name]
+        feats = build_efficientnet_backbone(g, self.model_name, H, W, self._sync_names)
+        return {lv: Sym(g, n) for lv, n in feats.items()}

@@ -26,6 +26,32 @@ from retinanet.model.graph import build_retinanet_graph, init_variables
 from retinanet.model.layers import DetectionPostProcess
 
 
+class LayerView:
+    """One entry of `model.layers` as Executor._maybe_freeze_layers / _get_weight_decay_variables walk them
+    (executor.py:154-176, 296-327, after `_maybe_flatten_layers`): `.name`, `.weights` (objects with `.name`),
+    `.trainable` (setting it False freezes every variable of the layer, Keras semantics)."""
+
+    class _W:
+        def __init__(self, name):
+            self.name = name
+
+    def __init__(self, model, name, var_names):
+        self._model, self.name, self.var_names = model, name, list(var_names)
+        self.weights = [LayerView._W(n) for n in self.var_names]
+
+    @property
+    def trainable(self):
+        return not all(n in self._model._frozen for n in self.var_names)
+
+    @trainable.setter
+    def trainable(self, value):
+        if value:
+            self._model._frozen.difference_update(self.var_names)
+        else:
+            self._model._frozen.update(self.var_names)
+        self._model._train_engines.clear()
+
+
 class RetinaNetModel:
     name = "retinanet"
 
@@ -37,8 +63,27 @@ class RetinaNetModel:
         self.loss = loss_fn
         self.optimizer = None
         self._engines = {}
+        self._train_engines = {}
         self._frozen = set()
         self.loaded_extras = {}
+        self.input_shape = (None,) + tuple(graph.tensors["images"][:3])
+
+    @property
+    def layers(self):
+        """Layers at the granularity the reference's executor sees after flattening one level: every ResNet conv /
+        BatchNorm layer on its own (the backbone is a nested functional model), every top-level EfficientNet
+        sub-layer (stem, blocks_i), and the custom layers `fpn`, `box-head`, `class-head` as ONE layer each."""
+        groups = OrderedDict()
+        for k in self.variables:
+            parts = k.split("/")
+            if parts[0] in ("fpn", "box-head", "class-head"):
+                key = parts[0]
+            elif parts[0].startswith("efficientnet"):
+                key = "/".join(parts[:2])
+            else:
+                key = parts[0]
+            groups.setdefault(key, []).append(k)
+        return [LayerView(self, name, names) for name, names in groups.items()]
 
     # -- Keras-like surface used by the reference's Executor (executor.py:119,144,244,259,543) --
     @property
@@ -105,9 +150,15 @@ class RetinaNetModel:
         print_fn(f"retinanet: {len(self.variables)} variables, {n:,} trainable parameters")
 
     def freeze(self, regex):
+        """variable-level freeze (tests, tools); the executor freezes by LAYER through `.layers`"""
         for k in self.variables:
             if regex.search(k):
                 self._frozen.add(k)
+        self._train_engines.clear()
+
+    @property
+    def frozen_variable_names(self):
+        return set(self._frozen)
 
     def _refresh(self):
         for eng in self._engines.values():
@@ -122,9 +173,23 @@ class RetinaNetModel:
                                                  capture_graph=capture_graph)
         return self._engines[key]
 
+    def train_engine(self, batch_size, process_group=None, world_size=None):
+        """The TrainEngine that serves `model(images, training=True)` and Executor._train_step for this batch size
+        (built once; rebuilt when the set of frozen layers changes)."""
+        from retinanet.model.train_engine import TrainEngine
+        key = (int(batch_size), world_size)
+        if key not in self._train_engines:
+            self._train_engines[key] = TrainEngine(self, batch_size, frozen_names=self._frozen,
+                                                   process_group=process_group, world_size=world_size)
+        return self._train_engines[key]
+
     def __call__(self, images, training=False):
+        """model/builder.py:94-106: images f32[B,H,W,3] -> {'class-predictions': {'3'..'7': f32[B,s,s,A*K]},
+        'box-predictions': {'3'..'7': f32[B,s,s,4A]}}.  training=True runs the training forward (batch-statistics
+        BatchNorm on the live layers, frozen layers in inference mode — executor.py:154-176) and leaves the saved
+        activations in the engine for `backward`."""
         if training:
-            raise NotImplementedError("training forward is served by retinanet.model.train_engine")
+            return self.train_engine(images.shape[0]).forward(images)
         return self.inference_engine(images.shape[0])(images)
 
 
@@ -145,7 +210,10 @@ class ModelBuilder:
     def __init__(self, params, run_mode, device=None, seed=1337):
         self.params = params
         self._run_mode = run_mode
-        self._device = torch.device(device if device is not None else "cuda")
+        if device is None:   # one process per GPU: LOCAL_RANK picks it (retinanet/distribute.py)
+            import os
+            device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        self._device = torch.device(device)
         self._seed = seed
 
     def __call__(self):
@@ -154,10 +222,11 @@ class ModelBuilder:
         variables = init_variables(graph, seed=self._seed, device=self._device)
         loss_fn = RetinaNetLoss(params.architecture.head.num_classes, params.loss)
         model = RetinaNetModel(params, graph, variables, self._device, loss_fn=loss_fn)
-        if "train" in self._run_mode:
-            from retinanet.optimizers import build_optimizer
-            model.optimizer = build_optimizer(params.training.optimizer, params.training.train_steps,
-                                              precision=params.floatx.precision)
+        # model/builder.py:108-117: the optimizer is always built and compiled into the model (the export and eval
+        # paths read optimizer.iterations / the moving averages)
+        from retinanet.optimizers import build_optimizer
+        model.optimizer = build_optimizer(params.training.optimizer, params.training.train_steps,
+                                          precision=params.floatx.precision)
         return model
 
     def prepare_model_for_export(self, model, mode="tf"):

@@ -2,8 +2,9 @@
 
 This is the host-side description the executors in `retinanet.model.engine` turn into HIP
 launches; it plays the role of the Keras functional graph the reference builds in
-retinanet/model/builder.py:36-106 (backbone resnet.py:289-341, neck fpn_base.py:54-71 +
-fpn.py:81-107, BalanceFeatures balance_features.py:19-60, heads detection_head.py:90-104).
+retinanet/model/builder.py:36-106.  The pieces are added by the sub-builders, named like the reference's:
+`build_backbone` (model/backbone/), `build_neck` (model/neck/), `build_detection_heads` (model/head/),
+`BalanceFeatures` (model/layers/) — each returns a layer object that is CALLED on symbolic tensors (`Sym`).
 Variable names follow the Keras names so FREEZE_VARS_REGEX and weight
 files keyed by name keep working; conv kernels are HWIO float32 like the reference's.
 """
@@ -13,10 +14,6 @@ import math
 from collections import OrderedDict
 
 import numpy as np
-
-_RESNET_LAYERS = {50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3], 200: [3, 24, 36, 3],
-                  26: [2, 2, 2, 2], 14: [1, 1, 1, 1]}
-
 
 class Graph:
     """ops: list of dicts; tensors: name -> (H, W, C, dtype) with an implicit batch dim."""
@@ -91,6 +88,30 @@ class Graph:
         return out
 
 
+class Sym:
+    """A symbolic tensor: a name in a `Graph` — what calling a sub-builder's layer on an input returns, the way
+    calling a Keras layer on a `tf.keras.Input` returns a KerasTensor (model/builder.py:47-93)."""
+
+    def __init__(self, graph, name):
+        self.graph, self.name = graph, name
+
+    @property
+    def shape(self):
+        H, W, C, _ = self.graph.tensors[self.name]
+        return (None, H, W, C)
+
+    def __repr__(self):
+        return f"Sym({self.name}, {self.shape})"
+
+
+def graph_input(input_shape, name="images"):
+    """tf.keras.Input(shape=[H, W, channels], name='images') (model/builder.py:46-50): a fresh graph and its input"""
+    H, W, C = input_shape
+    g = Graph()
+    g.tensor(name, H, W, C, "f32")
+    return Sym(g, name)
+
+
 def _bn_name(i, sync):
     base = "sync_batch_normalization" if sync else "batch_normalization"
     return base if i == 0 else f"{base}_{i}"
@@ -98,81 +119,6 @@ def _bn_name(i, sync):
 
 def _conv_name(i):
     return "conv2d" if i == 0 else f"conv2d_{i}"
-
-
-def build_retinanet_graph(params, sync_bn_names=False):
-    arch = params.architecture
-    btype = arch.backbone.type.lower()
-    if "resnet" not in btype and not btype.startswith("efficientnet-b"):
-        raise NotImplementedError(f"backbone {arch.backbone.type}: the ResNet and EfficientNet-B families are built; "
-                                  "EfficientNet-lite / MobileDet are out of scope (SURVEY §2.1)")
-    if "resnet" in btype:
-        depth = int(arch.backbone.depth)
-        if depth not in _RESNET_LAYERS:
-            raise ValueError(f"unsupported bottleneck ResNet depth {depth}")
-    separable = bool(arch.conv_2d.use_seperable_conv)
-    if arch.feature_fusion.type != "fpn":
-        raise ValueError("{} FPN not implemented".format(arch.feature_fusion.type))
-    if arch.feature_fusion.fusion_mode != "sum":
-        raise NotImplementedError("fusion_mode other than 'sum' is unused by every shipped config")
-    if arch.auxillary_head.use_auxillary_head:
-        raise NotImplementedError("auxillary head is disabled in every shipped config")
-    H, W = params.input.input_shape
-    g = Graph()
-    act = arch.activation.type
-    cidx = [0]
-
-    def rconv(k, cin, cout, stride):
-        name = _conv_name(cidx[0])
-        g.add_conv_layer(name, k, cin, cout, stride, bias=False, init="variance_scaling")
-        return name
-
-    def rbn(C, zero=False):
-        name = _bn_name(cidx[0], sync_bn_names)
-        g.add_bn_layer(name, C, gamma_zero=zero)
-        cidx[0] += 1
-        return name
-
-    g.tensor("images", H, W, 3, "f32")
-    if btype.startswith("efficientnet-b"):
-        from retinanet.model.graph_efficientnet import build_efficientnet_backbone
-        feats = build_efficientnet_backbone(g, btype, H, W, sync_bn_names)
-        return _build_fpn_and_heads(g, params, feats, act, sync_bn_names, separable)
-    # ---- ResNet (resnet.py:289-341); ResNet blocks always use ReLU (resnet.py:68-69) ---------
-    c = rconv(7, 3, 64, 2)
-    b = rbn(64)
-    Hs, Ws = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
-    g.tensor("stem", Hs, Ws, 64)
-    g.ops.append(dict(op="stem", out="stem", inp="images", conv=c, bn=b, act="relu"))
-    Hp, Wp = math.ceil(Hs / 2), math.ceil(Ws / 2)
-    # MaxPool 3x3 s2 SAME: total pad = max((Ho-1)*2+3-H, 0), before = total//2 (TF rule)
-    pt = max((Hp - 1) * 2 + 3 - Hs, 0) // 2
-    pl = max((Wp - 1) * 2 + 3 - Ws, 0) // 2
-    g.tensor("pool", Hp, Wp, 64)
-    g.ops.append(dict(op="maxpool", out="pool", inp="stem", k=3, stride=2, pad_top=pt, pad_left=pl))
-    x, cin = "pool", 64
-    feats = {}
-    for gi, (filters, blocks, stride) in enumerate(zip([64, 128, 256, 512], _RESNET_LAYERS[depth], [1, 2, 2, 2])):
-        for bi in range(blocks):
-            s = stride if bi == 0 else 1
-            pre = f"g{gi + 1}b{bi}"
-            shortcut = x
-            if bi == 0:
-                pc = rconv(1, cin, 4 * filters, s)
-                pb = rbn(4 * filters)
-                shortcut = g.conv(pre + "_sc", x, pc, pb, act=None, pad=0)
-            c1 = rconv(1, cin, filters, 1)
-            b1 = rbn(filters)
-            t = g.conv(pre + "_a", x, c1, b1, act="relu")
-            c2 = rconv(3, filters, filters, s)
-            b2 = rbn(filters)
-            t = g.conv(pre + "_b", t, c2, b2, act="relu")
-            c3 = rconv(1, filters, 4 * filters, 1)
-            b3 = rbn(4 * filters, zero=True)
-            x = g.conv(pre + "_out", t, c3, b3, act="relu", residual=shortcut)
-            cin = 4 * filters
-        feats[str(gi + 2)] = x
-    return _build_fpn_and_heads(g, params, feats, act, sync_bn_names, separable)
 
 
 def _conv_or_sep(g, separable, out, inp, name, k, cout, bias_init, init, bn, act, group, out_dtype="bf16",
@@ -192,79 +138,40 @@ def _conv_or_sep(g, separable, out, inp, name, k, cout, bias_init, init, bn, act
     return g.conv(out, out + ":dw", name, bn, act=act, group=group, out_dtype=out_dtype, pad=0)
 
 
-def _build_fpn_and_heads(g, params, feats, act, sync_bn_names, separable):
+def build_retinanet_graph(params, sync_bn_names=False):
+    """The whole detector as one static graph, composed from the sub-builders exactly as the reference's
+    ModelBuilder.__call__ composes its Keras layers (model/builder.py:36-106)."""
+    from retinanet.model.backbone import build_backbone
+    from retinanet.model.head import build_detection_heads
+    from retinanet.model.layers.balance_features import BalanceFeatures
+    from retinanet.model.neck import build_neck
+    from retinanet.model.utils import get_activation_op
     arch = params.architecture
-    # ---- FPN (fpn_base.py:54-71, fpn.py:81-107) ------------------------------------------------
-    ff = arch.feature_fusion
-    F = int(ff.filters)
-    lo, hi, bmax = int(ff.min_level), int(ff.max_level), int(ff.backbone_max_level)
-    bn_tag = "sync_batch_normalization" if sync_bn_names else "batch_normalization"
-    top = feats[str(bmax)]
-    ctop = g.tensors[top][2]
-    g.add_bn_layer(f"fpn/backbone_max_level_{bn_tag}", F)
-    _conv_or_sep(g, separable, "fpn_c6pre", top, "fpn/backbone_max_level_conv_1x1", 1, F, 0.0, "variance_scaling",
-                 f"fpn/backbone_max_level_{bn_tag}", None, None if separable else "fpn_1x1")
-    prev = "fpn_c6pre"
-    for level in range(bmax + 1, hi + 1):
-        Hl, Wl = g.tensors[prev][0] // 2, g.tensors[prev][1] // 2
-        g.tensor(f"fpn_in{level}", Hl, Wl, F)
-        g.ops.append(dict(op="maxpool", out=f"fpn_in{level}", inp=prev, k=2, stride=2, pad_top=0, pad_left=0))
-        prev = f"fpn_in{level}"
-    for level in range(lo, bmax + 1):
-        src = feats[str(level)]
-        name = f"fpn/p{level}-in-channel-normalize-conv-1x1"
-        bn = f"fpn/p{level}-in-channel-normalize-{bn_tag}"
-        g.add_bn_layer(bn, F)
-        _conv_or_sep(g, separable, f"fpn_in{level}", src, name, 1, F, 0.0, "variance_scaling", bn, None,
-                     None if separable else "fpn_1x1")
-    levels = list(range(lo, hi + 1))
-    for level in levels[:-1]:
-        Hl, Wl, _, _ = g.tensors[f"fpn_in{level}"]
-        g.tensor(f"fpn_td{level}", Hl, Wl, F)
-    g.ops.append(dict(op="topdown", ins=[f"fpn_in{l}" for l in levels],
-                      outs=[f"fpn_td{l}" for l in levels[:-1]] + [f"fpn_in{hi}"], act=act))
-    for level in levels:
-        name = f"fpn/p{level}-out-conv-3x3"
-        bn = f"fpn/p{level}-out-{bn_tag}"
-        g.add_bn_layer(bn, F)
-        src = f"fpn_td{level}" if level != hi else f"fpn_in{hi}"
-        _conv_or_sep(g, separable, f"fpn_out{level}", src, name, 3, F, 0.0, "variance_scaling", bn, None,
-                     "fpn_out")
-    feat = {l: f"fpn_out{l}" for l in levels}
-    if ff.use_balanced_features:
-        g.ops.append(dict(op="balance", tensors=[feat[l] for l in levels], mid=1))  # min_level + 1
-
-    # ---- heads (detection_head.py:8-104, head/builder.py:7-43) ------------------------------
-    hd = arch.head
-    nconv, HF = int(hd.num_convs), int(hd.filters)
-    A, K = int(hd.num_anchors), int(hd.num_classes)
-    outs = {"box": {}, "class": {}}
-    head_init = "variance_scaling" if separable else "normal_0.01"
-    for head in ("box-head", "class-head"):
-        for i in range(nconv):
-            for level in levels:
-                g.add_bn_layer(f"{head}/{head}-{i}-p{level}-{bn_tag}", HF)
-    defined = set()
-    for i in range(nconv):
-        for head in ("box-head", "class-head"):
-            for level in levels:
-                src = feat[level] if i == 0 else f"{head}_t{i - 1}_p{level}"
-                name = f"{head}/{head}-{i}-conv2d"
-                _conv_or_sep(g, separable, f"{head}_t{i}_p{level}", src, name, 3, HF, 0.0, head_init,
-                             f"{head}/{head}-{i}-p{level}-{bn_tag}", act, f"tower{i}", define=name not in defined)
-                defined.add(name)
-    for head, key, ofilt, bias_init in (("box-head", "box", A * 4, 0.0),
-                                       ("class-head", "class", A * K, -float(np.log((1 - 0.01) / 0.01)))):
-        for level in levels:
-            src = f"{head}_t{nconv - 1}_p{level}" if nconv else feat[level]
-            name = f"{head}/{head}-prediction-conv2d"
-            _conv_or_sep(g, separable, f"{head}_pred_p{level}", src, name, 3, ofilt, bias_init, head_init, None, None,
-                         f"pred_{key}", out_dtype="f32", define=name not in defined)
-            defined.add(name)
-            outs[key][str(level)] = f"{head}_pred_p{level}"
-    g.outputs = {"class-predictions": outs["class"], "box-predictions": outs["box"]}
-    g.levels = levels
-    g.meta = dict(num_anchors=A, num_classes=K, filters=F)
+    if arch.auxillary_head.use_auxillary_head:
+        raise NotImplementedError("auxillary head is disabled in every shipped config")
+    norm = dict(arch.batch_norm)
+    norm["sync_names"] = bool(sync_bn_names)
+    input_shape = list(params.input.input_shape) + [int(params.input.get("channels", 3))]
+    images = graph_input(input_shape)
+    activation_fn = get_activation_op(arch.activation.type)
+    backbone = build_backbone(input_shape=input_shape, params=arch.backbone, normalization_op_params=norm)
+    neck = build_neck(params=arch.feature_fusion, conv_2d_op_params=arch.conv_2d, normalization_op_params=norm,
+                      activation_fn=activation_fn)
+    box_head, class_head = build_detection_heads(
+        params=arch.head, min_level=arch.feature_fusion.min_level, max_level=arch.feature_fusion.max_level,
+        conv_2d_op_params=arch.conv_2d, normalization_op_params=norm, activation_fn=activation_fn)
+    features = neck(backbone(images))
+    if arch.feature_fusion.use_balanced_features:
+        features = BalanceFeatures(min_level=arch.feature_fusion.min_level, max_level=arch.feature_fusion.max_level,
+                                   intermediate_level=arch.feature_fusion.min_level + 1)(features)
+    box_outputs = box_head(features)
+    class_outputs = class_head(features)
+    g = images.graph
+    g.outputs = {"class-predictions": {lv: t.name for lv, t in class_outputs.items()},
+                 "box-predictions": {lv: t.name for lv, t in box_outputs.items()}}
+    g.levels = list(range(int(arch.feature_fusion.min_level), int(arch.feature_fusion.max_level) + 1))
+    g.meta = dict(num_anchors=int(arch.head.num_anchors), num_classes=int(arch.head.num_classes),
+                  filters=int(arch.feature_fusion.filters))
     return g
 
 

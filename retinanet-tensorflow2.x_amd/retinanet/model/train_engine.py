@@ -47,7 +47,7 @@ def _ohwi_to_hwio(w):
 
 
 class TrainEngine:
-    def __init__(self, model, batch_size, frozen_regexes=(), process_group=None, world_size=1):
+    def __init__(self, model, batch_size, frozen_regexes=(), process_group=None, world_size=None, frozen_names=()):
         self.model = model
         self.g = model.graph
         self.params_cfg = model.params
@@ -55,15 +55,22 @@ class TrainEngine:
         self.dev = model.device
         self.lib = _C.lib()
         self.pg = process_group
+        if world_size is None:   # one source of truth with RetinaNetLoss, which asks torch.distributed
+            import torch.distributed as dist
+            world_size = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.world = int(world_size)
         bn = self.params_cfg.architecture.batch_norm
         self.eps, self.momentum_bn = float(bn.epsilon), float(bn.momentum)
         self.sync_bn = bool(bn.use_sync) and self.world > 1
-        self.frozen = set()
+        self.frozen = set(frozen_names)
         for k in model.variables:
             if any(rx.search(k) for rx in frozen_regexes):
                 self.frozen.add(k)
         self._keep = []
+        self._train_step_active = False
+        self._overlap_on = False
+        self._overlap_done = 0
+        self._step_args = dict(wdc=0.0, alpha=0.0, unscale=1.0, clip=0.0)
         self.conv_launches = []   # (name, rn_conv_problem) of every implicit-GEMM launch: lib.rn_conv_kernel_id(byref(p))
         self.step_count = 0
         self.conv_profile = None
@@ -171,7 +178,10 @@ class TrainEngine:
         names = [k for k in v if self.g.var_specs[k].get("trainable", True) and k not in self.frozen]
         self.train_names = names
         segs, block_seg = [], []
-        off = bf_off = nblk = 0
+        # the first 4 floats of every arena are reserved: G[0] / G[1] are the "a clip factor != 1 on some rank" /
+        # "gradients not finite on some rank" slots that ride in the LAST gradient bucket's all-reduce (the bucket
+        # at the front of the arena completes last in the backward pass)
+        off, bf_off, nblk = 4, 0, 0
         self.p_off, self.bf_off = {}, {}     # bf_off: conv name | "dw:<name>" | "<se>:w1" / "<se>:w2" -> offset in Pbf
         self.fwd_packs = []                  # live convs whose Cin is not its own K-step padding: repacked per step
         self.fwd_pack_of = {}
@@ -232,7 +242,11 @@ class TrainEngine:
         self.n_blocks, self.n_segs = len(block_seg), len(segs)
         self.opt_ws = torch.empty((lib.rn_optim_workspace_bytes(self.n_blocks, self.n_segs),), dtype=torch.uint8,
                                   device=self.dev)
-        self.metrics = torch.zeros((4,), dtype=torch.float32, device=self.dev)
+        self.metrics = torch.zeros((8,), dtype=torch.float32, device=self.dev)
+        self._block_elems = [(segs[si][0] + (bi - segs[si][3]) * chunk, min(chunk, segs[si][1] - (bi - segs[si][3]) * chunk))
+                             for bi, si in enumerate(block_seg)]   # (arena offset, elements) of every optimizer block
+        self._seg_blocks = {k: (s[3], s[4]) for k, s in zip(names, segs)}   # variable -> (first block, blocks)
+        self.loss_scale = None     # LossScaleOptimizer state (mixed_float16 configs): see optimizer_step
         self.load_from_model()
 
     def _pview(self, name, arena=None):
@@ -314,7 +328,10 @@ class TrainEngine:
 
     def save_checkpoint(self, prefix):
         """Weights + BN moving statistics + optimizer slots (`momentum`, `average`) + the step counter, in
-        TensorFlow's checkpoint format (what executor.py:652-654 / 695-697 write through `model.save_weights`)."""
+        TensorFlow's checkpoint FILE format (where executor.py:652-654 / 695-697 call `model.save_weights`).  Interop
+        is one-way: this build reads what the reference wrote (by variable name through the object graph); the
+        reference's Keras `load_weights` matches structurally and will not consume the flat object graph written
+        here (retinanet/tf_checkpoint.py::save_weights)."""
         with torch.cuda.device(self.dev):
             self.store_to_model(use_ema=False)
             torch.cuda.synchronize()
@@ -830,7 +847,9 @@ class TrainEngine:
                      self._pview(name + "/conv2d/bias", self.G).data_ptr(),
                      self._pview(name + "/conv2d_1/kernel", self.G).data_ptr(),
                      self._pview(name + "/conv2d_1/bias", self.G).data_ptr(), self.se_ws.data_ptr(), self.se_ws.numel())
-                self.bwd_steps.append(lambda st, a=a: _C.check(lib.rn_squeeze_excite_bwd(*a, st), "rn_squeeze_excite_bwd"))
+                se_bwd = lambda st, a=a: _C.check(lib.rn_squeeze_excite_bwd(*a, st), "rn_squeeze_excite_bwd")
+                se_bwd.writes = [name + sfx for sfx in ("/conv2d/kernel", "/conv2d/bias", "/conv2d_1/kernel", "/conv2d_1/bias")]
+                self.bwd_steps.append(se_bwd)
             elif kind == "maxpool":
                 op = item
                 if not self.requires.get(op["inp"]):
@@ -870,6 +889,7 @@ class TrainEngine:
                     _C.check(lib.rn_conv2d_nhwc_wgrad(ctypes.byref(pw), dwp.data_ptr(), 0.0, wsw.data_ptr(),
                                                       wsw.numel(), st), "stem wgrad")
                     gview.copy_(dwp[:, :, :k, :3])   # [co][r][8 taps x 4 ch] -> [co][r][s][c]
+                stem_bwd.writes = [self._kvar(op), op["bn"] + "/gamma", op["bn"] + "/beta"]
                 self.bwd_steps.append(stem_bwd)
             elif kind == "topdown":
                 op = item
@@ -925,6 +945,7 @@ class TrainEngine:
                     import torch.distributed as dist
                     dist.all_reduce(bsums, group=self.pg)
                 _C.check(lib.rn_bn_bwd_apply(prb, st), "rn_bn_bwd_apply")
+            run.writes = [op["bn"] + sfx for op in ops for sfx in ("/gamma", "/beta")]
             self.bwd_steps.append(run)
             dy_of = {op["out"]: dys[i] for i, op in enumerate(ops)}
         else:
@@ -967,7 +988,8 @@ class TrainEngine:
             self._keep += [p, ws]
             a = (ctypes.byref(p), dw.data_ptr(), 0.0, ws.data_ptr(), ws.numel())
             self.bwd_steps.append(self._side(lambda st, a=a: _C.check(lib.rn_conv2d_nhwc_wgrad(*a, st),
-                                                                     "rn_conv2d_nhwc_wgrad")))
+                                                                     "rn_conv2d_nhwc_wgrad"),
+                                             writes=[c.get("kvar", cname + "/kernel")]))
             if c["bias"]:
                 # bias gradient = column sums of dy over every segment (two-stage reduction kernel)
                 pb2 = _C.BnProblem()
@@ -987,7 +1009,7 @@ class TrainEngine:
                 def bias_grad(st, pr=ctypes.byref(pb2), ws2=ws2, bs=bs, db=db, n=c["cout"]):
                     _C.check(lib.rn_bn_stats(pr, _C.ptr(ws2), ws2.numel(), st), "bias colsum")
                     torch.sum(bs[:, 0, :n], dim=0, out=db)
-                self.bwd_steps.append(self._side(bias_grad))
+                self.bwd_steps.append(self._side(bias_grad, writes=[cname + "/bias"]))
         # (c) data gradients.  Segments of one launch must write distinct gradient buffers (both
         # heads read the same pyramid level): split the group into launches with unique inputs.
         need = [op for op in ops if self.requires.get(op["inp"])]
@@ -1021,6 +1043,7 @@ class TrainEngine:
                     import torch.distributed as dist
                     dist.all_reduce(bsums, group=self.pg)
                 _C.check(lib.rn_bn_bwd_apply(prb, st), "rn_bn_bwd_apply")
+            run.writes = [op["bn"] + sfx for op in ops for sfx in ("/gamma", "/beta")]
             self.bwd_steps.append(run)
             dy_of = {op["out"]: dys[i] for i, op in enumerate(ops)}
         else:
@@ -1043,7 +1066,7 @@ class TrainEngine:
             self._keep += [p, ws]
             a = (ctypes.byref(p), self._pview(d["kvar"], self.G).data_ptr(), ws.data_ptr(), ws.numel())
             self.bwd_steps.append(self._side(lambda st, a=a: _C.check(lib.rn_depthwise_conv2d_nhwc_wgrad(*a, st),
-                                                                     "dw wgrad")))
+                                                                     "dw wgrad"), writes=[d["kvar"]]))
         need = [op for op in ops if self.requires.get(op["inp"])]
         launches = []
         for op in need:
@@ -1204,9 +1227,11 @@ class TrainEngine:
         return self.outputs
 
     @staticmethod
-    def _side(fn):
-        """marks a backward step whose results only the optimizer reads (weight / bias gradients)"""
+    def _side(fn, writes=()):
+        """marks a backward step whose results only the optimizer reads (weight / bias gradients); `writes` = the
+        variables whose gradient the step completes (bucket readiness of the overlapped all-reduce)"""
         fn.side = True
+        fn.writes = list(writes)
         return fn
 
     def _ensure_side_stream(self):
@@ -1253,9 +1278,12 @@ class TrainEngine:
             self._dgrad_prepacked = False
         else:
             self.refresh_dgrad_weights(st)
+        overlap = self._overlap_begin()
         if not self.side_stream_on:
-            for fn in self.bwd_steps:
+            for i, fn in enumerate(self.bwd_steps):
                 fn(st)
+                if overlap:
+                    self._overlap_after_step(i, torch.cuda.current_stream(self.dev), None)
             return
         # two streams: a side step waits (event) for everything the main stream has enqueued so far — its inputs
         # dy / x are complete at that point and are not written again before the join below — and the main stream
@@ -1276,41 +1304,206 @@ class TrainEngine:
             else:
                 fn(st)
                 fresh = False
+            if overlap:
+                self._overlap_after_step(i, main, side)
         main.wait_stream(side)
 
-    def optimizer_step(self, lr, momentum, clipnorm, wd_alpha, ema_decay):
-        lib, st = self.lib, _C.current_stream()
-        _C.check(lib.rn_optim_clip(self.G.data_ptr(), self.P.data_ptr(), self.segs_dev.data_ptr(), self.n_segs,
-                                   self.block_seg_dev.data_ptr(), self.n_blocks, wd_alpha / self.world,
-                                   clipnorm if clipnorm else 0.0, self.metrics.data_ptr(), self.opt_ws.data_ptr(),
-                                   self.opt_ws.numel(), st), "rn_optim_clip")
+    # ---- gradient all-reduce overlapped with the backward pass -------------------------------------
+    # executor.py:432-437 clips the LOCAL gradients and then sums them over the replicas; the clip factors need every
+    # gradient, so a literal translation can only start the all-reduce after the whole backward pass.  Here the
+    # buckets go out as the backward pass completes them, UNclipped ("optimistic": local gradients are pre-divided by
+    # the replica count, so the per-tensor / global norms sit far below clipnorm after the first steps), each rank
+    # keeps a copy of what it sent, and at the end one flag that rode in the last bucket says whether any rank's
+    # factor was != 1.  Only then is the correction sum_r (factor_r - 1) * g_r all-reduced and added — the result is
+    # sum_r factor_r * g_r, the reference's clip-then-sum.
+    def _plan_buckets(self):
+        bucket_bytes = int(os.environ.get("RNET_C1_BUCKET_MB", "25")) << 20
+        written = {}
+        for i, fn in enumerate(self.bwd_steps):
+            for k in getattr(fn, "writes", ()):
+                written[k] = i
+        missing = [k for k in self.train_names if k not in written]
+        if missing:
+            raise RuntimeError(f"no backward step completes the gradient of {missing[:4]}")
+        buckets, cur = [], None
+        for k in self.train_names:     # arena order = forward order: the backward pass completes the tail first
+            off, n = self.p_off[k]
+            b0, nb = self._seg_blocks[k]
+            if cur is None or (cur["end"] - cur["begin"]) * 4 >= bucket_bytes:
+                cur = dict(begin=off, end=off, block_begin=b0, block_count=0, ready=-1)
+                buckets.append(cur)
+            cur["end"] = (off + n + 3) // 4 * 4
+            cur["block_count"] += nb
+            cur["ready"] = max(cur["ready"], written[k])
+        buckets[0]["begin"] = 0        # the flag slots ride in the bucket that completes last
+        order = sorted(range(len(buckets)), key=lambda j: (buckets[j]["ready"], -j))
+        if order[-1] != 0:             # keep the invariant simple: bucket 0 goes last
+            buckets[0]["ready"] = max(b["ready"] for b in buckets)
+        self._buckets = buckets
+        self._bucket_at = {}
+        for j, bkt in enumerate(buckets):
+            self._bucket_at.setdefault(bkt["ready"], []).append(j)
+        for lst in self._bucket_at.values():
+            lst.sort(reverse=True)     # bucket 0 after the others that become ready with the same step
+
+    def _overlap_begin(self):
+        """True when this backward pass launches the gradient all-reduce bucket by bucket (world > 1, or forced
+        with RNET_C1_OVERLAP=1 for the single-replica equivalence test)."""
+        mode = os.environ.get("RNET_C1_OVERLAP", "auto")
+        on = self._train_step_active and (mode == "1" or (mode != "0" and self.world > 1))
+        self._overlap_works = []
+        self._overlap_on = on
+        if not on:
+            return False
+        if getattr(self, "_buckets", None) is None:
+            self._plan_buckets()
+            self._comm_stream = torch.cuda.Stream(self.dev)
+            self._comm_events = [(torch.cuda.Event(), torch.cuda.Event()) for _ in self._buckets]
+            self.L = torch.zeros_like(self.G)      # what this rank contributed (for the clip correction)
+            if self.world > 1:
+                import torch.distributed as dist
+                # its own communicator: the latency-bound SyncBN all-reduces of the main stream must not queue
+                # behind a 25 MB bucket on the same RCCL stream
+                self.pg_c1 = dist.new_group(backend=dist.get_backend(self.pg))
+        self._overlap_done = 0
+        return True
+
+    def _overlap_after_step(self, i, main, side):
+        for j in self._bucket_at.get(i, ()):
+            self._launch_bucket(j, main, side)
+
+    def _launch_bucket(self, j, main, side):
+        lib, bkt, comm = self.lib, self._buckets[j], self._comm_stream
+        e_main, e_side = self._comm_events[j]
+        e_main.record(main)
+        comm.wait_event(e_main)
+        if side is not None:
+            e_side.record(side)
+            comm.wait_event(e_side)
+        cst = ctypes.c_void_p(comm.cuda_stream)
+        a = self._step_args
+        with torch.cuda.stream(comm):
+            _C.check(lib.rn_optim_clip_prepare(self.G.data_ptr(), self.P.data_ptr(), self.segs_dev.data_ptr(),
+                                               self.block_seg_dev.data_ptr(), self.n_blocks, bkt["block_begin"],
+                                               bkt["block_count"], a["wdc"], a["unscale"], self.L.data_ptr(),
+                                               self.opt_ws.data_ptr(), self.opt_ws.numel(), cst), "rn_optim_clip_prepare")
+            self._overlap_done += 1
+            if self._overlap_done == len(self._buckets):
+                assert j == 0
+                # every gradient of this rank is final: clip factors, metrics, and the two flags into G[0:2]
+                _C.check(lib.rn_optim_clip_factors(self.segs_dev.data_ptr(), self.n_segs, self.n_blocks, a["clip"],
+                                                   a["alpha"], self.metrics.data_ptr(), self.G.data_ptr(),
+                                                   self.opt_ws.data_ptr(), self.opt_ws.numel(), cst), "rn_optim_clip_factors")
+            if self.world > 1:
+                import torch.distributed as dist
+                self._overlap_works.append(dist.all_reduce(self.G[bkt["begin"]:bkt["end"]], group=self.pg_c1,
+                                                           async_op=True))
+        self._overlap_last_event = torch.cuda.Event()
+        self._overlap_last_event.record(comm)
+
+    def _overlap_finish(self):
+        """After the join: wait for the buckets; when some rank's clip fired, all-reduce the correction."""
+        cur = torch.cuda.current_stream(self.dev)
+        for w in self._overlap_works:
+            w.wait()
+        cur.wait_stream(self._comm_stream)
+        fired = float(self.G[0].item()) != 0.0      # one host sync per step: the collective below is conditional
+        self.clip_fired = fired
+        if not fired:
+            return
+        st = _C.current_stream()
+        _C.check(self.lib.rn_optim_clip_apply(self.L.data_ptr(), self.L.data_ptr(), self.segs_dev.data_ptr(),
+                                              self.block_seg_dev.data_ptr(), self.n_blocks, self.opt_ws.data_ptr(),
+                                              self.opt_ws.numel(), st), "rn_optim_clip_apply")
+        self.L[:4].zero_()
         if self.world > 1:
             from retinanet.distribute import all_reduce_sum_bucketed
-            all_reduce_sum_bucketed(self.G, self.world, self.pg)   # executor.py:436-437: SUM after clipping
+            all_reduce_sum_bucketed(self.L, self.world, self.pg)
+        self.G[4:].add_(self.L[4:])
+
+    def optimizer_step(self, lr, momentum, clipnorm, wd_alpha, ema_decay, nesterov=False, overlapped=False):
+        """weight decay + per-tensor / global clipping (executor.py:401-407) + all-reduce SUM (executor.py:436-437)
+        + SGD momentum / moving average (optimizers/builder.py:45-54).  overlapped=True: backward() already sent the
+        buckets (see above); only the flag check / correction and the SGD kernel are left."""
+        lib, st = self.lib, _C.current_stream()
+        unscale = 1.0 / self.loss_scale["scale"] if self.loss_scale else 1.0
+        if overlapped:
+            self._overlap_finish()
+            skip = self.G.data_ptr() + 4 if self.loss_scale else None     # G[1]: not finite on some rank
+        else:
+            _C.check(lib.rn_optim_clip(self.G.data_ptr(), self.P.data_ptr(), self.segs_dev.data_ptr(), self.n_segs,
+                                       self.block_seg_dev.data_ptr(), self.n_blocks, wd_alpha / self.world, wd_alpha,
+                                       unscale, clipnorm if clipnorm else 0.0, self.metrics.data_ptr(),
+                                       self.opt_ws.data_ptr(), self.opt_ws.numel(), st), "rn_optim_clip")
+            skip = None
+            if self.loss_scale:
+                self.G[1:2].copy_(self.metrics[5:6])
+                skip = self.G.data_ptr() + 4
+            if self.world > 1:
+                from retinanet.distribute import all_reduce_sum_bucketed
+                all_reduce_sum_bucketed(self.G, self.world, self.pg)   # executor.py:436-437: SUM after clipping
         _C.check(lib.rn_optim_sgd_step(self.P.data_ptr(), self.G.data_ptr(), self.V.data_ptr(),
                                        self.E.data_ptr() if ema_decay is not None else None, self.Pbf.data_ptr(),
                                        self.segs_dev.data_ptr(), self.block_seg_dev.data_ptr(), self.n_blocks,
-                                       lr, momentum, ema_decay if ema_decay is not None else 0.0, st),
-                 "rn_optim_sgd_step")
+                                       lr, momentum, ema_decay if ema_decay is not None else 0.0, 1 if nesterov else 0,
+                                       skip, st), "rn_optim_sgd_step")
         self.refresh_stem_pack()
+        if self.loss_scale:
+            self._update_loss_scale()
+
+    def _update_loss_scale(self):
+        """tf.keras.mixed_precision.LossScaleOptimizer(dynamic=True) (optimizers/builder.py:56-64): halve the scale
+        when a step's gradients were not finite (the step was dropped), double it after `growth_steps` good steps."""
+        ls = self.loss_scale
+        bad = float(self.G[1].item()) != 0.0       # host sync: mixed_float16 configs only
+        ls["skipped"] = bad
+        if bad:
+            ls["scale"], ls["good"] = max(ls["scale"] / 2.0, 1.0), 0
+        else:
+            ls["good"] += 1
+            if ls["good"] >= ls["growth_steps"]:
+                ls["scale"], ls["good"] = ls["scale"] * 2.0, 0
 
     def train_step(self, images, targets):
-        """(images f32[B,H,W,3], targets from LabelEncoder.encode_batch) -> loss dict (device scalars)."""
+        """(images f32[B,H,W,3], targets from LabelEncoder.encode_batch) -> the loss dict of Executor._train_step
+        (executor.py:409-441; device scalars)."""
         cfg = self.params_cfg.training
         opt = self.model.optimizer
+        if self.model.loss._num_replicas() != self.world:
+            raise RuntimeError(f"RetinaNetLoss sees {self.model.loss._num_replicas()} replicas, the engine {self.world}")
+        if opt.dynamic_loss_scale and self.loss_scale is None:
+            self.loss_scale = dict(scale=float(opt.initial_loss_scale), good=0, growth_steps=int(opt.loss_scale_growth_steps),
+                                   skipped=False)
         with torch.cuda.device(self.dev):
+            step = self.step_count
+            alpha = cfg.weight_decay_alpha if cfg.use_weight_decay else 0.0
+            scale = self.loss_scale["scale"] if self.loss_scale else 1.0
+            self._step_args = dict(wdc=alpha / self.world, alpha=alpha, unscale=1.0 / scale,
+                                   clip=float(opt.clipnorm) if opt.clipnorm else 0.0)
             self._prepack_dgrad_weights()
             preds = self.forward(images)
-            loss = self.model.loss(targets, preds, compute_grads=True, grad_scale=1.0 / self.world,
+            # per_replica_loss = total / replicas, times the loss scale under mixed_float16 (executor.py:421-425)
+            loss = self.model.loss(targets, preds, compute_grads=True, grad_scale=scale / self.world,
                                    grads_bf16=self.loss_grad_buffers())
-            self.backward(None)
-            step = self.step_count
-            self.optimizer_step(opt.lr(step), opt.momentum, opt.clipnorm,
-                                cfg.weight_decay_alpha if cfg.use_weight_decay else 0.0,
-                                opt.ema_decay(step) if opt.use_moving_average else None)
-            self.step_count += 1
+            self._train_step_active = True
+            try:
+                self.backward(None)
+            finally:
+                self._train_step_active = False
+            overlapped = self._overlap_on      # backward() sent the gradient buckets as it completed them
+            if overlapped and self._overlap_done != len(self._buckets):
+                raise RuntimeError("overlapped all-reduce: not every gradient bucket was launched")
+            self.optimizer_step(opt.lr(step), opt.momentum, opt.clipnorm, alpha,
+                                opt.ema_decay(step) if opt.use_moving_average else None, nesterov=opt.nesterov,
+                                overlapped=overlapped)
+            if not (self.loss_scale and self.loss_scale["skipped"]):
+                self.step_count += 1          # a dropped step does not advance optimizer.iterations
             opt.iterations = self.step_count
         out = dict(loss)
+        out["total-loss"] = loss["weighted-loss"]                # executor.py:414-419
+        if cfg.use_weight_decay:
+            out["l2-regularization"] = self.metrics[3]
+            out["total-loss"] = loss["weighted-loss"] + self.metrics[3]
         out["gradient-norm"] = self.metrics[0] * self.world      # executor.py:440
         out["num-anchors-matched"] = loss["num-anchors-matched"] / self.B   # executor.py:439
         return out

@@ -69,7 +69,10 @@ class OptimizerConfig:
         self.learning_rate = learning_rate
         self.use_moving_average = use_moving_average
         self.moving_average_decay = moving_average_decay
+        # tf.keras.mixed_precision.LossScaleOptimizer(dynamic=True) defaults (optimizers/builder.py:56-64)
         self.dynamic_loss_scale = loss_scale
+        self.initial_loss_scale = 2.0 ** 15
+        self.loss_scale_growth_steps = 2000
         self.iterations = 0
 
     def lr(self, step=None):

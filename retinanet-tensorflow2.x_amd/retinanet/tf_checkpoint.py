@@ -409,7 +409,11 @@ class TensorBundleReader:
         variables = {}
         for i, (full, key) in attr.items():
             if full and i not in slot_nodes:
-                variables.setdefault(full, key)
+                if full in variables and variables[full] != key:
+                    # two different variables under one Keras name: loading by name cannot tell them apart
+                    raise CheckpointError(f"object graph holds two variables named {full!r} "
+                                          f"({variables[full]!r} and {key!r}): cannot be loaded by name")
+                variables[full] = key
         return variables, slots
 
 
@@ -486,7 +490,14 @@ def _object_graph_proto(var_keys, slot_keys):
 
 
 def save_weights(prefix, variables, slots=None, update_state=True):
-    """variables: {name: array} (conv kernels HWIO, as Keras holds them); slots: {(name, slot_name): array}."""
+    """variables: {name: array} (conv kernels HWIO, as Keras holds them); slots: {(name, slot_name): array}.
+
+    ONE-WAY INTEROP: the files are valid TensorFlow checkpoints (tf.train.load_checkpoint / list_variables read every
+    tensor by key, and this module's reader maps them back through the object graph's full names), but the object
+    graph written here is flat — root -> one child per variable name.  Keras' `model.load_weights` /
+    `tf.train.Checkpoint.restore` match a checkpoint STRUCTURALLY (`layer_with_weights-N/...` children in Keras' own
+    layer numbering), which cannot be reproduced without TensorFlow, so they will not restore these files into the
+    reference's Keras model.  Reading checkpoints the reference wrote works the other way round (object_graph())."""
     slots = slots or {}
     var_keys = {n: n + _VALUE_SUFFIX for n in variables}
     slot_keys = {(n, s): f"{n}/.OPTIMIZER_SLOT/optimizer/{s}{_VALUE_SUFFIX}" for (n, s) in slots}

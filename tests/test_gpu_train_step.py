@@ -149,7 +149,8 @@ def test_train_step_at_baseline_sizes(cuda, size, B):
     ids = _kernel_ids(eng)
     assert ids["fwd:tower0"] == 2 and ids["dgrad:tower3"] == 2 and ids["fwd:pred_class"] == 2, ids
     assert ids["dgrad:pred_class"] == 2 and ids["fwd:fpn_out"] == 2, ids
-    assert ids["fwd:g2b1_out"] == 1 and ids["dgrad:g2b1_out"] == 1, ids
+    # residual 1x1 (128 -> 512) forward and the data gradient of the 1x1 in front of it (dx has 512 channels)
+    assert ids["fwd:g2b1_out"] == 1 and ids["dgrad:g2b1_a"] == 1, ids
     assert all(B * s.H * s.W < (1 << 22) for _, pr in eng.conv_launches for s in [pr.seg[0]])   # rn_fdiv's bound
     ref = RefTrainer(p, model.variables, frozen_names=eng.frozen, emulate_bf16=True, dtype=torch.float32)
     preds = eng.forward(images.to(cuda))

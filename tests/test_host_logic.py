@@ -68,7 +68,7 @@ def test_efficientnet_b3_graph_inventory():
     FPN/heads at 160 filters; Keras variable names of MBConvBlock._build (efficientnet.py:335-421)."""
     from retinanet.cfg import efficientnet_params
     from retinanet.model.graph import build_retinanet_graph
-    from retinanet.model.graph_efficientnet import block_table, round_filters
+    from retinanet.model.backbone.efficientnet import block_table, round_filters
     t = block_table("efficientnet-b3")
     assert round_filters(32, 1.2) == 40 and len(t) == 26
     assert [(b["cin"], b["cout"], b["k"], b["stride"]) for b in t[:3]] == [(40, 24, 3, 1), (24, 24, 3, 1), (24, 32, 3, 2)]

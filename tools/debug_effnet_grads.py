@@ -1,42 +1,20 @@
-"""Per-tensor gradient comparison (TrainEngine vs RefTrainer) for an EfficientNet RetinaNet — debugging aid."""
+"""Per-tensor gradient comparison (TrainEngine vs RefTrainer) for an EfficientNet RetinaNet — debugging aid.
+python tools/debug_effnet_grads.py [model] [size] [batch] [dense|loss]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in ("retinanet-tensorflow2.x_amd", "tests/golden", "oracle", "tests"):
     sys.path.insert(0, os.path.join(ROOT, p))
 import numpy as np, torch
-from model_ref import RefTrainer
-from retinanet.cfg import efficientnet_params
-from retinanet.model import ModelBuilder
-from retinanet.model.train_engine import TrainEngine
-from test_gpu_efficientnet import _engine_grad
-cuda = torch.device("cuda:0")
-name, size, B = sys.argv[1] if len(sys.argv) > 1 else "efficientnet-b0", int(sys.argv[2]) if len(sys.argv) > 2 else 256, 2
-p = efficientnet_params(name, input_size=size)
-p.architecture.batch_norm.use_sync = False
-builder = ModelBuilder(p, "train", device=cuda, seed=5)
-model = builder()
-g = torch.Generator().manual_seed(5)
-for k, v in model.variables.items():
-    if k.endswith("/gamma"):
-        last = k.endswith("tpu_batch_normalization_2/gamma") or k.endswith("blocks_0/tpu_batch_normalization_1/gamma")
-        lo, span = (0.1, 0.2) if last else (0.75, 0.5)
-        v.copy_((torch.rand(v.shape, generator=g) * span + lo).to(cuda))
-    elif k.endswith("/beta"):
-        v.copy_((torch.randn(v.shape, generator=g) * 0.1).to(cuda))
-eng = TrainEngine(model, B, frozen_regexes=[])
-ref = RefTrainer(p, model.variables, frozen_names=eng.frozen, emulate_bf16=True)
-images = torch.randn((B, size, size, 3), generator=g)
-preds = eng.forward(images.to(cuda))
-up = {k: {lv: torch.randn(preds[k][lv].shape, generator=g) for lv in preds[k]} for k in preds}
-eng.backward({k: {lv: t.to(cuda) for lv, t in d.items()} for k, d in up.items()})
-torch.cuda.synchronize()
-rp = ref.forward_train(images)
-sum((rp[k][lv] * up[k][lv].double()).sum() for k in up for lv in up[k]).backward()
-rows = []
-for k in eng.train_names:
-    want = ref.leaf[k].grad
-    got = _engine_grad(eng, k).double()
-    a, b = got.reshape(-1), want.reshape(-1)
-    rows.append((float(a @ b / (a.norm() * b.norm() + 1e-30)), float(a.norm() / (b.norm() + 1e-30)), float(b.norm()), k))
-for r in rows:
-    print(f"{r[0]:+.4f} {r[1]:8.3f} {r[2]:10.3e} {r[3]}")
+import test_gpu_efficientnet as T
+name = sys.argv[1] if len(sys.argv) > 1 else "efficientnet-b0"
+size = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+upstream = sys.argv[4] if len(sys.argv) > 4 else "dense"
+fwd, rows, losses = T.run_wiring(torch.device("cuda:0"), name, size, B, upstream)
+print("forward relative error: max %.4f" % max(fwd.values()), {k: round(v, 4) for k, v in fwd.items()})
+print("losses (engine, restatement):", losses)
+zero = T._zero_gradient_betas(name)
+for r in sorted(rows):
+    print(f"{r[0]:+.4f} {r[1]:8.3f} {r[2]:10.3e} {r[3]}{'  [analytically zero]' if r[3] in zero else ''}")
+cs = [r[0] for r in rows if r[3] not in zero]
+print("cosine median %.4f min %.4f" % (np.median(cs), min(cs)))
