@@ -422,6 +422,21 @@ int rn_optim_sgd_step(float* params, const float* grads, float* momentum_buf, fl
                       float ema_decay, int nesterov, const float* skip_flag, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * C1-C3  collectives of the data-parallel step over RCCL / xGMI (the reference reaches them through
+ * tf.distribute: retinanet_loss.py:46-49, model/utils.py:10-12, executor.py:436-437).  One process per GPU; rank 0
+ * draws a unique id (rn_comm_unique_id, rn_comm_unique_id_bytes() bytes) and hands it to every rank out of band;
+ * rn_comm_init is collective.  A collective is enqueued on the CALLER'S stream (asynchronous to the host, in stream
+ * order with the kernels around it); in-place SUM.  Use one communicator per stream that carries collectives.
+ * rn_allreduce_bucket: gradient buckets (RN_DT_F32 / RN_DT_BF16); rn_allreduce_small: the few-KB fp32 messages
+ * (SyncBatchNorm [sum | sum of squares], the loss normaliser) on the latency path.  Status RN_ECOMM on failure. */
+int rn_comm_unique_id_bytes(void);
+int rn_comm_unique_id(void* out /* host, rn_comm_unique_id_bytes() bytes */);
+int rn_comm_init(const void* unique_id /* host */, int rank, int world, void** comm_out);
+int rn_comm_destroy(void* comm);
+int rn_allreduce_bucket(void* comm, void* ptr /* device */, int64_t count, int dtype, void* stream);
+int rn_allreduce_small(void* comm, float* ptr /* device */, int count, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * K6  tf.keras.layers.MaxPool2D  (resnet.py:304-307 3x3 s2 SAME; fpn_base.py:25-26,68 2x2 s2)
  * explicit pads; padded taps are skipped (-inf). bf16 NHWC.
  */

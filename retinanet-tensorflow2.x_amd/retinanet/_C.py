@@ -190,6 +190,12 @@ _SIGNATURES = {
                                   c_int, c_int, c_void_p]),
     "rn_fpn_topdown": (c_int, [_PP, _PP, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rn_balance_features": (c_int, [_PP, _PP, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rn_comm_unique_id_bytes": (c_int, []),
+    "rn_comm_unique_id": (c_int, [c_void_p]),
+    "rn_comm_init": (c_int, [c_void_p, c_int, c_int, POINTER(c_void_p)]),
+    "rn_comm_destroy": (c_int, [c_void_p]),
+    "rn_allreduce_bucket": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "rn_allreduce_small": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     # host functions (TFRecord input format)
     "rn_crc32c": (c_uint32, [c_void_p, c_size_t]),
     "rn_crc32c_masked": (c_uint32, [c_void_p, c_size_t]),

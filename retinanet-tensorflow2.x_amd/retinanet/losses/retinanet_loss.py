@@ -39,8 +39,10 @@ class RetinaNetLoss:
             return dist.get_world_size(self._pg)
         return 1
 
-    def __call__(self, targets, predictions, compute_grads=True, grad_scale=None, grads_bf16=None):
-        """grads_bf16 = {"class-predictions": {level: bf16[B,H,W,stride]}, "box-predictions": {...}}: write the
+    def __call__(self, targets, predictions, compute_grads=True, grad_scale=None, grads_bf16=None, normalizer=None):
+        """normalizer: optional device f32[1] = all_reduce_sum(sum(num-positives) + 1) / replicas already computed by
+        the caller (the training engine folds that scalar into its first SyncBN message) — else computed here.
+        grads_bf16 = {"class-predictions": {level: bf16[B,H,W,stride]}, "box-predictions": {...}}: write the
         gradients as bf16 into these (channel-padded) tensors instead of fp32 `self.grads` — the training engine
         passes the dy tensors of the prediction convs, so no fp32 gradient is materialised."""
         lib = _C.lib()
@@ -55,7 +57,10 @@ class RetinaNetLoss:
         # normaliser = all_reduce_sum(sum(num-positives) + 1) / replicas  (retinanet_loss.py:38-49)
         from retinanet.distribute import global_normalizer
         R = self._num_replicas()
-        normalizer = global_normalizer(targets["num-positives"].sum(), R, self._pg)
+        if normalizer is None:
+            normalizer = global_normalizer(targets["num-positives"].sum(), R, self._pg)
+        else:
+            normalizer = normalizer.reshape(1).to(torch.float32).contiguous()
         offs = [0]
         cl, bl = [], []
         for lv in levels:

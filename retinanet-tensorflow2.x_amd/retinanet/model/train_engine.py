@@ -68,9 +68,13 @@ class TrainEngine:
                 self.frozen.add(k)
         self._keep = []
         self._train_step_active = False
+        self._c2_local, self._c2_sent, self.c2_normalizer = None, False, None
         self._overlap_on = False
         self._overlap_done = 0
         self._step_args = dict(wdc=0.0, alpha=0.0, unscale=1.0, clip=0.0)
+        self.native_comm = None   # retinanet.comm.NativeComm for the small per-layer messages (SyncBN, normaliser)
+        self._algo = {}           # id(rn_conv_problem) -> (algorithmic FLOPs, algorithmic bytes) where the launch executes more
+        self.hbm_profile = None   # bench.py: list that collects (event0, event1, kernel name, algorithmic bytes)
         self.conv_launches = []   # (name, rn_conv_problem) of every implicit-GEMM launch: lib.rn_conv_kernel_id(byref(p))
         self.step_count = 0
         self.conv_profile = None
@@ -471,18 +475,26 @@ class TrainEngine:
 
     # ---- helpers to build launches ---------------------------------------------------------------------
     def _conv_meta(self, p):
-        """(algorithmic FLOPs, algorithmic HBM bytes, kernel variant or None) of a launch.  Bytes = every
-        input pixel read once + every output written once (+ residual read) + weights.  Variants that
-        bench.py tracks: the 256x256x32 kernel and the 128x128x64 kernel, both with bf16 output."""
-        flops, byts, dom = 0, 0, True
+        """(ALGORITHMIC FLOPs, algorithmic HBM bytes, kernel variant or None) of a launch — SURVEY 8(d): FLOPs =
+        2 * Ho*Wo*k*k*Cin*Cout of the LAYER per image (a data-gradient launch counts its layer's forward MACs, not the
+        zero-upsampled or channel-padded GEMM it executes; split-bf16 weight planes count once); bytes = every input
+        pixel read once + every output written once (+ residual read) + weights.  Variants bench.py tracks: the
+        256x256x32 kernels and the 128x128x64 kernel, bf16 output."""
         osz = 4 if p.out_dtype == _C.RN_DT_F32 else 2
+        dom = True
         for i in range(p.num_segments):
             s = p.seg[i]
-            flops += 2 * s.N * s.Ho * s.Wo * p.R * p.S * s.Cin * s.Cout
-            byts += 2 * s.N * s.H * s.W * s.pix_stride + osz * s.N * s.Ho * s.Wo * s.Cout + 2 * p.R * p.S * s.Cin * s.Cout
-            if s.residual:
-                byts += 2 * s.N * s.Ho * s.Wo * s.Cout
             dom = dom and s.Cout > 64 and s.Cin % 64 == 0 and p.out_dtype == _C.RN_DT_BF16
+        if id(p) in self._algo:
+            flops, byts = self._algo[id(p)]
+        else:
+            flops = byts = 0
+            for i in range(p.num_segments):
+                s = p.seg[i]
+                flops += 2 * s.N * s.Ho * s.Wo * p.R * p.S * s.Cin * s.Cout
+                byts += 2 * s.N * s.H * s.W * s.pix_stride + osz * s.N * s.Ho * s.Wo * s.Cout + 2 * p.R * p.S * s.Cin * s.Cout
+                if s.residual:
+                    byts += 2 * s.N * s.Ho * s.Wo * s.Cout
         # one name per device symbol, so that a bench line and a rocprof kernel-stats row can be matched
         variant = None
         kid = self.lib.rn_conv_kernel_id(ctypes.byref(p))
@@ -572,6 +584,38 @@ class TrainEngine:
         self._keep.append(p)
         return p
 
+    def _allreduce_small(self, t):
+        """SyncBatchNorm / normaliser message: rn_allreduce_small on the compute stream when a native communicator was
+        handed in (retinanet.comm.maybe_enable_native), torch.distributed otherwise"""
+        if self.native_comm is not None:
+            self.native_comm.all_reduce_small(t)
+        else:
+            import torch.distributed as dist
+            dist.all_reduce(t, group=self.pg)
+
+    def _bn_pass(self, kind, pb, fn):
+        """BatchNorm elementwise / reduction passes (HBM-bound): bench.py brackets them with events on the launch stream.
+        Algorithmic bytes: apply = read y + write z (+ residual); bwd_reduce = read y + dz (+ z for the residual
+        layers' gate); bwd_apply = the same reads + write dy (+ dres, + its old value when accumulating)."""
+        prof = self.hbm_profile
+        if prof is None:
+            return fn()
+        byts = 0
+        for i in range(pb.num_segments):
+            s = pb.seg[i]
+            n = int(s.P) * int(s.C) * 2
+            if kind == "bn_apply":
+                byts += n * (3 if s.residual else 2)
+            elif kind == "bn_bwd_reduce":
+                byts += n * (3 if s.residual and pb.act else 2)
+            else:
+                byts += n * ((3 if s.residual and pb.act else 2) + 1 + ((2 if s.dres_accumulate else 1) if s.dres else 0))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(self.dev))
+        fn()
+        e1.record(torch.cuda.current_stream(self.dev))
+        prof.append((e0, e1, kind, byts))
+
     def _bn_stats_finalize(self, prb, ws, sums, st):
         """Batch statistics -> (mean, invstd, scale, shift) + moving statistics.  One replica: the final reduction
         kernel also finalizes; SyncBN: the [2][C] sums are all-reduced between the two."""
@@ -582,7 +626,15 @@ class TrainEngine:
         _C.check(lib.rn_bn_stats(prb, _C.ptr(ws), ws.numel(), st), "rn_bn_stats")
         if self.sync_bn:
             import torch.distributed as dist
-            dist.all_reduce(sums, group=self.pg)
+            fold = self._c2_local is not None and not self._c2_sent
+            if fold:
+                # C2 (the loss normaliser's scalar all-reduce, retinanet_loss.py:46-49) rides in the spare slot of
+                # the step's FIRST SyncBN message instead of being a collective of its own
+                sums[-1:].copy_(self._c2_local)
+            self._allreduce_small(sums)
+            if fold:
+                self._c2_sent = True
+                self.c2_normalizer = sums[-1:] / float(self.world)
         _C.check(lib.rn_bn_finalize(prb, st), "rn_bn_finalize")
 
     def _bn_problem(self, ops, conv_problem=None):
@@ -595,7 +647,7 @@ class TrainEngine:
         p.bessel = 0 if self.sync_bn else 1
         p.eps, p.momentum, p.count_scale = self.eps, self.momentum_bn, float(self.world if self.sync_bn else 1)
         csum = sum(self.tensors[o["out"]][2] for o in ops)
-        sums = torch.zeros((2 * csum,), dtype=torch.float32, device=self.dev)
+        sums = torch.zeros((2 * csum + 1,), dtype=torch.float32, device=self.dev)   # + the slot C2 rides in
         bsums = torch.zeros((2 * csum,), dtype=torch.float32, device=self.dev)
         fwd = torch.zeros((4 * csum,), dtype=torch.float32, device=self.dev)
         off = 0
@@ -685,10 +737,10 @@ class TrainEngine:
                     self.bn_groups[op["out"]] = (pb, sums, bsums, ws, dys, [op])
                     prb = ctypes.byref(pb)
 
-                    def run_stem(st, p=p, prb=prb, ws=ws, sums=sums):
+                    def run_stem(st, p=p, prb=prb, ws=ws, sums=sums, pb=pb):
                         self._launch_conv(p, st, "stem(train)")
                         self._bn_stats_finalize(prb, ws, sums, st)
-                        _C.check(lib.rn_bn_apply(prb, st), "rn_bn_apply")
+                        self._bn_pass("bn_apply", pb, lambda: _C.check(lib.rn_bn_apply(prb, st), "rn_bn_apply"))
                     self.fwd_steps.append(run_stem)
                 else:
                     self.fwd_steps.append(lambda st, p=p: self._launch_conv(p, st, "stem"))
@@ -710,10 +762,10 @@ class TrainEngine:
                     self.bn_groups[ops[0]["out"]] = (pb, sums, bsums, ws, dys, ops)
                     prb = ctypes.byref(pb)
 
-                    def run(st, pc=pc, prb=prb, ws=ws, sums=sums):
+                    def run(st, pc=pc, prb=prb, ws=ws, sums=sums, pb=pb):
                         self._launch_conv(pc, st, "conv(train)")
                         self._bn_stats_finalize(prb, ws, sums, st)
-                        _C.check(lib.rn_bn_apply(prb, st), "rn_bn_apply")
+                        self._bn_pass("bn_apply", pb, lambda: _C.check(lib.rn_bn_apply(prb, st), "rn_bn_apply"))
                     self.fwd_steps.append(run)
                 else:
                     pc = self._conv_problem(ops, lambda o: self.t[o["out"]], raw_mode=False)
@@ -735,10 +787,10 @@ class TrainEngine:
                     self.bn_groups[ops[0]["out"]] = (pb, sums, bsums, ws, dys, ops)
                     prb = ctypes.byref(pb)
 
-                    def run_dw(st, prd=prd, prb=prb, ws=ws, sums=sums):
+                    def run_dw(st, prd=prd, prb=prb, ws=ws, sums=sums, pb=pb):
                         _C.check(lib.rn_depthwise_conv2d_nhwc_fwd(prd, st), "depthwise(train)")
                         self._bn_stats_finalize(prb, ws, sums, st)
-                        _C.check(lib.rn_bn_apply(prb, st), "rn_bn_apply")
+                        self._bn_pass("bn_apply", pb, lambda: _C.check(lib.rn_bn_apply(prb, st), "rn_bn_apply"))
                     self.fwd_steps.append(run_dw)
                 else:
                     if ops[0].get("act") not in (None, "none"):
@@ -883,8 +935,7 @@ class TrainEngine:
                 def stem_bwd(st, prb=ctypes.byref(pb), ws=ws, bsums=bsums, pw=pw, wsw=wsw, dwp=dwp, gview=gview, k=k):
                     _C.check(lib.rn_bn_bwd_reduce(prb, _C.ptr(ws), ws.numel(), st), "rn_bn_bwd_reduce")
                     if self.sync_bn:
-                        import torch.distributed as dist
-                        dist.all_reduce(bsums, group=self.pg)
+                        self._allreduce_small(bsums)
                     _C.check(lib.rn_bn_bwd_apply(prb, st), "rn_bn_bwd_apply")
                     _C.check(lib.rn_conv2d_nhwc_wgrad(ctypes.byref(pw), dwp.data_ptr(), 0.0, wsw.data_ptr(),
                                                       wsw.numel(), st), "stem wgrad")
@@ -939,12 +990,12 @@ class TrainEngine:
                     s.dres_accumulate = 0 if mark(res) else 1
             prb = ctypes.byref(pb)
 
-            def run(st, prb=prb, ws=ws, bsums=bsums):
-                _C.check(lib.rn_bn_bwd_reduce(prb, _C.ptr(ws), ws.numel(), st), "rn_bn_bwd_reduce")
+            def run(st, prb=prb, ws=ws, bsums=bsums, pb=pb):
+                self._bn_pass("bn_bwd_reduce", pb, lambda: _C.check(lib.rn_bn_bwd_reduce(prb, _C.ptr(ws), ws.numel(), st),
+                                                                     "rn_bn_bwd_reduce"))
                 if self.sync_bn:
-                    import torch.distributed as dist
-                    dist.all_reduce(bsums, group=self.pg)
-                _C.check(lib.rn_bn_bwd_apply(prb, st), "rn_bn_bwd_apply")
+                    self._allreduce_small(bsums)
+                self._bn_pass("bn_bwd_apply", pb, lambda: _C.check(lib.rn_bn_bwd_apply(prb, st), "rn_bn_bwd_apply"))
             run.writes = [op["bn"] + sfx for op in ops for sfx in ("/gamma", "/beta")]
             self.bwd_steps.append(run)
             dy_of = {op["out"]: dys[i] for i, op in enumerate(ops)}
@@ -1037,12 +1088,12 @@ class TrainEngine:
                 pb.seg[i].dz = self.grad[op["out"]].data_ptr()
             prb = ctypes.byref(pb)
 
-            def run(st, prb=prb, ws=ws, bsums=bsums):
-                _C.check(lib.rn_bn_bwd_reduce(prb, _C.ptr(ws), ws.numel(), st), "rn_bn_bwd_reduce")
+            def run(st, prb=prb, ws=ws, bsums=bsums, pb=pb):
+                self._bn_pass("bn_bwd_reduce", pb, lambda: _C.check(lib.rn_bn_bwd_reduce(prb, _C.ptr(ws), ws.numel(), st),
+                                                                     "rn_bn_bwd_reduce"))
                 if self.sync_bn:
-                    import torch.distributed as dist
-                    dist.all_reduce(bsums, group=self.pg)
-                _C.check(lib.rn_bn_bwd_apply(prb, st), "rn_bn_bwd_apply")
+                    self._allreduce_small(bsums)
+                self._bn_pass("bn_bwd_apply", pb, lambda: _C.check(lib.rn_bn_bwd_apply(prb, st), "rn_bn_bwd_apply"))
             run.writes = [op["bn"] + sfx for op in ops for sfx in ("/gamma", "/beta")]
             self.bwd_steps.append(run)
             dy_of = {op["out"]: dys[i] for i, op in enumerate(ops)}
@@ -1176,6 +1227,16 @@ class TrainEngine:
             s.Ho, s.Wo, s.Cout = H, W, c["cin"]
         self._keep.append(p)
         self.conv_launches.append(("dgrad:" + (need[0].get("group") or need[0]["out"]), p))
+        fl = by = 0
+        for op in need:     # the layer's own MACs and tensors: dy [B,Ho,Wo,Cout] in, dx [B,H,W,Cin] out (+ accumulate read)
+            c = self.g.convs[op["conv"]]
+            Ho, Wo = self.tensors[op["out"]][:2]
+            x = self._src(op["inp"])
+            fl += 2 * B * Ho * Wo * c["k"] * c["k"] * c["cin"] * c["cout"]
+            by += 2 * B * Ho * Wo * c["cout"] + 2 * B * x.shape[1] * x.shape[2] * c["cin"] + 2 * c["k"] * c["k"] * c["cin"] * c["cout"]
+        by += sum(2 * B * self._src(o["inp"]).shape[1] * self._src(o["inp"]).shape[2] * self.g.convs[o["conv"]]["cin"]
+                  for i, o in enumerate(need) if p.seg[i].residual)
+        self._algo[id(p)] = (fl, by)
 
         def dgrad(st, p=p, ups=ups, scatters=scatters):
             for u in ups:
@@ -1481,10 +1542,14 @@ class TrainEngine:
             self._step_args = dict(wdc=alpha / self.world, alpha=alpha, unscale=1.0 / scale,
                                    clip=float(opt.clipnorm) if opt.clipnorm else 0.0)
             self._prepack_dgrad_weights()
+            self._c2_local, self._c2_sent, self.c2_normalizer = None, False, None
+            if self.sync_bn:    # sum(num-positives) + 1 of this rank (retinanet_loss.py:38): folded into SyncBN traffic
+                self._c2_local = (targets["num-positives"].sum() + 1.0).reshape(1).to(torch.float32)
             preds = self.forward(images)
+            self._c2_local = None
             # per_replica_loss = total / replicas, times the loss scale under mixed_float16 (executor.py:421-425)
             loss = self.model.loss(targets, preds, compute_grads=True, grad_scale=scale / self.world,
-                                   grads_bf16=self.loss_grad_buffers())
+                                   grads_bf16=self.loss_grad_buffers(), normalizer=self.c2_normalizer)
             self._train_step_active = True
             try:
                 self.backward(None)

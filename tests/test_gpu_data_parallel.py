@@ -24,7 +24,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _build(world, rank):
+def _build(world, rank, clipnorm=1e9):
     sys.path.insert(0, PKG)
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
     from make_golden import synth_gt
@@ -35,7 +35,7 @@ def _build(world, rank):
     dev = torch.device("cuda:0")
     p = default_params(input_size=SIZE, batch_train=B)
     p.architecture.backbone.depth = 14
-    p.training.optimizer.clipnorm = 1e9          # per-replica clipping is the one intentionally non-linear stage
+    p.training.optimizer.clipnorm = clipnorm     # per-replica clipping is the one intentionally non-linear stage
     builder = ModelBuilder(p, "train", device=dev, seed=SEED)
     model = builder()
     per = B // world
@@ -58,7 +58,14 @@ def _step(model, eng, images, targets):
     model.optimizer.lr = lambda step: 0.01
     out = eng.train_step(images, targets)
     torch.cuda.synchronize()
-    return {"P": eng.P.cpu().numpy(), "loss": float(out["weighted-loss"].item()),
+    gb = np.zeros(eng.P.numel(), bool)           # which arena elements are BatchNorm gamma / beta
+    for k in eng.train_names:
+        if k.endswith(("/gamma", "/beta")):
+            off, n = eng.p_off[k]
+            gb[off:off + n] = True
+    return {"P": eng.P.cpu().numpy(), "loss": float(out["weighted-loss"].item()), "gamma_beta": gb,
+            "norm_before_clip": float(eng.metrics[1].item()), "clip_fired": bool(getattr(eng, "clip_fired", False)),
+            "overlapped": bool(eng._overlap_on), "l2": float(out["l2-regularization"].item()),
             "mm": {k: v["mm"].cpu().numpy() for k, v in eng.bn_state.items()}}
 
 
@@ -68,6 +75,36 @@ def _worker(rank, world, port, out):
     model, eng, images, targets = _build(world, rank)
     assert eng.sync_bn
     out[rank] = _step(model, eng, images, targets)
+    assert out[rank]["overlapped"]                 # the default N > 1 path: buckets go out during the backward pass
+    assert eng.c2_normalizer is not None           # ... and the loss normaliser rode in the first SyncBN message
+    dist.destroy_process_group()
+
+
+def _worker_orders(rank, world, port, out):
+    """the same step three ways: plain order (clip, then one all-reduce after the backward pass), overlapped buckets
+    without a clip, overlapped buckets with a clip that fires on ONE rank only"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = {}
+    for tag, overlap, clip in (("plain", "0", 1e9), ("overlapped", "auto", 1e9)):
+        os.environ["RNET_C1_OVERLAP"] = overlap
+        model, eng, images, targets = _build(world, rank, clipnorm=clip)
+        res[tag] = _step(model, eng, images, targets)
+        del model, eng
+        torch.cuda.empty_cache()
+    norms = [torch.zeros(1) for _ in range(world)]
+    dist.all_gather(norms, torch.tensor([res["plain"]["norm_before_clip"]]))
+    norms = sorted(float(n) for n in norms)
+    clip = 0.5 * (norms[0] + norms[1])             # between the two ranks' local gradient norms
+    res["clipnorm"] = clip
+    for tag, overlap in (("plain_clip", "0"), ("overlapped_clip", "auto")):
+        os.environ["RNET_C1_OVERLAP"] = overlap
+        model, eng, images, targets = _build(world, rank, clipnorm=clip)
+        res[tag] = _step(model, eng, images, targets)
+        del model, eng
+        torch.cuda.empty_cache()
+    os.environ.pop("RNET_C1_OVERLAP", None)
+    out[rank] = res
     dist.destroy_process_group()
 
 
@@ -93,3 +130,33 @@ def test_two_ranks_match_one_process(cuda):
     assert 0.5 * (r0["loss"] + r1["loss"]) == pytest.approx(single["loss"], rel=0.02)
     for k in single["mm"]:                                          # SyncBN: global batch statistics
         np.testing.assert_allclose(r0["mm"][k], single["mm"][k], rtol=2e-2, atol=2e-3)
+    # BatchNorm gamma / beta on their own (0.1 % of the parameters: invisible in the whole-arena cosine): their
+    # gradients are each replica's LOCAL sums until the optimizer's all-reduce (they used to come out
+    # world x too large because the SyncBN backward all-reduce ran before they were written)
+    gb = single["gamma_beta"]
+    assert gb.sum() > 1000
+    cos_gb = float(np.dot(upd_1[gb], upd_2[gb]) / (np.linalg.norm(upd_1[gb]) * np.linalg.norm(upd_2[gb])))
+    assert cos_gb > 0.98, cos_gb
+    assert abs(np.linalg.norm(upd_2[gb]) / np.linalg.norm(upd_1[gb]) - 1) < 0.05
+    assert r0["l2"] == pytest.approx(single["l2"], rel=1e-5)        # the l2 term is the same on every replica
+
+
+def test_overlapped_allreduce_equals_the_plain_order(cuda):
+    """gradient buckets all-reduced DURING the backward pass on unclipped gradients, the clip applied
+    as a correction only when some rank's factor != 1.  Against the reference's literal order (clip the local
+    gradients, then all-reduce — executor.py:432-437): bit-identical weights while no clip fires, and the same
+    weights to fp32 rounding when the clip fires on one rank only."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_orders, args=(2, _free_port(), out), nprocs=2, join=True)
+    for rank in (0, 1):
+        r = out[rank]
+        assert not r["plain"]["overlapped"] and r["overlapped"]["overlapped"]
+        assert not r["overlapped"]["clip_fired"]
+        np.testing.assert_array_equal(r["plain"]["P"], r["overlapped"]["P"])
+        assert r["overlapped_clip"]["overlapped"] and r["overlapped_clip"]["clip_fired"]
+        np.testing.assert_allclose(r["plain_clip"]["P"], r["overlapped_clip"]["P"], rtol=1e-5, atol=1e-7)
+        assert np.abs(r["plain_clip"]["P"] - r["plain"]["P"]).max() > 0      # the clip changed the update
+    np.testing.assert_array_equal(out[0]["overlapped_clip"]["P"], out[1]["overlapped_clip"]["P"])
+    lo, hi = sorted(out[r]["plain"]["norm_before_clip"] for r in (0, 1))
+    assert lo < out[0]["clipnorm"] < hi
