@@ -4,9 +4,9 @@
 `accumulate_results` (:95-134) is served by `rn_coco_accumulate` on the detections as they come
 off the NMS kernels (rescale to original-image pixels, int32 truncation, xyxy -> xywh, class id
 remap); the per-detection dict list and the JSON dump stay host code.  The category table comes
-from the annotation JSON itself (`categories`), so pycocotools is only needed by `evaluate()`
-(`COCOeval`, :136-157) — it is not installed in this image and `evaluate()` says so after writing
-the prediction file.
+from the annotation JSON itself (`categories`).  `evaluate()` (:136-157) runs pycocotools' `COCOeval` when
+pycocotools is installed and otherwise the NumPy restatement of it in `retinanet/eval/cocoeval.py` (bbox only,
+same twelve statistics).
 """
 from __future__ import annotations
 
@@ -76,20 +76,26 @@ class COCOEvaluator:
                 self._processed_detections.append({"image_id": image_ids[i], "category_id": cat_h[i][d],
                                                    "bbox": bbox_h[i][d], "score": float(scores_h[i][d])})
 
-    def evaluate(self):
+    def evaluate(self, print_fn=None):
         with open(self.prediction_file_path, "w") as f:
             json.dump(self._processed_detections, f, indent=4)
         try:
             from pycocotools.coco import COCO
             from pycocotools.cocoeval import COCOeval
-        except ImportError as e:
-            raise RuntimeError(f"predictions written to {self.prediction_file_path}; COCOeval needs pycocotools, which is "
-                               "not installed in this environment") from e
-        gt = COCO(self.annotation_file_path)
-        ev = COCOeval(gt, gt.loadRes(self.prediction_file_path), "bbox")
-        ev.evaluate()
-        ev.accumulate()
-        ev.summarize()
+            gt = COCO(self.annotation_file_path)
+            ev = COCOeval(gt, gt.loadRes(self.prediction_file_path), "bbox")
+            ev.evaluate()
+            ev.accumulate()
+            ev.summarize()
+        except ImportError:
+            from retinanet.eval.cocoeval import COCO, COCOeval
+            gt = COCO(self.annotation_file_path)
+            ev = COCOeval(gt, gt.loadRes(self.prediction_file_path) if self._processed_detections
+                          else COCO(dataset={"images": list(gt.imgs.values()), "categories": list(gt.cats.values()),
+                                             "annotations": []}), "bbox")
+            ev.evaluate()
+            ev.accumulate()
+            ev.summarize(print_fn=print_fn)
         return {"AP-IoU=0.50:0.95": ev.stats[0], "AP-IoU=0.50": ev.stats[1], "AP-IoU=0.75": ev.stats[2],
                 "AR-(all)-IoU=0.50:0.95": ev.stats[6], "AR-(L)-IoU=0.50:0.95": ev.stats[-1]}
 
