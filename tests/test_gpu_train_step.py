@@ -171,11 +171,14 @@ def test_train_step_at_baseline_sizes(cuda, size, B):
     eng.backward(model.loss.grads)
     torch.cuda.synchronize()
     rp = ref.forward_train(images)
-    # bounds = the restatement's own float32-vs-float64 noise at this configuration (tools/oracle_noise_floor.py 50 640
-    # 4 loss: forward 0.055, gradient cosine median 0.929, 5 %-quantile 0.900; the HIP path measures 0.061 / 0.932)
+    # bounds = the restatement's own float32-vs-float64 noise at this configuration (tools/oracle_noise_floor.py 50
+    # <size> <batch> loss, CPU): forward relative error / gradient cosine median / 5 %-quantile
+    #   640 x 640 : 0.0554 / 0.929 / 0.900   (the HIP path measures 0.061 / 0.932)
+    #   1024 x 1024: 0.0622 / 0.9175 / 0.873
+    floor_fwd, floor_med, floor_q05 = {640: (0.0554, 0.929, 0.900), 1024: (0.0622, 0.9175, 0.8726)}[size]
     for k in ("class-predictions", "box-predictions"):
         for lv in rp[k]:
-            assert _rel(preds[k][lv].float().cpu(), rp[k][lv].detach()) < 1.3 * 0.0554, (k, lv)
+            assert _rel(preds[k][lv].float().cpu(), rp[k][lv].detach()) < 1.3 * floor_fwd, (k, lv)
     rl = ref.loss(rp, targets["_flat"]["class-targets"].cpu().numpy(), targets["_flat"]["box-targets"].cpu().numpy(),
                   float(targets["num-positives"].sum().item()))
     for k in ("box-loss", "class-loss", "weighted-loss"):
@@ -196,8 +199,8 @@ def test_train_step_at_baseline_sizes(cuda, size, B):
               "class-head/class-head-prediction-conv2d/bias", "box-head/box-head-prediction-conv2d/bias"):
         assert by[k][0] > 0.995 and abs(by[k][1] - 1) < 0.02, by[k]
     print("gradient cosine: min %.4f (%s), median %.4f" % (rows[0][0], rows[0][2], np.median([r[0] for r in rows])))
-    assert rows[len(rows) // 20][0] > 0.900 - 0.05, rows[:len(rows) // 20 + 1]
-    assert np.median([r[0] for r in rows]) > 0.929 - 0.025, np.median([r[0] for r in rows])
+    assert rows[len(rows) // 20][0] > floor_q05 - 0.05, rows[:len(rows) // 20 + 1]
+    assert np.median([r[0] for r in rows]) > floor_med - 0.025, np.median([r[0] for r in rows])
     gn_got = float(torch.sqrt(sum((_engine_grad(eng, k).double() ** 2).sum() for k in eng.train_names)))
     gn_want = float(torch.sqrt(sum((ref.leaf[k].grad.double() ** 2).sum() for k in eng.train_names)))
     assert gn_got == pytest.approx(gn_want, rel=0.03)
