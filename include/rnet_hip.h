@@ -570,6 +570,15 @@ int rn_example_parse(const uint8_t* record, size_t nbytes, rn_example_info* info
 size_t rn_example_serialize(const uint8_t* image, size_t image_bytes, int64_t image_id, const float* boxes,
                             int n_boxes, const int64_t* classes, int n_classes, uint8_t* out, size_t capacity);
 
+/* ---------------------------------------------------------------------------------------
+ * §8(f)-4  JPEG decoding for the TFRecord input path (host only; tf.io.decode_image in dataloader/tfrecord_parser.py:20-23):
+ * baseline / extended-sequential Huffman JPEG, grayscale or YCbCr with 4:4:4 / 4:2:2 / 4:4:0 / 4:2:0 sampling, restart
+ * intervals; libjpeg's defaults restated (islow integer IDCT, fancy chroma up-sampling, 16-bit fixed-point YCbCr->RGB).
+ * Progressive / arithmetic / 12-bit / CMYK files return RN_EINVAL with a message. */
+int rn_jpeg_info(const void* data, size_t len, int32_t* width, int32_t* height, int32_t* components);
+int rn_jpeg_decode(const void* data, size_t len, uint8_t* rgb_out /* [height,width,3] */, size_t out_bytes);
+int rn_jpeg_idct_islow(const int32_t* coef64 /* dequantized, row-major */, uint8_t* out64);
+
 #ifdef __cplusplus
 }
 #endif

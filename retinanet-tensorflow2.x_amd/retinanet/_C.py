@@ -196,6 +196,9 @@ _SIGNATURES = {
     "rn_comm_destroy": (c_int, [c_void_p]),
     "rn_allreduce_bucket": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "rn_allreduce_small": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    "rn_jpeg_info": (c_int, [c_void_p, c_size_t, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)]),
+    "rn_jpeg_decode": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t]),
+    "rn_jpeg_idct_islow": (c_int, [c_void_p, c_void_p]),
     # host functions (TFRecord input format)
     "rn_crc32c": (c_uint32, [c_void_p, c_size_t]),
     "rn_crc32c_masked": (c_uint32, [c_void_p, c_size_t]),

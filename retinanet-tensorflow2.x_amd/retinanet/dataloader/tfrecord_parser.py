@@ -159,6 +159,20 @@ def _bmp_decode(data):
     return img if top_down else img[::-1]
 
 
+def _jpeg_decode(data):
+    """baseline JPEG -> uint8 [h, w, 3] through the native decoder (csrc/rn_jpeg.hip: libjpeg's islow IDCT, fancy
+    chroma up-sampling and YCbCr tables restated; grayscale replicated like decode_image(channels=3))"""
+    lib = _C.lib()
+    buf = np.frombuffer(data, dtype=np.uint8)
+    w, h, c = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    if lib.rn_jpeg_info(buf.ctypes.data, buf.size, ctypes.byref(w), ctypes.byref(h), ctypes.byref(c)) != 0:
+        raise ImageDecodeError(lib.rn_last_error().decode())
+    out = np.empty((h.value, w.value, 3), np.uint8)
+    if lib.rn_jpeg_decode(buf.ctypes.data, buf.size, out.ctypes.data, out.size) != 0:
+        raise ImageDecodeError(lib.rn_last_error().decode())
+    return out
+
+
 def decode_image(data, channels=3):
     """uint8 [h, w, 3]."""
     if channels != 3:
@@ -168,15 +182,10 @@ def decode_image(data, channels=3):
         return np.ascontiguousarray(_png_decode(data))
     if data[:2] == b"BM":
         return np.ascontiguousarray(_bmp_decode(data))
-    if data[:3] == b"\xff\xd8\xff" or data[:6] in (b"GIF87a", b"GIF89a"):
-        try:
-            import io
-
-            from PIL import Image
-        except ImportError as e:
-            raise ImageDecodeError("JPEG / GIF records need Pillow (not in this image); PNG and BMP are decoded "
-                                   "natively") from e
-        return np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
+    if data[:3] == b"\xff\xd8\xff":
+        return _jpeg_decode(data)
+    if data[:6] in (b"GIF87a", b"GIF89a"):
+        raise ImageDecodeError("GIF records are not decoded by this build (no detection data set ships them)")
     raise ImageDecodeError("unknown image format (tf.io.decode_image: BMP, GIF, JPEG or PNG)")
 
 

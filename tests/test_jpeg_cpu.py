@@ -1,0 +1,333 @@
+"""CPU: the native baseline JPEG decoder (csrc/rn_jpeg.hip) behind `decode_image`.
+
+libjpeg is not available, so the decoder is pinned from the outside: an INDEPENDENT baseline JPEG encoder written here
+(float64 DCT, its own canonical Huffman tables, 4:4:4 / 4:2:2 / 4:2:0 / grayscale, restart intervals) produces the
+files; the entropy stage must recover every quantised coefficient exactly (checked through images whose blocks are
+exactly representable), the islow inverse DCT must stay within one grey level of the float64 inverse DCT
+(IEEE 1180 style), and whole photographs-like images must match a float64 decoding pipeline (float IDCT, triangle
+up-sampling, JFIF colour matrix) within two levels."""
+import heapq
+import struct
+
+import numpy as np
+import pytest
+from scipy.fft import dctn, idctn
+
+from retinanet import _C
+from retinanet.dataloader.tfrecord_parser import ImageDecodeError, decode_image
+
+ZZ = np.array([0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14,
+               21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53,
+               60, 61, 54, 47, 55, 62, 63])
+
+
+# ---- an independent baseline encoder ----------------------------------------------------------------------------
+def _canonical(freq, nsym):
+    """Huffman code lengths (<= 16) from frequencies -> (bits[16], vals, {sym: (code, len)}); flat code if too deep"""
+    syms = [s for s in range(nsym) if freq.get(s, 0) > 0] or [0]
+    if len(syms) == 1:
+        lengths = {syms[0]: 1}
+    else:
+        heap = [(freq[s], i, [s]) for i, s in enumerate(syms)]
+        heapq.heapify(heap)
+        lengths = {s: 0 for s in syms}
+        n = len(heap)
+        while len(heap) > 1:
+            a, b = heapq.heappop(heap), heapq.heappop(heap)
+            for s in a[2] + b[2]:
+                lengths[s] += 1
+            n += 1
+            heapq.heappush(heap, (a[0] + b[0], n, a[2] + b[2]))
+    if max(lengths.values()) > 15 or len(syms) == 1:
+        ln = max(1, int(np.ceil(np.log2(len(syms) + 1))))      # flat code, all-ones code left unused
+        lengths = {s: ln for s in syms}
+    else:   # keep the all-ones code unused (T.81 Annex C): lengthen the longest code by one bit
+        last = max(syms, key=lambda s: (lengths[s], s))
+        lengths[last] += 1
+    order = sorted(syms, key=lambda s: (lengths[s], s))
+    bits = [sum(1 for s in order if lengths[s] == l) for l in range(1, 17)]
+    table, code, prev = {}, 0, lengths[order[0]]
+    for s in order:
+        code <<= lengths[s] - prev
+        prev = lengths[s]
+        table[s] = (code, lengths[s])
+        code += 1
+    return bits, order, table
+
+
+class _BitWriter:
+    def __init__(self):
+        self.out, self.acc, self.n = bytearray(), 0, 0
+
+    def put(self, code, length):
+        self.acc = (self.acc << length) | code
+        self.n += length
+        while self.n >= 8:
+            b = (self.acc >> (self.n - 8)) & 0xFF
+            self.out.append(b)
+            if b == 0xFF:
+                self.out.append(0)
+            self.n -= 8
+        self.acc &= (1 << self.n) - 1
+
+    def flush(self):
+        if self.n:
+            self.put((1 << (8 - self.n)) - 1, 8 - self.n)
+
+
+def _cat(v):
+    return int(abs(v)).bit_length()
+
+
+def _quant_tables(quality):
+    lum = np.array([16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51,
+                    87, 80, 62, 18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120,
+                    101, 72, 92, 95, 98, 112, 100, 103, 99]).reshape(8, 8)
+    chrom = np.full((8, 8), 99)
+    chrom[:4, :4] = [[17, 18, 24, 47], [18, 21, 26, 66], [24, 26, 56, 99], [47, 66, 99, 99]]
+    scale = 5000 / quality if quality < 50 else 200 - 2 * quality
+    f = lambda t: np.clip((t * scale + 50) // 100, 1, 255).astype(np.int64)
+    return f(lum), f(chrom)
+
+
+def encode_jpeg(img, quality=85, sampling=(2, 2), restart=0, coefficients=None):
+    """img uint8 [H,W,3] or [H,W]; returns (bytes, quantised coefficient planes, quant tables, plane geometry)"""
+    gray = img.ndim == 2
+    H, W = img.shape[:2]
+    x = img.astype(np.float64)
+    if gray:
+        planes, samp = [x], [(1, 1)]
+    else:
+        r, g, b = x[..., 0], x[..., 1], x[..., 2]
+        y = 0.299 * r + 0.587 * g + 0.114 * b
+        cb = -0.168735892 * r - 0.331264108 * g + 0.5 * b + 128
+        cr = 0.5 * r - 0.418687589 * g - 0.081312411 * b + 128
+        planes, samp = [y, cb, cr], [sampling, (1, 1), (1, 1)]
+    hmax, vmax = max(s[0] for s in samp), max(s[1] for s in samp)
+    mcux, mcuy = -(-W // (8 * hmax)), -(-H // (8 * vmax))
+    ql, qc = _quant_tables(quality)
+    qcoefs = []
+    for ci, (p, (h, v)) in enumerate(zip(planes, samp)):
+        fx, fy = hmax // h, vmax // v
+        ph, pw = -(-H // fy) * fy, -(-W // fx) * fx
+        p = np.pad(p, ((0, ph - H), (0, pw - W)), mode="edge")
+        p = p.reshape(ph // fy, fy, pw // fx, fx).mean(axis=(1, 3))          # box down-sampling
+        bh, bw = mcuy * v * 8, mcux * h * 8
+        p = np.pad(p, ((0, bh - p.shape[0]), (0, bw - p.shape[1])), mode="edge") - 128.0
+        blocks = p.reshape(bh // 8, 8, bw // 8, 8).transpose(0, 2, 1, 3)
+        q = ql if ci == 0 else qc
+        qcoefs.append(np.round(dctn(blocks, axes=(2, 3), norm="ortho") / q).astype(np.int64))
+    if coefficients is not None:
+        qcoefs = coefficients
+    # symbol statistics -> Huffman tables (one DC + one AC table per class: luma / chroma)
+    def block_symbols(blk, pred):
+        zz = blk.reshape(64)[ZZ]
+        diff = int(zz[0]) - pred
+        out = [("dc", _cat(diff), diff)]
+        run = 0
+        last = max([k for k in range(1, 64) if zz[k] != 0], default=0)
+        for k in range(1, last + 1):
+            if zz[k] == 0:
+                run += 1
+                continue
+            while run > 15:
+                out.append(("ac", 0xF0, 0))
+                run -= 16
+            out.append(("ac", (run << 4) | _cat(zz[k]), int(zz[k])))
+            run = 0
+        if last < 63:
+            out.append(("ac", 0x00, 0))
+        return out, int(zz[0])
+    seq, preds, count = [], [0] * len(planes), 0
+    for my in range(mcuy):
+        for mx in range(mcux):
+            if restart and count and count % restart == 0:
+                seq.append(("rst", (count // restart - 1) % 8, 0, 0))
+                preds = [0] * len(planes)
+            for ci, (h, v) in enumerate(samp):
+                for by in range(v):
+                    for bx in range(h):
+                        syms, preds[ci] = block_symbols(qcoefs[ci][my * v + by, mx * h + bx], preds[ci])
+                        seq += [(k, s, val, 0 if ci == 0 else 1) for k, s, val in syms]
+            count += 1
+    freq = {("dc", 0): {}, ("dc", 1): {}, ("ac", 0): {}, ("ac", 1): {}}
+    for k, s, _, cls in seq:
+        if k != "rst":
+            freq[(k, cls)][s] = freq[(k, cls)].get(s, 0) + 1
+    tables = {key: _canonical(f, 12 if key[0] == "dc" else 256) for key, f in freq.items() if f or key[1] == 0}
+    bw_ = _BitWriter()
+    body = bytearray()
+    for k, s, val, cls in seq:
+        if k == "rst":
+            bw_.flush()
+            body += bw_.out + bytes([0xFF, 0xD0 + s])
+            bw_ = _BitWriter()
+            continue
+        code, ln = tables[(k, cls)][2][s]
+        bw_.put(code, ln)
+        size = s if k == "dc" else s & 15
+        if size:
+            bw_.put(val if val >= 0 else val + (1 << size) - 1, size)
+    bw_.flush()
+    body += bw_.out
+    seg = lambda m, payload: bytes([0xFF, m]) + struct.pack(">H", len(payload) + 2) + payload
+    out = bytearray(b"\xff\xd8") + seg(0xE0, b"JFIF\x00\x01\x01\x00\x00\x01\x00\x01\x00\x00")
+    out += seg(0xDB, bytes([0]) + bytes(ql.reshape(64)[ZZ].tolist()))
+    if not gray:
+        out += seg(0xDB, bytes([1]) + bytes(qc.reshape(64)[ZZ].tolist()))
+    sof = struct.pack(">BHHB", 8, H, W, len(planes))
+    for ci, (h, v) in enumerate(samp):
+        sof += bytes([ci + 1, (h << 4) | v, 0 if ci == 0 else 1])
+    out += seg(0xC0, sof)
+    for (k, cls), (bits, vals, _) in tables.items():
+        out += seg(0xC4, bytes([(0x10 if k == "ac" else 0) | cls]) + bytes(bits) + bytes(vals))
+    if restart:
+        out += seg(0xDD, struct.pack(">H", restart))
+    sos = bytes([len(planes)]) + b"".join(bytes([ci + 1, 0x00 if ci == 0 else 0x11]) for ci in range(len(planes))) + b"\x00\x3f\x00"
+    out += seg(0xDA, sos) + body + b"\xff\xd9"
+    return bytes(out), qcoefs, (ql, qc), (samp, hmax, vmax)
+
+
+def float_decode(qcoefs, qt, geom, H, W):
+    """float64 decoding pipeline: IDCT, triangle ("fancy") chroma up-sampling, JFIF colour matrix"""
+    samp, hmax, vmax = geom
+    planes = []
+    for ci, q in enumerate(qcoefs):
+        pix = idctn(q * (qt[0] if ci == 0 else qt[1]), axes=(2, 3), norm="ortho") + 128.0
+        nby, nbx = pix.shape[:2]
+        p = np.clip(np.round(pix.transpose(0, 2, 1, 3).reshape(nby * 8, nbx * 8)), 0, 255)
+        h, v = samp[ci]
+        dh, dw = -(-H * v // vmax), -(-W * h // hmax)
+        p = p[:dh, :dw]
+        if vmax // v == 2:
+            up, dn = np.vstack([p[:1], p[:-1]]), np.vstack([p[1:], p[-1:]])
+            q2 = np.empty((2 * dh, dw))
+            q2[0::2], q2[1::2] = 0.75 * p + 0.25 * up, 0.75 * p + 0.25 * dn
+            p = q2
+        if hmax // h == 2:
+            lf, rt = np.hstack([p[:, :1], p[:, :-1]]), np.hstack([p[:, 1:], p[:, -1:]])
+            q2 = np.empty((p.shape[0], 2 * p.shape[1]))
+            q2[:, 0::2], q2[:, 1::2] = 0.75 * p + 0.25 * lf, 0.75 * p + 0.25 * rt
+            p = q2
+        planes.append(p[:H, :W])
+    if len(planes) == 1:
+        return np.repeat(np.clip(np.round(planes[0]), 0, 255)[..., None], 3, axis=2)
+    y, cb, cr = planes[0], planes[1] - 128, planes[2] - 128
+    rgb = np.stack([y + 1.402 * cr, y - 0.344136 * cb - 0.714136 * cr, y + 1.772 * cb], axis=-1)
+    return np.clip(np.round(rgb), 0, 255)
+
+
+def _photo(rng, H, W):
+    """smooth structure + edges + a little noise: something with energy in every DCT band"""
+    yy, xx = np.mgrid[0:H, 0:W]
+    base = np.stack([128 + 90 * np.sin(xx / 17.0 + c) * np.cos(yy / 23.0 - c) for c in (0.0, 1.1, 2.3)], axis=-1)
+    base[H // 3:H // 2, W // 4:W // 2] += 60
+    return np.clip(base + rng.normal(0, 6, (H, W, 3)), 0, 255).astype(np.uint8)
+
+
+# ---- tests -------------------------------------------------------------------------------------------------------
+def test_idct_islow_against_float64():
+    lib = _C.lib()
+    rng = np.random.default_rng(0)
+    worst, sq = 0, 0.0
+    for _ in range(400):
+        sparsity = rng.uniform(0.05, 1.0)
+        coef = (rng.integers(-300, 301, (8, 8)) * (rng.uniform(size=(8, 8)) < sparsity)).astype(np.int32)
+        coef[0, 0] = rng.integers(-1000, 1001)
+        out = np.zeros(64, np.uint8)
+        assert lib.rn_jpeg_idct_islow(coef.ctypes.data, out.ctypes.data) == 0
+        ref = idctn(coef.astype(np.float64), norm="ortho") + 128
+        inside = (ref > 0.5) & (ref < 254.5)           # clamped pixels say nothing about the transform
+        err = np.abs(out.reshape(8, 8).astype(np.float64) - ref)[inside]
+        if err.size:
+            worst, sq = max(worst, err.max()), sq + float((err ** 2).mean())
+    assert worst <= 1.0 + 1e-9 and sq / 400 < 0.12         # IEEE 1180: peak error 1, small mean square error
+
+
+@pytest.mark.parametrize("gray,sampling,restart", [(False, (1, 1), 0), (False, (2, 1), 0), (False, (2, 2), 0),
+                                                   (False, (1, 2), 0), (True, (1, 1), 0), (False, (2, 2), 3)])
+def test_entropy_stage_is_exact(gray, sampling, restart):
+    """DC-only blocks with DC a multiple of 8 (and all-ones quantisation tables) are exactly representable after the
+    IDCT (DC / 8 + 128): every decoded pixel must equal its block's level — any slip in Huffman decoding, DC
+    prediction, restart handling or MCU / block ordering shows up as a wrong block.  AC coefficients are checked
+    through the float pipeline in the next test."""
+    rng = np.random.default_rng(3)
+    H, W = 37, 53
+    img = rng.integers(0, 256, (H, W) if gray else (H, W, 3)).astype(np.uint8)
+    _, q, qt, geom = encode_jpeg(img, 90, sampling, restart)
+    coefs = []
+    for ci, c in enumerate(q):
+        z = np.zeros_like(c)
+        qq = qt[0] if ci == 0 else qt[1]
+        levels = rng.integers(-12, 13, c.shape[:2])            # DC = levels * 8 / q00 must be an integer: use q-multiples
+        z[..., 0, 0] = levels * 8
+        coefs.append(z)
+    ones = (np.ones((8, 8), np.int64), np.ones((8, 8), np.int64))
+    data, _, _, _ = encode_jpeg(img, 90, sampling, restart, coefficients=coefs)
+    # the encoder writes its quality-90 tables; rewrite them to all-ones so that DC levels are exact
+    data = bytearray(data)
+    pos = 0
+    while True:
+        pos = data.find(b"\xff\xdb", pos)
+        if pos < 0:
+            break
+        data[pos + 5:pos + 69] = bytes([1] * 64)
+        pos += 69
+    got = decode_image(bytes(data)).astype(np.int64)
+    want = float_decode(coefs, ones, geom, H, W).astype(np.int64)
+    if gray:
+        np.testing.assert_array_equal(got, want)              # flat blocks, no colour conversion: exact
+    elif sampling == (1, 1):
+        assert np.abs(got - want).max() <= 1                   # + the fixed-point colour matrix
+    else:
+        assert np.abs(got - want).max() <= 2                   # + the integer triangle filter on the chroma planes
+
+
+@pytest.mark.parametrize("sampling,restart,quality,size", [((1, 1), 0, 92, (64, 48)), ((2, 1), 0, 85, (61, 83)),
+                                                           ((2, 2), 0, 85, (75, 101)), ((1, 2), 0, 80, (40, 33)),
+                                                           ((2, 2), 5, 70, (97, 64)), ((2, 2), 0, 35, (128, 128))])
+def test_whole_images_against_float_pipeline(sampling, restart, quality, size):
+    rng = np.random.default_rng(11)
+    img = _photo(rng, *size)
+    data, q, qt, geom = encode_jpeg(img, quality, sampling, restart)
+    got = decode_image(data)
+    assert got.shape == img.shape and got.dtype == np.uint8
+    want = float_decode(q, qt, geom, *size)
+    err = np.abs(got.astype(np.float64) - want)
+    assert err.max() <= 3 and err.mean() < 0.6, (err.max(), err.mean())
+    psnr = 10 * np.log10(255 ** 2 / np.mean((got.astype(np.float64) - img) ** 2))
+    assert psnr > (30 if quality >= 70 else 24), psnr
+
+
+def test_grayscale_and_errors():
+    rng = np.random.default_rng(5)
+    g = _photo(rng, 50, 70)[..., 1]
+    data, q, qt, geom = encode_jpeg(g, 90)
+    got = decode_image(data)
+    assert got.shape == (50, 70, 3) and (got[..., 0] == got[..., 1]).all() and (got[..., 1] == got[..., 2]).all()
+    assert np.abs(got[..., 0].astype(np.float64) - float_decode(q, qt, geom, 50, 70)[..., 0]).max() <= 1
+    import ctypes
+    lib = _C.lib()
+    w, h, c = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    buf = np.frombuffer(data, np.uint8)
+    assert lib.rn_jpeg_info(buf.ctypes.data, buf.size, ctypes.byref(w), ctypes.byref(h), ctypes.byref(c)) == 0
+    assert (w.value, h.value, c.value) == (70, 50, 1)
+    prog = data.replace(b"\xff\xc0", b"\xff\xc2", 1)            # SOF2: progressive -> refused, with a message
+    with pytest.raises(ImageDecodeError, match="progressive"):
+        decode_image(prog)
+    with pytest.raises(ImageDecodeError):
+        decode_image(data[:len(data) // 2].replace(b"\xff\xda", b"\xff\xfe"))   # no scan
+    with pytest.raises(ImageDecodeError):
+        decode_image(b"\xff\xd8\xff\xe0\x00\x02")
+
+
+def test_jpeg_record_through_parse_example():
+    from retinanet.dataloader.tfrecord_parser import parse_example
+    from retinanet.dataset_utils.tfrecord_writer import serialize_example
+    rng = np.random.default_rng(9)
+    img = _photo(rng, 48, 64)
+    data, _, _, _ = encode_jpeg(img, 90, (2, 2))
+    rec = serialize_example(data, [[0.1, 0.2, 0.6, 0.7]], [17], 42)
+    s = parse_example(rec)
+    assert s["image"].shape == (48, 64, 3) and s["image"].dtype == np.float32 and s["image_id"] == 42
+    np.testing.assert_array_equal(s["image"], decode_image(data).astype(np.float32))
