@@ -149,7 +149,9 @@ def test_command_lines_and_export_signatures(trained, cuda, tmp_path):
     os.chdir(tmp_path)
     try:
         ex_eval = cli_main(["--config_path", str(cfg), "--run_evaluation", "--global_seed=3"])
-        assert ex_eval.run_mode == "val" and int(ex_eval.optimizer.iterations) == 3
+        from retinanet import tf_checkpoint
+        latest = tf_checkpoint.latest_checkpoint(os.path.join(p.experiment.model_dir, p.experiment.name))
+        assert ex_eval.run_mode == "val" and int(ex_eval.optimizer.iterations) == int(latest.rsplit("_", 1)[1])
         # python -m retinanet.export --mode tf --export_saved_model --export_checkpoint
         out_dir = tmp_path / "export"
         export.main(["--config_path", str(cfg), "--mode", "tf", "--export_dir", str(out_dir), "--export_saved_model",
@@ -158,7 +160,7 @@ def test_command_lines_and_export_signatures(trained, cuda, tmp_path):
         os.chdir(cwd)
     sm_dir = out_dir / "tiny" / "tf"
     assert (out_dir / "tiny" / "config.json").exists() and (sm_dir / "weights.safetensors").exists()
-    assert (out_dir / "tiny" / "final_weights_step_3.index").exists()
+    assert (out_dir / "tiny" / (os.path.basename(latest) + ".index")).exists()
     spec = json.load(open(sm_dir / "signatures.json"))["signatures"]
     assert spec["serving_default"]["inputs"]["image"]["shape"] == [2, SIZE, SIZE, 3]
     assert spec["serving_default"]["outputs"]["boxes"]["shape"] == [2, 100, 4]
@@ -175,9 +177,11 @@ def test_command_lines_and_export_signatures(trained, cuda, tmp_path):
     # the export holds the MOVING AVERAGES (use_moving_average: true) — same detections as the EMA weights served directly
     b = ModelBuilder(p, "val", device=cuda)
     m = b()
-    ex._engine.store_to_model(use_ema=True)
-    m.set_weights(ex.model.get_weights())
-    ex._engine.store_to_model(use_ema=False)
+    slots = m.load_weights(latest)
+    for (var, slot), arr in slots.items():
+        if slot == "average":
+            m.variables[var].copy_(torch.as_tensor(np.asarray(arr)).reshape(m.variables[var].shape))
+    m._refresh()
     ref = b.add_post_processing_stage(m)(batch.to(cuda))
     for k in ("boxes", "scores", "classes", "valid_detections"):
         torch.testing.assert_close(det[k], ref[k], rtol=0, atol=0)

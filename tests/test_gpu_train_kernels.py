@@ -375,12 +375,14 @@ def test_optimizer_step(cuda):
     bs_d = torch.tensor(block_seg, dtype=torch.int32, device=cuda)
     wdv, gd, vd, ed = w.to(cuda), gr.to(cuda), v.to(cuda), ema.to(cuda)
     bf = torch.zeros((total,), dtype=torch.bfloat16, device=cuda)
-    metrics = torch.zeros((4,), dtype=torch.float32, device=cuda)
+    metrics = torch.zeros((8,), dtype=torch.float32, device=cuda)
     ws = _ws(lib.rn_optim_workspace_bytes(len(block_seg), len(sizes)), cuda)
     alpha, R, clip, lr, mom, dec = 1e-4, 4, 10.0, 0.1, 0.9, 0.5
     st = _C.current_stream()
+    loss_scale = 1024.0        # LossScaleOptimizer: the gradients arrive scaled, the kernel unscales them first
+    gd.mul_(loss_scale)
     _C.check(lib.rn_optim_clip(_C.ptr(gd), _C.ptr(wdv), _C.ptr(segs_d), len(sizes), _C.ptr(bs_d), len(block_seg),
-                               alpha / R, clip, _C.ptr(metrics), _C.ptr(ws), ws.numel(), st))
+                               alpha / R, alpha, 1.0 / loss_scale, clip, _C.ptr(metrics), _C.ptr(ws), ws.numel(), st))
     torch.cuda.synchronize()
     # reference (executor.py:401-407 on float64)
     gs, ws64 = gr.double(), w.double()
@@ -394,8 +396,25 @@ def test_optimizer_step(cuda):
     torch.testing.assert_close(gd.cpu().double(), want_g, rtol=1e-5, atol=1e-7)
     assert metrics[1].item() == pytest.approx(gn, rel=1e-5)
     assert metrics[0].item() == pytest.approx(min(gn, clip), rel=1e-5)
+    l2 = sum(alpha * 0.5 * float((ws64[offs[i]:offs[i] + n] ** 2).sum()) for i, n in enumerate(sizes) if wd[i])
+    assert metrics[3].item() == pytest.approx(l2, rel=1e-5)          # l2-regularization (executor.py:296-299)
+    assert metrics[4].item() == 1.0 and metrics[5].item() == 0.0    # a clip factor fired; gradients finite
+    # a dropped step (skip flag set): nothing moves
+    flag = torch.ones((1,), dtype=torch.float32, device=cuda)
     _C.check(lib.rn_optim_sgd_step(_C.ptr(wdv), _C.ptr(gd), _C.ptr(vd), _C.ptr(ed), _C.ptr(bf), _C.ptr(segs_d),
-                                   _C.ptr(bs_d), len(block_seg), lr, mom, dec, st))
+                                   _C.ptr(bs_d), len(block_seg), lr, mom, dec, 0, _C.ptr(flag), st))
+    torch.cuda.synchronize()
+    assert torch.equal(wdv.cpu(), w) and torch.equal(vd.cpu(), v)
+    # Keras SGD with nesterov=True on a copy: w += m*v_new - lr*g
+    wn, vn = w.to(cuda).clone(), v.to(cuda).clone()
+    _C.check(lib.rn_optim_sgd_step(_C.ptr(wn), _C.ptr(gd), _C.ptr(vn), None, _C.ptr(bf), _C.ptr(segs_d),
+                                   _C.ptr(bs_d), len(block_seg), lr, mom, 0.0, 1, None, st))
+    torch.cuda.synchronize()
+    vnew = mom * v.double() - lr * want_g
+    torch.testing.assert_close(wn.cpu().double(), w.double() + mom * vnew - lr * want_g, rtol=1e-5, atol=1e-6)
+    flag.zero_()
+    _C.check(lib.rn_optim_sgd_step(_C.ptr(wdv), _C.ptr(gd), _C.ptr(vd), _C.ptr(ed), _C.ptr(bf), _C.ptr(segs_d),
+                                   _C.ptr(bs_d), len(block_seg), lr, mom, dec, 0, _C.ptr(flag), st))
     torch.cuda.synchronize()
     v2 = mom * v.double() - lr * want_g
     w2 = w.double() + v2
@@ -407,6 +426,12 @@ def test_optimizer_step(cuda):
         got = bf[offs[i]:offs[i] + n].float().cpu()
         want = w2[offs[i]:offs[i] + n].float().to(torch.bfloat16).float() if wd[i] else torch.zeros(n)
         torch.testing.assert_close(got, want, rtol=1 / 128, atol=1e-3)
+    # non-finite gradients: flagged, so that the caller can drop the step and halve the loss scale
+    gd[5] = float("inf")
+    _C.check(lib.rn_optim_clip(_C.ptr(gd), _C.ptr(wdv), _C.ptr(segs_d), len(sizes), _C.ptr(bs_d), len(block_seg),
+                               alpha / R, alpha, 1.0, clip, _C.ptr(metrics), _C.ptr(ws), ws.numel(), st))
+    torch.cuda.synchronize()
+    assert metrics[5].item() == 1.0
 
 
 @pytest.mark.parametrize("N,H,W,C,Ho,Wo", [(2, 5, 7, 16, 10, 14), (1, 4, 3, 64, 7, 5), (3, 8, 8, 8, 16, 16)])

@@ -274,10 +274,17 @@ def test_train_step_losses_and_optimizer_arithmetic(cuda):
         torch.testing.assert_close(eng.V[off:off + n].double().cpu(), v1, rtol=1e-4, atol=1e-7)
         torch.testing.assert_close(eng.P[off:off + n].double().cpu(), w1, rtol=1e-5, atol=1e-6)
         torch.testing.assert_close(eng.E[off:off + n].double().cpu(), e1, rtol=1e-5, atol=1e-6)
-        if k.endswith("/kernel"):   # bf16 compute copy refreshed by the same kernel
+        if k.endswith("/kernel") and k[:-len("/kernel")] in eng.bf_off:   # bf16 compute copy refreshed by the same kernel
             cname = k[:-len("/kernel")]
             bf = eng.Pbf[eng.bf_off[cname]:eng.bf_off[cname] + n].float().cpu()
             torch.testing.assert_close(bf, w1.float().to(torch.bfloat16).float(), rtol=1 / 128, atol=1e-6)
+    # the float32 prediction kernels are re-split into bf16 planes after the step: hi + lo = w to 16 mantissa bits
+    for cname, buf in eng.split_pack_of.items():
+        c = eng.g.convs[cname]
+        off, n = eng.p_off[cname + "/kernel"]
+        wm = eng.P[off:off + n].reshape(c["cout"], c["k"], c["k"], c["cin"]).double().cpu()
+        planes = buf[:c["cout"]].double().cpu().reshape(c["cout"], c["k"], c["k"], -1, buf.shape[-1] // 2)
+        torch.testing.assert_close(planes.sum(dim=3)[..., :c["cin"]], wm, rtol=2.0 ** -15, atol=1e-9)
     bn = next(iter(eng.bn_state))   # moving statistics of a live BN layer (momentum 0.99, Bessel-corrected)
     torch.testing.assert_close(eng.bn_state[bn]["mm"].cpu().double(), ref.new_stats[bn + "/moving_mean"], rtol=0.02, atol=2e-3)
     torch.testing.assert_close(eng.bn_state[bn]["mv"].cpu().double(), ref.new_stats[bn + "/moving_variance"], rtol=0.02, atol=2e-3)
