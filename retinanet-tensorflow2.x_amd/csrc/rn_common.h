@@ -39,8 +39,10 @@ __device__ __forceinline__ uint16_t rn_f32_to_bf16(float f) {
   u += 0x7fffu + ((u >> 16) & 1u);
   return (uint16_t)(u >> 16);
 }
-// round to bf16 and back: where the reference materialises a bf16 tensor between two layers
-__device__ __forceinline__ float rn_rb(float v) { return rn_bf16_to_f32(rn_f32_to_bf16(v)); }
+// round to bf16 and back: where the reference materialises a bf16 tensor between two layers.  The hardware
+// conversion (v_cvt_pk_bf16_f32, round to nearest even — the same values as rn_f32_to_bf16 for every finite input)
+// instead of the ~6-instruction integer sequence: the 128-row conv epilogue applies it to every accumulator.
+__device__ __forceinline__ float rn_rb(float v) { return (float)(__bf16)v; }
 __device__ __forceinline__ uint32_t rn_pack_bf16x2(float lo, float hi) {
   return (uint32_t)rn_f32_to_bf16(lo) | ((uint32_t)rn_f32_to_bf16(hi) << 16);
 }

@@ -391,7 +391,7 @@ static bool conv_use_halo(const rn_conv_problem* p) {
   if (p->R != 3 || p->S != 3 || p->stride_h != 1 || p->stride_w != 1 || p->pad_top != 1 || p->pad_left != 1)
     return false;
   static std::mutex mu;
-  static std::map<std::tuple<int, int, int>, int> patch_px;   // (N, H, W) -> worst patch, computed once
+  static std::map<std::tuple<int, int, int, int>, int> patch_px;   // (N, H, W, pitch) -> worst patch, computed once
   for (int i = 0; i < p->num_segments; ++i) {
     const rn_conv_segment& s = p->seg[i];
     if (s.Ho != s.H || s.Wo != s.W || s.Cin % 32 != 0) return false;
@@ -399,10 +399,14 @@ static bool conv_use_halo(const rn_conv_problem* p) {
     int px;
     {
       std::lock_guard<std::mutex> lock(mu);
-      auto key = std::make_tuple(s.N, s.H, s.W);
-      auto it = patch_px.find(key);
-      if (it == patch_px.end()) it = patch_px.emplace(key, rn_conv_halo_patch_pixels(s.N, s.H, s.W)).first;
-      px = it->second;
+      // the wide pitch when its patch fits, else the tight one (the kernel is told per segment: halo_pitch)
+      for (int pitch : {rn_conv_halo_pitch(s.W), s.W + 1}) {
+        auto key = std::make_tuple(s.N, s.H, s.W, pitch);
+        auto it = patch_px.find(key);
+        if (it == patch_px.end()) it = patch_px.emplace(key, rn_conv_halo_patch_pixels(s.N, s.H, s.W, pitch)).first;
+        px = it->second;
+        if (px <= rn_conv_halo_capacity()) break;
+      }
     }
     if (px > rn_conv_halo_capacity()) return false;
   }
@@ -472,7 +476,9 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
     RN_CHECK_ARG(terms <= 3, "rn_conv2d_nhwc_fwd: segment %d w_terms=%d (1..3)", i, s.w_terms);
     d.cwrap = rn_conv_cin_pad(s.Cin);
     d.CinP = terms * d.cwrap;
-    d.pad2_ = 0;
+    d.halo_pitch = s.W + 1;
+    if (rn_conv_halo_patch_pixels(s.N, s.H, s.W, rn_conv_halo_pitch(s.W)) <= rn_conv_halo_capacity())
+      d.halo_pitch = rn_conv_halo_pitch(s.W);
     tiles += (int)rn_cdiv(M, BM) * d.n_tiles;
   }
   a.total_tiles = tiles;

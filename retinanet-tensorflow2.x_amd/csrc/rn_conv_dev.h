@@ -20,7 +20,8 @@ struct ConvSegDev {
   const float* bias;   // Conv2D bias, added to the fp32 accumulator (rnet_hip.h: epilogue)
   int N, H, W, Cin, pix_stride, Ho, Wo, Cout;
   int M, tile_begin, n_tiles, CinP;  // CinP = K extent per tap = w_terms * (Cin rounded up to the K step)
-  int cwrap, pad2_;                  // input channels wrap at cwrap (= CinP / w_terms): split-bf16 weight planes
+  int cwrap, halo_pitch;             // input channels wrap at cwrap (= CinP / w_terms): split-bf16 weight planes;
+                                     // halo kernel: patch pixels per image row (W + 1, or that rounded up to 8)
 };
 
 
@@ -55,6 +56,7 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wav
 int rn_launch_conv_big(const ConvArgs& a, bool out_f32, hipStream_t st);
 // rn_conv_halo.hip (3x3 / stride 1 / pad 1)
 int rn_launch_conv_halo(const ConvArgs& a, bool out_f32, hipStream_t st);
-int rn_conv_halo_patch_pixels(int N, int H, int W);
+int rn_conv_halo_patch_pixels(int N, int H, int W, int pitch);
+int rn_conv_halo_pitch(int W);
 int rn_conv_halo_capacity();
 #endif  // RN_CONV_DEV_H_

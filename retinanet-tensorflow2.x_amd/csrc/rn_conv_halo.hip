@@ -59,7 +59,7 @@ constexpr int LDS_BYTES = SEG_TABLE + 16 * 4 + RN_CONV_MAX_SEGMENTS * 64;   // 8
 struct HaloSeg {
   const uint16_t* x;
   const uint16_t* w;
-  int N, H, W, pix_stride, Cout, M, tile_begin, n_tiles, CinP, cwrap;
+  int N, H, W, pix_stride, Cout, M, tile_begin, n_tiles, CinP, cwrap, pitch;
 };
 // layout: 16 dwords of tile_begin (INT_MAX past the last segment), then 16 dwords per segment
 __device__ __forceinline__ void halo_seg_table_fill(char* smem, const ConvArgs& args, int tid) {
@@ -72,7 +72,7 @@ __device__ __forceinline__ void halo_seg_table_fill(char* smem, const ConvArgs& 
     d[0] = (unsigned)px; d[1] = (unsigned)(px >> 32); d[2] = (unsigned)pw; d[3] = (unsigned)(pw >> 32);
     d[4] = g.N; d[5] = g.H; d[6] = g.W; d[7] = g.pix_stride;
     d[8] = g.Cout; d[9] = g.M; d[10] = g.tile_begin; d[11] = g.n_tiles;
-    d[12] = g.CinP; d[13] = g.cwrap; d[14] = 0; d[15] = 0;
+    d[12] = g.CinP; d[13] = g.cwrap; d[14] = g.halo_pitch; d[15] = 0;
   }
 }
 __device__ __forceinline__ int halo_seg_of_tile(const char* smem, int tile) {
@@ -91,7 +91,7 @@ __device__ __forceinline__ HaloSeg halo_seg(const char* smem, int si) {
   g.w = (const uint16_t*)(((unsigned long long)HALO_U(q0.w) << 32) | HALO_U(q0.z));
   g.N = (int)HALO_U(q1.x); g.H = (int)HALO_U(q1.y); g.W = (int)HALO_U(q1.z); g.pix_stride = (int)HALO_U(q1.w);
   g.Cout = (int)HALO_U(q2.x); g.M = (int)HALO_U(q2.y); g.tile_begin = (int)HALO_U(q2.z); g.n_tiles = (int)HALO_U(q2.w);
-  g.CinP = (int)HALO_U(q3.x); g.cwrap = (int)HALO_U(q3.y);
+  g.CinP = (int)HALO_U(q3.x); g.cwrap = (int)HALO_U(q3.y); g.pitch = (int)HALO_U(q3.z);
 #undef HALO_U
   return g;
 }
@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
     const HaloSeg sg__ = halo_seg(smem, si__);                                                        \
     const int lt__ = tile__ - sg__.tile_begin;                                                        \
     const int m0__ = rn_fdiv(lt__, sg__.n_tiles, __frcp_rn((float)sg__.n_tiles)) * BM;                \
-    const int H__ = sg__.H, W__ = sg__.W, PS__ = sg__.pix_stride, W1__ = W__ + 1, H1__ = H__ + 1;     \
+    const int H__ = sg__.H, W__ = sg__.W, PS__ = sg__.pix_stride, W1__ = sg__.pitch, H1__ = H__ + 1;  \
     const int HW__ = H__ * W__;                                                                       \
     p_nch = sg__.CinP / BK;                                                                           \
     p_wrap = sg__.cwrap / BK;                                                                         \
@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
     c_nch = sg__.CinP / BK;                                                                           \
     c_chunk = 0;                                                                                      \
     const int H__ = sg__.H, W__ = sg__.W, H1__ = H__ + 1, HW__ = H__ * W__;                           \
-    c_W1 = W__ + 1;                                                                                   \
+    c_W1 = sg__.pitch;                                                                                \
     const float rHW__ = __frcp_rn((float)HW__), rW__ = __frcp_rn((float)W__);                         \
     const int nf__ = rn_fdiv(c_m0, HW__, rHW__);                                                      \
     const int Gf__ = nf__ * H1__ + rn_fdiv(c_m0 - nf__ * HW__, W__, rW__) + 1;                        \
@@ -476,7 +476,15 @@ int rn_launch_conv_halo(const ConvArgs& a, bool out_f32, hipStream_t st) {
 // patch pixels the worst tile of an [N, H, W] tensor needs (rows from one above its first pixel row to one below
 // its last in the shared-pad numbering, W + 1 apart, + the closing zero pixel); the caller compares it with the
 // kernel's capacity
-int rn_conv_halo_patch_pixels(int N, int H, int W) {
+// Patch pixels per image row.  W + 1 = the shared zero column; rounded up to a multiple of 8 pixels (8 x 16 B = one
+// 128-byte bank row per plane) a fragment of 32 consecutive output pixels that crosses a row seam shifts by whole
+// bank rows instead of one 16-byte slot, so ds_read_b128's lane groups stay conflict free (17 % of the LDS cycles were
+// bank conflicts at the seams: profiles/r01_pmc_train_b32_lds_conflicts.csv) — when the wider patch still fits.
+static int g_halo_pitch_mode = 1;
+extern "C" void rn_debug_conv_halo_pitch(int mode) { g_halo_pitch_mode = mode; }   // 0: W + 1 (A/B timing)
+int rn_conv_halo_pitch(int W) { return g_halo_pitch_mode ? (W + 1 + 7) / 8 * 8 : W + 1; }
+
+int rn_conv_halo_patch_pixels(int N, int H, int W, int pitch) {
   const long long M = (long long)N * H * W, HW = (long long)H * W;
   long long worst = 0;
   for (long long m0 = 0; m0 < M; m0 += BM) {
@@ -485,6 +493,6 @@ int rn_conv_halo_patch_pixels(int N, int H, int W) {
     const long long Gf = nf * (H + 1) + (m0 - nf * HW) / W + 1, Gl = nl * (H + 1) + (ml - nl * HW) / W + 1;
     worst = worst > Gl - Gf + 3 ? worst : Gl - Gf + 3;
   }
-  return (int)(worst * (W + 1) + 1);
+  return (int)(worst * pitch + 1);
 }
 int rn_conv_halo_capacity() { return PIX_PX; }

@@ -142,7 +142,7 @@ def test_command_lines_and_export_signatures(trained, cuda, tmp_path):
     from retinanet.dataloader.preprocessing_pipeline import PreprocessingPipeline
     from retinanet.model import ModelBuilder
     src, p, ex, _ = trained
-    cfg = tmp_path / "tiny.json"
+    cfg = tmp_path / "config_tiny.json"      # (the evaluator dumps its predictions to <experiment.name>.json in the cwd)
     cfg.write_text(json.dumps(p))
     # python -m retinanet --config_path ... --run_evaluation : evaluation only, from the latest checkpoint
     cwd = os.getcwd()
