@@ -476,11 +476,13 @@ int rn_launch_conv_halo(const ConvArgs& a, bool out_f32, hipStream_t st) {
 // patch pixels the worst tile of an [N, H, W] tensor needs (rows from one above its first pixel row to one below
 // its last in the shared-pad numbering, W + 1 apart, + the closing zero pixel); the caller compares it with the
 // kernel's capacity
-// Patch pixels per image row.  W + 1 = the shared zero column; rounded up to a multiple of 8 pixels (8 x 16 B = one
-// 128-byte bank row per plane) a fragment of 32 consecutive output pixels that crosses a row seam shifts by whole
-// bank rows instead of one 16-byte slot, so ds_read_b128's lane groups stay conflict free (17 % of the LDS cycles were
-// bank conflicts at the seams: profiles/r01_pmc_train_b32_lds_conflicts.csv) — when the wider patch still fits.
-static int g_halo_pitch_mode = 1;
+// Patch pixels per image row: W + 1 (the shared zero column).  Mode 1 rounds it up to a multiple of 8 pixels (8 x 16 B =
+// one 128-byte bank row per plane), so that a fragment of 32 consecutive output pixels that crosses a row seam
+// shifts by whole bank rows and ds_read_b128's lane groups stay conflict free (17 % of the LDS cycles are bank
+// conflicts at the seams: profiles/r01_pmc_train_b32_lds_conflicts.csv).  Measured (tools/ab_halo_pitch.py, same box,
+// alternating runs): the training step is 0.6 % SLOWER with it (34.87 / 34.96 ms -> 35.11 / 35.13 ms) — the 9 % more
+// patch bytes through the LDS-DMA cost more than the conflicts did — so the tight pitch stays the default.
+static int g_halo_pitch_mode = 0;
 extern "C" void rn_debug_conv_halo_pitch(int mode) { g_halo_pitch_mode = mode; }   // 0: W + 1 (A/B timing)
 int rn_conv_halo_pitch(int W) { return g_halo_pitch_mode ? (W + 1 + 7) / 8 * 8 : W + 1; }
 

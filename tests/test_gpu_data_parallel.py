@@ -160,3 +160,37 @@ def test_overlapped_allreduce_equals_the_plain_order(cuda):
     np.testing.assert_array_equal(out[0]["overlapped_clip"]["P"], out[1]["overlapped_clip"]["P"])
     lo, hi = sorted(out[r]["plain"]["norm_before_clip"] for r in (0, 1))
     assert lo < out[0]["clipnorm"] < hi
+
+
+def _worker_native_comm(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, PKG)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
+    from retinanet.comm import NativeComm
+    dev = torch.device("cuda:0")
+    comm = NativeComm(rank, world, dev)
+    x = torch.arange(5000, dtype=torch.float32, device=dev) * 0.25
+    want = x.clone()
+    with torch.cuda.device(dev):
+        comm.all_reduce_small(x[:4099])
+        y = torch.randn((1 << 20,), device=dev).to(torch.bfloat16)
+        y0 = y.clone()
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):             # a collective is enqueued on the CALLER'S stream
+            comm.all_reduce_bucket(y)
+        torch.cuda.synchronize()
+    out[rank] = bool(torch.equal(x, want)) and bool(torch.equal(y, y0))
+    comm.close()
+    dist.destroy_process_group()
+
+
+def test_native_comm_single_rank_plumbing(cuda):
+    """rn_comm over RCCL with ONE rank (all a one-GPU box can run): dlopen of librccl, the unique-id hand-off through
+    torch.distributed, ncclCommInitRank, all-reduces on the current and on a side stream — a sum over one rank is the
+    identity.  (Two ranks need two GPUs: RCCL refuses two ranks on one device.)"""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_native_comm, args=(1, _free_port(), out), nprocs=1, join=True)
+    assert out[0] is True
