@@ -286,8 +286,12 @@ int rn_pack_conv_weight_dgrad(const float* w_ohwi, int R, int S, int Cin, int Co
 #define RN_DGRAD_PACK_MAX 64
 typedef struct {
   const float* w_ohwi; /* f32 master [Cout][R][S][Cin] */
-  void* w_packed;      /* bf16 [cout_pad(Cin)][R][S][Cout_pad] */
-  int32_t R, S, Cin, Cout, Cout_pad, pad_;
+  void* w_packed;      /* bf16 [cout_pad(Cin)][R][S][Cout_pad];  pad_ == 1: bf16 [cout_pad(4*Cin)][2][2][Cout_pad] */
+  int32_t R, S, Cin, Cout, Cout_pad;
+  int32_t pad_;        /* 0: the form above.  1: sub-pixel form of a 3x3 / stride 2 / pad 1 layer (even input size): the data
+                        * gradient is rn_conv2d_nhwc_fwd on dy with R = S = 2, stride 1, pad 0, output size = dy's size,
+                        * 4*Cin output channels (phase (a,b) of dx[2i+a][2j+b] in channels (a*2+b)*Cin ..), followed by
+                        * rn_depth_to_space2x: 16 tap products per dy pixel instead of 36 for the zero-upsampled form. */
 } rn_dgrad_pack;
 int rn_pack_conv_weight_dgrad_batch(const rn_dgrad_pack* items /* host */, int n, void* stream);
 /* f32 [P,C] -> bf16 [P,Cpad], zero padded channels (dy of the 36/720-channel prediction convs is
@@ -299,6 +303,8 @@ int rn_upsample_zero2x(const void* x, void* y, int N, int H, int W, int C, int H
  * accumulate = 1 adds in fp32 and rounds once, touching only the even positions.  Data gradient of a 1x1 / stride-2
  * convolution (the ResNet projection shortcuts): the GEMM runs on dy at the low resolution. */
 int rn_scatter_add2x(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, int accumulate, void* stream);
+/* y[n, 2i+a, 2j+b, c] (+)= x[n, i, j, (a*2+b)*C + c]; x bf16 [N,H,W,4C], y bf16 [N,2H,2W,C] */
+int rn_depth_to_space2x(const void* x, void* y, int N, int H, int W, int C, int accumulate, void* stream);
 int rn_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
 /* dy = dz * act'(z) for a layer with an activation but no BatchNorm in front */
 int rn_act_bwd(const void* dz, const void* z, void* dy, int64_t n, int act, void* stream);

@@ -269,8 +269,37 @@ struct DgradPackArgs {
   int n;
   rn_dgrad_pack item[RN_DGRAD_PACK_MAX];
 };
+// Sub-pixel form of the data gradient of a 3x3 / stride 2 / pad 1 convolution (rn_dgrad_pack.pad_ == 1): dx at
+// (2i + a, 2j + b) only sees filter rows r with r = a + 1 - 2(oy - i): phase a = 0 -> r = 1 at dy row i; phase
+// a = 1 -> r = 2 at row i and r = 0 at row i + 1 (columns alike).  All four phases share the 2 x 2 window
+// {i, i+1} x {j, j+1} of dy, so the whole gradient is ONE stride-1 2x2 convolution of dy with 4 * Cin output channels
+// (phase-major) followed by a depth-to-space — 16 tap-channel products per dy pixel instead of the 36 of the
+// zero-upsampled form (9 carry data).  Packed bf16 [cout_pad(4*Cin)][2][2][Cout_pad]; row n = (a*2 + b)*Cin + ci.
+__device__ __forceinline__ float dgrad_s2_weight(const float* __restrict__ w, int Cin, int Cout, int n, int u, int v, int co) {
+  if (n >= 4 * Cin || co >= Cout) return 0.0f;
+  const int ph = n / Cin, ci = n - ph * Cin, a = ph >> 1, b = ph & 1;
+  const int r = a == 0 ? (u == 0 ? 1 : -1) : (u == 0 ? 2 : 0);
+  const int s = b == 0 ? (v == 0 ? 1 : -1) : (v == 0 ? 2 : 0);
+  if (r < 0 || s < 0) return 0.0f;
+  return w[(((long long)co * 3 + r) * 3 + s) * Cin + ci];
+}
+
 __global__ void __launch_bounds__(256) pack_dgrad_batch_kernel(const DgradPackArgs a) {
   const rn_dgrad_pack& it = a.item[blockIdx.y];
+  if (it.pad_ == 1) {
+    const int Cin = it.Cin, Cout = it.Cout, Cout_pad = it.Cout_pad;
+    const int rows = 4 * Cin <= 64 ? 64 : ((4 * Cin + 127) / 128) * 128;
+    const long long total = (long long)rows * 4 * Cout_pad;
+    uint16_t* __restrict__ out = (uint16_t*)it.w_packed;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+      const int co = (int)(i % Cout_pad);
+      const long long t = i / Cout_pad;
+      const int v = (int)(t & 1), u = (int)((t >> 1) & 1), n = (int)(t >> 2);
+      out[i] = rn_f32_to_bf16(dgrad_s2_weight(it.w_ohwi, Cin, Cout, n, u, v, co));
+    }
+    return;
+  }
   const int R = it.R, S = it.S, Cin = it.Cin, Cout = it.Cout, Cout_pad = it.Cout_pad;
   const int Cin_pad = Cin <= 64 ? 64 : ((Cin + 127) / 128) * 128;   // rn_conv_cout_pad(Cin)
   const long long total = (long long)Cin_pad * R * S * Cout_pad;
@@ -299,8 +328,11 @@ extern "C" int rn_pack_conv_weight_dgrad_batch(const rn_dgrad_pack* items, int n
       const rn_dgrad_pack& it = items[base + i];
       RN_CHECK_ARG(it.w_ohwi && it.w_packed && it.R > 0 && it.S > 0 && it.Cin > 0 && it.Cout > 0 &&
                        it.Cout_pad >= it.Cout, "rn_pack_conv_weight_dgrad_batch: bad item %d", base + i);
+      RN_CHECK_ARG(it.pad_ == 0 || (it.pad_ == 1 && it.R == 3 && it.S == 3),
+                   "rn_pack_conv_weight_dgrad_batch: item %d: the sub-pixel form is for 3x3 kernels", base + i);
       a.item[i] = it;
-      const long long total = (long long)rn_conv_cout_pad(it.Cin) * it.R * it.S * it.Cout_pad;
+      const long long total = it.pad_ == 1 ? (long long)rn_conv_cout_pad(4 * it.Cin) * 4 * it.Cout_pad
+                                           : (long long)rn_conv_cout_pad(it.Cin) * it.R * it.S * it.Cout_pad;
       if (total > most) most = total;
     }
     const int bx = (int)(rn_cdiv(most, 256) < 256 ? rn_cdiv(most, 256) : 256);

@@ -631,6 +631,41 @@ extern "C" int rn_scatter_add2x(const void* x, void* y, int N, int H, int W, int
   return RN_OK;
 }
 
+// depth-to-space by 2: y[n, 2i + a, 2j + b, c] (+)= x[n, i, j, (a*2 + b)*C + c] — puts the four phases of the
+// sub-pixel stride-2 data gradient (rn_dgrad_pack.pad_ == 1) in place; accumulate adds in fp32, one rounding
+__global__ void __launch_bounds__(TR_THREADS)
+depth_to_space2x_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int N, int H, int W, int C8, int accumulate) {
+  const long long total = (long long)N * H * W * 4 * C8;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C8);
+    long long t = i / C8;
+    const int ph = (int)(t & 3);
+    t >>= 2;
+    const int w = (int)(t % W);
+    t /= W;
+    const int h = (int)(t % H);
+    const int n = (int)(t / H);
+    const long long o = (((long long)n * 2 * H + 2 * h + (ph >> 1)) * 2 * W + 2 * w + (ph & 1)) * C8 + c;
+    uint4 v = x[i];
+    if (accumulate) {
+      const bf8 a = unpack8(v), b = unpack8(y[o]);
+      bf8 r;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) r.v[q] = a.v[q] + b.v[q];
+      v = pack8(r);
+    }
+    y[o] = v;
+  }
+}
+extern "C" int rn_depth_to_space2x(const void* x, void* y, int N, int H, int W, int C, int accumulate, void* stream) {
+  RN_CHECK_ARG(x && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "rn_depth_to_space2x: bad argument");
+  hipLaunchKernelGGL(depth_to_space2x_kernel, dim3(tr_blocks((long long)N * H * W * 4 * (C / 8))), dim3(TR_THREADS), 0,
+                     (hipStream_t)stream, (const uint4*)x, (uint4*)y, N, H, W, C / 8, accumulate);
+  RN_CHECK_LAUNCH();
+  return RN_OK;
+}
+
 extern "C" int rn_act_bwd(const void* dz, const void* z, void* dy, int64_t n, int act, void* stream) {
   RN_CHECK_ARG(dz && z && dy && n > 0 && n % 8 == 0, "rn_act_bwd: bad argument");
   hipLaunchKernelGGL(act_bwd_kernel, dim3(tr_blocks(n / 8)), dim3(TR_THREADS), 0, (hipStream_t)stream,

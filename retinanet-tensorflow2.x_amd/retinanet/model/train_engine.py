@@ -1183,18 +1183,43 @@ class TrainEngine:
         # as it is (a quarter of the pixels of the zero-upsampled form) and rn_scatter_add2x puts the rows in place
         lowres = k == 1 and stride == 2 and need[0]["pad"] == 0 and os.environ.get("RNET_DGRAD_LOWRES", "1") != "0"
         scatters = []
+        # 3x3 / stride 2 / pad 1 on even inputs (the first block of ResNet stages 2-4): sub-pixel form — one 2x2
+        # stride-1 conv of dy with 4*Cin phase-major output channels + a depth-to-space, 16 tap products per dy pixel
+        # instead of the 36 (9 useful) of the zero-upsampled form (rn_dgrad_pack.pad_ == 1)
+        subpixel = (k == 3 and stride == 2 and need[0]["pad"] == 1 and os.environ.get("RNET_DGRAD_SUBPIXEL", "1") != "0"
+                    and all(self._src(o["inp"]).shape[1] % 2 == 0 and self._src(o["inp"]).shape[2] % 2 == 0
+                            and (4 * self.g.convs[o["conv"]]["cin"]) % 8 == 0 for o in need))
+        if subpixel:
+            p.R = p.S = 2
+            p.pad_top = p.pad_left = 0
+        d2s = []
         for i, op in enumerate(need):
             c = self.g.convs[op["conv"]]
             dy = dy_of[op["out"]]
             cw = dy.shape[3]
             cwp = lib.rn_conv_cin_pad(cw)     # K of the dgrad GEMM, zero padded in the packed weights only
             if op["conv"] not in packs:
-                buf = torch.empty((lib.rn_conv_cout_pad(c["cin"]), k, k, cwp), dtype=torch.bfloat16, device=self.dev)
+                if subpixel:
+                    buf = torch.empty((lib.rn_conv_cout_pad(4 * c["cin"]), 2, 2, cwp), dtype=torch.bfloat16, device=self.dev)
+                else:
+                    buf = torch.empty((lib.rn_conv_cout_pad(c["cin"]), k, k, cwp), dtype=torch.bfloat16, device=self.dev)
                 packs[op["conv"]] = buf
                 off, _ = self.p_off[c.get("kvar", op["conv"] + "/kernel")]
-                self.dgrad_packs.append((self.P.data_ptr() + 4 * off, k, c["cin"], c["cout"], cwp, buf))
+                self.dgrad_packs.append((self.P.data_ptr() + 4 * off, k, c["cin"], c["cout"], cwp, buf, 1 if subpixel else 0))
             x = self._src(op["inp"])
             H, W = x.shape[1], x.shape[2]
+            if subpixel:
+                gbuf = self._gradbuf(op["inp"])
+                first = mark(op["inp"] if op["inp"] not in self.bal_src else "bal:" + op["inp"])
+                tmp = torch.empty((B, dy.shape[1], dy.shape[2], 4 * c["cin"]), dtype=torch.bfloat16, device=self.dev)
+                self._keep.append(tmp)
+                d2s.append((tmp.data_ptr(), gbuf.data_ptr(), B, dy.shape[1], dy.shape[2], c["cin"], 0 if first else 1))
+                s = p.seg[i]
+                s.x, s.w, s.y = dy.data_ptr(), packs[op["conv"]].data_ptr(), tmp.data_ptr()
+                s.scale, s.shift, s.residual = None, None, None
+                s.N, s.H, s.W, s.Cin, s.pix_stride = B, dy.shape[1], dy.shape[2], cw, cw
+                s.Ho, s.Wo, s.Cout = dy.shape[1], dy.shape[2], 4 * c["cin"]
+                continue
             if lowres:
                 gbuf = self._gradbuf(op["inp"])
                 first = mark(op["inp"] if op["inp"] not in self.bal_src else "bal:" + op["inp"])
@@ -1238,26 +1263,30 @@ class TrainEngine:
                   for i, o in enumerate(need) if p.seg[i].residual)
         self._algo[id(p)] = (fl, by)
 
-        def dgrad(st, p=p, ups=ups, scatters=scatters):
+        def dgrad(st, p=p, ups=ups, scatters=scatters, d2s=d2s):
             for u in ups:
                 _C.check(lib.rn_upsample_zero2x(*u, st), "rn_upsample_zero2x")
             self._launch_conv(p, st, "dgrad")
             for sc in scatters:
                 _C.check(lib.rn_scatter_add2x(*sc, st), "rn_scatter_add2x")
+            for ds in d2s:
+                _C.check(lib.rn_depth_to_space2x(*ds, st), "rn_depth_to_space2x")
         self.bwd_steps.append(dgrad)
 
     # ---- one training step -----------------------------------------------------------------------------
     def refresh_dgrad_weights(self, st):
         lib = self.lib
         if self.dgrad_packs and os.environ.get("RNET_BATCH_DGRAD_PACK", "1") == "0":   # A/B switch (tools/)
-            for (mptr, k, cin, cout, cw, buf) in self.dgrad_packs:
+            for (mptr, k, cin, cout, cw, buf, mode) in self.dgrad_packs:
+                if mode:
+                    raise RuntimeError("RNET_BATCH_DGRAD_PACK=0 has no sub-pixel packing: set RNET_DGRAD_SUBPIXEL=0 with it")
                 _C.check(lib.rn_pack_conv_weight_dgrad(mptr, k, k, cin, cout, cw, buf.data_ptr(), st), "pack dgrad")
         elif self.dgrad_packs:
             if getattr(self, "_dgrad_pack_items", None) is None:   # descriptors are static: build them once
                 arr = (_C.DgradPack * len(self.dgrad_packs))()
-                for i, (mptr, k, cin, cout, cw, buf) in enumerate(self.dgrad_packs):
+                for i, (mptr, k, cin, cout, cw, buf, mode) in enumerate(self.dgrad_packs):
                     arr[i].w_ohwi, arr[i].w_packed = mptr, buf.data_ptr()
-                    arr[i].R, arr[i].S, arr[i].Cin, arr[i].Cout, arr[i].Cout_pad = k, k, cin, cout, cw
+                    arr[i].R, arr[i].S, arr[i].Cin, arr[i].Cout, arr[i].Cout_pad, arr[i].pad_ = k, k, cin, cout, cw, mode
                 self._dgrad_pack_items = arr
             _C.check(lib.rn_pack_conv_weight_dgrad_batch(self._dgrad_pack_items, len(self.dgrad_packs), st),
                      "pack dgrad")

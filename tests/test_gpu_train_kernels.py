@@ -120,6 +120,49 @@ def test_dgrad_via_forward_kernel(cuda, k, stride, cin, cout):
     torch.testing.assert_close(dx.float().cpu(), ref, rtol=1 / 128, atol=scale / 200)
 
 
+@pytest.mark.parametrize("N,H,W,cin,cout,accumulate", [(2, 12, 12, 64, 64, False), (1, 20, 16, 128, 128, True),
+                                                      (2, 8, 10, 256, 256, False), (1, 6, 6, 32, 96, True)])
+def test_dgrad_stride2_subpixel(cuda, N, H, W, cin, cout, accumulate):
+    """Data gradient of a 3x3 / stride 2 / pad 1 conv in its sub-pixel form (rn_dgrad_pack.pad_ == 1): one 2x2
+    stride-1 conv of dy with 4*Cin phase-major channels + rn_depth_to_space2x, against autograd."""
+    from retinanet import _C
+    lib = _C.lib()
+    g = torch.Generator().manual_seed(cin + cout + H)
+    Ho, Wo = H // 2, W // 2
+    w = torch.randn((cout, 3, 3, cin), generator=g) / math.sqrt(9 * cin)         # compute layout OHWI
+    dy = _bf(torch.randn((N, Ho, Wo, cout), generator=g))
+    xr = torch.zeros((N, cin, H, W), dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(xr, _bf(w).double().permute(0, 3, 1, 2), stride=2, padding=1)
+    assert y.shape[2:] == (Ho, Wo)
+    y.backward(dy.double().permute(0, 3, 1, 2))
+    want = xr.grad.permute(0, 2, 3, 1).float()
+    wd = w.to(cuda).contiguous()
+    cwp = lib.rn_conv_cin_pad(cout)
+    wp = torch.empty((lib.rn_conv_cout_pad(4 * cin), 2, 2, cwp), dtype=torch.bfloat16, device=cuda)
+    item = (_C.DgradPack * 1)()
+    item[0].w_ohwi, item[0].w_packed = wd.data_ptr(), wp.data_ptr()
+    item[0].R, item[0].S, item[0].Cin, item[0].Cout, item[0].Cout_pad, item[0].pad_ = 3, 3, cin, cout, cwp, 1
+    _C.check(lib.rn_pack_conv_weight_dgrad_batch(item, 1, _C.current_stream()))
+    dyd = dy.to(cuda).contiguous()
+    phases = torch.empty((N, Ho, Wo, 4 * cin), dtype=torch.bfloat16, device=cuda)
+    p = _C.ConvProblem()
+    p.R = p.S = 2
+    p.stride_h = p.stride_w = 1
+    p.pad_top = p.pad_left = 0
+    p.act, p.out_dtype, p.num_segments = _C.RN_ACT_NONE, _C.RN_DT_BF16, 1
+    s = p.seg[0]
+    s.x, s.w, s.y = dyd.data_ptr(), wp.data_ptr(), phases.data_ptr()
+    s.N, s.H, s.W, s.Cin, s.pix_stride, s.Ho, s.Wo, s.Cout = N, Ho, Wo, cout, cout, Ho, Wo, 4 * cin
+    _C.check(lib.rn_conv2d_nhwc_fwd(ctypes.byref(p), _C.current_stream()))
+    old = _bf(torch.randn((N, H, W, cin), generator=g))
+    dx = old.to(cuda).clone()
+    _C.check(lib.rn_depth_to_space2x(_C.ptr(phases), _C.ptr(dx), N, Ho, Wo, cin, 1 if accumulate else 0, _C.current_stream()))
+    torch.cuda.synchronize()
+    ref = _bf(_bf(want) + old.float()).float() if accumulate else _bf(want).float()
+    scale = ref.abs().max().item()
+    torch.testing.assert_close(dx.float().cpu(), ref, rtol=1 / 128, atol=scale / 200)
+
+
 # ---------------------------------------------------------------------------------------------
 def _bn_problem(cuda, segs, act, eps=1e-3, momentum=0.99, bessel=1, with_bwd=False):
     from retinanet import _C
