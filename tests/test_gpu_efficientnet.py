@@ -383,12 +383,6 @@ def run_wiring(cuda, name, size, B, upstream, with_floor=False):
     return fwd, rows, losses, fwd32, table(lambda k: ref32.leaf[k].grad)
 
 
-# tools/oracle_noise_floor.py efficientnet-b3 640 2 loss (CPU, this repo): the restatement in float32 against itself in
-# float64 — forward relative error 0.234, gradient cosine median 0.790.  The HIP path measures 0.204 / 0.804 at batch 4.
-B3_640_FWD_BOUND = 1.3 * 0.234
-B3_640_COS_MEDIAN_BOUND = 0.790 - 0.03
-
-
 def _signal_rows(rows, name):
     """tensors that carry signal: not a bias in front of a BatchNorm, not an analytically-zero beta, and at least
     0.3 x the median gradient norm"""
@@ -423,18 +417,22 @@ def test_efficientnet_backward_wiring(cuda):
 
 
 def test_config4_efficientnet_b3_640_train_step(cuda):
-    """BASELINE configs[4] at full size — EfficientNet-B3, 640 x 640, separable FPN / heads, a shard of 2 images (the float64 restatement of 4 takes minutes) —
-    one forward + RetinaNetLoss + backward with the real targets against the float64 restatement.  Bounds = 1.3 x the
-    restatement's own float32-vs-float64 noise at this configuration (tools/oracle_noise_floor.py efficientnet-b3 640
-    2 loss, recorded in DESIGN.md section 6)."""
+    """BASELINE configs[4] at full size — EfficientNet-B3, 640 x 640, separable FPN / heads, a shard of 2 images (the
+    float64 restatement of more takes minutes) — one forward + RetinaNetLoss + backward with the real targets against
+    the float64 restatement.  Same criterion as the small case: the restatement's own float32 evaluation is the
+    noise floor (26 MBConv blocks: forward 23 %, gradient-cosine median 0.79 — tools/oracle_noise_floor.py
+    efficientnet-b3 640 2 loss); the HIP path may be 1.3 x as far on the forward outputs and must keep the gradient
+    direction the floor keeps."""
     name = "efficientnet-b3"
-    fwd, rows, losses = run_wiring(cuda, name, 640, 2, "loss")
+    fwd, rows, losses, fwd_floor, rows_floor = run_wiring(cuda, name, 640, 2, "loss", with_floor=True)
     for k, (got, want) in losses.items():
         assert got == pytest.approx(want, rel=0.01), k
-    assert max(fwd.values()) <= B3_640_FWD_BOUND, sorted(fwd.items(), key=lambda kv: -kv[1])[:3]
-    sig = _signal_rows(rows, name)
+    assert max(fwd.values()) <= 1.3 * max(fwd_floor.values()) + 0.005, (max(fwd.values()), max(fwd_floor.values()))
+    sig, sig_floor = _signal_rows(rows, name), _signal_rows(rows_floor, name)
     cos = np.array([r[0] for r in sig.values()])
-    assert np.median(cos) > B3_640_COS_MEDIAN_BOUND, np.median(cos)
+    cos_floor = np.array([sig_floor[k][0] for k in sig if k in sig_floor])
+    print("gradient cosine median: HIP %.4f, float32 restatement %.4f" % (np.median(cos), np.median(cos_floor)))
+    assert np.median(cos) > np.median(cos_floor) - 0.05, (np.median(cos), np.median(cos_floor))
     by = {r[3]: r[0] for r in rows}
     assert by["class-head/class-head-prediction-conv2d/pointwise_kernel"] > 0.995
     assert by["class-head/class-head-prediction-conv2d/bias"] > 0.999
