@@ -435,6 +435,10 @@ int rn_optim_sgd_step(float* params, const float* grads, float* momentum_buf, fl
  * order with the kernels around it); in-place SUM.  Use one communicator per stream that carries collectives.
  * rn_allreduce_bucket: gradient buckets (RN_DT_F32 / RN_DT_BF16); rn_allreduce_small: the few-KB fp32 messages
  * (SyncBatchNorm [sum | sum of squares], the loss normaliser) on the latency path.  Status RN_ECOMM on failure. */
+/* Data-parallel runs: keep n compute units free of the persistent kernels (256-row convs, wgrad_big), whose workgroups
+ * own a CU for a whole tile loop — RCCL's kernels (the ~130 latency-bound SyncBN all-reduces per step beside the
+ * second stream's weight-gradient kernels, the gradient buckets beside the convolutions) then always find a CU. */
+int rn_set_reserved_cus(int n);
 int rn_comm_unique_id_bytes(void);
 int rn_comm_unique_id(void* out /* host, rn_comm_unique_id_bytes() bytes */);
 int rn_comm_init(const void* unique_id /* host */, int rank, int world, void** comm_out);

@@ -8,6 +8,8 @@
 #include "../../include/rnet_hip.h"
 
 void rn_set_error(const char* fmt, ...);
+int rn_persistent_grid(int work_items, int num_cu);   // rn_core.hip: min(items, CUs not reserved for RCCL)
+int rn_reserved_cus();
 
 #define RN_CHECK_ARG(cond, ...)  \
   do {                           \

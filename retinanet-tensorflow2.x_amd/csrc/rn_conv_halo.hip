@@ -457,7 +457,7 @@ int rn_launch_conv_halo(const ConvArgs& a, bool out_f32, hipStream_t st) {
       num_cu = prop.multiProcessorCount;
     attr_set = true;
   }
-  int grid = a.total_tiles < num_cu ? a.total_tiles : num_cu;   // one persistent workgroup per CU
+  int grid = rn_persistent_grid(a.total_tiles, num_cu);   // one persistent workgroup per CU (minus the CUs kept for RCCL)
   if (g_halo_grid > 0 && g_halo_grid < grid) grid = g_halo_grid;
   bool has_res = false;   // one residual input anywhere -> the variant that carries the residual path
   for (int i = 0; i < a.nseg; ++i) has_res = has_res || a.seg[i].residual != nullptr;

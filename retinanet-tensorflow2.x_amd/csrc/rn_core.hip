@@ -25,3 +25,24 @@ extern "C" int rn_device_ok(void) {
   if (hipGetDeviceProperties(&p, 0) != hipSuccess) return 0;
   return strncmp(p.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
 }
+
+// Compute units the persistent kernels leave free (data-parallel runs): RCCL's kernels need CUs of their own.  A
+// persistent 256-row conv / wgrad workgroup owns its CU (130-160 KB of LDS, ~220 VGPRs per wave), so a collective that
+// arrives while such a kernel covers every CU waits for a whole tile loop to end (hundreds of microseconds) — ~130
+// latency-bound SyncBatchNorm all-reduces per step run beside the weight-gradient kernels of the second stream, and the
+// gradient buckets beside the convolutions.  With n CUs kept free, the persistent grids are num_cu - n workgroups.
+static int g_rn_reserved_cus = 0;
+extern "C" int rn_set_reserved_cus(int n) {
+  if (n < 0 || n > 128) {
+    rn_set_error("rn_set_reserved_cus: %d out of range (0..128)", n);
+    return RN_EINVAL;
+  }
+  g_rn_reserved_cus = n;
+  return RN_OK;
+}
+int rn_persistent_grid(int work_items, int num_cu) {
+  int g = num_cu - g_rn_reserved_cus;
+  if (g < 1) g = 1;
+  return work_items < g ? work_items : g;
+}
+int rn_reserved_cus() { return g_rn_reserved_cus; }

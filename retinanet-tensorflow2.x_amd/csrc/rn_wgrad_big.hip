@@ -63,10 +63,13 @@ __global__ void __launch_bounds__(512) wgrad_big_kernel(const WgArgs args) {
   // chunk in lockstep and share its rows in L2)
   const int tiles_per_tap = args.co_tiles * args.ci_tiles;
   const int tiles_all = tiles_per_tap * args.R * args.S;
+  // One work item per workgroup when the grid covers them all (the single-GPU case); with CUs kept free for RCCL
+  // (rn_set_reserved_cus) the grid is smaller than the item count and a workgroup walks items bid, bid + grid, ...
+#pragma unroll 1
+  for (int bid = blockIdx.x; bid < tiles_all * args.total_chunks; bid += gridDim.x) {
   int logical;
   {
     const int total = tiles_all * args.total_chunks;
-    const int bid = blockIdx.x;
     const int xcd = bid & 7, slot = bid >> 3;
     const int q = total >> 3, rr = total & 7;
     logical = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + slot;
@@ -281,6 +284,8 @@ __global__ void __launch_bounds__(512) wgrad_big_kernel(const WgArgs args) {
         if (cob + dco < Cout && ci < Cin) po[(long long)dco * row_stride] = acc[i][j][q];
       }
     }
+  __syncthreads();   // the next item's DMA reuses the stages
+  }   // work items of this workgroup
 }
 
 }  // namespace
@@ -310,6 +315,7 @@ bool rn_wgrad_big_plan(const rn_wgrad_problem* p, WgArgs& a) {
   // the candidates are priced with a greedy simulation of that mapping (per-workgroup cost = K steps + a
   // fixed prologue / epilogue / partial-tile cost) and the cheapest wins.  Plans are cached per shape.
   long long CH = 0;
+  if (!g_big_target_user) g_big_target_blocks = 256 - rn_reserved_cus();   // one round of the CUs the kernel may use
   {
     static std::mutex mu;
     static std::unordered_map<std::string, long long> cache;
@@ -395,7 +401,15 @@ int rn_launch_wgrad_big(const WgArgs& a, hipStream_t st) {
     linear = linear && s.Ho == s.H && s.Wo == s.W &&
              (long long)s.N * s.H * s.W * (s.xS > s.dyS ? s.xS : s.dyS) * 2 < (1ll << 31) - (1ll << 24);
   }
-  dim3 grid((unsigned)(a.co_tiles * a.ci_tiles * a.R * a.S * a.total_chunks));
+  int items = a.co_tiles * a.ci_tiles * a.R * a.S * a.total_chunks;
+  static int num_cu = 0;
+  if (!num_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    num_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+              prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  dim3 grid((unsigned)(rn_reserved_cus() > 0 ? rn_persistent_grid(items, num_cu) : items));
   if (linear) hipLaunchKernelGGL(wgrad_big_kernel<true>, grid, dim3(512), LDS_BYTES, st, a);
   else hipLaunchKernelGGL(wgrad_big_kernel<false>, grid, dim3(512), LDS_BYTES, st, a);
   RN_CHECK_LAUNCH();

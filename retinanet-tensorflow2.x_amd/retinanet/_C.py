@@ -191,6 +191,7 @@ _SIGNATURES = {
                                   c_int, c_int, c_void_p]),
     "rn_fpn_topdown": (c_int, [_PP, _PP, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rn_balance_features": (c_int, [_PP, _PP, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rn_set_reserved_cus": (c_int, [c_int]),
     "rn_comm_unique_id_bytes": (c_int, []),
     "rn_comm_unique_id": (c_int, [c_void_p]),
     "rn_comm_init": (c_int, [c_void_p, c_int, c_int, POINTER(c_void_p)]),

@@ -62,6 +62,9 @@ class TrainEngine:
         bn = self.params_cfg.architecture.batch_norm
         self.eps, self.momentum_bn = float(bn.epsilon), float(bn.momentum)
         self.sync_bn = bool(bn.use_sync) and self.world > 1
+        # data parallel: the persistent kernels leave a few CUs to RCCL (csrc/rn_core.hip, rn_set_reserved_cus)
+        _C.check(self.lib.rn_set_reserved_cus(int(os.environ.get("RNET_COMM_CUS", "8")) if self.world > 1 else 0),
+                 "rn_set_reserved_cus")
         self.frozen = set(frozen_names)
         for k in model.variables:
             if any(rx.search(k) for rx in frozen_regexes):

@@ -77,6 +77,64 @@ def test_wgrad(cuda, shape, request):
     torch.testing.assert_close(dw.cpu().double(), 2 * want, rtol=1e-3, atol=2e-3 * scale)
 
 
+def test_kernels_with_compute_units_reserved_for_rccl(cuda):
+    """rn_set_reserved_cus (data-parallel runs): the persistent kernels run on fewer workgroups than CUs, wgrad_big
+    walks several work items per workgroup.  The 256-row convs must give bit-identical outputs (a tile's arithmetic
+    does not depend on which workgroup computes it); wgrad_big re-plans its split-K chunks for the smaller machine,
+    so its sums are compared with the float64 reference."""
+    from retinanet import _C
+    import test_gpu_conv as TC
+    lib = _C.lib()
+    g = torch.Generator().manual_seed(77)
+    seg = {"x": torch.randn((4, 24, 24, 256), generator=g), "w": torch.randn((3, 3, 256, 256), generator=g) / 48.0,
+           "bias": torch.randn((256,), generator=g), "scale": torch.rand((256,), generator=g) + 0.5,
+           "shift": torch.randn((256,), generator=g) * 0.1}
+    outs = {}
+    lib.rn_debug_conv_tile(2)
+    try:
+        for reserved, halo in ((0, 1), (128, 1), (0, 0), (100, 0)):
+            _C.check(lib.rn_set_reserved_cus(reserved))
+            lib.rn_debug_conv_halo(halo)
+            outs[(reserved, halo)] = TC._conv_gpu(cuda, [seg], 3, 1, 1, "relu", False)[0]
+    finally:
+        lib.rn_debug_conv_halo(1)
+        lib.rn_debug_conv_tile(0)
+        _C.check(lib.rn_set_reserved_cus(0))
+    assert torch.equal(outs[(0, 1)], outs[(128, 1)]) and torch.equal(outs[(0, 0)], outs[(100, 0)])
+    TC._close(outs[(0, 1)], TC._conv_ref(seg, 3, 1, 1, "relu", False), False)
+    # wgrad_big with 128 of the CUs reserved: several work items per workgroup
+    lib.rn_debug_wgrad_big_min_pixels(1)
+    try:
+        N, H, ci, co, k = 4, 20, 256, 256, 3
+        x = _bf(torch.randn((N, H, H, ci), generator=g))
+        dy = _bf(torch.randn((N, H, H, co), generator=g))
+        w = torch.zeros((co, ci, k, k), dtype=torch.float64, requires_grad=True)
+        F.conv2d(x.double().permute(0, 3, 1, 2), w, padding=1).backward(dy.double().permute(0, 3, 1, 2))
+        want = w.grad.permute(0, 2, 3, 1)
+        xd, dyd = x.to(cuda), dy.to(cuda)
+        got = {}
+        for reserved in (0, 128):
+            _C.check(lib.rn_set_reserved_cus(reserved))
+            p = _C.WgradProblem()
+            p.R = p.S = k
+            p.stride_h = p.stride_w = p.pad_top = p.pad_left = 1
+            p.num_segments = 1
+            s = p.seg[0]
+            s.x, s.dy = xd.data_ptr(), dyd.data_ptr()
+            s.N, s.H, s.W, s.Cin, s.Ho, s.Wo, s.Cout = N, H, H, ci, H, H, co
+            ws = _ws(lib.rn_wgrad_workspace_bytes(ctypes.byref(p)), cuda)
+            dw = torch.zeros((co, k, k, ci), dtype=torch.float32, device=cuda)
+            _C.check(lib.rn_conv2d_nhwc_wgrad(ctypes.byref(p), _C.ptr(dw), 0.0, _C.ptr(ws), ws.numel(), _C.current_stream()))
+            torch.cuda.synchronize()
+            got[reserved] = dw.cpu().double()
+    finally:
+        lib.rn_debug_wgrad_big_min_pixels(16384)
+        _C.check(lib.rn_set_reserved_cus(0))
+    scale = want.abs().max().item()
+    for reserved in (0, 128):
+        torch.testing.assert_close(got[reserved], want, rtol=1e-3, atol=1e-3 * scale)
+
+
 @pytest.mark.parametrize("k,stride,cin,cout", [(3, 1, 128, 256), (1, 1, 256, 128), (3, 2, 128, 128), (1, 2, 256, 512)])
 def test_dgrad_via_forward_kernel(cuda, k, stride, cin, cout):
     """dx = conv_fwd(dy [zero-upsampled for stride 2], flipped/transposed weights)."""
