@@ -186,7 +186,7 @@ def run_train(args, dev, rank, world):
     # launches of the dominant kernel share the chip with wgrad kernels and their event-bracketed durations above
     # include that sharing.  One more, untimed, step with the one-stream backward gives the kernel's own duration.
     exclusive = None
-    if getattr(eng, "side_stream_on", False) and dom_name in by_kernel:
+    if getattr(eng, "side_stream_on", False) and dom_name in by_kernel and not args.no_exclusive:
         eng.side_stream_on = False
         prof1 = []
         eng.conv_profile = prof1
@@ -377,6 +377,9 @@ def main():
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--logit-std", type=float, default=1.0)
     ap.add_argument("--no-infer", action="store_true")
+    ap.add_argument("--no-exclusive", action="store_true",
+                    help="skip the one extra one-stream step behind `roofline.exclusive` (profile runs: the kernel "
+                         "trace then holds warm-up + timed steps only, like the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

@@ -248,14 +248,25 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_fwd_kernel(const ConvArg
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+      float t[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t[r] = acc[i][j][r] + bs;
+      if (round1) {   // uniform branches per stage, not per element
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[r] = rn_rb(t[r]);
+      }
+      if (affine) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[r] = t[r] * sc + sf;
+      }
+      if (round2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[r] = rn_rb(t[r]);
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ml = wave_m * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        float t = acc[i][j][r] + bs;
-        if (round1) t = rn_rb(t);
-        if (affine) t = t * sc + sf;
-        if (round2) t = rn_rb(t);
-        cl[ml * BN + nl] = t;
+        cl[ml * BN + nl] = t[r];
       }
     }
   }

@@ -117,14 +117,27 @@ __global__ void __launch_bounds__(DW_THREADS) depthwise_strip_kernel(const DwArg
       // bf16 tensors where the reference has them: DepthwiseConv2D output, BatchNorm output in front of swish
       // (rnet_hip.h, rn_conv_segment); the accumulate form (data gradients: no affine) adds in fp32, one rounding
       const bool affine = s.scale != nullptr || s.shift != nullptr;
+      float v[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        float v = acc[tt][q];
-        if (affine) v = rn_rb(v) * sc[q] + sh[q];
-        if (s.residual) v = (affine ? rn_rb(v) : v) + res.v[q];
-        if (a.act == RN_ACT_SWISH) v = rn_rb(v);
-        o.v[q] = act_exact(v, a.act);
+      for (int q = 0; q < 8; ++q) v[q] = acc[tt][q];
+      if (affine) {   // uniform branches per stage, not per element
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = rn_rb(v[q]) * sc[q] + sh[q];
       }
+      if (s.residual) {
+        if (affine) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] = rn_rb(v[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] += res.v[q];
+      }
+      if (a.act == RN_ACT_SWISH) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = rn_rb(v[q]);
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) o.v[q] = act_exact(v[q], a.act);
       s.y[oi] = pack8(o);
     }
   }

@@ -291,18 +291,26 @@ __global__ void __launch_bounds__(TR_THREADS) bn_apply_kernel(const BnArgs a) {
     bf8 res;
     if (s.residual) res = unpack8(s.residual[i]);
     const float m = s.sample_scale ? s.sample_scale[(int)(i / C8) / (int)s.rows_per_sample] : 1.0f;
+    // one uniform branch per stage, not per element (a runtime test inside the unrolled 8-channel loops compiles
+    // to scalar compares and branches PER ELEMENT and makes the pass issue-bound: 40 -> 46 us per launch)
     const bool swish = a.act == RN_ACT_SWISH;
-    const bool r1 = s.residual != nullptr || s.sample_scale != nullptr || swish;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      float v = y.v[q] * sc[q] + sh[q];
-      if (r1) v = rn_rb(v);
-      if (s.sample_scale) v = rn_rb(v * m);
-      if (s.residual) {
-        v += res.v[q];
-        if (swish) v = rn_rb(v);
+    for (int q = 0; q < 8; ++q) o.v[q] = y.v[q] * sc[q] + sh[q];
+    if (s.residual != nullptr || s.sample_scale != nullptr || swish) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) o.v[q] = rn_rb(o.v[q]);
+    }
+    if (s.sample_scale) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) o.v[q] = rn_rb(o.v[q] * m);
+    }
+    if (s.residual) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) o.v[q] += res.v[q];
+      if (swish) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o.v[q] = rn_rb(o.v[q]);
       }
-      o.v[q] = v;
     }
     rn_apply_act_n<8>(o.v, a.act);
     s.z[i] = pack8(o);

@@ -228,6 +228,9 @@ def lib():
             raise RnetError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        # PyTorch first: it ships its own HIP runtime, and a process must end up with ONE (librnet_hip.so then binds to
+        # the copy that is already loaded; the other order gives two runtimes and "no ROCm-capable device" on launch)
+        import torch  # noqa: F401
         handle = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(handle, name)

@@ -6,7 +6,9 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof
 mkdir -p $OUT
 cd $R
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train -- python3 bench.py --steps 5 --warmup 2 --no-infer --no-cpu-baseline > $OUT/train.log 2>&1
+# the bench's own training leg (default --steps 20 --warmup 3), without the extra one-stream step: every step in the
+# trace is a two-stream step like the timed ones, so the dominant kernel's average here is the bench line's avg_launch_us
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train -- python3 bench.py --no-exclusive --no-infer --no-cpu-baseline > $OUT/train.log 2>&1
 # the same command with the one-stream backward: kernel durations without the wgrad launches of the second stream
 RNET_WGRAD_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train1s -- python3 bench.py --steps 5 --warmup 2 --no-infer --no-cpu-baseline > $OUT/train1s.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/infer -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/infer.log 2>&1
