@@ -202,6 +202,16 @@ typedef struct {
   const float* bias;    /* f32[Cout] or NULL: the Conv2D layer's bias, added to the fp32 accumulator */
   int32_t w_terms;      /* 0 or 1: plain bf16 weights; 2 / 3: split-bf16 planes along Cin (see above) */
   int32_t pad_;
+  /* optional: stage 1 of rn_bn_bwd_reduce fused into a DATA-GRADIENT launch.  The launch's output is dz, the gradient
+   * that arrives at a BatchNorm + ReLU layer with no residual input (y = that layer's raw conv output, same shape as
+   * this launch's output; bn_bwd_fwd = its rn_bn_segment.fwd: mean | invstd | scale | shift).  With both set (and
+   * bn_partial; bf16 output, no scale / shift / bias / residual / activation on the launch itself), every 128-pixel
+   * row block b writes   bn_partial[(b*2 + 0)*Cout + c] = sum g,   [(b*2 + 1)*Cout + c] = sum g*y,
+   * g = dz_stored * [y*scale + shift > 0]   (RAW second moment: rn_bn_bwd_reduce turns it into sum g*xhat =
+   * invstd * (sum g*y - mean * sum g) in its final, double-precision pass — rn_bn_segment.ext_chunks_bwd).
+   * Row blocks as for the forward statistics (rn_conv_tile_rows()).  All segments of a launch or none. */
+  const void* bn_bwd_y;
+  const float* bn_bwd_fwd;
 } rn_conv_segment;
 
 typedef struct {
@@ -354,7 +364,11 @@ typedef struct {
    * (rn_conv_segment.bn_partial) as `ext_chunks` row blocks at workspace + rn_bn_partial_offset_bytes(); rn_bn_stats
    * then only runs the ordered final reduction.  All segments of a problem must agree. */
   int32_t ext_chunks;
-  int32_t pad_;
+  /* > 0: stage 1 of rn_bn_bwd_reduce was written by the data-gradient launch that produced dz
+   * (rn_conv_segment.bn_bwd_y) as `ext_chunks_bwd` row blocks of (sum g, sum g*y) at workspace +
+   * rn_bn_bwd_partial_offset_bytes(); rn_bn_bwd_reduce then only runs the ordered final reduction (and converts the
+   * raw moment).  Only for act = relu / none without residual and without sample_scale.  All segments or none. */
+  int32_t ext_chunks_bwd;
 } rn_bn_segment;
 
 typedef struct {
@@ -369,6 +383,7 @@ typedef struct {
 
 size_t rn_bn_workspace_bytes(const rn_bn_problem* problem /* host */);
 size_t rn_bn_partial_offset_bytes(const rn_bn_problem* problem, int segment);   /* forward-stats partials in the workspace */
+size_t rn_bn_bwd_partial_offset_bytes(const rn_bn_problem* problem, int segment);   /* backward partials (ext_chunks_bwd) */
 int rn_bn_stats(const rn_bn_problem* problem, void* workspace, size_t workspace_bytes, void* stream);
 /* rn_bn_stats + rn_bn_finalize in one call for single-replica BatchNorm (no all-reduce between them): the final
  * reduction kernel finishes each channel with the finalize arithmetic — same values, one launch less per layer */

@@ -279,6 +279,15 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_fwd_kernel(const ConvArg
   // fused BatchNorm forward statistics (rn_conv_segment.bn_partial): sums of the STORED bf16 values of this
   // thread's 4 channels over its rows; reduced over the workgroup's 128 rows below
   const bool stats = !OUT_F32 && sg.bn_partial != nullptr;
+  // ... or stage 1 of the BatchNorm BACKWARD reduction of the layer whose dz this launch writes
+  // (rn_conv_segment.bn_bwd_y): sums of g = dz * [y*scale + shift > 0] and of g*y
+  const bool bnbwd = stats && sg.bn_y != nullptr;
+  float bsc[4] = {0.f, 0.f, 0.f, 0.f}, bsh[4] = {0.f, 0.f, 0.f, 0.f};
+  if (bnbwd && n < Cout) {
+    const float4 a4 = *(const float4*)(sg.bn_fwd + 2 * Cout + n), b4 = *(const float4*)(sg.bn_fwd + 3 * Cout + n);
+    bsc[0] = a4.x; bsc[1] = a4.y; bsc[2] = a4.z; bsc[3] = a4.w;
+    bsh[0] = b4.x; bsh[1] = b4.y; bsh[2] = b4.z; bsh[3] = b4.w;
+  }
   float st0[4] = {0.f, 0.f, 0.f, 0.f}, st1[4] = {0.f, 0.f, 0.f, 0.f};
   if (n < Cout) {
 #pragma unroll 4
@@ -314,8 +323,20 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_fwd_kernel(const ConvArg
         if (stats) {
           const float w4[4] = {__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xffff0000u),
                                __uint_as_float(pk.y << 16), __uint_as_float(pk.y & 0xffff0000u)};
+          if (bnbwd) {
+            const uint2 yv = *(const uint2*)(sg.bn_y + o);
+            const float y4[4] = {__uint_as_float(yv.x << 16), __uint_as_float(yv.x & 0xffff0000u),
+                                 __uint_as_float(yv.y << 16), __uint_as_float(yv.y & 0xffff0000u)};
 #pragma unroll
-          for (int q = 0; q < 4; ++q) { st0[q] += w4[q]; st1[q] += w4[q] * w4[q]; }
+            for (int q = 0; q < 4; ++q) {
+              const float g = (y4[q] * bsc[q] + bsh[q]) > 0.0f ? w4[q] : 0.0f;
+              st0[q] += g;
+              st1[q] += g * y4[q];
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { st0[q] += w4[q]; st1[q] += w4[q] * w4[q]; }
+          }
         }
       }
     }
@@ -477,6 +498,15 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
     d.x = (const uint16_t*)s.x; d.w = (const uint16_t*)s.w; d.y = s.y;
     d.scale = s.scale; d.shift = s.shift; d.residual = (const uint16_t*)s.residual;
     d.bn_partial = s.bn_partial;
+    d.bn_y = (const uint16_t*)s.bn_bwd_y;
+    d.bn_fwd = s.bn_bwd_fwd;
+    if (s.bn_bwd_y) {
+      RN_CHECK_ARG(s.bn_partial && s.bn_bwd_fwd && p->out_dtype == RN_DT_BF16 && !s.scale && !s.shift && !s.bias &&
+                       !s.residual && p->act == RN_ACT_NONE && s.Cout % 8 == 0 && (uintptr_t)s.bn_bwd_y % 16 == 0,
+                   "rn_conv2d_nhwc_fwd: segment %d: bn_bwd_y needs bn_partial + bn_bwd_fwd on a plain bf16 launch", i);
+    }
+    RN_CHECK_ARG((s.bn_bwd_y != nullptr) == (p->seg[0].bn_bwd_y != nullptr),
+                 "rn_conv2d_nhwc_fwd: bn_bwd_y must be set on all segments or none");
     d.bias = s.bias;
     d.N = s.N; d.H = s.H; d.W = s.W; d.Cin = s.Cin; d.pix_stride = s.pix_stride;
     d.Ho = s.Ho; d.Wo = s.Wo; d.Cout = s.Cout;

@@ -37,7 +37,7 @@ constexpr int A_BYTES = BM * BK * 2, STAGE_BYTES = (BM + BN) * BK * 2;
 constexpr int RING_BYTES = STAGES * STAGE_BYTES, PATCH_BYTES = 4096;
 constexpr int LDS_BYTES = RING_BYTES + NW * PATCH_BYTES;
 
-template <bool OUT_F32, bool HAS_RES>
+template <bool OUT_F32, bool HAS_RES, bool BN_BWD = false>   // BN_BWD: rn_conv_big_epi.h
 __global__ void __launch_bounds__(512) conv_big_kernel(const ConvArgs args) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int total = args.total_tiles;
@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(512) conv_big_kernel(const ConvArgs args) {
 
   // ---- epilogue of the compute-side tile (per wave; acc is re-initialised for the next tile afterwards) --------------------
   auto epilogue = [&]() __attribute__((always_inline)) {
-    big_epilogue<OUT_F32, HAS_RES>(acc, args, c_si, c_m0, c_n0, wave, smem + RING_BYTES + wave * PATCH_BYTES);
+    big_epilogue<OUT_F32, HAS_RES, BN_BWD>(acc, args, c_si, c_m0, c_n0, wave, smem + RING_BYTES + wave * PATCH_BYTES);
   };
 
   // ---- prologue ------------------------------------------------------------------------------------
@@ -287,6 +287,8 @@ int rn_launch_conv_big(const ConvArgs& a, bool out_f32, hipStream_t st) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_big_kernel<true, true>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_big_kernel<false, false, true>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
@@ -299,7 +301,9 @@ int rn_launch_conv_big(const ConvArgs& a, bool out_f32, hipStream_t st) {
   bool has_res = false;   // one residual input anywhere -> the variant that carries the residual path
   for (int i = 0; i < a.nseg; ++i) has_res = has_res || a.seg[i].residual != nullptr;
   const dim3 g3(grid), b3(512);
-  if (out_f32) {
+  if (a.seg[0].bn_y) {   // data gradient + stage 1 of the BatchNorm backward reduction (validated by the caller)
+    hipLaunchKernelGGL((conv_big_kernel<false, false, true>), g3, b3, LDS_BYTES, st, a);
+  } else if (out_f32) {
     if (has_res) hipLaunchKernelGGL((conv_big_kernel<true, true>), g3, b3, LDS_BYTES, st, a);
     else hipLaunchKernelGGL((conv_big_kernel<true, false>), g3, b3, LDS_BYTES, st, a);
   } else {

@@ -114,9 +114,15 @@ __device__ __forceinline__ void big_acc_init(f32x16_t (&acc)[4][2], const ConvAr
 // the compiler puts in front of their uses also wait for the stores issued before them (loads and stores share
 // vmcnt and retire in order) — with the loads merely predicated off, every 32-pixel block of a tile would still
 // wait for the previous block's stores to reach L2 (measured: 25 000 cycles per tile epilogue instead of ~5 000).
-template <bool OUT_F32, bool HAS_RES>
+// BN_BWD (bf16, no residual / affine / bias / activation on the launch): the launch writes dz of a BatchNorm + ReLU
+// layer; the wave also reads that layer's raw conv output y for its rows (through the residual prefetch registers)
+// and accumulates stage 1 of the backward reduction — sum g, sum g*y, g = dz_stored * [y*scale + shift > 0] — into
+// bn_partial (rnet_hip.h: rn_conv_segment.bn_bwd_y).
+template <bool OUT_F32, bool HAS_RES, bool BN_BWD = false>
 __device__ __forceinline__ void big_epilogue(f32x16_t (&acc)[4][2], const ConvArgs& args, int c_si, int c_m0,
                                              int c_n0, int wave, char* patch) {
+  static_assert(!(BN_BWD && (OUT_F32 || HAS_RES)), "BN_BWD: plain bf16 launches only");
+  constexpr bool LOADS = HAS_RES || BN_BWD;   // the epilogue prefetches a second [M][Cout] bf16 tensor
   const int wave_m = wave >> 2, wave_n = wave & 3;
   const ConvSegDev& sg = args.seg[c_si];
   const int Cout = sg.Cout, M = sg.M;
@@ -141,6 +147,13 @@ __device__ __forceinline__ void big_epilogue(f32x16_t (&acc)[4][2], const ConvAr
       const float4 a = *(const float4*)(sg.shift + nr), b = *(const float4*)(sg.shift + nr + 4);
       sf[0] = a.x; sf[1] = a.y; sf[2] = a.z; sf[3] = a.w; sf[4] = b.x; sf[5] = b.y; sf[6] = b.z; sf[7] = b.w;
     }
+    if (BN_BWD && nok) {   // the launch itself has no affine: sc / sf carry the BatchNorm layer's scale / shift (mask only)
+      const float* f2 = sg.bn_fwd + 2 * Cout + nr;
+      const float* f3 = sg.bn_fwd + 3 * Cout + nr;
+      const float4 a = *(const float4*)f2, b = *(const float4*)(f2 + 4), c = *(const float4*)f3, d = *(const float4*)(f3 + 4);
+      sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w; sc[4] = b.x; sc[5] = b.y; sc[6] = b.z; sc[7] = b.w;
+      sf[0] = c.x; sf[1] = c.y; sf[2] = c.z; sf[3] = c.w; sf[4] = d.x; sf[5] = d.y; sf[6] = d.z; sf[7] = d.w;
+    }
     // Take the scale / shift registers through an empty asm: the compiler has to wait for these (conditional)
     // loads HERE.  Left to the first real use it re-waits inside every predicated store block further down, and a
     // vmcnt wait there also waits for the stores issued before it (loads and stores retire in order): each
@@ -149,6 +162,8 @@ __device__ __forceinline__ void big_epilogue(f32x16_t (&acc)[4][2], const ConvAr
     for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(sc[q]), "+v"(sf[q]));
     EPI_STAMP(12);
     const bool has_res = HAS_RES && sg.residual != nullptr;
+    const uint16_t* const side = BN_BWD ? sg.bn_y : sg.residual;   // the tensor the prefetch reads
+    const bool has_side = BN_BWD ? true : has_res;
     // fused BatchNorm forward statistics (training, raw conv output): per-lane sums of the stored values
     const bool stats = sg.bn_partial != nullptr;
     float st0[8], st1[8];
@@ -159,16 +174,16 @@ __device__ __forceinline__ void big_epilogue(f32x16_t (&acc)[4][2], const ConvAr
     const long long row_bytes = (long long)Cout * 2;
     const int act = args.act;
     const bool clamp_lo = act == RN_ACT_RELU || act == RN_ACT_RELU6, clamp_hi = act == RN_ACT_RELU6;
-    const bool affine = sg.scale != nullptr || sg.shift != nullptr;
+    const bool affine = !BN_BWD && (sg.scale != nullptr || sg.shift != nullptr);
     // conv (+bias) output only: the transposed bf16 rows are the result, up to relu / relu6 on the packed pairs
-    const bool plain = !affine && !has_res && act != RN_ACT_SWISH;
+    const bool plain = BN_BWD || (!affine && !has_res && act != RN_ACT_SWISH);
     const bool round2 = affine && has_res;   // the BatchNorm output is a bf16 tensor before the residual add
-    uint4 rv[2][HAS_RES ? 4 : 1];
+    uint4 rv[2][LOADS ? 4 : 1];
 #define BIG_RES_PREFETCH(buf_, i_)                                                                    \
-_Pragma("unroll") for (int pass = 0; pass < (HAS_RES ? 4 : 0); ++pass) {                            \
+_Pragma("unroll") for (int pass = 0; pass < (LOADS ? 4 : 0); ++pass) {                              \
   const int m = mw0 + (i_) * 32 + pass * 8 + rrow;                                                  \
   rv[buf_][pass] = make_uint4(0u, 0u, 0u, 0u);                                                      \
-  if (has_res && nok && m < M) rv[buf_][pass] = *(const uint4*)(sg.residual + (long long)m * Cout + nr); \
+  if (has_side && nok && m < M) rv[buf_][pass] = *(const uint4*)(side + (long long)m * Cout + nr);  \
 }
     BIG_RES_PREFETCH(0, 0);
 #pragma unroll
@@ -219,7 +234,7 @@ _Pragma("unroll") for (int pass = 0; pass < (HAS_RES ? 4 : 0); ++pass) {        
               ov.z = pk_min_i16(ov.z, 0x40c040c0u); ov.w = pk_min_i16(ov.w, 0x40c040c0u);
             }
           } else {
-            const uint4 r4 = HAS_RES ? rv[i & 1][HAS_RES ? pass : 0] : make_uint4(0u, 0u, 0u, 0u);
+            const uint4 r4 = HAS_RES ? rv[i & 1][LOADS ? pass : 0] : make_uint4(0u, 0u, 0u, 0u);
             float f[8] = {bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y), bf_lo(v.z), bf_hi(v.z), bf_lo(v.w), bf_hi(v.w)};
             const float rr[8] = {bf_lo(r4.x), bf_hi(r4.x), bf_lo(r4.y), bf_hi(r4.y),
                                  bf_lo(r4.z), bf_hi(r4.z), bf_lo(r4.w), bf_hi(r4.w)};
@@ -255,8 +270,20 @@ _Pragma("unroll") for (int pass = 0; pass < (HAS_RES ? 4 : 0); ++pass) {        
           if (stats) {
             const float w[8] = {bf_lo(ov.x), bf_hi(ov.x), bf_lo(ov.y), bf_hi(ov.y),
                                 bf_lo(ov.z), bf_hi(ov.z), bf_lo(ov.w), bf_hi(ov.w)};
+            if (BN_BWD) {
+              const uint4 y4 = rv[i & 1][LOADS ? pass : 0];
+              const float yy[8] = {bf_lo(y4.x), bf_hi(y4.x), bf_lo(y4.y), bf_hi(y4.y),
+                                   bf_lo(y4.z), bf_hi(y4.z), bf_lo(y4.w), bf_hi(y4.w)};
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { st0[q] += w[q]; st1[q] += w[q] * w[q]; }
+              for (int q = 0; q < 8; ++q) {
+                const float g = (yy[q] * sc[q] + sf[q]) > 0.0f ? w[q] : 0.0f;
+                st0[q] += g;
+                st1[q] += g * yy[q];
+              }
+            } else {
+#pragma unroll
+              for (int q = 0; q < 8; ++q) { st0[q] += w[q]; st1[q] += w[q] * w[q]; }
+            }
           }
         }
       }

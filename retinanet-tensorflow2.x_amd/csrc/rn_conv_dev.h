@@ -18,6 +18,8 @@ struct ConvSegDev {
   const uint16_t* residual;
   float* bn_partial;   // fused BatchNorm forward statistics (bf16 outputs), or null
   const float* bias;   // Conv2D bias, added to the fp32 accumulator (rnet_hip.h: epilogue)
+  const uint16_t* bn_y;   // fused stage 1 of the BatchNorm backward reduction (rn_conv_segment.bn_bwd_y), or null
+  const float* bn_fwd;    //   that layer's mean | invstd | scale | shift
   int N, H, W, Cin, pix_stride, Ho, Wo, Cout;
   int M, tile_begin, n_tiles, CinP;  // CinP = K extent per tap = w_terms * (Cin rounded up to the K step)
   int cwrap, halo_pitch;             // input channels wrap at cwrap (= CinP / w_terms): split-bf16 weight planes;
@@ -53,7 +55,7 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wav
 
 
 // rn_conv_big.hip
-int rn_launch_conv_big(const ConvArgs& a, bool out_f32, hipStream_t st);
+int rn_launch_conv_big(const ConvArgs& a, bool out_f32, hipStream_t st);   // (bn_y set on segment 0: the BN_BWD variant)
 // rn_conv_halo.hip (3x3 / stride 1 / pad 1)
 int rn_launch_conv_halo(const ConvArgs& a, bool out_f32, hipStream_t st);
 int rn_conv_halo_patch_pixels(int N, int H, int W, int pitch);

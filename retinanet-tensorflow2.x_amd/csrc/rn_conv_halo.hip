@@ -96,7 +96,7 @@ __device__ __forceinline__ HaloSeg halo_seg(const char* smem, int si) {
   return g;
 }
 
-template <bool OUT_F32, bool HAS_RES>
+template <bool OUT_F32, bool HAS_RES, bool BN_BWD = false>   // BN_BWD: rn_conv_big_epi.h
 __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int total = args.total_tiles;
@@ -379,7 +379,7 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
   c_par ^= 1;                                                                             \
   if (__builtin_expect(++c_chunk == c_nch, 0)) {                                          \
     HALO_EPI_PROBE(8);                                                                    \
-    big_epilogue<OUT_F32, HAS_RES>(acc, args, c_si, c_m0, c_n0, wave,                              \
+    big_epilogue<OUT_F32, HAS_RES, BN_BWD>(acc, args, c_si, c_m0, c_n0, wave,                              \
                           smem + (c_par ^ 1) * PIX_BYTES + wave * 4096 /* 32 KB of the dead 40 KB patch */); \
     HALO_EPI_PROBE(9);                                                                    \
     HALO_EPI_COUNT();                                                                     \
@@ -450,6 +450,8 @@ int rn_launch_conv_halo(const ConvArgs& a, bool out_f32, hipStream_t st) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<true, true>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<false, false, true>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
@@ -462,7 +464,9 @@ int rn_launch_conv_halo(const ConvArgs& a, bool out_f32, hipStream_t st) {
   bool has_res = false;   // one residual input anywhere -> the variant that carries the residual path
   for (int i = 0; i < a.nseg; ++i) has_res = has_res || a.seg[i].residual != nullptr;
   const dim3 g3(grid), b3(512);
-  if (out_f32) {
+  if (a.seg[0].bn_y) {   // data gradient + stage 1 of the BatchNorm backward reduction (validated by the caller)
+    hipLaunchKernelGGL((conv_halo_kernel<false, false, true>), g3, b3, LDS_BYTES, st, a);
+  } else if (out_f32) {
     if (has_res) hipLaunchKernelGGL((conv_halo_kernel<true, true>), g3, b3, LDS_BYTES, st, a);
     else hipLaunchKernelGGL((conv_halo_kernel<true, false>), g3, b3, LDS_BYTES, st, a);
   } else {

@@ -13,7 +13,7 @@ void rn_set_error(const char* fmt, ...) {
 
 extern "C" const char* rn_last_error(void) { return g_rn_err; }
 
-extern "C" int rn_abi_version(void) { return 2; }
+extern "C" int rn_abi_version(void) { return 3; }
 
 extern "C" int rn_device_ok(void) {
   int n = 0;

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("RNET_HIP_LIB") or os.path.join(_HERE, "librnet_hip.so
 RN_DT_F32, RN_DT_BF16 = 0, 1
 RN_ACT_NONE, RN_ACT_RELU, RN_ACT_RELU6, RN_ACT_SWISH = 0, 1, 2, 3
 RN_CONV_MAX_SEGMENTS = 10
-ABI_VERSION = 2
+ABI_VERSION = 3
 # f32 kernels of the dtype=float32 prediction convs (detection_head.py:80-88) as split-bf16 planes (rn_conv_segment.w_terms)
 PRED_W_TERMS = int(os.environ.get("RNET_PRED_W_TERMS", "2"))
 ACT_IDS = {None: RN_ACT_NONE, "none": RN_ACT_NONE, "relu": RN_ACT_RELU, "relu6": RN_ACT_RELU6,
@@ -43,7 +43,8 @@ class ConvSegment(Structure):
     _fields_ = [("x", c_void_p), ("w", c_void_p), ("y", c_void_p), ("scale", c_void_p), ("shift", c_void_p),
                 ("residual", c_void_p), ("N", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32),
                 ("pix_stride", c_int32), ("Ho", c_int32), ("Wo", c_int32), ("Cout", c_int32), ("bn_partial", c_void_p),
-                ("bias", c_void_p), ("w_terms", c_int32), ("pad_", c_int32)]
+                ("bias", c_void_p), ("w_terms", c_int32), ("pad_", c_int32), ("bn_bwd_y", c_void_p),
+                ("bn_bwd_fwd", c_void_p)]
 
 
 class ConvProblem(Structure):
@@ -81,7 +82,7 @@ class BnSegment(Structure):
                 ("gamma", c_void_p), ("beta", c_void_p), ("moving_mean", c_void_p), ("moving_var", c_void_p),
                 ("dgamma", c_void_p), ("dbeta", c_void_p), ("P", c_int64), ("C", c_int32),
                 ("dres_accumulate", c_int32), ("sample_scale", c_void_p), ("rows_per_sample", c_int64),
-                ("ext_chunks", c_int32), ("pad_", c_int32)]
+                ("ext_chunks", c_int32), ("ext_chunks_bwd", c_int32)]
 
 
 class BnProblem(Structure):
@@ -162,6 +163,7 @@ _SIGNATURES = {
     "rn_act_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "rn_bn_workspace_bytes": (c_size_t, [POINTER(BnProblem)]),
     "rn_bn_partial_offset_bytes": (c_size_t, [POINTER(BnProblem), c_int]),
+    "rn_bn_bwd_partial_offset_bytes": (c_size_t, [POINTER(BnProblem), c_int]),
     "rn_bn_stats": (c_int, [POINTER(BnProblem), c_void_p, c_size_t, c_void_p]),
     "rn_bn_stats_finalize": (c_int, [POINTER(BnProblem), c_void_p, c_size_t, c_void_p]),
     "rn_bn_finalize": (c_int, [POINTER(BnProblem), c_void_p]),

@@ -373,6 +373,92 @@ def test_bn_forward_stats_fused_into_conv_epilogue(cuda, k, tile):
         torch.testing.assert_close(sums[True][i], want, rtol=1e-5, atol=tol)
 
 
+@pytest.mark.parametrize("k,tile", [(1, 2), (3, 2), (1, 1), (3, 1)])
+def test_bn_backward_reduction_fused_into_the_data_gradient(cuda, k, tile):
+    """rn_conv_segment.bn_bwd_y + rn_bn_segment.ext_chunks_bwd: the launch that writes dz of a BatchNorm + ReLU layer
+    also writes stage 1 of that layer's backward reduction (sum g, sum g*y); rn_bn_bwd_reduce only runs the ordered
+    final pass and converts the raw moment.  dz must be bit-identical to the plain launch, the sums must match the
+    unfused kernels on the same stored dz (fp32 association differs) and a float64 evaluation — 128-row kernel,
+    conv_big_kernel and conv_halo_kernel, pixel tails and a channel tail (Cout 320)."""
+    from retinanet import _C
+    lib = _C.lib()
+    g = torch.Generator().manual_seed(29)
+    shapes = [(2, 19, 21, 128, 256), (1, 16, 16, 128, 320), (3, 7, 5, 128, 512)]   # N, H, W, Cin, Cout
+    pc = _C.ConvProblem()
+    pc.R = pc.S = k
+    pc.stride_h = pc.stride_w = 1
+    pc.pad_top = pc.pad_left = (k - 1) // 2
+    pc.act, pc.out_dtype, pc.num_segments = _C.RN_ACT_NONE, _C.RN_DT_BF16, len(shapes)
+    keep, dzs, segs = [], [], []
+    for i, (N, H, W, cin, cout) in enumerate(shapes):
+        x = _bf(torch.randn((N, H, W, cin), generator=g)).to(cuda)
+        w = (torch.randn((k, k, cin, cout), generator=g) / (8 * k)).to(cuda).contiguous()
+        wp = torch.empty((lib.rn_conv_cout_pad(cout), k, k, cin), dtype=torch.bfloat16, device=cuda)
+        _C.check(lib.rn_pack_conv_weight(_C.ptr(w), k, k, cin, cout, cin, _C.ptr(wp), _C.current_stream()))
+        dz = torch.empty((N, H, W, cout), dtype=torch.bfloat16, device=cuda)
+        s = pc.seg[i]
+        s.x, s.w, s.y, s.scale, s.shift, s.residual = x.data_ptr(), wp.data_ptr(), dz.data_ptr(), None, None, None
+        s.N, s.H, s.W, s.Cin, s.pix_stride, s.Ho, s.Wo, s.Cout = N, H, W, cin, cin, H, W, cout
+        keep += [x, w, wp]
+        dzs.append(dz)
+        # the BatchNorm layer whose output gradient the launch produces: raw conv output with a channel-dependent
+        # mean (the raw moment's cancellation) and about half of the units switched off by the ReLU
+        segs.append({"y": torch.randn((N, H, W, cout), generator=g) * 1.5 + torch.linspace(-3, 3, cout),
+                     "dz": torch.zeros((N, H, W, cout)),
+                     "gamma": torch.rand((cout,), generator=g) + 0.5, "beta": torch.randn((cout,), generator=g) * 0.3,
+                     "moving_mean": torch.zeros((cout,)), "moving_var": torch.ones((cout,))})
+    st = _C.current_stream()
+    lib.rn_debug_conv_tile(tile)
+    try:
+        rows = lib.rn_conv_tile_rows(ctypes.byref(pc))
+        assert rows == (256 if tile == 2 else 128)
+        if tile == 2:
+            assert lib.rn_conv_kernel_id(ctypes.byref(pc)) == (2 if k == 3 else 1)
+        out = {}
+        for fused in (False, True):
+            p, dev = _bn_problem(cuda, segs, "relu")
+            ws = None
+            for i, dz in enumerate(dzs):
+                p.seg[i].dz = dz.data_ptr()
+                if fused:
+                    P = p.seg[i].P
+                    p.seg[i].ext_chunks_bwd = 2 * ((P + 255) // 256) if rows == 256 else (P + 127) // 128
+            ws = _ws(lib.rn_bn_workspace_bytes(ctypes.byref(p)), cuda)
+            _C.check(lib.rn_bn_stats_finalize(ctypes.byref(p), _C.ptr(ws), ws.numel(), st))   # mean | invstd | scale | shift
+            _C.check(lib.rn_bn_apply(ctypes.byref(p), st))
+            ws.fill_(0x7f)    # stale bytes must not leak into the sums
+            for i in range(len(dzs)):
+                sg = pc.seg[i]
+                sg.bn_partial = (ws.data_ptr() + lib.rn_bn_bwd_partial_offset_bytes(ctypes.byref(p), i)) if fused else None
+                sg.bn_bwd_y = dev[i]["y"].data_ptr() if fused else None
+                sg.bn_bwd_fwd = dev[i]["fwd"].data_ptr() if fused else None
+                dzs[i].zero_()
+            _C.check(lib.rn_conv2d_nhwc_fwd(ctypes.byref(pc), st))
+            _C.check(lib.rn_bn_bwd_reduce(ctypes.byref(p), _C.ptr(ws), ws.numel(), st))
+            _C.check(lib.rn_bn_bwd_apply(ctypes.byref(p), st))
+            torch.cuda.synchronize()
+            out[fused] = dict(dz=[d.clone() for d in dzs], bsums=[d["bsums"].cpu().double() for d in dev],
+                              dgamma=[d["dgamma"].cpu().double() for d in dev], dbeta=[d["dbeta"].cpu().double() for d in dev],
+                              dy=[d["dy"].float().cpu() for d in dev], fwd=[d["fwd"].cpu().double() for d in dev],
+                              y=[d["y"].float().cpu().double() for d in dev])
+    finally:
+        lib.rn_debug_conv_tile(0)
+    for i in range(len(shapes)):
+        assert torch.equal(out[True]["dz"][i], out[False]["dz"][i])
+        C = shapes[i][4]
+        y = out[True]["y"][i].reshape(-1, C)
+        dz = out[True]["dz"][i].float().cpu().double().reshape(-1, C)
+        mean, istd, sc, sh = out[True]["fwd"][i]
+        gg = dz * ((y.float() * sc.float() + sh.float()) > 0).double()     # the kernels' fp32 mask
+        want = torch.stack([gg.sum(0), (gg * (y - mean) * istd).sum(0)])
+        tol = 2e-5 * want.abs().max().item()
+        torch.testing.assert_close(out[False]["bsums"][i], want, rtol=1e-4, atol=tol)
+        torch.testing.assert_close(out[True]["bsums"][i], want, rtol=1e-4, atol=tol)
+        torch.testing.assert_close(out[True]["dbeta"][i], want[0], rtol=1e-4, atol=tol)
+        torch.testing.assert_close(out[True]["dgamma"][i], want[1], rtol=1e-4, atol=tol)
+        torch.testing.assert_close(out[True]["dy"][i], out[False]["dy"][i], rtol=1 / 128, atol=1e-3 * out[False]["dy"][i].abs().max().item())
+
+
 def test_pool_topdown_balance_backward(cuda):
     from retinanet import _C
     lib = _C.lib()

@@ -29,6 +29,10 @@ PRESETS = {
     "g3_out": ([(40, 256, 1024)], 1, 1, False, True),
     "g4_3x3": ([(20, 512, 512)], 3, 1, False, False),
     "g4_a": ([(20, 2048, 512)], 1, 1, False, False),
+    "g4_out": ([(20, 512, 2048)], 1, 1, False, True),
+    "g3_sc": ([(40, 512, 1024)], 1, 1, False, False),
+    "fpn_out": ([(s, 256, 256) for s in (80, 40, 20, 10, 5)], 3, 1, False, False),
+    "fpn_lat": ([(80, 512, 256), (40, 1024, 256), (20, 2048, 256)], 1, 1, False, False),
 }
 
 
