@@ -206,10 +206,10 @@ typedef struct {
    * that arrives at a BatchNorm + ReLU layer with no residual input (y = that layer's raw conv output, same shape as
    * this launch's output; bn_bwd_fwd = its rn_bn_segment.fwd: mean | invstd | scale | shift).  With both set (and
    * bn_partial; bf16 output, no scale / shift / bias / residual / activation on the launch itself), every 128-pixel
-   * row block b writes   bn_partial[(b*2 + 0)*Cout + c] = sum g,   [(b*2 + 1)*Cout + c] = sum g*y,
-   * g = dz_stored * [y*scale + shift > 0]   (RAW second moment: rn_bn_bwd_reduce turns it into sum g*xhat =
-   * invstd * (sum g*y - mean * sum g) in its final, double-precision pass — rn_bn_segment.ext_chunks_bwd).
-   * Row blocks as for the forward statistics (rn_conv_tile_rows()).  All segments of a launch or none. */
+   * row block b writes   bn_partial[(b*2 + 0)*Cout + c] = sum g,   [(b*2 + 1)*Cout + c] = sum g*xhat,
+   * g = dz_stored * [y*scale + shift > 0], xhat = (y - mean)*invstd — what stage 1 of rn_bn_bwd_reduce computes from
+   * the same stored values (rn_bn_segment.ext_chunks_bwd).  Row blocks as for the forward statistics
+   * (rn_conv_tile_rows()).  All segments of a launch or none. */
   const void* bn_bwd_y;
   const float* bn_bwd_fwd;
 } rn_conv_segment;
@@ -365,9 +365,9 @@ typedef struct {
    * then only runs the ordered final reduction.  All segments of a problem must agree. */
   int32_t ext_chunks;
   /* > 0: stage 1 of rn_bn_bwd_reduce was written by the data-gradient launch that produced dz
-   * (rn_conv_segment.bn_bwd_y) as `ext_chunks_bwd` row blocks of (sum g, sum g*y) at workspace +
-   * rn_bn_bwd_partial_offset_bytes(); rn_bn_bwd_reduce then only runs the ordered final reduction (and converts the
-   * raw moment).  Only for act = relu / none without residual and without sample_scale.  All segments or none. */
+   * (rn_conv_segment.bn_bwd_y) as `ext_chunks_bwd` row blocks of (sum g, sum g*xhat) at workspace +
+   * rn_bn_bwd_partial_offset_bytes(); rn_bn_bwd_reduce then only runs the ordered final reduction.  Only for
+   * act = relu without residual and without sample_scale.  All segments or none. */
   int32_t ext_chunks_bwd;
 } rn_bn_segment;
 
@@ -467,6 +467,16 @@ int rn_allreduce_small(void* comm, float* ptr /* device */, int count, void* str
  */
 int rn_maxpool2d_nhwc(const void* x, void* y, int N, int H, int W, int C, int k, int stride, int pad_top,
                       int pad_left, int Ho, int Wo, void* stream);
+
+/* K1 + K6 fused for the ResNet stem with BatchNorm in inference form (`resnet_initial` frozen, builder.py:28-29;
+ * serving): Conv2D 7x7/2 fixed padding + scale/shift + relu|relu6 + MaxPool 3x3/2 (resnet.py:288-307) in one launch —
+ * the stem output never goes to HBM.  x: bf16 [N,Hp,Wp,4] from rn_pack_image_nhwc4; w_packed: rn_pack_stem_weight_rs
+ * (R = S = 7, Cout = 64); Hs x Ws: the conv output size; y: bf16 [N,Po,Qo,64].  Same arithmetic and rounding points
+ * as rn_conv2d_nhwc_fwd (R=7, S=1, Cin=32, pix_stride=4, stride 2) followed by rn_maxpool2d_nhwc: bit-identical.
+ * RN_EINVAL for any other layer shape (callers keep the two-launch path). */
+int rn_stem_conv_bn_relu_pool(const void* x, const void* w_packed, const float* scale, const float* shift, void* y,
+                              int N, int Hp, int Wp, int Hs, int Ws, int R, int Cout, int act, int pool_k,
+                              int pool_stride, int pool_pad_top, int pool_pad_left, int Po, int Qo, void* stream);
 
 /* K7 (a6)  FPN top-down path, FeatureFusion mode 'sum' + NearestUpsampling2D + activation
  * (fpn.py:93-98, feature_fusion.py:41-56, nearest_upsampling.py:19-21):

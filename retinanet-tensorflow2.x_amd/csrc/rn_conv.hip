@@ -228,6 +228,20 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_fwd_kernel(const ConvArg
     if (t == 123.456f) ((float*)sg.y)[tid] = t;
     return;
   }
+  // fused BatchNorm backward reduction (rn_conv_segment.bn_bwd_y): the y values stage 2 needs — this thread's 4
+  // channels of its BM / ROWS rows — are fetched NOW, so that their HBM latency runs under stage 1 and the barrier
+  // (loaded where they are used, behind the stores of the previous row, each launch paid ~35 us for them)
+  constexpr int E_TPR = BN / 4, E_ROWS = NTHREADS / E_TPR, E_NIT = BM / E_ROWS;
+  uint2 ypre[E_NIT];
+  if (!OUT_F32 && sg.bn_partial != nullptr && sg.bn_y != nullptr) {
+    const int er_ = tid / E_TPR, n_ = n0 + (tid % E_TPR) * 4;
+#pragma unroll
+    for (int it = 0; it < E_NIT; ++it) {
+      const int m_ = m0 + er_ + it * E_ROWS;
+      ypre[it] = make_uint2(0u, 0u);
+      if (m_ < M && n_ < sg.Cout) ypre[it] = *(const uint2*)(sg.bn_y + (long long)m_ * sg.Cout + n_);
+    }
+  }
   // stage 1: registers -> LDS fp32 [BM][BN]: conv (+bias) output and BatchNorm affine, each rounded to bf16 where
   // the reference holds a bf16 tensor between two layers (rnet_hip.h, rn_conv_segment)
   float* cl = (float*)smem;
@@ -280,18 +294,22 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_fwd_kernel(const ConvArg
   // thread's 4 channels over its rows; reduced over the workgroup's 128 rows below
   const bool stats = !OUT_F32 && sg.bn_partial != nullptr;
   // ... or stage 1 of the BatchNorm BACKWARD reduction of the layer whose dz this launch writes
-  // (rn_conv_segment.bn_bwd_y): sums of g = dz * [y*scale + shift > 0] and of g*y
+  // (rn_conv_segment.bn_bwd_y): sums of g = dz * [y*scale + shift > 0] and of g*xhat
   const bool bnbwd = stats && sg.bn_y != nullptr;
-  float bsc[4] = {0.f, 0.f, 0.f, 0.f}, bsh[4] = {0.f, 0.f, 0.f, 0.f};
+  float bsc[4] = {0.f, 0.f, 0.f, 0.f}, bsh[4] = {0.f, 0.f, 0.f, 0.f}, bmu[4] = {0.f, 0.f, 0.f, 0.f}, bis[4] = {0.f, 0.f, 0.f, 0.f};
   if (bnbwd && n < Cout) {
+    const float4 m4 = *(const float4*)(sg.bn_fwd + n), i4 = *(const float4*)(sg.bn_fwd + Cout + n);
     const float4 a4 = *(const float4*)(sg.bn_fwd + 2 * Cout + n), b4 = *(const float4*)(sg.bn_fwd + 3 * Cout + n);
+    bmu[0] = m4.x; bmu[1] = m4.y; bmu[2] = m4.z; bmu[3] = m4.w;
+    bis[0] = i4.x; bis[1] = i4.y; bis[2] = i4.z; bis[3] = i4.w;
     bsc[0] = a4.x; bsc[1] = a4.y; bsc[2] = a4.z; bsc[3] = a4.w;
     bsh[0] = b4.x; bsh[1] = b4.y; bsh[2] = b4.z; bsh[3] = b4.w;
   }
   float st0[4] = {0.f, 0.f, 0.f, 0.f}, st1[4] = {0.f, 0.f, 0.f, 0.f};
   if (n < Cout) {
-#pragma unroll 4
-    for (int rr = er; rr < BM; rr += ROWS) {
+#pragma unroll
+    for (int it = 0; it < E_NIT; ++it) {
+      const int rr = er + it * ROWS;
       const int m = m0 + rr;
       if (m >= M) break;
       float4 v = *(const float4*)(cl + rr * BN + ec);
@@ -324,14 +342,14 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_fwd_kernel(const ConvArg
           const float w4[4] = {__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xffff0000u),
                                __uint_as_float(pk.y << 16), __uint_as_float(pk.y & 0xffff0000u)};
           if (bnbwd) {
-            const uint2 yv = *(const uint2*)(sg.bn_y + o);
+            const uint2 yv = ypre[it];
             const float y4[4] = {__uint_as_float(yv.x << 16), __uint_as_float(yv.x & 0xffff0000u),
                                  __uint_as_float(yv.y << 16), __uint_as_float(yv.y & 0xffff0000u)};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               const float g = (y4[q] * bsc[q] + bsh[q]) > 0.0f ? w4[q] : 0.0f;
               st0[q] += g;
-              st1[q] += g * y4[q];
+              st1[q] += g * ((y4[q] - bmu[q]) * bis[q]);
             }
           } else {
 #pragma unroll

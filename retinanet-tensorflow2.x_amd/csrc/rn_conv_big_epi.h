@@ -116,7 +116,7 @@ __device__ __forceinline__ void big_acc_init(f32x16_t (&acc)[4][2], const ConvAr
 // wait for the previous block's stores to reach L2 (measured: 25 000 cycles per tile epilogue instead of ~5 000).
 // BN_BWD (bf16, no residual / affine / bias / activation on the launch): the launch writes dz of a BatchNorm + ReLU
 // layer; the wave also reads that layer's raw conv output y for its rows (through the residual prefetch registers)
-// and accumulates stage 1 of the backward reduction — sum g, sum g*y, g = dz_stored * [y*scale + shift > 0] — into
+// and accumulates stage 1 of the backward reduction — sum g, sum g*xhat, g = dz_stored * [y*scale + shift > 0] — into
 // bn_partial (rnet_hip.h: rn_conv_segment.bn_bwd_y).
 template <bool OUT_F32, bool HAS_RES, bool BN_BWD = false>
 __device__ __forceinline__ void big_epilogue(f32x16_t (&acc)[4][2], const ConvArgs& args, int c_si, int c_m0,
@@ -147,7 +147,19 @@ __device__ __forceinline__ void big_epilogue(f32x16_t (&acc)[4][2], const ConvAr
       const float4 a = *(const float4*)(sg.shift + nr), b = *(const float4*)(sg.shift + nr + 4);
       sf[0] = a.x; sf[1] = a.y; sf[2] = a.z; sf[3] = a.w; sf[4] = b.x; sf[5] = b.y; sf[6] = b.z; sf[7] = b.w;
     }
+    float mu[BN_BWD ? 8 : 1], is[BN_BWD ? 8 : 1];
+    if (BN_BWD) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { mu[q] = 0.0f; is[q] = 0.0f; }
+    }
     if (BN_BWD && nok) {   // the launch itself has no affine: sc / sf carry the BatchNorm layer's scale / shift (mask only)
+      const float* f0 = sg.bn_fwd + nr;
+      const float* f1 = sg.bn_fwd + Cout + nr;
+      {
+        const float4 a = *(const float4*)f0, b = *(const float4*)(f0 + 4), c = *(const float4*)f1, d = *(const float4*)(f1 + 4);
+        mu[0] = a.x; mu[1] = a.y; mu[2] = a.z; mu[3] = a.w; mu[4] = b.x; mu[5] = b.y; mu[6] = b.z; mu[7] = b.w;
+        is[0] = c.x; is[1] = c.y; is[2] = c.z; is[3] = c.w; is[4] = d.x; is[5] = d.y; is[6] = d.z; is[7] = d.w;
+      }
       const float* f2 = sg.bn_fwd + 2 * Cout + nr;
       const float* f3 = sg.bn_fwd + 3 * Cout + nr;
       const float4 a = *(const float4*)f2, b = *(const float4*)(f2 + 4), c = *(const float4*)f3, d = *(const float4*)(f3 + 4);
@@ -160,6 +172,10 @@ __device__ __forceinline__ void big_epilogue(f32x16_t (&acc)[4][2], const ConvAr
     // 8-row pass then costs a full store round trip to L2 (measured ~3 000 cycles per 32-pixel block).
 #pragma unroll
     for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(sc[q]), "+v"(sf[q]));
+    if (BN_BWD) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(mu[q]), "+v"(is[q]));
+    }
     EPI_STAMP(12);
     const bool has_res = HAS_RES && sg.residual != nullptr;
     const uint16_t* const side = BN_BWD ? sg.bn_y : sg.residual;   // the tensor the prefetch reads
@@ -278,7 +294,7 @@ _Pragma("unroll") for (int pass = 0; pass < (LOADS ? 4 : 0); ++pass) {          
               for (int q = 0; q < 8; ++q) {
                 const float g = (yy[q] * sc[q] + sf[q]) > 0.0f ? w[q] : 0.0f;
                 st0[q] += g;
-                st1[q] += g * yy[q];
+                st1[q] += g * ((yy[q] - mu[BN_BWD ? q : 0]) * is[BN_BWD ? q : 0]);
               }
             } else {
 #pragma unroll

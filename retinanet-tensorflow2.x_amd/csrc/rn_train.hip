@@ -117,7 +117,6 @@ struct BnSegDev {
 };
 struct BnArgs {
   int nseg, act, bessel, mode, fuse_finalize;
-  int raw_moment;      // mode 1 with external partials: the second sum is sum g*y, converted in the final pass
   float eps, momentum, count_scale;
   float* ws;           // partials: [seg][chunk][2][C] laid out with ws_off
   long long ws_off[RN_CONV_MAX_SEGMENTS];
@@ -243,13 +242,6 @@ __global__ void __launch_bounds__(1024) bn_colreduce_final_kernel(const BnArgs a
     if (cc < s.C) {
       double t = 0.0;
       for (int j = 0; j < 64; ++j) t += red[which][j][cl];
-      if (a.mode == 1 && a.raw_moment && which == 1) {
-        // partials written by the data-gradient epilogue: (sum g, sum g*y) -> sum g*xhat = invstd*(sum g*y - mean*sum g)
-        // (in double on the full sums: the cancellation costs nothing here)
-        double t0 = 0.0;
-        for (int j = 0; j < 64; ++j) t0 += red[0][j][cl];
-        t = (double)s.fwd[1 * s.C + cc] * (t - (double)s.fwd[0 * s.C + cc] * t0);
-      }
       float* out = a.mode == 0 ? s.sums : s.bsums;
       out[which * s.C + cc] = (float)t;
       // gamma / beta gradients are THIS replica's sums (tf.gradients of SyncBatchNormalization: only the
@@ -380,7 +372,7 @@ __global__ void __launch_bounds__(TR_THREADS) bn_bwd_apply_kernel(const BnArgs a
 // mode 0 (forward statistics) honours rn_bn_segment.ext_chunks: stage-1 partials written by the conv epilogue
 static int bn_fill(const rn_bn_problem* p, BnArgs& a, int need_ws, int mode = 1) {
   if (!p || p->num_segments < 1 || p->num_segments > RN_CONV_MAX_SEGMENTS) return -1;
-  a.nseg = p->num_segments; a.act = p->act; a.bessel = p->bessel; a.mode = 0; a.fuse_finalize = 0; a.raw_moment = 0;
+  a.nseg = p->num_segments; a.act = p->act; a.bessel = p->bessel; a.mode = 0; a.fuse_finalize = 0;
   a.eps = p->eps; a.momentum = p->momentum; a.count_scale = p->count_scale > 0 ? p->count_scale : 1.0f;
   long long off = 0;
   for (int i = 0; i < p->num_segments; ++i) {
@@ -448,7 +440,6 @@ static int bn_colreduce(const rn_bn_problem* p, int mode, void* ws, size_t ws_by
     RN_CHECK_ARG(bn_gate_mode(p) == G_U_RELU, "%s: ext_chunks_bwd needs act = relu without residual inputs", fn);
     for (int i = 0; i < p->num_segments; ++i)
       RN_CHECK_ARG(!p->seg[i].sample_scale, "%s: ext_chunks_bwd with sample_scale", fn);
-    a.raw_moment = 1;
   }
   if (!ws || ws_bytes < rn_bn_workspace_bytes(p)) {
     rn_set_error("%s: workspace too small", fn);

@@ -189,6 +189,7 @@ _SIGNATURES = {
                                   c_float, c_float, c_float, c_int, c_void_p, c_void_p]),
     "rn_prepare_image": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, POINTER(c_float),
                                  POINTER(c_float), c_float, c_void_p]),
+    "rn_stem_conv_bn_relu_pool": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 14 + [c_void_p]),
     "rn_maxpool2d_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                   c_int, c_int, c_void_p]),
     "rn_fpn_topdown": (c_int, [_PP, _PP, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

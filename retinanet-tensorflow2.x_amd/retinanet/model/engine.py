@@ -11,6 +11,7 @@ launch list is fixed — so the whole forward pass can be captured in a HIP grap
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 
@@ -21,6 +22,26 @@ _DT = {"bf16": torch.bfloat16, "f32": torch.float32}
 
 def _conv_out_hw(H, W, k, s, pad):
     return (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+
+
+def stem_pool_partner(g, stem_op, stem_k):
+    """The MaxPool op that rn_stem_conv_bn_relu_pool can absorb: the ResNet stem (7x7/2, 64 channels, relu | relu6)
+    whose only consumer is a 3x3 / stride-2 pool with SAME pads (resnet.py:288-307); None otherwise (EfficientNet's
+    3x3 swish stem has no pool).  RNET_FUSE_STEM_POOL=0 keeps the two launches."""
+    if os.environ.get("RNET_FUSE_STEM_POOL", "1") == "0":
+        return None
+    c = g.convs[stem_op["conv"]]
+    if stem_k != 7 or c["cout"] != 64 or stem_op.get("act") not in ("relu", "relu6"):
+        return None
+    users = [o for o in g.ops if stem_op["out"] in
+             [v for k, vv in o.items() if k not in ("op", "out", "outs", "conv", "bn", "act")
+              for v in (vv if isinstance(vv, (list, tuple)) else [vv]) if isinstance(v, str)]]
+    if len(users) != 1 or users[0]["op"] != "maxpool":
+        return None
+    pool = users[0]
+    if pool["k"] != 3 or pool["stride"] != 2 or pool["pad_top"] not in (0, 1) or pool["pad_left"] not in (0, 1):
+        return None
+    return pool
 
 
 class InferenceEngine:
@@ -226,6 +247,7 @@ class InferenceEngine:
         lib = self.lib
         B = self.B
         done_groups = set()
+        fused_pools = set()   # MaxPool outputs written by the fused stem launch
         for op in self.g.ops:
             kind = op["op"]
             if kind == "stem":
@@ -252,6 +274,17 @@ class InferenceEngine:
                 s.Ho, s.Wo, s.Cout = y.shape[1], y.shape[2], c["cout"]
                 self._keep.append(p)
                 pref = ctypes.byref(p)
+                pool = stem_pool_partner(self.g, op, self.stem_k)
+                if pool is not None:   # ResNet: stem + BatchNorm + relu + MaxPool in one launch, the stem output stays on chip
+                    z = self.t[pool["out"]]
+                    fa = (pin, s.w, s.scale, s.shift, z.data_ptr(), B, self.Hp, self.Wp, y.shape[1], y.shape[2], self.stem_k,
+                          c["cout"], p.act, pool["k"], pool["stride"], pool["pad_top"], pool["pad_left"], z.shape[1], z.shape[2])
+                    fused_pools.add(pool["out"])
+
+                    def stem_pool(st, fa=fa):
+                        _C.check(lib.rn_stem_conv_bn_relu_pool(*fa, st), "rn_stem_conv_bn_relu_pool")
+                    self.steps.append((stem_pool, "conv:stem"))
+                    continue
 
                 def stem(st, pref=pref):
                     _C.check(lib.rn_conv2d_nhwc_fwd(pref, st), "rn_conv2d_nhwc_fwd[stem]")
@@ -281,6 +314,8 @@ class InferenceEngine:
                     _C.check(lib.rn_squeeze_excite_inplace(*args, st), f"rn_squeeze_excite_inplace[{name}]")
                 self.steps.append((se_run, "se:" + op["tensor"]))
             elif kind == "maxpool":
+                if op["out"] in fused_pools:
+                    continue
                 x, y = self.t[op["inp"]], self.t[op["out"]]
                 args = (x.data_ptr(), y.data_ptr(), B, x.shape[1], x.shape[2], x.shape[3], op["k"], op["stride"],
                         op["pad_top"], op["pad_left"], y.shape[1], y.shape[2])

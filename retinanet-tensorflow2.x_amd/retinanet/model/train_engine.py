@@ -82,6 +82,10 @@ class TrainEngine:
         self.step_count = 0
         self.conv_profile = None
         self.fuse_bn_stats = os.environ.get("RNET_FUSE_BN_STATS", "1") != "0"   # conv epilogue writes BN partial sums
+        # data-gradient epilogue writes stage 1 of the BatchNorm backward reduction of the layer it produces dz for
+        self.fuse_bn_bwd = os.environ.get("RNET_FUSE_BN_BWD", "1") != "0"
+        self.bn_bwd_ws = {}       # id(rn_bn_problem) -> workspace that holds the externally written backward partials
+        self.bn_bwd_fused = []    # tensor names whose BatchNorm backward reduction runs in a dgrad epilogue
         # weight / bias gradient launches on a second HIP stream: nothing in the backward pass reads them, so they
         # run beside the data-gradient chain (MFMA-bound wgrad next to the HBM-bound BatchNorm backward kernels)
         self.side_stream_on = os.environ.get("RNET_WGRAD_STREAM", "1") != "0"
@@ -601,7 +605,7 @@ class TrainEngine:
         Algorithmic bytes: apply = read y + write z (+ residual); bwd_reduce = read y + dz (+ z for the residual
         layers' gate); bwd_apply = the same reads + write dy (+ dres, + its old value when accumulating)."""
         prof = self.hbm_profile
-        if prof is None:
+        if prof is None or (kind == "bn_bwd_reduce" and pb.seg[0].ext_chunks_bwd > 0):   # only the final pass is left
             return fn()
         byts = 0
         for i in range(pb.num_segments):
@@ -705,6 +709,7 @@ class TrainEngine:
     def _build_forward(self):
         lib, B = self.lib, self.B
         self.fwd_steps = []
+        self.fused_pools = set()   # MaxPool outputs written by rn_stem_conv_bn_relu_pool
         self.bn_groups = {}   # first op out -> (problem, sums, bsums, ws, dys, ops)
         self.bal_src = {}     # tensor name -> balance output tensor (consumers read the balanced copy)
         done = set()
@@ -746,7 +751,19 @@ class TrainEngine:
                         self._bn_pass("bn_apply", pb, lambda: _C.check(lib.rn_bn_apply(prb, st), "rn_bn_apply"))
                     self.fwd_steps.append(run_stem)
                 else:
-                    self.fwd_steps.append(lambda st, p=p: self._launch_conv(p, st, "stem"))
+                    from .engine import stem_pool_partner
+                    pool = stem_pool_partner(self.g, op, self.stem_k)
+                    if pool is not None and not self.requires.get(op["out"]):
+                        # frozen stem (`resnet_initial`): conv + folded BatchNorm + relu + MaxPool in one launch
+                        z = self.t[pool["out"]]
+                        fa = (pin, s.w, s.scale, s.shift, z.data_ptr(), B, self.Hp, self.Wp, y.shape[1], y.shape[2],
+                              self.stem_k, c["cout"], p.act, pool["k"], pool["stride"], pool["pad_top"], pool["pad_left"],
+                              z.shape[1], z.shape[2])
+                        self.fused_pools.add(pool["out"])
+                        self.fwd_steps.append(lambda st, fa=fa: _C.check(lib.rn_stem_conv_bn_relu_pool(*fa, st),
+                                                                         "rn_stem_conv_bn_relu_pool"))
+                    else:
+                        self.fwd_steps.append(lambda st, p=p: self._launch_conv(p, st, "stem"))
             elif kind == "conv":
                 grp = op.get("group")
                 if grp is not None:
@@ -810,6 +827,8 @@ class TrainEngine:
                      se["se"], state.data_ptr(), state.numel())
                 self.fwd_steps.append(lambda st, a=a: _C.check(lib.rn_squeeze_excite_fwd(*a, st), "rn_squeeze_excite_fwd"))
             elif kind == "maxpool":
+                if op["out"] in self.fused_pools:   # written by the fused stem launch
+                    continue
                 x, y = self.t[op["inp"]], self.t[op["out"]]
                 args = (x.data_ptr(), y.data_ptr(), B, x.shape[1], x.shape[2], x.shape[3], op["k"], op["stride"],
                         op["pad_top"], op["pad_left"], y.shape[1], y.shape[2])
@@ -992,6 +1011,7 @@ class TrainEngine:
                     s.dres = self.grad[res].data_ptr()
                     s.dres_accumulate = 0 if mark(res) else 1
             prb = ctypes.byref(pb)
+            ws = self.bn_bwd_ws.get(id(pb), ws)   # stage 1 already written there by the dgrad launch that produced dz
 
             def run(st, prb=prb, ws=ws, bsums=bsums, pb=pb):
                 self._bn_pass("bn_bwd_reduce", pb, lambda: _C.check(lib.rn_bn_bwd_reduce(prb, _C.ptr(ws), ws.numel(), st),
@@ -1172,6 +1192,41 @@ class TrainEngine:
                 _C.check(lib.rn_depthwise_conv2d_nhwc_fwd(ctypes.byref(p), st), "dw dgrad")
             self.bwd_steps.append(dgrad)
 
+    def _consumers(self, name):
+        """how many ops read tensor `name` (conv / depthwise / pooling inputs, residual inputs, top-down / balance
+        members)"""
+        if not hasattr(self, "_consumer_count"):
+            cnt = {}
+            for op in self.ops:
+                for key, val in op.items():
+                    if key in ("op", "out", "outs", "conv", "bn", "dw", "act", "group", "out_dtype", "kvar"):
+                        continue
+                    for v in (val if isinstance(val, (list, tuple)) else [val]):
+                        if isinstance(v, str) and v in self.tensors:
+                            cnt[v] = cnt.get(v, 0) + 1
+            self._consumer_count = cnt
+        return self._consumer_count.get(name, 0)
+
+    def _bn_bwd_fusable(self, name):
+        """(rn_bn_problem, segment) of the BatchNorm + ReLU layer that produced `name` when stage 1 of its backward
+        reduction can run in the epilogue of the ONE data-gradient launch that writes its dz: trainable BatchNorm,
+        relu, no residual input, no drop_connect factors, a single-segment group, a single consumer."""
+        if not self.fuse_bn_bwd or name in self.bal_src or self._consumers(name) != 1:
+            return None
+        if not hasattr(self, "_bn_of_tensor"):
+            self._bn_of_tensor = {}
+            for pb, _, _, _, _, gops in self.bn_groups.values():
+                for i, o in enumerate(gops):
+                    self._bn_of_tensor[o["out"]] = (pb, i, o, len(gops))
+        hit = self._bn_of_tensor.get(name)
+        if hit is None:
+            return None
+        pb, i, o, nseg = hit
+        if (nseg != 1 or o["op"] != "conv" or o.get("act") != "relu" or o.get("residual") or
+                o.get("survival") is not None or not self._bn_trainable(o) or pb.seg[i].sample_scale):
+            return None
+        return pb, i
+
     def _plan_dgrad_launch(self, need, dy_of, mark, packs):
         lib, B = self.lib, self.B
         c0 = self.g.convs[need[0]["conv"]]
@@ -1196,6 +1251,7 @@ class TrainEngine:
             p.R = p.S = 2
             p.pad_top = p.pad_left = 0
         d2s = []
+        plain_first = []   # per segment of the plain form: this launch is the first writer of its gradient buffer
         for i, op in enumerate(need):
             c = self.g.convs[op["conv"]]
             dy = dy_of[op["out"]]
@@ -1247,12 +1303,29 @@ class TrainEngine:
                 raise NotImplementedError("stride > 2")
             gbuf = self._gradbuf(op["inp"])
             first = mark(op["inp"] if op["inp"] not in self.bal_src else "bal:" + op["inp"])
+            plain_first.append(first and stride == 1)
             s = p.seg[i]
             s.x, s.w, s.y = src.data_ptr(), packs[op["conv"]].data_ptr(), gbuf.data_ptr()
             s.scale, s.shift = None, None
             s.residual = None if first else gbuf.data_ptr()
             s.N, s.H, s.W, s.Cin, s.pix_stride = B, src.shape[1], src.shape[2], cw, cw
             s.Ho, s.Wo, s.Cout = H, W, c["cin"]
+        # stage 1 of the BatchNorm backward reduction of the layers whose dz this launch writes (all segments or none)
+        bn_fused = 0
+        hits = [self._bn_bwd_fusable(op["inp"]) for op in need] if len(plain_first) == len(need) and all(plain_first) else []
+        if hits and all(h is not None for h in hits):
+            rows = lib.rn_conv_tile_rows(ctypes.byref(p))
+            for i, (op, (pb, j)) in enumerate(zip(need, hits)):
+                P = int(pb.seg[j].P)
+                pb.seg[j].ext_chunks_bwd = 2 * ((P + 255) // 256) if rows == 256 else (P + 127) // 128
+                wsb = torch.empty((max(lib.rn_bn_workspace_bytes(ctypes.byref(pb)), 256),), dtype=torch.uint8, device=self.dev)
+                self.bn_bwd_ws[id(pb)] = wsb
+                s = p.seg[i]
+                s.bn_partial = wsb.data_ptr() + lib.rn_bn_bwd_partial_offset_bytes(ctypes.byref(pb), j)
+                s.bn_bwd_y = self.raw[op["inp"]].data_ptr()
+                s.bn_bwd_fwd = pb.seg[j].fwd
+                self.bn_bwd_fused.append(op["inp"])
+                bn_fused += 2 * P * int(pb.seg[j].C)     # bytes of y the epilogue reads
         self._keep.append(p)
         self.conv_launches.append(("dgrad:" + (need[0].get("group") or need[0]["out"]), p))
         fl = by = 0
@@ -1264,6 +1337,7 @@ class TrainEngine:
             by += 2 * B * Ho * Wo * c["cout"] + 2 * B * x.shape[1] * x.shape[2] * c["cin"] + 2 * c["k"] * c["k"] * c["cin"] * c["cout"]
         by += sum(2 * B * self._src(o["inp"]).shape[1] * self._src(o["inp"]).shape[2] * self.g.convs[o["conv"]]["cin"]
                   for i, o in enumerate(need) if p.seg[i].residual)
+        by += bn_fused
         self._algo[id(p)] = (fl, by)
 
         def dgrad(st, p=p, ups=ups, scatters=scatters, d2s=d2s):

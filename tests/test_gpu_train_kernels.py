@@ -376,8 +376,8 @@ def test_bn_forward_stats_fused_into_conv_epilogue(cuda, k, tile):
 @pytest.mark.parametrize("k,tile", [(1, 2), (3, 2), (1, 1), (3, 1)])
 def test_bn_backward_reduction_fused_into_the_data_gradient(cuda, k, tile):
     """rn_conv_segment.bn_bwd_y + rn_bn_segment.ext_chunks_bwd: the launch that writes dz of a BatchNorm + ReLU layer
-    also writes stage 1 of that layer's backward reduction (sum g, sum g*y); rn_bn_bwd_reduce only runs the ordered
-    final pass and converts the raw moment.  dz must be bit-identical to the plain launch, the sums must match the
+    also writes stage 1 of that layer's backward reduction (sum g, sum g*xhat); rn_bn_bwd_reduce only runs the ordered
+    final pass.  dz must be bit-identical to the plain launch, the sums must match the
     unfused kernels on the same stored dz (fp32 association differs) and a float64 evaluation — 128-row kernel,
     conv_big_kernel and conv_halo_kernel, pixel tails and a channel tail (Cout 320)."""
     from retinanet import _C
@@ -402,7 +402,7 @@ def test_bn_backward_reduction_fused_into_the_data_gradient(cuda, k, tile):
         keep += [x, w, wp]
         dzs.append(dz)
         # the BatchNorm layer whose output gradient the launch produces: raw conv output with a channel-dependent
-        # mean (the raw moment's cancellation) and about half of the units switched off by the ReLU
+        # mean and about half of the units switched off by the ReLU
         segs.append({"y": torch.randn((N, H, W, cout), generator=g) * 1.5 + torch.linspace(-3, 3, cout),
                      "dz": torch.zeros((N, H, W, cout)),
                      "gamma": torch.rand((cout,), generator=g) + 0.5, "beta": torch.randn((cout,), generator=g) * 0.3,

@@ -232,6 +232,44 @@ def test_two_stream_backward_is_bit_identical(cuda):
         assert torch.equal(grads[0], grads[i]), f"run {i} differs from the one-stream gradients"
 
 
+def test_bn_backward_reduction_in_the_dgrad_epilogue_matches_the_separate_pass(cuda, monkeypatch):
+    """RNET_FUSE_BN_BWD (default on): the data-gradient launch that writes dz of a BatchNorm + ReLU layer with one
+    consumer also writes stage 1 of that layer's backward reduction.  dz itself is unchanged; (sum g, sum g*xhat)
+    come out of a different fp32 association, so every gradient must agree with the
+    separate-pass engine to fp32-summation accuracy (far inside one bf16 ulp of what follows)."""
+    p, model, eng, targets, images = _setup(cuda, 256, 4, True, freeze=True)
+    # ResNet-26 (2 bottleneck blocks per group, group 1 frozen): conv a -> b of the stride-1 blocks and conv b -> c of
+    # every block in groups 2-4
+    assert len(eng.bn_bwd_fused) == 9, eng.bn_bwd_fused
+    monkeypatch.setenv("RNET_FUSE_BN_BWD", "0")
+    from retinanet.model.train_engine import TrainEngine
+    import re
+    plain = TrainEngine(model, 4, frozen_regexes=[re.compile(r"^(conv2d|batch_normalization)(_[1-7])?/")])
+    assert plain.bn_bwd_fused == []
+    preds = eng.forward(images.to(cuda))
+    g = torch.Generator().manual_seed(7)
+    up = {k: {lv: torch.randn(preds[k][lv].shape, generator=g).to(cuda) for lv in preds[k]} for k in preds}
+    grads = []
+    for e in (eng, plain):
+        e.G.zero_()
+        e.forward(images.to(cuda), draw=False)
+        e.backward(up)
+        torch.cuda.synchronize()
+        grads.append(e.G.clone())
+    assert int((grads[0] != 0).sum()) > grads[0].numel() // 2
+    # the first fused layer of the backward order (last block of group 4, conv b -> c) receives the same dz in both
+    # engines: its gamma / beta gradients ARE the two reductions of identical inputs
+    top = next(o for o in eng.ops if o.get("out") == eng.bn_bwd_fused[0])
+    for sfx in ("/gamma", "/beta"):
+        a, b = eng._pview(top["bn"] + sfx, grads[0]).double(), plain._pview(top["bn"] + sfx, grads[1]).double()
+        assert (a - b).norm().item() <= 1e-5 * b.norm().item(), (top["bn"] + sfx, (a - b).norm().item() / b.norm().item())
+    # below it the ~1e-6 differences of the sums flip single bf16 roundings of dy, which the net amplifies like any
+    # other perturbation (see _setup): the gradients stay the same vectors to a few 1e-3
+    worst = max(((eng._pview(k, grads[0]).double() - plain._pview(k, grads[1]).double()).norm().item() /
+                 (plain._pview(k, grads[1]).double().norm().item() + 1e-30), k) for k in eng.train_names)
+    assert worst[0] < 3e-2, worst
+
+
 def test_train_step_losses_and_optimizer_arithmetic(cuda):
     """One full step with the real loss: loss values against the restatement, then the optimizer
     stages re-derived in float64 from the engine's own raw gradients (executor.py:401-407,
