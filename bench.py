@@ -21,7 +21,7 @@ conv_big_kernel, conv_fwd_kernel<128,128,64>; forward convs and every dgrad) too
 FLOPs of its launches (2*Ho*Wo*k*k*Cin*Cout of the layer: a dgrad launch counts its layer's MACs, not the
 zero-upsampled / channel-padded GEMM it executes) / sum of their HIP-event times (events recorded on the launch
 stream inside the timed steps), against 2.5 PFLOP/s dense bf16; the others are listed under `other_conv_kernels`,
-and the HBM-bound kernels (residual 1x1 convs on conv_big_kernel<false,true>, the BatchNorm passes) under
+and the HBM-bound kernels (residual 1x1 convs on conv_big_kernel<false,true,false>, the BatchNorm passes) under
 `hbm_kernels` as GB/s of algorithmic bytes against 8 TB/s.
 """
 import argparse
@@ -85,9 +85,9 @@ def conv_variant(engine, step_name):
             kid = engine.lib.rn_conv_kernel_id(ctypes.byref(p))
             res = "true" if any(p.seg[i].residual for i in range(p.num_segments)) else "false"
             if kid == 2:
-                return f"conv_halo_kernel<false, {res}> (256x256x32, 3x3 halo patch)"
+                return f"conv_halo_kernel<false, {res}, false> (256x256x32, 3x3 halo patch)"
             if kid == 1:
-                return f"conv_big_kernel<false, {res}> (256x256x32)"
+                return f"conv_big_kernel<false, {res}, false> (256x256x32)"
             return "conv_fwd_kernel<128,128,64,bf16>" if c["cout"] > 64 and c["cin"] % 64 == 0 else None
     return None
 
@@ -172,7 +172,7 @@ def run_train(args, dev, rank, world):
     for e0, e1, kind, byts in hbm:
         acc = hbm_by.setdefault(kind + "_kernel", [0.0, 0, 0])
         acc[0] += e0.elapsed_time(e1); acc[1] += byts; acc[2] += 1
-    for name in [k for k in by_kernel if k.startswith("conv_big_kernel<false, true>")]:   # residual 1x1 layers
+    for name in [k for k in by_kernel if k.startswith("conv_big_kernel<false, true, false>")]:   # residual 1x1 layers
         v = by_kernel[name]
         hbm_by[name] = [v[0], v[2], v[3]]
     hbm_kernels = {k: {"GB/s": round(v[1] / (v[0] * 1e-3) / 1e9, 1) if v[0] else 0.0,

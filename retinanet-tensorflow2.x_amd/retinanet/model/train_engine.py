@@ -506,7 +506,9 @@ class TrainEngine:
         variant = None
         kid = self.lib.rn_conv_kernel_id(ctypes.byref(p))
         has_res = any(p.seg[i].residual for i in range(p.num_segments))
-        tmpl = f"<{'true' if p.out_dtype == _C.RN_DT_F32 else 'false'}, {'true' if has_res else 'false'}>"
+        bnb = bool(p.seg[0].bn_bwd_y)   # the BN_BWD variants (stage 1 of a BatchNorm backward reduction in the epilogue)
+        tmpl = (f"<{'true' if p.out_dtype == _C.RN_DT_F32 else 'false'}, {'true' if has_res else 'false'}, "
+                f"{'true' if bnb else 'false'}>")
         if kid == 2:
             variant = "conv_halo_kernel" + tmpl + " (256x256x32, 3x3 halo patch)"
         elif kid == 1:
