@@ -369,6 +369,10 @@ typedef struct {
    * rn_bn_bwd_partial_offset_bytes(); rn_bn_bwd_reduce then only runs the ordered final reduction.  Only for
    * act = relu without residual and without sample_scale.  All segments or none. */
   int32_t ext_chunks_bwd;
+  /* optional, u8 [P*C/8]: gate bits of a relu / relu6 that follows a residual add.  rn_bn_apply writes bit (c & 7) of
+   * byte (p*C + c)/8 = [act'(z) != 0] for the bf16 z it stores; with it set on every segment rn_bn_bwd_reduce and
+   * rn_bn_bwd_apply read these P*C/8 bytes instead of z (2*P*C bytes) — same gate, same results. */
+  void* act_mask;
 } rn_bn_segment;
 
 typedef struct {

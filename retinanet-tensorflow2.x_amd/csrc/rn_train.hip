@@ -62,10 +62,12 @@ __device__ __forceinline__ float act_deriv(float z, float u, int act) {
 // How the BatchNorm backward kernels turn dz into g = dz * act'(.): decided on the host once per launch and
 // compiled in (a runtime `act` / `residual` test inside the unrolled 8-channel loops becomes a chain of scalar
 // compares and branches PER ELEMENT — the passes are then issue-bound, not HBM-bound).
-enum { G_GENERIC = 0, G_NONE = 1, G_U_RELU = 2, G_U_RELU6 = 3, G_Z_RELU = 4, G_Z_RELU6 = 5, G_SWISH = 6 };
+// G_MASK: relu / relu6 behind a residual add with the gate stored by the forward pass as ONE BIT per element
+// (rn_bn_segment.act_mask): the backward passes read P*C/8 bytes instead of the 2*P*C of z.
+enum { G_GENERIC = 0, G_NONE = 1, G_U_RELU = 2, G_U_RELU6 = 3, G_Z_RELU = 4, G_Z_RELU6 = 5, G_SWISH = 6, G_MASK = 7 };
 template <int G>
 __device__ __forceinline__ float grad_gate(float dz, float z, float u, int act, bool from_u) {
-  if (G == G_NONE) return dz;
+  if (G == G_NONE || G == G_MASK) return dz;                     // G_MASK: the caller applies the stored bit
   if (G == G_U_RELU) return u > 0.0f ? dz : 0.0f;               // rounding to bf16 never changes the sign
   if (G == G_U_RELU6) {
     const float ub = (float)(__bf16)u;                           // the op's bf16 input (see act_mask_u)
@@ -87,6 +89,9 @@ static int bn_gate_mode(const rn_bn_problem* p) {
   for (int i = 0; i < p->num_segments; ++i) with_res += p->seg[i].residual ? 1 : 0;
   if (with_res != 0 && with_res != p->num_segments) return G_GENERIC;
   if (with_res == 0) return p->act == RN_ACT_RELU ? G_U_RELU : (p->act == RN_ACT_RELU6 ? G_U_RELU6 : G_GENERIC);
+  int with_mask = 0;
+  for (int i = 0; i < p->num_segments; ++i) with_mask += p->seg[i].act_mask ? 1 : 0;
+  if (with_mask == p->num_segments && (p->act == RN_ACT_RELU || p->act == RN_ACT_RELU6)) return G_MASK;
   return p->act == RN_ACT_RELU ? G_Z_RELU : (p->act == RN_ACT_RELU6 ? G_Z_RELU6 : G_GENERIC);
 }
 #define BN_DISPATCH_GATE(mode_, CALL_)                  \
@@ -97,6 +102,7 @@ static int bn_gate_mode(const rn_bn_problem* p) {
     case G_Z_RELU: CALL_(G_Z_RELU); break;              \
     case G_Z_RELU6: CALL_(G_Z_RELU6); break;            \
     case G_SWISH: CALL_(G_SWISH); break;                \
+    case G_MASK: CALL_(G_MASK); break;                  \
     default: CALL_(G_GENERIC); break;                   \
   }
 
@@ -114,6 +120,7 @@ struct BnSegDev {
   long long P;
   int C, dres_accumulate, chunks, rows_per_chunk;
   const float* sample_scale; long long rows_per_sample;
+  unsigned char* mask;   // one bit per element: act'(z) != 0 (written by bn_apply, read by the G_MASK backward passes)
 };
 struct BnArgs {
   int nseg, act, bessel, mode, fuse_finalize;
@@ -166,12 +173,15 @@ __global__ void __launch_bounds__(TR_THREADS) bn_colreduce_kernel(const BnArgs a
         constexpr bool need_z = G == G_Z_RELU || G == G_Z_RELU6 || G == G_GENERIC;
         bf8 z;
         if (need_z && (G != G_GENERIC || (a.act != RN_ACT_NONE && !from_u))) z = unpack8(s.z[o]);
+        unsigned bits = 0xffu;
+        if (G == G_MASK) bits = s.mask[o];
         float m = 1.0f;
         if (s.sample_scale) m = s.sample_scale[(int)r / (int)s.rows_per_sample];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           const float u = y.v[q] * scq[q] + shq[q];
-          const float g = grad_gate<G < 0 ? 0 : G>(dz.v[q], z.v[q], u, a.act, from_u) * m;
+          float g = grad_gate<G < 0 ? 0 : G>(dz.v[q], z.v[q], u, a.act, from_u) * m;
+          if (G == G_MASK) g = ((bits >> q) & 1u) ? g : 0.0f;
           s0[q] += g;
           s1[q] += g * ((y.v[q] - mean[q]) * istd[q]);
         }
@@ -313,7 +323,15 @@ __global__ void __launch_bounds__(TR_THREADS) bn_apply_kernel(const BnArgs a) {
       }
     }
     rn_apply_act_n<8>(o.v, a.act);
-    s.z[i] = pack8(o);
+    const uint4 zp = pack8(o);
+    s.z[i] = zp;
+    if (s.mask) {   // gate bits of the STORED bf16 output (what the backward would otherwise re-read as z)
+      const bf8 zs = unpack8(zp);
+      unsigned bits = 0u;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) bits |= (act_mask(zs.v[q], a.act) != 0.0f ? 1u : 0u) << q;
+      s.mask[i] = (unsigned char)bits;
+    }
   }
 }
 
@@ -349,11 +367,14 @@ __global__ void __launch_bounds__(TR_THREADS) bn_bwd_apply_kernel(const BnArgs a
     bf8 z;
     if (need_z && (G != G_GENERIC || (a.act != RN_ACT_NONE && !from_u))) z = unpack8(s.z[i]);
     const float m = s.sample_scale ? s.sample_scale[(int)(i / C8) / (int)s.rows_per_sample] : 1.0f;
+    unsigned bits = 0xffu;
+    if (G == G_MASK) bits = s.mask[i];
     bf8 g, o;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const float u = y.v[q] * sc[q] + shq[q];
       g.v[q] = grad_gate<G>(dz.v[q], z.v[q], u, a.act, from_u);
+      if (G == G_MASK) g.v[q] = ((bits >> q) & 1u) ? g.v[q] : 0.0f;
       const float xh = (y.v[q] - mean[q]) * istd[q];
       o.v[q] = sc[q] * (g.v[q] * m - k1[q] - xh * k2[q]);
     }
@@ -385,6 +406,7 @@ static int bn_fill(const rn_bn_problem* p, BnArgs& a, int need_ws, int mode = 1)
     d.moving_mean = s.moving_mean; d.moving_var = s.moving_var; d.dgamma = s.dgamma; d.dbeta = s.dbeta;
     d.P = s.P; d.C = s.C; d.dres_accumulate = s.dres_accumulate;
     d.sample_scale = s.sample_scale; d.rows_per_sample = s.rows_per_sample > 0 ? s.rows_per_sample : 1;
+    d.mask = (unsigned char*)s.act_mask;
     if (s.sample_scale && p->act == RN_ACT_SWISH) return -1;   // swish' is recomputed without the factor
     // ~2048 workgroups per segment over (row chunks x 64-channel slabs): narrow layers (EfficientNet: 24..144
     // channels = 1..3 slabs) get more row chunks, so the reduction still fills the chip
@@ -455,7 +477,7 @@ static int bn_colreduce(const rn_bn_problem* p, int mode, void* ws, size_t ws_by
   for (int i = 0; i < a.nseg; ++i) {
     const BnSegDev& s = a.seg[i];
     RN_CHECK_ARG(s.y && (mode == 0 ? s.sums != nullptr : (s.dz && s.bsums && s.fwd)), "%s: null tensor", fn);
-    RN_CHECK_ARG(mode == 0 || a.act == RN_ACT_NONE || s.z, "%s: z needed for the activation mask", fn);
+    RN_CHECK_ARG(mode == 0 || a.act == RN_ACT_NONE || s.z || s.mask, "%s: z needed for the activation mask", fn);
     if (s.chunks > max_chunks) max_chunks = s.chunks;
     if ((s.C + 63) / 64 > max_slabs) max_slabs = (s.C + 63) / 64;
     if (s.C > max_c) max_c = s.C;
@@ -520,7 +542,7 @@ extern "C" int rn_bn_bwd_apply(const rn_bn_problem* p, void* stream) {
   for (int i = 0; i < a.nseg; ++i) {
     RN_CHECK_ARG(a.seg[i].y && a.seg[i].dz && a.seg[i].dy && a.seg[i].fwd && a.seg[i].bsums,
                  "rn_bn_bwd_apply: null tensor");
-    RN_CHECK_ARG(a.act == RN_ACT_NONE || a.seg[i].z, "rn_bn_bwd_apply: z needed for the activation mask");
+    RN_CHECK_ARG(a.act == RN_ACT_NONE || a.seg[i].z || a.seg[i].mask, "rn_bn_bwd_apply: z needed for the activation mask");
     const long long t = a.seg[i].P * (a.seg[i].C / 8);
     if (t > mx) mx = t;
   }

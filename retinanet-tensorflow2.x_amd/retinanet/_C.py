@@ -82,7 +82,7 @@ class BnSegment(Structure):
                 ("gamma", c_void_p), ("beta", c_void_p), ("moving_mean", c_void_p), ("moving_var", c_void_p),
                 ("dgamma", c_void_p), ("dbeta", c_void_p), ("P", c_int64), ("C", c_int32),
                 ("dres_accumulate", c_int32), ("sample_scale", c_void_p), ("rows_per_sample", c_int64),
-                ("ext_chunks", c_int32), ("ext_chunks_bwd", c_int32)]
+                ("ext_chunks", c_int32), ("ext_chunks_bwd", c_int32), ("act_mask", c_void_p)]
 
 
 class BnProblem(Structure):

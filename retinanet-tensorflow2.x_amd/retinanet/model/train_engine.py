@@ -84,6 +84,7 @@ class TrainEngine:
         self.fuse_bn_stats = os.environ.get("RNET_FUSE_BN_STATS", "1") != "0"   # conv epilogue writes BN partial sums
         # data-gradient epilogue writes stage 1 of the BatchNorm backward reduction of the layer it produces dz for
         self.fuse_bn_bwd = os.environ.get("RNET_FUSE_BN_BWD", "1") != "0"
+        self.bn_act_mask = os.environ.get("RNET_BN_ACT_MASK", "1") != "0"   # relu gates of the residual layers as bit masks
         self.bn_bwd_ws = {}       # id(rn_bn_problem) -> workspace that holds the externally written backward partials
         self.bn_bwd_fused = []    # tensor names whose BatchNorm backward reduction runs in a dgrad epilogue
         # weight / bias gradient launches on a second HIP stream: nothing in the backward pass reads them, so they
@@ -613,12 +614,13 @@ class TrainEngine:
         for i in range(pb.num_segments):
             s = pb.seg[i]
             n = int(s.P) * int(s.C) * 2
+            gate = (n // 16 if s.act_mask else n) if (s.residual and pb.act) else 0   # z, or its one-bit gate
             if kind == "bn_apply":
-                byts += n * (3 if s.residual else 2)
+                byts += n * (3 if s.residual else 2) + (n // 16 if s.act_mask else 0)
             elif kind == "bn_bwd_reduce":
-                byts += n * (3 if s.residual and pb.act else 2)
+                byts += n * 2 + gate
             else:
-                byts += n * ((3 if s.residual and pb.act else 2) + 1 + ((2 if s.dres_accumulate else 1) if s.dres else 0))
+                byts += n * 2 + gate + n * (1 + ((2 if s.dres_accumulate else 1) if s.dres else 0))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(torch.cuda.current_stream(self.dev))
         fn()
@@ -682,6 +684,12 @@ class TrainEngine:
             s.dgamma = self._pview(bn + "/gamma", self.G).data_ptr()
             s.dbeta = self._pview(bn + "/beta", self.G).data_ptr()
             s.P, s.C, s.dres_accumulate = y.shape[0] * y.shape[1] * y.shape[2], C, 0
+            if s.residual and op["act"] in ("relu", "relu6") and self.bn_act_mask:
+                # relu behind the residual add: the forward stores the gate as one bit per element, the two backward
+                # passes read P*C/8 bytes instead of z (rn_bn_segment.act_mask)
+                mk = torch.empty((int(s.P) * C // 8,), dtype=torch.uint8, device=self.dev)
+                self._keep.append(mk)
+                s.act_mask = mk.data_ptr()
             if op.get("survival") is not None and self.drop_connect:
                 if self.dc_all is None:     # one [blocks, B] tensor so that a step draws every factor at once
                     nsurv = sum(1 for o in self.ops if o.get("survival") is not None)

@@ -251,6 +251,47 @@ def _bn_problem(cuda, segs, act, eps=1e-3, momentum=0.99, bessel=1, with_bwd=Fal
     return p, dev
 
 
+@pytest.mark.parametrize("act", ["relu", "relu6"])
+def test_bn_backward_gate_from_the_bit_mask(cuda, act):
+    """rn_bn_segment.act_mask: rn_bn_apply stores the relu gate of a residual layer as one bit per element and the two
+    backward passes read it instead of z — every output must be bit-identical to the z-reading kernels."""
+    from retinanet import _C
+    lib = _C.lib()
+    g = torch.Generator().manual_seed(5)
+    shapes = [(2, 9, 7, 64), (1, 5, 5, 256), (3, 4, 4, 8)]
+    segs = [{"y": torch.randn((N, H, W, C), generator=g) * 2 + 0.5, "residual": torch.randn((N, H, W, C), generator=g) * 3,
+             "dz": torch.randn((N, H, W, C), generator=g), "gamma": torch.rand((C,), generator=g) + 0.5,
+             "beta": torch.randn((C,), generator=g) * 0.2, "moving_mean": torch.zeros((C,)), "moving_var": torch.ones((C,))}
+            for (N, H, W, C) in shapes]
+    out = {}
+    for masked in (False, True):
+        p, dev = _bn_problem(cuda, segs, act)
+        masks = []
+        for i, d in enumerate(dev):
+            p.seg[i].dres = d["dres"].data_ptr()
+            if masked:
+                masks.append(torch.full((d["y"].numel() // 8,), 0xA5, dtype=torch.uint8, device=cuda))
+                p.seg[i].act_mask = masks[-1].data_ptr()
+        ws = _ws(lib.rn_bn_workspace_bytes(ctypes.byref(p)), cuda)
+        st = _C.current_stream()
+        _C.check(lib.rn_bn_stats_finalize(ctypes.byref(p), _C.ptr(ws), ws.numel(), st))
+        _C.check(lib.rn_bn_apply(ctypes.byref(p), st))
+        if masked:
+            for d in dev:
+                d["z"].fill_(float("nan"))     # the backward must not look at z any more
+        _C.check(lib.rn_bn_bwd_reduce(ctypes.byref(p), _C.ptr(ws), ws.numel(), st))
+        _C.check(lib.rn_bn_bwd_apply(ctypes.byref(p), st))
+        torch.cuda.synchronize()
+        out[masked] = [{k: d[k].clone() for k in ("dy", "dres", "bsums", "dgamma", "dbeta")} for d in dev]
+        if masked:
+            for d, mk in zip(out[False], masks):
+                assert 0.05 < float((mk.int() != 0).float().mean()) <= 1.0
+    for a, b in zip(out[False], out[True]):
+        for k in a:
+            assert torch.equal(a[k].view(torch.int32) if a[k].dtype == torch.float32 else a[k].view(torch.int16),
+                               b[k].view(torch.int32) if b[k].dtype == torch.float32 else b[k].view(torch.int16)), k
+
+
 @pytest.mark.parametrize("act,use_res", [("relu", True), ("relu", False), (None, False), ("relu6", True),
                                          ("swish", False)])
 def test_bn_train_forward_backward(cuda, act, use_res):
