@@ -51,7 +51,12 @@ struct DwArgs {
 // (T-1)*stride + K input vectors are loaded once (all in flight together) and reused by every tap that
 // touches them: K*((T-1)*S+K) 16-byte loads per strip instead of T*K*K, fully unrolled.  (The first version
 // looped over the taps with data-dependent `continue`s: one L1/L2 round trip after the other, ~10x off HBM.)
-template <int K, int S>
+// EPI: the epilogue's shape, decided on the host and compiled in (bit 0: scale / shift, bit 1: residual input, bit 2:
+// swish; EPI_RUNTIME: the segments disagree, test at run time).  With the tests at run time every path's registers
+// count against a kernel that already sits at the 256-VGPR limit (K = 5: 780 bytes of scratch per lane and twice the
+// time, K = 3: 216 -> 252 VGPRs) — the rounding points added in round 2 did exactly that.
+constexpr int EPI_RUNTIME = 8;
+template <int K, int S, int EPI>
 __global__ void __launch_bounds__(DW_THREADS) depthwise_strip_kernel(const DwArgs a) {
   constexpr int T = 4;
   constexpr int WIN = (T - 1) * S + K;
@@ -101,43 +106,39 @@ __global__ void __launch_bounds__(DW_THREADS) depthwise_strip_kernel(const DwArg
           }
         }
       }
+#ifndef DW_NO_ROW_FENCE
+      // K = 5: the five rows' 8 + 5 loads each do not fit the register file together (65 x 4 VGPRs + 32 accumulators):
+      // left alone the compiler hoists them all and spills ~900 bytes per lane.  The fence keeps two rows (stride 2: one row of 11 + 5 loads) in flight.
+      if (K == 5 && (S == 2 || (r & 1))) asm volatile("" ::: "memory");
+#endif
     }
+    const bool affine = EPI == EPI_RUNTIME ? (s.scale != nullptr || s.shift != nullptr) : (EPI & 1) != 0;
+    const bool has_res = EPI == EPI_RUNTIME ? s.residual != nullptr : (EPI & 2) != 0;
+    const bool swish = EPI == EPI_RUNTIME ? a.act == RN_ACT_SWISH : (EPI & 4) != 0;
     float sc[8], sh[8];
+    if (affine) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      sc[q] = s.scale ? s.scale[c * 8 + q] : 1.0f;
-      sh[q] = s.shift ? s.shift[c * 8 + q] : 0.0f;
+      for (int q = 0; q < 8; ++q) {
+        sc[q] = s.scale ? s.scale[c * 8 + q] : 1.0f;
+        sh[q] = s.shift ? s.shift[c * 8 + q] : 0.0f;
+      }
     }
 #pragma unroll
     for (int tt = 0; tt < T; ++tt) {
       if (ox0 + tt >= s.Wo) break;
       const long long oi = (((long long)n * s.Ho + oy) * s.Wo + ox0 + tt) * s.C8 + c;
       bf8 o, res;
-      if (s.residual) res = unpack8(s.residual[oi]);
+      if (has_res) res = unpack8(s.residual[oi]);
       // bf16 tensors where the reference has them: DepthwiseConv2D output, BatchNorm output in front of swish
       // (rnet_hip.h, rn_conv_segment); the accumulate form (data gradients: no affine) adds in fp32, one rounding
-      const bool affine = s.scale != nullptr || s.shift != nullptr;
-      float v[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = acc[tt][q];
-      if (affine) {   // uniform branches per stage, not per element
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = rn_rb(v[q]) * sc[q] + sh[q];
+      for (int q = 0; q < 8; ++q) {
+        float v = acc[tt][q];
+        if (affine) v = rn_rb(v) * sc[q] + sh[q];
+        if (has_res) v = (affine ? rn_rb(v) : v) + res.v[q];
+        if (swish) v = rn_rb(v);
+        o.v[q] = swish ? act_exact(v, RN_ACT_SWISH) : act_exact(v, a.act);
       }
-      if (s.residual) {
-        if (affine) {
-#pragma unroll
-          for (int q = 0; q < 8; ++q) v[q] = rn_rb(v[q]);
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] += res.v[q];
-      }
-      if (a.act == RN_ACT_SWISH) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = rn_rb(v[q]);
-      }
-#pragma unroll
-      for (int q = 0; q < 8; ++q) o.v[q] = act_exact(v[q], a.act);
       s.y[oi] = pack8(o);
     }
   }
@@ -168,15 +169,30 @@ extern "C" int rn_depthwise_conv2d_nhwc_fwd(const rn_dw_problem* p, void* stream
   if (blocks > 32768) blocks = 32768;
   const dim3 grid((unsigned)blocks), block(DW_THREADS);
   hipStream_t st = (hipStream_t)stream;
-  const int key = p->k * 10 + p->stride;
-  switch (key) {
-    case 11: hipLaunchKernelGGL((depthwise_strip_kernel<1, 1>), grid, block, 0, st, a); break;
-    case 12: hipLaunchKernelGGL((depthwise_strip_kernel<1, 2>), grid, block, 0, st, a); break;
-    case 31: hipLaunchKernelGGL((depthwise_strip_kernel<3, 1>), grid, block, 0, st, a); break;
-    case 32: hipLaunchKernelGGL((depthwise_strip_kernel<3, 2>), grid, block, 0, st, a); break;
-    case 51: hipLaunchKernelGGL((depthwise_strip_kernel<5, 1>), grid, block, 0, st, a); break;
-    default: hipLaunchKernelGGL((depthwise_strip_kernel<5, 2>), grid, block, 0, st, a); break;
+  // the epilogue variant: what every segment agrees on (forward: affine + swish; data gradients: plain or accumulate)
+  int epi = ((p->seg[0].scale || p->seg[0].shift) ? 1 : 0) | (p->seg[0].residual ? 2 : 0) | (p->act == RN_ACT_SWISH ? 4 : 0);
+  for (int i = 1; i < p->num_segments; ++i) {
+    const rn_dw_segment& s = p->seg[i];
+    if ((((s.scale || s.shift) ? 1 : 0) | (s.residual ? 2 : 0)) != (epi & 3)) epi = EPI_RUNTIME;
   }
+  const int key = p->k * 10 + p->stride;
+#define DW_LAUNCH_(K_, S_)                                                                                          \
+  switch (epi) {                                                                                                    \
+    case 0: hipLaunchKernelGGL((depthwise_strip_kernel<K_, S_, 0>), grid, block, 0, st, a); break;                  \
+    case 1: hipLaunchKernelGGL((depthwise_strip_kernel<K_, S_, 1>), grid, block, 0, st, a); break;                  \
+    case 2: hipLaunchKernelGGL((depthwise_strip_kernel<K_, S_, 2>), grid, block, 0, st, a); break;                  \
+    case 5: hipLaunchKernelGGL((depthwise_strip_kernel<K_, S_, 5>), grid, block, 0, st, a); break;                  \
+    default: hipLaunchKernelGGL((depthwise_strip_kernel<K_, S_, EPI_RUNTIME>), grid, block, 0, st, a); break;       \
+  }
+  switch (key) {
+    case 11: DW_LAUNCH_(1, 1); break;
+    case 12: DW_LAUNCH_(1, 2); break;
+    case 31: DW_LAUNCH_(3, 1); break;
+    case 32: DW_LAUNCH_(3, 2); break;
+    case 51: DW_LAUNCH_(5, 1); break;
+    default: DW_LAUNCH_(5, 2); break;
+  }
+#undef DW_LAUNCH_
   RN_CHECK_LAUNCH();
   return RN_OK;
 }
