@@ -327,7 +327,9 @@ __global__ void __launch_bounds__(256) depthwise_wgrad_kernel(const DwgArgs a) {
     }
   }
   __shared__ float red[32][SLAB + 1];
-#pragma unroll 1
+  // fully unrolled: with a run-time tap index the accumulators are an indexed private array, i.e. they live in scratch
+  // memory for the whole kernel (304 / 416 bytes per lane) and every accumulate goes through it
+#pragma unroll
   for (int t = 0; t < K * K; ++t) {
 #pragma unroll
     for (int q = 0; q < CPT; ++q) red[rl][cg * CPT + q] = acc[t][q];
