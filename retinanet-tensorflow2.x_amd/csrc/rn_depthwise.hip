@@ -25,6 +25,19 @@ __device__ __forceinline__ uint4 pack8(const bf8& r) {
   u.z = rn_pack_bf16x2(r.v[4], r.v[5]); u.w = rn_pack_bf16x2(r.v[6], r.v[7]);
   return u;
 }
+// Packed fp32 pairs (v_pk_mul_f32 / v_pk_add_f32: two lanes of fp32 per VALU slot).  The depthwise kernels are
+// VALU-bound — a 5x5 tap loop is ~530 instructions per 16-byte output with scalar fp32 — and the packed forms halve
+// the multiply / add count with the same roundings (a product is still rounded before it is added).
+typedef float dw_f2 __attribute__((ext_vector_type(2)));
+struct bf8p { dw_f2 v[4]; };
+__device__ __forceinline__ bf8p unpack8p(uint4 u) {
+  bf8p r;
+  r.v[0] = dw_f2{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u)};
+  r.v[1] = dw_f2{__uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+  r.v[2] = dw_f2{__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u)};
+  r.v[3] = dw_f2{__uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u)};
+  return r;
+}
 // per-element form on purpose: with the array form (rn_apply_act_n) the 5x5 strip kernel's unrolled 4-pixel
 // epilogue compiled 4.5x slower (361 us against 79 us per launch on EfficientNet-B3)
 __device__ __forceinline__ float act_exact(float v, int act) {
@@ -73,13 +86,19 @@ __global__ void __launch_bounds__(DW_THREADS) depthwise_strip_kernel(const DwArg
     t /= strips;
     const int oy = (int)(t % (unsigned)s.Ho);
     const int n = (int)(t / (unsigned)s.Ho);
-    float acc[T][8];
+    dw_f2 acc[T][4];
 #pragma unroll
     for (int tt = 0; tt < T; ++tt)
 #pragma unroll
-      for (int q = 0; q < 8; ++q) acc[tt][q] = 0.0f;
+      for (int q = 0; q < 4; ++q) acc[tt][q] = dw_f2{0.0f, 0.0f};
     const int ix0 = ox0 * S - a.pl;
-#pragma unroll
+    // ROLLED over the filter rows: unrolled, the compiler keeps several rows' windows, weights and their unpacked
+    // floats live — 256 VGPRs + ~200 AGPRs for K = 5, one wave per SIMD — and a wave then sits out every L2 round trip
+    // alone.  Rolled: 126-166 VGPRs, 3-4 waves per SIMD; the 5x5 layers of EfficientNet-B3 run 1.9-2.3x faster
+    // (k5 / 80x80 / 288 ch, batch 32: 313 -> 156 us forward, 269 -> 116 us as a data gradient), the 3x3 ones 1.1-1.3x.
+    // (An LDS-staged variant — rows DMA'd once into a ring, fragments read from LDS — was built and measured at 198 us
+    // for the same layer: the kernel is bound by VALU issue and occupancy, not by where the window comes from.)
+#pragma unroll 1
     for (int r = 0; r < K; ++r) {
       const int iy = oy * S - a.pt + r;
       const bool rowok = (unsigned)iy < (unsigned)s.H;
@@ -95,22 +114,17 @@ __global__ void __launch_bounds__(DW_THREADS) depthwise_strip_kernel(const DwArg
       for (int ss = 0; ss < K; ++ss) wr[ss] = s.w[(long long)(r * K + ss) * s.C8 + c];
 #pragma unroll
       for (int j = 0; j < WIN; ++j) {
-        const bf8 xv = unpack8(win[j]);
+        const bf8p xv = unpack8p(win[j]);
 #pragma unroll
         for (int tt = 0; tt < T; ++tt) {
           const int ss = j - tt * S;          // compile-time after unrolling
           if (ss >= 0 && ss < K) {
-            const bf8 wv = unpack8(wr[ss]);
+            const bf8p wv = unpack8p(wr[ss]);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc[tt][q] += xv.v[q] * wv.v[q];
+            for (int q = 0; q < 4; ++q) acc[tt][q] += xv.v[q] * wv.v[q];
           }
         }
       }
-#ifndef DW_NO_ROW_FENCE
-      // K = 5: the five rows' 8 + 5 loads each do not fit the register file together (65 x 4 VGPRs + 32 accumulators):
-      // left alone the compiler hoists them all and spills ~900 bytes per lane.  The fence keeps two rows (stride 2: one row of 11 + 5 loads) in flight.
-      if (K == 5 && (S == 2 || (r & 1))) asm volatile("" ::: "memory");
-#endif
     }
     const bool affine = EPI == EPI_RUNTIME ? (s.scale != nullptr || s.shift != nullptr) : (EPI & 1) != 0;
     const bool has_res = EPI == EPI_RUNTIME ? s.residual != nullptr : (EPI & 2) != 0;
@@ -133,7 +147,7 @@ __global__ void __launch_bounds__(DW_THREADS) depthwise_strip_kernel(const DwArg
       // (rnet_hip.h, rn_conv_segment); the accumulate form (data gradients: no affine) adds in fp32, one rounding
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        float v = acc[tt][q];
+        float v = acc[tt][q >> 1][q & 1];
         if (affine) v = rn_rb(v) * sc[q] + sh[q];
         if (has_res) v = (affine ? rn_rb(v) : v) + res.v[q];
         if (swish) v = rn_rb(v);
@@ -242,6 +256,21 @@ struct DwgArgs {
   DwgSegDev seg[RN_CONV_MAX_SEGMENTS];
 };
 
+// the same as packed pairs (v_pk_mul_f32 / v_pk_add_f32 in the tap loop)
+template <int CPT>
+__device__ __forceinline__ void dwg_load_p(const uint16_t* p, dw_f2* v) {
+  if (CPT == 8) {
+    const uint4 u = *(const uint4*)p;
+    v[0] = dw_f2{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u)};
+    v[1] = dw_f2{__uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+    v[2] = dw_f2{__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u)};
+    v[3] = dw_f2{__uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u)};
+  } else {
+    const uint2 u = *(const uint2*)p;
+    v[0] = dw_f2{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u)};
+    v[1] = dw_f2{__uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+  }
+}
 // CPT consecutive bf16 channels with ONE 16-byte (CPT = 8) or 8-byte (CPT = 4) load
 template <int CPT>
 __device__ __forceinline__ void dwg_load(const uint16_t* p, float* v) {
@@ -273,11 +302,12 @@ __global__ void __launch_bounds__(256) depthwise_wgrad_kernel(const DwgArgs a) {
   const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
   const int c0 = slab * SLAB + cg * CPT;
   const bool live = c0 < a.C;
-  float acc[K * K][CPT];
+  constexpr int CP2 = CPT / 2;
+  dw_f2 acc[K * K][CP2];
 #pragma unroll
   for (int t = 0; t < K * K; ++t)
 #pragma unroll
-    for (int q = 0; q < CPT; ++q) acc[t][q] = 0.0f;
+    for (int q = 0; q < CP2; ++q) acc[t][q] = dw_f2{0.0f, 0.0f};
   const int strips = (s.Wo + T - 1) / T;
   const int items = s.N * s.Ho * strips;           // s.P holds the item count of the segment
   const int i0 = (chunk - s.chunk_begin) * a.rows_per_chunk;
@@ -288,14 +318,14 @@ __global__ void __launch_bounds__(256) depthwise_wgrad_kernel(const DwgArgs a) {
       const int t2 = it / strips;
       const int oy = t2 % s.Ho;
       const int n = t2 / s.Ho;
-      float g[T][CPT];
+      dw_f2 g[T][CP2];
 #pragma unroll
       for (int tt = 0; tt < T; ++tt) {
         if (ox0 + tt < s.Wo) {
-          dwg_load<CPT>(s.dy + (((long long)n * s.Ho + oy) * s.Wo + ox0 + tt) * a.C + c0, g[tt]);
+          dwg_load_p<CPT>(s.dy + (((long long)n * s.Ho + oy) * s.Wo + ox0 + tt) * a.C + c0, g[tt]);
         } else {
 #pragma unroll
-          for (int q = 0; q < CPT; ++q) g[tt][q] = 0.0f;
+          for (int q = 0; q < CP2; ++q) g[tt][q] = dw_f2{0.0f, 0.0f};
         }
       }
       const int ix0 = ox0 * S - a.pl;
@@ -307,19 +337,19 @@ __global__ void __launch_bounds__(256) depthwise_wgrad_kernel(const DwgArgs a) {
 #pragma unroll
         for (int j = 0; j < WIN; ++j) {
           const int ix = ix0 + j;
-          float xv[CPT];
+          dw_f2 xv[CP2];
           if ((unsigned)ix < (unsigned)s.W) {
-            dwg_load<CPT>(xrow + (long long)ix * a.C, xv);
+            dwg_load_p<CPT>(xrow + (long long)ix * a.C, xv);
           } else {
 #pragma unroll
-            for (int q = 0; q < CPT; ++q) xv[q] = 0.0f;
+            for (int q = 0; q < CP2; ++q) xv[q] = dw_f2{0.0f, 0.0f};
           }
 #pragma unroll
           for (int tt = 0; tt < T; ++tt) {
             const int ss = j - tt * S;     // compile-time after unrolling
             if (ss >= 0 && ss < K) {
 #pragma unroll
-              for (int q = 0; q < CPT; ++q) acc[r * K + ss][q] += g[tt][q] * xv[q];
+              for (int q = 0; q < CP2; ++q) acc[r * K + ss][q] += g[tt][q] * xv[q];
             }
           }
         }
@@ -332,7 +362,7 @@ __global__ void __launch_bounds__(256) depthwise_wgrad_kernel(const DwgArgs a) {
 #pragma unroll
   for (int t = 0; t < K * K; ++t) {
 #pragma unroll
-    for (int q = 0; q < CPT; ++q) red[rl][cg * CPT + q] = acc[t][q];
+    for (int q = 0; q < CPT; ++q) red[rl][cg * CPT + q] = acc[t][q >> 1][q & 1];
     __syncthreads();
     if (threadIdx.x < SLAB) {
       float sum = 0.0f;
