@@ -36,6 +36,10 @@ enum { RN_ACT_NONE = 0, RN_ACT_RELU = 1, RN_ACT_RELU6 = 2, RN_ACT_SWISH = 3 };
 const char* rn_last_error(void);
 /* library ABI version; bumped when a signature changes */
 int rn_abi_version(void);
+/* 16-bit storage type of activations / packed weights this build was compiled for: 0 = bfloat16 (librnet_hip.so,
+ * `mixed_bfloat16`), 1 = IEEE half (librnet_hip_f16.so: the same sources with -DRN_F16, `mixed_float16`).  Wherever this
+ * header says "bf16" for a tensor, the half build stores IEEE half there; RN_DT_BF16 names "the 16-bit type". */
+int rn_storage_dtype(void);
 /* 1 if a gfx950 device is visible to this process, 0 otherwise (never initialises more
  * than hipGetDeviceCount + properties) */
 int rn_device_ok(void);

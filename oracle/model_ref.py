@@ -27,30 +27,37 @@ _LAYERS = {14: [1, 1, 1, 1], 26: [2, 2, 2, 2], 50: [3, 4, 6, 3], 101: [3, 4, 23,
 
 
 class _RoundBF16(torch.autograd.Function):
-    """Round to bfloat16 in the forward AND the backward pass: what materialising an activation
-    (and, in training, its gradient) as a bf16 tensor does on the GPU path."""
+    """Round to the policy's 16-bit type (bfloat16 under mixed_bfloat16, float16 under mixed_float16) in the forward
+    AND the backward pass: what materialising an activation (and, in training, its gradient) as a 16-bit tensor does
+    on the GPU path."""
 
     @staticmethod
-    def forward(ctx, x):
-        return x.to(torch.bfloat16).to(x.dtype)
+    def forward(ctx, x, dt):
+        ctx.dt = dt
+        return x.to(dt).to(x.dtype)
 
     @staticmethod
     def backward(ctx, g):
-        return g.to(torch.bfloat16).to(g.dtype)
+        return g.to(ctx.dt).to(g.dtype), None
 
 
 def _r(x, on):
+    """`on`: False / None = no rounding, True = bfloat16, or the torch dtype itself (torch.float16: mixed_float16)."""
     if not on:
         return x
+    dt = torch.bfloat16 if on is True else on
     if x.requires_grad:
-        return _RoundBF16.apply(x)
-    return x.to(torch.bfloat16).to(x.dtype)
+        return _RoundBF16.apply(x, dt)
+    return x.to(dt).to(x.dtype)
 
 
 class RefModel:
     def __init__(self, params, variables, emulate_bf16=False, sync_bn_names=False):
         self.p = params
         self.v = {k: v.detach().to("cpu", torch.float32) for k, v in variables.items()}
+        # True = the 16-bit type of the config's mixed-precision policy (float16 under mixed_float16, else bfloat16)
+        if emulate_bf16 is True and str(getattr(getattr(params, "floatx", None), "precision", "")) == "mixed_float16":
+            emulate_bf16 = torch.float16
         self.bf = emulate_bf16
         self.eps = float(params.architecture.batch_norm.epsilon)
         self.bn_tag = "sync_batch_normalization" if sync_bn_names else "batch_normalization"

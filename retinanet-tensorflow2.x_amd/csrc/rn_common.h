@@ -33,6 +33,25 @@ int rn_reserved_cus();
 static inline int64_t rn_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t rn_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// ---- the 16-bit storage type of activations and packed weights -------------------------------------------------
+// The library is built twice from the same sources: librnet_hip.so with bfloat16 storage (the `mixed_bfloat16`
+// policy of the reference's TPU / bf16 configs, __main__.py:76-77) and, with -DRN_F16, librnet_hip_f16.so with IEEE
+// half storage (`mixed_float16`, BASELINE config 5: EfficientNet-B3 fp16 mixed precision + LossScaleOptimizer) on
+// v_mfma_f32_32x32x16_f16.  Everything below keeps its historical "bf16" name; under RN_F16 it means "the 16-bit type".
+#ifdef RN_F16
+typedef _Float16 rn_h16;
+#define RN_MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define RN_DS_READ_TR16_B64 __builtin_amdgcn_ds_read_tr16_b64_v4f16
+#define RN_SIX_X2 0x46004600u   /* 6.0 twice */
+__device__ __forceinline__ float rn_bf16_to_f32(uint16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+__device__ __forceinline__ uint16_t rn_f32_to_bf16(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }   // RNE
+__device__ __forceinline__ float rn_lo16(uint32_t u) { return rn_bf16_to_f32((uint16_t)(u & 0xffffu)); }
+__device__ __forceinline__ float rn_hi16(uint32_t u) { return rn_bf16_to_f32((uint16_t)(u >> 16)); }
+#else
+typedef __bf16 rn_h16;
+#define RN_MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#define RN_DS_READ_TR16_B64 __builtin_amdgcn_ds_read_tr16_b64_v4bf16
+#define RN_SIX_X2 0x40c040c0u   /* 6.0 twice */
 // ---- bf16 <-> f32 (round to nearest even), device side ------------------------------------
 __device__ __forceinline__ float rn_bf16_to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 __device__ __forceinline__ uint16_t rn_f32_to_bf16(float f) {
@@ -41,10 +60,13 @@ __device__ __forceinline__ uint16_t rn_f32_to_bf16(float f) {
   u += 0x7fffu + ((u >> 16) & 1u);
   return (uint16_t)(u >> 16);
 }
-// round to bf16 and back: where the reference materialises a bf16 tensor between two layers.  The hardware
+__device__ __forceinline__ float rn_lo16(uint32_t u) { return __uint_as_float(u << 16); }          // low / high element
+__device__ __forceinline__ float rn_hi16(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }  // of a packed pair
+#endif
+// round to the 16-bit type and back: where the reference materialises a 16-bit tensor between two layers.  The hardware
 // conversion (v_cvt_pk_bf16_f32, round to nearest even — the same values as rn_f32_to_bf16 for every finite input)
 // instead of the ~6-instruction integer sequence: the 128-row conv epilogue applies it to every accumulator.
-__device__ __forceinline__ float rn_rb(float v) { return (float)(__bf16)v; }
+__device__ __forceinline__ float rn_rb(float v) { return (float)(rn_h16)v; }
 __device__ __forceinline__ uint32_t rn_pack_bf16x2(float lo, float hi) {
   return (uint32_t)rn_f32_to_bf16(lo) | ((uint32_t)rn_f32_to_bf16(hi) << 16);
 }

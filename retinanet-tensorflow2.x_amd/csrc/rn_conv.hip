@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_fwd_kernel(const ConvArg
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             if (!(ABL & 4)) {
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+              acc[i][j] = RN_MFMA_32x32x16(fa[i], fb[j], acc[i][j], 0, 0, 0);
             } else {
               acc[i][j][0] += (float)fa[i][0] + (float)fb[j][0];
             }
@@ -339,12 +339,10 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_fwd_kernel(const ConvArg
         pk.y = rn_pack_bf16x2(v.z, v.w);
         *(uint2*)((uint16_t*)sg.y + o) = pk;
         if (stats) {
-          const float w4[4] = {__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xffff0000u),
-                               __uint_as_float(pk.y << 16), __uint_as_float(pk.y & 0xffff0000u)};
+          const float w4[4] = {rn_lo16(pk.x), rn_hi16(pk.x), rn_lo16(pk.y), rn_hi16(pk.y)};
           if (bnbwd) {
             const uint2 yv = ypre[it];
-            const float y4[4] = {__uint_as_float(yv.x << 16), __uint_as_float(yv.x & 0xffff0000u),
-                                 __uint_as_float(yv.y << 16), __uint_as_float(yv.y & 0xffff0000u)};
+            const float y4[4] = {rn_lo16(yv.x), rn_hi16(yv.x), rn_lo16(yv.y), rn_hi16(yv.y)};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               const float g = (y4[q] * bsc[q] + bsh[q]) > 0.0f ? w4[q] : 0.0f;

@@ -185,10 +185,10 @@ __global__ void __launch_bounds__(512) conv_big_kernel(const ConvArgs args) {
     __builtin_amdgcn_sched_barrier(0);                                                                \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                     \
       _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                   \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt0[j], px0[i], acc[i][j], 0, 0, 0);      \
+        acc[i][j] = RN_MFMA_32x32x16(wt0[j], px0[i], acc[i][j], 0, 0, 0);      \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                     \
       _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                   \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt1[j], px1[i], acc[i][j], 0, 0, 0);      \
+        acc[i][j] = RN_MFMA_32x32x16(wt1[j], px1[i], acc[i][j], 0, 0, 0);      \
     __builtin_amdgcn_sched_barrier(0);                                                                \
   } while (0)
 #define BIG_BARRIER()                       \

@@ -26,7 +26,7 @@ __device__ unsigned long long g_halo_clk[48];
 #define EPI_ABLATE 0
 #endif
 
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef rn_h16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
@@ -41,8 +41,8 @@ __device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
 __device__ __forceinline__ uint32_t pk_min_i16(uint32_t a, uint32_t b) {
   return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(i16x2_t, a), __builtin_bit_cast(i16x2_t, b)));
 }
-__device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
-__device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ float bf_lo(uint32_t u) { return rn_lo16(u); }
+__device__ __forceinline__ float bf_hi(uint32_t u) { return rn_hi16(u); }
 
 // a / b for 0 <= a < 2^22, b > 0, through the float reciprocal (rcp_b ~ 1 / b): the estimate is off by at most
 // one, fixed up with the exact remainder — ~8 VALU instructions against ~45 for the compiler's integer division.
@@ -246,8 +246,8 @@ _Pragma("unroll") for (int pass = 0; pass < (LOADS ? 4 : 0); ++pass) {          
               ov.x = pk_max_i16(ov.x, 0u); ov.y = pk_max_i16(ov.y, 0u); ov.z = pk_max_i16(ov.z, 0u); ov.w = pk_max_i16(ov.w, 0u);
             }
             if (clamp_hi) {
-              ov.x = pk_min_i16(ov.x, 0x40c040c0u); ov.y = pk_min_i16(ov.y, 0x40c040c0u);
-              ov.z = pk_min_i16(ov.z, 0x40c040c0u); ov.w = pk_min_i16(ov.w, 0x40c040c0u);
+              ov.x = pk_min_i16(ov.x, RN_SIX_X2); ov.y = pk_min_i16(ov.y, RN_SIX_X2);
+              ov.z = pk_min_i16(ov.z, RN_SIX_X2); ov.w = pk_min_i16(ov.w, RN_SIX_X2);
             }
           } else {
             const uint4 r4 = HAS_RES ? rv[i & 1][LOADS ? pass : 0] : make_uint4(0u, 0u, 0u, 0u);
@@ -278,8 +278,8 @@ _Pragma("unroll") for (int pass = 0; pass < (LOADS ? 4 : 0); ++pass) {          
               ov.x = pk_max_i16(ov.x, 0u); ov.y = pk_max_i16(ov.y, 0u); ov.z = pk_max_i16(ov.z, 0u); ov.w = pk_max_i16(ov.w, 0u);
             }
             if (clamp_hi) {
-              ov.x = pk_min_i16(ov.x, 0x40c040c0u); ov.y = pk_min_i16(ov.y, 0x40c040c0u);
-              ov.z = pk_min_i16(ov.z, 0x40c040c0u); ov.w = pk_min_i16(ov.w, 0x40c040c0u);
+              ov.x = pk_min_i16(ov.x, RN_SIX_X2); ov.y = pk_min_i16(ov.y, RN_SIX_X2);
+              ov.z = pk_min_i16(ov.z, RN_SIX_X2); ov.w = pk_min_i16(ov.w, RN_SIX_X2);
             }
           }
           if (!(EPI_ABLATE & 16) || ov.x == 0x12345678u) *(uint4*)(ybase + (long long)(i * 32 + pass * 8) * row_bytes) = ov;

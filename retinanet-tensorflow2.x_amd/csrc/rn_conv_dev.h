@@ -4,7 +4,7 @@
 #define RN_CONV_DEV_H_
 #include "rn_common.h"
 
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef rn_h16 bf16x8_t __attribute__((ext_vector_type(8)));   // 8 elements of the 16-bit storage type (rn_common.h)
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
 #define CONV_THREADS 256

@@ -15,6 +15,15 @@ extern "C" const char* rn_last_error(void) { return g_rn_err; }
 
 extern "C" int rn_abi_version(void) { return 3; }
 
+// 0: bfloat16 storage (librnet_hip.so), 1: IEEE half (librnet_hip_f16.so, built with -DRN_F16)
+extern "C" int rn_storage_dtype(void) {
+#ifdef RN_F16
+  return 1;
+#else
+  return 0;
+#endif
+}
+
 extern "C" int rn_device_ok(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {

@@ -32,10 +32,10 @@ typedef float dw_f2 __attribute__((ext_vector_type(2)));
 struct bf8p { dw_f2 v[4]; };
 __device__ __forceinline__ bf8p unpack8p(uint4 u) {
   bf8p r;
-  r.v[0] = dw_f2{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u)};
-  r.v[1] = dw_f2{__uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
-  r.v[2] = dw_f2{__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u)};
-  r.v[3] = dw_f2{__uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u)};
+  r.v[0] = dw_f2{rn_lo16(u.x), rn_hi16(u.x)};
+  r.v[1] = dw_f2{rn_lo16(u.y), rn_hi16(u.y)};
+  r.v[2] = dw_f2{rn_lo16(u.z), rn_hi16(u.z)};
+  r.v[3] = dw_f2{rn_lo16(u.w), rn_hi16(u.w)};
   return r;
 }
 // per-element form on purpose: with the array form (rn_apply_act_n) the 5x5 strip kernel's unrolled 4-pixel
@@ -261,14 +261,14 @@ template <int CPT>
 __device__ __forceinline__ void dwg_load_p(const uint16_t* p, dw_f2* v) {
   if (CPT == 8) {
     const uint4 u = *(const uint4*)p;
-    v[0] = dw_f2{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u)};
-    v[1] = dw_f2{__uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
-    v[2] = dw_f2{__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u)};
-    v[3] = dw_f2{__uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u)};
+    v[0] = dw_f2{rn_lo16(u.x), rn_hi16(u.x)};
+    v[1] = dw_f2{rn_lo16(u.y), rn_hi16(u.y)};
+    v[2] = dw_f2{rn_lo16(u.z), rn_hi16(u.z)};
+    v[3] = dw_f2{rn_lo16(u.w), rn_hi16(u.w)};
   } else {
     const uint2 u = *(const uint2*)p;
-    v[0] = dw_f2{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u)};
-    v[1] = dw_f2{__uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+    v[0] = dw_f2{rn_lo16(u.x), rn_hi16(u.x)};
+    v[1] = dw_f2{rn_lo16(u.y), rn_hi16(u.y)};
   }
 }
 // CPT consecutive bf16 channels with ONE 16-byte (CPT = 8) or 8-byte (CPT = 4) load

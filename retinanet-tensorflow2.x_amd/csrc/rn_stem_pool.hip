@@ -48,7 +48,7 @@ __device__ __forceinline__ uint32_t sp_pk_max(uint32_t a, uint32_t b) {
 }
 __device__ __forceinline__ uint32_t sp_pack2(float lo, float hi) {
   typedef float f2 __attribute__((ext_vector_type(2)));
-  typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+  typedef rn_h16 b2 __attribute__((ext_vector_type(2)));
   f2 v = {lo, hi};
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, b2));
 }
@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) stem_pool_kernel(const StemPoolAr
       for (int b = 0; b < 3; ++b) {
         if (b == 2 && !last_live) continue;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[b][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], pf[b], acc[b][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) acc[b][j] = RN_MFMA_32x32x16(wf[j], pf[b], acc[b][j], 0, 0, 0);
       }
     }
     __syncthreads();   // every wave is done reading the patch: the conv tile may overwrite it

@@ -44,7 +44,7 @@ __device__ __forceinline__ float act_mask(float z, int act) {
 __device__ __forceinline__ float act_mask_u(float u, int act) {
   if (act == RN_ACT_RELU) return u > 0.0f ? 1.0f : 0.0f;      // rounding to bf16 never changes the sign
   if (act == RN_ACT_RELU6) {
-    const float ub = (float)(__bf16)u;                         // v_cvt_pk_bf16_f32 (RNE)
+    const float ub = rn_rb(u);                                 // v_cvt_pk_bf16_f32 (RNE)
     return (ub > 0.0f && ub < 6.0f) ? 1.0f : 0.0f;
   }
   return 1.0f;
@@ -70,7 +70,7 @@ __device__ __forceinline__ float grad_gate(float dz, float z, float u, int act, 
   if (G == G_NONE || G == G_MASK) return dz;                     // G_MASK: the caller applies the stored bit
   if (G == G_U_RELU) return u > 0.0f ? dz : 0.0f;               // rounding to bf16 never changes the sign
   if (G == G_U_RELU6) {
-    const float ub = (float)(__bf16)u;                           // the op's bf16 input (see act_mask_u)
+    const float ub = rn_rb(u);                                   // the op's bf16 input (see act_mask_u)
     return (ub > 0.0f && ub < 6.0f) ? dz : 0.0f;
   }
   if (G == G_Z_RELU) return z > 0.0f ? dz : 0.0f;

@@ -33,8 +33,8 @@ __device__ __forceinline__ bf16x8_t wg_frag(const char* tile, int kb, int lane, 
   const int r0 = row0, r1 = row0 + 4;
   const lds_b4_t* p0 = (const lds_b4_t*)(tile + r0 * 256 + ((slot ^ ((r0 & 3) << 2)) << 4) + sub);
   const lds_b4_t* p1 = (const lds_b4_t*)(tile + r1 * 256 + ((slot ^ ((r1 & 3) << 2)) << 4) + sub);
-  const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_t*)p0);
-  const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_t*)p1);
+  const bf16x4_t lo = rn_ds_read_tr4(p0);
+  const bf16x4_t hi = rn_ds_read_tr4(p1);
   bf16x8_t r;
   r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
   r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wgrad_kernel(const WgArgs args)
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = RN_MFMA_32x32x16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();

@@ -46,8 +46,8 @@ __device__ __forceinline__ int frag_off(int lane, int col0) {
   return r0 * 512 + (((col >> 3) ^ ((r0 & 3) << 2)) << 4) + (col & 7) * 2;
 }
 __device__ __forceinline__ bf16x8_t frag_read(const char* p) {   // p: rows r0 (..+3 via transpose), r0 + 4 at +2048
-  const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_t*)p);
-  const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_t*)(p + 2048));
+  const bf16x4_t lo = rn_ds_read_tr4((const lds_b4_t*)p);
+  const bf16x4_t hi = rn_ds_read_tr4((const lds_b4_t*)(p + 2048));
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
@@ -227,10 +227,10 @@ __global__ void __launch_bounds__(512) wgrad_big_kernel(const WgArgs args) {
     __builtin_amdgcn_sched_barrier(0);                                                            \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
       _Pragma("unroll") for (int j = 0; j < 2; ++j)                                               \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[i], fb0[j], acc[i][j], 0, 0, 0);  \
+        acc[i][j] = RN_MFMA_32x32x16(fa0[i], fb0[j], acc[i][j], 0, 0, 0);  \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
       _Pragma("unroll") for (int j = 0; j < 2; ++j)                                               \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[i], fb1[j], acc[i][j], 0, 0, 0);  \
+        acc[i][j] = RN_MFMA_32x32x16(fa1[i], fb1[j], acc[i][j], 0, 0, 0);  \
     __builtin_amdgcn_sched_barrier(0);                                                            \
   } while (0)
 #define WGB_BARRIER()                       \

@@ -4,11 +4,21 @@
 #define RN_WGRAD_DEV_H_
 #include "rn_common.h"
 
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef rn_h16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef rn_h16 bf16x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(3))) bf16x4_t lds_b4_t;
+// ds_read_b64_tr_b16 of four 16-bit elements: the builtin is typed per element type (bf16: ext vector of __bf16;
+// f16: GCC vector of __fp16), the register contents are the same 64 bits either way
+#ifdef RN_F16
+typedef __fp16 rn_tr4_t __attribute__((__vector_size__(8)));
+#else
+typedef bf16x4_t rn_tr4_t;
+#endif
+typedef __attribute__((address_space(3))) rn_tr4_t lds_b4_t;
+__device__ __forceinline__ bf16x4_t rn_ds_read_tr4(const lds_b4_t* p) {
+  return __builtin_bit_cast(bf16x4_t, RN_DS_READ_TR16_B64((lds_b4_t*)p));
+}
 
 #define WG_THREADS 256
 #define WG_BK 64

@@ -13,6 +13,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RNET_HIP_LIB: alternative build of the same ABI (A/B timing of kernel variants on one GPU box)
 LIB_PATH = os.environ.get("RNET_HIP_LIB") or os.path.join(_HERE, "librnet_hip.so")
+LIB_PATH_F16 = os.environ.get("RNET_HIP_LIB_F16") or os.path.join(_HERE, "librnet_hip_f16.so")
 
 RN_DT_F32, RN_DT_BF16 = 0, 1
 RN_ACT_NONE, RN_ACT_RELU, RN_ACT_RELU6, RN_ACT_SWISH = 0, 1, 2, 3
@@ -94,6 +95,7 @@ _PP = POINTER(c_void_p)
 _SIGNATURES = {
     "rn_last_error": (c_char_p, []),
     "rn_abi_version": (c_int, []),
+    "rn_storage_dtype": (c_int, []),
     "rn_device_ok": (c_int, []),
     "rn_anchors_generate": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int, POINTER(c_float),
                                     POINTER(c_float), c_int, POINTER(c_float), c_int, POINTER(c_int64),
@@ -216,7 +218,7 @@ _SIGNATURES = {
                                         c_size_t]),
 }
 
-_lib = None
+_libs = {}
 
 
 def exported_symbols():
@@ -224,30 +226,37 @@ def exported_symbols():
     return sorted(_SIGNATURES)
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
+def lib(f16=False):
+    """librnet_hip.so (bfloat16 storage) or, f16=True, librnet_hip_f16.so: the same sources built with -DRN_F16 (IEEE
+    half storage + v_mfma_f32_32x32x16_f16) for the `mixed_float16` configs.  Kernels without 16-bit tensors (anchors,
+    matching, loss, post-processing, pre-processing) are identical in both."""
+    f16 = bool(f16)
+    if f16 not in _libs:
+        path = LIB_PATH_F16 if f16 else LIB_PATH
+        if not os.path.exists(path):
             raise RnetError(
-                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
         # PyTorch first: it ships its own HIP runtime, and a process must end up with ONE (librnet_hip.so then binds to
         # the copy that is already loaded; the other order gives two runtimes and "no ROCm-capable device" on launch)
         import torch  # noqa: F401
-        handle = ctypes.CDLL(LIB_PATH)
+        handle = ctypes.CDLL(path)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
         if handle.rn_abi_version() != ABI_VERSION:
-            raise RnetError(f"{LIB_PATH}: ABI version {handle.rn_abi_version()}, this binding needs {ABI_VERSION}: rebuild")
-        _lib = handle
-    return _lib
+            raise RnetError(f"{path}: ABI version {handle.rn_abi_version()}, this binding needs {ABI_VERSION}: rebuild")
+        if handle.rn_storage_dtype() != (1 if f16 else 0):
+            raise RnetError(f"{path}: built for the other 16-bit storage type: rebuild")
+        _libs[f16] = handle
+    return _libs[f16]
 
 
 def check(status: int, what: str = ""):
     if status != 0:
-        msg = lib().rn_last_error()
+        msgs = [h.rn_last_error() for h in _libs.values()]   # the failing call went to one of the loaded builds
+        msg = b" | ".join(m for m in msgs if m)
         raise RnetError(f"{what} failed with status {status}: {msg.decode() if msg else ''}")
 
 

@@ -91,10 +91,11 @@ class RetinaNetLoss:
                 gb = [grads_bf16["box-predictions"][lv] for lv in levels]
                 na = cl[0].shape[-1] // K
                 for c, b, tc, tb in zip(cl, bl, gc, gb):
-                    if (tc.dtype != torch.bfloat16 or tb.dtype != torch.bfloat16 or not tc.is_contiguous()
+                    if (tc.dtype not in (torch.bfloat16, torch.float16) or tb.dtype != tc.dtype or not tc.is_contiguous()
                             or not tb.is_contiguous() or tc.shape[:-1] != c.shape[:-1] or tb.shape[:-1] != b.shape[:-1]
                             or tc.shape[-1] != gc[0].shape[-1] or tb.shape[-1] != gb[0].shape[-1]):
-                        raise ValueError("grads_bf16 tensors must be contiguous bf16 [B,H,W,stride] like the predictions")
+                        raise ValueError("grads_bf16 tensors must be contiguous 16-bit [B,H,W,stride] like the predictions")
+                lib = _C.lib(gc[0].dtype == torch.float16)   # the build whose 16-bit type the gradient tensors hold
                 _C.check(lib.rn_retinanet_loss_fwd_bwd_bf16(
                     _C.ptr_array(cl), _C.ptr_array(bl), _C.ptr_array(gc), _C.ptr_array(gb), gc[0].shape[-1],
                     gb[0].shape[-1], na, _C.i64_array(offs), len(levels), B, K, _C.ptr(cls_t), _C.ptr(box_t),

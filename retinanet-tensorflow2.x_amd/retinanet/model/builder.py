@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import json
 import logging
+import os
 import re
 from collections import OrderedDict
 
@@ -170,7 +171,9 @@ class RetinaNetModel:
         if key not in self._engines:
             self._engines[key] = InferenceEngine(self.graph, self.variables, batch_size, self.device,
                                                  bn_epsilon=self.params.architecture.batch_norm.epsilon,
-                                                 capture_graph=capture_graph)
+                                                 capture_graph=capture_graph,
+                                                 f16=(str(self.params.floatx.precision) == "mixed_float16"
+                                                      and os.environ.get("RNET_F16", "1") != "0"))
         return self._engines[key]
 
     def train_engine(self, batch_size, process_group=None, world_size=None):

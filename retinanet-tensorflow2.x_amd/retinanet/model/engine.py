@@ -45,12 +45,15 @@ def stem_pool_partner(g, stem_op, stem_k):
 
 
 class InferenceEngine:
-    def __init__(self, graph, variables, batch_size, device, bn_epsilon=1e-3, capture_graph=False):
+    def __init__(self, graph, variables, batch_size, device, bn_epsilon=1e-3, capture_graph=False, f16=False):
         self.g = graph
         self.B = int(batch_size)
         self.dev = torch.device(device)
         self.eps = float(bn_epsilon)
-        self.lib = _C.lib()
+        self.f16 = bool(f16)   # `mixed_float16`: IEEE-half activations on librnet_hip_f16.so, else bfloat16
+        self.h16 = torch.float16 if self.f16 else self.h16
+        self._DT = {"bf16": self.h16, "f32": torch.float32}
+        self.lib = _C.lib(self.f16)
         self._keep = []     # ctypes structs / arrays that must outlive the launches
         self.steps = []     # list of (callable, name)
         self.t = {}         # tensor name -> torch tensor
@@ -65,7 +68,7 @@ class InferenceEngine:
     # ---- buffers ---------------------------------------------------------------------------
     def _alloc(self):
         for name, (H, W, C, dt) in self.g.tensors.items():
-            self.t[name] = torch.empty((self.B, H, W, C), dtype=_DT[dt], device=self.dev)
+            self.t[name] = torch.empty((self.B, H, W, C), dtype=self._DT[dt], device=self.dev)
         # first-layer conv: the image is repacked to a zero-bordered bf16 NHWC4 buffer (rn_pack_image_nhwc4)
         stem = next(o for o in self.g.ops if o["op"] == "stem")
         Hs, Ws = self.g.tensors[stem["out"]][:2]
@@ -74,7 +77,7 @@ class InferenceEngine:
         H, W, _, _ = self.g.tensors["images"]
         self.Hp = max((Hs - 1) * 2 + k, H + self.stem_pad[0])
         self.Wp = -(-max((Ws - 1) * 2 + 8, W + self.stem_pad[1]) // 8) * 8
-        self.stem_in = torch.empty((self.B, self.Hp, self.Wp, 4), dtype=torch.bfloat16, device=self.dev)
+        self.stem_in = torch.empty((self.B, self.Hp, self.Wp, 4), dtype=self.h16, device=self.dev)
         se_ops = [o for o in self.g.ops if o["op"] == "se"]
         if se_ops:
             nbytes = max(self.lib.rn_se_workspace_bytes(self.B, self.g.ses[o["se"]]["C"]) for o in se_ops)
@@ -99,9 +102,9 @@ class InferenceEngine:
                 name = op["se"]
                 se = self.g.ses[name]
                 f32 = lambda n: variables[name + n].to(self.dev, torch.float32)
-                stable(name + ":w1", f32("/conv2d/kernel").reshape(se["C"], se["se"]).t().to(torch.bfloat16))
+                stable(name + ":w1", f32("/conv2d/kernel").reshape(se["C"], se["se"]).t().to(self.h16))
                 stable(name + ":b1", f32("/conv2d/bias"))
-                stable(name + ":w2", f32("/conv2d_1/kernel").reshape(se["se"], se["C"]).t().to(torch.bfloat16))
+                stable(name + ":w2", f32("/conv2d_1/kernel").reshape(se["se"], se["C"]).t().to(self.h16))
                 stable(name + ":b2", f32("/conv2d_1/bias"))
                 continue
             if op["op"] == "dwconv":
@@ -109,7 +112,7 @@ class InferenceEngine:
                 w = variables[d["kvar"]].to(self.dev, torch.float32).contiguous()
                 buf = self.packed.get(op["dw"])
                 if buf is None:
-                    buf = torch.empty((d["k"] * d["k"], d["C"]), dtype=torch.bfloat16, device=self.dev)
+                    buf = torch.empty((d["k"] * d["k"], d["C"]), dtype=self.h16, device=self.dev)
                 _C.check(lib.rn_pack_depthwise_weight(_C.ptr(w), d["k"], d["C"], _C.ptr(buf), st),
                          "rn_pack_depthwise_weight")
                 self.packed[op["dw"]] = buf
@@ -126,7 +129,7 @@ class InferenceEngine:
                     buf = self.packed.get(cname)
                     k = self.stem_k
                     if buf is None:
-                        buf = torch.empty((cout_pad, k, 32), dtype=torch.bfloat16, device=self.dev)
+                        buf = torch.empty((cout_pad, k, 32), dtype=self.h16, device=self.dev)
                     _C.check(lib.rn_pack_stem_weight_rs(_C.ptr(w), k, k, c["cout"], _C.ptr(buf), st),
                              "rn_pack_stem_weight_rs")
                 else:
@@ -134,7 +137,7 @@ class InferenceEngine:
                     cin_pad = lib.rn_conv_cin_pad(c["cin"])
                     terms = self._w_terms(op)
                     if buf is None:
-                        buf = torch.empty((cout_pad, c["k"], c["k"], terms * cin_pad), dtype=torch.bfloat16,
+                        buf = torch.empty((cout_pad, c["k"], c["k"], terms * cin_pad), dtype=self.h16,
                                           device=self.dev)
                     if terms > 1:   # f32 layer (detection_head.py:80-88): its f32 kernel as split-bf16 planes
                         _C.check(lib.rn_pack_conv_weight_split(_C.ptr(w), 0, c["k"], c["k"], c["cin"], c["cout"], cin_pad,

@@ -53,7 +53,13 @@ class TrainEngine:
         self.params_cfg = model.params
         self.B = int(batch_size)
         self.dev = model.device
-        self.lib = _C.lib()
+        # `mixed_float16` (BASELINE config 5): IEEE-half activations / packed weights on librnet_hip_f16.so + the
+        # LossScaleOptimizer arithmetic of optimizer_step; RNET_F16=0 keeps bfloat16 storage under that policy
+        self.f16 = (str(getattr(getattr(model.params, "floatx", None), "precision", "")) == "mixed_float16"
+                    and os.environ.get("RNET_F16", "1") != "0")
+        self.h16 = torch.float16 if self.f16 else self.h16
+        self._DT = {"bf16": self.h16, "f32": torch.float32}
+        self.lib = _C.lib(self.f16)
         self.pg = process_group
         if world_size is None:   # one source of truth with RetinaNetLoss, which asks torch.distributed
             import torch.distributed as dist
@@ -211,7 +217,7 @@ class TrainEngine:
                 elif layer in f32_convs and _C.PRED_W_TERMS > 1:
                     cinp = lib.rn_conv_cin_pad(c["cin"])        # detection_head.py:80-88: the layer keeps its f32 kernel
                     buf = torch.zeros((lib.rn_conv_cout_pad(c["cout"]), c["k"], c["k"], _C.PRED_W_TERMS * cinp),
-                                      dtype=torch.bfloat16, device=self.dev)
+                                      dtype=self.h16, device=self.dev)
                     self.split_packs.append((k, c, cinp, buf))
                     self.split_pack_of[layer] = buf
                 elif lib.rn_conv_cin_pad(c["cin"]) == c["cin"]:
@@ -220,7 +226,7 @@ class TrainEngine:
                     bf_off += lib.rn_conv_cout_pad(c["cout"]) * c["k"] * c["k"] * c["cin"]
                 else:
                     cinp = lib.rn_conv_cin_pad(c["cin"])
-                    buf = torch.zeros((lib.rn_conv_cout_pad(c["cout"]), c["k"], c["k"], cinp), dtype=torch.bfloat16,
+                    buf = torch.zeros((lib.rn_conv_cout_pad(c["cout"]), c["k"], c["k"], cinp), dtype=self.h16,
                                       device=self.dev)
                     self.fwd_packs.append((k, c, cinp, buf))
                     self.fwd_pack_of[layer] = buf
@@ -244,7 +250,7 @@ class TrainEngine:
         self.G = torch.zeros_like(self.P)
         self.V = torch.zeros_like(self.P)
         self.E = torch.zeros_like(self.P)
-        self.Pbf = torch.zeros((max(bf_off, 8),), dtype=torch.bfloat16, device=self.dev)
+        self.Pbf = torch.zeros((max(bf_off, 8),), dtype=self.h16, device=self.dev)
         self._bf_copies = [(self.p_off[k], s[6]) for k, s in zip(names, segs) if s[6] >= 0]
         seg_np = np.zeros((len(segs),), dtype=_SEG_DTYPE)
         for i, s in enumerate(segs):
@@ -294,7 +300,7 @@ class TrainEngine:
             c = self.g.convs[op["conv"]]
             k = c["k"]
             if getattr(self, "stem_packed", None) is None:
-                self.stem_packed = torch.zeros((self.lib.rn_conv_cout_pad(c["cout"]), k, 32), dtype=torch.bfloat16,
+                self.stem_packed = torch.zeros((self.lib.rn_conv_cout_pad(c["cout"]), k, 32), dtype=self.h16,
                                                device=self.dev)
             w = _ohwi_to_hwio(self._pview(self._kvar(op)).reshape(c["cout"], k, k, 3))
             _C.check(self.lib.rn_pack_stem_weight_rs(_C.ptr(w), k, k, c["cout"], _C.ptr(self.stem_packed), st),
@@ -381,7 +387,7 @@ class TrainEngine:
         B, dev = self.B, self.dev
         self.t, self.raw, self.grad = {}, {}, {}
         for name, (H, W, C, dt) in self.tensors.items():
-            self.t[name] = torch.empty((B, H, W, C), dtype=_DT[dt], device=dev)
+            self.t[name] = torch.empty((B, H, W, C), dtype=self._DT[dt], device=dev)
         # first-layer conv: zero-bordered bf16 NHWC4 copy of the image (rn_pack_image_nhwc4)
         stem = self._stem_op()
         Hs, Ws = self.tensors[stem["out"]][:2]
@@ -390,7 +396,7 @@ class TrainEngine:
         H, W, _, _ = self.tensors["images"]
         self.Hp = max((Hs - 1) * 2 + self.stem_k, H + self.stem_pad[0])
         self.Wp = -(-max((Ws - 1) * 2 + 8, W + self.stem_pad[1]) // 8) * 8
-        self.stem_in = torch.empty((B, self.Hp, self.Wp, 4), dtype=torch.bfloat16, device=dev)
+        self.stem_in = torch.empty((B, self.Hp, self.Wp, 4), dtype=self.h16, device=dev)
         for op in self.ops:
             if op["op"] in ("conv", "stem", "dwconv") and self._bn_trainable(op):
                 self.raw[op["out"]] = torch.empty_like(self.t[op["out"]])
@@ -427,7 +433,7 @@ class TrainEngine:
                         need.add(n)
         for n in need:
             H, W, C, _ = self.tensors[n]
-            self.grad[n] = torch.zeros((B, H, W, C), dtype=torch.bfloat16, device=dev)
+            self.grad[n] = torch.zeros((B, H, W, C), dtype=self.h16, device=dev)
         for n, t in self.bal_out.items():
             self.grad["bal:" + n] = torch.zeros_like(t)
         self.bn_state = {}
@@ -451,12 +457,12 @@ class TrainEngine:
             w = v[self._kvar(op)].to(self.dev, torch.float32).contiguous()
             cp = lib.rn_conv_cout_pad(c["cout"])
             if op["op"] == "stem":
-                buf = torch.empty((cp, c["k"], 32), dtype=torch.bfloat16, device=self.dev)
+                buf = torch.empty((cp, c["k"], 32), dtype=self.h16, device=self.dev)
                 _C.check(lib.rn_pack_stem_weight_rs(_C.ptr(w), c["k"], c["k"], c["cout"], _C.ptr(buf), st),
                          "rn_pack_stem_weight_rs")
             else:
                 cinp = lib.rn_conv_cin_pad(c["cin"])
-                buf = torch.empty((cp, c["k"], c["k"], cinp), dtype=torch.bfloat16, device=self.dev)
+                buf = torch.empty((cp, c["k"], c["k"], cinp), dtype=self.h16, device=self.dev)
                 _C.check(lib.rn_pack_conv_weight(_C.ptr(w), c["k"], c["k"], c["cin"], c["cout"], cinp,
                                                  _C.ptr(buf), st), "rn_pack_conv_weight")
             self.packed_frozen[cname] = buf
@@ -1038,7 +1044,7 @@ class TrainEngine:
                 if op["out_dtype"] == "f32":      # prediction convs: loss gradient arrives in fp32
                     shp = list(self.t[op["out"]].shape)
                     shp[3] = (shp[3] + 63) // 64 * 64     # K dimension of the dgrad GEMM: pad 36/720 -> 64/768
-                    dyb = torch.zeros(shp, dtype=torch.bfloat16, device=self.dev)
+                    dyb = torch.zeros(shp, dtype=self.h16, device=self.dev)
                     dy_of[op["out"]] = dyb
                 else:
                     dyb = torch.empty_like(self.t[op["out"]])
@@ -1171,7 +1177,7 @@ class TrainEngine:
             for i, op in enumerate(sub):
                 d = self.g.dws[op["dw"]]
                 if op["dw"] not in flips:
-                    buf = torch.empty((k * k, d["C"]), dtype=torch.bfloat16, device=self.dev)
+                    buf = torch.empty((k * k, d["C"]), dtype=self.h16, device=self.dev)
                     flips[op["dw"]] = buf
                     off, _ = self.p_off[d["kvar"]]
                     self.dw_flip_packs.append((self.P.data_ptr() + 4 * off, k, d["C"], buf))
@@ -1179,7 +1185,7 @@ class TrainEngine:
                 x = self._src(op["inp"])
                 H, W = x.shape[1], x.shape[2]
                 if stride == 2:
-                    up = torch.empty((B, H, W, d["C"]), dtype=torch.bfloat16, device=self.dev)
+                    up = torch.empty((B, H, W, d["C"]), dtype=self.h16, device=self.dev)
                     ups.append((dy.data_ptr(), up.data_ptr(), B, dy.shape[1], dy.shape[2], d["C"], H, W))
                     self._keep.append(up)
                     src = up
@@ -1269,9 +1275,9 @@ class TrainEngine:
             cwp = lib.rn_conv_cin_pad(cw)     # K of the dgrad GEMM, zero padded in the packed weights only
             if op["conv"] not in packs:
                 if subpixel:
-                    buf = torch.empty((lib.rn_conv_cout_pad(4 * c["cin"]), 2, 2, cwp), dtype=torch.bfloat16, device=self.dev)
+                    buf = torch.empty((lib.rn_conv_cout_pad(4 * c["cin"]), 2, 2, cwp), dtype=self.h16, device=self.dev)
                 else:
-                    buf = torch.empty((lib.rn_conv_cout_pad(c["cin"]), k, k, cwp), dtype=torch.bfloat16, device=self.dev)
+                    buf = torch.empty((lib.rn_conv_cout_pad(c["cin"]), k, k, cwp), dtype=self.h16, device=self.dev)
                 packs[op["conv"]] = buf
                 off, _ = self.p_off[c.get("kvar", op["conv"] + "/kernel")]
                 self.dgrad_packs.append((self.P.data_ptr() + 4 * off, k, c["cin"], c["cout"], cwp, buf, 1 if subpixel else 0))
@@ -1280,7 +1286,7 @@ class TrainEngine:
             if subpixel:
                 gbuf = self._gradbuf(op["inp"])
                 first = mark(op["inp"] if op["inp"] not in self.bal_src else "bal:" + op["inp"])
-                tmp = torch.empty((B, dy.shape[1], dy.shape[2], 4 * c["cin"]), dtype=torch.bfloat16, device=self.dev)
+                tmp = torch.empty((B, dy.shape[1], dy.shape[2], 4 * c["cin"]), dtype=self.h16, device=self.dev)
                 self._keep.append(tmp)
                 d2s.append((tmp.data_ptr(), gbuf.data_ptr(), B, dy.shape[1], dy.shape[2], c["cin"], 0 if first else 1))
                 s = p.seg[i]
@@ -1292,7 +1298,7 @@ class TrainEngine:
             if lowres:
                 gbuf = self._gradbuf(op["inp"])
                 first = mark(op["inp"] if op["inp"] not in self.bal_src else "bal:" + op["inp"])
-                tmp = torch.empty((B, dy.shape[1], dy.shape[2], c["cin"]), dtype=torch.bfloat16, device=self.dev)
+                tmp = torch.empty((B, dy.shape[1], dy.shape[2], c["cin"]), dtype=self.h16, device=self.dev)
                 self._keep.append(tmp)
                 scatters.append((tmp.data_ptr(), gbuf.data_ptr(), B, dy.shape[1], dy.shape[2], c["cin"], H, W,
                                  0 if first else 1))
@@ -1303,7 +1309,7 @@ class TrainEngine:
                 s.Ho, s.Wo, s.Cout = dy.shape[1], dy.shape[2], c["cin"]
                 continue
             if stride == 2:
-                up = torch.empty((B, H, W, cw), dtype=torch.bfloat16, device=self.dev)
+                up = torch.empty((B, H, W, cw), dtype=self.h16, device=self.dev)
                 ups.append((dy.data_ptr(), up.data_ptr(), B, dy.shape[1], dy.shape[2], cw, H, W))
                 self._keep.append(up)
                 src = up

@@ -24,6 +24,16 @@ def test_library_exports_every_declared_symbol():
     assert lib.rn_abi_version() == _C.ABI_VERSION
 
 
+def test_half_build_exports_the_same_interface():
+    """librnet_hip_f16.so: the same sources compiled with -DRN_F16 (IEEE-half storage, `mixed_float16` configs)"""
+    from retinanet import _C
+    lib = _C.lib(True)
+    for name in _declared():
+        assert hasattr(lib, name), name
+    assert lib.rn_abi_version() == _C.ABI_VERSION
+    assert lib.rn_storage_dtype() == 1 and _C.lib().rn_storage_dtype() == 0
+
+
 def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "retinanet-tensorflow2.x_amd")
     for d, _, files in os.walk(pkg):

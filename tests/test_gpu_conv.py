@@ -15,8 +15,18 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
+# the 16-bit storage type under test: tests/test_gpu_f16.py re-runs cases of this module with torch.float16 on
+# librnet_hip_f16.so (the same sources built with -DRN_F16)
+H16 = torch.bfloat16
+
+
+def _lib():
+    from retinanet import _C
+    return _C.lib(H16 == torch.float16)
+
+
 def _bf(x):
-    return x.to(torch.bfloat16)
+    return x.to(H16)
 
 
 def _seed(case):
@@ -26,7 +36,7 @@ def _seed(case):
 
 def _conv_gpu(cuda, segs, k, stride, pad, act, out_f32):
     from retinanet import _C
-    lib = _C.lib()
+    lib = _lib()
     p = _C.ConvProblem()
     p.R = p.S = k
     p.stride_h = p.stride_w = stride
@@ -41,7 +51,7 @@ def _conv_gpu(cuda, segs, k, stride, pad, act, out_f32):
         kk, _, cin, cout = w.shape
         cinp = lib.rn_conv_cin_pad(cin)
         terms = int(s.get("w_terms", 1))
-        wp = torch.empty((lib.rn_conv_cout_pad(cout), kk, kk, terms * cinp), dtype=torch.bfloat16, device=cuda)
+        wp = torch.empty((lib.rn_conv_cout_pad(cout), kk, kk, terms * cinp), dtype=H16, device=cuda)
         if terms > 1:
             _C.check(lib.rn_pack_conv_weight_split(_C.ptr(w), 0, kk, kk, cin, cout, cinp, terms, _C.ptr(wp),
                                                    _C.current_stream()))
@@ -49,7 +59,7 @@ def _conv_gpu(cuda, segs, k, stride, pad, act, out_f32):
             _C.check(lib.rn_pack_conv_weight(_C.ptr(w), kk, kk, cin, cout, cinp, _C.ptr(wp), _C.current_stream()))
         N, H, W, _ = x.shape
         Ho, Wo = (H + 2 * pad - kk) // stride + 1, (W + 2 * pad - kk) // stride + 1
-        y = torch.empty((N, Ho, Wo, cout), dtype=torch.float32 if out_f32 else torch.bfloat16, device=cuda)
+        y = torch.empty((N, Ho, Wo, cout), dtype=torch.float32 if out_f32 else H16, device=cuda)
         sc = s.get("scale"); sh = s.get("shift"); res = s.get("residual"); bs = s.get("bias")
         sc = None if sc is None else sc.to(cuda).float().contiguous()
         sh = None if sh is None else sh.to(cuda).float().contiguous()
@@ -156,7 +166,7 @@ def test_conv_big_tile_kernel(cuda, case):
     """Same cases through the 256x256x32 four-stage kernel (rn_conv_big.hip; normally picked only
     when the launch has >= 192 such tiles)."""
     from retinanet import _C
-    lib = _C.lib()
+    lib = _lib()
     lib.rn_debug_conv_tile(2)
     try:
         test_conv_single(cuda, case)
@@ -185,7 +195,7 @@ def test_conv_halo_kernel(cuda, case):
     """3x3 / stride 1 / pad 1 with Cout >= 256 through the halo-patch kernel (rn_conv_halo.hip), against the
     float64 reference and against conv_big_kernel on the same inputs (same products, other summation order)."""
     from retinanet import _C
-    lib = _C.lib()
+    lib = _lib()
     N, H, W, Cin, Cout, act, use_res, out_f32 = case
     g = torch.Generator().manual_seed(_seed(case))
     s = {"x": torch.randn((N, H, W, Cin), generator=g),
@@ -236,7 +246,7 @@ def test_conv_bias_only_rounds_once(cuda, case):
     against the float64 restatement at most a sliver of the outputs may sit one bf16 step off (fp32 summation
     order)."""
     from retinanet import _C
-    lib = _C.lib()
+    lib = _lib()
     N, H, W, Cin, Cout, k, act, grid = case
     g = torch.Generator().manual_seed(_seed(case))
     s = {"x": torch.randn((N, H, W, Cin), generator=g),
@@ -270,7 +280,7 @@ def test_conv_bias_then_batchnorm_rounding_points(cuda, case):
     """Conv2D(+bias) -> BatchNormalization (-> + residual) as ONE launch: bias before the first rounding, scale /
     shift after it, the residual after the second — on every kernel the dispatcher can pick."""
     from retinanet import _C
-    lib = _C.lib()
+    lib = _lib()
     N, H, W, Cin, Cout, k, act, use_res, kid = case
     g = torch.Generator().manual_seed(_seed(case))
     s = {"x": torch.randn((N, H, W, Cin), generator=g),
@@ -308,7 +318,7 @@ def test_conv_f32_weights_as_split_bf16_planes(cuda, case):
     the product with the untouched f32 kernel the 2-plane form is within 2^-16 per weight (<= 3e-5), the 3-plane
     form exact to fp32.  One plane (plain bf16 weights, what round 1 shipped) is ~1e-3 off: measured below."""
     from retinanet import _C
-    lib = _C.lib()
+    lib = _lib()
     N, H, W, Cin, Cout, k, terms, kid = case
     g = torch.Generator().manual_seed(_seed(case))
     s = {"x": torch.randn((N, H, W, Cin), generator=g).relu(),          # tower outputs are post-ReLU
@@ -344,7 +354,7 @@ def test_conv_halo_asymmetric_weights(cuda):
     """Exact shift test through the halo kernel: output channel c = input channel (c+1)%C read through tap
     (r=0, s=2), i.e. pixel (y-1, x+1); borders must be exact zeros."""
     from retinanet import _C
-    lib = _C.lib()
+    lib = _lib()
     C = 256
     x = (torch.arange(2 * 9 * 11 * C, dtype=torch.float32).reshape(2, 9, 11, C) * 7) % 61
     w = torch.zeros((3, 3, C, C))
@@ -392,7 +402,7 @@ def test_conv_grouped_pyramid(cuda):
 def test_stem_conv(cuda):
     """7x7 s2 stem through the packed NHWC4 image + [64][7][32] weights (resnet.py:297-300)."""
     from retinanet import _C
-    lib = _C.lib()
+    lib = _lib()
     g = torch.Generator().manual_seed(9)
     N, H, W = 2, 64, 96
     img = torch.randn((N, H, W, 3), generator=g)
@@ -400,12 +410,12 @@ def test_stem_conv(cuda):
     scale, shift = torch.rand((64,), generator=g) + 0.5, torch.randn((64,), generator=g) * 0.1
     Wp = lib.rn_stem_padded_width(W)
     imd = img.to(cuda).contiguous()
-    packed = torch.empty((N, H + 6, Wp, 4), dtype=torch.bfloat16, device=cuda)
+    packed = torch.empty((N, H + 6, Wp, 4), dtype=H16, device=cuda)
     _C.check(lib.rn_pack_stem_input(_C.ptr(imd), N, H, W, _C.ptr(packed), _C.current_stream()))
     wd = w.to(cuda).contiguous()
-    wp = torch.empty((64, 7, 32), dtype=torch.bfloat16, device=cuda)
+    wp = torch.empty((64, 7, 32), dtype=H16, device=cuda)
     _C.check(lib.rn_pack_stem_weight(_C.ptr(wd), 64, _C.ptr(wp), _C.current_stream()))
-    y = torch.empty((N, H // 2, W // 2, 64), dtype=torch.bfloat16, device=cuda)
+    y = torch.empty((N, H // 2, W // 2, 64), dtype=H16, device=cuda)
     sc, sh = scale.to(cuda), shift.to(cuda)
     p = _C.ConvProblem()
     p.R, p.S, p.stride_h, p.stride_w, p.pad_top, p.pad_left = 7, 1, 2, 2, 0, 0
@@ -425,11 +435,11 @@ def test_stem_conv(cuda):
 
 def test_maxpool_same_and_valid(cuda):
     from retinanet import _C
-    lib = _C.lib()
+    lib = _lib()
     g = torch.Generator().manual_seed(2)
     x = _bf(torch.randn((2, 20, 20, 64), generator=g))
     xd = x.to(cuda)
-    y = torch.empty((2, 10, 10, 64), dtype=torch.bfloat16, device=cuda)
+    y = torch.empty((2, 10, 10, 64), dtype=H16, device=cuda)
     # 3x3 s2 SAME on an even size: pad 0 top/left, 1 bottom/right
     _C.check(lib.rn_maxpool2d_nhwc(_C.ptr(xd), _C.ptr(y), 2, 20, 20, 64, 3, 2, 0, 0, 10, 10, _C.current_stream()))
     xp = F.pad(x.float().permute(0, 3, 1, 2), (0, 1, 0, 1), value=float("-inf"))
@@ -445,7 +455,7 @@ def _pyramid(g, N, H0, C, L=5):
 @pytest.mark.parametrize("act", ["relu", "relu6"])
 def test_fpn_topdown(cuda, act):
     from retinanet import _C
-    lib = _C.lib()
+    lib = _lib()
     g = torch.Generator().manual_seed(3)
     pyr = _pyramid(g, 2, 32, 64)
     ins = [p.to(cuda) for p in pyr]
@@ -464,7 +474,7 @@ def test_fpn_topdown(cuda, act):
 
 def test_balance_features(cuda):
     from retinanet import _C
-    lib = _C.lib()
+    lib = _lib()
     g = torch.Generator().manual_seed(4)
     pyr = _pyramid(g, 2, 32, 64)
     ts = [p.to(cuda).clone() for p in pyr]

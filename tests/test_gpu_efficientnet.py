@@ -483,5 +483,5 @@ def test_efficientnet_train_steps_reduce_loss(cuda):
     still = [k for k, d in moved if d == 0.0 and "kernel" in k.rsplit("/", 1)[-1]]
     assert not still, still[:10]
     for (off, n), bfo in eng._bf_copies:   # bf16 compute copies follow the f32 masters
-        torch.testing.assert_close(eng.Pbf[bfo:bfo + n].float(), eng.P[off:off + n].to(torch.bfloat16).float(), rtol=0, atol=0)
+        torch.testing.assert_close(eng.Pbf[bfo:bfo + n].float(), eng.P[off:off + n].to(eng.h16).float(), rtol=0, atol=0)
 
