@@ -51,7 +51,7 @@ class InferenceEngine:
         self.dev = torch.device(device)
         self.eps = float(bn_epsilon)
         self.f16 = bool(f16)   # `mixed_float16`: IEEE-half activations on librnet_hip_f16.so, else bfloat16
-        self.h16 = torch.float16 if self.f16 else self.h16
+        self.h16 = torch.float16 if self.f16 else torch.bfloat16
         self._DT = {"bf16": self.h16, "f32": torch.float32}
         self.lib = _C.lib(self.f16)
         self._keep = []     # ctypes structs / arrays that must outlive the launches

@@ -57,7 +57,7 @@ class TrainEngine:
         # LossScaleOptimizer arithmetic of optimizer_step; RNET_F16=0 keeps bfloat16 storage under that policy
         self.f16 = (str(getattr(getattr(model.params, "floatx", None), "precision", "")) == "mixed_float16"
                     and os.environ.get("RNET_F16", "1") != "0")
-        self.h16 = torch.float16 if self.f16 else self.h16
+        self.h16 = torch.float16 if self.f16 else torch.bfloat16
         self._DT = {"bf16": self.h16, "f32": torch.float32}
         self.lib = _C.lib(self.f16)
         self.pg = process_group
