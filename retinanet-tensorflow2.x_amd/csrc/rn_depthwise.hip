@@ -4,8 +4,10 @@
 //     in fpn_base.py:28-39 / detection_head.py:37-50), TF SAME padding, fused BN scale/shift + act;
 //   * squeeze-and-excitation (efficientnet.py:222-265): global average pool, the two 1x1 "convs" on
 //     the pooled vector (swish, sigmoid) and the per-(image, channel) gate.
-// All HBM-bound: bf16 NHWC, 8 channels (16 B) per thread, fp32 math.  Grouped like the GEMM convs so
-// the five pyramid levels of a shared separable head conv go out in one launch.
+// 16-bit NHWC (rn_common.h: bfloat16, or IEEE half in the -DRN_F16 build), 8 channels (16 B) per thread, fp32 math.
+// HBM-bound in principle; the k x k tap loops are VALU-issue bound in practice (packed fp32 pairs, rolled filter rows:
+// see depthwise_strip_kernel).  Grouped like the GEMM convs so the five pyramid levels of a shared separable head conv
+// go out in one launch.
 #include "rn_common.h"
 
 #define DW_THREADS 256
