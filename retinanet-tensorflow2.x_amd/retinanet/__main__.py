@@ -57,7 +57,8 @@ def main(argv=None):
         logging.warning("Running in multi_host mode")
     if FLAGS.xla:
         logging.warning("--xla: there is no tracing compiler in this build; ignored")
-    logging.info("Compute dtype: %s", "bfloat16" if "16" in params.floatx.precision else "float32")
+    logging.info("Compute dtype: %s", {"mixed_bfloat16": "bfloat16", "mixed_float16": "float16"}.get(
+        str(params.floatx.precision), "float32"))
     logging.info("Variable dtype: float32")
 
     strategy = get_strategy(params.training.strategy)
