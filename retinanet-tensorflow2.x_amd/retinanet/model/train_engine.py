@@ -1238,7 +1238,7 @@ class TrainEngine:
         if hit is None:
             return None
         pb, i, o, nseg = hit
-        if (nseg != 1 or o["op"] != "conv" or o.get("act") != "relu" or o.get("residual") or
+        if (o["op"] != "conv" or o.get("act") != "relu" or o.get("residual") or
                 o.get("survival") is not None or not self._bn_trainable(o) or pb.seg[i].sample_scale):
             return None
         return pb, i
@@ -1329,19 +1329,30 @@ class TrainEngine:
         # stage 1 of the BatchNorm backward reduction of the layers whose dz this launch writes (all segments or none)
         bn_fused = 0
         hits = [self._bn_bwd_fusable(op["inp"]) for op in need] if len(plain_first) == len(need) and all(plain_first) else []
-        if hits and all(h is not None for h in hits):
+        # all segments of a BatchNorm problem or none: the launch must write dz of EVERY segment of each problem it
+        # touches (the head towers: one launch per tower depth over both heads x five levels = the ten segments of
+        # that depth's BatchNorm group), each exactly once
+        ok = bool(hits) and all(h is not None for h in hits)
+        if ok:
+            by_pb = {}
+            for pb, j in hits:
+                by_pb.setdefault(id(pb), (pb, []))[1].append(j)
+            ok = all(sorted(js) == list(range(pb.num_segments)) for pb, js in by_pb.values())
+        if ok:
             rows = lib.rn_conv_tile_rows(ctypes.byref(p))
-            for i, (op, (pb, j)) in enumerate(zip(need, hits)):
+            for pb, j in hits:
                 P = int(pb.seg[j].P)
                 pb.seg[j].ext_chunks_bwd = 2 * ((P + 255) // 256) if rows == 256 else (P + 127) // 128
-                wsb = torch.empty((max(lib.rn_bn_workspace_bytes(ctypes.byref(pb)), 256),), dtype=torch.uint8, device=self.dev)
-                self.bn_bwd_ws[id(pb)] = wsb
+            for pb, _ in by_pb.values():
+                self.bn_bwd_ws[id(pb)] = torch.empty((max(lib.rn_bn_workspace_bytes(ctypes.byref(pb)), 256),),
+                                                     dtype=torch.uint8, device=self.dev)
+            for i, (op, (pb, j)) in enumerate(zip(need, hits)):
                 s = p.seg[i]
-                s.bn_partial = wsb.data_ptr() + lib.rn_bn_bwd_partial_offset_bytes(ctypes.byref(pb), j)
+                s.bn_partial = self.bn_bwd_ws[id(pb)].data_ptr() + lib.rn_bn_bwd_partial_offset_bytes(ctypes.byref(pb), j)
                 s.bn_bwd_y = self.raw[op["inp"]].data_ptr()
                 s.bn_bwd_fwd = pb.seg[j].fwd
                 self.bn_bwd_fused.append(op["inp"])
-                bn_fused += 2 * P * int(pb.seg[j].C)     # bytes of y the epilogue reads
+                bn_fused += 2 * int(pb.seg[j].P) * int(pb.seg[j].C)     # bytes of y the epilogue reads
         self._keep.append(p)
         self.conv_launches.append(("dgrad:" + (need[0].get("group") or need[0]["out"]), p))
         fl = by = 0

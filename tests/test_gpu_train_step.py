@@ -240,7 +240,8 @@ def test_bn_backward_reduction_in_the_dgrad_epilogue_matches_the_separate_pass(c
     p, model, eng, targets, images = _setup(cuda, 256, 4, True, freeze=True)
     # ResNet-26 (2 bottleneck blocks per group, group 1 frozen): conv a -> b of the stride-1 blocks and conv b -> c of
     # every block in groups 2-4
-    assert len(eng.bn_bwd_fused) == 9, eng.bn_bwd_fused
+    # ... + the ten segments (two heads x five levels) of head-tower depths 0-2: 9 + 30
+    assert len(eng.bn_bwd_fused) == 39, eng.bn_bwd_fused
     monkeypatch.setenv("RNET_FUSE_BN_BWD", "0")
     from retinanet.model.train_engine import TrainEngine
     import re
@@ -257,8 +258,9 @@ def test_bn_backward_reduction_in_the_dgrad_epilogue_matches_the_separate_pass(c
         torch.cuda.synchronize()
         grads.append(e.G.clone())
     assert int((grads[0] != 0).sum()) > grads[0].numel() // 2
-    # the first fused layer of the backward order (last block of group 4, conv b -> c) receives the same dz in both
-    # engines: its gamma / beta gradients ARE the two reductions of identical inputs
+    # the first fused layer of the backward order (head-tower depth 2, whose dz comes out of the depth-3 conv's data
+    # gradient: nothing above it is fused) receives the same dz in both engines: its gamma / beta gradients ARE the two
+    # reductions of identical inputs
     top = next(o for o in eng.ops if o.get("out") == eng.bn_bwd_fused[0])
     for sfx in ("/gamma", "/beta"):
         a, b = eng._pview(top["bn"] + sfx, grads[0]).double(), plain._pview(top["bn"] + sfx, grads[1]).double()
@@ -266,7 +268,8 @@ def test_bn_backward_reduction_in_the_dgrad_epilogue_matches_the_separate_pass(c
     # below it the ~1e-6 differences of the sums flip single bf16 roundings of dy, which the net amplifies like any
     # other perturbation (see _setup): the gradients stay the same vectors to a few 1e-3
     worst = max(((eng._pview(k, grads[0]).double() - plain._pview(k, grads[1]).double()).norm().item() /
-                 (plain._pview(k, grads[1]).double().norm().item() + 1e-30), k) for k in eng.train_names)
+                 (plain._pview(k, grads[1]).double().norm().item() + 1e-30), k) for k in eng.train_names
+                if not (k.endswith("/bias") and "prediction" not in k))   # bias in front of BatchNorm: zero gradient, pure noise
     assert worst[0] < 3e-2, worst
 
 
