@@ -92,6 +92,7 @@ class TrainEngine:
         self.fuse_bn_bwd = os.environ.get("RNET_FUSE_BN_BWD", "1") != "0"
         self.bn_act_mask = os.environ.get("RNET_BN_ACT_MASK", "1") != "0"   # relu gates of the residual layers as bit masks
         self.bn_bwd_ws = {}       # id(rn_bn_problem) -> workspace that holds the externally written backward partials
+        self._bn_bwd_pending = {}  # id(rn_bn_problem) -> segments whose dz-writing launch is planned (see _plan_dgrad_launch)
         self.bn_bwd_fused = []    # tensor names whose BatchNorm backward reduction runs in a dgrad epilogue
         # weight / bias gradient launches on a second HIP stream: nothing in the backward pass reads them, so they
         # run beside the data-gradient chain (MFMA-bound wgrad next to the HBM-bound BatchNorm backward kernels)
@@ -110,6 +111,10 @@ class TrainEngine:
             self._fold_frozen()
             self._build_forward()
             self._build_backward()
+            for name, cp in self.conv_launches:   # a launch writes stage-1 BatchNorm partials for all its segments or none
+                marks = {bool(cp.seg[i].bn_bwd_y) for i in range(cp.num_segments)}
+                if name.startswith("dgrad:") and len(marks) != 1:
+                    raise RuntimeError(f"{name}: BatchNorm backward fusion covers only part of the launch's segments")
 
     # ------------------------------------------------------------------------------------------
     def _prepare_graph(self):
@@ -1329,30 +1334,40 @@ class TrainEngine:
         # stage 1 of the BatchNorm backward reduction of the layers whose dz this launch writes (all segments or none)
         bn_fused = 0
         hits = [self._bn_bwd_fusable(op["inp"]) for op in need] if len(plain_first) == len(need) and all(plain_first) else []
-        # all segments of a BatchNorm problem or none: the launch must write dz of EVERY segment of each problem it
-        # touches (the head towers: one launch per tower depth over both heads x five levels = the ten segments of
-        # that depth's BatchNorm group), each exactly once
-        ok = bool(hits) and all(h is not None for h in hits)
-        if ok:
-            by_pb = {}
-            for pb, j in hits:
-                by_pb.setdefault(id(pb), (pb, []))[1].append(j)
-            ok = all(sorted(js) == list(range(pb.num_segments)) for pb, js in by_pb.values())
-        if ok:
+        # all segments of a BatchNorm problem or none (rn_bn_bwd_reduce): a problem is switched over once the launches
+        # planned so far write dz of EVERY one of its segments, each exactly once — one launch for a bottleneck layer,
+        # one launch over both heads x five levels for head-tower depths 0-2, the two prediction convs' data gradients
+        # together for depth 3.  Until then the assignments wait in self._bn_bwd_pending; the rn_conv_problem structs
+        # are read at launch time, so they can still be patched when the last segment turns up.
+        if hits and all(h is not None for h in hits):
             rows = lib.rn_conv_tile_rows(ctypes.byref(p))
-            for pb, j in hits:
-                P = int(pb.seg[j].P)
-                pb.seg[j].ext_chunks_bwd = 2 * ((P + 255) // 256) if rows == 256 else (P + 127) // 128
-            for pb, _ in by_pb.values():
-                self.bn_bwd_ws[id(pb)] = torch.empty((max(lib.rn_bn_workspace_bytes(ctypes.byref(pb)), 256),),
-                                                     dtype=torch.uint8, device=self.dev)
             for i, (op, (pb, j)) in enumerate(zip(need, hits)):
-                s = p.seg[i]
-                s.bn_partial = self.bn_bwd_ws[id(pb)].data_ptr() + lib.rn_bn_bwd_partial_offset_bytes(ctypes.byref(pb), j)
-                s.bn_bwd_y = self.raw[op["inp"]].data_ptr()
-                s.bn_bwd_fwd = pb.seg[j].fwd
-                self.bn_bwd_fused.append(op["inp"])
-                bn_fused += 2 * int(pb.seg[j].P) * int(pb.seg[j].C)     # bytes of y the epilogue reads
+                pend = self._bn_bwd_pending.setdefault(id(pb), {"pb": pb, "seg": {}})
+                if j in pend["seg"]:          # a second writer: not a single-consumer layer after all
+                    pend["dead"] = True
+                pend["seg"][j] = (p, i, op["inp"], rows)
+            for key in {id(pb) for pb, _ in hits}:
+                pend = self._bn_bwd_pending[key]
+                pb = pend["pb"]
+                if pend.get("dead") or pend.get("done") or sorted(pend["seg"]) != list(range(pb.num_segments)):
+                    continue
+                pend["done"] = True
+                for j, (_, _, _, r) in pend["seg"].items():
+                    P = int(pb.seg[j].P)
+                    pb.seg[j].ext_chunks_bwd = 2 * ((P + 255) // 256) if r == 256 else (P + 127) // 128
+                wsb = torch.empty((max(lib.rn_bn_workspace_bytes(ctypes.byref(pb)), 256),), dtype=torch.uint8, device=self.dev)
+                self.bn_bwd_ws[key] = wsb
+                for j, (cp, ci, name, _) in pend["seg"].items():
+                    sg = cp.seg[ci]
+                    sg.bn_partial = wsb.data_ptr() + lib.rn_bn_bwd_partial_offset_bytes(ctypes.byref(pb), j)
+                    sg.bn_bwd_y = self.raw[name].data_ptr()
+                    sg.bn_bwd_fwd = pb.seg[j].fwd
+                    self.bn_bwd_fused.append(name)
+                    if id(cp) in self._algo:    # an earlier launch: add the bytes of y its epilogue now reads
+                        fl0, by0 = self._algo[id(cp)]
+                        self._algo[id(cp)] = (fl0, by0 + 2 * int(pb.seg[j].P) * int(pb.seg[j].C))
+                    else:
+                        bn_fused += 2 * int(pb.seg[j].P) * int(pb.seg[j].C)
         self._keep.append(p)
         self.conv_launches.append(("dgrad:" + (need[0].get("group") or need[0]["out"]), p))
         fl = by = 0

@@ -240,8 +240,8 @@ def test_bn_backward_reduction_in_the_dgrad_epilogue_matches_the_separate_pass(c
     p, model, eng, targets, images = _setup(cuda, 256, 4, True, freeze=True)
     # ResNet-26 (2 bottleneck blocks per group, group 1 frozen): conv a -> b of the stride-1 blocks and conv b -> c of
     # every block in groups 2-4
-    # ... + the ten segments (two heads x five levels) of head-tower depths 0-2: 9 + 30
-    assert len(eng.bn_bwd_fused) == 39, eng.bn_bwd_fused
+    # ... + the ten segments (two heads x five levels) of each of the four head-tower depths: 9 + 40
+    assert len(eng.bn_bwd_fused) == 49, eng.bn_bwd_fused
     monkeypatch.setenv("RNET_FUSE_BN_BWD", "0")
     from retinanet.model.train_engine import TrainEngine
     import re
@@ -258,7 +258,7 @@ def test_bn_backward_reduction_in_the_dgrad_epilogue_matches_the_separate_pass(c
         torch.cuda.synchronize()
         grads.append(e.G.clone())
     assert int((grads[0] != 0).sum()) > grads[0].numel() // 2
-    # the first fused layer of the backward order (head-tower depth 2, whose dz comes out of the depth-3 conv's data
+    # the first fused layer of the backward order (head-tower depth 3, whose dz comes out of a prediction conv's data
     # gradient: nothing above it is fused) receives the same dz in both engines: its gamma / beta gradients ARE the two
     # reductions of identical inputs
     top = next(o for o in eng.ops if o.get("out") == eng.bn_bwd_fused[0])
