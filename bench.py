@@ -26,6 +26,7 @@ and the HBM-bound kernels (residual 1x1 convs on conv_big_kernel<false,true,fals
 """
 import argparse
 import json
+import re
 import os
 import sys
 import time
@@ -159,20 +160,27 @@ def run_train(args, dev, rank, world):
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
-    # per kernel variant: [ms, flops, bytes, launches]; the dominant kernel is the one with most time
-    def per_kernel(events):
+    # per kernel: [ms, flops, bytes, launches]; the dominant kernel is the one with most time.  The third template flag
+    # of the 256-row kernels (BN_BWD: the epilogue also writes stage 1 of a BatchNorm backward reduction) does not make
+    # another kernel — same K loop, same tiles — so its two device symbols are ONE roofline entry, with the
+    # per-symbol figures kept under `symbols` (what a rocprof kernel-stats row can be matched against).
+    def family(variant):
+        return re.sub(r"^(conv_(?:halo|big)_kernel<\w+, \w+), \w+>", r"\1, *>", variant)
+
+    def per_kernel(events, key=family):
         acc_by = {}
         for e0, e1, fl, by, variant in events:
-            acc = acc_by.setdefault(variant, [0.0, 0, 0, 0])
+            acc = acc_by.setdefault(key(variant), [0.0, 0, 0, 0])
             acc[0] += e0.elapsed_time(e1); acc[1] += fl; acc[2] += by; acc[3] += 1
         return acc_by
     by_kernel = per_kernel(prof)
+    by_symbol = per_kernel(prof, key=lambda v: v)
     # HBM-bound kernels: algorithmic bytes / event time against 8 TB/s
     hbm_by = {}
     for e0, e1, kind, byts in hbm:
         acc = hbm_by.setdefault(kind + "_kernel", [0.0, 0, 0])
         acc[0] += e0.elapsed_time(e1); acc[1] += byts; acc[2] += 1
-    for name in [k for k in by_kernel if k.startswith("conv_big_kernel<false, true, false>")]:   # residual 1x1 layers
+    for name in [k for k in by_kernel if k.startswith("conv_big_kernel<false, true, *>")]:   # residual 1x1 layers
         v = by_kernel[name]
         hbm_by[name] = [v[0], v[2], v[3]]
     hbm_kernels = {k: {"GB/s": round(v[1] / (v[0] * 1e-3) / 1e9, 1) if v[0] else 0.0,
@@ -195,10 +203,12 @@ def run_train(args, dev, rank, world):
         torch.cuda.synchronize()
         eng.side_stream_on = True
         ms1, fl1, _, n1 = per_kernel(prof1).get(dom_name, [0.0, 0, 0, 0])
+        excl_symbols = {k: {"launches": v[3], "avg_launch_us": round(v[0] * 1e3 / max(v[3], 1), 2)}
+                        for k, v in per_kernel(prof1, key=lambda v: v).items() if family(k) == dom_name}
         if ms1:
             exclusive = {"achieved": round(fl1 / (ms1 * 1e-3) / 1e12, 2),
                          "frac": round(fl1 / (ms1 * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
-                         "avg_launch_us": round(ms1 * 1e3 / max(n1, 1), 2), "launches": n1,
+                         "avg_launch_us": round(ms1 * 1e3 / max(n1, 1), 2), "launches": n1, "symbols": excl_symbols,
                          "how": "one extra untimed step with RNET_WGRAD_STREAM=0 semantics (one-stream backward): "
                                 "the same launches with the chip to themselves"}
     res = {"dt": dt, "B": B, "loss": float(out["weighted-loss"].item()),
@@ -209,6 +219,10 @@ def run_train(args, dev, rank, world):
                         "traffic": None, "kernel": dom_name + " (forward + dgrad launches)",
                         "launches_per_step": dom_n // max(sampled, 1), "sampled_steps": sampled,
                         "avg_launch_us": round(dom_ms * 1e3 / max(dom_n, 1), 2),
+                        "symbols": {k: {"launches_per_step": v[3] // max(sampled, 1),
+                                        "avg_launch_us": round(v[0] * 1e3 / max(v[3], 1), 2),
+                                        "algorithmic_gflop_per_launch": round(v[1] / max(v[3], 1) / 1e9, 3)}
+                                    for k, v in by_symbol.items() if family(k) == dom_name},
                         "ms_per_step": round(dom_ms / max(sampled, 1), 3),
                         "algorithmic_gflop_per_launch": round(dom_flops / max(dom_n, 1) / 1e9, 3),
                         "algorithmic_bytes_per_launch": int(dom_bytes / max(dom_n, 1)),
@@ -425,9 +439,14 @@ def main():
         try:
             # profiles/traffic.json (tools/summarize_profiles.py): per device symbol, HBM bytes per launch from the
             # FETCH_SIZE / WRITE_SIZE passes of the same bench command
-            sym = line["roofline"]["kernel"].split(" (")[0]
-            ent = json.load(open(tpath)).get("kernels", {}).get(sym)
-            line["roofline"]["traffic"] = ent.get("bytes_per_launch") if ent else None
+            kern = json.load(open(tpath)).get("kernels", {})
+            tot = n = 0
+            for sym, st in line["roofline"].get("symbols", {}).items():   # launch-weighted mean over the device symbols
+                ent = kern.get(sym.split(" (")[0])
+                if ent:
+                    tot += ent["bytes_per_launch"] * st["launches_per_step"]
+                    n += st["launches_per_step"]
+            line["roofline"]["traffic"] = int(tot / n) if n else None
         except Exception:
             pass
     if world == 1 and rank == 0:

@@ -232,16 +232,18 @@ def test_two_stream_backward_is_bit_identical(cuda):
         assert torch.equal(grads[0], grads[i]), f"run {i} differs from the one-stream gradients"
 
 
-def test_bn_backward_reduction_in_the_dgrad_epilogue_matches_the_separate_pass(cuda, monkeypatch):
+@pytest.mark.parametrize("groups", [False, True], ids=["backbone", "backbone+head-towers"])
+def test_bn_backward_reduction_in_the_dgrad_epilogue_matches_the_separate_pass(cuda, monkeypatch, groups):
     """RNET_FUSE_BN_BWD (default on): the data-gradient launch that writes dz of a BatchNorm + ReLU layer with one
     consumer also writes stage 1 of that layer's backward reduction.  dz itself is unchanged; (sum g, sum g*xhat)
     come out of a different fp32 association, so every gradient must agree with the
     separate-pass engine to fp32-summation accuracy (far inside one bf16 ulp of what follows)."""
+    monkeypatch.setenv("RNET_FUSE_BN_BWD", "2" if groups else "1")
     p, model, eng, targets, images = _setup(cuda, 256, 4, True, freeze=True)
     # ResNet-26 (2 bottleneck blocks per group, group 1 frozen): conv a -> b of the stride-1 blocks and conv b -> c of
-    # every block in groups 2-4
-    # ... + the ten segments (two heads x five levels) of each of the four head-tower depths: 9 + 40
-    assert len(eng.bn_bwd_fused) == 49, eng.bn_bwd_fused
+    # every block in groups 2-4; RNET_FUSE_BN_BWD=2: + the ten segments (two heads x five levels) of each of the four
+    # head-tower depths (depth 3 completes across the two prediction convs' launches)
+    assert len(eng.bn_bwd_fused) == (49 if groups else 9), eng.bn_bwd_fused
     monkeypatch.setenv("RNET_FUSE_BN_BWD", "0")
     from retinanet.model.train_engine import TrainEngine
     import re
@@ -258,8 +260,8 @@ def test_bn_backward_reduction_in_the_dgrad_epilogue_matches_the_separate_pass(c
         torch.cuda.synchronize()
         grads.append(e.G.clone())
     assert int((grads[0] != 0).sum()) > grads[0].numel() // 2
-    # the first fused layer of the backward order (head-tower depth 3, whose dz comes out of a prediction conv's data
-    # gradient: nothing above it is fused) receives the same dz in both engines: its gamma / beta gradients ARE the two
+    # the first fused layer of the backward order (the last block of group 4, or head-tower depth 3 when the head groups
+    # are fused: nothing above it is) receives the same dz in both engines: its gamma / beta gradients ARE the two
     # reductions of identical inputs
     top = next(o for o in eng.ops if o.get("out") == eng.bn_bwd_fused[0])
     for sfx in ("/gamma", "/beta"):
