@@ -20,8 +20,9 @@ which does not shard ("replicas only"), and `cpu_baseline`: the C
 conv_big_kernel, conv_fwd_kernel<128,128,64>; forward convs and every dgrad) took most time: sum of ALGORITHMIC
 FLOPs of its launches (2*Ho*Wo*k*k*Cin*Cout of the layer: a dgrad launch counts its layer's MACs, not the
 zero-upsampled / channel-padded GEMM it executes) / sum of their HIP-event times (events recorded on the launch
-stream inside the timed steps), against 2.5 PFLOP/s dense bf16; the others are listed under `other_conv_kernels`,
-and the HBM-bound kernels (residual 1x1 convs on conv_big_kernel<false,true,false>, the BatchNorm passes) under
+stream inside the timed steps), against 2.5 PFLOP/s dense bf16 (one entry per kernel: the device symbols that differ
+only in the BN_BWD epilogue flag are summed and listed under `roofline.symbols`); the others are listed under `other_conv_kernels`,
+and the HBM-bound kernels (residual 1x1 convs on conv_big_kernel<false,true,*>, the BatchNorm passes) under
 `hbm_kernels` as GB/s of algorithmic bytes against 8 TB/s.
 """
 import argparse
