@@ -76,7 +76,9 @@ __device__ __forceinline__ float grad_gate(float dz, float z, float u, int act, 
   if (G == G_Z_RELU) return z > 0.0f ? dz : 0.0f;
   if (G == G_Z_RELU6) return (z > 0.0f && z < 6.0f) ? dz : 0.0f;
   if (G == G_SWISH) {
-    const float sg = 1.0f / (1.0f + __expf(-u));
+    // v_rcp_f32 (1 ulp) instead of the correctly rounded division the build flags give `/` (~10 instructions): the
+    // swish passes of EfficientNet are VALU-bound, and the gate is a factor of a gradient that is rounded to 16 bits
+    const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-u));
     return dz * (sg + u * sg * (1.0f - sg));
   }
   return act == RN_ACT_NONE ? dz : dz * (from_u ? act_mask_u(u, act) : act_deriv(z, u, act));
