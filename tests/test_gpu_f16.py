@@ -52,6 +52,50 @@ def test_split_weight_planes_f16(cuda, half):
         tc.test_conv_f32_weights_as_split_bf16_planes(cuda, case)
 
 
+# ---- the training kernels (tests/test_gpu_train_kernels.py) on the half build ----------------------------------------
+import test_gpu_train_kernels as tk
+
+
+@pytest.fixture()
+def half_train(monkeypatch):
+    monkeypatch.setattr(tk, "H16", torch.float16)
+    yield
+
+
+def test_wgrad_kernels_f16(cuda, half_train, request):
+    for shape in tk.WGRAD_SHAPES[:5] + tk.WGRAD_SHAPES[7:10]:   # 128-tile kernel and wgrad_big_kernel
+        tk.test_wgrad(cuda, shape, request)
+
+
+@pytest.mark.parametrize("k,stride,cin,cout", [(3, 1, 128, 256), (1, 1, 256, 128), (3, 2, 128, 128), (1, 2, 256, 512)])
+def test_dgrad_f16(cuda, half_train, k, stride, cin, cout):
+    tk.test_dgrad_via_forward_kernel(cuda, k, stride, cin, cout)
+
+
+def test_dgrad_subpixel_f16(cuda, half_train):
+    tk.test_dgrad_stride2_subpixel(cuda, 1, 20, 16, 128, 128, True)
+
+
+@pytest.mark.parametrize("act,use_res", [("relu", True), ("relu", False), ("swish", False)])
+def test_batchnorm_train_kernels_f16(cuda, half_train, act, use_res):
+    tk.test_bn_train_forward_backward(cuda, act, use_res)
+
+
+@pytest.mark.parametrize("k,tile", [(1, 2), (3, 2), (3, 1)])
+def test_batchnorm_fusions_f16(cuda, half_train, k, tile):
+    tk.test_bn_forward_stats_fused_into_conv_epilogue(cuda, k, tile)
+    tk.test_bn_backward_reduction_fused_into_the_data_gradient(cuda, k, tile)
+    tk.test_bn_backward_gate_from_the_bit_mask(cuda, "relu")
+
+
+def test_pool_topdown_balance_backward_f16(cuda, half_train):
+    tk.test_pool_topdown_balance_backward(cuda)
+
+
+def test_optimizer_step_f16(cuda, half_train):
+    tk.test_optimizer_step(cuda)
+
+
 def test_resnet_forward_under_mixed_float16(cuda):
     """ResNet-50 RetinaNet under the mixed_float16 policy: the engine picks the half build, the restatement rounds to
     half at the same layer boundaries; same bounds as the bfloat16 model test (half has three more mantissa bits)."""

@@ -11,8 +11,18 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
+# the 16-bit storage type under test: tests/test_gpu_f16.py re-runs cases of this module with torch.float16 on
+# librnet_hip_f16.so
+H16 = torch.bfloat16
+
+
+def _lib():
+    from retinanet import _C
+    return _C.lib(H16 == torch.float16)
+
+
 def _bf(x):
-    return x.to(torch.bfloat16)
+    return x.to(H16)
 
 
 def _ws(nbytes, dev):
@@ -20,7 +30,7 @@ def _ws(nbytes, dev):
 
 
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("shape", [
+WGRAD_SHAPES = [
     # list of (N, H, Cin, Cout) segments, k, stride
     ([(2, 12, 128, 128)], 3, 1),
     ([(2, 16, 256, 128)], 1, 1),
@@ -33,13 +43,17 @@ def _ws(nbytes, dev):
     ([(2, 64, 256, 720)], 3, 1),                                 # 256x256-tile kernel: 3 co tiles, Cout tail
     ([(3, 48, 512, 256)], 1, 1),                                 # 256x256-tile kernel: 1x1, 2 ci tiles
     ([(2, 96, 256, 512)], 3, 2),                                 # 256x256-tile kernel: stride 2
-], ids=["3x3", "1x1", "3x3s2", "pred36", "pyramid", "cin192_720", "co640", "big_pyramid", "big_720", "big_1x1",
-        "big_s2"])
+]
+
+
+@pytest.mark.parametrize("shape", WGRAD_SHAPES,
+                         ids=["3x3", "1x1", "3x3s2", "pred36", "pyramid", "cin192_720", "co640", "big_pyramid", "big_720",
+                              "big_1x1", "big_s2"])
 def test_wgrad(cuda, shape, request):
     from retinanet import _C
-    lib = _C.lib()
+    lib = _lib()
     segs, k, stride = shape
-    big = request.node.callspec.id.startswith("big_")
+    big = any(shape is sh for sh in WGRAD_SHAPES[7:])        # the big_* cases
     lib.rn_debug_wgrad_big_min_pixels(1 if big else 16384)   # the big_* cases must run the 256x256-tile kernel
     request.addfinalizer(lambda: lib.rn_debug_wgrad_big_min_pixels(16384))
     g = torch.Generator().manual_seed(len(segs) * 100 + k + stride)
@@ -84,7 +98,7 @@ def test_kernels_with_compute_units_reserved_for_rccl(cuda):
     so its sums are compared with the float64 reference."""
     from retinanet import _C
     import test_gpu_conv as TC
-    lib = _C.lib()
+    lib = _lib()
     g = torch.Generator().manual_seed(77)
     seg = {"x": torch.randn((4, 24, 24, 256), generator=g), "w": torch.randn((3, 3, 256, 256), generator=g) / 48.0,
            "bias": torch.randn((256,), generator=g), "scale": torch.rand((256,), generator=g) + 0.5,
@@ -139,7 +153,7 @@ def test_kernels_with_compute_units_reserved_for_rccl(cuda):
 def test_dgrad_via_forward_kernel(cuda, k, stride, cin, cout):
     """dx = conv_fwd(dy [zero-upsampled for stride 2], flipped/transposed weights)."""
     from retinanet import _C
-    lib = _C.lib()
+    lib = _lib()
     g = torch.Generator().manual_seed(k * 10 + stride)
     N, H = 2, 12
     pad = (k - 1) // 2
@@ -151,16 +165,16 @@ def test_dgrad_via_forward_kernel(cuda, k, stride, cin, cout):
     y.backward(dy.double().permute(0, 3, 1, 2))
     want = xr.grad.permute(0, 2, 3, 1).float()
     wd = w.to(cuda).contiguous()
-    wp = torch.empty((lib.rn_conv_cout_pad(cin), k, k, cout), dtype=torch.bfloat16, device=cuda)
+    wp = torch.empty((lib.rn_conv_cout_pad(cin), k, k, cout), dtype=H16, device=cuda)
     _C.check(lib.rn_pack_conv_weight_dgrad(_C.ptr(wd), k, k, cin, cout, cout, _C.ptr(wp), _C.current_stream()))
     dyd = dy.to(cuda).contiguous()
     if stride == 2:
-        up = torch.empty((N, H, H, cout), dtype=torch.bfloat16, device=cuda)
+        up = torch.empty((N, H, H, cout), dtype=H16, device=cuda)
         _C.check(lib.rn_upsample_zero2x(_C.ptr(dyd), _C.ptr(up), N, Ho, Ho, cout, H, H, _C.current_stream()))
         src = up
     else:
         src = dyd
-    dx = torch.empty((N, H, H, cin), dtype=torch.bfloat16, device=cuda)
+    dx = torch.empty((N, H, H, cin), dtype=H16, device=cuda)
     acc = _bf(torch.randn((N, H, H, cin), generator=g)).to(cuda)   # accumulate into an existing gradient
     dx.copy_(acc)
     p = _C.ConvProblem()
@@ -184,7 +198,7 @@ def test_dgrad_stride2_subpixel(cuda, N, H, W, cin, cout, accumulate):
     """Data gradient of a 3x3 / stride 2 / pad 1 conv in its sub-pixel form (rn_dgrad_pack.pad_ == 1): one 2x2
     stride-1 conv of dy with 4*Cin phase-major channels + rn_depth_to_space2x, against autograd."""
     from retinanet import _C
-    lib = _C.lib()
+    lib = _lib()
     g = torch.Generator().manual_seed(cin + cout + H)
     Ho, Wo = H // 2, W // 2
     w = torch.randn((cout, 3, 3, cin), generator=g) / math.sqrt(9 * cin)         # compute layout OHWI
@@ -196,13 +210,13 @@ def test_dgrad_stride2_subpixel(cuda, N, H, W, cin, cout, accumulate):
     want = xr.grad.permute(0, 2, 3, 1).float()
     wd = w.to(cuda).contiguous()
     cwp = lib.rn_conv_cin_pad(cout)
-    wp = torch.empty((lib.rn_conv_cout_pad(4 * cin), 2, 2, cwp), dtype=torch.bfloat16, device=cuda)
+    wp = torch.empty((lib.rn_conv_cout_pad(4 * cin), 2, 2, cwp), dtype=H16, device=cuda)
     item = (_C.DgradPack * 1)()
     item[0].w_ohwi, item[0].w_packed = wd.data_ptr(), wp.data_ptr()
     item[0].R, item[0].S, item[0].Cin, item[0].Cout, item[0].Cout_pad, item[0].pad_ = 3, 3, cin, cout, cwp, 1
     _C.check(lib.rn_pack_conv_weight_dgrad_batch(item, 1, _C.current_stream()))
     dyd = dy.to(cuda).contiguous()
-    phases = torch.empty((N, Ho, Wo, 4 * cin), dtype=torch.bfloat16, device=cuda)
+    phases = torch.empty((N, Ho, Wo, 4 * cin), dtype=H16, device=cuda)
     p = _C.ConvProblem()
     p.R = p.S = 2
     p.stride_h = p.stride_w = 1
@@ -256,7 +270,7 @@ def test_bn_backward_gate_from_the_bit_mask(cuda, act):
     """rn_bn_segment.act_mask: rn_bn_apply stores the relu gate of a residual layer as one bit per element and the two
     backward passes read it instead of z — every output must be bit-identical to the z-reading kernels."""
     from retinanet import _C
-    lib = _C.lib()
+    lib = _lib()
     g = torch.Generator().manual_seed(5)
     shapes = [(2, 9, 7, 64), (1, 5, 5, 256), (3, 4, 4, 8)]
     segs = [{"y": torch.randn((N, H, W, C), generator=g) * 2 + 0.5, "residual": torch.randn((N, H, W, C), generator=g) * 3,
@@ -296,7 +310,7 @@ def test_bn_backward_gate_from_the_bit_mask(cuda, act):
                                          ("swish", False)])
 def test_bn_train_forward_backward(cuda, act, use_res):
     from retinanet import _C
-    lib = _C.lib()
+    lib = _lib()
     g = torch.Generator().manual_seed(11)
     shapes = [(2, 9, 7, 64), (1, 5, 5, 256), (3, 4, 4, 8)]
     segs = []
@@ -358,7 +372,7 @@ def test_bn_forward_stats_fused_into_conv_epilogue(cuda, k, tile):
     sums, rn_bn_stats only runs the final reduction.  Must give the statistics of the unfused path on the same
     stored bf16 output (fp32 summation order differs), including pixel tails and a channel tail (Cout 320)."""
     from retinanet import _C
-    lib = _C.lib()
+    lib = _lib()
     g = torch.Generator().manual_seed(23)
     shapes = [(2, 19, 21, 128, 256), (1, 16, 16, 128, 320), (3, 7, 5, 128, 512)]   # N, H, W, Cin, Cout
     pc = _C.ConvProblem()
@@ -370,9 +384,9 @@ def test_bn_forward_stats_fused_into_conv_epilogue(cuda, k, tile):
     for i, (N, H, W, cin, cout) in enumerate(shapes):
         x = _bf(torch.randn((N, H, W, cin), generator=g)).to(cuda)
         w = (torch.randn((k, k, cin, cout), generator=g) / (8 * k) + 0.02 / k).to(cuda).contiguous()
-        wp = torch.empty((lib.rn_conv_cout_pad(cout), k, k, cin), dtype=torch.bfloat16, device=cuda)
+        wp = torch.empty((lib.rn_conv_cout_pad(cout), k, k, cin), dtype=H16, device=cuda)
         _C.check(lib.rn_pack_conv_weight(_C.ptr(w), k, k, cin, cout, cin, _C.ptr(wp), _C.current_stream()))
-        y = torch.empty((N, H, W, cout), dtype=torch.bfloat16, device=cuda)
+        y = torch.empty((N, H, W, cout), dtype=H16, device=cuda)
         s = pc.seg[i]
         s.x, s.w, s.y, s.scale, s.shift, s.residual = x.data_ptr(), wp.data_ptr(), y.data_ptr(), None, None, None
         s.N, s.H, s.W, s.Cin, s.pix_stride, s.Ho, s.Wo, s.Cout = N, H, W, cin, cin, H, W, cout
@@ -422,7 +436,7 @@ def test_bn_backward_reduction_fused_into_the_data_gradient(cuda, k, tile):
     unfused kernels on the same stored dz (fp32 association differs) and a float64 evaluation — 128-row kernel,
     conv_big_kernel and conv_halo_kernel, pixel tails and a channel tail (Cout 320)."""
     from retinanet import _C
-    lib = _C.lib()
+    lib = _lib()
     g = torch.Generator().manual_seed(29)
     shapes = [(2, 19, 21, 128, 256), (1, 16, 16, 128, 320), (3, 7, 5, 128, 512)]   # N, H, W, Cin, Cout
     pc = _C.ConvProblem()
@@ -434,9 +448,9 @@ def test_bn_backward_reduction_fused_into_the_data_gradient(cuda, k, tile):
     for i, (N, H, W, cin, cout) in enumerate(shapes):
         x = _bf(torch.randn((N, H, W, cin), generator=g)).to(cuda)
         w = (torch.randn((k, k, cin, cout), generator=g) / (8 * k)).to(cuda).contiguous()
-        wp = torch.empty((lib.rn_conv_cout_pad(cout), k, k, cin), dtype=torch.bfloat16, device=cuda)
+        wp = torch.empty((lib.rn_conv_cout_pad(cout), k, k, cin), dtype=H16, device=cuda)
         _C.check(lib.rn_pack_conv_weight(_C.ptr(w), k, k, cin, cout, cin, _C.ptr(wp), _C.current_stream()))
-        dz = torch.empty((N, H, W, cout), dtype=torch.bfloat16, device=cuda)
+        dz = torch.empty((N, H, W, cout), dtype=H16, device=cuda)
         s = pc.seg[i]
         s.x, s.w, s.y, s.scale, s.shift, s.residual = x.data_ptr(), wp.data_ptr(), dz.data_ptr(), None, None, None
         s.N, s.H, s.W, s.Cin, s.pix_stride, s.Ho, s.Wo, s.Cout = N, H, W, cin, cin, H, W, cout
@@ -502,7 +516,7 @@ def test_bn_backward_reduction_fused_into_the_data_gradient(cuda, k, tile):
 
 def test_pool_topdown_balance_backward(cuda):
     from retinanet import _C
-    lib = _C.lib()
+    lib = _lib()
     g = torch.Generator().manual_seed(21)
     st = _C.current_stream()
     N, C = 2, 64
@@ -539,7 +553,7 @@ def test_pool_topdown_balance_backward(cuda):
         up = F.interpolate(outs[l + 1].permute(0, 3, 1, 2), scale_factor=2, mode="nearest").permute(0, 2, 3, 1)
         outs[l] = F.relu(leaves[l] + up)
     sum((o * d.float()).sum() for o, d in zip(outs, douts)).backward()
-    outs_d = [o.detach().to(torch.bfloat16).to(cuda) for o in outs]
+    outs_d = [o.detach().to(H16).to(cuda) for o in outs]
     d_d = [d.to(cuda) for d in douts]
     din = [torch.empty_like(t) for t in d_d]
     for l in range(L):
@@ -562,7 +576,7 @@ def test_pool_topdown_balance_backward(cuda):
     ins_d = [t.to(cuda) for t in ins]
     d_d = [t.to(cuda) for t in douts]
     din = [torch.empty_like(t) for t in d_d]
-    avg_d = avg.detach().permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(cuda)
+    avg_d = avg.detach().permute(0, 2, 3, 1).contiguous().to(H16).to(cuda)
     scratch = torch.empty_like(avg_d)
     _C.check(lib.rn_balance_features_bwd(_C.ptr_array(d_d), _C.ptr_array(ins_d), _C.ptr_array(din), _C.ptr(avg_d),
                                          _C.ptr(scratch), L, mid, N, H0, H0, C, st))
@@ -577,7 +591,7 @@ def test_pool_topdown_balance_backward(cuda):
 
 def test_optimizer_step(cuda):
     from retinanet import _C
-    lib = _C.lib()
+    lib = _lib()
     g = torch.Generator().manual_seed(5)
     sizes = [64, 36864, 256, 70000, 8]
     wd = [0, 1, 0, 1, 0]
@@ -602,7 +616,7 @@ def test_optimizer_step(cuda):
     segs_d = torch.from_numpy(seg_np.view(np.uint8)).to(cuda)
     bs_d = torch.tensor(block_seg, dtype=torch.int32, device=cuda)
     wdv, gd, vd, ed = w.to(cuda), gr.to(cuda), v.to(cuda), ema.to(cuda)
-    bf = torch.zeros((total,), dtype=torch.bfloat16, device=cuda)
+    bf = torch.zeros((total,), dtype=H16, device=cuda)
     metrics = torch.zeros((8,), dtype=torch.float32, device=cuda)
     ws = _ws(lib.rn_optim_workspace_bytes(len(block_seg), len(sizes)), cuda)
     alpha, R, clip, lr, mom, dec = 1e-4, 4, 10.0, 0.1, 0.9, 0.5
@@ -652,7 +666,7 @@ def test_optimizer_step(cuda):
     torch.testing.assert_close(ed.cpu().double(), e2, rtol=1e-5, atol=1e-6)
     for i, n in enumerate(sizes):
         got = bf[offs[i]:offs[i] + n].float().cpu()
-        want = w2[offs[i]:offs[i] + n].float().to(torch.bfloat16).float() if wd[i] else torch.zeros(n)
+        want = w2[offs[i]:offs[i] + n].float().to(H16).float() if wd[i] else torch.zeros(n)
         torch.testing.assert_close(got, want, rtol=1 / 128, atol=1e-3)
     # non-finite gradients: flagged, so that the caller can drop the step and halve the loss scale
     gd[5] = float("inf")
@@ -667,7 +681,7 @@ def test_scatter_add2x(cuda, N, H, W, C, Ho, Wo):
     """rn_scatter_add2x: y[n,2h,2w,:] (+)= x[n,h,w,:] — the placement step of the low-resolution data gradient of a
     1x1 / stride-2 convolution; fp32 add with one rounding, the other positions untouched (accumulate) or zero."""
     from retinanet import _C
-    lib = _C.lib()
+    lib = _lib()
     g = torch.Generator().manual_seed(N * 100 + C)
     x = _bf(torch.randn((N, H, W, C), generator=g))
     y0 = _bf(torch.randn((N, Ho, Wo, C), generator=g))
@@ -678,4 +692,4 @@ def test_scatter_add2x(cuda, N, H, W, C, Ho, Wo):
         want = y0.float().clone() if acc else torch.zeros((N, Ho, Wo, C))
         hh, ww = (Ho + 1) // 2, (Wo + 1) // 2
         want[:, ::2, ::2, :] += x.float()[:, :hh, :ww, :]
-        assert torch.equal(yd.float().cpu(), want.to(torch.bfloat16).float())
+        assert torch.equal(yd.float().cpu(), want.to(H16).float())
