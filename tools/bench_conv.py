@@ -30,6 +30,14 @@ PRESETS = {
     "g4_3x3": ([(20, 512, 512)], 3, 1, False, False),
     "g4_a": ([(20, 2048, 512)], 1, 1, False, False),
     "g4_out": ([(20, 512, 2048)], 1, 1, False, True),
+    # EfficientNet-B3 MBConv 1x1 layers (expand / project), batch 32 at 640^2
+    "e_exp160": ([(160, 32, 192)], 1, 1, False, False),
+    "e_exp80": ([(80, 48, 288)], 1, 1, False, False),
+    "e_exp40": ([(40, 136, 816)], 1, 1, False, False),
+    "e_exp20": ([(20, 232, 1392)], 1, 1, False, False),
+    "e_proj80": ([(80, 288, 48)], 1, 1, False, True),
+    "e_proj40": ([(40, 816, 136)], 1, 1, False, True),
+    "e_proj20": ([(20, 1392, 232)], 1, 1, False, True),
     "g3_sc": ([(40, 512, 1024)], 1, 1, False, False),
     "fpn_out": ([(s, 256, 256) for s in (80, 40, 20, 10, 5)], 3, 1, False, False),
     "fpn_lat": ([(80, 512, 256), (40, 1024, 256), (20, 2048, 256)], 1, 1, False, False),
