@@ -10,12 +10,12 @@ from model_ref import RefTrainer
 pytestmark = pytest.mark.gpu
 
 
-def _setup(cuda, size, B, balanced, seed=3, depth=26, freeze=True):
+def _setup(cuda, size, B, balanced, seed=3, depth=26, freeze=True, precision="mixed_bfloat16"):
     from retinanet.cfg import default_params
     from retinanet.dataloader import LabelEncoder
     from retinanet.model import ModelBuilder
     from retinanet.model.train_engine import TrainEngine
-    p = default_params(input_size=size, balanced=balanced)
+    p = default_params(input_size=size, balanced=balanced, precision=precision)
     p.architecture.batch_norm.use_sync = False
     # A randomly initialised 50-layer ReLU/BN net with O(1) residual gammas amplifies ANY perturbation
     # (bf16 rounding included) by ~1.3x per block, so element-wise parity with a float64 run is not
@@ -83,8 +83,11 @@ def _gradient_rows(grad_of, ref, names):
     return rows
 
 
-@pytest.mark.parametrize("size,B,balanced,freeze", [(256, 4, True, True), (256, 3, False, True), (256, 2, True, False)])
-def test_backward_wiring_dense_upstream(cuda, size, B, balanced, freeze):
+@pytest.mark.parametrize("size,B,balanced,freeze,precision", [
+    (256, 4, True, True, "mixed_bfloat16"), (256, 3, False, True, "mixed_bfloat16"), (256, 2, True, False, "mixed_bfloat16"),
+    (256, 4, True, True, "mixed_float16"),      # the half build (librnet_hip_f16.so) against the restatement rounding to half
+])
+def test_backward_wiring_dense_upstream(cuda, size, B, balanced, freeze, precision):
     """Whole-network backward (heads -> BalanceFeatures -> FPN -> ResNet) for a dense random upstream gradient on the
     predictions, against autograd through the bf16-emulating CPU restatement in float64.
 
@@ -94,7 +97,8 @@ def test_backward_wiring_dense_upstream(cuda, size, B, balanced, freeze):
     flipped bf16 rounding (tools/oracle_noise_floor.py: ResNet-26 256^2, forward 3.3 %, gradient cosine median 0.971,
     minimum 0.940; the HIP path measures 3.1 %, 0.971, 0.936).  The HIP path must sit at that floor: forward error
     <= 1.3 x the floor, every tensor's gradient cosine within 0.06 of its floor value, the median within 0.015."""
-    p, model, eng, targets, images = _setup(cuda, size, B, balanced, freeze=freeze)
+    p, model, eng, targets, images = _setup(cuda, size, B, balanced, freeze=freeze, precision=precision)
+    assert eng.f16 == (precision == "mixed_float16")
     ref = RefTrainer(p, model.variables, frozen_names=eng.frozen, emulate_bf16=True)
     ref32 = RefTrainer(p, model.variables, frozen_names=eng.frozen, emulate_bf16=True, dtype=torch.float32)
     if not freeze:
