@@ -21,6 +21,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: exactly the functions declared here are exported */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 typedef enum {
   RN_OK = 0,
@@ -163,6 +167,43 @@ int rn_nms_per_class(const float* cand_scores, const float* cand_boxes, int B, i
 int rn_rowmax_argmax(const float* scores, int64_t rows, int K, float* max_out, int32_t* argmax_out, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * per-device handle and per-call launch options.
+ *
+ * The library keeps NO mutable process-wide state: what used to be process-global tuning / test knobs is an
+ * rn_launch_opts value carried by every MFMA problem descriptor (rn_conv_problem.opts, rn_wgrad_problem.opts), so two
+ * engines in one process (train + eval of one Executor) cannot see each other's settings and a launch is a pure
+ * function of its arguments.  All zero = the dispatcher's own choice.
+ */
+typedef struct {
+  int32_t conv_tile;           /* 0: auto | 1: the 128-row conv_fwd_kernel | 2: the 256-row kernels wherever the shape allows */
+  int32_t conv_no_halo;        /* 1: conv_big_kernel where conv_halo_kernel would run (A/B, tests) */
+  int32_t conv_big_min_tiles;  /* > 0: 256-row tiles a launch needs to go to the 256-row kernels (default 192) */
+  int32_t max_workgroups;      /* > 0: cap on the persistent grids of conv_big / conv_halo (default: one per CU) */
+  int32_t reserved_cus;        /* data-parallel runs: compute units the persistent kernels (256-row convs, wgrad_big,
+                                * wgrad_halo) leave free — their workgroups own a CU for a whole tile loop, and RCCL's
+                                * kernels (~130 latency-bound SyncBN all-reduces per step, the gradient buckets) then
+                                * always find one.  0..128 */
+  int32_t wgrad_kernel;        /* 0: auto | 1: wgrad_kernel (128 x 128 per-tap tiles) | 2: the 256-wide kernels whenever
+                                * the channel counts allow, whatever the pixel count (tests at small sizes) */
+  int32_t wgrad_target_blocks; /* > 0: workgroups a weight-gradient launch aims for (split-K plan; A/B timing) */
+  int32_t ablate;              /* tools/bench_conv.py: ablated variants of conv_fwd_kernel<128,128,64> — timing only */
+} rn_launch_opts;
+
+/* Opaque per-device context: device id, compute-unit count, the default rn_launch_opts of the engine that owns it and
+ * the RCCL communicators created through it (destroyed with it).  One per engine / Python process and GPU; not
+ * thread-safe; functions are re-entrant across handles. */
+typedef struct rn_handle rn_handle;
+int rn_create(int device_id, rn_handle** out);
+int rn_destroy(rn_handle* h);
+int rn_handle_device(const rn_handle* h);
+int rn_handle_num_cus(const rn_handle* h);
+int rn_handle_set_launch_opts(rn_handle* h, const rn_launch_opts* opts);   /* RN_EINVAL on an out-of-range field */
+int rn_handle_get_launch_opts(const rn_handle* h, rn_launch_opts* opts);
+/* collective: rn_comm_init into slot `slot` (0..3) of the handle; rn_handle_comm returns it (NULL when unset) */
+int rn_handle_comm_init(rn_handle* h, int slot, const void* unique_id /* host */, int rank, int world);
+void* rn_handle_comm(const rn_handle* h, int slot);
+
+/* ---------------------------------------------------------------------------------------
  * K1/K2 (a5,a6,a8)  tf.keras.layers.Conv2D as used by resnet.py:118-144, fpn_base.py:44-50,
  * fpn.py:47-66, detection_head.py:56-88 — grouped implicit-GEMM convolution on MFMA.
  *
@@ -224,6 +265,7 @@ typedef struct {
   int32_t out_dtype; /* RN_DT_BF16 or RN_DT_F32 */
   int32_t num_segments;
   rn_conv_segment seg[RN_CONV_MAX_SEGMENTS];
+  rn_launch_opts opts;
 } rn_conv_problem;
 
 int rn_conv2d_nhwc_fwd(const rn_conv_problem* problem /* host */, void* stream);
@@ -285,6 +327,7 @@ typedef struct {
   int32_t R, S, stride_h, stride_w, pad_top, pad_left;
   int32_t num_segments;
   rn_wgrad_segment seg[RN_CONV_MAX_SEGMENTS];
+  rn_launch_opts opts;
 } rn_wgrad_problem;
 
 size_t rn_wgrad_workspace_bytes(const rn_wgrad_problem* problem /* host */);
@@ -454,14 +497,12 @@ int rn_optim_sgd_step(float* params, const float* grads, float* momentum_buf, fl
  * C1-C3  collectives of the data-parallel step over RCCL / xGMI (the reference reaches them through
  * tf.distribute: retinanet_loss.py:46-49, model/utils.py:10-12, executor.py:436-437).  One process per GPU; rank 0
  * draws a unique id (rn_comm_unique_id, rn_comm_unique_id_bytes() bytes) and hands it to every rank out of band;
- * rn_comm_init is collective.  A collective is enqueued on the CALLER'S stream (asynchronous to the host, in stream
+ * rn_comm_init is collective: agree on rn_comm_available() over the job before any rank calls it, and on its status
+ * afterwards before any rank uses (or abandons) the communicator.  A collective is enqueued on the CALLER'S stream (asynchronous to the host, in stream
  * order with the kernels around it); in-place SUM.  Use one communicator per stream that carries collectives.
  * rn_allreduce_bucket: gradient buckets (RN_DT_F32 / RN_DT_BF16); rn_allreduce_small: the few-KB fp32 messages
  * (SyncBatchNorm [sum | sum of squares], the loss normaliser) on the latency path.  Status RN_ECOMM on failure. */
-/* Data-parallel runs: keep n compute units free of the persistent kernels (256-row convs, wgrad_big), whose workgroups
- * own a CU for a whole tile loop — RCCL's kernels (the ~130 latency-bound SyncBN all-reduces per step beside the
- * second stream's weight-gradient kernels, the gradient buckets beside the convolutions) then always find a CU. */
-int rn_set_reserved_cus(int n);
+int rn_comm_available(void);   /* local check, no collective: 1 if librccl loads with every entry point rn_comm needs */
 int rn_comm_unique_id_bytes(void);
 int rn_comm_unique_id(void* out /* host, rn_comm_unique_id_bytes() bytes */);
 int rn_comm_init(const void* unique_id /* host */, int rank, int world, void** comm_out);
@@ -622,6 +663,9 @@ int rn_jpeg_info(const void* data, size_t len, int32_t* width, int32_t* height, 
 int rn_jpeg_decode(const void* data, size_t len, uint8_t* rgb_out /* [height,width,3] */, size_t out_bytes);
 int rn_jpeg_idct_islow(const int32_t* coef64 /* dequantized, row-major */, uint8_t* out64);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

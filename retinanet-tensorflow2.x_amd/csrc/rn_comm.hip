@@ -77,6 +77,11 @@ struct RnComm {
 
 extern "C" int rn_comm_unique_id_bytes(void) { return NCCL_UNIQUE_ID_BYTES; }
 
+// Local, non-collective: 1 when librccl and every entry point this file uses can be loaded in this process.  Callers
+// agree on it (a MIN over the job) BEFORE any rank enters the collective rn_comm_init, so that a rank whose librccl is
+// missing cannot leave the others waiting inside ncclCommInitRank.
+extern "C" int rn_comm_available(void) { return rccl_load() ? 1 : 0; }
+
 extern "C" int rn_comm_unique_id(void* out) {
   RN_CHECK_ARG(out != nullptr, "rn_comm_unique_id: null output");
   if (!rccl_load()) return RN_ECOMM;

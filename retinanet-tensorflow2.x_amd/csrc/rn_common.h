@@ -8,8 +8,10 @@
 #include "../../include/rnet_hip.h"
 
 void rn_set_error(const char* fmt, ...);
-int rn_persistent_grid(int work_items, int num_cu);   // rn_core.hip: min(items, CUs not reserved for RCCL)
-int rn_reserved_cus();
+// rn_core.hip: min(items, CUs not reserved for RCCL, opts.max_workgroups); CU count of the current device
+int rn_persistent_grid(int work_items, int num_cu, const rn_launch_opts& opts);
+int rn_num_cus();
+int rn_validate_launch_opts(const rn_launch_opts& opts, const char* who);
 
 #define RN_CHECK_ARG(cond, ...)  \
   do {                           \

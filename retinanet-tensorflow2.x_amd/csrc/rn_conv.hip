@@ -395,13 +395,6 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
   return RN_OK;
 }
 
-static int g_conv_ablate = 0;
-static int g_conv_force_small = 0, g_conv_force_big = 0;
-// internal: 1 = always the 128-row kernel, 2 = always the 256-row kernel (A/B timing in tools/)
-extern "C" void rn_debug_conv_tile(int mode) { g_conv_force_small = mode == 1; g_conv_force_big = mode == 2; }
-// internal (not in rnet_hip.h): select an ablated kernel for tools/bench_conv.py
-extern "C" void rn_debug_conv_ablate(int mask) { g_conv_ablate = mask; }
-
 template <int ABL>
 static int launch_ablate(const ConvArgs& a, hipStream_t st) {
   constexpr int lds = 2 * (128 + 128) * 64 * 2;
@@ -414,11 +407,9 @@ static int launch_ablate(const ConvArgs& a, hipStream_t st) {
 
 // 256 x 256 x 32 tiles (rn_conv_big.hip) for the MFMA-bound layers: every segment at least 256 output
 // channels wide, and enough tiles to fill the 256 CUs (one workgroup per CU) a few times over.
-static long long g_conv_big_min_tiles = 192;
-extern "C" void rn_debug_conv_big_min_tiles(int n) { g_conv_big_min_tiles = n; }   // tools/: A/B timing
-
+// (rn_launch_opts: conv_tile forces either family, conv_big_min_tiles moves the threshold.)
 static bool conv_use_big(const rn_conv_problem* p) {
-  if (g_conv_force_small) return false;
+  if (p->opts.conv_tile == 1) return false;
   long long tiles256 = 0;
   for (int i = 0; i < p->num_segments; ++i) {
     const rn_conv_segment& s = p->seg[i];
@@ -426,16 +417,13 @@ static bool conv_use_big(const rn_conv_problem* p) {
     if (s.bias && s.residual) return false;   // the residual variants of the 256-row kernels carry no bias path
     tiles256 += rn_cdiv((long long)s.N * s.Ho * s.Wo, 256) * rn_cdiv(s.Cout, 256);
   }
-  return g_conv_force_big || tiles256 >= g_conv_big_min_tiles;
+  return p->opts.conv_tile == 2 || tiles256 >= (p->opts.conv_big_min_tiles > 0 ? p->opts.conv_big_min_tiles : 192);
 }
 
 // 3x3 / stride 1 / pad 1 launches of the 256-row class go to the halo kernel (rn_conv_halo.hip) when every
 // segment's worst tile fits its patch buffer.
-static int g_conv_halo = 1;
-extern "C" void rn_debug_conv_halo(int on) { g_conv_halo = on; }   // tools/, tests: A/B against conv_big_kernel
-
 static bool conv_use_halo(const rn_conv_problem* p) {
-  if (!g_conv_halo || !conv_use_big(p)) return false;
+  if (p->opts.conv_no_halo || !conv_use_big(p)) return false;
   if (p->R != 3 || p->S != 3 || p->stride_h != 1 || p->stride_w != 1 || p->pad_top != 1 || p->pad_left != 1)
     return false;
   static std::mutex mu;
@@ -479,6 +467,7 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
   RN_CHECK_ARG(p->R >= 1 && p->S >= 1 && p->R * p->S <= 32, "rn_conv2d_nhwc_fwd: R*S=%d > 32", p->R * p->S);
   RN_CHECK_ARG(p->stride_h >= 1 && p->stride_w >= 1, "rn_conv2d_nhwc_fwd: bad stride");
   RN_CHECK_ARG(p->out_dtype == RN_DT_BF16 || p->out_dtype == RN_DT_F32, "rn_conv2d_nhwc_fwd: bad out_dtype");
+  if (const int orc = rn_validate_launch_opts(p->opts, "rn_conv2d_nhwc_fwd")) return orc;
   ConvArgs a;
   a.R = p->R; a.S = p->S; a.sh = p->stride_h; a.sw = p->stride_w; a.pt = p->pad_top; a.pl = p->pad_left;
   a.act = p->act; a.nseg = p->num_segments; a.pad_ = 0;
@@ -541,8 +530,8 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
   a.total_tiles = tiles;
   hipStream_t st = (hipStream_t)stream;
   const bool f32 = p->out_dtype == RN_DT_F32;
-  if (g_conv_ablate && BM == 128 && BN == 128 && BK == 64 && !f32) {
-    switch (g_conv_ablate) {
+  if (p->opts.ablate && BM == 128 && BN == 128 && BK == 64 && !f32) {
+    switch (p->opts.ablate) {
       case 1: return launch_ablate<1>(a, st);
       case 2: return launch_ablate<2>(a, st);
       case 3: return launch_ablate<3>(a, st);
@@ -557,12 +546,12 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
       default: break;
     }
   }
-  if (big && conv_use_halo(p)) return rn_launch_conv_halo(a, f32, st);
+  if (big && conv_use_halo(p)) return rn_launch_conv_halo(a, f32, p->opts, st);
   if (big) {
     a.pad_ = 1;   // float-reciprocal index arithmetic in the tile set-up, valid while every M < 2^22
     for (int i = 0; i < a.nseg; ++i)
       if (a.seg[i].M >= (1 << 22)) a.pad_ = 0;
-    return rn_launch_conv_big(a, f32, st);
+    return rn_launch_conv_big(a, f32, p->opts, st);
   }
   if (BN == 128 && BK == 64) return f32 ? launch_conv<128, 128, 64, true>(a, st) : launch_conv<128, 128, 64, false>(a, st);
   if (BN == 64 && BK == 64) return f32 ? launch_conv<128, 64, 64, true>(a, st) : launch_conv<128, 64, 64, false>(a, st);

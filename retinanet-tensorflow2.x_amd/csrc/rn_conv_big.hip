@@ -271,13 +271,8 @@ __global__ void __launch_bounds__(512) conv_big_kernel(const ConvArgs args) {
 
 }  // namespace
 
-// internal hook kept for tools/bench_conv.py (the ablation builds were removed with the persistent rewrite)
-extern "C" void rn_debug_conv_big_ablate(int) {}
-
-extern int g_halo_grid;
-int rn_launch_conv_big(const ConvArgs& a, bool out_f32, hipStream_t st) {
+int rn_launch_conv_big(const ConvArgs& a, bool out_f32, const rn_launch_opts& opts, hipStream_t st) {
   static bool attr_set = false;
-  static int num_cu = 256;
   if (!attr_set) {
     RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_big_kernel<false, false>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
@@ -289,15 +284,10 @@ int rn_launch_conv_big(const ConvArgs& a, bool out_f32, hipStream_t st) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_big_kernel<false, false, true>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-        prop.multiProcessorCount > 0)
-      num_cu = prop.multiProcessorCount;
     attr_set = true;
   }
-  int grid = rn_persistent_grid(a.total_tiles, num_cu);   // one persistent workgroup per CU (minus the CUs kept for RCCL)
-  if (g_halo_grid > 0 && g_halo_grid < grid) grid = g_halo_grid;     // rn_debug_conv_halo_grid (tests, tools)
+  // one persistent workgroup per CU (minus the CUs kept for RCCL; opts.max_workgroups caps it)
+  const int grid = rn_persistent_grid(a.total_tiles, rn_num_cus(), opts);
   bool has_res = false;   // one residual input anywhere -> the variant that carries the residual path
   for (int i = 0; i < a.nseg; ++i) has_res = has_res || a.seg[i].residual != nullptr;
   const dim3 g3(grid), b3(512);

@@ -55,9 +55,9 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wav
 
 
 // rn_conv_big.hip
-int rn_launch_conv_big(const ConvArgs& a, bool out_f32, hipStream_t st);   // (bn_y set on segment 0: the BN_BWD variant)
+int rn_launch_conv_big(const ConvArgs& a, bool out_f32, const rn_launch_opts& opts, hipStream_t st);   // (bn_y set on segment 0: the BN_BWD variant)
 // rn_conv_halo.hip (3x3 / stride 1 / pad 1)
-int rn_launch_conv_halo(const ConvArgs& a, bool out_f32, hipStream_t st);
+int rn_launch_conv_halo(const ConvArgs& a, bool out_f32, const rn_launch_opts& opts, hipStream_t st);
 int rn_conv_halo_patch_pixels(int N, int H, int W, int pitch);
 int rn_conv_halo_pitch(int W);
 int rn_conv_halo_capacity();

@@ -31,11 +31,9 @@
 #ifndef HALO_ABLATE
 #define HALO_ABLATE 0
 #endif
-int g_halo_grid = 0;   // also honoured by conv_big_kernel's launcher
-extern "C" void rn_debug_conv_halo_grid(int n) { g_halo_grid = n; }   // tools/, tests: fewer persistent workgroups than CUs
 
 #ifdef HALO_PROF   // probe builds: core clock (clock64) and 100 MHz wall clock at the start / end of workgroup 0
-extern "C" int rn_debug_halo_clocks(unsigned long long* out) {
+extern "C" __attribute__((visibility("default"))) int rn_debug_halo_clocks(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_halo_clk), sizeof(g_halo_clk)) == hipSuccess ? 0 : -3;
 }
 #endif
@@ -438,9 +436,8 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
 
 }  // namespace
 
-int rn_launch_conv_halo(const ConvArgs& a, bool out_f32, hipStream_t st) {
+int rn_launch_conv_halo(const ConvArgs& a, bool out_f32, const rn_launch_opts& opts, hipStream_t st) {
   static bool attr_set = false;
-  static int num_cu = 256;
   if (!attr_set) {
     RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<false, false>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
@@ -452,15 +449,10 @@ int rn_launch_conv_halo(const ConvArgs& a, bool out_f32, hipStream_t st) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<false, false, true>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-        prop.multiProcessorCount > 0)
-      num_cu = prop.multiProcessorCount;
     attr_set = true;
   }
-  int grid = rn_persistent_grid(a.total_tiles, num_cu);   // one persistent workgroup per CU (minus the CUs kept for RCCL)
-  if (g_halo_grid > 0 && g_halo_grid < grid) grid = g_halo_grid;
+  // one persistent workgroup per CU (minus the CUs kept for RCCL; opts.max_workgroups caps it)
+  const int grid = rn_persistent_grid(a.total_tiles, rn_num_cus(), opts);
   bool has_res = false;   // one residual input anywhere -> the variant that carries the residual path
   for (int i = 0; i < a.nseg; ++i) has_res = has_res || a.seg[i].residual != nullptr;
   const dim3 g3(grid), b3(512);
@@ -480,15 +472,11 @@ int rn_launch_conv_halo(const ConvArgs& a, bool out_f32, hipStream_t st) {
 // patch pixels the worst tile of an [N, H, W] tensor needs (rows from one above its first pixel row to one below
 // its last in the shared-pad numbering, W + 1 apart, + the closing zero pixel); the caller compares it with the
 // kernel's capacity
-// Patch pixels per image row: W + 1 (the shared zero column).  Mode 1 rounds it up to a multiple of 8 pixels (8 x 16 B =
-// one 128-byte bank row per plane), so that a fragment of 32 consecutive output pixels that crosses a row seam
-// shifts by whole bank rows and ds_read_b128's lane groups stay conflict free (17 % of the LDS cycles are bank
-// conflicts at the seams: profiles/r01_pmc_train_b32_lds_conflicts.csv).  Measured (tools/ab_halo_pitch.py, same box,
-// alternating runs): the training step is 0.6 % SLOWER with it (34.87 / 34.96 ms -> 35.11 / 35.13 ms) — the 9 % more
-// patch bytes through the LDS-DMA cost more than the conflicts did — so the tight pitch stays the default.
-static int g_halo_pitch_mode = 0;
-extern "C" void rn_debug_conv_halo_pitch(int mode) { g_halo_pitch_mode = mode; }   // 0: W + 1 (A/B timing)
-int rn_conv_halo_pitch(int W) { return g_halo_pitch_mode ? (W + 1 + 7) / 8 * 8 : W + 1; }
+// Patch pixels per image row: W + 1 (the shared zero column).  A pitch rounded up to 8 pixels (one 128-byte bank row per
+// plane, so that a fragment crossing a row seam stays conflict free: 17 % of the LDS cycles are bank conflicts at the
+// seams, profiles/r01_pmc_train_b32_lds_conflicts.csv) was measured 0.6 % SLOWER on the training step (34.87 / 34.96 ms
+// -> 35.11 / 35.13 ms: the 9 % more patch bytes through the LDS-DMA cost more than the conflicts did) and was removed.
+int rn_conv_halo_pitch(int W) { return W + 1; }
 
 int rn_conv_halo_patch_pixels(int N, int H, int W, int pitch) {
   const long long M = (long long)N * H * W, HW = (long long)H * W;

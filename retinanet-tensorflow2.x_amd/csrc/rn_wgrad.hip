@@ -263,14 +263,12 @@ wgrad_reduce_kernel(const float4* __restrict__ ws, long long n4, int chunks, flo
 
 // workgroups a launch aims for (2 per CU x 256 CUs x a few rounds); fewer = fewer split-K partials to
 // write and reduce, more = better balance.  Tunable from tools/ for A/B timing.
-static int g_wgrad_target_blocks = 1024;
-static int g_wgrad_force_small = 0;
-extern "C" void rn_debug_wgrad_force_small(int on) { g_wgrad_force_small = on; }
-extern "C" void rn_debug_wgrad_target_blocks(int n) { if (n > 0) g_wgrad_target_blocks = n; }
+// (rn_launch_opts.wgrad_target_blocks overrides it, .wgrad_kernel picks the kernel family.)
 
 static int wgrad_plan(const rn_wgrad_problem* p, WgArgs& a) {
   if (!p || p->num_segments < 1 || p->num_segments > RN_CONV_MAX_SEGMENTS) return -1;
   if (p->R < 1 || p->S < 1 || p->stride_h < 1 || p->stride_w < 1) return -1;
+  if (rn_validate_launch_opts(p->opts, "rn_conv2d_nhwc_wgrad")) return -1;
   a.R = p->R; a.S = p->S; a.sh = p->stride_h; a.sw = p->stride_w; a.pt = p->pad_top; a.pl = p->pad_left;
   a.nseg = p->num_segments;
   a.Cin = p->seg[0].Cin; a.Cout = p->seg[0].Cout;
@@ -296,7 +294,7 @@ static int wgrad_plan(const rn_wgrad_problem* p, WgArgs& a) {
   if (a.co_groups > a.co_tiles) a.co_groups = a.co_tiles;
   a.gco = (int)rn_cdiv(a.co_tiles, a.co_groups);
   a.co_groups = (int)rn_cdiv(a.co_tiles, a.gco);
-  long long target = rn_cdiv(g_wgrad_target_blocks, tiles);
+  long long target = rn_cdiv(p->opts.wgrad_target_blocks > 0 ? p->opts.wgrad_target_blocks : 1024, tiles);
   if (target < 1) target = 1;
   if (target > 256) target = 256;
   long long CH = rn_cdiv(rn_cdiv(Ptot, target), WG_BK) * WG_BK;
@@ -318,7 +316,7 @@ static int wgrad_plan(const rn_wgrad_problem* p, WgArgs& a) {
   a.total_chunks = chunks;
   a.pad_ = 0;
   // large layers: 256 x 256 per-tap tiles on the ping-pong kernel (rn_wgrad_big.hip); pad_ = 1 marks the choice
-  if (!g_wgrad_force_small && rn_wgrad_big_plan(p, a)) a.pad_ = 1;
+  if (p->opts.wgrad_kernel != 1 && rn_wgrad_big_plan(p, a)) a.pad_ = 1;
   return 0;
 }
 
@@ -341,7 +339,7 @@ extern "C" int rn_conv2d_nhwc_wgrad(const rn_wgrad_problem* p, float* dw, float 
   a.ws = (float*)workspace;
   hipStream_t st = (hipStream_t)stream;
   if (a.pad_ == 1) {
-    const int rc = rn_launch_wgrad_big(a, st);
+    const int rc = rn_launch_wgrad_big(a, p->opts, st);
     if (rc != RN_OK) return rc;
     const long long nb = (long long)a.Cout * a.R * a.S * a.Cin;
     const long long nb4 = nb / 4;

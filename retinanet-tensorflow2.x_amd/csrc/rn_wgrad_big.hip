@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(512) wgrad_big_kernel(const WgArgs args) {
   const int tiles_per_tap = args.co_tiles * args.ci_tiles;
   const int tiles_all = tiles_per_tap * args.R * args.S;
   // One work item per workgroup when the grid covers them all (the single-GPU case); with CUs kept free for RCCL
-  // (rn_set_reserved_cus) the grid is smaller than the item count and a workgroup walks items bid, bid + grid, ...
+  // (rn_launch_opts.reserved_cus) the grid is smaller than the item count and a workgroup walks items bid, bid + grid, ...
 #pragma unroll 1
   for (int bid = blockIdx.x; bid < tiles_all * args.total_chunks; bid += gridDim.x) {
   int logical;
@@ -290,11 +290,6 @@ __global__ void __launch_bounds__(512) wgrad_big_kernel(const WgArgs args) {
 
 }  // namespace
 
-static long long g_big_target_blocks = 256;   // one round of the 256 CUs: fewest split-K partials
-static bool g_big_target_user = false;          // set by the debug override: no candidate search
-extern "C" void rn_debug_wgrad_big_target_blocks(int n) { g_big_target_blocks = n; g_big_target_user = true; }
-static long long g_big_min_pixels = 16384;
-extern "C" void rn_debug_wgrad_big_min_pixels(int n) { g_big_min_pixels = n; }   // tests: force the big kernel
 
 // Layers worth the 256 x 256 tile: both channel counts >= 256 and enough pixels to split K over the CUs.
 bool rn_wgrad_big_plan(const rn_wgrad_problem* p, WgArgs& a) {
@@ -303,7 +298,7 @@ bool rn_wgrad_big_plan(const rn_wgrad_problem* p, WgArgs& a) {
   for (int i = 0; i < p->num_segments; ++i) Ptot += (long long)p->seg[i].N * p->seg[i].Ho * p->seg[i].Wo;
   const int co_tiles = (int)rn_cdiv(a.Cout, 256), ci_tiles = (int)rn_cdiv(a.Cin, 256);
   const int tiles = co_tiles * ci_tiles * a.R * a.S;
-  if (Ptot < g_big_min_pixels || tiles > 512) return false;
+  if ((Ptot < 16384 && p->opts.wgrad_kernel != 2) || tiles > 512) return false;
   a.co_tiles = co_tiles;
   a.ci_tiles = ci_tiles;
   a.co_groups = 1;
@@ -315,7 +310,9 @@ bool rn_wgrad_big_plan(const rn_wgrad_problem* p, WgArgs& a) {
   // the candidates are priced with a greedy simulation of that mapping (per-workgroup cost = K steps + a
   // fixed prologue / epilogue / partial-tile cost) and the cheapest wins.  Plans are cached per shape.
   long long CH = 0;
-  if (!g_big_target_user) g_big_target_blocks = 256 - rn_reserved_cus();   // one round of the CUs the kernel may use
+  // one round of the CUs the kernel may use: fewest split-K partials (opts.wgrad_target_blocks: no candidate search)
+  const bool g_big_target_user = p->opts.wgrad_target_blocks > 0;
+  const long long g_big_target_blocks = g_big_target_user ? p->opts.wgrad_target_blocks : 256 - p->opts.reserved_cus;
   {
     static std::mutex mu;
     static std::unordered_map<std::string, long long> cache;
@@ -386,7 +383,7 @@ bool rn_wgrad_big_plan(const rn_wgrad_problem* p, WgArgs& a) {
   return true;
 }
 
-int rn_launch_wgrad_big(const WgArgs& a, hipStream_t st) {
+int rn_launch_wgrad_big(const WgArgs& a, const rn_launch_opts& opts, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
     RN_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_big_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -402,14 +399,9 @@ int rn_launch_wgrad_big(const WgArgs& a, hipStream_t st) {
              (long long)s.N * s.H * s.W * (s.xS > s.dyS ? s.xS : s.dyS) * 2 < (1ll << 31) - (1ll << 24);
   }
   int items = a.co_tiles * a.ci_tiles * a.R * a.S * a.total_chunks;
-  static int num_cu = 0;
-  if (!num_cu) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    num_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-              prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-  }
-  dim3 grid((unsigned)(rn_reserved_cus() > 0 ? rn_persistent_grid(items, num_cu) : items));
+  rn_launch_opts o = opts;
+  o.max_workgroups = 0;   // the cap is for the persistent convolution grids
+  dim3 grid((unsigned)(opts.reserved_cus > 0 ? rn_persistent_grid(items, rn_num_cus(), o) : items));
   if (linear) hipLaunchKernelGGL(wgrad_big_kernel<true>, grid, dim3(512), LDS_BYTES, st, a);
   else hipLaunchKernelGGL(wgrad_big_kernel<false>, grid, dim3(512), LDS_BYTES, st, a);
   RN_CHECK_LAUNCH();

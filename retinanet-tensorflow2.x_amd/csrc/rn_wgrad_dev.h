@@ -42,5 +42,5 @@ struct WgArgs {
 // rn_wgrad_big.hip: eligibility + plan (fills a.CH / chunk_begin / total_chunks / co_tiles / ci_tiles for
 // 256-wide tiles) and launch of the partial-tile kernel (same workspace layout as wgrad_kernel)
 bool rn_wgrad_big_plan(const rn_wgrad_problem* p, WgArgs& a);
-int rn_launch_wgrad_big(const WgArgs& a, hipStream_t st);
+int rn_launch_wgrad_big(const WgArgs& a, const rn_launch_opts& opts, hipStream_t st);
 #endif  // RN_WGRAD_DEV_H_

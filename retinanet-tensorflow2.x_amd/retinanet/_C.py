@@ -18,7 +18,7 @@ LIB_PATH_F16 = os.environ.get("RNET_HIP_LIB_F16") or os.path.join(_HERE, "librne
 RN_DT_F32, RN_DT_BF16 = 0, 1
 RN_ACT_NONE, RN_ACT_RELU, RN_ACT_RELU6, RN_ACT_SWISH = 0, 1, 2, 3
 RN_CONV_MAX_SEGMENTS = 10
-ABI_VERSION = 3
+ABI_VERSION = 4
 # f32 kernels of the dtype=float32 prediction convs (detection_head.py:80-88) as split-bf16 planes (rn_conv_segment.w_terms)
 PRED_W_TERMS = int(os.environ.get("RNET_PRED_W_TERMS", "2"))
 ACT_IDS = {None: RN_ACT_NONE, "none": RN_ACT_NONE, "relu": RN_ACT_RELU, "relu6": RN_ACT_RELU6,
@@ -40,6 +40,25 @@ class ExampleInfo(Structure):   # rn_example_info
                 ("n_classes", c_int32), ("pad_", c_int32)]
 
 
+class LaunchOpts(Structure):   # rn_launch_opts: per-call options of the MFMA kernels (all zero = the dispatcher's choice)
+    _fields_ = [("conv_tile", c_int32), ("conv_no_halo", c_int32), ("conv_big_min_tiles", c_int32),
+                ("max_workgroups", c_int32), ("reserved_cus", c_int32), ("wgrad_kernel", c_int32),
+                ("wgrad_target_blocks", c_int32), ("ablate", c_int32)]
+
+    def __init__(self, **kw):
+        super().__init__()
+        for k, v in kw.items():
+            if k not in dict(self._fields_):
+                raise TypeError(f"rn_launch_opts has no field {k!r}")
+            setattr(self, k, int(v))
+
+    def copy(self, **kw):
+        o = LaunchOpts(**{k: getattr(self, k) for k, _ in self._fields_})
+        for k, v in kw.items():
+            setattr(o, k, int(v))
+        return o
+
+
 class ConvSegment(Structure):
     _fields_ = [("x", c_void_p), ("w", c_void_p), ("y", c_void_p), ("scale", c_void_p), ("shift", c_void_p),
                 ("residual", c_void_p), ("N", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32),
@@ -51,7 +70,7 @@ class ConvSegment(Structure):
 class ConvProblem(Structure):
     _fields_ = [("R", c_int32), ("S", c_int32), ("stride_h", c_int32), ("stride_w", c_int32),
                 ("pad_top", c_int32), ("pad_left", c_int32), ("act", c_int32), ("out_dtype", c_int32),
-                ("num_segments", c_int32), ("seg", ConvSegment * RN_CONV_MAX_SEGMENTS)]
+                ("num_segments", c_int32), ("seg", ConvSegment * RN_CONV_MAX_SEGMENTS), ("opts", LaunchOpts)]
 
 
 class WgradSegment(Structure):
@@ -63,7 +82,7 @@ class WgradSegment(Structure):
 class WgradProblem(Structure):
     _fields_ = [("R", c_int32), ("S", c_int32), ("stride_h", c_int32), ("stride_w", c_int32),
                 ("pad_top", c_int32), ("pad_left", c_int32), ("num_segments", c_int32),
-                ("seg", WgradSegment * RN_CONV_MAX_SEGMENTS)]
+                ("seg", WgradSegment * RN_CONV_MAX_SEGMENTS), ("opts", LaunchOpts)]
 
 
 class DwSegment(Structure):
@@ -196,7 +215,15 @@ _SIGNATURES = {
                                   c_int, c_int, c_void_p]),
     "rn_fpn_topdown": (c_int, [_PP, _PP, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rn_balance_features": (c_int, [_PP, _PP, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "rn_set_reserved_cus": (c_int, [c_int]),
+    "rn_create": (c_int, [c_int, POINTER(c_void_p)]),
+    "rn_destroy": (c_int, [c_void_p]),
+    "rn_handle_device": (c_int, [c_void_p]),
+    "rn_handle_num_cus": (c_int, [c_void_p]),
+    "rn_handle_set_launch_opts": (c_int, [c_void_p, POINTER(LaunchOpts)]),
+    "rn_handle_get_launch_opts": (c_int, [c_void_p, POINTER(LaunchOpts)]),
+    "rn_handle_comm_init": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int]),
+    "rn_handle_comm": (c_void_p, [c_void_p, c_int]),
+    "rn_comm_available": (c_int, []),
     "rn_comm_unique_id_bytes": (c_int, []),
     "rn_comm_unique_id": (c_int, [c_void_p]),
     "rn_comm_init": (c_int, [c_void_p, c_int, c_int, POINTER(c_void_p)]),
@@ -251,6 +278,49 @@ def lib(f16=False):
             raise RnetError(f"{path}: built for the other 16-bit storage type: rebuild")
         _libs[f16] = handle
     return _libs[f16]
+
+
+class Handle:
+    """rn_handle (include/rnet_hip.h): per-device context of one engine — device id, CU count, the
+    engine's default rn_launch_opts, and the native communicators created through it (destroyed with it)."""
+
+    def __init__(self, library, device_id, opts=None):
+        self.lib = library
+        self.h = c_void_p()
+        check(library.rn_create(int(device_id), ctypes.byref(self.h)), "rn_create")
+        if opts is not None:
+            self.set_launch_opts(opts)
+
+    def set_launch_opts(self, opts):
+        check(self.lib.rn_handle_set_launch_opts(self.h, ctypes.byref(opts)), "rn_handle_set_launch_opts")
+
+    def launch_opts(self):
+        o = LaunchOpts()
+        check(self.lib.rn_handle_get_launch_opts(self.h, ctypes.byref(o)), "rn_handle_get_launch_opts")
+        return o
+
+    @property
+    def device(self):
+        return self.lib.rn_handle_device(self.h)
+
+    @property
+    def num_cus(self):
+        return self.lib.rn_handle_num_cus(self.h)
+
+    def comm_init(self, slot, unique_id, rank, world):
+        check(self.lib.rn_handle_comm_init(self.h, int(slot), unique_id, int(rank), int(world)), "rn_handle_comm_init")
+        return c_void_p(self.lib.rn_handle_comm(self.h, int(slot)))
+
+    def close(self):
+        if self.h:
+            self.lib.rn_destroy(self.h)
+            self.h = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def check(status: int, what: str = ""):

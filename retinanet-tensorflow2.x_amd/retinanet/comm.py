@@ -5,8 +5,13 @@ messages — ~65 + 65 SyncBatchNorm all-reduces and the loss normaliser — go t
 communicator is up: one ncclAllReduce in program order on the compute stream instead of a Python dispatch through
 c10d plus a hop to the process group's stream and back per message.
 
-`maybe_enable_native(engine)` is what the executor / bench call when world > 1: it builds a communicator, VALIDATES it
-against torch.distributed on a known vector, and only then hands it to the engine.  RNET_COMM=torch switches it off."""
+`maybe_enable_native(engine)` is what the executor / bench call when world > 1.  Every fallible stage is COLLECTIVE:
+the ranks agree (a MIN over torch.distributed) that librccl loads everywhere before anyone enters the collective
+`rn_comm_init`, rank 0 broadcasts (ok, unique id) so a failed draw makes all ranks bail together, the init status is
+agreed on before any rank uses or abandons the communicator, and the communicator is VALIDATED against
+torch.distributed on a known vector before the engine gets it.  A failure on one rank therefore sends every rank down
+the torch.distributed path — never one rank into `except` while the others wait in a collective.
+RNET_COMM=torch switches the native path off."""
 from __future__ import annotations
 
 import ctypes
@@ -18,21 +23,62 @@ import torch
 from retinanet import _C
 
 
+def _agree(ok, device, group):
+    """MIN of a local success flag over the job (torch.distributed): True only if every rank says True."""
+    import torch.distributed as dist
+    t = torch.tensor([1.0 if ok else 0.0], device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(t.item() == 1.0)
+
+
 class NativeComm:
-    def __init__(self, rank, world, device, group=None):
+    """One RCCL communicator behind the C ABI.  Construction is collective and never raises on one rank only:
+    `self.ok` is the job-wide verdict (False on every rank if any stage failed anywhere)."""
+
+    def __init__(self, rank, world, device, group=None, handle=None, slot=0, lib=None):
         import torch.distributed as dist
-        lib = _C.lib()
+        lib = lib if lib is not None else (handle.lib if handle is not None else _C.lib())
+        self._h, self.rank, self.world, self.device, self._lib = None, rank, world, device, lib
+        self._owned = handle is None      # a communicator created through an rn_handle is destroyed with it
+        self.ok, self.error = False, ""
+        # stage 0 — local preconditions, agreed on before anything collective in RCCL
+        try:
+            local = lib.rn_comm_available() == 1
+        except Exception as e:   # noqa: BLE001
+            local, self.error = False, str(e)
+        if not _agree(local, device, group):
+            self.error = self.error or "librccl is not loadable on every rank"
+            return
+        # stage 1 — rank 0 draws the unique id and broadcasts (ok, id): all ranks take the same branch
         n = lib.rn_comm_unique_id_bytes()
-        buf = (ctypes.c_char * n)()
+        box = [None]
         if rank == 0:
-            _C.check(lib.rn_comm_unique_id(buf), "rn_comm_unique_id")
-        box = [bytes(buf.raw) if rank == 0 else None]
+            buf = (ctypes.c_char * n)()
+            box = [bytes(buf.raw) if lib.rn_comm_unique_id(buf) == 0 else None]
         dist.broadcast_object_list(box, src=0, group=group)       # the out-of-band hand-off of the unique id
+        if box[0] is None:
+            self.error = "rank 0 could not draw an RCCL unique id"
+            return
         uid = (ctypes.c_char * n).from_buffer_copy(box[0])
-        handle = ctypes.c_void_p()
-        with torch.cuda.device(device):
-            _C.check(lib.rn_comm_init(uid, int(rank), int(world), ctypes.byref(handle)), "rn_comm_init")
-        self._h, self.rank, self.world, self.device, self._lib = handle, rank, world, device, lib
+        # stage 2 — the collective init; its status is agreed on before any rank uses or abandons the communicator
+        comm, status = ctypes.c_void_p(), -1
+        try:
+            with torch.cuda.device(device):
+                if handle is not None:
+                    status = lib.rn_handle_comm_init(handle.h, int(slot), uid, int(rank), int(world))
+                    comm = ctypes.c_void_p(lib.rn_handle_comm(handle.h, int(slot))) if status == 0 else comm
+                else:
+                    status = lib.rn_comm_init(uid, int(rank), int(world), ctypes.byref(comm))
+        except Exception as e:   # noqa: BLE001
+            self.error = str(e)
+        if status != 0 and not self.error:
+            self.error = (lib.rn_last_error() or b"").decode()
+        self._h = comm if status == 0 else None
+        if not _agree(status == 0, device, group):
+            self.error = self.error or "rn_comm_init failed on another rank"
+            self.close()
+            return
+        self.ok = True
 
     def all_reduce_small(self, t):
         assert t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda
@@ -44,22 +90,29 @@ class NativeComm:
                  "rn_allreduce_bucket")
 
     def close(self):
-        if self._h:
+        if self._h and self._owned:
             self._lib.rn_comm_destroy(self._h)
-            self._h = None
+        self._h = None
+        self.ok = False
 
 
 def maybe_enable_native(engine):
-    """Give `engine` (TrainEngine) a validated native communicator for its small messages; returns it or None."""
+    """Give `engine` (TrainEngine) a validated native communicator for its small messages; returns it or None.
+    Collective over engine.pg: every rank returns a communicator or every rank returns None."""
     import torch.distributed as dist
     mode = os.environ.get("RNET_COMM", "auto")
     if engine.world <= 1 or mode == "torch" or not dist.is_initialized():
         return None
     if dist.get_backend(engine.pg) != "nccl":     # gloo (CPU / one-device functional runs): nothing to take over
         return None
+    comm = NativeComm(dist.get_rank(engine.pg), engine.world, engine.dev, engine.pg,
+                      handle=getattr(engine, "handle", None), slot=0)
+    if not comm.ok:
+        logging.warning("rn_comm unavailable, SyncBN messages stay on torch.distributed: %s", comm.error)
+        return None
+    # stage 3 — validate against torch.distributed before trusting it with SyncBatchNorm statistics
+    good, err = False, ""
     try:
-        comm = NativeComm(dist.get_rank(engine.pg), engine.world, engine.dev, engine.pg)
-        # validate against torch.distributed before trusting it with SyncBatchNorm statistics
         g = torch.Generator(device="cpu").manual_seed(1234 + comm.rank)
         x = torch.randn((4099,), generator=g).to(engine.dev)
         want = x.clone()
@@ -67,12 +120,13 @@ def maybe_enable_native(engine):
         with torch.cuda.device(engine.dev):
             comm.all_reduce_small(x)
             torch.cuda.synchronize()
-        ok = torch.tensor([1.0 if torch.allclose(x, want, rtol=1e-5, atol=1e-5) else 0.0], device=engine.dev)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=engine.pg)
-        if ok.item() != 1.0:
-            raise RuntimeError("native all-reduce disagrees with torch.distributed")
-    except Exception as e:      # any failure: stay on torch.distributed (all ranks take the same branch: the
-        logging.warning("rn_comm unavailable, SyncBN messages stay on torch.distributed: %s", e)   # check is collective)
+        good = bool(torch.allclose(x, want, rtol=1e-5, atol=1e-5))
+    except Exception as e:   # noqa: BLE001 — the verdict below is still collective
+        err = str(e)
+    if not _agree(good, engine.dev, engine.pg):
+        logging.warning("rn_comm disagrees with torch.distributed on some rank, SyncBN messages stay on "
+                        "torch.distributed %s", err)
+        comm.close()
         return None
     engine.native_comm = comm
     logging.info("SyncBN / normaliser messages go through rn_comm (RCCL on the compute stream)")

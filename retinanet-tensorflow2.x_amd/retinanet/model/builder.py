@@ -65,6 +65,9 @@ class RetinaNetModel:
         self.optimizer = None
         self._engines = {}
         self._train_engines = {}
+        # rn_launch_opts (dict of fields or _C.LaunchOpts) for the engines this model builds: kernel-family overrides
+        # for tests / A/B timing, per model — the library has no process-wide knobs.  Set before the first call.
+        self.launch_opts = None
         self._frozen = set()
         self.loaded_extras = {}
         self.input_shape = (None,) + tuple(graph.tensors["images"][:3])
@@ -173,7 +176,8 @@ class RetinaNetModel:
                                                  bn_epsilon=self.params.architecture.batch_norm.epsilon,
                                                  capture_graph=capture_graph,
                                                  f16=(str(self.params.floatx.precision) == "mixed_float16"
-                                                      and os.environ.get("RNET_F16", "1") != "0"))
+                                                      and os.environ.get("RNET_F16", "1") != "0"),
+                                                 launch_opts=self.launch_opts)
         return self._engines[key]
 
     def train_engine(self, batch_size, process_group=None, world_size=None):
@@ -183,7 +187,8 @@ class RetinaNetModel:
         key = (int(batch_size), world_size)
         if key not in self._train_engines:
             self._train_engines[key] = TrainEngine(self, batch_size, frozen_names=self._frozen,
-                                                   process_group=process_group, world_size=world_size)
+                                                   process_group=process_group, world_size=world_size,
+                                                   launch_opts=self.launch_opts)
         return self._train_engines[key]
 
     def __call__(self, images, training=False):

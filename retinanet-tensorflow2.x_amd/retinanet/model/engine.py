@@ -45,7 +45,8 @@ def stem_pool_partner(g, stem_op, stem_k):
 
 
 class InferenceEngine:
-    def __init__(self, graph, variables, batch_size, device, bn_epsilon=1e-3, capture_graph=False, f16=False):
+    def __init__(self, graph, variables, batch_size, device, bn_epsilon=1e-3, capture_graph=False, f16=False,
+                 launch_opts=None):
         self.g = graph
         self.B = int(batch_size)
         self.dev = torch.device(device)
@@ -54,6 +55,11 @@ class InferenceEngine:
         self.h16 = torch.float16 if self.f16 else torch.bfloat16
         self._DT = {"bf16": self.h16, "f32": torch.float32}
         self.lib = _C.lib(self.f16)
+        # rn_launch_opts of THIS engine's conv launches (kernel-family overrides for tests / A/B timing; the library has
+        # no process-wide knobs)
+        if isinstance(launch_opts, dict):
+            launch_opts = _C.LaunchOpts(**launch_opts)
+        self.launch_opts = launch_opts.copy() if launch_opts is not None else _C.LaunchOpts()
         self._keep = []     # ctypes structs / arrays that must outlive the launches
         self.steps = []     # list of (callable, name)
         self.t = {}         # tensor name -> torch tensor
@@ -195,6 +201,7 @@ class InferenceEngine:
         first = ops[0]
         c0 = self.g.convs[first["conv"]]
         p = _C.ConvProblem()
+        p.opts = self.launch_opts
         p.R = p.S = c0["k"]
         p.stride_h = p.stride_w = c0["stride"]
         p.pad_top = p.pad_left = first["pad"]
@@ -265,6 +272,7 @@ class InferenceEngine:
                              "rn_pack_image_nhwc4")
                 self.steps.append((pack, "pack_stem_input"))
                 p = _C.ConvProblem()
+                p.opts = self.launch_opts
                 p.R, p.S, p.stride_h, p.stride_w, p.pad_top, p.pad_left = self.stem_k, 1, 2, 2, 0, 0
                 p.act = _C.ACT_IDS[op["act"]]
                 p.out_dtype = _C.RN_DT_BF16

@@ -47,7 +47,11 @@ def _ohwi_to_hwio(w):
 
 
 class TrainEngine:
-    def __init__(self, model, batch_size, frozen_regexes=(), process_group=None, world_size=None, frozen_names=()):
+    def __init__(self, model, batch_size, frozen_regexes=(), process_group=None, world_size=None, frozen_names=(),
+                 launch_opts=None):
+        """launch_opts: `_C.LaunchOpts` (or a dict of its fields) copied into every rn_conv_problem / rn_wgrad_problem of
+        THIS engine (include/rnet_hip.h rn_launch_opts) — kernel-family overrides for tests and A/B timing; the library
+        has no process-wide knobs."""
         self.model = model
         self.g = model.graph
         self.params_cfg = model.params
@@ -68,9 +72,15 @@ class TrainEngine:
         bn = self.params_cfg.architecture.batch_norm
         self.eps, self.momentum_bn = float(bn.epsilon), float(bn.momentum)
         self.sync_bn = bool(bn.use_sync) and self.world > 1
-        # data parallel: the persistent kernels leave a few CUs to RCCL (csrc/rn_core.hip, rn_set_reserved_cus)
-        _C.check(self.lib.rn_set_reserved_cus(int(os.environ.get("RNET_COMM_CUS", "8")) if self.world > 1 else 0),
-                 "rn_set_reserved_cus")
+        if isinstance(launch_opts, dict):
+            launch_opts = _C.LaunchOpts(**launch_opts)
+        self.launch_opts = launch_opts.copy() if launch_opts is not None else _C.LaunchOpts()
+        # data parallel: the persistent kernels leave a few CUs to RCCL (rn_launch_opts.reserved_cus)
+        if self.world > 1 and not self.launch_opts.reserved_cus:
+            self.launch_opts.reserved_cus = int(os.environ.get("RNET_COMM_CUS", "8"))
+        # the per-device handle (rn_create): device, CU count, this engine's launch defaults; owns the native communicators
+        self.handle = _C.Handle(self.lib, self.dev.index if self.dev.index is not None else torch.cuda.current_device(),
+                                self.launch_opts)
         self.frozen = set(frozen_names)
         for k in model.variables:
             if any(rx.search(k) for rx in frozen_regexes):
@@ -562,6 +572,7 @@ class TrainEngine:
         first = ops[0]
         c0 = self.g.convs[first["conv"]]
         p = _C.ConvProblem()
+        p.opts = self.launch_opts
         p.R = p.S = c0["k"]
         p.stride_h = p.stride_w = c0["stride"]
         p.pad_top = p.pad_left = first["pad"]
@@ -751,6 +762,7 @@ class TrainEngine:
                                             pin, st), "rn_pack_image_nhwc4"))
                 live = self._conv_trainable(op)
                 p = _C.ConvProblem()
+                p.opts = self.launch_opts
                 p.R, p.S, p.stride_h, p.stride_w, p.pad_top, p.pad_left = self.stem_k, 1, 2, 2, 0, 0
                 p.act = _C.RN_ACT_NONE if live else _C.ACT_IDS[op["act"]]
                 p.out_dtype, p.num_segments = _C.RN_DT_BF16, 1
@@ -967,6 +979,7 @@ class TrainEngine:
                 c = self.g.convs[op["conv"]]
                 H, W = self.t["images"].shape[1], self.t["images"].shape[2]
                 pw = _C.WgradProblem()
+                pw.opts = self.launch_opts
                 k = self.stem_k
                 pw.R, pw.S, pw.stride_h, pw.stride_w, pw.pad_top, pw.pad_left, pw.num_segments = k, 1, 2, 2, 0, 0, 1
                 sg = pw.seg[0]
@@ -1071,6 +1084,7 @@ class TrainEngine:
         for cname, cops in by_conv.items():
             c = self.g.convs[cname]
             p = _C.WgradProblem()
+            p.opts = self.launch_opts
             p.R = p.S = c["k"]
             p.stride_h = p.stride_w = c["stride"]
             p.pad_top = p.pad_left = cops[0]["pad"]
@@ -1259,6 +1273,7 @@ class TrainEngine:
         c0 = self.g.convs[need[0]["conv"]]
         k, stride = c0["k"], c0["stride"]
         p = _C.ConvProblem()
+        p.opts = self.launch_opts
         p.R = p.S = k
         p.stride_h = p.stride_w = 1
         p.pad_top = p.pad_left = k - 1 - need[0]["pad"]

@@ -75,3 +75,80 @@ def test_get_strategy_types():
         get_strategy(AttrDict(type="bogus", name=""))
     s = get_strategy(AttrDict(type="gpu", name=""))
     assert s.num_replicas_in_sync == 1
+
+
+class _FakeCommLib:
+    """Stands in for librnet_hip.so's rn_comm entry points so that a failure can be injected on ONE rank at each stage
+    of NativeComm's construction (no GPU, no RCCL: the point is the control flow around the collectives)."""
+
+    def __init__(self, rank, fail_stage, fail_rank):
+        self.rank, self.fail_stage, self.fail_rank = rank, fail_stage, fail_rank
+        self.inits = 0
+
+    def _fails(self, stage):
+        return self.fail_stage == stage and self.rank == self.fail_rank
+
+    def rn_comm_available(self):
+        return 0 if self._fails("available") else 1
+
+    def rn_comm_unique_id_bytes(self):
+        return 128
+
+    def rn_comm_unique_id(self, buf):
+        return -4 if self._fails("unique_id") else 0
+
+    def rn_comm_init(self, uid, rank, world, comm_out):
+        self.inits += 1
+        if self._fails("init"):
+            return -4
+        comm_out._obj.value = 0x1000 + rank
+        return 0
+
+    def rn_comm_destroy(self, comm):
+        return 0
+
+    def rn_last_error(self):
+        return b"injected failure"
+
+
+def _worker_comm_failure(rank, world, port, out):
+    sys.path.insert(0, PKG)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import contextlib
+    from unittest import mock
+    from retinanet.comm import NativeComm
+    res = {}
+    # (stage, rank that fails): a failed draw can only happen on rank 0; the others on either rank
+    cases = [("none", 0), ("available", 0), ("available", 1), ("unique_id", 0), ("init", 0), ("init", 1)]
+    with mock.patch("torch.cuda.device", lambda d: contextlib.nullcontext()):   # CPU box: no device to select
+        for stage, who in cases:
+            lib = _FakeCommLib(rank, stage, who)
+            comm = NativeComm(rank, world, torch.device("cpu"), None, lib=lib)
+            res[f"{stage}@{who}"] = (comm.ok, lib.inits, comm._h is not None)
+    # the ranks are still in lockstep: one more collective completes
+    t = torch.ones(1)
+    dist.all_reduce(t)
+    res["tail"] = t.item()
+    out[rank] = res
+    dist.destroy_process_group()
+
+
+def test_native_comm_construction_is_collective_safe():
+    """retinanet/comm.py: a failure on ONE rank at any stage — librccl not loadable,
+    the unique-id draw, the collective init itself — must send EVERY rank down the fallback together, never one rank into
+    an exception while the others wait in a collective.  Two gloo ranks, injected failures; the run deadlocks (and the
+    test times out) if a stage is not collective."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_comm_failure, args=(world, _free_port(), out), nprocs=world, join=True)
+    r0, r1 = out[0], out[1]
+    assert r0["tail"] == r1["tail"] == 2.0
+    assert r0["none@0"] == r1["none@0"] == (True, 1, True)
+    for key in ("available@0", "available@1", "unique_id@0"):
+        # agreed on before anyone entered the collective init: no rank called it
+        assert r0[key] == r1[key] == (False, 0, False), (key, r0[key], r1[key])
+    for key in ("init@0", "init@1"):
+        # every rank entered the init; the status is agreed on afterwards and the survivor drops its communicator
+        assert r0[key] == r1[key] == (False, 1, False), (key, r0[key], r1[key])

@@ -15,9 +15,27 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-# the 16-bit storage type under test: tests/test_gpu_f16.py re-runs cases of this module with torch.float16 on
-# librnet_hip_f16.so (the same sources built with -DRN_F16)
+# The 16-bit storage type under test.  A test parametrized with build="f16" runs on librnet_hip_f16.so (the same sources
+# built with -DRN_F16: IEEE-half storage, v_mfma_f32_32x32x16_f16 — the arithmetic of `mixed_float16`) with half tensors
+# against the same float64 restatement, whose rounding points then round to half; every other test runs the bfloat16
+# build.  The autouse fixture below sets it per test from the test's own parameters: no test calls another test.
 H16 = torch.bfloat16
+_DT = {"bf16": torch.bfloat16, "f16": torch.float16}
+
+
+@pytest.fixture(autouse=True)
+def _storage_type(request):
+    global H16
+    params = request.node.callspec.params if hasattr(request.node, "callspec") else {}
+    H16 = _DT[params.get("build", "bf16")]
+    yield
+    H16 = torch.bfloat16
+
+
+def _builds(cases, f16_cases, tag=""):
+    """(build, case) parameters: every case on the bfloat16 build + `f16_cases` on the half build"""
+    ps = [pytest.param("bf16", c, id=tag + "x".join(str(v) for v in c)) for c in cases]
+    return ps + [pytest.param("f16", c, id="f16-" + tag + "x".join(str(v) for v in c)) for c in f16_cases]
 
 
 def _lib():
@@ -34,10 +52,13 @@ def _seed(case):
     return zlib.crc32(repr(case).encode()) % (2 ** 31)
 
 
-def _conv_gpu(cuda, segs, k, stride, pad, act, out_f32):
+def _conv_gpu(cuda, segs, k, stride, pad, act, out_f32, opts=None):
+    """opts: rn_launch_opts fields of THIS launch (kernel family, persistent grid, ...): per-call, no process state"""
     from retinanet import _C
     lib = _lib()
     p = _C.ConvProblem()
+    if opts:
+        p.opts = _C.LaunchOpts(**opts)
     p.R = p.S = k
     p.stride_h = p.stride_w = stride
     p.pad_top = p.pad_left = pad
@@ -145,8 +166,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(str(v) for v in c))
-def test_conv_single(cuda, case):
+def _run_conv_single(cuda, case, opts=None):
     N, H, W, Cin, Cout, k, stride, act, use_res, out_f32 = case
     g = torch.Generator().manual_seed(_seed(case))
     pad = (k - 1) // 2
@@ -156,23 +176,29 @@ def test_conv_single(cuda, case):
          "scale": torch.rand((Cout,), generator=g) + 0.5, "shift": torch.randn((Cout,), generator=g) * 0.1}
     if use_res:
         s["residual"] = torch.randn((N, Ho, Wo, Cout), generator=g)
-    got = _conv_gpu(cuda, [s], k, stride, pad, act, out_f32)[0]
+    got = _conv_gpu(cuda, [s], k, stride, pad, act, out_f32, opts)[0]
     _close(got, _conv_ref(s, k, stride, pad, act, out_f32), out_f32)
 
 
-@pytest.mark.parametrize("case", [c for c in CASES if c[4] > 128 and c[4] % 8 == 0],
-                         ids=lambda c: "big-" + "x".join(str(v) for v in c))
-def test_conv_big_tile_kernel(cuda, case):
-    """Same cases through the 256x256x32 four-stage kernel (rn_conv_big.hip; normally picked only
-    when the launch has >= 192 such tiles)."""
-    from retinanet import _C
-    lib = _lib()
-    lib.rn_debug_conv_tile(2)
-    try:
-        test_conv_single(cuda, case)
-        test_conv_grouped_pyramid(cuda)
-    finally:
-        lib.rn_debug_conv_tile(0)
+@pytest.mark.parametrize("build,case", _builds(CASES, CASES))
+def test_conv_single(cuda, build, case):
+    """what the dispatcher picks at these sizes: the 128-row conv_fwd_kernel"""
+    _run_conv_single(cuda, case)
+
+
+_BIG_CASES = [c for c in CASES if c[4] > 128 and c[4] % 8 == 0]
+
+
+@pytest.mark.parametrize("build,case", _builds(_BIG_CASES, _BIG_CASES[:6], "big-"))
+def test_conv_big_tile_kernel(cuda, build, case):
+    """Same cases through the 256-row persistent kernels (rn_conv_big.hip / rn_conv_halo.hip; normally picked only
+    when the launch has >= 192 such tiles): rn_launch_opts.conv_tile = 2 on this launch."""
+    _run_conv_single(cuda, case, opts=dict(conv_tile=2))
+
+
+@pytest.mark.parametrize("build", ["bf16", "f16"])
+def test_conv_grouped_pyramid_on_the_256_row_kernels(cuda, build):
+    _run_grouped_pyramid(cuda, opts=dict(conv_tile=2))
 
 
 HALO_CASES = [
@@ -190,8 +216,8 @@ HALO_CASES = [
 ]
 
 
-@pytest.mark.parametrize("case", HALO_CASES, ids=lambda c: "halo-" + "x".join(str(v) for v in c))
-def test_conv_halo_kernel(cuda, case):
+@pytest.mark.parametrize("build,case", _builds(HALO_CASES, HALO_CASES[:6], "halo-"))
+def test_conv_halo_kernel(cuda, build, case):
     """3x3 / stride 1 / pad 1 with Cout >= 256 through the halo-patch kernel (rn_conv_halo.hip), against the
     float64 reference and against conv_big_kernel on the same inputs (same products, other summation order)."""
     from retinanet import _C
@@ -203,22 +229,18 @@ def test_conv_halo_kernel(cuda, case):
          "scale": torch.rand((Cout,), generator=g) + 0.5, "shift": torch.randn((Cout,), generator=g) * 0.1}
     if use_res:
         s["residual"] = torch.randn((N, H, W, Cout), generator=g)
-    lib.rn_debug_conv_tile(2)
-    try:
-        p = _C.ConvProblem()
-        p.R = p.S = 3
-        p.stride_h = p.stride_w = p.pad_top = p.pad_left = 1
-        p.out_dtype, p.num_segments = (_C.RN_DT_F32 if out_f32 else _C.RN_DT_BF16), 1
-        sg = p.seg[0]
-        sg.N, sg.H, sg.W, sg.Cin, sg.pix_stride, sg.Ho, sg.Wo, sg.Cout = N, H, W, Cin, Cin, H, W, Cout
-        assert lib.rn_conv_kernel_id(ctypes.byref(p)) == 2
-        got = _conv_gpu(cuda, [s], 3, 1, 1, act, out_f32)[0]
-        lib.rn_debug_conv_halo(0)
-        assert lib.rn_conv_kernel_id(ctypes.byref(p)) == 1
-        big = _conv_gpu(cuda, [s], 3, 1, 1, act, out_f32)[0]
-    finally:
-        lib.rn_debug_conv_halo(1)
-        lib.rn_debug_conv_tile(0)
+    p = _C.ConvProblem()
+    p.R = p.S = 3
+    p.stride_h = p.stride_w = p.pad_top = p.pad_left = 1
+    p.out_dtype, p.num_segments = (_C.RN_DT_F32 if out_f32 else _C.RN_DT_BF16), 1
+    sg = p.seg[0]
+    sg.N, sg.H, sg.W, sg.Cin, sg.pix_stride, sg.Ho, sg.Wo, sg.Cout = N, H, W, Cin, Cin, H, W, Cout
+    p.opts = _C.LaunchOpts(conv_tile=2)
+    assert lib.rn_conv_kernel_id(ctypes.byref(p)) == 2
+    got = _conv_gpu(cuda, [s], 3, 1, 1, act, out_f32, dict(conv_tile=2))[0]
+    p.opts = _C.LaunchOpts(conv_tile=2, conv_no_halo=1)
+    assert lib.rn_conv_kernel_id(ctypes.byref(p)) == 1
+    big = _conv_gpu(cuda, [s], 3, 1, 1, act, out_f32, dict(conv_tile=2, conv_no_halo=1))[0]
     want = _conv_ref(s, 3, 1, 1, act, out_f32)
     _close(got, want, out_f32)
     scale = want.abs().max().item() + 1e-6
@@ -253,13 +275,7 @@ def test_conv_bias_only_rounds_once(cuda, case):
          "w": torch.randn((k, k, Cin, Cout), generator=g) / math.sqrt(k * k * Cin),
          "bias": torch.randn((Cout,), generator=g)}
     pad = (k - 1) // 2
-    lib.rn_debug_conv_tile(2)
-    lib.rn_debug_conv_halo_grid(grid)
-    try:
-        got = _conv_gpu(cuda, [s], k, 1, pad, act, False)[0]
-    finally:
-        lib.rn_debug_conv_halo_grid(0)
-        lib.rn_debug_conv_tile(0)
+    got = _conv_gpu(cuda, [s], k, 1, pad, act, False, dict(conv_tile=2, max_workgroups=grid))[0]
     want = _conv_ref(s, k, 1, pad, act, False)
     _close(got, want, False)
     assert (got != want).float().mean().item() < 2e-3
@@ -290,11 +306,7 @@ def test_conv_bias_then_batchnorm_rounding_points(cuda, case):
     if use_res:
         s["residual"] = torch.randn((N, H, W, Cout), generator=g)
     pad = (k - 1) // 2
-    lib.rn_debug_conv_tile(2 if kid else 1)
-    try:
-        got = _conv_gpu(cuda, [s], k, 1, pad, act, False)[0]
-    finally:
-        lib.rn_debug_conv_tile(0)
+    got = _conv_gpu(cuda, [s], k, 1, pad, act, False, dict(conv_tile=2 if kid else 1))[0]
     _close(got, _conv_ref(s, k, 1, pad, act, False), False)
 
 
@@ -310,8 +322,8 @@ SPLIT_CASES = [
 ]
 
 
-@pytest.mark.parametrize("case", SPLIT_CASES, ids=lambda c: "split-" + "x".join(str(v) for v in c))
-def test_conv_f32_weights_as_split_bf16_planes(cuda, case):
+@pytest.mark.parametrize("build,case", _builds(SPLIT_CASES, SPLIT_CASES[:4], "split-"))
+def test_conv_f32_weights_as_split_bf16_planes(cuda, build, case):
     """The dtype=float32 prediction convs (detection_head.py:80-88): bf16 activations x f32 kernel + f32 bias,
     f32 accumulate, f32 out.  With rn_conv_segment.w_terms the kernel is carried as 2 (3) bf16 planes: against the
     float64 product with the SAME planes only fp32 summation order is left (<= 2e-5 of the output range); against
@@ -325,22 +337,18 @@ def test_conv_f32_weights_as_split_bf16_planes(cuda, case):
          "w": torch.randn((k, k, Cin, Cout), generator=g) * 0.01,      # RandomNormal(0.01), detection_head.py:40-43
          "bias": torch.full((Cout,), -4.59512), "w_terms": terms}
     pad = (k - 1) // 2
-    lib.rn_debug_conv_tile(2 if kid else 1)
-    lib.rn_debug_conv_halo(1 if kid == 2 else 0)
-    try:
-        p = _C.ConvProblem()
-        p.R = p.S = k
-        p.stride_h = p.stride_w = 1
-        p.pad_top = p.pad_left = pad
-        p.out_dtype, p.num_segments = _C.RN_DT_F32, 1
-        sg = p.seg[0]
-        sg.N, sg.H, sg.W, sg.Cin, sg.pix_stride, sg.Ho, sg.Wo, sg.Cout = N, H, W, Cin, Cin, H, W, Cout
-        assert lib.rn_conv_kernel_id(ctypes.byref(p)) == kid
-        got = _conv_gpu(cuda, [s], k, 1, pad, None, True)[0]
-        one = _conv_gpu(cuda, [dict(s, w_terms=1)], k, 1, pad, None, True)[0]
-    finally:
-        lib.rn_debug_conv_halo(1)
-        lib.rn_debug_conv_tile(0)
+    opts = dict(conv_tile=2 if kid else 1, conv_no_halo=0 if kid == 2 else 1)
+    p = _C.ConvProblem()
+    p.R = p.S = k
+    p.stride_h = p.stride_w = 1
+    p.pad_top = p.pad_left = pad
+    p.out_dtype, p.num_segments = _C.RN_DT_F32, 1
+    sg = p.seg[0]
+    sg.N, sg.H, sg.W, sg.Cin, sg.pix_stride, sg.Ho, sg.Wo, sg.Cout = N, H, W, Cin, Cin, H, W, Cout
+    p.opts = _C.LaunchOpts(**opts)
+    assert lib.rn_conv_kernel_id(ctypes.byref(p)) == kid
+    got = _conv_gpu(cuda, [s], k, 1, pad, None, True, opts)[0]
+    one = _conv_gpu(cuda, [dict(s, w_terms=1)], k, 1, pad, None, True, opts)[0]
     same_planes = _conv_ref(s, k, 1, pad, None, True)
     exact = _conv_ref(dict(s, w_terms=3), k, 1, pad, None, True)
     spread = (exact + 4.59512).abs().max().item()       # range of the logits around the bias
@@ -360,11 +368,7 @@ def test_conv_halo_asymmetric_weights(cuda):
     w = torch.zeros((3, 3, C, C))
     for c in range(C):
         w[0, 2, (c + 1) % C, c] = 1.0
-    lib.rn_debug_conv_tile(2)
-    try:
-        got = _conv_gpu(cuda, [{"x": x, "w": w}], 3, 1, 1, None, True)[0]
-    finally:
-        lib.rn_debug_conv_tile(0)
+    got = _conv_gpu(cuda, [{"x": x, "w": w}], 3, 1, 1, None, True, dict(conv_tile=2))[0]
     want = torch.zeros_like(got)
     want[:, 1:, :-1, :] = torch.roll(x, -1, dims=3)[:, :-1, 1:, :]
     torch.testing.assert_close(got, want, rtol=0, atol=0)
@@ -384,7 +388,7 @@ def test_conv_asymmetric_weights_detect_transposes(cuda):
     torch.testing.assert_close(got, want, rtol=0, atol=0)
 
 
-def test_conv_grouped_pyramid(cuda):
+def _run_grouped_pyramid(cuda, opts=None):
     """One launch, 10 segments: the two head towers over five pyramid levels (shared kernel
     size, per-segment weights/BN) — the shape of detection_head.py:94-100."""
     g = torch.Generator().manual_seed(5)
@@ -394,9 +398,13 @@ def test_conv_grouped_pyramid(cuda):
         for s in (16, 8, 4, 2, 1):
             segs.append({"x": torch.randn((2, s, s, 256), generator=g), "w": w,
                          "scale": torch.rand((256,), generator=g) + 0.5, "shift": torch.randn((256,), generator=g) * 0.1})
-    got = _conv_gpu(cuda, segs, 3, 1, 1, "relu", False)
+    got = _conv_gpu(cuda, segs, 3, 1, 1, "relu", False, opts)
     for s, y in zip(segs, got):
         _close(y, _conv_ref(s, 3, 1, 1, "relu", False), False)
+
+
+def test_conv_grouped_pyramid(cuda):
+    _run_grouped_pyramid(cuda)
 
 
 def test_stem_conv(cuda):

@@ -54,14 +54,25 @@ def _kernel_ids(model, B):
     return {name: _C.lib().rn_conv_kernel_id(ctypes.byref(p)) for name, p in eng.conv_problems.items()}
 
 
-@pytest.mark.parametrize("size,balanced,act", [(256, True, "relu"), (128, False, "relu6")])
-def test_forward_matches_cpu_restatement(cuda, size, balanced, act):
+@pytest.mark.parametrize("size,balanced,act,kernels", [(256, True, "relu", "auto"), (128, False, "relu6", "auto"),
+                                                       (256, True, "relu", "persistent")])
+def test_forward_matches_cpu_restatement(cuda, size, balanced, act, kernels):
+    """kernels = "persistent": the same network with every eligible layer forced onto the 256 x 256 persistent kernels
+    (conv_big_kernel, and conv_halo_kernel for the 3x3 / stride 1 layers) through the model's rn_launch_opts — at test
+    sizes the dispatcher would otherwise keep the 128-row kernel, so this is the whole-network parity check of the
+    kernels the full-size bench runs on."""
     from retinanet.cfg import default_params
     from retinanet.model import ModelBuilder
     p = default_params(input_size=size, balanced=balanced, activation=act)
     model = ModelBuilder(p, "val", device=cuda)()
     _randomize(model, 1)
     B = 2
+    if kernels == "persistent":
+        model.launch_opts = dict(conv_tile=2)
+        ids = _kernel_ids(model, B)
+        assert ids["conv:tower0"] == 2 and ids["conv:g2b1_out"] == 1, ids
+    else:
+        assert _kernel_ids(model, B)["conv:tower0"] == 0
     g = torch.Generator().manual_seed(1337)
     images = torch.randn((B, size, size, 3), generator=g)
     preds = model(images.to(cuda), training=False)
@@ -92,19 +103,6 @@ def test_forward_at_baseline_sizes(cuda, size, B):
         # stage 1 at 1024^2: 4 x 256 x 256 = 262 144 pixels per launch < 2^22 (rn_fdiv's validity bound)
         assert B * (size // 4) ** 2 < (1 << 22)
     _check_predictions(preds, RefModel(p, model.variables, emulate_bf16=True)(images))
-
-
-def test_forward_through_the_persistent_kernels(cuda):
-    """The same network with every eligible layer forced onto the 256 x 256 persistent kernels (conv_big_kernel,
-    and conv_halo_kernel for the 3x3 / stride 1 layers) — at test sizes the dispatcher would otherwise keep the
-    128-row kernel, so this is the whole-network parity check of the kernels the full-size bench runs on."""
-    from retinanet import _C
-    lib = _C.lib()
-    lib.rn_debug_conv_tile(2)
-    try:
-        test_forward_matches_cpu_restatement(cuda, 256, True, "relu")
-    finally:
-        lib.rn_debug_conv_tile(0)
 
 
 def test_serving_path_end_to_end(cuda):

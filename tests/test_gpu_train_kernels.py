@@ -11,9 +11,20 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-# the 16-bit storage type under test: tests/test_gpu_f16.py re-runs cases of this module with torch.float16 on
-# librnet_hip_f16.so
+# The 16-bit storage type under test: a test parametrized with build="f16" runs on librnet_hip_f16.so (-DRN_F16, IEEE half)
+# with half tensors; everything else on the bfloat16 build.  Set per test from its own parameters by the autouse fixture.
 H16 = torch.bfloat16
+_DT = {"bf16": torch.bfloat16, "f16": torch.float16}
+BUILDS = ["bf16", "f16"]
+
+
+@pytest.fixture(autouse=True)
+def _storage_type(request):
+    global H16
+    params = request.node.callspec.params if hasattr(request.node, "callspec") else {}
+    H16 = _DT[params.get("build", "bf16")]
+    yield
+    H16 = torch.bfloat16
 
 
 def _lib():
@@ -46,16 +57,18 @@ WGRAD_SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("shape", WGRAD_SHAPES,
-                         ids=["3x3", "1x1", "3x3s2", "pred36", "pyramid", "cin192_720", "co640", "big_pyramid", "big_720",
-                              "big_1x1", "big_s2"])
-def test_wgrad(cuda, shape, request):
+_WGRAD_IDS = ["3x3", "1x1", "3x3s2", "pred36", "pyramid", "cin192_720", "co640", "big_pyramid", "big_720", "big_1x1",
+              "big_s2"]
+_WGRAD_F16 = [0, 1, 2, 3, 4, 7, 8, 9]     # the half build: the 128-tile kernel and the 256-wide kernels
+
+
+@pytest.mark.parametrize("build,shape_id", [("bf16", i) for i in _WGRAD_IDS] + [("f16", _WGRAD_IDS[i]) for i in _WGRAD_F16])
+def test_wgrad(cuda, build, shape_id):
     from retinanet import _C
     lib = _lib()
-    segs, k, stride = shape
-    big = any(shape is sh for sh in WGRAD_SHAPES[7:])        # the big_* cases
-    lib.rn_debug_wgrad_big_min_pixels(1 if big else 16384)   # the big_* cases must run the 256x256-tile kernel
-    request.addfinalizer(lambda: lib.rn_debug_wgrad_big_min_pixels(16384))
+    idx = _WGRAD_IDS.index(shape_id)
+    segs, k, stride = WGRAD_SHAPES[idx]
+    big = idx >= 7        # the big_* cases must run the 256-wide kernels: rn_launch_opts.wgrad_kernel = 2 on this call
     g = torch.Generator().manual_seed(len(segs) * 100 + k + stride)
     pad = (k - 1) // 2
     cin, cout = segs[0][2], segs[0][3]
@@ -64,6 +77,7 @@ def test_wgrad(cuda, shape, request):
     p.stride_h = p.stride_w = stride
     p.pad_top = p.pad_left = pad
     p.num_segments = len(segs)
+    p.opts = _C.LaunchOpts(wgrad_kernel=2 if big else 0)
     keep = []
     want = torch.zeros((cout, k, k, cin), dtype=torch.float64)
     for i, (N, H, ci, co) in enumerate(segs):
@@ -92,10 +106,10 @@ def test_wgrad(cuda, shape, request):
 
 
 def test_kernels_with_compute_units_reserved_for_rccl(cuda):
-    """rn_set_reserved_cus (data-parallel runs): the persistent kernels run on fewer workgroups than CUs, wgrad_big
-    walks several work items per workgroup.  The 256-row convs must give bit-identical outputs (a tile's arithmetic
-    does not depend on which workgroup computes it); wgrad_big re-plans its split-K chunks for the smaller machine,
-    so its sums are compared with the float64 reference."""
+    """rn_launch_opts.reserved_cus (data-parallel runs): the persistent kernels run on fewer workgroups than CUs, the
+    256-wide weight-gradient kernels walk several work items per workgroup.  The 256-row convs must give bit-identical
+    outputs (a tile's arithmetic does not depend on which workgroup computes it); the weight-gradient kernels re-plan
+    their split-K chunks for the smaller machine, so their sums are compared with the float64 reference."""
     from retinanet import _C
     import test_gpu_conv as TC
     lib = _lib()
@@ -104,53 +118,73 @@ def test_kernels_with_compute_units_reserved_for_rccl(cuda):
            "bias": torch.randn((256,), generator=g), "scale": torch.rand((256,), generator=g) + 0.5,
            "shift": torch.randn((256,), generator=g) * 0.1}
     outs = {}
-    lib.rn_debug_conv_tile(2)
-    try:
-        for reserved, halo in ((0, 1), (128, 1), (0, 0), (100, 0)):
-            _C.check(lib.rn_set_reserved_cus(reserved))
-            lib.rn_debug_conv_halo(halo)
-            outs[(reserved, halo)] = TC._conv_gpu(cuda, [seg], 3, 1, 1, "relu", False)[0]
-    finally:
-        lib.rn_debug_conv_halo(1)
-        lib.rn_debug_conv_tile(0)
-        _C.check(lib.rn_set_reserved_cus(0))
-    assert torch.equal(outs[(0, 1)], outs[(128, 1)]) and torch.equal(outs[(0, 0)], outs[(100, 0)])
-    TC._close(outs[(0, 1)], TC._conv_ref(seg, 3, 1, 1, "relu", False), False)
-    # wgrad_big with 128 of the CUs reserved: several work items per workgroup
-    lib.rn_debug_wgrad_big_min_pixels(1)
-    try:
-        N, H, ci, co, k = 4, 20, 256, 256, 3
-        x = _bf(torch.randn((N, H, H, ci), generator=g))
-        dy = _bf(torch.randn((N, H, H, co), generator=g))
-        w = torch.zeros((co, ci, k, k), dtype=torch.float64, requires_grad=True)
-        F.conv2d(x.double().permute(0, 3, 1, 2), w, padding=1).backward(dy.double().permute(0, 3, 1, 2))
-        want = w.grad.permute(0, 2, 3, 1)
-        xd, dyd = x.to(cuda), dy.to(cuda)
-        got = {}
-        for reserved in (0, 128):
-            _C.check(lib.rn_set_reserved_cus(reserved))
-            p = _C.WgradProblem()
-            p.R = p.S = k
-            p.stride_h = p.stride_w = p.pad_top = p.pad_left = 1
-            p.num_segments = 1
-            s = p.seg[0]
-            s.x, s.dy = xd.data_ptr(), dyd.data_ptr()
-            s.N, s.H, s.W, s.Cin, s.Ho, s.Wo, s.Cout = N, H, H, ci, H, H, co
-            ws = _ws(lib.rn_wgrad_workspace_bytes(ctypes.byref(p)), cuda)
-            dw = torch.zeros((co, k, k, ci), dtype=torch.float32, device=cuda)
-            _C.check(lib.rn_conv2d_nhwc_wgrad(ctypes.byref(p), _C.ptr(dw), 0.0, _C.ptr(ws), ws.numel(), _C.current_stream()))
-            torch.cuda.synchronize()
-            got[reserved] = dw.cpu().double()
-    finally:
-        lib.rn_debug_wgrad_big_min_pixels(16384)
-        _C.check(lib.rn_set_reserved_cus(0))
+    for reserved, no_halo in ((0, 0), (128, 0), (0, 1), (100, 1)):
+        outs[(reserved, no_halo)] = TC._conv_gpu(cuda, [seg], 3, 1, 1, "relu", False,
+                                                 dict(conv_tile=2, reserved_cus=reserved, conv_no_halo=no_halo))[0]
+    assert torch.equal(outs[(0, 0)], outs[(128, 0)]) and torch.equal(outs[(0, 1)], outs[(100, 1)])
+    TC._close(outs[(0, 0)], TC._conv_ref(seg, 3, 1, 1, "relu", False), False)
+    # out-of-range values are refused per call
+    with pytest.raises(_C.RnetError):
+        TC._conv_gpu(cuda, [seg], 3, 1, 1, "relu", False, dict(reserved_cus=129))
+    # 256-wide weight-gradient kernels with 128 of the CUs reserved: several work items per workgroup
+    N, H, ci, co, k = 4, 20, 256, 256, 3
+    x = _bf(torch.randn((N, H, H, ci), generator=g))
+    dy = _bf(torch.randn((N, H, H, co), generator=g))
+    w = torch.zeros((co, ci, k, k), dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double().permute(0, 3, 1, 2), w, padding=1).backward(dy.double().permute(0, 3, 1, 2))
+    want = w.grad.permute(0, 2, 3, 1)
+    xd, dyd = x.to(cuda), dy.to(cuda)
+    got = {}
+    for reserved in (0, 128):
+        p = _C.WgradProblem()
+        p.R = p.S = k
+        p.stride_h = p.stride_w = p.pad_top = p.pad_left = 1
+        p.num_segments = 1
+        p.opts = _C.LaunchOpts(wgrad_kernel=2, reserved_cus=reserved)
+        s = p.seg[0]
+        s.x, s.dy = xd.data_ptr(), dyd.data_ptr()
+        s.N, s.H, s.W, s.Cin, s.Ho, s.Wo, s.Cout = N, H, H, ci, H, H, co
+        ws = _ws(lib.rn_wgrad_workspace_bytes(ctypes.byref(p)), cuda)
+        dw = torch.zeros((co, k, k, ci), dtype=torch.float32, device=cuda)
+        _C.check(lib.rn_conv2d_nhwc_wgrad(ctypes.byref(p), _C.ptr(dw), 0.0, _C.ptr(ws), ws.numel(), _C.current_stream()))
+        torch.cuda.synchronize()
+        got[reserved] = dw.cpu().double()
     scale = want.abs().max().item()
     for reserved in (0, 128):
         torch.testing.assert_close(got[reserved], want, rtol=1e-3, atol=1e-3 * scale)
 
 
+def test_two_engines_in_one_process_do_not_share_launch_options(cuda):
+    """the library keeps no mutable process-wide state.  Two rn_handle contexts hold different
+    rn_launch_opts; a launch is a function of its own problem descriptor only."""
+    from retinanet import _C
+    lib = _lib()
+    a = _C.Handle(lib, 0, _C.LaunchOpts(conv_tile=2, reserved_cus=8))
+    b = _C.Handle(lib, 0, _C.LaunchOpts(conv_tile=1))
+    assert a.device == b.device == 0 and a.num_cus == b.num_cus >= 64
+    oa, ob = a.launch_opts(), b.launch_opts()
+    assert (oa.conv_tile, oa.reserved_cus, ob.conv_tile, ob.reserved_cus) == (2, 8, 1, 0)
+    with pytest.raises(_C.RnetError):
+        a.set_launch_opts(_C.LaunchOpts(conv_tile=3))
+    assert a.launch_opts().conv_tile == 2           # a refused update leaves the handle as it was
+    p = _C.ConvProblem()
+    p.R = p.S = 3
+    p.stride_h = p.stride_w = p.pad_top = p.pad_left = 1
+    p.out_dtype, p.num_segments = _C.RN_DT_BF16, 1
+    sg = p.seg[0]
+    sg.N, sg.H, sg.W, sg.Cin, sg.pix_stride, sg.Ho, sg.Wo, sg.Cout = 2, 24, 24, 256, 256, 24, 24, 256
+    ids = []
+    for h in (a, b, a):
+        p.opts = h.launch_opts()
+        ids.append(lib.rn_conv_kernel_id(ctypes.byref(p)))
+    assert ids == [2, 0, 2]
+    a.close()
+    b.close()
+
+
+@pytest.mark.parametrize("build", BUILDS)
 @pytest.mark.parametrize("k,stride,cin,cout", [(3, 1, 128, 256), (1, 1, 256, 128), (3, 2, 128, 128), (1, 2, 256, 512)])
-def test_dgrad_via_forward_kernel(cuda, k, stride, cin, cout):
+def test_dgrad_via_forward_kernel(cuda, build, k, stride, cin, cout):
     """dx = conv_fwd(dy [zero-upsampled for stride 2], flipped/transposed weights)."""
     from retinanet import _C
     lib = _lib()
@@ -192,9 +226,10 @@ def test_dgrad_via_forward_kernel(cuda, k, stride, cin, cout):
     torch.testing.assert_close(dx.float().cpu(), ref, rtol=1 / 128, atol=scale / 200)
 
 
-@pytest.mark.parametrize("N,H,W,cin,cout,accumulate", [(2, 12, 12, 64, 64, False), (1, 20, 16, 128, 128, True),
-                                                      (2, 8, 10, 256, 256, False), (1, 6, 6, 32, 96, True)])
-def test_dgrad_stride2_subpixel(cuda, N, H, W, cin, cout, accumulate):
+@pytest.mark.parametrize("build,N,H,W,cin,cout,accumulate", [
+    ("bf16", 2, 12, 12, 64, 64, False), ("bf16", 1, 20, 16, 128, 128, True), ("bf16", 2, 8, 10, 256, 256, False),
+    ("bf16", 1, 6, 6, 32, 96, True), ("f16", 1, 20, 16, 128, 128, True)])
+def test_dgrad_stride2_subpixel(cuda, build, N, H, W, cin, cout, accumulate):
     """Data gradient of a 3x3 / stride 2 / pad 1 conv in its sub-pixel form (rn_dgrad_pack.pad_ == 1): one 2x2
     stride-1 conv of dy with 4*Cin phase-major channels + rn_depth_to_space2x, against autograd."""
     from retinanet import _C
@@ -265,8 +300,8 @@ def _bn_problem(cuda, segs, act, eps=1e-3, momentum=0.99, bessel=1, with_bwd=Fal
     return p, dev
 
 
-@pytest.mark.parametrize("act", ["relu", "relu6"])
-def test_bn_backward_gate_from_the_bit_mask(cuda, act):
+@pytest.mark.parametrize("build,act", [("bf16", "relu"), ("bf16", "relu6"), ("f16", "relu")])
+def test_bn_backward_gate_from_the_bit_mask(cuda, build, act):
     """rn_bn_segment.act_mask: rn_bn_apply stores the relu gate of a residual layer as one bit per element and the two
     backward passes read it instead of z — every output must be bit-identical to the z-reading kernels."""
     from retinanet import _C
@@ -306,9 +341,10 @@ def test_bn_backward_gate_from_the_bit_mask(cuda, act):
                                b[k].view(torch.int32) if b[k].dtype == torch.float32 else b[k].view(torch.int16)), k
 
 
-@pytest.mark.parametrize("act,use_res", [("relu", True), ("relu", False), (None, False), ("relu6", True),
-                                         ("swish", False)])
-def test_bn_train_forward_backward(cuda, act, use_res):
+@pytest.mark.parametrize("build,act,use_res", [
+    ("bf16", "relu", True), ("bf16", "relu", False), ("bf16", None, False), ("bf16", "relu6", True), ("bf16", "swish", False),
+    ("f16", "relu", True), ("f16", "relu", False), ("f16", "swish", False)])
+def test_bn_train_forward_backward(cuda, build, act, use_res):
     from retinanet import _C
     lib = _lib()
     g = torch.Generator().manual_seed(11)
@@ -366,8 +402,9 @@ def test_bn_train_forward_backward(cuda, act, use_res):
         torch.testing.assert_close(d["moving_var"].cpu().double(), mv, rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("k,tile", [(1, 2), (3, 2), (1, 1), (3, 1)])
-def test_bn_forward_stats_fused_into_conv_epilogue(cuda, k, tile):
+@pytest.mark.parametrize("build,k,tile", [("bf16", 1, 2), ("bf16", 3, 2), ("bf16", 1, 1), ("bf16", 3, 1),
+                                          ("f16", 1, 2), ("f16", 3, 2), ("f16", 3, 1)])
+def test_bn_forward_stats_fused_into_conv_epilogue(cuda, build, k, tile):
     """rn_conv_segment.bn_partial + rn_bn_segment.ext_chunks: the 256-row conv kernel writes the per-128-row partial
     sums, rn_bn_stats only runs the final reduction.  Must give the statistics of the unfused path on the same
     stored bf16 output (fp32 summation order differs), including pixel tails and a channel tail (Cout 320)."""
@@ -395,8 +432,8 @@ def test_bn_forward_stats_fused_into_conv_epilogue(cuda, k, tile):
         segs.append({"y": torch.zeros((N, H, W, cout)), "gamma": torch.ones((cout,)), "beta": torch.zeros((cout,)),
                      "moving_mean": torch.zeros((cout,)), "moving_var": torch.ones((cout,))})
     st = _C.current_stream()
-    lib.rn_debug_conv_tile(tile)       # 2: the 256-row kernels, 1: the 128-row kernel (one partial row per tile)
-    try:
+    pc.opts = _C.LaunchOpts(conv_tile=tile)       # 2: the 256-row kernels, 1: the 128-row kernel (one partial row per tile)
+    if True:
         rows = lib.rn_conv_tile_rows(ctypes.byref(pc))
         assert rows == (256 if tile == 2 else 128)
         if tile == 2:
@@ -418,8 +455,6 @@ def test_bn_forward_stats_fused_into_conv_epilogue(cuda, k, tile):
             _C.check(lib.rn_bn_stats(ctypes.byref(p), _C.ptr(ws), ws.numel(), st))
             torch.cuda.synchronize()
             sums[fused] = [d["sums"].cpu().double() for d in dev]
-    finally:
-        lib.rn_debug_conv_tile(0)
     for i, y in enumerate(ys):
         yd = y.float().cpu().double().reshape(-1, y.shape[-1])
         want = torch.stack([yd.sum(0), (yd * yd).sum(0)])
@@ -428,8 +463,9 @@ def test_bn_forward_stats_fused_into_conv_epilogue(cuda, k, tile):
         torch.testing.assert_close(sums[True][i], want, rtol=1e-5, atol=tol)
 
 
-@pytest.mark.parametrize("k,tile", [(1, 2), (3, 2), (1, 1), (3, 1)])
-def test_bn_backward_reduction_fused_into_the_data_gradient(cuda, k, tile):
+@pytest.mark.parametrize("build,k,tile", [("bf16", 1, 2), ("bf16", 3, 2), ("bf16", 1, 1), ("bf16", 3, 1),
+                                          ("f16", 1, 2), ("f16", 3, 2), ("f16", 3, 1)])
+def test_bn_backward_reduction_fused_into_the_data_gradient(cuda, build, k, tile):
     """rn_conv_segment.bn_bwd_y + rn_bn_segment.ext_chunks_bwd: the launch that writes dz of a BatchNorm + ReLU layer
     also writes stage 1 of that layer's backward reduction (sum g, sum g*xhat); rn_bn_bwd_reduce only runs the ordered
     final pass.  dz must be bit-identical to the plain launch, the sums must match the
@@ -463,8 +499,8 @@ def test_bn_backward_reduction_fused_into_the_data_gradient(cuda, k, tile):
                      "gamma": torch.rand((cout,), generator=g) + 0.5, "beta": torch.randn((cout,), generator=g) * 0.3,
                      "moving_mean": torch.zeros((cout,)), "moving_var": torch.ones((cout,))})
     st = _C.current_stream()
-    lib.rn_debug_conv_tile(tile)
-    try:
+    pc.opts = _C.LaunchOpts(conv_tile=tile)
+    if True:
         rows = lib.rn_conv_tile_rows(ctypes.byref(pc))
         assert rows == (256 if tile == 2 else 128)
         if tile == 2:
@@ -496,8 +532,6 @@ def test_bn_backward_reduction_fused_into_the_data_gradient(cuda, k, tile):
                               dgamma=[d["dgamma"].cpu().double() for d in dev], dbeta=[d["dbeta"].cpu().double() for d in dev],
                               dy=[d["dy"].float().cpu() for d in dev], fwd=[d["fwd"].cpu().double() for d in dev],
                               y=[d["y"].float().cpu().double() for d in dev])
-    finally:
-        lib.rn_debug_conv_tile(0)
     for i in range(len(shapes)):
         assert torch.equal(out[True]["dz"][i], out[False]["dz"][i])
         C = shapes[i][4]
@@ -514,7 +548,8 @@ def test_bn_backward_reduction_fused_into_the_data_gradient(cuda, k, tile):
         torch.testing.assert_close(out[True]["dy"][i], out[False]["dy"][i], rtol=1 / 128, atol=1e-3 * out[False]["dy"][i].abs().max().item())
 
 
-def test_pool_topdown_balance_backward(cuda):
+@pytest.mark.parametrize("build", BUILDS)
+def test_pool_topdown_balance_backward(cuda, build):
     from retinanet import _C
     lib = _lib()
     g = torch.Generator().manual_seed(21)
@@ -589,7 +624,8 @@ def test_pool_topdown_balance_backward(cuda):
         assert (err > 5e-2 * ref.abs().max().item()).float().mean().item() < 0.02, l
 
 
-def test_optimizer_step(cuda):
+@pytest.mark.parametrize("build", BUILDS)
+def test_optimizer_step(cuda, build):
     from retinanet import _C
     lib = _lib()
     g = torch.Generator().manual_seed(5)

@@ -10,7 +10,7 @@ from model_ref import RefTrainer
 pytestmark = pytest.mark.gpu
 
 
-def _setup(cuda, size, B, balanced, seed=3, depth=26, freeze=True, precision="mixed_bfloat16"):
+def _setup(cuda, size, B, balanced, seed=3, depth=26, freeze=True, precision="mixed_bfloat16", launch_opts=None):
     from retinanet.cfg import default_params
     from retinanet.dataloader import LabelEncoder
     from retinanet.model import ModelBuilder
@@ -41,7 +41,7 @@ def _setup(cuda, size, B, balanced, seed=3, depth=26, freeze=True, precision="mi
         rx = [re.compile(r"^(conv2d|batch_normalization)(_[1-7])?/")]
     if not freeze:    # the 30x configs train everything from scratch (training.freeze_variables: [])
         rx = []
-    eng = TrainEngine(model, B, frozen_regexes=rx)
+    eng = TrainEngine(model, B, frozen_regexes=rx, launch_opts=launch_opts)
     enc = LabelEncoder(p, device=cuda)
     rng = np.random.default_rng(seed)
     gts = [synth_gt(rng, int(rng.integers(2, 9)), size) for _ in range(B)]
@@ -83,11 +83,27 @@ def _gradient_rows(grad_of, ref, names):
     return rows
 
 
-@pytest.mark.parametrize("size,B,balanced,freeze,precision", [
-    (256, 4, True, True, "mixed_bfloat16"), (256, 3, False, True, "mixed_bfloat16"), (256, 2, True, False, "mixed_bfloat16"),
-    (256, 4, True, True, "mixed_float16"),      # the half build (librnet_hip_f16.so) against the restatement rounding to half
+def _kernel_ids(eng):
+    import ctypes
+    from retinanet import _C
+    return {name: eng.lib.rn_conv_kernel_id(ctypes.byref(p)) for name, p in eng.conv_launches}
+
+
+# the whole-network wiring check runs on both kernel families: "auto" = what the dispatcher picks at these small
+# sizes (the 128-row kernels), "persistent" = every eligible layer forced onto the 256-wide persistent kernels
+# (conv_big / conv_halo for forward and data gradients with their fused BatchNorm statistics, the 256-wide weight-gradient
+# kernels) — the kernels the full-size training bench runs on.  Per-engine rn_launch_opts, not process state.
+_PERSISTENT = dict(conv_tile=2, wgrad_kernel=2)
+
+
+@pytest.mark.parametrize("size,B,balanced,freeze,precision,kernels", [
+    (256, 4, True, True, "mixed_bfloat16", "auto"), (256, 3, False, True, "mixed_bfloat16", "auto"),
+    (256, 2, True, False, "mixed_bfloat16", "auto"),
+    (256, 4, True, True, "mixed_float16", "auto"),      # the half build (librnet_hip_f16.so) against the restatement rounding to half
+    (256, 4, True, True, "mixed_bfloat16", "persistent"),
+    (256, 4, True, True, "mixed_float16", "persistent"),
 ])
-def test_backward_wiring_dense_upstream(cuda, size, B, balanced, freeze, precision):
+def test_backward_wiring_dense_upstream(cuda, size, B, balanced, freeze, precision, kernels):
     """Whole-network backward (heads -> BalanceFeatures -> FPN -> ResNet) for a dense random upstream gradient on the
     predictions, against autograd through the bf16-emulating CPU restatement in float64.
 
@@ -95,10 +111,18 @@ def test_backward_wiring_dense_upstream(cuda, size, B, balanced, freeze, precisi
     rounding points, only the fp summation differs) lands as far from its float64 evaluation as any correct
     implementation can be expected to — a randomly initialised net with training-mode BatchNorm amplifies every
     flipped bf16 rounding (tools/oracle_noise_floor.py: ResNet-26 256^2, forward 3.3 %, gradient cosine median 0.971,
-    minimum 0.940; the HIP path measures 3.1 %, 0.971, 0.936).  The HIP path must sit at that floor: forward error
-    <= 1.3 x the floor, every tensor's gradient cosine within 0.06 of its floor value, the median within 0.015."""
-    p, model, eng, targets, images = _setup(cuda, size, B, balanced, freeze=freeze, precision=precision)
+    minimum 0.940; the HIP path measures 3.1 %, 0.971, 0.936 — on the 128-row and on the 256-row kernels alike: every
+    kernel rounds to bf16 at the same points, include/rnet_hip.h rn_conv_segment).  The HIP path must sit at that
+    floor: forward error <= 1.3 x the floor, every tensor's gradient cosine within 0.06 of its floor value, the median
+    within 0.015."""
+    p, model, eng, targets, images = _setup(cuda, size, B, balanced, freeze=freeze, precision=precision,
+                                            launch_opts=_PERSISTENT if kernels == "persistent" else None)
     assert eng.f16 == (precision == "mixed_float16")
+    ids = _kernel_ids(eng)
+    if kernels == "persistent":
+        assert ids["fwd:tower0"] == 2 and ids["dgrad:tower3"] == 2 and any(v == 1 for v in ids.values()), ids
+    else:
+        assert ids["fwd:tower0"] == 0, ids
     ref = RefTrainer(p, model.variables, frozen_names=eng.frozen, emulate_bf16=True)
     ref32 = RefTrainer(p, model.variables, frozen_names=eng.frozen, emulate_bf16=True, dtype=torch.float32)
     if not freeze:
@@ -126,31 +150,6 @@ def test_backward_wiring_dense_upstream(cuda, size, B, balanced, freeze, precisi
     # the layers next to the loss see almost no accumulated rounding noise
     assert rows["class-head/class-head-prediction-conv2d/kernel"][0] > 0.995
     assert rows["box-head/box-head-prediction-conv2d/kernel"][0] > 0.995
-
-
-def test_backward_wiring_through_the_persistent_kernels(cuda):
-    """The same whole-network backward with every eligible layer forced onto the 256-wide persistent kernels
-    (conv_big / conv_halo for forward and data gradients, their fused BatchNorm statistics, wgrad_big for the
-    weight gradients) — the kernels the full-size training bench runs on, which the dispatcher would not pick at
-    test sizes."""
-    from retinanet import _C
-    lib = _C.lib()
-    lib.rn_debug_conv_tile(2)
-    lib.rn_debug_wgrad_big_min_pixels(1)
-    try:
-        # same bounds as the 128-row kernels (the restatement's own noise floor): every kernel rounds to bf16 at the
-        # same points (include/rnet_hip.h, rn_conv_segment) — measured forward relative error 0.031 on both,
-        # gradient cosine median 0.971 on both
-        test_backward_wiring_dense_upstream(cuda, 256, 4, True, True)
-    finally:
-        lib.rn_debug_conv_tile(0)
-        lib.rn_debug_wgrad_big_min_pixels(16384)
-
-
-def _kernel_ids(eng):
-    import ctypes
-    from retinanet import _C
-    return {name: _C.lib().rn_conv_kernel_id(ctypes.byref(p)) for name, p in eng.conv_launches}
 
 
 @pytest.mark.parametrize("size,B", [(640, 8), (1024, 4)], ids=["config2-resnet50-640-b8", "config3-resnet50-1024-b4"])

@@ -149,9 +149,10 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
     """sizeof / offsetof of every struct the binding mirrors, taken from the C compiler's view of include/rnet_hip.h"""
     from retinanet import _C
     structs = {"rn_conv_segment": (_C.ConvSegment, ["x", "bias", "w_terms", "Cout", "bn_partial"]),
-               "rn_conv_problem": (_C.ConvProblem, ["seg", "num_segments", "out_dtype"]),
+               "rn_launch_opts": (_C.LaunchOpts, ["conv_tile", "reserved_cus", "wgrad_kernel", "ablate"]),
+               "rn_conv_problem": (_C.ConvProblem, ["seg", "num_segments", "out_dtype", "opts"]),
                "rn_wgrad_segment": (_C.WgradSegment, ["dy_pix_stride", "x_pix_stride"]),
-               "rn_wgrad_problem": (_C.WgradProblem, ["seg"]),
+               "rn_wgrad_problem": (_C.WgradProblem, ["seg", "opts"]),
                "rn_dw_segment": (_C.DwSegment, ["residual", "Wo"]),
                "rn_dw_problem": (_C.DwProblem, ["seg"]),
                "rn_bn_segment": (_C.BnSegment, ["sample_scale", "ext_chunks", "P"]),

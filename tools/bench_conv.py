@@ -58,19 +58,13 @@ def main():
     ap.add_argument("--tile", type=int, default=0, help="1 = force 128-row kernel, 2 = force the 256x256 kernel")
     a = ap.parse_args()
     lib = _C.lib()
-    if a.ablate:
-        lib.rn_debug_conv_ablate(a.ablate)
-        lib.rn_debug_conv_big_ablate(a.ablate)
-    if a.tile:
-        lib.rn_debug_conv_tile(a.tile)
-    if a.no_halo:
-        lib.rn_debug_conv_halo(0)
-    if a.halo_grid:
-        lib.rn_debug_conv_halo_grid(a.halo_grid)
+    opts = _C.LaunchOpts(ablate=a.ablate or 0, conv_tile=a.tile or 0, conv_no_halo=1 if a.no_halo else 0,
+                         max_workgroups=a.halo_grid or 0)   # rn_launch_opts of every launch below
     dev = torch.device("cuda:0")
     for name in a.preset.split(","):
         segs, k, stride, f32, use_res = PRESETS[name]
         p = _C.ConvProblem()
+        p.opts = opts
         p.R = p.S = k
         p.stride_h = p.stride_w = stride
         p.pad_top = p.pad_left = (k - 1) // 2

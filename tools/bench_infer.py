@@ -12,15 +12,13 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--big-min-tiles", type=int, default=0, help="override the 256-row kernels' minimum tile count")
     a = ap.parse_args()
-    if a.big_min_tiles:
-        from retinanet import _C
-        _C.lib().rn_debug_conv_big_min_tiles(a.big_min_tiles)
     from retinanet.cfg import default_params
     from retinanet.model import ModelBuilder
     dev = torch.device("cuda:0")
     p = default_params(input_size=a.size, inference_batch=a.batch)
     b = ModelBuilder(p, "val", device=dev, seed=1337)
     model = b()
+    model.launch_opts = dict(conv_big_min_tiles=a.big_min_tiles or 0)
     x = torch.randn((a.batch, a.size, a.size, 3), device=dev)
     preds = model(x)
     std = torch.cat([preds["class-predictions"][l].reshape(-1) for l in "34567"]).std().item()

@@ -36,19 +36,12 @@ def main():
     from retinanet.model import ModelBuilder
     from retinanet.model.train_engine import TrainEngine
     dev = torch.device("cuda:0")
-    if a.big_min_tiles:
-        from retinanet import _C
-        _C.lib().rn_debug_conv_big_min_tiles(a.big_min_tiles)
-    if a.wgrad_big_blocks:
-        from retinanet import _C
-        _C.lib().rn_debug_wgrad_big_target_blocks(a.wgrad_big_blocks)
-    if a.wgrad_blocks:
-        from retinanet import _C
-        _C.lib().rn_debug_wgrad_target_blocks(a.wgrad_blocks)
+    opts = dict(conv_big_min_tiles=a.big_min_tiles or 0, wgrad_target_blocks=(a.wgrad_big_blocks or a.wgrad_blocks or 0))
     p = default_params(input_size=a.size)
     b = ModelBuilder(p, "train", device=dev)
     model = b()
-    eng = TrainEngine(model, a.batch, frozen_regexes=[b.FREEZE_VARS_REGEX[n] for n in p.training.freeze_variables])
+    eng = TrainEngine(model, a.batch, frozen_regexes=[b.FREEZE_VARS_REGEX[n] for n in p.training.freeze_variables],
+                      launch_opts=opts)
     enc = LabelEncoder(p, device=dev)
     gb, gc, cnt = [t.to(dev) for t in synth_targets(enc, a.batch, a.size, 1337)]
     images = torch.randn((a.batch, a.size, a.size, 3), device=dev)

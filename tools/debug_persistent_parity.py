@@ -15,11 +15,10 @@ lib = _C.lib()
 
 
 def run(tag, conv_tile, wg_big, halo=1, fuse="1"):
-    lib.rn_debug_conv_tile(conv_tile)
-    lib.rn_debug_wgrad_big_min_pixels(1 if wg_big else 16384)
-    lib.rn_debug_conv_halo(halo)
     os.environ["RNET_FUSE_BN_STATS"] = fuse
-    p, model, eng, targets, images = T._setup(cuda, 256, 4, True, freeze=True)
+    p, model, eng, targets, images = T._setup(cuda, 256, 4, True, freeze=True,
+                                              launch_opts=dict(conv_tile=conv_tile, wgrad_kernel=2 if wg_big else 0,
+                                                               conv_no_halo=0 if halo else 1))
     ref = RefTrainer(p, model.variables, frozen_names=eng.frozen, emulate_bf16=True)
     preds = eng.forward(images.to(cuda))
     g = torch.Generator().manual_seed(99)

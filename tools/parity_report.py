@@ -18,9 +18,9 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 def run(tag, tile, randomize=True):
     from retinanet.cfg import default_params
     from retinanet.model import ModelBuilder
-    lib.rn_debug_conv_tile(tile)
     p = default_params(input_size=size, balanced=True)
     model = ModelBuilder(p, "val", device=cuda)()
+    model.launch_opts = dict(conv_tile=tile)   # rn_launch_opts of this model's engines
     if randomize:
         T._randomize(model, 1)
     images = torch.randn((B, size, size, 3), generator=torch.Generator().manual_seed(1337))
@@ -40,7 +40,6 @@ def run(tag, tile, randomize=True):
     for name, pr in eng.conv_problems.items():
         kids[lib.rn_conv_kernel_id(ctypes.byref(pr))] = kids.get(lib.rn_conv_kernel_id(ctypes.byref(pr)), 0) + 1
     print(f"{tag:40s} size {size} B {B}: max err / range {worst_max:.5f}  mean err / range {worst_mean:.6f}  launches by kernel id {kids}")
-    lib.rn_debug_conv_tile(0)
 
 
 run("dispatcher's choice, random BN", 0)

@@ -54,14 +54,12 @@ def main():
     from retinanet.model.train_engine import TrainEngine
     from retinanet.optimizers import build_optimizer
     dev = torch.device("cuda:0")
-    if a.wgrad_big_blocks:
-        from retinanet import _C
-        _C.lib().rn_debug_wgrad_big_target_blocks(a.wgrad_big_blocks)
     p = default_params(input_size=a.size)
     b = ModelBuilder(p, "train", device=dev)
     model = b()
     model.optimizer = build_optimizer(p.training.optimizer, p.training.train_steps, p.floatx.precision)
-    eng = TrainEngine(model, a.batch, frozen_regexes=[b.FREEZE_VARS_REGEX[n] for n in p.training.freeze_variables])
+    eng = TrainEngine(model, a.batch, frozen_regexes=[b.FREEZE_VARS_REGEX[n] for n in p.training.freeze_variables],
+                      launch_opts=dict(wgrad_target_blocks=a.wgrad_big_blocks or 0))
     enc = LabelEncoder(p, device=dev)
     gb, gc, cnt = [t.to(dev) for t in synth_targets(enc, a.batch, a.size, 1337)]
     targets = enc.encode_batch(gb, gc, cnt)
