@@ -142,16 +142,17 @@ def run_train(args, dev, rank, world):
     torch.cuda.synchronize()
     # HIP events bracket the conv launches of every 5th timed step (and the last one): two event records
     # per launch on ~90 launches cost ~1.5 ms, which would otherwise inflate every timed step
-    prof, hbm = [], []
+    prof, hbm, wprof = [], [], []
     sampled = 0
     t0 = time.perf_counter()
     for i in range(args.steps):
         sample = (i % 5 == 4) or i == args.steps - 1
         eng.conv_profile = prof if sample else None
         eng.hbm_profile = hbm if sample else None
+        eng.wgrad_profile = wprof if sample else None
         sampled += int(sample)
         out = step()
-    eng.conv_profile = eng.hbm_profile = None
+    eng.conv_profile = eng.hbm_profile = eng.wgrad_profile = None
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -194,15 +195,42 @@ def run_train(args, dev, rank, world):
     # The timed steps run the weight-gradient launches on a second stream (TrainEngine.backward), so the dgrad
     # launches of the dominant kernel share the chip with wgrad kernels and their event-bracketed durations above
     # include that sharing.  One more, untimed, step with the one-stream backward gives the kernel's own duration.
+    def wgrad_entry(events, steps_):
+        """weight-gradient launches (rn_conv2d_nhwc_wgrad = partial-tile kernel + ordered split-K reduction): algorithmic
+        FLOPs = 2 * pixels * k*k * Cin * Cout of the layer / HIP-event time on the launch stream, per kernel family"""
+        by = {}
+        for e0, e1, fl, name in events:
+            acc = by.setdefault(name, [0.0, 0, 0])
+            acc[0] += e0.elapsed_time(e1); acc[1] += fl; acc[2] += 1
+        tot_ms, tot_fl = sum(v[0] for v in by.values()), sum(v[1] for v in by.values())
+        if not tot_ms:
+            return None
+        return {"bound": "mfma", "achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2), "peak": PEAK_BF16_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                "ms_per_step": round(tot_ms / max(steps_, 1), 3),
+                "launches_per_step": sum(v[2] for v in by.values()) // max(steps_, 1),
+                "algorithmic_gflop_per_step": round(tot_fl / max(steps_, 1) / 1e9, 1),
+                "kernels": {k: {"ms_per_step": round(v[0] / max(steps_, 1), 3), "launches_per_step": v[2] // max(steps_, 1),
+                                "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1) if v[0] else 0.0,
+                                "frac": round(v[1] / (v[0] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if v[0] else 0.0}
+                            for k, v in sorted(by.items())}}
+    wgrad_roof = wgrad_entry(wprof, sampled)
+    if wgrad_roof:
+        wgrad_roof["concurrency"] = ("second stream: these launches run beside the data-gradient chain of the main stream "
+                                     "in the timed steps" if getattr(eng, "side_stream_on", False) else "one stream")
     exclusive = None
     if getattr(eng, "side_stream_on", False) and dom_name in by_kernel and not args.no_exclusive:
         eng.side_stream_on = False
-        prof1 = []
-        eng.conv_profile = prof1
+        prof1, wprof1 = [], []
+        eng.conv_profile, eng.wgrad_profile = prof1, wprof1
         step()
-        eng.conv_profile = None
+        eng.conv_profile = eng.wgrad_profile = None
         torch.cuda.synchronize()
         eng.side_stream_on = True
+        w1 = wgrad_entry(wprof1, 1)
+        if wgrad_roof and w1:
+            wgrad_roof["exclusive"] = {k: w1[k] for k in ("achieved", "frac", "ms_per_step", "kernels")}
+            wgrad_roof["exclusive"]["how"] = "the same launches in one extra untimed one-stream step (chip to themselves)"
         ms1, fl1, _, n1 = per_kernel(prof1).get(dom_name, [0.0, 0, 0, 0])
         excl_symbols = {k: {"launches": v[3], "avg_launch_us": round(v[0] * 1e3 / max(v[3], 1), 2)}
                         for k, v in per_kernel(prof1, key=lambda v: v).items() if family(k) == dom_name}
@@ -230,11 +258,43 @@ def run_train(args, dev, rank, world):
                         "concurrency": ("dgrad launches overlap wgrad launches of a second stream in the timed steps"
                                         if getattr(eng, "side_stream_on", False) else "one stream"),
                         "exclusive": exclusive,
+                        "wgrad": wgrad_roof,
                         "hbm_kernels": {"bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s", "kernels": hbm_kernels},
                         "other_conv_kernels": {k: {"ms_per_step": round(v[0] / max(sampled, 1), 3),
                                                    "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1) if v[0] else 0.0}
                                                for k, v in by_kernel.items() if k != dom_name}}}
     return res, params, model, eng
+
+
+def mfma_sustained(dev):
+    """What the matrix pipe of THIS part sustains, measured live (csrc/rn_probe.hip: nothing but v_mfma_f32_32x32x16_bf16,
+    2 waves per SIMD, no memory traffic): on random operands and on zeros, with the core clock workgroup 0 saw
+    (shader-clock ticks / 100 MHz wall-clock ticks).  The chip clocks to its power budget, so the nominal 2.5 PFLOP/s
+    (2.4 GHz) is not reachable on real data; `frac_of_sustained` prices a kernel against the random-operand figure."""
+    from retinanet import _C
+    lib = _C.lib()
+    iters = 4096
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    out = torch.empty((4 * cus * 512,), dtype=torch.float32, device=dev)
+    clocks = torch.zeros((4,), dtype=torch.int64, device=dev)
+    res = {}
+    for name, table in (("random", torch.rand((1024,), generator=torch.Generator().manual_seed(7)).sub_(0.5).to(dev)),
+                        ("zeros", torch.zeros((1024,), device=dev))):
+        best, ghz = 0.0, 0.0
+        for rep_ in range(4):    # the first launch warms up; the clock settles within a launch
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _C.check(lib.rn_probe_mfma(_C.ptr(table), _C.ptr(out), iters, _C.ptr(clocks), _C.current_stream()), "rn_probe_mfma")
+            e1.record()
+            torch.cuda.synchronize()
+            tf = lib.rn_probe_mfma_flops(iters) / (e0.elapsed_time(e1) * 1e-3) / 1e12
+            c = clocks.tolist()
+            if rep_ and tf > best:
+                best, ghz = tf, (c[1] - c[0]) / max(c[3] - c[2], 1) * 0.1      # ticks per 10 ns -> GHz
+        res[name] = {"tflops": round(best, 1), "core_clock_ghz": round(ghz, 3)}
+    res["how"] = ("rn_probe_mfma: 16 x v_mfma_f32_32x32x16_bf16 per wave and iteration, 8 waves per workgroup, no memory "
+                  "traffic; best of 3 launches; core clock = s_memtime ticks / wall_clock64 (100 MHz) ticks of workgroup 0")
+    return res
 
 
 def run_infer(args, dev, rank):
@@ -396,6 +456,7 @@ def main():
                     help="skip the one extra one-stream step behind `roofline.exclusive` (profile runs: the kernel "
                          "trace then holds warm-up + timed steps only, like the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-probe", action="store_true", help="skip the MFMA-only probe behind roofline.sustained")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -435,6 +496,19 @@ def main():
                    "final_loss": round(train["loss"], 4), "gradient_norm": round(train["grad_norm"], 4)},
         "roofline": train["roofline"],
     }
+    if rank == 0 and not args.no_probe:
+        try:
+            sus = mfma_sustained(dev)
+            rl = line["roofline"]
+            rl["sustained"] = sus
+            if sus["random"]["tflops"] > 0:
+                rl["frac_of_sustained"] = round(rl["achieved"] / sus["random"]["tflops"], 4)
+                if rl.get("exclusive"):
+                    rl["exclusive"]["frac_of_sustained"] = round(rl["exclusive"]["achieved"] / sus["random"]["tflops"], 4)
+                if rl.get("wgrad"):
+                    rl["wgrad"]["frac_of_sustained"] = round(rl["wgrad"]["achieved"] / sus["random"]["tflops"], 4)
+        except Exception as e:   # noqa: BLE001 — a probe failure must not lose the bench line
+            line["roofline"]["sustained"] = {"error": str(e)}
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:

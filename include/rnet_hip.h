@@ -331,6 +331,9 @@ typedef struct {
 } rn_wgrad_problem;
 
 size_t rn_wgrad_workspace_bytes(const rn_wgrad_problem* problem /* host */);
+/* Which kernel rn_conv2d_nhwc_wgrad runs for `problem`: 0 = wgrad_kernel (128 x 128 per-tap tiles, K step 64 pixels),
+ * 1 = wgrad_big_kernel (256 x 256 per-tap tiles, ping-pong); -1 on a malformed problem.  Bench bookkeeping only. */
+int rn_wgrad_kernel_id(const rn_wgrad_problem* problem /* host */);
 int rn_conv2d_nhwc_wgrad(const rn_wgrad_problem* problem /* host */, float* dw, float beta, void* workspace,
                          size_t workspace_bytes, void* stream);
 
@@ -509,6 +512,17 @@ int rn_comm_init(const void* unique_id /* host */, int rank, int world, void** c
 int rn_comm_destroy(void* comm);
 int rn_allreduce_bucket(void* comm, void* ptr /* device */, int64_t count, int dtype, void* stream);
 int rn_allreduce_small(void* comm, float* ptr /* device */, int count, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Measurement infrastructure for SURVEY 8(d) (bench.py's roofline): the matrix-pipe rate this part SUSTAINS.
+ * rn_probe_mfma runs only v_mfma_f32_32x32x16 (8 waves per workgroup = 2 per SIMD, one resident workgroup per CU, 4 x CUs
+ * workgroups, `iters` x 16 MFMAs per wave; no memory traffic) on operands converted from `table` (device f32[1024]: random
+ * values or zeros — the chip clocks to its power budget, so the rate depends on the data).  out: device f32[4*CUs*512]
+ * (keeps the work live).  clocks: device u64[4] = shader clock (s_memtime) at the first / last instruction of workgroup 0,
+ * 100 MHz wall clock at the same points: (c1 - c0) / ((w1 - w0) / 100) = core clock in MHz.  rn_probe_mfma_flops(iters) =
+ * FLOPs of one launch on the current device. */
+long long rn_probe_mfma_flops(int iters);
+int rn_probe_mfma(const float* table, float* out, int iters, unsigned long long* clocks, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * K6  tf.keras.layers.MaxPool2D  (resnet.py:304-307 3x3 s2 SAME; fpn_base.py:25-26,68 2x2 s2)

@@ -320,6 +320,14 @@ static int wgrad_plan(const rn_wgrad_problem* p, WgArgs& a) {
   return 0;
 }
 
+/* which kernel rn_conv2d_nhwc_wgrad runs for `problem`: 0 = wgrad_kernel (128 x 128 per-tap tiles), 1 = wgrad_big_kernel
+ * (256 x 256 per-tap tiles); -1 on a malformed problem.  Profiling / bench bookkeeping only. */
+extern "C" int rn_wgrad_kernel_id(const rn_wgrad_problem* p) {
+  WgArgs a;
+  if (wgrad_plan(p, a)) return -1;
+  return a.pad_;
+}
+
 extern "C" size_t rn_wgrad_workspace_bytes(const rn_wgrad_problem* p) {
   WgArgs a;
   if (wgrad_plan(p, a)) return 0;

@@ -173,6 +173,7 @@ _SIGNATURES = {
     "rn_pack_stem_weight_rs": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rn_pack_image_nhwc4": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rn_wgrad_workspace_bytes": (c_size_t, [POINTER(WgradProblem)]),
+    "rn_wgrad_kernel_id": (c_int, [POINTER(WgradProblem)]),
     "rn_conv2d_nhwc_wgrad": (c_int, [POINTER(WgradProblem), c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
     "rn_pack_conv_weight_dgrad": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rn_pack_conv_weight_dgrad_batch": (c_int, [POINTER(DgradPack), c_int, c_void_p]),
@@ -230,6 +231,8 @@ _SIGNATURES = {
     "rn_comm_destroy": (c_int, [c_void_p]),
     "rn_allreduce_bucket": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "rn_allreduce_small": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    "rn_probe_mfma_flops": (c_longlong, [c_int]),
+    "rn_probe_mfma": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "rn_jpeg_info": (c_int, [c_void_p, c_size_t, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)]),
     "rn_jpeg_decode": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t]),
     "rn_jpeg_idct_islow": (c_int, [c_void_p, c_void_p]),

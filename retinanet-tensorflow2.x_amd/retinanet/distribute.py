@@ -45,6 +45,21 @@ class Strategy:
         if self.world > 1:
             dist.barrier(group=self.group)
 
+    def any_true(self, flag):
+        """collective OR of a per-rank condition (loop control that every rank must leave together)"""
+        if self.world == 1:
+            return bool(flag)
+        t = torch.tensor([1.0 if flag else 0.0], device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return bool(t.item() > 0)
+
+    def broadcast_object(self, obj, src=0):
+        if self.world == 1:
+            return obj
+        box = [obj]
+        dist.broadcast_object_list(box, src=src, group=self.group)
+        return box[0]
+
 
 def get_strategy(params):
     """params = config `training.strategy` ({'type': 'gpu'|'cpu'|'multi_gpu'|'tpu', 'name': ...})."""

@@ -182,7 +182,9 @@ class Executor:
         if "global_clipnorm" in opt_cfg or "clipnorm" in opt_cfg:
             self._clip_gradients = True
             logging.warning("Training with `clip_gradients=True`")
-        if self.optimizer.clipnorm is None:     # executor.py:432-434 reads optimizer.clipnorm unconditionally
+        if "train" in self.run_mode and self.optimizer.clipnorm is None:
+            # executor.py:432-434 reads optimizer.clipnorm unconditionally — in the train step only: val /
+            # continuous_eval / export never clip a gradient
             raise AssertionError("`training.optimizer.clipnorm` is required: gradients are always clipped")
         if self.params.fine_tuning.fine_tune:
             logging.info("Loading pretrained weights for fine-tuning from %s",
@@ -205,6 +207,9 @@ class Executor:
                                  f"{self.num_replicas} replicas")
             self._engine = self._model.train_engine(per_replica, process_group=getattr(self.distribute_strategy, "group", None),
                                                     world_size=self.num_replicas)
+            if self.num_replicas > 1:     # SyncBN / normaliser messages through rn_comm when it validates on every rank
+                from retinanet import comm
+                comm.maybe_enable_native(self._engine)
 
     def _maybe_freeze_layers(self):
         patterns = self.params.training.freeze_variables
@@ -331,7 +336,28 @@ class Executor:
         detections = self._eval_model(data["image"].to(self._model.device), training=False)
         return {"image_id": data["image_id"], "detections": detections, "resize_scale": data["resize_scale"]}
 
-    def distributed_eval_step(self, data):
+    def _pad_eval_batch(self, data, per_replica):
+        """One process per GPU reads its own shard of the validation files, so the ranks' LAST batches differ: a rank
+        may hold a short batch, or none while another still has records.  Every rank therefore always contributes a
+        batch of the fixed per-replica size to the gather — missing rows are zero images — plus a 0/1 validity row
+        mask; the gathered rows are filtered by it.  (The reference never meets this: one process feeds all replicas
+        from an unsharded validation set, executor.py:455-552.)"""
+        H, W = int(self.params.input.input_shape[0]), int(self.params.input.input_shape[1])
+        n = 0 if data is None else int(torch.as_tensor(data["image"]).shape[0])
+        if n > per_replica:
+            raise ValueError(f"validation batch of {n} images on a replica whose share is {per_replica}")
+        image = torch.zeros((per_replica, H, W, 3), dtype=torch.float32)
+        image_id = torch.full((per_replica,), -1, dtype=torch.int64)
+        scale = torch.ones((per_replica, 2), dtype=torch.float32)
+        if n:
+            image[:n] = torch.as_tensor(data["image"]).to(torch.float32).cpu()
+            image_id[:n] = torch.as_tensor(data["image_id"]).to(torch.int64).reshape(-1).cpu()
+            scale[:n] = torch.as_tensor(data["resize_scale"]).to(torch.float32).reshape(n, 2).cpu()
+        mask = torch.zeros((per_replica,), dtype=torch.int32)
+        mask[:n] = 1
+        return {"image": image, "image_id": image_id, "resize_scale": scale}, mask
+
+    def distributed_eval_step(self, data, row_mask=None):
         res = self._eval_step(data)
         st = self.distribute_strategy
         if self.num_replicas > 1:       # strategy.gather(axis=0) over the replicas (executor.py:397-398)
@@ -339,7 +365,32 @@ class Executor:
             res = {"image_id": st.gather(torch.as_tensor(res["image_id"]).to(dev)).cpu(),
                    "detections": {k: st.gather(v) for k, v in res["detections"].items()},
                    "resize_scale": st.gather(torch.as_tensor(res["resize_scale"]).to(dev)).cpu()}
+            if row_mask is not None:    # drop the padding rows of short / exhausted shards
+                keep = st.gather(row_mask.to(dev)).bool()
+                res = {"image_id": res["image_id"][keep.cpu()],
+                       "detections": {k: v[keep] for k, v in res["detections"].items()},
+                       "resize_scale": res["resize_scale"][keep.cpu()]}
         return res
+
+    def _gathered_eval_results(self, total_steps):
+        """Yields the (gathered) results of one evaluation step after the other, at most `total_steps` of them.
+        Multi-replica loop control is collective: the ranks agree each round whether ANY of them still holds records, so
+        a rank whose shard is exhausted keeps taking part in the gathers (with an all-padding batch) instead of leaving
+        the others blocked in all_gather; `total_steps` comes from the config and is the same on every rank."""
+        multi = self.num_replicas > 1
+        per_replica = max(self.batch_size["val"] // self.num_replicas, 1)
+        iterator, steps = iter(self._val_dataset()), 0
+        while steps < total_steps:
+            data = next(iterator, None)
+            row_mask = None
+            if multi:
+                if not self.distribute_strategy.any_true(data is not None):
+                    break
+                data, row_mask = self._pad_eval_batch(data, per_replica)
+            elif data is None:
+                break
+            steps += 1
+            yield self.distributed_eval_step(data, row_mask)
 
     def _train_step(self, data):
         images, targets = data
@@ -389,18 +440,21 @@ class Executor:
                                   remap_class_ids=self.params.training.remap_class_ids)
         logging.info("Evaluating at step %d for %d steps", current_step, total_steps)
         meter = AverageMeter("eval_steps_per_second")
-        for i, data in enumerate(self._val_dataset()):
+        multi = self.num_replicas > 1
+        for i, results in enumerate(self._gathered_eval_results(total_steps)):
             start = time()
-            results = self.distributed_eval_step(data)
-            evaluator.accumulate_results(results)
+            if len(results["image_id"]):
+                evaluator.accumulate_results(results)
             execution_time = max(np.round(time() - start, 2), 1e-2)
             meter.accumulate(1 / execution_time)
             sps = meter.averaged_value
             logging.info("[global_step %d/%d][eval_step %d/%d] [ETA: %s] [%.2f imgs/s]", current_step, self.train_steps,
                          i + 1, total_steps, format_eta((total_steps - (i + 1)) / sps), sps * self.batch_size["val"])
-            if (i + 1) == total_steps:
-                break
-        scores = evaluator.evaluate()
+        # every rank holds the same gathered detections; the chief alone writes the prediction file and runs COCOeval
+        # (all ranks opening `<name>.json` with 'w' and reading it back is a truncate / read race), then shares the scores
+        scores = evaluator.evaluate() if self._is_chief else None
+        if multi:
+            scores = self.distribute_strategy.broadcast_object(scores, src=0)
         if "eval" in self._summary_writers:
             self._summary_writers["eval"].scalars(current_step, {k: scores[k] for k in (
                 "AP-IoU=0.50:0.95", "AP-IoU=0.50", "AP-IoU=0.75", "AR-(all)-IoU=0.50:0.95", "AR-(L)-IoU=0.50:0.95")})
@@ -474,7 +528,10 @@ class Executor:
     def train(self):
         done = self._run_training_loop()
         while not done and self._current_trial < self._max_trials:
+            self.distribute_strategy.barrier()     # the chief's last _save is complete before anyone looks
             latest = tf_checkpoint.latest_checkpoint(self.model_dir)
+            if self.num_replicas > 1:               # one answer for every rank
+                latest = self.distribute_strategy.broadcast_object(latest, src=0)
             if latest is not None:
                 at = int(latest.split("_")[-1])
                 resume_at = self.save_every * ((at // self.save_every) - 1)

@@ -95,8 +95,10 @@ class TrainEngine:
         self._algo = {}           # id(rn_conv_problem) -> (algorithmic FLOPs, algorithmic bytes) where the launch executes more
         self.hbm_profile = None   # bench.py: list that collects (event0, event1, kernel name, algorithmic bytes)
         self.conv_launches = []   # (name, rn_conv_problem) of every implicit-GEMM launch: lib.rn_conv_kernel_id(byref(p))
+        self.wgrad_launches = []  # (name, rn_wgrad_problem) of every weight-gradient launch
         self.step_count = 0
         self.conv_profile = None
+        self.wgrad_profile = None   # bench.py: list that collects (event0, event1, algorithmic FLOPs, kernel) per wgrad launch
         self.fuse_bn_stats = os.environ.get("RNET_FUSE_BN_STATS", "1") != "0"   # conv epilogue writes BN partial sums
         # data-gradient epilogue writes stage 1 of the BatchNorm backward reduction of the layer it produces dz for
         self.fuse_bn_bwd = os.environ.get("RNET_FUSE_BN_BWD", "1") != "0"
@@ -372,8 +374,11 @@ class TrainEngine:
         with torch.cuda.device(self.dev):
             self.store_to_model(use_ema=False)
             torch.cuda.synchronize()
-        self.model.save_weights(prefix, slots=self.optimizer_slots(),
-                                extra={"SGD/iter": np.asarray(self.step_count, dtype=np.int64)})
+        extra = {"SGD/iter": np.asarray(self.step_count, dtype=np.int64)}
+        if self.loss_scale:   # Keras' LossScaleOptimizer checkpoints its dynamic state the same way
+            extra["loss_scale/current_loss_scale"] = np.asarray(self.loss_scale["scale"], dtype=np.float32)
+            extra["loss_scale/good_steps"] = np.asarray(self.loss_scale["good"], dtype=np.int64)
+        self.model.save_weights(prefix, slots=self.optimizer_slots(), extra=extra)
 
     def restore_checkpoint(self, prefix):
         """executor.py:221-244: load the latest weights and continue from their step."""
@@ -389,6 +394,12 @@ class TrainEngine:
             self.step_count = int(it) if it is not None else 0
             if self.model.optimizer is not None:
                 self.model.optimizer.iterations = self.step_count
+            ls = self.model.loaded_extras.get("loss_scale/current_loss_scale")
+            opt = self.model.optimizer
+            if ls is not None and opt is not None and opt.dynamic_loss_scale:   # a resumed mixed_float16 run keeps its scale
+                good = self.model.loaded_extras.get("loss_scale/good_steps")
+                self.loss_scale = dict(scale=float(ls), good=int(good) if good is not None else 0,
+                                       growth_steps=int(opt.loss_scale_growth_steps), skipped=False)
 
     def store_to_model(self, use_ema=False):
         """flat arenas -> model.variables (executor.assign_moving_averaged_weights when use_ema)."""
@@ -1099,10 +1110,26 @@ class TrainEngine:
                              device=self.dev)
             dw = self._pview(c.get("kvar", cname + "/kernel"), self.G)
             self._keep += [p, ws]
+            self.wgrad_launches.append(("wgrad:" + cname, p))
             a = (ctypes.byref(p), dw.data_ptr(), 0.0, ws.data_ptr(), ws.numel())
-            self.bwd_steps.append(self._side(lambda st, a=a: _C.check(lib.rn_conv2d_nhwc_wgrad(*a, st),
-                                                                     "rn_conv2d_nhwc_wgrad"),
-                                             writes=[c.get("kvar", cname + "/kernel")]))
+            # algorithmic FLOPs of the layer's weight gradient: 2 * pixels * k*k * Cin * Cout over the segments
+            flw = sum(2 * B * p.seg[i].Ho * p.seg[i].Wo * c["k"] * c["k"] * c["cin"] * c["cout"] for i in range(len(cops)))
+            wname = ("wgrad_kernel (128x128 per-tap tiles)", "wgrad_big_kernel (256x256 per-tap tiles)",
+                     "wgrad_halo_kernel")[max(lib.rn_wgrad_kernel_id(ctypes.byref(p)), 0)] + " + wgrad_reduce_kernel"
+
+            def wgrad(st, a=a, flw=flw, wname=wname):
+                prof = self.wgrad_profile
+                if prof is None:
+                    _C.check(lib.rn_conv2d_nhwc_wgrad(*a, st), "rn_conv2d_nhwc_wgrad")
+                    return
+                # bench.py: HIP events on the stream the launch goes to (the side stream in the two-stream backward)
+                cur = torch.cuda.current_stream(self.dev)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(cur)
+                _C.check(lib.rn_conv2d_nhwc_wgrad(*a, st), "rn_conv2d_nhwc_wgrad")
+                e1.record(cur)
+                prof.append((e0, e1, flw, wname))
+            self.bwd_steps.append(self._side(wgrad, writes=[c.get("kvar", cname + "/kernel")]))
             if c["bias"]:
                 # bias gradient = column sums of dy over every segment (two-stage reduction kernel)
                 pb2 = _C.BnProblem()
@@ -1288,7 +1315,7 @@ class TrainEngine:
         # instead of the 36 (9 useful) of the zero-upsampled form (rn_dgrad_pack.pad_ == 1)
         subpixel = (k == 3 and stride == 2 and need[0]["pad"] == 1 and os.environ.get("RNET_DGRAD_SUBPIXEL", "1") != "0"
                     and all(self._src(o["inp"]).shape[1] % 2 == 0 and self._src(o["inp"]).shape[2] % 2 == 0
-                            and (4 * self.g.convs[o["conv"]]["cin"]) % 8 == 0 for o in need))
+                            and self.g.convs[o["conv"]]["cin"] % 8 == 0 for o in need))   # rn_depth_to_space2x: C % 8
         if subpixel:
             p.R = p.S = 2
             p.pad_top = p.pad_left = 0

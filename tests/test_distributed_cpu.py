@@ -152,3 +152,67 @@ def test_native_comm_construction_is_collective_safe():
     for key in ("init@0", "init@1"):
         # every rank entered the init; the status is agreed on afterwards and the survivor drops its communicator
         assert r0[key] == r1[key] == (False, 1, False), (key, r0[key], r1[key])
+
+
+def _worker_eval_loop(rank, world, port, out):
+    sys.path.insert(0, PKG)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from types import SimpleNamespace
+    from retinanet.cfg import AttrDict
+    from retinanet.distribute import Strategy
+    from retinanet.executor import Executor
+    H = W = 8
+    per_replica = 3
+    # rank 0: 2 full batches + a short one (7 records); rank 1: ONE short batch (2 records) — the shards of a sharded
+    # validation set never line up
+    counts = {0: [3, 3, 1], 1: [2]}[rank]
+    first_id = {0: 100, 1: 200}[rank]
+
+    def dataset():
+        nxt = first_id
+        for n in counts:
+            ids = torch.arange(nxt, nxt + n)
+            nxt += n
+            img = ids.to(torch.float32).reshape(n, 1, 1, 1).expand(n, H, W, 3).clone()
+            yield {"image": img, "image_id": ids, "resize_scale": torch.full((n, 2), 0.5)}
+
+    def fake_model(images, training=False):        # detections that carry the image's id back
+        b = images.shape[0]
+        v = images[:, 0, 0, 0]
+        return {"boxes": v.reshape(b, 1, 1).expand(b, 1, 4).clone(), "scores": v.reshape(b, 1).clone(),
+                "classes": torch.zeros((b, 1), dtype=torch.int32), "valid_detections": torch.ones((b,), dtype=torch.int32)}
+
+    ex = Executor.__new__(Executor)
+    ex.params = AttrDict(input=AttrDict(input_shape=[H, W]))
+    ex.distribute_strategy = Strategy("multi_gpu", torch.device("cpu"), rank, world)
+    ex.num_replicas = world
+    ex.batch_size = {"val": per_replica * world}
+    ex._model = SimpleNamespace(device=torch.device("cpu"))
+    ex._eval_model = fake_model
+    ex._val_dataset = dataset
+    got_ids, got_scores, steps = [], [], 0
+    for res in ex._gathered_eval_results(total_steps=10):
+        steps += 1
+        got_ids += res["image_id"].tolist()
+        got_scores += res["detections"]["scores"].reshape(-1).tolist()
+        assert res["resize_scale"].shape == (len(res["image_id"]), 2)
+    scores = ex.distribute_strategy.broadcast_object({"AP": 0.5} if rank == 0 else None, src=0)
+    out[rank] = dict(ids=got_ids, scores=got_scores, steps=steps, ap=scores["AP"])
+    dist.destroy_process_group()
+
+
+def test_multi_replica_evaluation_with_uneven_shards_does_not_hang_or_drop_records():
+    """with one input pipeline per rank the validation shards are uneven — a rank that runs out of
+    records (or holds a short last batch) must keep taking part in the gathers.  Loop control is collective
+    (Strategy.any_true), every rank contributes a fixed-size padded batch + a row mask, the padding rows are dropped
+    after the gather: both ranks see every record exactly once, in the same order, and leave the loop together."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_eval_loop, args=(world, _free_port(), out), nprocs=world, join=True)
+    r0, r1 = out[0], out[1]
+    assert r0["ids"] == r1["ids"] and r0["steps"] == r1["steps"] == 3
+    assert sorted(r0["ids"]) == [100, 101, 102, 103, 104, 105, 106, 200, 201]
+    assert r0["scores"] == [float(i) for i in r0["ids"]]       # the detections travelled with their rows
+    assert r0["ap"] == r1["ap"] == 0.5
