@@ -183,8 +183,9 @@ typedef struct {
                                 * wgrad_halo) leave free — their workgroups own a CU for a whole tile loop, and RCCL's
                                 * kernels (~130 latency-bound SyncBN all-reduces per step, the gradient buckets) then
                                 * always find one.  0..128 */
-  int32_t wgrad_kernel;        /* 0: auto | 1: wgrad_kernel (128 x 128 per-tap tiles) | 2: the 256-wide kernels whenever
-                                * the channel counts allow, whatever the pixel count (tests at small sizes) */
+  int32_t wgrad_kernel;        /* 0: auto | 1: wgrad_kernel (128 x 128 per-tap tiles) | 2: the wide kernels (wgrad_halo_kernel for
+                                * 3x3 / stride 1, else wgrad_big_kernel) whenever the channel counts allow, whatever the
+                                * pixel count (tests at small sizes) | 3: as 2 but never wgrad_halo_kernel (A/B timing) */
   int32_t wgrad_target_blocks; /* > 0: workgroups a weight-gradient launch aims for (split-K plan; A/B timing) */
   int32_t ablate;              /* tools/bench_conv.py: ablated variants of conv_fwd_kernel<128,128,64> — timing only */
 } rn_launch_opts;
@@ -332,7 +333,8 @@ typedef struct {
 
 size_t rn_wgrad_workspace_bytes(const rn_wgrad_problem* problem /* host */);
 /* Which kernel rn_conv2d_nhwc_wgrad runs for `problem`: 0 = wgrad_kernel (128 x 128 per-tap tiles, K step 64 pixels),
- * 1 = wgrad_big_kernel (256 x 256 per-tap tiles, ping-pong); -1 on a malformed problem.  Bench bookkeeping only. */
+ * 1 = wgrad_big_kernel (256 x 256 per-tap tiles, ping-pong), 2 = wgrad_halo_kernel (3x3 / stride 1 / pad 1: all nine taps
+ * in one workgroup, reduction over image rows); -1 on a malformed problem.  Bench bookkeeping only. */
 int rn_wgrad_kernel_id(const rn_wgrad_problem* problem /* host */);
 int rn_conv2d_nhwc_wgrad(const rn_wgrad_problem* problem /* host */, float* dw, float beta, void* workspace,
                          size_t workspace_bytes, void* stream);

@@ -48,7 +48,7 @@ struct rn_handle {
 
 static int rn_check_opts(const rn_launch_opts& o, const char* who) {
   RN_CHECK_ARG(o.conv_tile >= 0 && o.conv_tile <= 2, "%s: conv_tile=%d (0..2)", who, o.conv_tile);
-  RN_CHECK_ARG(o.wgrad_kernel >= 0 && o.wgrad_kernel <= 2, "%s: wgrad_kernel=%d (0..2)", who, o.wgrad_kernel);
+  RN_CHECK_ARG(o.wgrad_kernel >= 0 && o.wgrad_kernel <= 3, "%s: wgrad_kernel=%d (0..3)", who, o.wgrad_kernel);
   RN_CHECK_ARG(o.reserved_cus >= 0 && o.reserved_cus <= 128, "%s: reserved_cus=%d out of range (0..128)", who,
                o.reserved_cus);
   RN_CHECK_ARG(o.max_workgroups >= 0 && o.conv_big_min_tiles >= 0 && o.wgrad_target_blocks >= 0,

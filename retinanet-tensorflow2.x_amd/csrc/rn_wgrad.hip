@@ -180,32 +180,75 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wgrad_kernel(const WgArgs args)
     }                                                                                             \
   } while (0)
 
+  // Fragment addresses inside a stage (see wg_frag for the layout): the swizzle term (row & 3) does not depend on the K
+  // slice, so one byte offset per 32-channel MFMA tile + immediates (K slice: 16 rows = 4096 B, second half: +1024) cover
+  // every transpose read.  The reads are issued from inline asm (rn_wgrad_dev.h): through the builtin the compiler put
+  // `s_waitcnt vmcnt(0)` in front of the first read of every K step — i.e. right behind the DMA of the NEXT stage, which
+  // was thereby waited for before any MFMA of the current one: no overlap inside a workgroup at all.
+  unsigned fbase[4];
+  {
+    const int g = lane >> 4, i = lane & 15;
+    const int row0 = (g >> 1) * 8 + (i >> 2);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int col = (t < 2 ? wave_m : wave_n) * 64 + (t & 1) * 32 + 16 * (g & 1) + 4 * (i & 3);
+      fbase[t] = (unsigned)((t < 2 ? 0 : WG_TILE_BYTES) + row0 * 256 + (((col >> 3) ^ ((row0 & 3) << 2)) << 4) + (col & 7) * 2);
+    }
+  }
+  const unsigned lds0 = rn_lds_addr(smem);
+#define WG_READS(q_, st_, kk_)                                                                     \
+  do {                                                                                             \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                \
+      const unsigned a__ = (st_) + fbase[t];                                                       \
+      RN_TR_ISSUE(q_[2 * t], a__, (kk_) * 4096);                                                   \
+      RN_TR_ISSUE(q_[2 * t + 1], a__, (kk_) * 4096 + 1024);                                        \
+    }                                                                                              \
+  } while (0)
+#define WG_WAIT(q_, n_)                                                                            \
+  asm volatile("s_waitcnt lgkmcnt(%8)"                                                             \
+               : "+v"(q_[0]), "+v"(q_[1]), "+v"(q_[2]), "+v"(q_[3]), "+v"(q_[4]), "+v"(q_[5]), "+v"(q_[6]), "+v"(q_[7]) \
+               : "i"(n_) : "memory")
+#define WG_MFMAS(q_)                                                                               \
+  do {                                                                                             \
+    const bf16x8_t fa0__ = rn_tr_frag(q_[0], q_[1]), fa1__ = rn_tr_frag(q_[2], q_[3]);             \
+    const bf16x8_t fb0__ = rn_tr_frag(q_[4], q_[5]), fb1__ = rn_tr_frag(q_[6], q_[7]);             \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    acc[0][0] = RN_MFMA_32x32x16(fa0__, fb0__, acc[0][0], 0, 0, 0);                                \
+    acc[0][1] = RN_MFMA_32x32x16(fa0__, fb1__, acc[0][1], 0, 0, 0);                                \
+    acc[1][0] = RN_MFMA_32x32x16(fa1__, fb0__, acc[1][0], 0, 0, 0);                                \
+    acc[1][1] = RN_MFMA_32x32x16(fa1__, fb1__, acc[1][1], 0, 0, 0);                                \
+  } while (0)
+
   WG_ISSUE(0, p_begin);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  __builtin_amdgcn_s_barrier();
   int cur = 0;
 #pragma unroll 1
   for (int kt = 0; kt < ksteps; ++kt) {
-    if (kt + 1 < ksteps) WG_ISSUE(cur ^ 1, p_begin + (kt + 1) * WG_BK);
-    const char* ta = smem + cur * (2 * WG_TILE_BYTES);
-    const char* tb = ta + WG_TILE_BYTES;
-#pragma unroll
-    for (int kk = 0; kk < WG_BK / 16; ++kk) {
-      bf16x8_t fa[2], fb[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) fa[i] = wg_frag(ta, kk * 16, lane, wave_m * 64 + i * 32);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) fb[j] = wg_frag(tb, kk * 16, lane, wave_n * 64 + j * 32);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = RN_MFMA_32x32x16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    }
+    if (kt + 1 < ksteps) WG_ISSUE(cur ^ 1, p_begin + (kt + 1) * WG_BK);   // lands under this step's reads and MFMAs
+    const unsigned st = lds0 + (unsigned)(cur * (2 * WG_TILE_BYTES));
+    // four K slices, reads of slice k + 1 in flight under the MFMAs of slice k (LDS reads return in order: a counted wait)
+    rn_u32x2_t qa[8], qb[8];
+    WG_READS(qa, st, 0);
+    WG_READS(qb, st, 1);
+    WG_WAIT(qa, 8);
+    WG_MFMAS(qa);
+    WG_READS(qa, st, 2);
+    WG_WAIT(qb, 8);
+    WG_MFMAS(qb);
+    WG_READS(qb, st, 3);
+    WG_WAIT(qa, 8);
+    WG_MFMAS(qa);
+    WG_WAIT(qb, 0);
+    WG_MFMAS(qb);
+    // the next stage has landed and every wave is done reading this one before it is overwritten
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    __builtin_amdgcn_s_barrier();
     cur ^= 1;
   }
+#undef WG_MFMAS
+#undef WG_WAIT
+#undef WG_READS
 #undef WG_ISSUE
 
   // partial tile -> workspace[chunk][co][tap][ci]
@@ -321,16 +364,21 @@ static int wgrad_plan(const rn_wgrad_problem* p, WgArgs& a) {
 }
 
 /* which kernel rn_conv2d_nhwc_wgrad runs for `problem`: 0 = wgrad_kernel (128 x 128 per-tap tiles), 1 = wgrad_big_kernel
- * (256 x 256 per-tap tiles); -1 on a malformed problem.  Profiling / bench bookkeeping only. */
+ * (256 x 256 per-tap tiles), 2 = wgrad_halo_kernel (3x3 / stride 1: all nine taps per workgroup); -1 on a malformed
+ * problem.  Profiling / bench bookkeeping only. */
 extern "C" int rn_wgrad_kernel_id(const rn_wgrad_problem* p) {
   WgArgs a;
   if (wgrad_plan(p, a)) return -1;
+  WhArgs h;
+  if (rn_wgrad_halo_plan(p, h)) return 2;
   return a.pad_;
 }
 
 extern "C" size_t rn_wgrad_workspace_bytes(const rn_wgrad_problem* p) {
   WgArgs a;
   if (wgrad_plan(p, a)) return 0;
+  WhArgs h;
+  if (rn_wgrad_halo_plan(p, h)) return rn_wgrad_halo_workspace_bytes(h);
   return (size_t)a.total_chunks * a.Cout * a.R * a.S * a.Cin * sizeof(float);
 }
 
@@ -343,6 +391,20 @@ extern "C" int rn_conv2d_nhwc_wgrad(const rn_wgrad_problem* p, float* dw, float 
   if (!workspace || workspace_bytes < need) {
     rn_set_error("rn_conv2d_nhwc_wgrad: workspace %zu < %zu", workspace_bytes, need);
     return RN_ENOMEM;
+  }
+  {
+    WhArgs h;
+    if (rn_wgrad_halo_plan(p, h)) {
+      h.ws = (float*)workspace;
+      const int rc = rn_launch_wgrad_halo(h, p->opts, (hipStream_t)stream);
+      if (rc != RN_OK) return rc;
+      const long long nb4 = (long long)h.Cout * 9 * h.Cin / 4;
+      int blocksh = (int)(rn_cdiv(nb4, 64) < 4096 ? rn_cdiv(nb4, 64) : 4096);
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocksh), dim3(256), 0, (hipStream_t)stream, (const float4*)workspace, nb4,
+                         h.total_chunks, (float4*)dw, beta);
+      RN_CHECK_LAUNCH();
+      return RN_OK;
+    }
   }
   a.ws = (float*)workspace;
   hipStream_t st = (hipStream_t)stream;

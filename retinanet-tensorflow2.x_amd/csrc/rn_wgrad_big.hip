@@ -94,6 +94,7 @@ __global__ void __launch_bounds__(512) wgrad_big_kernel(const WgArgs args) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave_m = wave >> 2, wave_n = wave & 3;   // wave_m is also the ping-pong group
+  const unsigned lds0 = rn_lds_addr(smem);
 
   const __amdgpu_buffer_rsrc_t rs_dy =
       __builtin_amdgcn_make_buffer_rsrc((void*)sg.dy, 0, (int)((long long)sg.P * sg.dyS * 2), 0x00020000);
@@ -203,16 +204,26 @@ __global__ void __launch_bounds__(512) wgrad_big_kernel(const WgArgs args) {
   for (int i = 0; i < 4; ++i) offa[i] = frag_off(lane, wave_m * 128 + i * 32);
 #pragma unroll
   for (int j = 0; j < 2; ++j) offb[j] = OP_BYTES + frag_off(lane, wave_n * 64 + j * 32);
+// 24 transpose reads from inline asm (rn_wgrad_dev.h: through the builtin the compiler drains the whole DMA ring — an
+// `s_waitcnt vmcnt(0)` in front of the first read of every K step — and the counted vmcnt(8) below is moot); they return
+// while this wave issues its DMA pieces; ONE wait names every destination
 #define WGB_READ(stage_)                                                                          \
   do {                                                                                            \
-    const char* t__ = smem + (stage_) * STAGE_BYTES;                                              \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) fb0[j] = frag_read(t__ + offb[j]);              \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) fa0[i] = frag_read(t__ + offa[i]);              \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) fb1[j] = frag_read(t__ + offb[j] + 16 * 512);   \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) fa1[i] = frag_read(t__ + offa[i] + 16 * 512);   \
+    const unsigned t__ = lds0 + (unsigned)((stage_) * STAGE_BYTES);                               \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                               \
+      const unsigned a__ = t__ + (unsigned)offb[j];                                               \
+      RN_TR_ISSUE(q[4 * j], a__, 0); RN_TR_ISSUE(q[4 * j + 1], a__, 2048);                        \
+      RN_TR_ISSUE(q[4 * j + 2], a__, 8192); RN_TR_ISSUE(q[4 * j + 3], a__, 8192 + 2048);          \
+    }                                                                                             \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
+      const unsigned a__ = t__ + (unsigned)offa[i];                                               \
+      RN_TR_ISSUE(q[8 + 4 * i], a__, 0); RN_TR_ISSUE(q[8 + 4 * i + 1], a__, 2048);                \
+      RN_TR_ISSUE(q[8 + 4 * i + 2], a__, 8192); RN_TR_ISSUE(q[8 + 4 * i + 3], a__, 8192 + 2048);  \
+    }                                                                                             \
   } while (0)
 #define WGB_LOADSEG(stage_)                                                                       \
   do {                                                                                            \
+    rn_u32x2_t q[24];                                                                             \
     WGB_READ(stage_);                                                                             \
     if (g_iss < ksteps) {                                                                         \
       WGB_ISSUE();                                                                                \
@@ -220,7 +231,17 @@ __global__ void __launch_bounds__(512) wgrad_big_kernel(const WgArgs args) {
     } else {                                                                                      \
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
     }                                                                                             \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                            \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                           \
+                 : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]),         \
+                   "+v"(q[8]), "+v"(q[9]), "+v"(q[10]), "+v"(q[11]), "+v"(q[12]), "+v"(q[13]), "+v"(q[14]), "+v"(q[15]),   \
+                   "+v"(q[16]), "+v"(q[17]), "+v"(q[18]), "+v"(q[19]), "+v"(q[20]), "+v"(q[21]), "+v"(q[22]), "+v"(q[23])  \
+                 :: "memory");                                                                    \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                               \
+      fb0[j] = rn_tr_frag(q[4 * j], q[4 * j + 1]); fb1[j] = rn_tr_frag(q[4 * j + 2], q[4 * j + 3]); \
+    }                                                                                             \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
+      fa0[i] = rn_tr_frag(q[8 + 4 * i], q[8 + 4 * i + 1]); fa1[i] = rn_tr_frag(q[8 + 4 * i + 2], q[8 + 4 * i + 3]); \
+    }                                                                                             \
   } while (0)
 #define WGB_COMPUTESEG()                                                                          \
   do {                                                                                            \
@@ -298,7 +319,7 @@ bool rn_wgrad_big_plan(const rn_wgrad_problem* p, WgArgs& a) {
   for (int i = 0; i < p->num_segments; ++i) Ptot += (long long)p->seg[i].N * p->seg[i].Ho * p->seg[i].Wo;
   const int co_tiles = (int)rn_cdiv(a.Cout, 256), ci_tiles = (int)rn_cdiv(a.Cin, 256);
   const int tiles = co_tiles * ci_tiles * a.R * a.S;
-  if ((Ptot < 16384 && p->opts.wgrad_kernel != 2) || tiles > 512) return false;
+  if ((Ptot < 16384 && p->opts.wgrad_kernel < 2) || tiles > 512) return false;
   a.co_tiles = co_tiles;
   a.ci_tiles = ci_tiles;
   a.co_groups = 1;

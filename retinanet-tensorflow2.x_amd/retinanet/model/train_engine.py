@@ -1106,8 +1106,13 @@ class TrainEngine:
                 s.x, s.dy = x.data_ptr(), dy.data_ptr()
                 s.N, s.H, s.W, s.Cin, s.Ho, s.Wo, s.Cout = B, x.shape[1], x.shape[2], c["cin"], dy.shape[1], dy.shape[2], c["cout"]
                 s.dy_pix_stride = dy.shape[3]
-            ws = torch.empty((max(lib.rn_wgrad_workspace_bytes(ctypes.byref(p)), 256),), dtype=torch.uint8,
-                             device=self.dev)
+            nws = lib.rn_wgrad_workspace_bytes(ctypes.byref(p))
+            if os.environ.get("RNET_AB_WORKSPACES") == "1":   # tools/ab_step.py switches kernel families between timed rounds
+                for alt in (1, 3):
+                    q = _C.WgradProblem.from_buffer_copy(p)
+                    q.opts.wgrad_kernel = alt
+                    nws = max(nws, lib.rn_wgrad_workspace_bytes(ctypes.byref(q)))
+            ws = torch.empty((max(nws, 256),), dtype=torch.uint8, device=self.dev)
             dw = self._pview(c.get("kvar", cname + "/kernel"), self.G)
             self._keep += [p, ws]
             self.wgrad_launches.append(("wgrad:" + cname, p))

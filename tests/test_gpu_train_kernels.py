@@ -54,21 +54,37 @@ WGRAD_SHAPES = [
     ([(2, 64, 256, 720)], 3, 1),                                 # 256x256-tile kernel: 3 co tiles, Cout tail
     ([(3, 48, 512, 256)], 1, 1),                                 # 256x256-tile kernel: 1x1, 2 ci tiles
     ([(2, 96, 256, 512)], 3, 2),                                 # 256x256-tile kernel: stride 2
+    # wgrad_halo_kernel (3x3 / stride 1 / pad 1, all nine taps per workgroup, reduction over image rows)
+    ([(3, 9, 64, 64)], 3, 1),                                    # one column strip with a tail (W = 9 < 16), odd H, N = 3
+    ([(2, 13, 128, 136)], 3, 1),                                 # Cout tail inside the second 128-wide co tile (136 = 128 + 8)
+    ([(1, 40, 128, 256), (2, 17, 128, 256), (5, 1, 128, 256)], 3, 1),   # segments: W = 40 (2.5 strips), 17 (tail of 1), H = W = 1
+    ([(2, 33, 512, 64)], 3, 1),                                  # 8 ci tiles, W = 33 (third strip holds one column)
 ]
+# square images in the list above; the halo cases add non-square ones below through _WGRAD_HW
+_WGRAD_HW = {"halo_w9": (9, 9), "halo_co136": (11, 13), "halo_segs": None, "halo_ci512": (6, 33)}
 
 
 _WGRAD_IDS = ["3x3", "1x1", "3x3s2", "pred36", "pyramid", "cin192_720", "co640", "big_pyramid", "big_720", "big_1x1",
-              "big_s2"]
-_WGRAD_F16 = [0, 1, 2, 3, 4, 7, 8, 9]     # the half build: the 128-tile kernel and the 256-wide kernels
+              "big_s2", "halo_w9", "halo_co136", "halo_segs", "halo_ci512"]
+# (build, shape, rn_launch_opts.wgrad_kernel, wgrad_target_blocks, kernel that must run: 0 = wgrad_kernel, 1 = wgrad_big_kernel,
+# 2 = wgrad_halo_kernel).  The first seven shapes at these sizes: the dispatcher's own choice (the 128-tile kernel).
+_WGRAD_CASES = ([("bf16", i, 0, 0, 0) for i in _WGRAD_IDS[:7]] + [("f16", _WGRAD_IDS[i], 0, 0, 0) for i in (0, 1, 2, 3, 4)]
+                + [("bf16", "big_pyramid", 2, 0, 2), ("bf16", "big_720", 2, 0, 2), ("f16", "big_pyramid", 2, 0, 2),
+                   ("f16", "big_720", 2, 0, 2),                       # 3x3 / stride 1: the halo kernel
+                   ("bf16", "big_pyramid", 3, 0, 1), ("bf16", "big_720", 3, 0, 1), ("f16", "big_pyramid", 3, 0, 1),
+                   ("bf16", "big_1x1", 2, 0, 1), ("bf16", "big_s2", 2, 0, 1), ("f16", "big_1x1", 2, 0, 1)]
+                # halo kernel: tails, segments, and split-K plans from one chunk to many short ones (chunk boundaries in
+                # the middle of a strip, chunks that span strips and segments)
+                + [("bf16", i, 2, tb, 2) for i in _WGRAD_IDS[11:] for tb in (0, 1, 64)]
+                + [("bf16", "pyramid", 2, 40, 2), ("bf16", "3x3", 2, 0, 2), ("f16", "halo_segs", 2, 64, 2)])
 
 
-@pytest.mark.parametrize("build,shape_id", [("bf16", i) for i in _WGRAD_IDS] + [("f16", _WGRAD_IDS[i]) for i in _WGRAD_F16])
-def test_wgrad(cuda, build, shape_id):
+@pytest.mark.parametrize("build,shape_id,kernel_opt,target_blocks,want_kernel", _WGRAD_CASES)
+def test_wgrad(cuda, build, shape_id, kernel_opt, target_blocks, want_kernel):
     from retinanet import _C
     lib = _lib()
     idx = _WGRAD_IDS.index(shape_id)
     segs, k, stride = WGRAD_SHAPES[idx]
-    big = idx >= 7        # the big_* cases must run the 256-wide kernels: rn_launch_opts.wgrad_kernel = 2 on this call
     g = torch.Generator().manual_seed(len(segs) * 100 + k + stride)
     pad = (k - 1) // 2
     cin, cout = segs[0][2], segs[0][3]
@@ -77,23 +93,26 @@ def test_wgrad(cuda, build, shape_id):
     p.stride_h = p.stride_w = stride
     p.pad_top = p.pad_left = pad
     p.num_segments = len(segs)
-    p.opts = _C.LaunchOpts(wgrad_kernel=2 if big else 0)
+    p.opts = _C.LaunchOpts(wgrad_kernel=kernel_opt, wgrad_target_blocks=target_blocks)
     keep = []
     want = torch.zeros((cout, k, k, cin), dtype=torch.float64)
     for i, (N, H, ci, co) in enumerate(segs):
-        x = _bf(torch.randn((N, H, H, ci), generator=g))
-        Ho = (H + 2 * pad - k) // stride + 1
-        dy = _bf(torch.randn((N, Ho, Ho, co), generator=g))
+        Hh, Ww = _WGRAD_HW.get(shape_id) or (H, H)
+        x = _bf(torch.randn((N, Hh, Ww, ci), generator=g))
+        Ho, Wo = (Hh + 2 * pad - k) // stride + 1, (Ww + 2 * pad - k) // stride + 1
+        dy = _bf(torch.randn((N, Ho, Wo, co), generator=g))
         xd, dyd = x.to(cuda), dy.to(cuda)
         s = p.seg[i]
         s.x, s.dy = xd.data_ptr(), dyd.data_ptr()
-        s.N, s.H, s.W, s.Cin, s.Ho, s.Wo, s.Cout = N, H, H, ci, Ho, Ho, co
+        s.N, s.H, s.W, s.Cin, s.Ho, s.Wo, s.Cout = N, Hh, Ww, ci, Ho, Wo, co
         keep += [xd, dyd]
         w = torch.zeros((co, ci, k, k), dtype=torch.float64, requires_grad=True)
         y = F.conv2d(x.double().permute(0, 3, 1, 2), w, stride=stride, padding=pad)
         y.backward(dy.double().permute(0, 3, 1, 2))
         want += w.grad.permute(0, 2, 3, 1)
+    assert lib.rn_wgrad_kernel_id(ctypes.byref(p)) == want_kernel
     ws = _ws(lib.rn_wgrad_workspace_bytes(ctypes.byref(p)), cuda)
+    ws.fill_(0x7f)      # stale workspace bytes must not leak into the sums
     dw = torch.full((cout, k, k, cin), 7.0, dtype=torch.float32, device=cuda)
     _C.check(lib.rn_conv2d_nhwc_wgrad(ctypes.byref(p), _C.ptr(dw), 0.0, _C.ptr(ws), ws.numel(), _C.current_stream()))
     torch.cuda.synchronize()
