@@ -17,6 +17,7 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <exception>
 #include <vector>
 
 #include "rn_common.h"
@@ -209,6 +210,11 @@ int parse_headers(Decoder& d, size_t& scan_pos, bool header_only) {
         rn_set_error("jpeg: unsupported frame (%d x %d, %d components)", d.width, d.height, d.ncomp);
         return RN_EINVAL;
       }
+      if ((long long)d.width * d.height > (64ll << 20)) {   // untrusted bytes: a corrupt header must not ask for gigabytes
+        rn_set_error("jpeg: frame %d x %d exceeds the 64 Mpixel limit", d.width, d.height);
+        return RN_EINVAL;
+      }
+      d.hmax = d.vmax = 1;          // a repeated SOF starts over
       for (int i = 0; i < d.ncomp; ++i) {
         Comp& c = d.comp[i];
         c.id = s[6 + 3 * i]; c.h = s[7 + 3 * i] >> 4; c.v = s[7 + 3 * i] & 15; c.tq = s[8 + 3 * i] & 3;
@@ -256,7 +262,7 @@ int parse_headers(Decoder& d, size_t& scan_pos, bool header_only) {
     } else if (m == 0xDD) {
       if (n >= 2) d.restart = be16(s);
     } else if (m == 0xDA) {
-      if (!d.got_sof || n < 1 + 2 * s[0] + 3 || s[0] != d.ncomp) {
+      if (!d.got_sof || n < 1 || n < 1 + 2 * s[0] + 3 || s[0] != d.ncomp) {
         rn_set_error("jpeg: SOS before SOF, or a non-interleaved multi-scan file (not supported)");
         return RN_EINVAL;
       }
@@ -325,6 +331,8 @@ int decode_scan(Decoder& d, size_t scan_pos) {
               return RN_EINVAL;
             }
             c.pred += t ? extend(b.get(t), t) : 0;
+            // a valid stream keeps DC differences inside 12 bits: clamp so that corrupt data cannot overflow the products
+            c.pred = c.pred < -32768 ? -32768 : (c.pred > 32767 ? 32767 : c.pred);
             coef[0] = c.pred * q[0];
             for (int k = 1; k < 64;) {
               const int rs = decode_symbol(b, d.ac[c.ta]);
@@ -407,7 +415,7 @@ void upsample(const Decoder& d, const Comp& c, std::vector<uint8_t>& out) {
 }  // namespace
 
 // width / height / components (1 or 3) of a baseline JPEG; RN_EINVAL with a message for anything else
-extern "C" int rn_jpeg_info(const void* data, size_t len, int32_t* width, int32_t* height, int32_t* components) {
+extern "C" int rn_jpeg_info(const void* data, size_t len, int32_t* width, int32_t* height, int32_t* components) try {
   RN_CHECK_ARG(data && width && height && components, "rn_jpeg_info: null argument");
   Decoder d;
   d.data = (const uint8_t*)data;
@@ -417,10 +425,13 @@ extern "C" int rn_jpeg_info(const void* data, size_t len, int32_t* width, int32_
   if (rc) return rc;
   *width = d.width; *height = d.height; *components = d.ncomp;
   return RN_OK;
+} catch (const std::exception& e) {      // no C++ exception crosses the C boundary (std::bad_alloc on a hostile header)
+  rn_set_error("rn_jpeg_info: %s", e.what());
+  return RN_ENOMEM;
 }
 
 // RGB u8 [height, width, 3] (grayscale replicated), decoded like libjpeg's defaults (see the header of this file)
-extern "C" int rn_jpeg_decode(const void* data, size_t len, uint8_t* rgb_out, size_t out_bytes) {
+extern "C" int rn_jpeg_decode(const void* data, size_t len, uint8_t* rgb_out, size_t out_bytes) try {
   RN_CHECK_ARG(data && rgb_out, "rn_jpeg_decode: null argument");
   Decoder d;
   d.data = (const uint8_t*)data;
@@ -456,6 +467,9 @@ extern "C" int rn_jpeg_decode(const void* data, size_t len, uint8_t* rgb_out, si
     rgb_out[3 * i + 2] = clamp255(yy + cb_b[b]);
   }
   return RN_OK;
+} catch (const std::exception& e) {
+  rn_set_error("rn_jpeg_decode: %s", e.what());
+  return RN_ENOMEM;
 }
 
 // the inverse DCT on its own, for the tests (coefficients already dequantized, natural order)

@@ -304,8 +304,8 @@ wgrad_reduce_kernel(const float4* __restrict__ ws, long long n4, int chunks, flo
   }
 }
 
-// workgroups a launch aims for (2 per CU x 256 CUs x a few rounds); fewer = fewer split-K partials to
-// write and reduce, more = better balance.  Tunable from tools/ for A/B timing.
+// workgroups a launch aims for (2 per CU x 256 CUs); fewer = fewer split-K partials to write and reduce, more = better
+// balance.  Tunable per call (rn_launch_opts.wgrad_target_blocks) for A/B timing.
 // (rn_launch_opts.wgrad_target_blocks overrides it, .wgrad_kernel picks the kernel family.)
 
 static int wgrad_plan(const rn_wgrad_problem* p, WgArgs& a) {
@@ -337,7 +337,10 @@ static int wgrad_plan(const rn_wgrad_problem* p, WgArgs& a) {
   if (a.co_groups > a.co_tiles) a.co_groups = a.co_tiles;
   a.gco = (int)rn_cdiv(a.co_tiles, a.co_groups);
   a.co_groups = (int)rn_cdiv(a.co_tiles, a.gco);
-  long long target = rn_cdiv(p->opts.wgrad_target_blocks > 0 ? p->opts.wgrad_target_blocks : 1024, tiles);
+  // 512 = one round of two workgroups per CU: measured (tools/bench_wgrad.py, same process) 58 vs 75 us on the 128 <-> 512
+  // 1x1 layers of ResNet stage 2 and 41 vs 55 us on 2048 -> 512 against the former 1024 — these layers are HBM-bound and
+  // every extra pixel chunk is another |W| x 4 bytes of partial tile written and read back
+  long long target = rn_cdiv(p->opts.wgrad_target_blocks > 0 ? p->opts.wgrad_target_blocks : 512, tiles);
   if (target < 1) target = 1;
   if (target > 256) target = 256;
   long long CH = rn_cdiv(rn_cdiv(Ptot, target), WG_BK) * WG_BK;

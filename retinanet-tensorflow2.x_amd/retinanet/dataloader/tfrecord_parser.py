@@ -8,8 +8,9 @@ The record framing / CRC-32C check and the tf.train.Example wire format are pars
         sample = parse_example(payload)         # {'image', 'image_id', 'objects': {'bbox', 'label'}}
 
 `sample['image']` is float32 [h, w, 3] like `tf.cast(tf.io.decode_image(..., channels=3), tf.float32)`.
-PNG and BMP are decoded here (zlib + numpy); JPEG needs Pillow, which this image does not ship — without it a JPEG
-record raises `ImageDecodeError` (a user with real COCO TFRecords installs Pillow; nothing else changes).
+PNG and BMP are decoded here (zlib + numpy); baseline JPEG by the native decoder (`rn_jpeg_decode`, csrc/rn_jpeg.hip:
+bit-identical to libjpeg-turbo); progressive / CMYK / arithmetic-coded JPEG fall back to Pillow when it is installed
+(logged once), else raise `ImageDecodeError`.
 `parse_example(..., decode=False)` returns the encoded bytes instead.
 """
 from __future__ import annotations
@@ -159,17 +160,50 @@ def _bmp_decode(data):
     return img if top_down else img[::-1]
 
 
+_PILLOW_WARNED = False
+
+
+def _jpeg_decode_pillow(data, why):
+    """JPEG flavours the native baseline decoder refuses (progressive, CMYK / Adobe, arithmetic coding — COCO holds a few
+    progressive files; tf.io.decode_image takes them all): Pillow's libjpeg-turbo, when it is installed, with ONE logged
+    warning per process.  Pillow's default decode parameters are libjpeg's (islow IDCT, fancy up-sampling), the ones the
+    native decoder restates."""
+    global _PILLOW_WARNED
+    try:
+        import io
+
+        from PIL import Image
+    except ImportError:
+        raise ImageDecodeError(why + " (and Pillow is not installed for the fallback)")
+    if not _PILLOW_WARNED:
+        import logging
+        logging.warning("JPEG not decodable by the native baseline decoder (%s): falling back to Pillow for such records", why)
+        _PILLOW_WARNED = True
+    try:
+        with Image.open(io.BytesIO(data)) as im:
+            return np.ascontiguousarray(np.asarray(im.convert("RGB"), dtype=np.uint8))
+    except Exception as e:   # noqa: BLE001 — corrupt bytes: the pipeline's own error type
+        raise ImageDecodeError(f"{why}; Pillow: {e}")
+
+
 def _jpeg_decode(data):
     """baseline JPEG -> uint8 [h, w, 3] through the native decoder (csrc/rn_jpeg.hip: libjpeg's islow IDCT, fancy
-    chroma up-sampling and YCbCr tables restated; grayscale replicated like decode_image(channels=3))"""
+    chroma up-sampling and YCbCr tables restated — bit-identical to libjpeg-turbo, tests/test_jpeg_cpu.py; grayscale
+    replicated like decode_image(channels=3)); files it does not support go to Pillow."""
     lib = _C.lib()
     buf = np.frombuffer(data, dtype=np.uint8)
     w, h, c = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
     if lib.rn_jpeg_info(buf.ctypes.data, buf.size, ctypes.byref(w), ctypes.byref(h), ctypes.byref(c)) != 0:
-        raise ImageDecodeError(lib.rn_last_error().decode())
+        why = lib.rn_last_error().decode()
+        if "not supported" in why or "unsupported" in why or "must be sampled" in why:
+            return _jpeg_decode_pillow(data, why)
+        raise ImageDecodeError(why)
     out = np.empty((h.value, w.value, 3), np.uint8)
     if lib.rn_jpeg_decode(buf.ctypes.data, buf.size, out.ctypes.data, out.size) != 0:
-        raise ImageDecodeError(lib.rn_last_error().decode())
+        why = lib.rn_last_error().decode()
+        if "not supported" in why:
+            return _jpeg_decode_pillow(data, why)
+        raise ImageDecodeError(why)
     return out
 
 

@@ -1,6 +1,9 @@
 """CPU: the native baseline JPEG decoder (csrc/rn_jpeg.hip) behind `decode_image`.
 
-libjpeg is not available, so the decoder is pinned from the outside: an INDEPENDENT baseline JPEG encoder written here
+Pin 1 (the sharp one): libjpeg-turbo itself, through Pillow — files encoded by Pillow (4:4:4 / 4:2:2 / 4:2:0 / grayscale,
+several qualities, restart intervals, odd sizes, optimised Huffman tables) must decode BIT-IDENTICALLY to Pillow's own
+decoding (libjpeg defaults: islow IDCT, fancy up-sampling, the jdcolor tables) — test_bit_identical_to_libjpeg_turbo.
+Pin 2 (independent of any libjpeg, kept from round 2): an INDEPENDENT baseline JPEG encoder written here
 (float64 DCT, its own canonical Huffman tables, 4:4:4 / 4:2:2 / 4:2:0 / grayscale, restart intervals) produces the
 files; the entropy stage must recover every quantised coefficient exactly (checked through images whose blocks are
 exactly representable), the islow inverse DCT must stay within one grey level of the float64 inverse DCT
@@ -331,3 +334,87 @@ def test_jpeg_record_through_parse_example():
     s = parse_example(rec)
     assert s["image"].shape == (48, 64, 3) and s["image"].dtype == np.float32 and s["image_id"] == 42
     np.testing.assert_array_equal(s["image"], decode_image(data).astype(np.float32))
+
+
+# ---- pin against libjpeg-turbo (through Pillow) -----------------------------------------------------------------------
+def _pillow():
+    return pytest.importorskip("PIL.Image")
+
+
+@pytest.mark.parametrize("sampling", ["4:4:4", "4:2:2", "4:2:0", "gray"])
+@pytest.mark.parametrize("quality", [35, 75, 95])
+@pytest.mark.parametrize("size,restart,optimize", [((64, 64), 0, False), ((37, 53), 0, True), ((120, 17), 2, False),
+                                                   ((8, 8), 0, False), ((1, 1), 0, False), ((50, 70), 1, True)])
+def test_bit_identical_to_libjpeg_turbo(sampling, quality, size, restart, optimize):
+    """The decoder restates libjpeg's baseline path (jdhuff / jidctint islow / jdsample h2v1 + h2v2 fancy / jdcolor); here
+    it meets the real library on the library's own files: every byte of the decoded image must match."""
+    import io
+    Image = _pillow()
+    rng = np.random.default_rng(size[0] * 1000 + size[1] + quality)
+    img = _photo(rng, size[0], size[1])
+    im = Image.fromarray(img[..., 0] if sampling == "gray" else img, "L" if sampling == "gray" else "RGB")
+    buf = io.BytesIO()
+    kw = dict(quality=quality, optimize=optimize)
+    if sampling != "gray":
+        kw["subsampling"] = sampling
+    if restart:
+        kw["restart_marker_rows"] = restart
+    im.save(buf, "JPEG", **kw)
+    data = buf.getvalue()
+    want = np.asarray(Image.open(io.BytesIO(data)).convert("RGB"), dtype=np.uint8)
+    got = decode_image(data)
+    assert got.shape == want.shape == (size[0], size[1], 3)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_progressive_and_cmyk_fall_back_to_pillow(caplog):
+    """tf.io.decode_image takes progressive / CMYK files (COCO holds a few progressive ones): the native decoder
+    refuses them with a message and decode_image hands them to Pillow (one warning per process)."""
+    import io
+    import logging
+    Image = _pillow()
+    rng = np.random.default_rng(11)
+    img = _photo(rng, 40, 56)
+    buf = io.BytesIO()
+    Image.fromarray(img, "RGB").save(buf, "JPEG", quality=85, progressive=True)
+    data = buf.getvalue()
+    import ctypes
+    lib = _C.lib()
+    w, h, c = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    b = np.frombuffer(data, np.uint8)
+    assert lib.rn_jpeg_info(b.ctypes.data, b.size, ctypes.byref(w), ctypes.byref(h), ctypes.byref(c)) != 0
+    assert b"progressive" in lib.rn_last_error()
+    with caplog.at_level(logging.WARNING):
+        got = decode_image(data)
+    np.testing.assert_array_equal(got, np.asarray(Image.open(io.BytesIO(data)).convert("RGB")))
+    buf = io.BytesIO()
+    Image.fromarray(img, "RGB").convert("CMYK").save(buf, "JPEG", quality=85)
+    got = decode_image(buf.getvalue())
+    assert got.shape == (40, 56, 3)
+
+
+def test_hostile_headers_do_not_abort_the_process():
+    """untrusted bytes — a final SOS segment of length 2, a 65535 x 65535 frame, a repeated SOF — must come
+    back as ImageDecodeError, never as std::terminate / a read past the buffer."""
+    rng = np.random.default_rng(3)
+    data, _, _, _ = encode_jpeg(_photo(rng, 16, 16), 80)
+    i = data.index(b"\xff\xc0")
+    huge = bytearray(data)
+    huge[i + 5:i + 9] = b"\xff\xff\xff\xff"          # height = width = 65535
+    with pytest.raises(ImageDecodeError, match="64 Mpixel"):
+        decode_image(bytes(huge))
+    short_sos = data[:data.index(b"\xff\xda")] + b"\xff\xda\x00\x02"
+    with pytest.raises(ImageDecodeError):
+        decode_image(short_sos)
+    j = data.index(b"\xff\xda")
+    twice = data[:j] + data[i:i + 2 + int.from_bytes(data[i + 2:i + 4], "big")] + data[j:]   # the SOF segment again
+    np.testing.assert_array_equal(decode_image(twice), decode_image(data))
+    rng = np.random.default_rng(4)
+    for _ in range(300):            # random corruption of header and entropy bytes
+        m = bytearray(data)
+        for _ in range(int(rng.integers(1, 6))):
+            m[int(rng.integers(2, len(m)))] = int(rng.integers(0, 256))
+        try:
+            decode_image(bytes(m))
+        except ImageDecodeError:
+            pass

@@ -2,7 +2,7 @@
 
     python tools/bench_wgrad.py [--preset tower,class,g3,g2,fpn80] [--variants halo,big,halo:1] [--rounds 7] [--iters 5]
 
-A variant is `<kernel>[:<ablate>]`: kernel = halo (rn_launch_opts.wgrad_kernel 2), big (3: the per-tap 256-wide kernel),
+A variant is `<kernel>[:<ablate>[:<wgrad_target_blocks>]]`: kernel = halo (rn_launch_opts.wgrad_kernel 2), big (3: the per-tap 256-wide kernel),
 small (1: the 128-tile kernel); ablate = rn_launch_opts.ablate bits the kernel under test understands (code variants
 compiled side by side for A/B).  Variants are timed in interleaved rounds in ONE process (cdna_hip_programming.md 5.4
 rules 13 / 24: the boxes of the pool differ by several percent, and so do separate invocations); median and min per
@@ -24,11 +24,17 @@ PRESETS = {   # list of (N, H, W, Cin, Cout) segments, k, stride
     "tower": ([(B, s, s, 256, 256) for s in (80, 40, 20, 10, 5)], 3, 1),
     "class": ([(B, s, s, 256, 720) for s in (80, 40, 20, 10, 5)], 3, 1),
     "fpn80": ([(B, 80, 80, 256, 256)], 3, 1),
+    "tower8": ([(B, s, s, 256, 2048) for s in (80, 40, 20, 10, 5)], 3, 1),   # 8 tower layers' worth of tiles: 4 chunks
+    "g2x3": ([(B, 80, 80, 128, 384)], 3, 1),
     "g3": ([(B, 40, 40, 256, 256)], 3, 1),
     "g2": ([(B, 80, 80, 128, 128)], 3, 1),
     "g4": ([(B, 20, 20, 512, 512)], 3, 1),
     "g2_1x1": ([(B, 80, 80, 128, 512)], 1, 1),
     "g3_1x1": ([(B, 40, 40, 1024, 256)], 1, 1),
+    "g3_1x1b": ([(B, 40, 40, 256, 1024)], 1, 1),
+    "g2_1x1b": ([(B, 80, 80, 512, 128)], 1, 1),
+    "g4_1x1": ([(B, 20, 20, 2048, 512)], 1, 1),
+    "fpn_lat": ([(B, 40, 40, 1024, 256)], 1, 1),
 }
 KERNEL = {"halo": 2, "big": 3, "small": 1, "auto": 0}
 
@@ -50,13 +56,13 @@ def main():
         keep, flops = [], 0
         problems = []
         for var in a.variants.split(","):
-            kern, _, abl = var.partition(":")
+            kern, abl, tb = (var.split(":") + ["", ""])[:3]
             p = _C.WgradProblem()
             p.R = p.S = k
             p.stride_h = p.stride_w = stride
             p.pad_top = p.pad_left = pad
             p.num_segments = len(segs)
-            p.opts = _C.LaunchOpts(wgrad_kernel=KERNEL[kern], ablate=int(abl or 0))
+            p.opts = _C.LaunchOpts(wgrad_kernel=KERNEL[kern], ablate=int(abl or 0), wgrad_target_blocks=int(tb or 0))
             problems.append((var, p))
         cin, cout = segs[0][3], segs[0][4]
         for i, (N, H, W, ci, co) in enumerate(segs):
@@ -92,7 +98,7 @@ def main():
                     times[var].append(e0.elapsed_time(e1) / a.iters * 1e3)
                 elif ref is None:
                     ref = dw.clone()
-                elif int(var.partition(":")[2] or 0) < 2:   # (ablate bits >= 2 skip work: timing only)
+                elif int((var.split(":") + [""])[1] or 0) < 2:   # (ablate bits >= 2 skip work: timing only)
                     # every variant computes the same sums (fp32 association differs between kernels)
                     err = (dw - ref).abs().max().item() / (ref.abs().max().item() + 1e-30)
                     assert err < 2e-3, (var, err)

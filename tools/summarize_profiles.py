@@ -46,12 +46,17 @@ def main():
             shutil.copy(f, os.path.join(out, dst))
             print("copied", f, "->", dst)
     per = defaultdict(lambda: defaultdict(list))    # kernel -> counter -> values
+    clock = defaultdict(list)                        # kernel -> (GRBM_GUI_ACTIVE, duration ns) per dispatch
     for sub in ("pmc_fetch", "pmc_write", "pmc_mfma"):
         f = newest(os.path.join(a.src, sub, "**", "*counter_collection.csv"))
         if not f:
             continue
         for r in csv.DictReader(open(f)):
             per[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                dur = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+                if dur > 0:
+                    clock[short(r["Kernel_Name"])].append((float(r["Counter_Value"]), dur))
     with open(os.path.join(out, f"{a.round}_pmc_train_b32_per_kernel.csv"), "w") as fo:
         fo.write("Kernel_Name,Counter_Name,Dispatches,Mean,Sum\n")
         for k in sorted(per):
@@ -76,6 +81,30 @@ def main():
         if e and ("mfma" in k or "conv" in k or "wgrad" in k or "bn_" in k):
             traffic["kernels"][k] = e
     json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
+    # Effective core clock per kernel: GRBM_GUI_ACTIVE counts busy cycles summed over the 8 XCDs, so
+    # GRBM_GUI_ACTIVE / 8 / (End_Timestamp - Start_Timestamp) is the clock a launch really ran at
+    # (MI355X_MICROARCH.md, "DVFS give-back").  Launches shorter than 20 us are left out (timestamp granularity).
+    clk = {"note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE over the one-stream training step "
+                   "(tools/run_profiles.sh): per kernel, mean over its launches >= 20 us of GRBM_GUI_ACTIVE / 8 XCDs / dispatch "
+                   "duration = effective core clock in GHz, next to the kernel's MFMA-busy fraction; the chip clocks to its "
+                   "power budget: 2.4 GHz nominal",
+           "kernels": {}}
+    for k, v in clock.items():
+        v = [(c, d) for c, d in v if d >= 20000]
+        if not v:
+            continue
+        ghz = [c / 8.0 / d for c, d in v]
+        e = {"launches": len(v), "effective_clock_ghz_mean": round(sum(ghz) / len(ghz), 3),
+             "effective_clock_ghz_min": round(min(ghz), 3), "effective_clock_ghz_max": round(max(ghz), 3),
+             "mean_duration_us": round(sum(d for _, d in v) / len(v) / 1e3, 1)}
+        m = traffic["kernels"].get(k, {}).get("mfma_busy_frac_of_simd_cycles")
+        if m is not None:
+            e["mfma_busy_frac_of_simd_cycles"] = m
+        clk["kernels"][k] = e
+    json.dump(clk, open(os.path.join(out, f"{a.round}_clock_per_kernel.json"), "w"), indent=1)
+    probe = os.path.join(a.src, "mfma_probe.json")
+    if os.path.exists(probe):
+        shutil.copy(probe, os.path.join(out, f"{a.round}_clock_mfma_probe.json"))
     print("kernels with counters:", len(traffic["kernels"]))
 
 
