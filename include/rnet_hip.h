@@ -338,6 +338,16 @@ size_t rn_wgrad_workspace_bytes(const rn_wgrad_problem* problem /* host */);
 int rn_wgrad_kernel_id(const rn_wgrad_problem* problem /* host */);
 int rn_conv2d_nhwc_wgrad(const rn_wgrad_problem* problem /* host */, float* dw, float beta, void* workspace,
                          size_t workspace_bytes, void* stream);
+/* n layers' weight gradients as one call: the same results as n calls of rn_conv2d_nhwc_wgrad (dws[i] for problems[i], both
+ * host arrays).  Layers of IDENTICAL geometry that wgrad_halo_kernel serves (n <= 8: the eight head-tower layers, the 3x3
+ * layers of one ResNet stage) run as ONE launch over (layer, co tile, ci tile) tiles + one reduction launch: a split-K
+ * workgroup writes its whole 288 KB accumulator as a partial tile, so a launch costs ~75 MB of partials however small
+ * the layer, and a grouped launch needs 1/n of the pixel chunks per layer.  rn_wgrad_group_fused tells which way a group
+ * goes (1: one launch); other groups are issued layer by layer.  Deterministic either way. */
+size_t rn_wgrad_group_workspace_bytes(const rn_wgrad_problem* const* problems /* host */, int n);
+int rn_wgrad_group_fused(const rn_wgrad_problem* const* problems /* host */, int n);
+int rn_conv2d_nhwc_wgrad_group(const rn_wgrad_problem* const* problems /* host */, int n, float* const* dws /* host */,
+                               float beta, void* workspace, size_t workspace_bytes, void* stream);
 
 /* dgrad: the data gradient of a stride-1 conv is rn_conv2d_nhwc_fwd run on dy with these weights
  * (bf16 [Cin_pad][R][S][Cout_pad], taps flipped, zero rows/columns in the padding) and pad' = k-1-pad; stride 2 goes through

@@ -272,8 +272,11 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wgrad_kernel(const WgArgs args)
 // -column form, which was latency bound at ~22 us per launch), then the four partial sums are added in lane order —
 // a fixed tree, so the result does not depend on the launch geometry.
 __global__ void __launch_bounds__(256)
-wgrad_reduce_kernel(const float4* __restrict__ ws, long long n4, int chunks, float4* __restrict__ dw, float beta) {
+wgrad_reduce_kernel(const float4* __restrict__ ws_all, long long n4, int chunks, const WgDwPtrs dws, float beta) {
   __shared__ float4 part[4][64];
+  // blockIdx.y = layer of a grouped launch: its partials are [group][chunk][n4], its output dws.p[group]
+  const float4* __restrict__ ws = ws_all + (long long)blockIdx.y * chunks * n4;
+  float4* __restrict__ dw = dws.p[blockIdx.y];
   const int col = threadIdx.x & 63, q = threadIdx.x >> 6;
   for (long long base = blockIdx.x * 64ll; base < n4; base += (long long)gridDim.x * 64) {
     const long long i = base + col;
@@ -373,7 +376,7 @@ extern "C" int rn_wgrad_kernel_id(const rn_wgrad_problem* p) {
   WgArgs a;
   if (wgrad_plan(p, a)) return -1;
   WhArgs h;
-  if (rn_wgrad_halo_plan(p, h)) return 2;
+  if (rn_wgrad_halo_plan(&p, 1, h)) return 2;
   return a.pad_;
 }
 
@@ -381,7 +384,7 @@ extern "C" size_t rn_wgrad_workspace_bytes(const rn_wgrad_problem* p) {
   WgArgs a;
   if (wgrad_plan(p, a)) return 0;
   WhArgs h;
-  if (rn_wgrad_halo_plan(p, h)) return rn_wgrad_halo_workspace_bytes(h);
+  if (rn_wgrad_halo_plan(&p, 1, h)) return rn_wgrad_halo_workspace_bytes(h);
   return (size_t)a.total_chunks * a.Cout * a.R * a.S * a.Cin * sizeof(float);
 }
 
@@ -397,14 +400,16 @@ extern "C" int rn_conv2d_nhwc_wgrad(const rn_wgrad_problem* p, float* dw, float 
   }
   {
     WhArgs h;
-    if (rn_wgrad_halo_plan(p, h)) {
+    if (rn_wgrad_halo_plan(&p, 1, h)) {
       h.ws = (float*)workspace;
       const int rc = rn_launch_wgrad_halo(h, p->opts, (hipStream_t)stream);
       if (rc != RN_OK) return rc;
       const long long nb4 = (long long)h.Cout * 9 * h.Cin / 4;
       int blocksh = (int)(rn_cdiv(nb4, 64) < 4096 ? rn_cdiv(nb4, 64) : 4096);
+      WgDwPtrs dws;
+      dws.p[0] = (float4*)dw;
       hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocksh), dim3(256), 0, (hipStream_t)stream, (const float4*)workspace, nb4,
-                         h.total_chunks, (float4*)dw, beta);
+                         h.total_chunks, dws, beta);
       RN_CHECK_LAUNCH();
       return RN_OK;
     }
@@ -417,8 +422,10 @@ extern "C" int rn_conv2d_nhwc_wgrad(const rn_wgrad_problem* p, float* dw, float 
     const long long nb = (long long)a.Cout * a.R * a.S * a.Cin;
     const long long nb4 = nb / 4;
     int blocksb = (int)(rn_cdiv(nb4, 64) < 4096 ? rn_cdiv(nb4, 64) : 4096);
+    WgDwPtrs dwsb;
+    dwsb.p[0] = (float4*)dw;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocksb), dim3(256), 0, st, (const float4*)workspace, nb4,
-                       a.total_chunks, (float4*)dw, beta);
+                       a.total_chunks, dwsb, beta);
     RN_CHECK_LAUNCH();
     return RN_OK;
   }
@@ -438,8 +445,70 @@ extern "C" int rn_conv2d_nhwc_wgrad(const rn_wgrad_problem* p, float* dw, float 
   const long long n = (long long)a.Cout * a.R * a.S * a.Cin;
   const long long n4 = n / 4;
   int blocks = (int)(rn_cdiv(n4, 64) < 4096 ? rn_cdiv(n4, 64) : 4096);
+  WgDwPtrs dwss;
+  dwss.p[0] = (float4*)dw;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)workspace, n4,
-                     a.total_chunks, (float4*)dw, beta);
+                     a.total_chunks, dwss, beta);
   RN_CHECK_LAUNCH();
+  return RN_OK;
+}
+
+// ---- several layers of identical geometry in one launch -----------------------------------------------------------
+// Equivalent to n calls of rn_conv2d_nhwc_wgrad.  When the layers share their geometry and wgrad_halo_kernel serves it
+// (the eight head-tower layers, the 3x3 layers of a ResNet stage), they run as ONE launch whose tiles are
+// (layer, co tile, ci tile): the split-K plan then cuts the pixels into 1/n of the chunks per layer — every workgroup
+// writes its whole accumulator (288 KB) as a partial tile, so a launch costs 75 MB of partials however small the layer —
+// and one reduction launch sums all layers.  Anything else falls back to the per-layer calls.
+extern "C" size_t rn_wgrad_group_workspace_bytes(const rn_wgrad_problem* const* ps, int n) {
+  if (!ps || n < 1) return 0;
+  size_t need = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!ps[i]) return 0;
+    const size_t b = rn_wgrad_workspace_bytes(ps[i]);
+    if (b == 0) return 0;
+    need = b > need ? b : need;
+  }
+  WhArgs h;
+  if (n > 1 && n <= RN_WGRAD_MAX_GROUP && rn_wgrad_halo_plan(ps, n, h)) {
+    const size_t g = rn_wgrad_halo_workspace_bytes(h);
+    need = g > need ? g : need;
+  }
+  return need;
+}
+
+extern "C" int rn_wgrad_group_fused(const rn_wgrad_problem* const* ps, int n) {   // 1: one grouped launch, 0: per-layer calls
+  WhArgs h;
+  return (ps && n > 1 && n <= RN_WGRAD_MAX_GROUP && rn_wgrad_halo_plan(ps, n, h)) ? 1 : 0;
+}
+
+extern "C" int rn_conv2d_nhwc_wgrad_group(const rn_wgrad_problem* const* ps, int n, float* const* dws, float beta,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
+  RN_CHECK_ARG(ps && dws && n >= 1, "rn_conv2d_nhwc_wgrad_group: bad argument");
+  for (int i = 0; i < n; ++i) RN_CHECK_ARG(ps[i] && dws[i], "rn_conv2d_nhwc_wgrad_group: null problem / output %d", i);
+  const size_t need = rn_wgrad_group_workspace_bytes(ps, n);
+  RN_CHECK_ARG(need > 0, "rn_conv2d_nhwc_wgrad_group: bad problem");
+  if (!workspace || workspace_bytes < need) {
+    rn_set_error("rn_conv2d_nhwc_wgrad_group: workspace %zu < %zu", workspace_bytes, need);
+    return RN_ENOMEM;
+  }
+  WhArgs h;
+  if (n > 1 && n <= RN_WGRAD_MAX_GROUP && rn_wgrad_halo_plan(ps, n, h)) {
+    h.ws = (float*)workspace;
+    const int rc = rn_launch_wgrad_halo(h, ps[0]->opts, (hipStream_t)stream);
+    if (rc != RN_OK) return rc;
+    const long long nb4 = (long long)h.Cout * 9 * h.Cin / 4;
+    int blocks = (int)(rn_cdiv(nb4, 64) < 4096 ? rn_cdiv(nb4, 64) : 4096);
+    if (blocks * n > 8192) blocks = 8192 / n;
+    WgDwPtrs d;
+    for (int i = 0; i < n; ++i) d.p[i] = (float4*)dws[i];
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream, (const float4*)workspace, nb4,
+                       h.total_chunks, d, beta);
+    RN_CHECK_LAUNCH();
+    return RN_OK;
+  }
+  for (int i = 0; i < n; ++i) {
+    const int rc = rn_conv2d_nhwc_wgrad(ps[i], dws[i], beta, workspace, workspace_bytes, stream);
+    if (rc != RN_OK) return rc;
+  }
   return RN_OK;
 }

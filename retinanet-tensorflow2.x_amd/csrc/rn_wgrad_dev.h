@@ -61,21 +61,29 @@ struct WgArgs {
 
 
 // rn_wgrad_halo.hip: all nine taps of a 3x3 / stride 1 / pad 1 layer in one workgroup, reduction over image rows
-struct WhSeg {
-  const uint16_t* x;
-  const uint16_t* dy;
+#define RN_WGRAD_MAX_GROUP 8
+struct WhSeg {   // geometry of a segment: shared by every layer of a grouped launch
   int N, H, W, xS, dyS;
   int ctiles;       // column strips of 16 pixels
   int L;            // steps per strip (two padded rows each), the strip's load-only step included
   int step_begin;   // first step of the segment in the launch's step sequence
   int pad_;
 };
+struct WhPtr {
+  const uint16_t* x;
+  const uint16_t* dy;
+};
 struct WhArgs {
   int nseg, Cin, Cout, co_tiles, ci_tiles, total_steps, CHs, total_chunks;
-  float* ws;
+  int ngroups, pad_;      // layers of identical geometry in this launch (rn_conv2d_nhwc_wgrad_group): tiles = groups x co x ci
+  float* ws;              // [group][chunk][co][tap][ci]
   WhSeg seg[RN_CONV_MAX_SEGMENTS];
+  WhPtr ptr[RN_WGRAD_MAX_GROUP][RN_CONV_MAX_SEGMENTS];
 };
-bool rn_wgrad_halo_plan(const rn_wgrad_problem* p, WhArgs& a);
+struct WgDwPtrs {         // output tensors of the (grouped) split-K reduction
+  float4* p[RN_WGRAD_MAX_GROUP];
+};
+bool rn_wgrad_halo_plan(const rn_wgrad_problem* const* ps, int ngroups, WhArgs& a);
 size_t rn_wgrad_halo_workspace_bytes(const WhArgs& a);
 int rn_launch_wgrad_halo(const WhArgs& a, const rn_launch_opts& opts, hipStream_t st);
 

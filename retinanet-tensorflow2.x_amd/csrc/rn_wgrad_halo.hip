@@ -31,6 +31,8 @@
 // load-only step that brings its first two dy rows); a workgroup = (co tile, ci tile, chunk of consecutive steps) and
 // writes its 128 x 9 x 64 partial tile into the same workspace layout as the per-tap kernels
 // ([chunk][co][tap][ci]), summed in index order by wgrad_reduce_kernel: deterministic, no float atomics.
+#include <string.h>
+
 #include <algorithm>
 
 #include "rn_wgrad_dev.h"
@@ -57,7 +59,8 @@ __global__ void __launch_bounds__(512) wgrad_halo_kernel(const WhArgs args) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave & 3, wn = wave >> 2;       // 4 (co) x 2 (ci) waves; wn is also the ping-pong group
-  const int tiles = args.co_tiles * args.ci_tiles;
+  const int tiles_g = args.co_tiles * args.ci_tiles;     // tiles of one layer
+  const int tiles = tiles_g * args.ngroups;
   const int items = tiles * args.total_chunks;
   const int Cin = args.Cin, Cout = args.Cout;
   const unsigned lds0 = rn_lds_addr(smem);
@@ -95,7 +98,8 @@ __global__ void __launch_bounds__(512) wgrad_halo_kernel(const WhArgs args) {
     }
     const int chunk = logical / tiles;
     const int tile = logical - chunk * tiles;
-    const int co_t = tile / args.ci_tiles, ci_t = tile - co_t * args.ci_tiles;
+    const int grp = tile / tiles_g, tile_g = tile - grp * tiles_g;
+    const int co_t = tile_g / args.ci_tiles, ci_t = tile_g - co_t * args.ci_tiles;
     const int co0 = co_t * 128, ci0 = ci_t * 64;
     const int step_a = chunk * args.CHs;
     const int step_b = step_a + args.CHs < args.total_steps ? step_a + args.CHs : args.total_steps;
@@ -144,9 +148,10 @@ __global__ void __launch_bounds__(512) wgrad_halo_kernel(const WhArgs args) {
     const WhSeg& sg__ = args.seg[i_si];                                                                    \
     i_N = sg__.N; i_H1 = sg__.H + 1; i_L = sg__.L; i_ctiles = sg__.ctiles;                                 \
     i_xrow = (unsigned)(sg__.W * sg__.xS * 2); i_dyrow = (unsigned)(sg__.W * sg__.dyS * 2);               \
-    rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)sg__.dy, 0,                                           \
+    const WhPtr& pt__ = args.ptr[grp][i_si];                                                               \
+    rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)pt__.dy, 0,                                           \
                                               (int)((long long)sg__.N * sg__.H * sg__.W * sg__.dyS * 2), 0x00020000); \
-    rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)sg__.x, 0,                                             \
+    rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)pt__.x, 0,                                             \
                                              (int)((long long)sg__.N * sg__.H * sg__.W * sg__.xS * 2), 0x00020000);  \
     const int x0__ = i_ct * 16;                                                                            \
     const int cdy__ = co0 + dy_slot * 8, cx__ = ci0 + x_slot * 8;                                          \
@@ -328,7 +333,7 @@ __global__ void __launch_bounds__(512) wgrad_halo_kernel(const WhArgs args) {
     // of the epilogue is live across the loop
     const int elane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const int row_stride = 9 * Cin;                      // floats between consecutive co rows
-    float* out = args.ws + (long long)chunk * Cout * row_stride;
+    float* out = args.ws + ((long long)grp * args.total_chunks + chunk) * Cout * row_stride;
     const int ci = ci0 + wn * 32 + (elane & 31);
     const int cob = co0 + wm * 32 + 4 * (elane >> 5);
 #pragma unroll
@@ -351,18 +356,25 @@ __global__ void __launch_bounds__(512) wgrad_halo_kernel(const WhArgs args) {
 // Layers this kernel serves: 3x3 / stride 1 / pad 1, same-size output, Cin a multiple of 64, Cout a multiple of 8 and
 // at least 64.  Auto-selected when the launch holds at least 16 384 output pixels (rn_launch_opts.wgrad_kernel = 2:
 // whatever the pixel count; = 3: keep the per-tap wgrad_big_kernel for A/B timing).
-bool rn_wgrad_halo_plan(const rn_wgrad_problem* p, WhArgs& a) {
+// ps[0..ngroups): layers of IDENTICAL geometry (rn_conv2d_nhwc_wgrad_group) — one launch, tiles = groups x co x ci, so
+// the split-K plan needs 1/ngroups of the pixel chunks per layer and writes 1/ngroups of the partial-tile bytes:
+// every workgroup of a launch writes its 288 KB accumulator once, 75 MB per launch however small the layer (measured:
+// eight head-tower layers as one launch 2.12 ms against 8 x 0.346 ms, tools/bench_wgrad.py presets tower8 / tower).
+bool rn_wgrad_halo_plan(const rn_wgrad_problem* const* ps, int ngroups, WhArgs& a) {
+  if (ngroups < 1 || ngroups > RN_WGRAD_MAX_GROUP) return false;
+  const rn_wgrad_problem* p = ps[0];
   if (p->R != 3 || p->S != 3 || p->stride_h != 1 || p->stride_w != 1 || p->pad_top != 1 || p->pad_left != 1) return false;
   if (p->opts.wgrad_kernel == 1 || p->opts.wgrad_kernel == 3) return false;
   const int Cin = p->seg[0].Cin, Cout = p->seg[0].Cout;
   if (Cin % 64 != 0 || Cout % 8 != 0 || Cout < 64) return false;
   long long Ptot = 0, steps = 0;
   a.nseg = p->num_segments;
+  a.ngroups = ngroups;
+  a.pad_ = 0;
   for (int i = 0; i < p->num_segments; ++i) {
     const rn_wgrad_segment& s = p->seg[i];
-    if (s.Ho != s.H || s.Wo != s.W) return false;
+    if (s.Ho != s.H || s.Wo != s.W || !s.x || !s.dy) return false;
     WhSeg& d = a.seg[i];
-    d.x = (const uint16_t*)s.x; d.dy = (const uint16_t*)s.dy;
     d.N = s.N; d.H = s.H; d.W = s.W;
     d.dyS = s.dy_pix_stride > 0 ? s.dy_pix_stride : s.Cout;
     d.xS = s.x_pix_stride > 0 ? s.x_pix_stride : s.Cin;
@@ -370,9 +382,22 @@ bool rn_wgrad_halo_plan(const rn_wgrad_problem* p, WhArgs& a) {
     // padded rows G = 1 .. N*(H+1) - 1 carry products; step t >= 1 of a strip covers G = 2t - 1, 2t; step 0 is load-only
     d.L = (int)rn_cdiv((long long)s.N * (s.H + 1) - 1, 2) + 1;
     d.step_begin = (int)steps;
+    d.pad_ = 0;
     steps += (long long)d.ctiles * d.L;
     Ptot += (long long)s.N * s.H * s.W;
     if ((long long)s.N * s.H * s.W * (d.xS > d.dyS ? d.xS : d.dyS) * 2 >= (1ll << 31) - (1ll << 24)) return false;
+    for (int g = 0; g < ngroups; ++g) {      // the other layers: the same geometry, their own tensors
+      const rn_wgrad_problem* q = ps[g];
+      const rn_wgrad_segment& t = q->seg[i];
+      if (q->R != p->R || q->S != p->S || q->stride_h != p->stride_h || q->stride_w != p->stride_w ||
+          q->pad_top != p->pad_top || q->pad_left != p->pad_left || q->num_segments != p->num_segments ||
+          memcmp(&q->opts, &p->opts, sizeof(p->opts)) != 0 || t.N != s.N || t.H != s.H || t.W != s.W || t.Cin != s.Cin ||
+          t.Ho != s.Ho || t.Wo != s.Wo || t.Cout != s.Cout || t.dy_pix_stride != s.dy_pix_stride ||
+          t.x_pix_stride != s.x_pix_stride || !t.x || !t.dy)
+        return false;
+      a.ptr[g][i].x = (const uint16_t*)t.x;
+      a.ptr[g][i].dy = (const uint16_t*)t.dy;
+    }
   }
   if (Ptot < 16384 && p->opts.wgrad_kernel != 2) return false;
   if (steps >= (1ll << 30)) return false;
@@ -380,7 +405,7 @@ bool rn_wgrad_halo_plan(const rn_wgrad_problem* p, WhArgs& a) {
   a.co_tiles = (int)rn_cdiv(Cout, 128);
   a.ci_tiles = Cin / 64;
   a.total_steps = (int)steps;
-  const int tiles = a.co_tiles * a.ci_tiles;
+  const int tiles = a.co_tiles * a.ci_tiles * ngroups;
   // one round of the CUs the kernel may use: fewest split-K partials; a chunk is at least 24 steps long (2 when the
   // caller sets the workgroup target: tests of the chunk seams)
   long long blocks = p->opts.wgrad_target_blocks > 0 ? p->opts.wgrad_target_blocks : 256 - p->opts.reserved_cus;
@@ -394,7 +419,7 @@ bool rn_wgrad_halo_plan(const rn_wgrad_problem* p, WhArgs& a) {
 }
 
 size_t rn_wgrad_halo_workspace_bytes(const WhArgs& a) {
-  return (size_t)a.total_chunks * a.Cout * 9 * a.Cin * sizeof(float);
+  return (size_t)a.ngroups * a.total_chunks * a.Cout * 9 * a.Cin * sizeof(float);
 }
 
 template <int VAR, int STAGES = WH_STAGES_DEFAULT>
@@ -411,7 +436,7 @@ static int wh_launch(const WhArgs& a, dim3 grid, hipStream_t st) {
 }
 
 int rn_launch_wgrad_halo(const WhArgs& a, const rn_launch_opts& opts, hipStream_t st) {
-  const int items = a.co_tiles * a.ci_tiles * a.total_chunks;
+  const int items = a.ngroups * a.co_tiles * a.ci_tiles * a.total_chunks;
   rn_launch_opts o = opts;
   o.max_workgroups = 0;   // the cap is for the persistent convolution grids
   dim3 grid((unsigned)(opts.reserved_cus > 0 ? rn_persistent_grid(items, rn_num_cus(), o) : items));

@@ -175,6 +175,10 @@ _SIGNATURES = {
     "rn_wgrad_workspace_bytes": (c_size_t, [POINTER(WgradProblem)]),
     "rn_wgrad_kernel_id": (c_int, [POINTER(WgradProblem)]),
     "rn_conv2d_nhwc_wgrad": (c_int, [POINTER(WgradProblem), c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
+    "rn_wgrad_group_workspace_bytes": (c_size_t, [POINTER(POINTER(WgradProblem)), c_int]),
+    "rn_wgrad_group_fused": (c_int, [POINTER(POINTER(WgradProblem)), c_int]),
+    "rn_conv2d_nhwc_wgrad_group": (c_int, [POINTER(POINTER(WgradProblem)), c_int, _PP, c_float, c_void_p, c_size_t,
+                                           c_void_p]),
     "rn_pack_conv_weight_dgrad": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rn_pack_conv_weight_dgrad_batch": (c_int, [POINTER(DgradPack), c_int, c_void_p]),
     "rn_cast_pad_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),

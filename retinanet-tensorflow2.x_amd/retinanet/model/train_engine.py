@@ -127,6 +127,7 @@ class TrainEngine:
             self._fold_frozen()
             self._build_forward()
             self._build_backward()
+            self._group_wgrad_steps()
             for name, cp in self.conv_launches:   # a launch writes stage-1 BatchNorm partials for all its segments or none
                 marks = {bool(cp.seg[i].bn_bwd_y) for i in range(cp.num_segments)}
                 if name.startswith("dgrad:") and len(marks) != 1:
@@ -1042,6 +1043,66 @@ class TrainEngine:
                      ins[0].shape[1], ins[0].shape[2], ins[0].shape[3])
                 self.bwd_steps.append(lambda st, a=a: _C.check(lib.rn_balance_features_bwd(*a, st), "balance_bwd"))
 
+    def _group_wgrad_steps(self):
+        """Weight-gradient launches of layers with IDENTICAL geometry become one rn_conv2d_nhwc_wgrad_group call (the
+        eight head-tower layers, the 3x3 layers of a ResNet stage: up to 8 per call), issued where the LAST of them
+        stood in the backward order — nothing but the optimizer reads a weight gradient, and dy / the saved activation
+        of the earlier layers are static buffers nobody writes again.  One launch over (layer, co tile, ci tile) tiles
+        needs 1/n of the split-K pixel chunks per layer: every workgroup writes its whole 288 KB accumulator as a partial
+        tile, ~75 MB per launch however small the layer.  RNET_WGRAD_GROUP=0 keeps one launch per layer."""
+        lib = self.lib
+        self.wgrad_groups = []
+        if os.environ.get("RNET_WGRAD_GROUP", "1") == "0":
+            return
+        by_sig = {}
+        for i, fn in enumerate(self.bwd_steps):
+            item = getattr(fn, "wgrad_item", None)
+            if item is None:
+                continue
+            p = item[0]
+            sig = (p.R, p.S, p.stride_h, p.stride_w, p.pad_top, p.pad_left, p.num_segments, bytes(p.opts),
+                   tuple((s.N, s.H, s.W, s.Cin, s.Ho, s.Wo, s.Cout, s.dy_pix_stride, s.x_pix_stride)
+                         for s in (p.seg[k] for k in range(p.num_segments))))
+            by_sig.setdefault(sig, []).append(i)
+        drop, replace = set(), {}
+        for sig, idxs in by_sig.items():
+            for lo in range(0, len(idxs), 8):
+                grp = idxs[lo:lo + 8]
+                if len(grp) < 2:
+                    continue
+                items = [self.bwd_steps[i].wgrad_item for i in grp]
+                arr = (ctypes.POINTER(_C.WgradProblem) * len(grp))(*[ctypes.pointer(it[0]) for it in items])
+                if lib.rn_wgrad_group_fused(arr, len(grp)) != 1:
+                    continue
+                nws = lib.rn_wgrad_group_workspace_bytes(arr, len(grp))
+                if os.environ.get("RNET_AB_WORKSPACES") == "1":   # tools/ab_step.py switches kernel families between rounds
+                    nws = max([nws] + [int(it[2].numel()) for it in items])
+                ws = torch.empty((max(nws, 256),), dtype=torch.uint8, device=self.dev)
+                dws = _C.ptr_array([it[1] for it in items])
+                flw = sum(it[3] for it in items)
+                writes = [w for i in grp for w in self.bwd_steps[i].writes]
+                a = (arr, len(grp), dws, 0.0, ws.data_ptr(), ws.numel())
+                wname = f"wgrad_halo_kernel ({len(grp)} layers per launch) + wgrad_reduce_kernel"
+
+                def wgrad_group(st, a=a, flw=flw, wname=wname):
+                    prof = self.wgrad_profile
+                    if prof is None:
+                        _C.check(lib.rn_conv2d_nhwc_wgrad_group(*a, st), "rn_conv2d_nhwc_wgrad_group")
+                        return
+                    cur = torch.cuda.current_stream(self.dev)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(cur)
+                    _C.check(lib.rn_conv2d_nhwc_wgrad_group(*a, st), "rn_conv2d_nhwc_wgrad_group")
+                    e1.record(cur)
+                    prof.append((e0, e1, flw, wname))
+                self._keep += [arr, dws, ws]
+                old_ws = {id(it[2]) for it in items}
+                self._keep = [k for k in self._keep if id(k) not in old_ws]      # the per-layer workspaces are not needed
+                replace[grp[-1]] = self._side(wgrad_group, writes=writes)
+                drop.update(grp[:-1])
+                self.wgrad_groups.append([it[0] for it in items])
+        self.bwd_steps = [replace.get(i, fn) for i, fn in enumerate(self.bwd_steps) if i not in drop]
+
     def _plan_conv_backward(self, ops, mark):
         lib, B = self.lib, self.B
         if not self._conv_trainable(ops[0]) and not any(self.requires.get(o["inp"]) for o in ops):
@@ -1134,7 +1195,9 @@ class TrainEngine:
                 _C.check(lib.rn_conv2d_nhwc_wgrad(*a, st), "rn_conv2d_nhwc_wgrad")
                 e1.record(cur)
                 prof.append((e0, e1, flw, wname))
-            self.bwd_steps.append(self._side(wgrad, writes=[c.get("kvar", cname + "/kernel")]))
+            step = self._side(wgrad, writes=[c.get("kvar", cname + "/kernel")])
+            step.wgrad_item = (p, dw, ws, flw)      # _group_wgrad_steps may merge it with same-shape layers
+            self.bwd_steps.append(step)
             if c["bias"]:
                 # bias gradient = column sums of dy over every segment (two-stage reduction kernel)
                 pb2 = _C.BnProblem()

@@ -124,6 +124,70 @@ def test_wgrad(cuda, build, shape_id, kernel_opt, target_blocks, want_kernel):
     torch.testing.assert_close(dw.cpu().double(), 2 * want, rtol=1e-3, atol=2e-3 * scale)
 
 
+@pytest.mark.parametrize("build,k,n,target_blocks,fused", [("bf16", 3, 4, 0, 1), ("bf16", 3, 8, 0, 1), ("bf16", 3, 3, 64, 1),
+                                                          ("f16", 3, 4, 0, 1), ("bf16", 1, 3, 0, 0)])
+def test_wgrad_group(cuda, build, k, n, target_blocks, fused):
+    """rn_conv2d_nhwc_wgrad_group: n layers of identical geometry (here: shared head convs over a small pyramid) as ONE
+    wgrad_halo_kernel launch over (layer, co tile, ci tile) tiles + one reduction launch — each layer against the float64
+    reference; a group the halo kernel does not serve (1x1) is issued layer by layer and must equal the single calls
+    bit for bit."""
+    from retinanet import _C
+    lib = _lib()
+    g = torch.Generator().manual_seed(31 + n + k)
+    pad = (k - 1) // 2
+    shapes = [(2, 24, 20), (2, 12, 10), (3, 5, 7)]      # N, H, W per segment
+    cin, cout = 128, 192
+    probs, keep, wants, dws = [], [], [], []
+    for layer in range(n):
+        p = _C.WgradProblem()
+        p.R = p.S = k
+        p.stride_h = p.stride_w = 1
+        p.pad_top = p.pad_left = pad
+        p.num_segments = len(shapes)
+        p.opts = _C.LaunchOpts(wgrad_kernel=2, wgrad_target_blocks=target_blocks)
+        want = torch.zeros((cout, k, k, cin), dtype=torch.float64)
+        for i, (N, H, W) in enumerate(shapes):
+            x = _bf(torch.randn((N, H, W, cin), generator=g))
+            dy = _bf(torch.randn((N, H, W, cout), generator=g))
+            xd, dyd = x.to(cuda), dy.to(cuda)
+            sg = p.seg[i]
+            sg.x, sg.dy = xd.data_ptr(), dyd.data_ptr()
+            sg.N, sg.H, sg.W, sg.Cin, sg.Ho, sg.Wo, sg.Cout = N, H, W, cin, H, W, cout
+            keep += [xd, dyd]
+            w = torch.zeros((cout, cin, k, k), dtype=torch.float64, requires_grad=True)
+            F.conv2d(x.double().permute(0, 3, 1, 2), w, padding=pad).backward(dy.double().permute(0, 3, 1, 2))
+            want += w.grad.permute(0, 2, 3, 1)
+        probs.append(p)
+        wants.append(want)
+        dws.append(torch.full((cout, k, k, cin), 7.0, dtype=torch.float32, device=cuda))
+    arr = (ctypes.POINTER(_C.WgradProblem) * n)(*[ctypes.pointer(p) for p in probs])
+    assert lib.rn_wgrad_group_fused(arr, n) == fused
+    ws = _ws(lib.rn_wgrad_group_workspace_bytes(arr, n), cuda)
+    ws.fill_(0x7f)
+    _C.check(lib.rn_conv2d_nhwc_wgrad_group(arr, n, _C.ptr_array(dws), 0.0, _C.ptr(ws), ws.numel(), _C.current_stream()))
+    torch.cuda.synchronize()
+    for layer in range(n):
+        scale = wants[layer].abs().max().item()
+        torch.testing.assert_close(dws[layer].cpu().double(), wants[layer], rtol=1e-3, atol=1e-3 * scale)
+    first = [d.clone() for d in dws]
+    _C.check(lib.rn_conv2d_nhwc_wgrad_group(arr, n, _C.ptr_array(dws), 0.0, _C.ptr(ws), ws.numel(), _C.current_stream()))
+    torch.cuda.synchronize()
+    for a, b in zip(first, dws):
+        assert torch.equal(a, b)              # deterministic: ordered split-K reduction
+    if not fused:
+        for layer in range(n):
+            one = torch.zeros_like(dws[layer])
+            w1 = _ws(lib.rn_wgrad_workspace_bytes(ctypes.byref(probs[layer])), cuda)
+            _C.check(lib.rn_conv2d_nhwc_wgrad(ctypes.byref(probs[layer]), _C.ptr(one), 0.0, _C.ptr(w1), w1.numel(),
+                                              _C.current_stream()))
+            torch.cuda.synchronize()
+            assert torch.equal(one, dws[layer])
+    # a layer whose geometry differs breaks the group: per-layer calls, still the right sums
+    if fused and n >= 3:
+        probs[1].seg[0].N = 1
+        assert lib.rn_wgrad_group_fused(arr, n) == 0
+
+
 def test_kernels_with_compute_units_reserved_for_rccl(cuda):
     """rn_launch_opts.reserved_cus (data-parallel runs): the persistent kernels run on fewer workgroups than CUs, the
     256-wide weight-gradient kernels walk several work items per workgroup.  The 256-row convs must give bit-identical
