@@ -11,7 +11,13 @@ the ranks agree (a MIN over torch.distributed) that librccl loads everywhere bef
 agreed on before any rank uses or abandons the communicator, and the communicator is VALIDATED against
 torch.distributed on a known vector before the engine gets it.  A failure on one rank therefore sends every rank down
 the torch.distributed path — never one rank into `except` while the others wait in a collective.
-RNET_COMM=torch switches the native path off."""
+
+Default since round 3: OFF (RNET_COMM=native turns it on).  Measured on one MI355X with a single-rank communicator
+(tools/probes/allreduce_small_cost.py, all a one-GPU box can run): 130 back-to-back 2 KB messages cost 4 - 6 us each on the
+stream, but the SyncBatchNorm pattern — a kernel, then a message, 130 times — took 10.6 - 46 ms through rn_allreduce_small
+on the compute stream (75 - 350 us per message: the host blocks inside ncclAllReduce while the stream it is handed is
+busy) against 1.8 ms through torch.distributed (c10d hands RCCL its own, idle stream and orders it with two events:
+7.8 us per message).  Until a multi-GPU node shows otherwise the measured path is the default."""
 from __future__ import annotations
 
 import ctypes
@@ -100,8 +106,8 @@ def maybe_enable_native(engine):
     """Give `engine` (TrainEngine) a validated native communicator for its small messages; returns it or None.
     Collective over engine.pg: every rank returns a communicator or every rank returns None."""
     import torch.distributed as dist
-    mode = os.environ.get("RNET_COMM", "auto")
-    if engine.world <= 1 or mode == "torch" or not dist.is_initialized():
+    mode = os.environ.get("RNET_COMM", "torch")
+    if engine.world <= 1 or mode != "native" or not dist.is_initialized():
         return None
     if dist.get_backend(engine.pg) != "nccl":     # gloo (CPU / one-device functional runs): nothing to take over
         return None

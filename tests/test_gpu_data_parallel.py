@@ -170,6 +170,7 @@ def _worker_native_comm(rank, world, port, out):
     from retinanet.comm import NativeComm
     dev = torch.device("cuda:0")
     comm = NativeComm(rank, world, dev)
+    assert comm.ok, comm.error
     x = torch.arange(5000, dtype=torch.float32, device=dev) * 0.25
     want = x.clone()
     with torch.cuda.device(dev):
