@@ -221,12 +221,14 @@ def run_train(args, dev, rank, world):
     exclusive = None
     if getattr(eng, "side_stream_on", False) and dom_name in by_kernel and not args.no_exclusive:
         eng.side_stream_on = False
+        eng.set_wgrad_cap(False)     # the two-stream step caps the weight-gradient grids to leave CUs to the main stream
         prof1, wprof1 = [], []
         eng.conv_profile, eng.wgrad_profile = prof1, wprof1
         step()
         eng.conv_profile = eng.wgrad_profile = None
         torch.cuda.synchronize()
         eng.side_stream_on = True
+        eng.set_wgrad_cap(True)
         w1 = wgrad_entry(wprof1, 1)
         if wgrad_roof and w1:
             wgrad_roof["exclusive"] = {k: w1[k] for k in ("achieved", "frac", "ms_per_step", "kernels")}

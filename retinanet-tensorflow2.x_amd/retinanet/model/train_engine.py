@@ -96,6 +96,13 @@ class TrainEngine:
         self.hbm_profile = None   # bench.py: list that collects (event0, event1, kernel name, algorithmic bytes)
         self.conv_launches = []   # (name, rn_conv_problem) of every implicit-GEMM launch: lib.rn_conv_kernel_id(byref(p))
         self.wgrad_launches = []  # (name, rn_wgrad_problem) of every weight-gradient launch
+        cus = os.environ.get("RNET_WGRAD_CUS", "176,256")
+        self._wgrad_cap = tuple(int(v) for v in cus.split(",")) if cus not in ("0", "") else None
+        if os.environ.get("RNET_WGRAD_STREAM", "1") == "0":
+            self._wgrad_cap = None      # one-stream backward: nothing to leave CUs to
+        if self._wgrad_cap and len(self._wgrad_cap) == 1:
+            self._wgrad_cap = (self._wgrad_cap[0], 2 * self._wgrad_cap[0])
+        self._wgrad_capped = []   # (problem, capped target): set_wgrad_cap(False) lifts the cap (bench.py's exclusive step)
         self.step_count = 0
         self.conv_profile = None
         self.wgrad_profile = None   # bench.py: list that collects (event0, event1, algorithmic FLOPs, kernel) per wgrad launch
@@ -1043,6 +1050,12 @@ class TrainEngine:
                      ins[0].shape[1], ins[0].shape[2], ins[0].shape[3])
                 self.bwd_steps.append(lambda st, a=a: _C.check(lib.rn_balance_features_bwd(*a, st), "balance_bwd"))
 
+    def set_wgrad_cap(self, on):
+        """The CU cap of the weight-gradient launches (see _plan_conv_backward) on / off: with the chip to themselves
+        (bench.py's one-stream `exclusive` step) they run uncapped; the workspaces fit either split-K plan."""
+        for p, cap in self._wgrad_capped:
+            p.opts.wgrad_target_blocks = cap if on else 0
+
     def _group_wgrad_steps(self):
         """Weight-gradient launches of layers with IDENTICAL geometry become one rn_conv2d_nhwc_wgrad_group call (the
         eight head-tower layers, the 3x3 layers of a ResNet stage: up to 8 per call), issued where the LAST of them
@@ -1075,6 +1088,13 @@ class TrainEngine:
                 if lib.rn_wgrad_group_fused(arr, len(grp)) != 1:
                     continue
                 nws = lib.rn_wgrad_group_workspace_bytes(arr, len(grp))
+                caps = [int(it[0].opts.wgrad_target_blocks) for it in items]
+                if any(caps):          # the uncapped plan (set_wgrad_cap(False)) must fit too
+                    for it in items:
+                        it[0].opts.wgrad_target_blocks = 0
+                    nws = max(nws, lib.rn_wgrad_group_workspace_bytes(arr, len(grp)))
+                    for it, c in zip(items, caps):
+                        it[0].opts.wgrad_target_blocks = c
                 if os.environ.get("RNET_AB_WORKSPACES") == "1":   # tools/ab_step.py switches kernel families between rounds
                     nws = max([nws] + [int(it[2].numel()) for it in items])
                 ws = torch.empty((max(nws, 256),), dtype=torch.uint8, device=self.dev)
@@ -1168,6 +1188,16 @@ class TrainEngine:
                 s.N, s.H, s.W, s.Cin, s.Ho, s.Wo, s.Cout = B, x.shape[1], x.shape[2], c["cin"], dy.shape[1], dy.shape[2], c["cout"]
                 s.dy_pix_stride = dy.shape[3]
             nws = lib.rn_wgrad_workspace_bytes(ctypes.byref(p))
+            # Two-stream backward: a weight-gradient launch is capped to ~2/3 of the CUs (rn_launch_opts.wgrad_target_blocks).
+            # Its persistent workgroups own a CU for hundreds of microseconds; when they cover the whole chip every
+            # main-stream launch — the critical path — queues behind them.  Measured in one process (tools/ab_step.py):
+            # 31.40 -> 30.48 ms and 32.45 -> 31.34 ms per step on two boxes with 176 workgroups for the 256-wide kernels
+            # and 256 (two per CU) for the 128-tile kernel; 128 / 192 is already slower again.  RNET_WGRAD_CUS=0: no cap.
+            if self._wgrad_cap and not p.opts.wgrad_target_blocks:
+                kid = lib.rn_wgrad_kernel_id(ctypes.byref(p))
+                p.opts.wgrad_target_blocks = self._wgrad_cap[0] if kid in (1, 2) else self._wgrad_cap[1]
+                nws = max(nws, lib.rn_wgrad_workspace_bytes(ctypes.byref(p)))   # either plan fits: set_wgrad_cap() may lift it
+                self._wgrad_capped.append((p, int(p.opts.wgrad_target_blocks)))
             if os.environ.get("RNET_AB_WORKSPACES") == "1":   # tools/ab_step.py switches kernel families between timed rounds
                 for alt in (1, 3):
                     q = _C.WgradProblem.from_buffer_copy(p)

@@ -6,7 +6,7 @@ between rounds; variants are timed in interleaved rounds and the median ms / ste
     RNET_AB_WORKSPACES=1 python tools/ab_step.py --variants "auto;wgrad_kernel=3;wgrad_kernel=1" [--rounds 5] [--steps 6]
 
 `field=value` pairs separated by commas apply to the weight-gradient problems; prefix `conv.` for the forward / dgrad
-problems (e.g. conv.conv_no_halo=1).  With RNET_HIP_LIB pointing at the probe build, `ablate=<code>` selects the code
+problems (e.g. conv.conv_no_halo=1), `halo.` / `big.` / `small.` for the weight-gradient problems on that kernel only.  With RNET_HIP_LIB pointing at the probe build, `ablate=<code>` selects the code
 variants compiled side by side there."""
 import argparse
 import os
@@ -55,10 +55,20 @@ def main():
             p.opts = o
         if spec == "auto":
             return
+        import ctypes
         for kv in spec.split(","):
             k, v = kv.split("=")
             targets = base_c if k.startswith("conv.") else base_w
-            for p, _ in targets:
+            only = None
+            for pre, kid in (("small.", 0), ("big.", 1), ("halo.", 2)):   # only the weight-gradient problems on that kernel
+                if k.startswith(pre):
+                    k, only = k[len(pre):], kid
+            for p, o in targets:
+                if only is not None:
+                    q = type(p).from_buffer_copy(p)
+                    q.opts = o
+                    if eng.lib.rn_wgrad_kernel_id(ctypes.byref(q)) != only:
+                        continue
                 setattr(p.opts, k.replace("conv.", ""), int(v))
 
     def step():
