@@ -17,6 +17,11 @@ PRESETS = {
     "tower_1x1": ([(s, 256, 256) for s in (80, 40, 20, 10, 5)] * 2, 1, 1, False, False),
     "tower_c64": ([(s, 64, 256) for s in (80, 40, 20, 10, 5)] * 2, 1, 1, False, False),
     "pred_class": ([(s, 256, 720) for s in (80, 40, 20, 10, 5)], 3, 1, True, False),
+    "pred_class_bf16": ([(s, 256, 720) for s in (80, 40, 20, 10, 5)], 3, 1, False, False),
+    "pred_768": ([(s, 256, 768) for s in (80, 40, 20, 10, 5)], 3, 1, True, False),
+    "pred_768_bf16": ([(s, 256, 768) for s in (80, 40, 20, 10, 5)], 3, 1, False, False),
+    "pred_box": ([(s, 256, 36) for s in (80, 40, 20, 10, 5)], 3, 1, True, False),
+    "tower1": ([(s, 256, 256) for s in (80, 40, 20, 10, 5)], 3, 1, False, False),
     "g1_3x3": ([(160, 64, 64)], 3, 1, False, False),
     "g1_out": ([(160, 64, 256)], 1, 1, False, True),
     "g1_a": ([(160, 256, 64)], 1, 1, False, False),
