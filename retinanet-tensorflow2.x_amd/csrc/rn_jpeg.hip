@@ -108,8 +108,23 @@ const uint8_t kZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18,
                              41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
                              30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
-// jidctint.c (JDCT_ISLOW): CONST_BITS 13, PASS1_BITS 2
-inline int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+// jidctint.c (JDCT_ISLOW): CONST_BITS 13, PASS1_BITS 2.  The arithmetic runs on a wrapping 32-bit integer: on a valid
+// file no intermediate leaves the int range and the results are libjpeg's bit for bit; on hostile coefficients (a 16-bit
+// DQT entry times a 16-bit coefficient) the sums wrap instead of being signed-overflow / negative-left-shift undefined
+// behaviour (found by the sanitizer fuzz run, tests/test_jpeg_cpu.py).
+struct wi {
+  uint32_t v;
+  wi() : v(0) {}
+  wi(int x) : v((uint32_t)x) {}
+  int s() const { return (int)v; }
+};
+inline wi operator+(wi a, wi b) { wi r; r.v = a.v + b.v; return r; }
+inline wi operator-(wi a, wi b) { wi r; r.v = a.v - b.v; return r; }
+inline wi operator*(wi a, int k) { wi r; r.v = a.v * (uint32_t)k; return r; }
+inline wi operator<<(wi a, int n) { wi r; r.v = a.v << n; return r; }
+inline wi& operator+=(wi& a, wi b) { a.v += b.v; return a; }
+inline wi& operator*=(wi& a, int k) { a.v *= (uint32_t)k; return a; }
+inline int descale(wi x, int n) { return (int)(x.v + (1u << (n - 1))) >> n; }
 inline uint8_t clamp255(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
 
 void idct_islow(const int* in /* dequantized, natural order */, uint8_t* out, int stride) {
@@ -118,16 +133,16 @@ void idct_islow(const int* in /* dequantized, natural order */, uint8_t* out, in
   int ws[64];
   for (int c = 0; c < 8; ++c) {   // pass 1: columns
     const int* p = in + c;
-    int z2 = p[16], z3 = p[48];
-    int z1 = (z2 + z3) * F0541;
-    int tmp2 = z1 + z3 * (-F1847), tmp3 = z1 + z2 * F0765;
+    wi z2 = p[16], z3 = p[48];
+    wi z1 = (z2 + z3) * F0541;
+    wi tmp2 = z1 + z3 * (-F1847), tmp3 = z1 + z2 * F0765;
     z2 = p[0]; z3 = p[32];
-    int tmp0 = (z2 + z3) << 13, tmp1 = (z2 - z3) << 13;
-    const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    wi tmp0 = (z2 + z3) << 13, tmp1 = (z2 - z3) << 13;
+    const wi tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
     tmp0 = p[56]; tmp1 = p[40]; tmp2 = p[24]; tmp3 = p[8];
     z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
-    int z4 = tmp1 + tmp3;
-    const int z5 = (z3 + z4) * F1175;
+    wi z4 = tmp1 + tmp3;
+    const wi z5 = (z3 + z4) * F1175;
     tmp0 *= F0298; tmp1 *= F2053; tmp2 *= F3072; tmp3 *= F1501;
     z1 *= -F0899; z2 *= -F2562; z3 *= -F1961; z4 *= -F0390;
     z3 += z5; z4 += z5;
@@ -140,24 +155,26 @@ void idct_islow(const int* in /* dequantized, natural order */, uint8_t* out, in
   }
   for (int r = 0; r < 8; ++r) {   // pass 2: rows
     const int* p = ws + r * 8;
-    int z2 = p[2], z3 = p[6];
-    int z1 = (z2 + z3) * F0541;
-    int tmp2 = z1 + z3 * (-F1847), tmp3 = z1 + z2 * F0765;
-    int tmp0 = (p[0] + p[4]) << 13, tmp1 = (p[0] - p[4]) << 13;
-    const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    wi z2 = p[2], z3 = p[6];
+    wi z1 = (z2 + z3) * F0541;
+    wi tmp2 = z1 + z3 * (-F1847), tmp3 = z1 + z2 * F0765;
+    wi tmp0 = (wi(p[0]) + wi(p[4])) << 13, tmp1 = (wi(p[0]) - wi(p[4])) << 13;
+    const wi tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
     tmp0 = p[7]; tmp1 = p[5]; tmp2 = p[3]; tmp3 = p[1];
     z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
-    int z4 = tmp1 + tmp3;
-    const int z5 = (z3 + z4) * F1175;
+    wi z4 = tmp1 + tmp3;
+    const wi z5 = (z3 + z4) * F1175;
     tmp0 *= F0298; tmp1 *= F2053; tmp2 *= F3072; tmp3 *= F1501;
     z1 *= -F0899; z2 *= -F2562; z3 *= -F1961; z4 *= -F0390;
     z3 += z5; z4 += z5;
     tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
     uint8_t* o = out + r * stride;
-    o[0] = clamp255(descale(tmp10 + tmp3, 18) + 128); o[7] = clamp255(descale(tmp10 - tmp3, 18) + 128);
-    o[1] = clamp255(descale(tmp11 + tmp2, 18) + 128); o[6] = clamp255(descale(tmp11 - tmp2, 18) + 128);
-    o[2] = clamp255(descale(tmp12 + tmp1, 18) + 128); o[5] = clamp255(descale(tmp12 - tmp1, 18) + 128);
-    o[3] = clamp255(descale(tmp13 + tmp0, 18) + 128); o[4] = clamp255(descale(tmp13 - tmp0, 18) + 128);
+    // (the level shift is added to a value that may sit at the edge of the int range on hostile data: saturate first)
+    auto px = [](wi x) { const int d = descale(x, 18); return clamp255((d > 1024 ? 1024 : (d < -1024 ? -1024 : d)) + 128); };
+    o[0] = px(tmp10 + tmp3); o[7] = px(tmp10 - tmp3);
+    o[1] = px(tmp11 + tmp2); o[6] = px(tmp11 - tmp2);
+    o[2] = px(tmp12 + tmp1); o[5] = px(tmp12 - tmp1);
+    o[3] = px(tmp13 + tmp0); o[4] = px(tmp13 - tmp0);
   }
 }
 
