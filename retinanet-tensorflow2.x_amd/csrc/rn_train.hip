@@ -126,6 +126,7 @@ struct BnSegDev {
 };
 struct BnArgs {
   int nseg, act, bessel, mode, fuse_finalize;
+  int chunk_u;          // elementwise passes: 0 = grid-stride lanes; U > 0 = one workgroup per 256 * U contiguous 16-byte units
   float eps, momentum, count_scale;
   float* ws;           // partials: [seg][chunk][2][C] laid out with ws_off
   long long ws_off[RN_CONV_MAX_SEGMENTS];
@@ -278,6 +279,29 @@ __global__ void bn_finalize_kernel(const BnArgs a) {
   bn_finalize_channel(a, s, c, (double)s.sums[c], (double)s.sums[s.C + c]);
 }
 
+// Which 16-byte units (8 channels of one pixel) a thread of the two elementwise passes walks: first, first + step, ... < last.
+//   chunk_u = 0: grid-stride — the stride is the thread count rounded down to a multiple of C/8, so a thread keeps ONE
+//     8-channel group for all its rows and holds that group's per-channel parameters in registers;
+//   chunk_u = U: workgroup b owns the contiguous units [b * 256 * U, (b + 1) * 256 * U) and a thread takes every 256th of
+//     them (same channel group again: the launcher picks this form only when C/8 divides 256).  Not persistent: the
+//     hardware hands out the chunks in address order as workgroups retire, and the pass streams at 5.6 - 6.0 TB/s where the
+//     grid-stride form of the same loop body reaches 4.9 - 5.5 (tools/probes/stream_probe.hip).
+#define BN_ELEMENTWISE_RANGE()                                                                        \
+  long long first, last, step;                                                                        \
+  if (a.chunk_u > 0) {                                                                                \
+    const long long span = 256ll * a.chunk_u;                                                         \
+    first = blockIdx.x * span + threadIdx.x;                                                          \
+    last = (blockIdx.x + 1) * span < total ? (blockIdx.x + 1) * span : total;                         \
+    step = 256;                                                                                       \
+    if (first >= last) return;                                                                        \
+  } else {                                                                                            \
+    const long long nthreads = (long long)gridDim.x * blockDim.x;                                     \
+    step = nthreads / C8 * C8;                                                                        \
+    first = blockIdx.x * (long long)blockDim.x + threadIdx.x;                                         \
+    last = total;                                                                                     \
+    if (first >= step) return;                                                                        \
+  }
+
 // z = act(y*scale + shift + residual), with a bf16 tensor where the reference has one between two layers: the
 // BatchNorm output (when something other than relu / relu6 follows it), the drop_connect output, the residual sum
 // in front of tf.nn.swish.  The grid-stride is rounded to a multiple of C/8 so a thread keeps ONE 8-channel group
@@ -286,18 +310,15 @@ __global__ void __launch_bounds__(TR_THREADS) bn_apply_kernel(const BnArgs a) {
   const BnSegDev& s = a.seg[blockIdx.y];
   const int C8 = s.C >> 3;
   const long long total = s.P * C8;
-  const long long nthreads = (long long)gridDim.x * blockDim.x;
-  const long long lanes = nthreads / C8 * C8;
-  const long long gtid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if (gtid >= lanes) return;
-  const int c8 = (int)(gtid % C8);
+  BN_ELEMENTWISE_RANGE();
+  const int c8 = (int)(first % C8);
   float sc[8], sh[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     sc[q] = s.fwd[2 * s.C + c8 * 8 + q];
     sh[q] = s.fwd[3 * s.C + c8 * 8 + q];
   }
-  for (long long i = gtid; i < total; i += lanes) {
+  for (long long i = first; i < last; i += step) {
     const bf8 y = unpack8(s.y[i]);
     bf8 o;
     bf8 res;
@@ -345,11 +366,8 @@ __global__ void __launch_bounds__(TR_THREADS) bn_bwd_apply_kernel(const BnArgs a
   const int C8 = s.C >> 3;
   const long long total = s.P * C8;
   const float inv_n = (float)(1.0 / ((double)s.P * (double)a.count_scale));
-  const long long nthreads = (long long)gridDim.x * blockDim.x;
-  const long long lanes = nthreads / C8 * C8;
-  const long long gtid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if (gtid >= lanes) return;
-  const int c8 = (int)(gtid % C8);
+  BN_ELEMENTWISE_RANGE();
+  const int c8 = (int)(first % C8);
   float mean[8], istd[8], sc[8], shq[8], k1[8], k2[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
@@ -361,7 +379,7 @@ __global__ void __launch_bounds__(TR_THREADS) bn_bwd_apply_kernel(const BnArgs a
     k1[q] = s.bsums[c] * inv_n;
     k2[q] = s.bsums[s.C + c] * inv_n;
   }
-  for (long long i = gtid; i < total; i += lanes) {
+  for (long long i = first; i < last; i += step) {
     const bf8 y = unpack8(s.y[i]);
     const bf8 dz = unpack8(s.dz[i]);
     const bool from_u = !s.residual && (a.act == RN_ACT_RELU || a.act == RN_ACT_RELU6);
@@ -395,7 +413,7 @@ __global__ void __launch_bounds__(TR_THREADS) bn_bwd_apply_kernel(const BnArgs a
 // mode 0 (forward statistics) honours rn_bn_segment.ext_chunks: stage-1 partials written by the conv epilogue
 static int bn_fill(const rn_bn_problem* p, BnArgs& a, int need_ws, int mode = 1) {
   if (!p || p->num_segments < 1 || p->num_segments > RN_CONV_MAX_SEGMENTS) return -1;
-  a.nseg = p->num_segments; a.act = p->act; a.bessel = p->bessel; a.mode = 0; a.fuse_finalize = 0;
+  a.nseg = p->num_segments; a.act = p->act; a.bessel = p->bessel; a.mode = 0; a.fuse_finalize = 0; a.chunk_u = 0;
   a.eps = p->eps; a.momentum = p->momentum; a.count_scale = p->count_scale > 0 ? p->count_scale : 1.0f;
   long long off = 0;
   for (int i = 0; i < p->num_segments; ++i) {
@@ -523,6 +541,26 @@ extern "C" int rn_bn_finalize(const rn_bn_problem* p, void* stream) {
   return RN_OK;
 }
 
+// grid of the elementwise passes; picks the chunked form (BN_ELEMENTWISE_RANGE) when every segment's C/8 divides 256.
+// U = 8 units per thread: each thread re-reads its 16 - 48 per-channel parameters per chunk, which is what U amortises
+// (training step on one box, tools/probes/ab_bn_chunk.sh: grid-stride 31.29 ms, U = 1: 33.1, 2: 31.9, 4: 31.14, 8: 31.09,
+// 16: 31.38, 32: 32.10 — few, long workgroups lose the ordered hand-out again).
+#ifndef RN_BN_CHUNK_U
+#define RN_BN_CHUNK_U 8
+#endif
+static int bn_elementwise_grid(BnArgs& a, long long max_units) {
+  static_assert(TR_THREADS == 256, "BN_ELEMENTWISE_RANGE assumes 256 threads");
+  bool chunk = RN_BN_CHUNK_U > 0;
+  for (int i = 0; i < a.nseg; ++i) chunk = chunk && 256 % (a.seg[i].C >> 3) == 0;
+  const long long blocks = rn_cdiv(max_units, 256ll * (RN_BN_CHUNK_U > 0 ? RN_BN_CHUNK_U : 1));
+  if (chunk && blocks < (1ll << 31)) {
+    a.chunk_u = RN_BN_CHUNK_U;
+    return (int)blocks;
+  }
+  a.chunk_u = 0;
+  return tr_blocks(max_units, 4096);
+}
+
 extern "C" int rn_bn_apply(const rn_bn_problem* p, void* stream) {
   BnArgs a;
   RN_CHECK_ARG(bn_fill(p, a, 0) == 0, "rn_bn_apply: bad problem");
@@ -532,7 +570,7 @@ extern "C" int rn_bn_apply(const rn_bn_problem* p, void* stream) {
     const long long t = a.seg[i].P * (a.seg[i].C / 8);
     if (t > mx) mx = t;
   }
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(tr_blocks(mx, 4096), a.nseg), dim3(TR_THREADS), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_elementwise_grid(a, mx), a.nseg), dim3(TR_THREADS), 0, (hipStream_t)stream, a);
   RN_CHECK_LAUNCH();
   return RN_OK;
 }
@@ -549,7 +587,7 @@ extern "C" int rn_bn_bwd_apply(const rn_bn_problem* p, void* stream) {
     if (t > mx) mx = t;
   }
   {
-    const dim3 grid(tr_blocks(mx, 4096), a.nseg), block(TR_THREADS);
+    const dim3 grid(bn_elementwise_grid(a, mx), a.nseg), block(TR_THREADS);
 #define BN_CALL_(G_) hipLaunchKernelGGL(bn_bwd_apply_kernel<G_>, grid, block, 0, (hipStream_t)stream, a)
     BN_DISPATCH_GATE(bn_gate_mode(p), BN_CALL_)
 #undef BN_CALL_
