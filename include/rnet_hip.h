@@ -175,7 +175,8 @@ int rn_rowmax_argmax(const float* scores, int64_t rows, int K, float* max_out, i
  * function of its arguments.  All zero = the dispatcher's own choice.
  */
 typedef struct {
-  int32_t conv_tile;           /* 0: auto | 1: the 128-row conv_fwd_kernel | 2: the 256-row kernels wherever the shape allows */
+  int32_t conv_tile;           /* 0: auto | 1: the 128-row conv_fwd_kernel with its full 128-column tiles (auto narrows them to 64
+                                * columns for launches of at most half a tile per CU) | 2: the 256-row kernels wherever the shape allows */
   int32_t conv_no_halo;        /* 1: conv_big_kernel where conv_halo_kernel would run (A/B, tests) */
   int32_t conv_big_min_tiles;  /* > 0: 256-row tiles a launch needs to go to the 256-row kernels (default 192) */
   int32_t max_workgroups;      /* > 0: cap on the persistent grids of conv_big / conv_halo (default: one per CU) */

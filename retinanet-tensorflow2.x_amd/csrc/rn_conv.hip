@@ -472,13 +472,23 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
   a.R = p->R; a.S = p->S; a.sh = p->stride_h; a.sw = p->stride_w; a.pt = p->pad_top; a.pl = p->pad_left;
   a.act = p->act; a.nseg = p->num_segments; a.pad_ = 0;
   const int cout_pad0 = rn_conv_cout_pad(p->seg[0].Cout);
-  const int BN = cout_pad0 <= 64 ? 64 : 128;
+  int BN = cout_pad0 <= 64 ? 64 : 128;
   // K step: 64 unless the (padded) channel count is small; Cin need only be a multiple of 8 — the
   // tail of the last K step reads past the pixel's channels (or out of range -> zeros) and meets the
   // zero-padded weight columns, so it contributes nothing.
   const int BK = rn_conv_cin_pad(p->seg[0].Cin) % 64 == 0 ? 64 : 32;
   const bool big = conv_use_big(p);
   const int BM = big ? 256 : 128;
+  if (!big && BN == 128) {
+    // Small launches (batch-8 inference, ResNet stage 4: 100 tiles of 128 x 128 on 256 CUs): 128 x 64 tiles put the work
+    // on twice as many CUs and read 12 KB instead of 16 KB of LDS fragments per wave and K step — the 128-row kernel is
+    // bound by fragment bandwidth at one workgroup per CU (DESIGN.md section 4, round-3 probes).  Only while the
+    // narrower tiles still fit one per CU: at two per CU they share that bandwidth again.
+    long long t128 = 0;
+    for (int i = 0; i < p->num_segments; ++i)
+      t128 += rn_cdiv((long long)p->seg[i].N * p->seg[i].Ho * p->seg[i].Wo, 128) * rn_cdiv(rn_conv_cout_pad(p->seg[i].Cout), 128);
+    if (2 * t128 <= rn_num_cus() && !p->opts.ablate && p->opts.conv_tile != 1) BN = 64;   // conv_tile = 1 keeps 128 x 128 (tests)
+  }
   const int BNT = big ? 256 : BN;   // n-tile width
   int tiles = 0;
   for (int i = 0; i < p->num_segments; ++i) {
@@ -492,7 +502,7 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
                  "rn_conv2d_nhwc_fwd: segment %d pix_stride=%d must be a positive multiple of 4", i, s.pix_stride);
     RN_CHECK_ARG(s.Cout % 4 == 0, "rn_conv2d_nhwc_fwd: segment %d Cout=%d not a multiple of 4", i, s.Cout);
     const int cp = rn_conv_cout_pad(s.Cout);
-    RN_CHECK_ARG((cp <= 64 ? 64 : 128) == BN, "rn_conv2d_nhwc_fwd: segments mix Cout tile widths");
+    RN_CHECK_ARG((cp <= 64) == (cout_pad0 <= 64), "rn_conv2d_nhwc_fwd: segments mix Cout tile widths");
     RN_CHECK_ARG(((uintptr_t)s.x | (uintptr_t)s.w | (uintptr_t)s.y | (uintptr_t)s.residual) % 16 == 0,
                  "rn_conv2d_nhwc_fwd: segment %d tensors must be 16-byte aligned", i);
     const long long M = (long long)s.N * s.Ho * s.Wo;

@@ -186,6 +186,29 @@ def test_conv_single(cuda, build, case):
     _run_conv_single(cuda, case)
 
 
+_WIDE_CASES = [c for c in CASES if c[4] > 64]
+
+
+@pytest.mark.parametrize("build,case", _builds(_WIDE_CASES, _WIDE_CASES[:4], "wide-"))
+def test_conv_single_full_width_tiles(cuda, build, case):
+    """At these sizes (at most half a 128 x 128 tile per CU) the dispatcher narrows the 128-row kernel's tiles to 64
+    columns; rn_launch_opts.conv_tile = 1 keeps the 128 x 128 form that larger launches run — the K order of an
+    accumulator is the same, so the two agree bit for bit."""
+    N, H, W, Cin, Cout, k, stride, act, use_res, out_f32 = case
+    g = torch.Generator().manual_seed(_seed(case))
+    pad = (k - 1) // 2
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    s = {"x": torch.randn((N, H, W, Cin), generator=g),
+         "w": torch.randn((k, k, Cin, Cout), generator=g) / math.sqrt(k * k * Cin),
+         "scale": torch.rand((Cout,), generator=g) + 0.5, "shift": torch.randn((Cout,), generator=g) * 0.1}
+    if use_res:
+        s["residual"] = torch.randn((N, Ho, Wo, Cout), generator=g)
+    wide = _conv_gpu(cuda, [s], k, stride, pad, act, out_f32, dict(conv_tile=1))[0]
+    auto = _conv_gpu(cuda, [s], k, stride, pad, act, out_f32, None)[0]
+    _close(wide, _conv_ref(s, k, stride, pad, act, out_f32), out_f32)
+    assert torch.equal(wide, auto)
+
+
 _BIG_CASES = [c for c in CASES if c[4] > 128 and c[4] % 8 == 0]
 
 
