@@ -45,11 +45,6 @@ __device__ __forceinline__ int frag_off(int lane, int col0) {
   const int r0 = (g >> 1) * 8 + (i >> 2);
   return r0 * 512 + (((col >> 3) ^ ((r0 & 3) << 2)) << 4) + (col & 7) * 2;
 }
-__device__ __forceinline__ bf16x8_t frag_read(const char* p) {   // p: rows r0 (..+3 via transpose), r0 + 4 at +2048
-  const bf16x4_t lo = rn_ds_read_tr4((const lds_b4_t*)p);
-  const bf16x4_t hi = rn_ds_read_tr4((const lds_b4_t*)(p + 2048));
-  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-}
 
 // LINEAR: stride 1, output size == input size, symmetric padding (every 1x1 / 3x3 layer of the network): the input
 // pixel of output pixel p at tap (r, s) is p + (r - pt)*W + (s - pl), so both operands' source offsets advance by a
