@@ -111,7 +111,8 @@ class TrainEngine:
         self.fuse_bn_bwd = os.environ.get("RNET_FUSE_BN_BWD", "1") != "0"
         # =2: also the multi-segment groups (the four head-tower depths).  Measured same-box: 3-4 more 122 us reduction
         # launches go, the eight 550 us tower data gradients get ~15 us longer each in the step: +0.25 % on the step
-        # for -0.026 on the dominant kernel's MFMA fraction — off by default, the capability stays tested
+        # (round 3, with the weight-gradient CU cap: 31.06 -> 30.92 ms, +0.45 %, tools/probes/ab_env.sh) for -0.026 on the
+        # dominant kernel's MFMA fraction, the figure bench.py's roofline reports — off by default, the capability stays tested
         self.fuse_bn_bwd_groups = os.environ.get("RNET_FUSE_BN_BWD", "1") == "2"
         self.bn_act_mask = os.environ.get("RNET_BN_ACT_MASK", "1") != "0"   # relu gates of the residual layers as bit masks
         self.bn_bwd_ws = {}       # id(rn_bn_problem) -> workspace that holds the externally written backward partials
