@@ -476,6 +476,23 @@ def cpu_baseline(params_train, model_train, frozen, params_infer, model_infer, b
     return out
 
 
+def launch_ranks(n):
+    """Start `n` ranks of this script under torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1) as a
+    child process and return its exit status.  Called before anything in this process has initialised the GPU."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this pool
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -494,7 +511,17 @@ def main():
     ap.add_argument("--no-probe", action="store_true", help="skip the MFMA-only probe behind roofline.sustained")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` typed by hand: this process becomes the LAUNCHER (distribute.py:16-18: one replica
+        # per GPU).  It has not touched the GPU (importing torch does not), starts the N ranks as a CHILD process group
+        # — no exec, no in-process retry —, lets rank 0's JSON line through on the inherited stdout and exits with the
+        # child's status.
+        sys.exit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with `python -m torch.distributed.run "
+                         f"--nnodes=1 --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...` or plain `python bench.py "
+                         f"--gpus {args.gpus}`")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # RNET_BENCH_ONE_DEVICE=1: functional check of the N>1 code path on a single-GPU box — every rank uses
@@ -528,6 +555,12 @@ def main():
                                f"shard: global batch {world * B}), resnet_initial frozen, "
                                f"{'SyncBN + RCCL gradient all-reduce' if world > 1 else 'single GPU'}",
                    "global_batch": world * B, "parallelism": f"dp{world}",
+                   # ranks of the process group the gradient all-reduce runs on, its backend ("nccl" = RCCL over xGMI;
+                   # "gloo" only in the one-device functional mode) and who carries the SyncBN / normaliser messages
+                   "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+                   "backend": dist.get_backend() if world > 1 else None,
+                   "comm": "native" if getattr(eng, "native_comm", None) is not None else "torch",
+                   "syncbn_messages": getattr(eng, "syncbn_messages_per_step", None),
                    "final_loss": round(train["loss"], 4), "gradient_norm": round(train["grad_norm"], 4)},
         "roofline": train["roofline"],
     }

@@ -92,6 +92,8 @@ class TrainEngine:
         self._overlap_done = 0
         self._step_args = dict(wdc=0.0, alpha=0.0, unscale=1.0, clip=0.0)
         self.native_comm = None   # retinanet.comm.NativeComm for the small per-layer messages (SyncBN, normaliser)
+        self._small_msgs = 0      # C3 messages (SyncBN sums; C2 rides in the first) sent since the step began
+        self.syncbn_messages_per_step = None   # their count in the last train_step (bench.py: config.syncbn_messages)
         self._algo = {}           # id(rn_conv_problem) -> (algorithmic FLOPs, algorithmic bytes) where the launch executes more
         self.hbm_profile = None   # bench.py: list that collects (event0, event1, kernel name, algorithmic bytes)
         self.conv_launches = []   # (name, rn_conv_problem) of every implicit-GEMM launch: lib.rn_conv_kernel_id(byref(p))
@@ -129,6 +131,10 @@ class TrainEngine:
         self.dc_generator.manual_seed(1337)
         self._prepare_graph()
         with torch.cuda.device(self.dev):
+            # split-K of the persistent conv kernels' last round (rn_conv_problem.splitk_ws): every forward / data-gradient
+            # launch runs on the main stream, in order, so one workspace serves them all; attached at creation because the
+            # dispatcher looks at it
+            self.splitk_ws = _C.new_splitk_workspace(self.lib, self.dev)
             self._analyse()
             self._alloc_params()
             self._alloc_tensors()
@@ -591,7 +597,7 @@ class TrainEngine:
         """forward conv launch over `ops`; raw_mode: write pre-BN output (+bias) without activation."""
         first = ops[0]
         c0 = self.g.convs[first["conv"]]
-        p = _C.ConvProblem()
+        p = _C.attach_splitk_workspace(_C.ConvProblem(), self.splitk_ws)
         p.opts = self.launch_opts
         p.R = p.S = c0["k"]
         p.stride_h = p.stride_w = c0["stride"]
@@ -643,6 +649,7 @@ class TrainEngine:
     def _allreduce_small(self, t):
         """SyncBatchNorm / normaliser message: rn_allreduce_small on the compute stream when a native communicator was
         handed in (retinanet.comm.maybe_enable_native), torch.distributed otherwise"""
+        self._small_msgs += 1
         if self.native_comm is not None:
             self.native_comm.all_reduce_small(t)
         else:
@@ -781,7 +788,7 @@ class TrainEngine:
                     lib.rn_pack_image_nhwc4(self._images_ptr, B, H, W, self.stem_pad[0], self.stem_pad[1], self.Hp, self.Wp,
                                             pin, st), "rn_pack_image_nhwc4"))
                 live = self._conv_trainable(op)
-                p = _C.ConvProblem()
+                p = _C.attach_splitk_workspace(_C.ConvProblem(), self.splitk_ws)
                 p.opts = self.launch_opts
                 p.R, p.S, p.stride_h, p.stride_w, p.pad_top, p.pad_left = self.stem_k, 1, 2, 2, 0, 0
                 p.act = _C.RN_ACT_NONE if live else _C.ACT_IDS[op["act"]]
@@ -1398,7 +1405,7 @@ class TrainEngine:
         lib, B = self.lib, self.B
         c0 = self.g.convs[need[0]["conv"]]
         k, stride = c0["k"], c0["stride"]
-        p = _C.ConvProblem()
+        p = _C.attach_splitk_workspace(_C.ConvProblem(), self.splitk_ws)
         p.opts = self.launch_opts
         p.R = p.S = k
         p.stride_h = p.stride_w = 1
@@ -1837,6 +1844,7 @@ class TrainEngine:
             self._step_args = dict(wdc=alpha / self.world, alpha=alpha, unscale=1.0 / scale,
                                    clip=float(opt.clipnorm) if opt.clipnorm else 0.0)
             self._prepack_dgrad_weights()
+            self._small_msgs = 0
             self._c2_local, self._c2_sent, self.c2_normalizer = None, False, None
             if self.sync_bn:    # sum(num-positives) + 1 of this rank (retinanet_loss.py:38): folded into SyncBN traffic
                 self._c2_local = (targets["num-positives"].sum() + 1.0).reshape(1).to(torch.float32)
@@ -1856,6 +1864,7 @@ class TrainEngine:
             self.optimizer_step(opt.lr(step), opt.momentum, opt.clipnorm, alpha,
                                 opt.ema_decay(step) if opt.use_moving_average else None, nesterov=opt.nesterov,
                                 overlapped=overlapped)
+            self.syncbn_messages_per_step = self._small_msgs if self.sync_bn else 0
             if not (self.loss_scale and self.loss_scale["skipped"]):
                 self.step_count += 1          # a dropped step does not advance optimizer.iterations
             opt.iterations = self.step_count
