@@ -268,9 +268,29 @@ typedef struct {
   int32_t num_segments;
   rn_conv_segment seg[RN_CONV_MAX_SEGMENTS];
   rn_launch_opts opts;
+  /* optional split-K workspace (device memory, 16-byte aligned, ZERO-FILLED once by the caller; the kernels leave its
+   * first 4 KB — arrival counters and a status word — zero again after every launch).  The persistent 256-row kernels
+   * walk their tiles in rounds of one tile per compute unit; the last round of a launch whose tile count is not a
+   * multiple of the grid leaves most of the chip idle for a whole tile (8.3 rounds run as 9; a 100-tile launch uses 100
+   * of 256 CUs).  With a workspace the halo kernel (3x3 / stride 1) runs the full rounds as before and the tiles of the
+   * last round in a second launch, each cut along K (input-channel chunks, >= 4 per part, <= 4 parts) over several
+   * workgroups: every part writes its fp32 accumulators here, part 0 adds them IN PART ORDER (deterministic: the same bits
+   * on every run) and runs the normal epilogue.  NULL / too small: whole tiles only (the round-3 behaviour).
+   * rn_conv_splitk_workspace_bytes() = what this problem can use on the current device (0: it would not split).
+   * Launches that share a workspace must be ordered on one stream.  Word 1023 of the workspace is set to 1 if a part
+   * ever gave up waiting (2 s) for its partners: results of that launch are then invalid (never seen; the tests read it).
+   * Measured (round 4): correct, deterministic — and not faster: the 256 KB a part hands over cost what its half tile of
+   * MFMA work saves, so the Python engines attach a workspace only under RNET_SPLITK=1. */
+  void* splitk_ws;
+  int64_t splitk_ws_bytes;
 } rn_conv_problem;
 
 int rn_conv2d_nhwc_fwd(const rn_conv_problem* problem /* host */, void* stream);
+size_t rn_conv_splitk_workspace_bytes(const rn_conv_problem* problem /* host */);
+/* enough for any problem on any device (64 MB + 4 KB).  The dispatcher also looks at splitk_ws: a 3x3 / stride 1 launch
+ * of fewer 256-row tiles than compute units (ResNet stage 3 / 4 at batch 8) goes to the halo kernel, every tile split,
+ * only when a workspace is attached — set it BEFORE asking rn_conv_kernel_id / rn_conv_tile_rows. */
+size_t rn_conv_splitk_workspace_max_bytes(void);
 
 /* HWIO f32 [R,S,Cin,Cout] (the Keras kernel layout, resnet.py:137-144) -> bf16
  * [Cout_pad,R,S,Cin_pad], zero padded.  Cout_pad = rn_conv_cout_pad(Cout). */

@@ -408,6 +408,27 @@ static int launch_ablate(const ConvArgs& a, hipStream_t st) {
 // 256 x 256 x 32 tiles (rn_conv_big.hip) for the MFMA-bound layers: every segment at least 256 output
 // channels wide, and enough tiles to fill the 256 CUs (one workgroup per CU) a few times over.
 // (rn_launch_opts: conv_tile forces either family, conv_big_min_tiles moves the threshold.)
+// Last-round split of a persistent launch (rnet_hip.h: rn_conv_problem.splitk_ws).  G0 workgroups walk `total` tiles in
+// rounds; the L = total mod G0 tiles of the last round are each cut into S = min(G0 / L, chunks / 4, 4) parts along K, so
+// that round keeps L * S workgroups busy for 1/S of a tile (+ the exchange of L * (S - 1) accumulator tiles through the
+// workspace) instead of L workgroups for a whole one.
+static int splitk_parts(int total, int min_chunks, int G0, long long* bytes) {
+  const int L = total % G0;
+  if (bytes) *bytes = 0;
+  if (L == 0 || L > 1023 || min_chunks < 8) return 1;
+  // every part costs its tile one more 256 KB slot to write and part 0 one more to read (~4 us each): at least 4 chunks
+  // (36 K steps, ~20 us) per part, at most 4 parts
+  int S = G0 / L;
+  if (S > min_chunks / 4) S = min_chunks / 4;
+  if (S > 4) S = 4;
+  if (S < 2) return 1;
+  if (bytes) *bytes = RN_SPLITK_HEADER_BYTES + (long long)L * S * RN_SPLITK_SLOT_BYTES;   // one slot per part
+  return S;
+}
+
+static bool conv_halo_shape(const rn_conv_problem* p);
+static int conv_min_chunks(const rn_conv_problem* p);
+
 static bool conv_use_big(const rn_conv_problem* p) {
   if (p->opts.conv_tile == 1) return false;
   long long tiles256 = 0;
@@ -417,13 +438,23 @@ static bool conv_use_big(const rn_conv_problem* p) {
     if (s.bias && s.residual) return false;   // the residual variants of the 256-row kernels carry no bias path
     tiles256 += rn_cdiv((long long)s.N * s.Ho * s.Wo, 256) * rn_cdiv(s.Cout, 256);
   }
-  return p->opts.conv_tile == 2 || tiles256 >= (p->opts.conv_big_min_tiles > 0 ? p->opts.conv_big_min_tiles : 192);
+  if (p->opts.conv_tile == 2 || tiles256 >= (p->opts.conv_big_min_tiles > 0 ? p->opts.conv_big_min_tiles : 192)) return true;
+  // A launch of fewer tiles than compute units (batch-8 inference, ResNet stage 3 / 4; stage 4 at any batch) used to go
+  // to the 128-row kernel because whole 256-row tiles would leave most of the chip idle.  With a split-K workspace the
+  // halo kernel cuts every tile into S parts (all tiles are "last round"): enough workgroups again, on the faster kernel.
+  if (p->splitk_ws && p->opts.conv_big_min_tiles == 0 && conv_halo_shape(p)) {
+    long long bytes = 0;
+    const int G0 = rn_persistent_grid(0x7fffffff, rn_num_cus(), p->opts);
+    const int S = tiles256 < G0 ? splitk_parts((int)tiles256, conv_min_chunks(p), G0, &bytes) : 1;
+    return S >= 2 && tiles256 * S >= G0 / 2 && bytes <= p->splitk_ws_bytes;
+  }
+  return false;
 }
 
 // 3x3 / stride 1 / pad 1 launches of the 256-row class go to the halo kernel (rn_conv_halo.hip) when every
 // segment's worst tile fits its patch buffer.
-static bool conv_use_halo(const rn_conv_problem* p) {
-  if (p->opts.conv_no_halo || !conv_use_big(p)) return false;
+static bool conv_halo_shape(const rn_conv_problem* p) {
+  if (p->opts.conv_no_halo) return false;
   if (p->R != 3 || p->S != 3 || p->stride_h != 1 || p->stride_w != 1 || p->pad_top != 1 || p->pad_left != 1)
     return false;
   static std::mutex mu;
@@ -447,6 +478,49 @@ static bool conv_use_halo(const rn_conv_problem* p) {
     if (px > rn_conv_halo_capacity()) return false;
   }
   return true;
+}
+static bool conv_use_halo(const rn_conv_problem* p) { return conv_halo_shape(p) && conv_use_big(p); }
+
+int rn_splitk_plan(ConvArgs& a, int min_chunks, void* ws, long long ws_bytes, const rn_launch_opts& opts) {
+  const int total = a.total_tiles;
+  a.split_f = total; a.split_s = 1; a.vtotal = total; a.pad2_ = 0; a.ws = nullptr;
+  const int G0 = rn_persistent_grid(0x7fffffff, rn_num_cus(), opts);
+  const int L = total % G0;
+  int S = ws ? splitk_parts(total, min_chunks, G0, nullptr) : 1;
+  while (S >= 2 && RN_SPLITK_HEADER_BYTES + (long long)L * S * RN_SPLITK_SLOT_BYTES > ws_bytes) --S;
+  if (S < 2) return total < G0 ? total : G0;
+  a.split_f = total - L; a.split_s = S; a.vtotal = L * S; a.ws = (float*)ws;   // vtotal: units of the SPLIT launch
+  return a.split_f ? G0 : L * S;
+}
+
+// K chunks (32 input channels x all taps) of the launch's shortest tile
+static int conv_min_chunks(const rn_conv_problem* p) {
+  int mc = 0x7fffffff;
+  for (int i = 0; i < p->num_segments; ++i) {
+    const int terms = p->seg[i].w_terms > 1 ? p->seg[i].w_terms : 1;
+    const int ch = terms * rn_conv_cin_pad(p->seg[i].Cin) / 32;
+    mc = ch < mc ? ch : mc;
+  }
+  return mc;
+}
+// ... or 0 when this launch cannot split (conv_big_kernel: whole tiles only — its 1x1 layers are HBM-bound)
+static int conv_splitk_min_chunks(const rn_conv_problem* p) { return conv_use_halo(p) ? conv_min_chunks(p) : 0; }
+
+// what any problem can use on any grid: 4 KB header + 256 accumulator slots (one per part: L * S <= 256 workgroups)
+extern "C" size_t rn_conv_splitk_workspace_max_bytes(void) { return RN_SPLITK_HEADER_BYTES + 256ull * RN_SPLITK_SLOT_BYTES; }
+
+extern "C" size_t rn_conv_splitk_workspace_bytes(const rn_conv_problem* p) {
+  if (!p || p->num_segments < 1 || p->num_segments > RN_CONV_MAX_SEGMENTS) return 0;
+  const int mc = conv_splitk_min_chunks(p);
+  if (!mc) return 0;
+  long long tiles = 0;
+  for (int i = 0; i < p->num_segments; ++i) {
+    const rn_conv_segment& s = p->seg[i];
+    tiles += rn_cdiv((long long)s.N * s.Ho * s.Wo, 256) * rn_cdiv(rn_conv_cout_pad(s.Cout), 256);
+  }
+  long long bytes = 0;
+  splitk_parts((int)tiles, mc, rn_persistent_grid(0x7fffffff, rn_num_cus(), p->opts), &bytes);
+  return (size_t)bytes;
 }
 
 /* 0: 128-row kernel, 1: conv_big_kernel, 2: conv_halo_kernel */
@@ -538,6 +612,9 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
     tiles += (int)rn_cdiv(M, BM) * d.n_tiles;
   }
   a.total_tiles = tiles;
+  a.split_f = a.vtotal = tiles; a.split_s = 1; a.pad2_ = 0; a.ws = nullptr;
+  RN_CHECK_ARG(p->splitk_ws == nullptr || ((uintptr_t)p->splitk_ws % 16 == 0 && p->splitk_ws_bytes >= 0),
+               "rn_conv2d_nhwc_fwd: splitk_ws must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const bool f32 = p->out_dtype == RN_DT_F32;
   if (p->opts.ablate && BM == 128 && BN == 128 && BK == 64 && !f32) {
@@ -556,7 +633,10 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
       default: break;
     }
   }
-  if (big && conv_use_halo(p)) return rn_launch_conv_halo(a, f32, p->opts, st);
+  if (big && conv_use_halo(p)) {
+    rn_splitk_plan(a, conv_splitk_min_chunks(p), p->splitk_ws, p->splitk_ws_bytes, p->opts);
+    return rn_launch_conv_halo(a, f32, p->opts, st);
+  }
   if (big) {
     a.pad_ = 1;   // float-reciprocal index arithmetic in the tile set-up, valid while every M < 2^22
     for (int i = 0; i < a.nseg; ++i)

@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(512) conv_big_kernel(const ConvArgs args) {
       if (tile__ >= args.seg[i].tile_begin) si__ = i;                                                 \
     const ConvSegDev& sg__ = args.seg[si__];                                                          \
     const int lt__ = tile__ - sg__.tile_begin;                                                        \
-    const int mt__ = rn_fdiv(lt__, sg__.n_tiles, __frcp_rn((float)sg__.n_tiles)); /* < 2^22 tiles */  \
+    const int mt__ = rn_fdiv(lt__, sg__.n_tiles, rn_rcp((float)sg__.n_tiles)); /* < 2^22 tiles */  \
     const int m0__ = mt__ * BM, n0__ = (lt__ - mt__ * sg__.n_tiles) * BN;                             \
     i_W = sg__.W; i_PS = sg__.pix_stride; i_Cin = sg__.CinP; i_cw = sg__.cwrap;                       \
     const int H__ = sg__.H, Ktot__ = RS * i_Cin;                                                      \
@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(512) conv_big_kernel(const ConvArgs args) {
                                              (int)((long long)sg__.N * H__ * i_W * i_PS * 2), 0x00020000); \
     rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)sg__.w, 0, (int)((long long)rows__ * Ktot__ * 2), \
                                              0x00020000);                                             \
-    const float rWo__ = __frcp_rn((float)sg__.Wo), rHo__ = __frcp_rn((float)sg__.Ho);                 \
+    const float rWo__ = rn_rcp((float)sg__.Wo), rHo__ = rn_rcp((float)sg__.Ho);                 \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                   \
       const int row = (j * NW + wave) * 16 + d_row;                                                   \
       const int chunk = d_pos ^ lds_swz<BK>(row);                                                     \
@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(512) conv_big_kernel(const ConvArgs args) {
       if (tile__ >= args.seg[i].tile_begin) c_si = i;                                                 \
     const ConvSegDev& sg__ = args.seg[c_si];                                                          \
     const int lt__ = tile__ - sg__.tile_begin;                                                        \
-    const int mt__ = rn_fdiv(lt__, sg__.n_tiles, __frcp_rn((float)sg__.n_tiles)); /* < 2^22 tiles */  \
+    const int mt__ = rn_fdiv(lt__, sg__.n_tiles, rn_rcp((float)sg__.n_tiles)); /* < 2^22 tiles */  \
     c_m0 = mt__ * BM;                                                                                 \
     c_n0 = (lt__ - mt__ * sg__.n_tiles) * BN;                                                         \
     c_ksteps = RS * (sg__.CinP / BK);                                                                 \

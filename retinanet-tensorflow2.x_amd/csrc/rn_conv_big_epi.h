@@ -47,6 +47,10 @@ __device__ __forceinline__ float bf_hi(uint32_t u) { return rn_hi16(u); }
 // a / b for 0 <= a < 2^22, b > 0, through the float reciprocal (rcp_b ~ 1 / b): the estimate is off by at most
 // one, fixed up with the exact remainder — ~8 VALU instructions against ~45 for the compiler's integer division.
 // The tile set-up code of the persistent kernels runs a few dozen of these per lane per tile, on all eight waves.
+// the reciprocal estimate for rn_fdiv: v_rcp_f32 (1 ulp).  a * rcp is then within 0.75 of a / b for a < 2^22, which the
+// +-1 fix-up covers; __frcp_rn (correctly rounded under -fhip-fp32-correctly-rounded-divide-sqrt) compiled to a
+// 12-instruction v_div_scale / v_div_fmas / v_div_fixup sequence per call, ~60 instructions per tile set-up
+__device__ __forceinline__ float rn_rcp(float b) { return __builtin_amdgcn_rcpf(b); }
 __device__ __forceinline__ int rn_fdiv(int a, int b, float rcp_b) {
   int q = (int)((float)a * rcp_b);
   const int r = a - q * b;
@@ -76,9 +80,10 @@ __device__ __forceinline__ bool big_bias_in_acc(const ConvArgs& args, const Conv
 // floats of the wave come through the scalar cache (uniform address, constant address space): no vector memory
 // operation, so the counted vmcnt waits of the DMA stream are not disturbed.
 template <bool OUT_F32, bool HAS_RES>
-__device__ __forceinline__ void big_acc_init(f32x16_t (&acc)[4][2], const ConvArgs& args, int c_si, int c_n0, int wave) {
+__device__ __forceinline__ void big_acc_init(f32x16_t (&acc)[4][2], const ConvArgs& args, int c_si, int c_n0, int wave,
+                                             bool with_bias = true) {   // false: parts 1.. of a split tile start from zero
   const ConvSegDev& sg = args.seg[c_si];
-  if (big_bias_in_acc<OUT_F32, HAS_RES>(args, sg)) {
+  if (with_bias && big_bias_in_acc<OUT_F32, HAS_RES>(args, sg)) {
     typedef const float __attribute__((address_space(4))) cfloat;
     const cfloat* b = (const cfloat*)(unsigned long long)sg.bias;
     const int nw0 = c_n0 + (wave & 3) * 64;
@@ -118,9 +123,51 @@ __device__ __forceinline__ void big_acc_init(f32x16_t (&acc)[4][2], const ConvAr
 // layer; the wave also reads that layer's raw conv output y for its rows (through the residual prefetch registers)
 // and accumulates stage 1 of the backward reduction — sum g, sum g*xhat, g = dz_stored * [y*scale + shift > 0] — into
 // bn_partial (rnet_hip.h: rn_conv_segment.bn_bwd_y).
-template <bool OUT_F32, bool HAS_RES, bool BN_BWD = false>
+// FROM_WS (part 0 of a split tile, rn_conv_halo.hip): the accumulators are not in registers but in the split-K workspace,
+// one slot per part — [wave][32 x (64 lanes x 16 B)], piece (i*2 + j)*4 + q = registers 4q..4q+3 of acc[i][j] — and each
+// 32-pixel block (i, j) is rebuilt, parts added in order, right before the epilogue consumes it: 16 - 32 live accumulator
+// registers instead of 128 (rebuilding all of them up front spilled; a kernel with scratch pays per launch).
+struct BigEpiSrc {
+  const char* slots;   // first slot of the tile
+  int nparts, voff;    // parts to add; this lane's byte offset inside a slot (wave * 32768 + lane * 16)
+};
+// NJ accumulator tiles (i, j0 .. j0 + NJ - 1) = the sum over the parts, in part order.  The slots were written with sc1 stores
+// and are read back from memory (~2 us per round trip): every load of the block — 4 parts x NJ x 4 quads, the parts past
+// nparts at an out-of-range offset, which the buffer load returns as zeros — is issued before the first add (loaded part by
+// part behind its own wait, a tile's 16 dependent round trips were 35 us of the owner's time).
+template <int NJ>
+__device__ __forceinline__ void big_epi_rebuild(f32x16_t* t, const BigEpiSrc& src, int i, int j0) {
+  typedef unsigned u32x4_t_ __attribute__((ext_vector_type(4)));
+  // one descriptor over the tile's consecutive slots; part p = p * slot bytes further
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)src.slots, 0, src.nparts * RN_SPLITK_SLOT_BYTES, 0x00020000);
+  u32x4_t_ v[4][NJ][4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        v[p][j][q] = __builtin_amdgcn_raw_buffer_load_b128(rs, src.voff + p * RN_SPLITK_SLOT_BYTES,
+                                                           ((i * 2 + j0 + j) * 4 + q) * 1024, 16);   // sc1
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float a0 = __uint_as_float(v[0][j][q].x), a1 = __uint_as_float(v[0][j][q].y);
+      float a2 = __uint_as_float(v[0][j][q].z), a3 = __uint_as_float(v[0][j][q].w);
+#pragma unroll
+      for (int p = 1; p < 4; ++p) {
+        a0 += __uint_as_float(v[p][j][q].x); a1 += __uint_as_float(v[p][j][q].y);
+        a2 += __uint_as_float(v[p][j][q].z); a3 += __uint_as_float(v[p][j][q].w);
+      }
+      t[j][q * 4] = a0; t[j][q * 4 + 1] = a1; t[j][q * 4 + 2] = a2; t[j][q * 4 + 3] = a3;
+    }
+}
+
+template <bool OUT_F32, bool HAS_RES, bool BN_BWD = false, bool FROM_WS = false>
 __device__ __forceinline__ void big_epilogue(f32x16_t (&acc)[4][2], const ConvArgs& args, int c_si, int c_m0,
-                                             int c_n0, int wave, char* patch) {
+                                             int c_n0, int wave, char* patch, const BigEpiSrc src = BigEpiSrc()) {
   static_assert(!(BN_BWD && (OUT_F32 || HAS_RES)), "BN_BWD: plain bf16 launches only");
   constexpr bool LOADS = HAS_RES || BN_BWD;   // the epilogue prefetches a second [M][Cout] bf16 tensor
   const int wave_m = wave >> 2, wave_n = wave & 3;
@@ -206,6 +253,7 @@ _Pragma("unroll") for (int pass = 0; pass < (LOADS ? 4 : 0); ++pass) {          
     for (int i = 0; i < 4; ++i) {
       EPI_STAMP(13 + 2 * i);
       if (i + 1 < 4) BIG_RES_PREFETCH((i + 1) & 1, i + 1);
+      if (FROM_WS) big_epi_rebuild<2>(&acc[i][0], src, i, 0);
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -337,6 +385,7 @@ _Pragma("unroll") for (int pass = 0; pass < (LOADS ? 4 : 0); ++pass) {          
       asm volatile("" : "+v"(sc.x), "+v"(sc.y), "+v"(sc.z), "+v"(sc.w), "+v"(sf.x), "+v"(sf.y), "+v"(sf.z), "+v"(sf.w));
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
+        if (FROM_WS) big_epi_rebuild<1>(&acc[i][j], src, i, j);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           float4 v;

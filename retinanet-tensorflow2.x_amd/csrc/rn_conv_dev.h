@@ -29,8 +29,17 @@ struct ConvSegDev {
 
 struct ConvArgs {
   int R, S, sh, sw, pt, pl, act, nseg, total_tiles, pad_;
+  // split-K of the last round of the persistent 256-row kernels (rnet_hip.h: rn_conv_problem.splitk_ws): the tiles
+  // [split_f, total_tiles) run in a second, SPLIT launch of vtotal = (total_tiles - split_f) * split_s workgroups;
+  // workgroup l * split_s + part computes the channel chunks [part * nch / split_s, (part + 1) * nch / split_s) of tile
+  // split_f + l.  No split: split_s = 1.
+  int split_f, split_s, vtotal, pad2_;
+  float* ws;   // [1024 words: arrival counter per leftover tile, word 1023 = status][slot (l, part - 1): 65536 floats]
   ConvSegDev seg[RN_CONV_MAX_SEGMENTS];
 };
+
+#define RN_SPLITK_HEADER_BYTES 4096
+#define RN_SPLITK_SLOT_BYTES (256 * 256 * 4)
 
 template <int BK>
 __device__ __forceinline__ int lds_swz(int row) {
@@ -58,6 +67,9 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wav
 int rn_launch_conv_big(const ConvArgs& a, bool out_f32, const rn_launch_opts& opts, hipStream_t st);   // (bn_y set on segment 0: the BN_BWD variant)
 // rn_conv_halo.hip (3x3 / stride 1 / pad 1)
 int rn_launch_conv_halo(const ConvArgs& a, bool out_f32, const rn_launch_opts& opts, hipStream_t st);
+// plan of the last-round split for a persistent launch of `total_tiles` tiles whose shortest tile has `min_chunks`
+// K chunks; fills a.split_f / split_s / vtotal / ws (no split when ws is null or too small) and returns the grid
+int rn_splitk_plan(ConvArgs& a, int min_chunks, void* ws, long long ws_bytes, const rn_launch_opts& opts);
 int rn_conv_halo_patch_pixels(int N, int H, int W, int pitch);
 int rn_conv_halo_pitch(int W);
 int rn_conv_halo_capacity();

@@ -47,9 +47,10 @@ constexpr int PLANE = PIX_PX * 16;                       // the patch is 4 plane
 constexpr int W_STAGE = BN * BK * 2;                     // 16 KB of weights per K step
 constexpr int W_STAGES = 3;                              // 9 taps = 3 x 3: the ring stage of a tap is tap % 3
 constexpr int W_RING = 2 * PIX_BYTES;
-constexpr int PA_TABLE = W_RING + W_STAGES * W_STAGE;    // per-thread source offsets of the patch pieces
-constexpr int SEG_TABLE = PA_TABLE + PIECES * 512 * 4;   // segment descriptors the tile set-ups need (see HaloSeg)
-constexpr int LDS_BYTES = SEG_TABLE + 16 * 4 + RN_CONV_MAX_SEGMENTS * 64;   // 80 + 48 + 10 + <1 = 139 KB
+constexpr int PA_TABLE = W_RING + W_STAGES * W_STAGE;    // source offset of every patch pixel (plane 0), one dword each
+constexpr int BASE_TABLE = PA_TABLE + PIX_PX * 4;        // 2 x 256 dwords: patch offset of every tile pixel, a ring of two tiles
+constexpr int SEG_TABLE = BASE_TABLE + 2 * BM * 4;       // segment descriptors the tile set-ups need (see HaloSeg)
+constexpr int LDS_BYTES = SEG_TABLE + 16 * 4 + RN_CONV_MAX_SEGMENTS * 64;   // 80 + 48 + 2.5 + 2 + <1 = 133 KB
 
 // What the three tile set-ups read of a segment, copied into LDS once per kernel: reading ConvArgs through the
 // scalar cache cost each set-up a chain of dependent s_loads (the segment search alone one per segment) — measured
@@ -94,10 +95,101 @@ __device__ __forceinline__ HaloSeg halo_seg(const char* smem, int si) {
   return g;
 }
 
-template <bool OUT_F32, bool HAS_RES, bool BN_BWD = false>   // BN_BWD: rn_conv_big_epi.h
+// Work unit of a virtual id (rn_conv_dev.h, ConvArgs::split_f): a whole tile, or part `part` of `nparts` of a tile of the
+// launch's last round — the channel chunks [part * nch / nparts, (part + 1) * nch / nparts) of it.
+// SPLIT launches (the split last round, rn_conv_dev.h): work unit v = l * split_s + part is part `part` of tile
+// split_f + l — the channel chunks [part * nch / split_s, (part + 1) * nch / split_s) of it.  The whole-tile launches
+// (SPLIT = false) compile to the round-3 code: unit = tile tile_of(v, total_tiles), every chunk.
+struct HaloUnit { int tile, begin, end; };
+template <bool SPLIT>
+__device__ __forceinline__ HaloUnit halo_unit(int v, const ConvArgs& a, int total, int nch) {
+  HaloUnit u;
+  if (!SPLIT) {
+    u.tile = tile_of(v, total); u.begin = 0; u.end = nch;
+  } else {
+    const int S = a.split_s;
+    const float rS = rn_rcp((float)S);
+    const int l = rn_fdiv(v, S, rS), part = v - l * S;
+    u.tile = a.split_f + l;
+    u.begin = rn_fdiv(part * nch, S, rS);
+    u.end = rn_fdiv((part + 1) * nch, S, rS);
+  }
+  return u;
+}
+template <bool SPLIT>
+__device__ __forceinline__ int halo_tile_of(int v, const ConvArgs& a, int total) {
+  if (!SPLIT) return tile_of(v, total);
+  return a.split_f + rn_fdiv(v, a.split_s, rn_rcp((float)a.split_s));
+}
+
+// ---- a part of a split tile (rnet_hip.h: rn_conv_problem.splitk_ws) ------------------------------------------------
+// EVERY part stores its raw fp32 accumulators (lane-linear, 16 B per lane and store) into its slot; parts 1.. then count
+// themselves in and are done.  Part 0 waits for the count; its epilogue then REBUILDS the accumulators from the slots, one
+// 32-pixel block at a time, parts added in order (deterministic) — its own slot included, so that the registers the K loop
+// accumulated in are dead after the stores (big_epilogue<.., FROM_WS>): `acc += slot` on the live registers, and all eight
+// blocks rebuilt up front, both made the allocator spill 130 - 350 bytes per lane, and a kernel with scratch pays ~40 us
+// per LAUNCH on this stack (the runtime attaches scratch memory per dispatch: measured, gpurun_out/r04c).  The hand-off
+// uses no cache-wide operation: the slots are written with WRITE-THROUGH stores (sc1) and read back with sc1 loads
+// (cdna_hip_programming.md section 6, guideline 16, R1): every storing wave drains its stores, a barrier, ONE lane bumps
+// the tile's arrival counter (relaxed, agent scope); part 0 polls the counter relaxed, a barrier, then sc1 loads.  (The
+// first version released / acquired at agent scope: buffer_wbl2 writes back the whole L2 of the XCD — the previous launch's
+// output tiles — and buffer_inv drops it, weights included, for every workgroup on that XCD: +30 us per launch.)
+// Producers never wait, so the owner's wait cannot deadlock; it is bounded all the same (2 s of the 100 MHz clock -> status
+// word 1023 = 1).  Called by all eight waves with their barrier counts aligned.  Returns true for part 0 (the caller runs
+// the tile's epilogue).
+// One slot = 256 KB = [wave][32 x (64 lanes x 16 B)]; buffer addressing: ONE lane offset register, the piece is a scalar offset.
+typedef unsigned halo_u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void halo_split_store(const f32x16_t (&acc)[4][2], const ConvArgs& args, int slot, int voff) {
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      (char*)args.ws + RN_SPLITK_HEADER_BYTES + (size_t)slot * RN_SPLITK_SLOT_BYTES, 0, RN_SPLITK_SLOT_BYTES, 0x00020000);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        halo_u32x4_t v = {__float_as_uint(acc[i][j][q * 4]), __float_as_uint(acc[i][j][q * 4 + 1]),
+                          __float_as_uint(acc[i][j][q * 4 + 2]), __float_as_uint(acc[i][j][q * 4 + 3])};
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, ((i * 2 + j) * 4 + q) * 1024, 16);   // aux 16 = sc1: write-through
+      }
+}
+__device__ __forceinline__ bool halo_split_exchange(f32x16_t (&acc)[4][2], const ConvArgs& args, int c_v, int wave) {
+  const int S = args.split_s;
+  const int l = c_v / S;     // leftover tile index (scalar division, once)
+  const int part = c_v - l * S;
+  unsigned* const head = (unsigned*)args.ws;
+  unsigned* const cnt = head + l;
+  const unsigned lane_ = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const bool first = wave == 0 && lane_ == 0;
+  const int voff = (int)(wave * 32768 + lane_ * 16);
+  halo_split_store(acc, args, l * S + part, voff);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (part > 0) {
+    if (first) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return false;
+  }
+  if (first) {
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)(S - 1)) {
+      __builtin_amdgcn_s_sleep(16);
+      if (wall_clock64() - t0 > 200000000ull) {
+        __hip_atomic_store(head + 1023, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+    __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+  }
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  return true;
+}
+
+template <bool OUT_F32, bool HAS_RES, bool BN_BWD = false, bool SPLIT = false>   // BN_BWD: rn_conv_big_epi.h
 __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int total = args.total_tiles;
+  const int total = SPLIT ? args.vtotal : args.total_tiles;   // work units: tiles, or the parts of the split last round
   const int G = gridDim.x;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -108,11 +200,17 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
   int stamp_n_[4] = {0, 0, 0, 0};
 #endif
   int p_v = blockIdx.x;        // virtual tile id; exhausted when >= total
-  int p_chunk = 0, p_nch = 0;  // chunk of that tile / its chunk count
+  int p_chunk = 0, p_nch = 0;  // chunk of that unit / the chunk its range ends at
   int p_wrap = 0;              // input channel chunks before they repeat (split-bf16 weight planes)
-  int p_par = 0;               // patch buffer it goes to
+  int p_par = 0;               // patch buffer it goes to; bit 1: parity of the tile's ordinal (ring slot of its base table)
   __amdgpu_buffer_rsrc_t rs_x;
-  // byte offset of this lane's 16 bytes of piece j at chunk 0 (or RN_OOB): kept in LDS, one dword per (j, thread)
+  // PA table (LDS, shared by the workgroup): byte offset of patch pixel p's first 16 bytes at chunk 0, or RN_OOB — one
+  // dword per patch pixel.  The four waves that stage the four 16-byte planes of a pixel used to compute the same
+  // (image, row, column) each: 5 entries per thread and tile, ~2 500 cycles of VALU in one load segment — and a long load
+  // segment stalls the other group at the barrier, so the two groups' set-ups cost a tile ~9 % of its time (DESIGN.md
+  // section 4).  Now every thread computes ONE patch pixel (the first two waves a second one: 640 pixels) and, waves
+  // 4..7, one entry of the base table the compute side reads at the tile's start (the patch offset of a tile pixel: each
+  // was computed by 8 lanes).  Written in the load segment of tap 5, first read two barriers later at the earliest.
   // The table address is rebuilt from a fresh lane id at every use (volatile: not hoisted), so that no
   // per-thread address stays live across the epilogue — the allocator would spill it and reload it, with an
   // `s_waitcnt vmcnt(0)`, in every load segment.
@@ -122,63 +220,82 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
 #define HALO_SETUP_STAMP(k_)
 #endif
 #define HALO_LANE(dst_) asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(dst_))
-#define HALO_PA_AT(j_, ln_) (*(unsigned*)(smem + PA_TABLE + (j_) * 2048 + wave * 256 + (ln_) * 4))
+// entry of the pixel this lane stages in piece j: pixel block 2j + wave/4, one pixel per lane
+#define HALO_PA_AT(j_, ln_) (*(unsigned*)(smem + PA_TABLE + ((2 * (j_) + (wave >> 2)) * 64 + (int)(ln_)) * 4))
+#define HALO_PA_PX(p_) (*(unsigned*)(smem + PA_TABLE + (p_) * 4))
+#define HALO_BASE_AT(slot_, m_) (*(int*)(smem + BASE_TABLE + (slot_) * (BM * 4) + (m_) * 4))
 
 #define HALO_SETUP_PIX()                                                                              \
   do {                                                                                                \
-    const int tile__ = tile_of(p_v, total);                                                           \
+    const int tile__ = halo_tile_of<SPLIT>(p_v, args, total);                                         \
     const int si__ = halo_seg_of_tile(smem, tile__);                                                  \
     const HaloSeg sg__ = halo_seg(smem, si__);                                                        \
     const int lt__ = tile__ - sg__.tile_begin;                                                        \
-    const int m0__ = rn_fdiv(lt__, sg__.n_tiles, __frcp_rn((float)sg__.n_tiles)) * BM;                \
+    const int m0__ = rn_fdiv(lt__, sg__.n_tiles, rn_rcp((float)sg__.n_tiles)) * BM;                \
     const int H__ = sg__.H, W__ = sg__.W, PS__ = sg__.pix_stride, W1__ = sg__.pitch, H1__ = H__ + 1;  \
     const int HW__ = H__ * W__;                                                                       \
-    p_nch = sg__.CinP / BK;                                                                           \
+    {                                                                                                 \
+      const HaloUnit un__ = halo_unit<SPLIT>(p_v, args, total, sg__.CinP / BK);                       \
+      p_chunk = un__.begin;                                                                           \
+      p_nch = un__.end;                                                                               \
+    }                                                                                                 \
     p_wrap = sg__.cwrap / BK;                                                                         \
     rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)sg__.x, 0,                                        \
                                              (int)((long long)sg__.N * HW__ * PS__ * 2), 0x00020000); \
     const int ml__ = (m0__ + BM - 1 < sg__.M ? m0__ + BM - 1 : sg__.M - 1);                           \
-    const float rHW__ = __frcp_rn((float)HW__), rW__ = __frcp_rn((float)W__);                         \
-    const float rW1__ = __frcp_rn((float)W1__), rH1__ = __frcp_rn((float)H1__);                       \
+    const float rHW__ = rn_rcp((float)HW__), rW__ = rn_rcp((float)W__);                         \
+    const float rW1__ = rn_rcp((float)W1__), rH1__ = rn_rcp((float)H1__);                       \
     const int nf__ = rn_fdiv(m0__, HW__, rHW__), nl__ = rn_fdiv(ml__, HW__, rHW__);                   \
     const int Gf__ = nf__ * H1__ + rn_fdiv(m0__ - nf__ * HW__, W__, rW__) + 1;   /* padded row of the first pixel */ \
     const int Gl__ = nl__ * H1__ + rn_fdiv(ml__ - nl__ * HW__, W__, rW__) + 1;                        \
     const int plast__ = (Gl__ - Gf__ + 3) * W1__;   /* last patch pixel: the zero right of the last row */ \
     unsigned ln__;                                                                                    \
     HALO_LANE(ln__);                                                                                  \
-    /* piece j of wave w = plane (w & 3), pixel block 2j + (w >> 2): 64 consecutive patch pixels, one per lane */ \
-    _Pragma("unroll") for (int j = 0; j < PIECES; ++j) {                                              \
-      const int p = (2 * j + (wave >> 2)) * 64 + (int)ln__;                                           \
+    const int t__ = wave * 64 + (int)ln__;                                                            \
+    /* patch pixel t (and 512 + t for the first two waves): plane 0's byte offset; piece j of wave w stages plane */ \
+    /* (w & 3) of pixel block 2j + (w >> 2) and adds its plane's 16 bytes at issue */                  \
+    _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                                   \
+      if (k == 1 && wave >= (PIX_PX - 512) / 64) break;                                               \
+      const int p = t__ + k * 512;                                                                    \
       const int prow = rn_fdiv(p, W1__, rW1__), pcol = p - prow * W1__;                               \
       const int Gp = Gf__ - 1 + prow;                                                                 \
       const int n = rn_fdiv(Gp, H1__, rH1__);                                                         \
       const int iy = Gp - n * H1__ - 1, ix = pcol - 1;                                                \
       const bool ok = (unsigned)iy < (unsigned)H__ && (unsigned)ix < (unsigned)W__ && p < plast__ &&  \
                       n < sg__.N;                                                                     \
-      HALO_PA_AT(j, ln__) = ok ? (unsigned)(((((long long)n * H__ + iy) * W__ + ix) * PS__ + (wave & 3) * 8) * 2) : RN_OOB; \
+      HALO_PA_PX(p) = ok ? (unsigned)((((n * H__ + iy) * W__ + ix) * PS__) * 2) : RN_OOB;   /* < 2 GiB: checked by the host */ \
     }                                                                                                 \
+    if (wave >= 4) {   /* base table of this tile (ring slot = ordinal parity): tile pixel t - 256 */  \
+      int m = m0__ + t__ - 256;                                                                       \
+      m = m < sg__.M ? m : sg__.M - 1;                                                                \
+      const int n = rn_fdiv(m, HW__, rHW__);                                                          \
+      const int rem = m - n * HW__;                                                                   \
+      const int oy = rn_fdiv(rem, W__, rW__), ox = rem - oy * W__;                                    \
+      HALO_BASE_AT((p_par >> 1) & 1, t__ - 256) = ((n * H1__ + oy + 1 - Gf__) * W1__ + ox) * 16;      \
+    }                                                                                                 \
+    p_par ^= 2;                                                                                       \
   } while (0)
 
 // one piece of the next chunk's patch (piece index compile time); after the last piece the stream advances
 #define HALO_ISSUE_PIX(j_, pa_)                                                                       \
   do {                                                                                                \
     const int pc__ = p_chunk < p_wrap ? p_chunk : (p_chunk < 2 * p_wrap ? p_chunk - p_wrap : p_chunk - 2 * p_wrap); \
-    const unsigned v__ = (pa_) == RN_OOB ? RN_OOB : (pa_) + (unsigned)(pc__ * (BK * 2));              \
+    const unsigned v__ = (pa_) == RN_OOB ? RN_OOB : (pa_) + (unsigned)(pc__ * (BK * 2) + (wave & 3) * 16); \
     if (!(HALO_ABLATE & 2))                                                                           \
-      dma16(rs_x, smem + p_par * PIX_BYTES + (wave & 3) * PLANE + (2 * (j_) + (wave >> 2)) * 1024, v__); \
+      dma16(rs_x, smem + (p_par & 1) * PIX_BYTES + (wave & 3) * PLANE + (2 * (j_) + (wave >> 2)) * 1024, v__); \
     if ((j_) == PIECES - 1 && p_v < total) {                                                          \
       p_par ^= 1;                                                                                     \
       if (++p_chunk == p_nch) {                                                                       \
-        p_chunk = 0;                                                                                  \
-        p_v += G;                                                                                     \
-        if (p_v < total) {                                                                            \
+        p_v = SPLIT ? total : p_v + G;   /* SPLIT: one unit per workgroup, no next-tile code */       \
+        if (!SPLIT && p_v < total) {                                                                  \
           HALO_SETUP_STAMP(32);                                                                       \
           HALO_SETUP_PIX();                                                                           \
           HALO_SETUP_STAMP(33);                                                                       \
         } else {  /* end of the stream: the remaining pieces are zero fills into the dead buffer */   \
           unsigned ln2__;                                                                             \
           HALO_LANE(ln2__);                                                                           \
-          _Pragma("unroll") for (int q = 0; q < PIECES; ++q) HALO_PA_AT(q, ln2__) = RN_OOB;           \
+          HALO_PA_PX(wave * 64 + (int)ln2__) = RN_OOB;                                                \
+          if (wave < (PIX_PX - 512) / 64) HALO_PA_PX(512 + wave * 64 + (int)ln2__) = RN_OOB;          \
         }                                                                                             \
       }                                                                                               \
     }                                                                                                 \
@@ -186,7 +303,7 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
 
   // ---- issue side, weights: the tile / chunk / tap whose 16 KB are being DMA'd (3 steps ahead) -------------
   int w_v = blockIdx.x;
-  int w_chunk = 0, w_nch = 0;
+  int w_chunk = 0, w_nch = 0, w_end = 0;   // chunk, chunks of the whole tile (the K stride of a tap), end of the unit's range
   __amdgpu_buffer_rsrc_t rs_w;
   unsigned b_off;              // piece 0 (rows wave*16 + lane/4 of the tile); piece 1 is 128 rows further
   unsigned w_step1 = 0;        // byte distance of piece 1, or RN_OOB when those rows are past the packed weights
@@ -194,12 +311,17 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
 
 #define HALO_SETUP_W()                                                                                \
   do {                                                                                                \
-    const int tile__ = tile_of(w_v, total);                                                           \
+    const int tile__ = halo_tile_of<SPLIT>(w_v, args, total);                                         \
     const int si__ = halo_seg_of_tile(smem, tile__);                                                  \
     const HaloSeg sg__ = halo_seg(smem, si__);                                                        \
     const int lt__ = tile__ - sg__.tile_begin;                                                        \
-    const int n0__ = (lt__ - rn_fdiv(lt__, sg__.n_tiles, __frcp_rn((float)sg__.n_tiles)) * sg__.n_tiles) * BN; \
+    const int n0__ = (lt__ - rn_fdiv(lt__, sg__.n_tiles, rn_rcp((float)sg__.n_tiles)) * sg__.n_tiles) * BN; \
     w_nch = sg__.CinP / BK;                                                                           \
+    {                                                                                                 \
+      const HaloUnit un__ = halo_unit<SPLIT>(w_v, args, total, w_nch);                                \
+      w_chunk = un__.begin;                                                                           \
+      if (SPLIT) w_end = un__.end;                                                                    \
+    }                                                                                                 \
     const int Ktot__ = 9 * sg__.CinP;                                                                 \
     const int rows__ = ((sg__.Cout + 127) / 128) * 128; /* packed weight rows */                      \
     rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)sg__.w, 0, (int)((long long)rows__ * Ktot__ * 2), \
@@ -225,17 +347,16 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
       dma16(rs_w, st__ + (NW + wave) * 1024, w_step1 == RN_OOB ? RN_OOB : b_off + koff__ + w_step1);  \
     }                                                                                                 \
     if ((tap_) == 8) {                                                                                \
-      if (++w_chunk == w_nch) {                                                                       \
-        w_chunk = 0;                                                                                  \
-        w_v += G;                                                                                     \
-        if (w_v < total) { HALO_SETUP_STAMP(34); HALO_SETUP_W(); HALO_SETUP_STAMP(35); }              \
+      if (++w_chunk == (SPLIT ? w_end : w_nch)) {                                                     \
+        w_v = SPLIT ? total : w_v + G;                                                                \
+        if (!SPLIT && w_v < total) { HALO_SETUP_STAMP(34); HALO_SETUP_W(); HALO_SETUP_STAMP(35); }    \
       }                                                                                               \
     }                                                                                                 \
   } while (0)
 
   // ---- compute side: the tile being accumulated ---------------------------------------------------------
   int c_v = blockIdx.x;
-  int c_chunk = 0, c_nch = 0, c_par = 0;
+  int c_chunk = 0, c_nch = 0, c_par = 0;   // c_nch: the chunk the unit's range ends at
   int c_m0 = 0, c_n0 = 0, c_si = 0, c_W1 = 0;
   int base[4];   // LDS byte offset (inside a patch) of this lane's 16 bytes of its 4 fragment rows at tap (0,0)
   // weights: row = lane&31 of a 32-row tile, 16-byte slot = 2*kk + (lane>>5), XOR-swizzled by (row/4)&3.
@@ -252,31 +373,27 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
 
 #define HALO_SETUP_COMPUTE()                                                                          \
   do {                                                                                                \
-    const int tile__ = tile_of(c_v, total);                                                           \
+    const int tile__ = halo_tile_of<SPLIT>(c_v, args, total);                                         \
     c_si = halo_seg_of_tile(smem, tile__);                                                            \
     const HaloSeg sg__ = halo_seg(smem, c_si);                                                        \
     const int lt__ = tile__ - sg__.tile_begin;                                                        \
-    const int mt__ = rn_fdiv(lt__, sg__.n_tiles, __frcp_rn((float)sg__.n_tiles));                     \
+    const int mt__ = rn_fdiv(lt__, sg__.n_tiles, rn_rcp((float)sg__.n_tiles));                     \
     c_m0 = mt__ * BM;                                                                                 \
     c_n0 = (lt__ - mt__ * sg__.n_tiles) * BN;                                                         \
-    c_nch = sg__.CinP / BK;                                                                           \
-    c_chunk = 0;                                                                                      \
-    const int H__ = sg__.H, W__ = sg__.W, H1__ = H__ + 1, HW__ = H__ * W__;                           \
+    {                                                                                                 \
+      const HaloUnit un__ = halo_unit<SPLIT>(c_v, args, total, sg__.CinP / BK);                       \
+      c_chunk = un__.begin;                                                                           \
+      c_nch = un__.end;                                                                               \
+    }                                                                                                 \
     c_W1 = sg__.pitch;                                                                                \
-    const float rHW__ = __frcp_rn((float)HW__), rW__ = __frcp_rn((float)W__);                         \
-    const int nf__ = rn_fdiv(c_m0, HW__, rHW__);                                                      \
-    const int Gf__ = nf__ * H1__ + rn_fdiv(c_m0 - nf__ * HW__, W__, rW__) + 1;                        \
     unsigned lq__;                                                                                    \
     HALO_LANE(lq__);                                                                                  \
     const int fr = (int)(lq__ & 31), fh = (int)(lq__ >> 5);                                           \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
-      int m = c_m0 + wave_m * 128 + i * 32 + fr;                                                      \
-      m = m < sg__.M ? m : sg__.M - 1;                                                                \
-      const int n = rn_fdiv(m, HW__, rHW__);                                                          \
-      const int rem = m - n * HW__;                                                                   \
-      const int oy = rn_fdiv(rem, W__, rW__), ox = rem - oy * W__;                                    \
-      base[i] = ((n * H1__ + oy + 1 - Gf__) * c_W1 + ox) * 16 + fh * PLANE;                           \
-    }                                                                                                 \
+    /* the patch offsets of this lane's four fragment pixels: written by the pixel stream's set-up of this tile (a */ \
+    /* pass or more ago, barriers in between), ring slot = parity of the tile's ordinal */             \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                     \
+      base[i] = HALO_BASE_AT((c_par >> 1) & 1, wave_m * 128 + i * 32 + fr) + fh * PLANE;              \
+    c_par ^= 2;                                                                                       \
   } while (0)
 
   f32x16_t acc[4][2];
@@ -294,7 +411,7 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
 #define HALO_READ(tap_)                                                                               \
   do {                                                                                                \
     const char* wb__ = smem + W_RING + ((tap_) % 3) * W_STAGE;                                        \
-    const char* pb__ = smem + c_par * PIX_BYTES + (((tap_) / 3) * c_W1 + ((tap_) % 3)) * 16;          \
+    const char* pb__ = smem + (c_par & 1) * PIX_BYTES + (((tap_) / 3) * c_W1 + ((tap_) % 3)) * 16;    \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) wt0[j] = *(const bf16x8_t*)(wb__ + off_w0 + j * 2048); \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) px0[i] = *(const bf16x8_t*)(pb__ + base[i]);        \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) wt1[j] = *(const bf16x8_t*)(wb__ + (off_w0 ^ 32) + j * 2048); \
@@ -350,15 +467,17 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
   __syncthreads();
   HALO_SETUP_PIX();
   HALO_SETUP_W();
+  __syncthreads();   // the PA / base tables are written by all waves
   HALO_SETUP_COMPUTE();
-  big_acc_init<OUT_F32, HAS_RES>(acc, args, c_si, c_n0, wave);
-  // patch of chunk 0 (5 pieces), then the weights of stream steps 0 and 1
+  big_acc_init<OUT_F32, HAS_RES>(acc, args, c_si, c_n0, wave, !SPLIT || c_chunk == 0);   // the bias belongs to part 0 of a split tile
+  // patch of the unit's first chunk (5 pieces), then the weights of stream steps 0 and 1
   {
     unsigned pa0[PIECES];
     unsigned ln0;
     HALO_LANE(ln0);
 #pragma unroll
     for (int j = 0; j < PIECES; ++j) pa0[j] = HALO_PA_AT(j, ln0);
+    __syncthreads();   // a one-chunk tile: the last piece below already sets up the NEXT tile's tables
     HALO_ISSUE_PIX(0, pa0[0]); HALO_ISSUE_PIX(1, pa0[1]); HALO_ISSUE_PIX(2, pa0[2]); HALO_ISSUE_PIX(3, pa0[3]);
     HALO_ISSUE_PIX(4, pa0[4]);
   }
@@ -376,16 +495,17 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
 #define HALO_CHUNK_END()                                                                  \
   c_par ^= 1;                                                                             \
   if (__builtin_expect(++c_chunk == c_nch, 0)) {                                          \
+    if (SPLIT) break;   /* a part of a split tile, the workgroup's only unit: handled behind the loop */ \
     HALO_EPI_PROBE(8);                                                                    \
     big_epilogue<OUT_F32, HAS_RES, BN_BWD>(acc, args, c_si, c_m0, c_n0, wave,                              \
-                          smem + (c_par ^ 1) * PIX_BYTES + wave * 4096 /* 32 KB of the dead 40 KB patch */); \
+                          smem + ((c_par ^ 1) & 1) * PIX_BYTES + wave * 4096 /* 32 KB of the dead 40 KB patch */); \
     HALO_EPI_PROBE(9);                                                                    \
     HALO_EPI_COUNT();                                                                     \
     if (c_v + G >= total) break;                                                          \
     c_v += G;                                                                             \
     HALO_LANE_CONSTS();                                                                   \
     HALO_SETUP_COMPUTE();                                                                 \
-    big_acc_init<OUT_F32, HAS_RES>(acc, args, c_si, c_n0, wave);                          \
+    big_acc_init<OUT_F32, HAS_RES>(acc, args, c_si, c_n0, wave, !SPLIT || c_chunk == 0);  \
     HALO_EPI_PROBE_AT(11, 2);                                                             \
   }
 // One loop body for both groups (the barrier that follows the compute segment sits before the tile-end work for
@@ -429,6 +549,19 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
     HALO_STEP(1) HALO_STEP(2) HALO_STEP(3) HALO_STEP(4) HALO_STEP(5) HALO_STEP(6) HALO_STEP(7)
     HALO_STEP(8) HALO_STEP(0)
   }
+  if (SPLIT) {   // partial accumulators through the workspace; part 0 then runs the tile's epilogue
+    if (wave_m == 1) HALO_BARRIER();   // group 0 left the loop one barrier ahead of group 1
+    if (halo_split_exchange(acc, args, c_v, wave)) {
+      BigEpiSrc src;
+      unsigned lane2_;
+      HALO_LANE(lane2_);
+      src.slots = (const char*)args.ws + RN_SPLITK_HEADER_BYTES + (size_t)c_v * RN_SPLITK_SLOT_BYTES;   // part 0: c_v = l * S
+      src.nparts = args.split_s;
+      src.voff = (int)(wave * 32768 + lane2_ * 16);
+      big_epilogue<OUT_F32, HAS_RES, BN_BWD, true>(acc, args, c_si, c_m0, c_n0, wave,
+                                                   smem + ((c_par ^ 1) & 1) * PIX_BYTES + wave * 4096, src);
+    }
+  }
 #ifdef HALO_PROF
   if (blockIdx.x == 0 && tid == 0) { g_halo_clk[2] = clock64(); g_halo_clk[3] = wall_clock64(); }
 #endif
@@ -436,37 +569,51 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
 
 }  // namespace
 
-int rn_launch_conv_halo(const ConvArgs& a, bool out_f32, const rn_launch_opts& opts, hipStream_t st) {
-  static bool attr_set = false;
+template <bool SPLIT>
+static int halo_launch(const ConvArgs& a, bool out_f32, int grid, hipStream_t st) {
+  static bool attr_set = false;   // per template instantiation
   if (!attr_set) {
-    RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<false, false>,
+    RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<false, false, false, SPLIT>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<false, true>,
+    RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<false, true, false, SPLIT>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<true, false>,
+    RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<true, false, false, SPLIT>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<true, true>,
+    RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<true, true, false, SPLIT>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<false, false, true>,
+    RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<false, false, true, SPLIT>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_set = true;
   }
-  // one persistent workgroup per CU (minus the CUs kept for RCCL; opts.max_workgroups caps it)
-  const int grid = rn_persistent_grid(a.total_tiles, rn_num_cus(), opts);
   bool has_res = false;   // one residual input anywhere -> the variant that carries the residual path
   for (int i = 0; i < a.nseg; ++i) has_res = has_res || a.seg[i].residual != nullptr;
   const dim3 g3(grid), b3(512);
   if (a.seg[0].bn_y) {   // data gradient + stage 1 of the BatchNorm backward reduction (validated by the caller)
-    hipLaunchKernelGGL((conv_halo_kernel<false, false, true>), g3, b3, LDS_BYTES, st, a);
+    hipLaunchKernelGGL((conv_halo_kernel<false, false, true, SPLIT>), g3, b3, LDS_BYTES, st, a);
   } else if (out_f32) {
-    if (has_res) hipLaunchKernelGGL((conv_halo_kernel<true, true>), g3, b3, LDS_BYTES, st, a);
-    else hipLaunchKernelGGL((conv_halo_kernel<true, false>), g3, b3, LDS_BYTES, st, a);
+    if (has_res) hipLaunchKernelGGL((conv_halo_kernel<true, true, false, SPLIT>), g3, b3, LDS_BYTES, st, a);
+    else hipLaunchKernelGGL((conv_halo_kernel<true, false, false, SPLIT>), g3, b3, LDS_BYTES, st, a);
   } else {
-    if (has_res) hipLaunchKernelGGL((conv_halo_kernel<false, true>), g3, b3, LDS_BYTES, st, a);
-    else hipLaunchKernelGGL((conv_halo_kernel<false, false>), g3, b3, LDS_BYTES, st, a);
+    if (has_res) hipLaunchKernelGGL((conv_halo_kernel<false, true, false, SPLIT>), g3, b3, LDS_BYTES, st, a);
+    else hipLaunchKernelGGL((conv_halo_kernel<false, false, false, SPLIT>), g3, b3, LDS_BYTES, st, a);
   }
   RN_CHECK_LAUNCH();
   return RN_OK;
+}
+
+// Whole tiles: one persistent workgroup per CU (minus the CUs kept for RCCL; opts.max_workgroups caps it).  With a
+// split plan (rn_splitk_plan: a.split_s > 1) the launch is TWO kernels: the full rounds — tiles [0, split_f), the
+// round-3 kernel untouched — and the SPLIT instantiation for the tiles of the last round, one part per workgroup.  (The
+// unit mapping inside the persistent loop cost the whole-tile kernel 10 % — registers — for a 5 % shorter tail.)
+int rn_launch_conv_halo(const ConvArgs& a, bool out_f32, const rn_launch_opts& opts, hipStream_t st) {
+  if (a.split_s <= 1) return halo_launch<false>(a, out_f32, rn_persistent_grid(a.total_tiles, rn_num_cus(), opts), st);
+  if (a.split_f > 0) {
+    ConvArgs full = a;
+    full.total_tiles = a.split_f;   // tile_of() then numbers the first split_f tiles
+    const int rc = halo_launch<false>(full, out_f32, rn_persistent_grid(full.total_tiles, rn_num_cus(), opts), st);
+    if (rc != RN_OK) return rc;
+  }
+  return halo_launch<true>(a, out_f32, a.vtotal, st);
 }
 
 // patch pixels the worst tile of an [N, H, W] tensor needs (rows from one above its first pixel row to one below

@@ -18,7 +18,7 @@ LIB_PATH_F16 = os.environ.get("RNET_HIP_LIB_F16") or os.path.join(_HERE, "librne
 RN_DT_F32, RN_DT_BF16 = 0, 1
 RN_ACT_NONE, RN_ACT_RELU, RN_ACT_RELU6, RN_ACT_SWISH = 0, 1, 2, 3
 RN_CONV_MAX_SEGMENTS = 10
-ABI_VERSION = 4
+ABI_VERSION = 5
 # f32 kernels of the dtype=float32 prediction convs (detection_head.py:80-88) as split-bf16 planes (rn_conv_segment.w_terms)
 PRED_W_TERMS = int(os.environ.get("RNET_PRED_W_TERMS", "2"))
 ACT_IDS = {None: RN_ACT_NONE, "none": RN_ACT_NONE, "relu": RN_ACT_RELU, "relu6": RN_ACT_RELU6,
@@ -70,7 +70,8 @@ class ConvSegment(Structure):
 class ConvProblem(Structure):
     _fields_ = [("R", c_int32), ("S", c_int32), ("stride_h", c_int32), ("stride_w", c_int32),
                 ("pad_top", c_int32), ("pad_left", c_int32), ("act", c_int32), ("out_dtype", c_int32),
-                ("num_segments", c_int32), ("seg", ConvSegment * RN_CONV_MAX_SEGMENTS), ("opts", LaunchOpts)]
+                ("num_segments", c_int32), ("seg", ConvSegment * RN_CONV_MAX_SEGMENTS), ("opts", LaunchOpts),
+                ("splitk_ws", c_void_p), ("splitk_ws_bytes", c_int64)]
 
 
 class WgradSegment(Structure):
@@ -148,6 +149,8 @@ _SIGNATURES = {
     "rn_conv_cout_pad": (c_int, [c_int]),
     "rn_conv_tile_rows": (c_int, [POINTER(ConvProblem)]),
     "rn_conv_kernel_id": (c_int, [POINTER(ConvProblem)]),
+    "rn_conv_splitk_workspace_bytes": (c_size_t, [POINTER(ConvProblem)]),
+    "rn_conv_splitk_workspace_max_bytes": (c_size_t, []),
     "rn_conv_cin_pad": (c_int, [c_int]),
     "rn_depthwise_conv2d_nhwc_fwd": (c_int, [POINTER(DwProblem), c_void_p]),
     "rn_pack_depthwise_weight": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
@@ -365,3 +368,23 @@ def i64_array(values):
 def current_stream():
     import torch
     return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def new_splitk_workspace(lib_, device):
+    """The zero-filled split-K workspace (rn_conv_problem.splitk_ws) of ONE engine: its conv launches are ordered on one
+    stream, so they share it.  Attach it to every rn_conv_problem when the problem is created — the dispatcher looks at
+    it (rn_conv_kernel_id / rn_conv_tile_rows).
+    OFF unless RNET_SPLITK=1: measured on MI355X (round 4) the split last round does not pay — a part
+    hands its tile over as 256 KB of fp32 accumulators, and writing + reading them back costs as much as the half tile of
+    MFMA work it saves (head towers at B = 32: 556 - 565 us against 540 - 550 us with whole tiles; batch-8 inference:
+    171 against 166 us).  The capability stays built and tested (tests/test_gpu_conv.py, tests/test_gpu_bench_shapes.py)."""
+    import torch
+    if os.environ.get("RNET_SPLITK", "0") != "1":
+        return None
+    return torch.zeros((int(lib_.rn_conv_splitk_workspace_max_bytes()),), dtype=torch.uint8, device=device)
+
+
+def attach_splitk_workspace(problem, ws):
+    if ws is not None:
+        problem.splitk_ws, problem.splitk_ws_bytes = ws.data_ptr(), ws.numel()
+    return problem

@@ -69,6 +69,8 @@ class InferenceEngine:
         with torch.cuda.device(self.dev):
             self._alloc()
             self.load_variables(variables)
+            # split-K of the persistent conv kernels' last round: the launches of this engine run in order on one stream
+            self.splitk_ws = _C.new_splitk_workspace(self.lib, self.dev)
             self._build()
 
     # ---- buffers ---------------------------------------------------------------------------
@@ -200,7 +202,7 @@ class InferenceEngine:
     def _add_conv_launch(self, ops):
         first = ops[0]
         c0 = self.g.convs[first["conv"]]
-        p = _C.ConvProblem()
+        p = _C.attach_splitk_workspace(_C.ConvProblem(), self.splitk_ws)
         p.opts = self.launch_opts
         p.R = p.S = c0["k"]
         p.stride_h = p.stride_w = c0["stride"]
@@ -271,7 +273,7 @@ class InferenceEngine:
                     _C.check(lib.rn_pack_image_nhwc4(pimg, B, H, W, pt, pl, self.Hp, self.Wp, pin, st),
                              "rn_pack_image_nhwc4")
                 self.steps.append((pack, "pack_stem_input"))
-                p = _C.ConvProblem()
+                p = _C.attach_splitk_workspace(_C.ConvProblem(), self.splitk_ws)
                 p.opts = self.launch_opts
                 p.R, p.S, p.stride_h, p.stride_w, p.pad_top, p.pad_left = self.stem_k, 1, 2, 2, 0, 0
                 p.act = _C.ACT_IDS[op["act"]]

@@ -36,6 +36,15 @@ def _engine(cuda, size, B):
     return eng
 
 
+@pytest.fixture
+def splitk_env(request, monkeypatch):
+    """'split': the engine attaches a split-K workspace to its conv launches (RNET_SPLITK=1: off by default, it does not
+    pay — retinanet/_C.py::new_splitk_workspace), so the launches checked below run their last round split along K"""
+    if request.param == "split":
+        monkeypatch.setenv("RNET_SPLITK", "1")
+    return request.param
+
+
 def _conv_sig(eng, name, p):
     segs = tuple((s.N, s.H, s.W, s.Cin, s.pix_stride, s.Ho, s.Wo, s.Cout, bool(s.scale), bool(s.shift), bool(s.bias),
                   bool(s.residual), bool(s.residual) and s.residual == s.y, s.w_terms, bool(s.bn_partial),
@@ -136,9 +145,16 @@ def _check_conv_launch(cuda, eng, name, p):
         d.N, d.H, d.W, d.Cin, d.pix_stride, d.Ho, d.Wo, d.Cout = s.N, s.H, s.W, s.Cin, s.pix_stride, s.Ho, s.Wo, s.Cout
         keep.append(wp)
         per_seg.append(t)
+    ws = None
+    if p.splitk_ws:      # the engine's launches carry a split-K workspace (the last round of a persistent grid is split along K)
+        ws = torch.zeros((int(p.splitk_ws_bytes),), dtype=torch.uint8, device=cuda)
+        q.splitk_ws, q.splitk_ws_bytes = ws.data_ptr(), ws.numel()
     assert lib.rn_conv_kernel_id(ctypes.byref(q)) == lib.rn_conv_kernel_id(ctypes.byref(p)), name
+    assert lib.rn_conv_splitk_workspace_bytes(ctypes.byref(q)) == lib.rn_conv_splitk_workspace_bytes(ctypes.byref(p)), name
     _C.check(lib.rn_conv2d_nhwc_fwd(ctypes.byref(q), _C.current_stream()), name)
     torch.cuda.synchronize()
+    if ws is not None:   # arrival counters consumed, status word (a part gave up waiting) clear
+        assert int(ws[:4096].view(torch.int32).abs().sum().item()) == 0, name
     for i, t in enumerate(per_seg):
         s = p.seg[i]
         xp = _pad_input(t["x"][..., :s.Cin], p.R, p.S, p.stride_h, p.pad_top, p.pad_left, s.Ho, s.Wo)
@@ -242,8 +258,9 @@ def _check_wgrad_launch(cuda, eng, name, p):
     assert torch.equal(dw, first), name
 
 
-@pytest.mark.parametrize("size,B", [(640, 32), (1024, 32)], ids=["bench-640-b32", "bench-1024-b32"])
-def test_every_distinct_launch_of_the_bench_engine(cuda, size, B):
+@pytest.mark.parametrize("size,B,splitk_env", [(640, 32, "whole"), (1024, 32, "whole"), (640, 32, "split")],
+                         ids=["bench-640-b32", "bench-1024-b32", "bench-640-b32-splitk"], indirect=["splitk_env"])
+def test_every_distinct_launch_of_the_bench_engine(cuda, size, B, splitk_env):
     eng = _engine(cuda, size, B)
     convs, seen = [], set()
     for name, p in eng.conv_launches:
@@ -258,9 +275,12 @@ def test_every_distinct_launch_of_the_bench_engine(cuda, size, B):
             seen.add(sig)
             wgrads.append((name, p))
     kinds = {}
+    n_split = 0
     for name, p in convs:
         k = (name.split(":")[0], eng.lib.rn_conv_kernel_id(ctypes.byref(p)))
         kinds[k] = kinds.get(k, 0) + 1
+        n_split += int(eng.lib.rn_conv_splitk_workspace_bytes(ctypes.byref(p)) > 0)
+    assert (n_split >= 4) if splitk_env == "split" else (n_split == 0), n_split   # towers / FPN / stage 4 split their last round
     # the engine at this size runs all three forward kernel families, as forward and as data-gradient launches
     for k in (("fwd", 0), ("fwd", 1), ("fwd", 2), ("dgrad", 0), ("dgrad", 1), ("dgrad", 2)):
         assert kinds.get(k, 0) >= 1, kinds

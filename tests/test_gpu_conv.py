@@ -52,8 +52,9 @@ def _seed(case):
     return zlib.crc32(repr(case).encode()) % (2 ** 31)
 
 
-def _conv_gpu(cuda, segs, k, stride, pad, act, out_f32, opts=None):
-    """opts: rn_launch_opts fields of THIS launch (kernel family, persistent grid, ...): per-call, no process state"""
+def _conv_gpu(cuda, segs, k, stride, pad, act, out_f32, opts=None, splitk_ws=None, expect_split=None):
+    """opts: rn_launch_opts fields of THIS launch (kernel family, persistent grid, ...): per-call, no process state;
+    splitk_ws: zero-filled uint8 device tensor handed to the launch as rn_conv_problem.splitk_ws"""
     from retinanet import _C
     lib = _lib()
     p = _C.ConvProblem()
@@ -96,6 +97,10 @@ def _conv_gpu(cuda, segs, k, stride, pad, act, out_f32, opts=None):
         g.N, g.H, g.W, g.Cin, g.pix_stride, g.Ho, g.Wo, g.Cout = N, H, W, cin, cin, Ho, Wo, cout
         keep += [x, wp, sc, sh, res, bs]
         outs.append(y)
+    if splitk_ws is not None:
+        p.splitk_ws, p.splitk_ws_bytes = splitk_ws.data_ptr(), splitk_ws.numel()
+    if expect_split is not None:
+        assert (lib.rn_conv_splitk_workspace_bytes(ctypes.byref(p)) > 0) == expect_split
     _C.check(lib.rn_conv2d_nhwc_fwd(ctypes.byref(p), _C.current_stream()), "conv")
     torch.cuda.synchronize()
     return [y.float().cpu() for y in outs]
@@ -271,6 +276,48 @@ def test_conv_halo_kernel(cuda, build, case):
     torch.testing.assert_close(got, big, rtol=1.0 / 128 if not out_f32 else 1e-4, atol=scale * (1 / 256 if not out_f32 else 1e-5))
     if not out_f32:
         assert (got != big).float().mean().item() < 0.02
+
+
+SPLITK_CASES = [
+    # N, H, W, Cin, Cout, act, residual, f32 output, bias, w_terms, persistent workgroups (0 = one per CU) -> tiles / rounds
+    # (a launch splits when its tiles have >= 8 chunks of 32 input channels: >= 4 chunks per part)
+    (2, 80, 80, 256, 256, "relu", False, False, False, 1, 0),    # 50 tiles on 256 CUs: one round, every tile in 2 parts
+    (1, 40, 40, 256, 512, None, True, False, False, 1, 6),       # 14 tiles on 6 workgroups: 2 rounds + 2 tiles in 2 parts
+    (1, 20, 20, 128, 720, None, False, True, False, 2, 5),       # f32 output, two weight planes: 6 tiles on 5, 1 tile in 2 parts
+    (2, 24, 24, 256, 256, "relu", False, False, True, 1, 4),     # bias in the accumulators: part 0 only
+    (3, 16, 16, 512, 256, "relu6", False, False, False, 1, 2),   # 3 tiles on 2: 1 round + 1 tile in 2 parts of 8 chunks
+    (1, 30, 30, 512, 256, "relu", False, False, False, 1, 0),    # 4 tiles on 256 CUs: 4 parts of 4 chunks each
+]
+
+
+@pytest.mark.parametrize("build,case", _builds(SPLITK_CASES, SPLITK_CASES[:3], "splitk-"))
+def test_conv_halo_split_last_round(cuda, build, case):
+    """rn_conv_problem.splitk_ws: the tiles of a persistent launch's last round are cut along K over several workgroups
+    (parts 1.. hand their fp32 accumulators to part 0 through the workspace).  Same float64 reference as the whole-tile
+    launch; the exchange adds in part order, so repeats are bit-identical; the workspace header is zero again afterwards
+    (arrival counters consumed, status word clear)."""
+    N, H, W, Cin, Cout, act, use_res, out_f32, use_bias, terms, wgs = case
+    g = torch.Generator().manual_seed(_seed(case))
+    s = {"x": torch.randn((N, H, W, Cin), generator=g),
+         "w": torch.randn((3, 3, Cin, Cout), generator=g) / math.sqrt(9 * Cin), "w_terms": terms}
+    if use_bias:
+        s["bias"] = torch.randn((Cout,), generator=g)
+    else:
+        s["scale"], s["shift"] = torch.rand((Cout,), generator=g) + 0.5, torch.randn((Cout,), generator=g) * 0.1
+    if use_res:
+        s["residual"] = torch.randn((N, H, W, Cout), generator=g)
+    opts = dict(conv_tile=2, max_workgroups=wgs)
+    ws = torch.zeros((80 << 20,), dtype=torch.uint8, device=cuda)
+    want = _conv_ref(s, 3, 1, 1, act, out_f32)
+    runs = [_conv_gpu(cuda, [s], 3, 1, 1, act, out_f32, opts, splitk_ws=ws, expect_split=True)[0] for _ in range(3)]
+    _close(runs[0], want, out_f32)
+    for r in runs[1:]:
+        assert torch.equal(r, runs[0])
+    assert int(ws[:4096].view(torch.int32).abs().sum().item()) == 0
+    whole = _conv_gpu(cuda, [s], 3, 1, 1, act, out_f32, opts)[0]          # no workspace: whole tiles, another sum order
+    _close(whole, want, out_f32)
+    if not out_f32:
+        assert (runs[0] != whole).float().mean().item() < 0.02
 
 
 BIAS_CASES = [
