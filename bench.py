@@ -114,13 +114,15 @@ def synth_ground_truth(B, size, seed):
 
 
 # ------------------------------------------------------------------------------------------------
-def run_train(args, dev, rank, world):
+def run_train(args, dev, rank, world, params=None):
+    """params: another configuration than BASELINE configs[2] (the `extra` entries of the N = 1 line)"""
     from retinanet.cfg import default_params
     from retinanet.dataloader import LabelEncoder
     from retinanet.model import ModelBuilder
     from retinanet.model.train_engine import TrainEngine
     B = args.train_batch
-    params = default_params(input_size=args.size, batch_train=B * world)
+    if params is None:
+        params = default_params(input_size=args.size, batch_train=B * world)
     builder = ModelBuilder(params, "train", device=dev, seed=1337)
     model = builder()
     rx = [builder.FREEZE_VARS_REGEX[n] for n in params.training.freeze_variables]
@@ -401,6 +403,72 @@ def run_infer(args, dev, rank):
     return res, params, model
 
 
+def run_extras(args, dev):
+    """Driver-visible numbers for BASELINE configs[3] and configs[4] on one GPU: a few training steps of
+    ResNet50-1024x1024 (bf16, 16 images: the HBM-bound FPN path) and of EfficientNet-B3 640x640 under its own policy
+    (`mixed_float16`: IEEE-half storage on librnet_hip_f16.so, dynamic loss scale), plus EfficientNet-B3 batch-8 inference
+    with soft-NMS.  Each with its dominant bracketed kernel: MFMA TFLOP/s for config 3, HBM GB/s of algorithmic bytes for
+    config 4 (its 1x1 convs, depthwise convs and BatchNorm passes are HBM-bound)."""
+    import copy
+    from retinanet.cfg import default_params, efficientnet_params
+    from retinanet.model import ModelBuilder
+    extra = {}
+    a3 = copy.copy(args)
+    a3.size, a3.train_batch, a3.steps, a3.warmup, a3.no_exclusive = 1024, 16, 5, 2, True
+    r3, _, _, eng = run_train(a3, dev, 0, 1, default_params(input_size=1024, batch_train=16))
+    rl = r3["roofline"]
+    extra["config3"] = {"workload": "ResNet50-1024x1024 bf16 training, 16 images on one GPU (BASELINE configs[3] shard), "
+                                    "resnet_initial frozen", "value": round(16 * a3.steps / r3["dt"], 2), "unit": "images/s",
+                        "ms_per_step": round(r3["dt"] / a3.steps * 1e3, 3), "steps": a3.steps, "warmup": a3.warmup,
+                        "final_loss": round(r3["loss"], 4),
+                        "roofline": {k: rl[k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "launches_per_step",
+                                                        "avg_launch_us", "ms_per_step", "algorithmic_gflop_per_launch")}}
+    del eng, r3
+    torch.cuda.empty_cache()
+    p4 = efficientnet_params("efficientnet-b3", input_size=640)
+    p4.architecture.batch_norm.use_sync = False
+    a4 = copy.copy(args)
+    a4.size, a4.train_batch, a4.steps, a4.warmup, a4.no_exclusive = 640, 32, 5, 2, True
+    r4, _, _, eng = run_train(a4, dev, 0, 1, p4)
+    hb = r4["roofline"]["hbm_kernels"]["kernels"]
+    conv = dict(r4["roofline"].get("other_conv_kernels", {}))
+    dom = max(hb, key=lambda k: hb[k]["ms_per_step"]) if hb else None
+    extra["config4"] = {"workload": "EfficientNet-B3 640x640 training, 32 images on one GPU (BASELINE configs[4] shard), "
+                                    f"policy {p4.floatx.precision}: IEEE-half storage on librnet_hip_f16.so, dynamic loss scale",
+                        "value": round(32 * a4.steps / r4["dt"], 2), "unit": "images/s", "dtype": "f16",
+                        "ms_per_step": round(r4["dt"] / a4.steps * 1e3, 3), "steps": a4.steps, "warmup": a4.warmup,
+                        "final_loss": round(r4["loss"], 4),
+                        "roofline": ({"bound": "hbm", "achieved": hb[dom]["GB/s"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                      "frac": hb[dom]["frac"], "kernel": dom, "ms_per_step": hb[dom]["ms_per_step"],
+                                      "launches_per_step": hb[dom]["launches_per_step"],
+                                      "algorithmic_MB_per_launch": hb[dom]["algorithmic_MB_per_launch"],
+                                      "other_hbm_kernels": {k: {kk: v[kk] for kk in ("GB/s", "ms_per_step")}
+                                                            for k, v in hb.items() if k != dom},
+                                      "mfma_kernels": {r4["roofline"]["kernel"]: {"ms_per_step": r4["roofline"]["ms_per_step"],
+                                                                                   "tflops": r4["roofline"]["achieved"]}, **conv}}
+                                     if dom else None)}
+    del eng, r4
+    torch.cuda.empty_cache()
+    bi = ModelBuilder(p4, "val", device=dev, seed=1337)
+    mi = bi()
+    infer = bi.add_post_processing_stage(mi, capture_graph=True)
+    x = torch.randn((args.infer_batch, 640, 640, 3), generator=torch.Generator().manual_seed(1337)).to(dev)
+    for _ in range(3):
+        infer(x)
+    torch.cuda.synchronize()
+    n = 20
+    t0 = time.perf_counter()
+    for _ in range(n):
+        out = infer(x)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    extra["config4"]["infer"] = {"workload": f"EfficientNet-B3 640x640 inference batch={args.infer_batch}, {p4.inference.mode} "
+                                             "(HIP-graph replay), reference initialisers", "value": round(args.infer_batch / dt, 2),
+                                 "unit": "images/s", "ms_per_step": round(dt * 1e3, 3), "steps": n,
+                                 "valid_detections": out["valid_detections"].tolist()}
+    return extra
+
+
 def cpu_baseline(params_train, model_train, frozen, params_infer, model_infer, budget_s=75.0):
     """the CPU restatement (oracle/, PyTorch-CPU fp32 — NOT TensorFlow) on the host cores.
     Inference = BASELINE configs[0] (ResNet50-640, batch 1, forward + decode + per-class top-k 5000 + PerClassHardNMS)
@@ -508,6 +576,7 @@ def main():
                     help="skip the one extra one-stream step behind `roofline.exclusive` (profile runs: the kernel "
                          "trace then holds warm-up + timed steps only, like the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip `extra`: BASELINE configs[3] / [4] on one GPU")
     ap.add_argument("--no-probe", action="store_true", help="skip the MFMA-only probe behind roofline.sustained")
     args = ap.parse_args()
 
@@ -600,6 +669,11 @@ def main():
         if not args.no_infer:
             inf, p_inf, m_inf = run_infer(args, dev, rank)
             line["infer"] = inf
+        if not args.no_extras:
+            try:
+                line["extra"] = run_extras(args, dev)
+            except Exception as e:   # noqa: BLE001 — the headline line must survive a failure in the side measurements
+                line["extra"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(p_train, m_train, frozen, p_inf, m_inf)
     if rank == 0:

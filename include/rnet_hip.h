@@ -31,7 +31,9 @@ typedef enum {
   RN_EINVAL = -1, /* bad shape / dtype / alignment / null pointer */
   RN_ENOMEM = -2, /* workspace too small */
   RN_EHIP = -3,   /* a HIP runtime call or launch failed (message has hipGetErrorString) */
-  RN_ECOMM = -4   /* collective failure */
+  RN_ECOMM = -4,  /* collective failure */
+  RN_EUNSUPPORTED = -5 /* well-formed input of a kind this library does not implement (rn_jpeg_*: progressive / arithmetic
+                        * / 12-bit / CMYK / unusual sampling): callers may route it elsewhere; RN_EINVAL = corrupt input */
 } rn_status;
 
 enum { RN_DT_F32 = 0, RN_DT_BF16 = 1 };
@@ -204,6 +206,9 @@ int rn_handle_get_launch_opts(const rn_handle* h, rn_launch_opts* opts);
 /* collective: rn_comm_init into slot `slot` (0..3) of the handle; rn_handle_comm returns it (NULL when unset) */
 int rn_handle_comm_init(rn_handle* h, int slot, const void* unique_id /* host */, int rank, int world);
 void* rn_handle_comm(const rn_handle* h, int slot);
+/* destroys the communicator of `slot` (a no-op on an empty slot) and frees the slot: a bootstrap that failed on some rank
+ * after rn_handle_comm_init abandons the communicator everywhere, and a later rn_handle_comm_init must find the slot empty */
+int rn_handle_comm_destroy(rn_handle* h, int slot);
 
 /* ---------------------------------------------------------------------------------------
  * K1/K2 (a5,a6,a8)  tf.keras.layers.Conv2D as used by resnet.py:118-144, fpn_base.py:44-50,
@@ -390,6 +395,10 @@ int rn_pack_conv_weight_dgrad_batch(const rn_dgrad_pack* items /* host */, int n
 /* f32 [P,C] -> bf16 [P,Cpad], zero padded channels (dy of the 36/720-channel prediction convs is
  * padded to a multiple of 64 so it can be the K dimension of the dgrad GEMM) */
 int rn_cast_pad_f32_to_bf16(const float* x, void* y, int64_t P, int C, int Cpad, void* stream);
+/* dst[c] = add + sum_{r < rows} src[r * row_stride + c] for c < n, rows added in index order: the bias gradient of a conv
+ * shared by the pyramid levels (sum of its per-level column sums, executor.py:427-428 through tape.gradient) and the
+ * batch's positive count + 1 (retinanet_loss.py:38) without a library reduction. */
+int rn_reduce_rows_f32(const float* src, int rows, int64_t row_stride, int n, float add, float* dst, void* stream);
 /* y[n,2h,2w,:] = x[n,h,w,:], zero elsewhere; bf16 NHWC */
 int rn_upsample_zero2x(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, void* stream);
 /* y[n,2h,2w,:] (+)= x[n,h,w,:], bf16: accumulate = 0 is rn_upsample_zero2x (zeros at the other positions),
@@ -705,7 +714,7 @@ size_t rn_example_serialize(const uint8_t* image, size_t image_bytes, int64_t im
  * §8(f)-4  JPEG decoding for the TFRecord input path (host only; tf.io.decode_image in dataloader/tfrecord_parser.py:20-23):
  * baseline / extended-sequential Huffman JPEG, grayscale or YCbCr with 4:4:4 / 4:2:2 / 4:4:0 / 4:2:0 sampling, restart
  * intervals; libjpeg's defaults restated (islow integer IDCT, fancy chroma up-sampling, 16-bit fixed-point YCbCr->RGB).
- * Progressive / arithmetic / 12-bit / CMYK files return RN_EINVAL with a message. */
+ * Progressive / arithmetic / 12-bit / CMYK files return RN_EUNSUPPORTED with a message (corrupt ones RN_EINVAL). */
 int rn_jpeg_info(const void* data, size_t len, int32_t* width, int32_t* height, int32_t* components);
 int rn_jpeg_decode(const void* data, size_t len, uint8_t* rgb_out /* [height,width,3] */, size_t out_bytes);
 int rn_jpeg_idct_islow(const int32_t* coef64 /* dequantized, row-major */, uint8_t* out64);

@@ -11,6 +11,11 @@ void rn_set_error(const char* fmt, ...);
 // rn_core.hip: min(items, CUs not reserved for RCCL, opts.max_workgroups); CU count of the current device
 int rn_persistent_grid(int work_items, int num_cu, const rn_launch_opts& opts);
 int rn_num_cus();
+// index of the current device, 0..63 (rn_core.hip).  Kernel function attributes (hipFuncSetAttribute) are PER DEVICE: a
+// process-wide `static bool attr_set` left the second GPU of a process without its dynamic-LDS limit.
+int rn_device_slot();
+// true the first time it is evaluated for the current device with this flag word (benign race: setting twice is harmless)
+#define RN_FIRST_ON_DEVICE(mask_) (!(((mask_) >> rn_device_slot()) & 1ull) && (((mask_) |= 1ull << rn_device_slot()), true))
 int rn_validate_launch_opts(const rn_launch_opts& opts, const char* who);
 
 #define RN_CHECK_ARG(cond, ...)  \

@@ -10,6 +10,8 @@
 // wave's 4 KB of LDS; no workgroup barrier.  The caller re-initialises acc for its next tile (big_acc_init).
 #ifndef RN_CONV_BIG_EPI_H_
 #define RN_CONV_BIG_EPI_H_
+#include <type_traits>
+
 #include "rn_conv_dev.h"
 
 #ifdef HALO_PROF   // probe builds (tools/probes/build_halo_ablate.sh): cycle stamps of workgroup 0, thread 0
@@ -248,109 +250,125 @@ _Pragma("unroll") for (int pass = 0; pass < (LOADS ? 4 : 0); ++pass) {          
   rv[buf_][pass] = make_uint4(0u, 0u, 0u, 0u);                                                      \
   if (has_side && nok && m < M) rv[buf_][pass] = *(const uint4*)(side + (long long)m * Cout + nr);  \
 }
-    BIG_RES_PREFETCH(0, 0);
+    // The block loop is compiled several times, for the modes a launch can be in — PLAIN (conv (+bias) output, relu / relu6
+    // on the packed pairs at most) with or without the fused statistics, and the general arithmetic — and ONE uniform
+    // branch per tile picks the copy.  With the mode tested inside the loop every 8-row pass ran ~9 scalar branches around
+    // the code it did not need (swish, the affine path, the statistics): 16 passes x ~350 cycles made the epilogue of a
+    // 256 x 256 tile 8 000 cycles, 8 % of a head-tower tile and half of a short-K 1x1 tile (round-4 probe; the stores
+    // themselves need ~2 000).  The clamp of PLAIN is branch-free: bounds -32768 / 32767 are the identity on packed i16.
+    const uint32_t lo2 = clamp_lo ? 0u : 0x80008000u, hi2 = clamp_hi ? RN_SIX_X2 : 0x7fff7fffu;
+    // (mode flags: 0 = off, 1 = on, 2 = decided at run time — the one fully general copy)
+    auto blocks = [&](auto plain_c, auto stats_c, auto round2_c, auto swish_c) __attribute__((always_inline)) {
+      constexpr bool PLAIN = decltype(plain_c)::value;     // compile time: no affine / residual / swish arithmetic
+      constexpr int STATS = decltype(stats_c)::value, ROUND2 = decltype(round2_c)::value, SWISH = decltype(swish_c)::value;
+      BIG_RES_PREFETCH(0, 0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      EPI_STAMP(13 + 2 * i);
-      if (i + 1 < 4) BIG_RES_PREFETCH((i + 1) & 1, i + 1);
-      if (FROM_WS) big_epi_rebuild<2>(&acc[i][0], src, i, 0);
+      for (int i = 0; i < 4; ++i) {
+        EPI_STAMP(13 + 2 * i);
+        if (i + 1 < 4) BIG_RES_PREFETCH((i + 1) & 1, i + 1);
+        if (FROM_WS) big_epi_rebuild<2>(&acc[i][0], src, i, 0);
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int nl = j * 32 + g * 8 + fh * 4;   // channel inside the wave's 64
-          uint2 pk;
-          pk.x = pack2(acc[i][j][g * 4 + 0], acc[i][j][g * 4 + 1]);
-          pk.y = pack2(acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
-          // ds_write_b64 is serviced in contiguous 16-lane groups over a 128-byte bank row: rows fr and fr + 8 share
-          // the 16-byte unit (same fr & 7), so the 8-byte half is flipped for rows 8-15 / 24-31 — 16 distinct 8-byte
-          // chunks per group instead of a 2-way conflict (SQ_LDS_BANK_CONFLICT was 18-25 % of the LDS cycles of the
-          // short-K 1x1 launches); the read-back swaps the halves back for odd passes
-          *(uint2*)(patch + fr * 128 + (((nl >> 3) ^ (fr & 7)) << 4) + ((((nl >> 2) ^ (fr >> 3)) & 1) << 3)) = pk;
-        }
-      EPI_STAMP(14 + 2 * i);
-      // read the block's four 8-row passes back before touching any of them: one LDS round trip per block instead
-      // of four dependent ones (each pass used to wait for its own read, then for a scalar reload of the output
-      // pointer, before its store could issue: ~600 cycles per pass of pure latency, 16 passes per tile)
-      uint4 vb[4];
-#pragma unroll
-      for (int pass = 0; pass < 4; ++pass) {
-        const int row = pass * 8 + rrow;
-        const uint4 t = *(const uint4*)(patch + row * 128 + ((ru ^ (row & 7)) << 4));
-        vb[pass] = (pass & 1) ? make_uint4(t.z, t.w, t.x, t.y) : t;   // rows 8-15 / 24-31: halves were flipped
-      }
-#pragma unroll
-      for (int pass = 0; pass < 4; ++pass) {
-        const int row = pass * 8 + rrow;
-        const uint4 v = vb[pass];
-        const int m = mw0 + i * 32 + row;
-        if (m < M && nok) {
-          uint4 ov;
-          if (plain) {
-            // raw conv output (training: BatchNorm follows) or bias-initialised accumulators: the transposed
-            // bf16 rows are the result, up to relu / relu6 on the packed pairs (see below)
-            ov = v;
-            if (clamp_lo) {
-              ov.x = pk_max_i16(ov.x, 0u); ov.y = pk_max_i16(ov.y, 0u); ov.z = pk_max_i16(ov.z, 0u); ov.w = pk_max_i16(ov.w, 0u);
-            }
-            if (clamp_hi) {
-              ov.x = pk_min_i16(ov.x, RN_SIX_X2); ov.y = pk_min_i16(ov.y, RN_SIX_X2);
-              ov.z = pk_min_i16(ov.z, RN_SIX_X2); ov.w = pk_min_i16(ov.w, RN_SIX_X2);
-            }
-          } else {
-            const uint4 r4 = HAS_RES ? rv[i & 1][LOADS ? pass : 0] : make_uint4(0u, 0u, 0u, 0u);
-            float f[8] = {bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y), bf_lo(v.z), bf_hi(v.z), bf_lo(v.w), bf_hi(v.w)};
-            const float rr[8] = {bf_lo(r4.x), bf_hi(r4.x), bf_lo(r4.y), bf_hi(r4.y),
-                                 bf_lo(r4.z), bf_hi(r4.z), bf_lo(r4.w), bf_hi(r4.w)};
-            // f = the Conv2D layer's bf16 output; BatchNorm affine -> bf16 tensor -> residual add -> bf16 tensor
-#pragma unroll
-            for (int q = 0; q < 8; ++q) f[q] = f[q] * sc[q] + sf[q];
-            if (round2) {
-#pragma unroll
-              for (int q = 0; q < 8; q += 2) {   // v_cvt_pk_bf16_f32 (RNE) and back
-                const uint32_t pq = pack2(f[q], f[q + 1]);
-                f[q] = bf_lo(pq); f[q + 1] = bf_hi(pq);
-              }
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) f[q] += rr[q];
-            if (act == RN_ACT_SWISH) {
-#pragma unroll
-              for (int q = 0; q < 8; ++q) { const float u = rn_rb(f[q]); f[q] = u / (1.0f + __expf(-u)); }
-            }
-            ov.x = pack2(f[0], f[1]); ov.y = pack2(f[2], f[3]); ov.z = pack2(f[4], f[5]); ov.w = pack2(f[6], f[7]);
-            // relu / relu6 on the packed bf16 pairs: rounding is monotonic and 0 and 6 are bf16 values, so
-            // act(round(x)) == round(act(x)); as signed 16-bit integers every negative bf16 is below 0 and
-            // positive ones order like their values (one v_pk_max_i16 / v_pk_min_i16 per two outputs)
-            if (clamp_lo) {
-              ov.x = pk_max_i16(ov.x, 0u); ov.y = pk_max_i16(ov.y, 0u); ov.z = pk_max_i16(ov.z, 0u); ov.w = pk_max_i16(ov.w, 0u);
-            }
-            if (clamp_hi) {
-              ov.x = pk_min_i16(ov.x, RN_SIX_X2); ov.y = pk_min_i16(ov.y, RN_SIX_X2);
-              ov.z = pk_min_i16(ov.z, RN_SIX_X2); ov.w = pk_min_i16(ov.w, RN_SIX_X2);
-            }
+          for (int g = 0; g < 4; ++g) {
+            const int nl = j * 32 + g * 8 + fh * 4;   // channel inside the wave's 64
+            uint2 pk;
+            pk.x = pack2(acc[i][j][g * 4 + 0], acc[i][j][g * 4 + 1]);
+            pk.y = pack2(acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
+            // ds_write_b64 is serviced in contiguous 16-lane groups over a 128-byte bank row: rows fr and fr + 8 share
+            // the 16-byte unit (same fr & 7), so the 8-byte half is flipped for rows 8-15 / 24-31 — 16 distinct 8-byte
+            // chunks per group instead of a 2-way conflict (SQ_LDS_BANK_CONFLICT was 18-25 % of the LDS cycles of the
+            // short-K 1x1 launches); the read-back swaps the halves back for odd passes
+            *(uint2*)(patch + fr * 128 + (((nl >> 3) ^ (fr & 7)) << 4) + ((((nl >> 2) ^ (fr >> 3)) & 1) << 3)) = pk;
           }
-          if (!(EPI_ABLATE & 16) || ov.x == 0x12345678u) *(uint4*)(ybase + (long long)(i * 32 + pass * 8) * row_bytes) = ov;
-          if (stats) {
-            const float w[8] = {bf_lo(ov.x), bf_hi(ov.x), bf_lo(ov.y), bf_hi(ov.y),
-                                bf_lo(ov.z), bf_hi(ov.z), bf_lo(ov.w), bf_hi(ov.w)};
-            if (BN_BWD) {
-              const uint4 y4 = rv[i & 1][LOADS ? pass : 0];
-              const float yy[8] = {bf_lo(y4.x), bf_hi(y4.x), bf_lo(y4.y), bf_hi(y4.y),
-                                   bf_lo(y4.z), bf_hi(y4.z), bf_lo(y4.w), bf_hi(y4.w)};
+        EPI_STAMP(14 + 2 * i);
+        // read the block's four 8-row passes back before touching any of them: one LDS round trip per block instead
+        // of four dependent ones (each pass used to wait for its own read, then for a scalar reload of the output
+        // pointer, before its store could issue: ~600 cycles per pass of pure latency, 16 passes per tile)
+        uint4 vb[4];
 #pragma unroll
-              for (int q = 0; q < 8; ++q) {
-                const float g = (yy[q] * sc[q] + sf[q]) > 0.0f ? w[q] : 0.0f;
-                st0[q] += g;
-                st1[q] += g * ((yy[q] - mu[BN_BWD ? q : 0]) * is[BN_BWD ? q : 0]);
-              }
+        for (int pass = 0; pass < 4; ++pass) {
+          const int row = pass * 8 + rrow;
+          const uint4 t = *(const uint4*)(patch + row * 128 + ((ru ^ (row & 7)) << 4));
+          vb[pass] = (pass & 1) ? make_uint4(t.z, t.w, t.x, t.y) : t;   // rows 8-15 / 24-31: halves were flipped
+        }
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+          const int row = pass * 8 + rrow;
+          const uint4 v = vb[pass];
+          const int m = mw0 + i * 32 + row;
+          if (m < M && nok) {
+            uint4 ov;
+            if (PLAIN) {
+              // raw conv output (training: BatchNorm follows) or bias-initialised accumulators: the transposed
+              // bf16 rows are the result, up to relu / relu6 on the packed pairs (see below)
+              ov.x = pk_min_i16(pk_max_i16(v.x, lo2), hi2); ov.y = pk_min_i16(pk_max_i16(v.y, lo2), hi2);
+              ov.z = pk_min_i16(pk_max_i16(v.z, lo2), hi2); ov.w = pk_min_i16(pk_max_i16(v.w, lo2), hi2);
             } else {
+              const uint4 r4 = HAS_RES ? rv[i & 1][LOADS ? pass : 0] : make_uint4(0u, 0u, 0u, 0u);
+              float f[8] = {bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y), bf_lo(v.z), bf_hi(v.z), bf_lo(v.w), bf_hi(v.w)};
+              const float rr[8] = {bf_lo(r4.x), bf_hi(r4.x), bf_lo(r4.y), bf_hi(r4.y),
+                                   bf_lo(r4.z), bf_hi(r4.z), bf_lo(r4.w), bf_hi(r4.w)};
+              // f = the Conv2D layer's bf16 output; BatchNorm affine -> bf16 tensor -> residual add -> bf16 tensor
 #pragma unroll
-              for (int q = 0; q < 8; ++q) { st0[q] += w[q]; st1[q] += w[q] * w[q]; }
+              for (int q = 0; q < 8; ++q) f[q] = f[q] * sc[q] + sf[q];
+              if (ROUND2 == 1 || (ROUND2 == 2 && round2)) {
+#pragma unroll
+                for (int q = 0; q < 8; q += 2) {   // v_cvt_pk_bf16_f32 (RNE) and back
+                  const uint32_t pq = pack2(f[q], f[q + 1]);
+                  f[q] = bf_lo(pq); f[q + 1] = bf_hi(pq);
+                }
+              }
+#pragma unroll
+              for (int q = 0; q < 8; ++q) f[q] += rr[q];
+              if (SWISH == 1 || (SWISH == 2 && act == RN_ACT_SWISH)) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { const float u = rn_rb(f[q]); f[q] = u / (1.0f + __expf(-u)); }
+              }
+              ov.x = pack2(f[0], f[1]); ov.y = pack2(f[2], f[3]); ov.z = pack2(f[4], f[5]); ov.w = pack2(f[6], f[7]);
+              // relu / relu6 on the packed bf16 pairs: rounding is monotonic and 0 and 6 are bf16 values, so
+              // act(round(x)) == round(act(x)); as signed 16-bit integers every negative bf16 is below 0 and
+              // positive ones order like their values (one v_pk_max_i16 / v_pk_min_i16 per two outputs)
+              ov.x = pk_min_i16(pk_max_i16(ov.x, lo2), hi2); ov.y = pk_min_i16(pk_max_i16(ov.y, lo2), hi2);
+              ov.z = pk_min_i16(pk_max_i16(ov.z, lo2), hi2); ov.w = pk_min_i16(pk_max_i16(ov.w, lo2), hi2);
+            }
+            if (!(EPI_ABLATE & 16) || ov.x == 0x12345678u) *(uint4*)(ybase + (long long)(i * 32 + pass * 8) * row_bytes) = ov;
+            if (STATS == 1 || (STATS == 2 && stats)) {
+              const float w[8] = {bf_lo(ov.x), bf_hi(ov.x), bf_lo(ov.y), bf_hi(ov.y),
+                                  bf_lo(ov.z), bf_hi(ov.z), bf_lo(ov.w), bf_hi(ov.w)};
+              if (BN_BWD) {
+                const uint4 y4 = rv[i & 1][LOADS ? pass : 0];
+                const float yy[8] = {bf_lo(y4.x), bf_hi(y4.x), bf_lo(y4.y), bf_hi(y4.y),
+                                     bf_lo(y4.z), bf_hi(y4.z), bf_lo(y4.w), bf_hi(y4.w)};
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                  const float g = (yy[q] * sc[q] + sf[q]) > 0.0f ? w[q] : 0.0f;
+                  st0[q] += g;
+                  st1[q] += g * ((yy[q] - mu[BN_BWD ? q : 0]) * is[BN_BWD ? q : 0]);
+                }
+              } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { st0[q] += w[q]; st1[q] += w[q] * w[q]; }
+              }
             }
           }
         }
       }
+    };
+    typedef std::integral_constant<int, 0> off_t;
+    typedef std::integral_constant<int, 1> on_t;
+    typedef std::integral_constant<int, 2> runtime_t;
+    if constexpr (BN_BWD) {   // always plain, always with the (backward) statistics: one copy
+      blocks(std::true_type{}, on_t{}, off_t{}, off_t{});
+    } else if (plain) {
+      if (stats) blocks(std::true_type{}, on_t{}, off_t{}, off_t{});
+      else blocks(std::true_type{}, off_t{}, off_t{}, off_t{});
+    } else if (!stats && act != RN_ACT_SWISH) {
+      // the inference layers (folded BatchNorm [+ residual] + relu) and the accumulating data gradients
+      if (round2) blocks(std::false_type{}, off_t{}, on_t{}, off_t{});
+      else blocks(std::false_type{}, off_t{}, off_t{}, off_t{});
+    } else {
+      blocks(std::false_type{}, runtime_t{}, runtime_t{}, runtime_t{});   // swish (EfficientNet), or statistics of a non-plain launch
     }
     EPI_STAMP(21);
     if (stats) {

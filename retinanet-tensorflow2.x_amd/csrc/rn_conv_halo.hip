@@ -571,8 +571,8 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
 
 template <bool SPLIT>
 static int halo_launch(const ConvArgs& a, bool out_f32, int grid, hipStream_t st) {
-  static bool attr_set = false;   // per template instantiation
-  if (!attr_set) {
+  static unsigned long long attr_set = 0;   // per template instantiation, one bit per device
+  if (RN_FIRST_ON_DEVICE(attr_set)) {
     RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<false, false, false, SPLIT>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<false, true, false, SPLIT>,
@@ -583,7 +583,6 @@ static int halo_launch(const ConvArgs& a, bool out_f32, int grid, hipStream_t st
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<false, false, true, SPLIT>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    attr_set = true;
   }
   bool has_res = false;   // one residual input anywhere -> the variant that carries the residual path
   for (int i = 0; i < a.nseg; ++i) has_res = has_res || a.seg[i].residual != nullptr;

@@ -116,6 +116,14 @@ extern "C" int rn_handle_comm_init(rn_handle* h, int slot, const void* unique_id
   return rn_comm_init(unique_id, rank, world, &h->comm[slot]);
 }
 
+extern "C" int rn_handle_comm_destroy(rn_handle* h, int slot) {
+  RN_CHECK_ARG(h && slot >= 0 && slot < 4, "rn_handle_comm_destroy: bad handle / slot %d (0..3)", slot);
+  if (!h->comm[slot]) return RN_OK;
+  void* c = h->comm[slot];
+  h->comm[slot] = nullptr;
+  return rn_comm_destroy(c);
+}
+
 extern "C" void* rn_handle_comm(const rn_handle* h, int slot) {
   return (h && slot >= 0 && slot < 4) ? h->comm[slot] : nullptr;
 }
@@ -130,6 +138,12 @@ int rn_persistent_grid(int work_items, int num_cu, const rn_launch_opts& o) {
   if (o.max_workgroups > 0 && o.max_workgroups < g) g = o.max_workgroups;
   if (g < 1) g = 1;
   return work_items < g ? work_items : g;
+}
+
+int rn_device_slot() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) return 0;
+  return dev & 63;
 }
 
 int rn_num_cus() {   // of the current device; cached per device id

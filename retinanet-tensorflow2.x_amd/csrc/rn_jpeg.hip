@@ -220,12 +220,16 @@ int parse_headers(Decoder& d, size_t& scan_pos, bool header_only) {
     if (m == 0xC0 || m == 0xC1) {
       if (n < 6 || s[0] != 8) {
         rn_set_error("jpeg: only 8-bit precision is supported");
-        return RN_EINVAL;
+        return n < 6 ? RN_EINVAL : RN_EUNSUPPORTED;
       }
       d.height = be16(s + 1); d.width = be16(s + 3); d.ncomp = s[5];
-      if (d.width <= 0 || d.height <= 0 || (d.ncomp != 1 && d.ncomp != 3) || n < 6 + 3 * d.ncomp) {
-        rn_set_error("jpeg: unsupported frame (%d x %d, %d components)", d.width, d.height, d.ncomp);
+      if (d.width <= 0 || d.height <= 0 || d.ncomp < 1 || n < 6 + 3 * d.ncomp) {   // corrupt: not a job for another decoder
+        rn_set_error("jpeg: bad frame header (%d x %d, %d components)", d.width, d.height, d.ncomp);
         return RN_EINVAL;
+      }
+      if (d.ncomp != 1 && d.ncomp != 3) {   // CMYK / YCCK
+        rn_set_error("jpeg: unsupported frame (%d x %d, %d components)", d.width, d.height, d.ncomp);
+        return RN_EUNSUPPORTED;
       }
       if ((long long)d.width * d.height > (64ll << 20)) {   // untrusted bytes: a corrupt header must not ask for gigabytes
         rn_set_error("jpeg: frame %d x %d exceeds the 64 Mpixel limit", d.width, d.height);
@@ -237,21 +241,21 @@ int parse_headers(Decoder& d, size_t& scan_pos, bool header_only) {
         c.id = s[6 + 3 * i]; c.h = s[7 + 3 * i] >> 4; c.v = s[7 + 3 * i] & 15; c.tq = s[8 + 3 * i] & 3;
         if (c.h < 1 || c.h > 2 || c.v < 1 || c.v > 2) {
           rn_set_error("jpeg: sampling factor %dx%d of component %d is not supported", c.h, c.v, i);
-          return RN_EINVAL;
+          return (c.h < 1 || c.v < 1) ? RN_EINVAL : RN_EUNSUPPORTED;
         }
         d.hmax = c.h > d.hmax ? c.h : d.hmax;
         d.vmax = c.v > d.vmax ? c.v : d.vmax;
       }
       if (d.ncomp == 3 && (d.comp[1].h != 1 || d.comp[1].v != 1 || d.comp[2].h != 1 || d.comp[2].v != 1)) {
         rn_set_error("jpeg: chroma components must be sampled 1x1");
-        return RN_EINVAL;
+        return RN_EUNSUPPORTED;
       }
       if (d.ncomp == 1) { d.comp[0].h = d.comp[0].v = 1; d.hmax = d.vmax = 1; }   // a single component is never interleaved
       d.got_sof = true;
       if (header_only) return RN_OK;
     } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
       rn_set_error("jpeg: SOF%d (progressive / lossless / arithmetic) is not supported, only baseline Huffman", m - 0xC0);
-      return RN_EINVAL;
+      return RN_EUNSUPPORTED;
     } else if (m == 0xDB) {
       int q = 0;
       while (q < n) {
@@ -281,7 +285,7 @@ int parse_headers(Decoder& d, size_t& scan_pos, bool header_only) {
     } else if (m == 0xDA) {
       if (!d.got_sof || n < 1 || n < 1 + 2 * s[0] + 3 || s[0] != d.ncomp) {
         rn_set_error("jpeg: SOS before SOF, or a non-interleaved multi-scan file (not supported)");
-        return RN_EINVAL;
+        return d.got_sof ? RN_EUNSUPPORTED : RN_EINVAL;
       }
       for (int i = 0; i < d.ncomp; ++i) {
         int ci = -1;

@@ -202,16 +202,10 @@ extern "C" int rn_stem_conv_bn_relu_pool(const void* x, const void* w_packed, co
   RN_CHECK_ARG(2 * (Po - 1) - pool_pad_top < Hs && 2 * (Qo - 1) - pool_pad_left < Ws && Po > 0 && Qo > 0,
                "rn_stem_conv_bn_relu_pool: pooled size %d x %d against conv output %d x %d", Po, Qo, Hs, Ws);
   RN_CHECK_ARG(((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)y) % 16 == 0, "rn_stem_conv_bn_relu_pool: alignment");
-  static bool attr_set = false;
-  static int num_cu = 256;
-  if (!attr_set) {
+  static unsigned long long attr_set = 0;   // one bit per device
+  if (RN_FIRST_ON_DEVICE(attr_set))
     RN_CHECK_HIP(hipFuncSetAttribute((const void*)stem_pool_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-      num_cu = prop.multiProcessorCount;
-    attr_set = true;
-  }
+  const int num_cu = rn_num_cus();
   StemPoolArgs a;
   a.x = (const uint16_t*)x; a.w = (const uint16_t*)w_packed; a.scale = scale; a.shift = shift; a.y = (uint16_t*)y;
   a.N = N; a.Hp = Hp; a.Wp = Wp; a.Hs = Hs; a.Ws = Ws; a.Po = Po; a.Qo = Qo; a.pt = pool_pad_top; a.pl = pool_pad_left;

@@ -654,6 +654,25 @@ extern "C" int rn_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* str
   return RN_OK;
 }
 
+// ---- dst[c] = add + sum over rows of src[r * row_stride + c], rows added in index order (deterministic) -----------------
+// The bias gradient of a conv shared by the pyramid levels = the sum of its per-level column sums (a handful of rows), and
+// the per-image positive counts of a batch: one thread per column, no library reduction on the product path.
+__global__ void __launch_bounds__(TR_THREADS)
+reduce_rows_kernel(const float* __restrict__ src, int rows, long long row_stride, int n, float add, float* __restrict__ dst) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  float s = 0.0f;
+  for (int r = 0; r < rows; ++r) s += src[r * row_stride + c];
+  dst[c] = s + add;
+}
+extern "C" int rn_reduce_rows_f32(const float* src, int rows, int64_t row_stride, int n, float add, float* dst, void* stream) {
+  RN_CHECK_ARG(src && dst && rows > 0 && n > 0 && row_stride >= 0, "rn_reduce_rows_f32: bad argument");
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((n + TR_THREADS - 1) / TR_THREADS), dim3(TR_THREADS), 0, (hipStream_t)stream,
+                     src, rows, (long long)row_stride, n, add, dst);
+  RN_CHECK_LAUNCH();
+  return RN_OK;
+}
+
 // ---- zero-insertion upsample: y[n,2h,2w,:] = x[n,h,w,:], zeros elsewhere (dgrad of stride 2) ---
 __global__ void __launch_bounds__(TR_THREADS)
 upsample_zero_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int N, int H, int W, int C8, int Ho,

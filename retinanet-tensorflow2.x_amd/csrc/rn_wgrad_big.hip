@@ -328,7 +328,7 @@ bool rn_wgrad_big_plan(const rn_wgrad_problem* p, WgArgs& a) {
   long long CH = 0;
   // one round of the CUs the kernel may use: fewest split-K partials (opts.wgrad_target_blocks: no candidate search)
   const bool g_big_target_user = p->opts.wgrad_target_blocks > 0;
-  const long long g_big_target_blocks = g_big_target_user ? p->opts.wgrad_target_blocks : 256 - p->opts.reserved_cus;
+  const long long g_big_target_blocks = g_big_target_user ? p->opts.wgrad_target_blocks : rn_num_cus() - p->opts.reserved_cus;
   {
     static std::mutex mu;
     static std::unordered_map<std::string, long long> cache;
@@ -400,13 +400,12 @@ bool rn_wgrad_big_plan(const rn_wgrad_problem* p, WgArgs& a) {
 }
 
 int rn_launch_wgrad_big(const WgArgs& a, const rn_launch_opts& opts, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_set = 0;   // one bit per device
+  if (RN_FIRST_ON_DEVICE(attr_set)) {
     RN_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_big_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      LDS_BYTES));
     RN_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_big_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      LDS_BYTES));
-    attr_set = true;
   }
   bool linear = a.sh == 1 && a.sw == 1 && a.pt == (a.R - 1) / 2 && a.pl == (a.S - 1) / 2 && (a.R & 1) && (a.S & 1);
   for (int i = 0; i < a.nseg; ++i) {

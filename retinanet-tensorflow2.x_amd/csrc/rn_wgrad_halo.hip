@@ -406,10 +406,11 @@ bool rn_wgrad_halo_plan(const rn_wgrad_problem* const* ps, int ngroups, WhArgs& 
   a.ci_tiles = Cin / 64;
   a.total_steps = (int)steps;
   const int tiles = a.co_tiles * a.ci_tiles * ngroups;
-  // one round of the CUs the kernel may use: fewest split-K partials; a chunk is at least 24 steps long (2 when the
-  // caller sets the workgroup target: tests of the chunk seams)
-  long long blocks = p->opts.wgrad_target_blocks > 0 ? p->opts.wgrad_target_blocks : 256 - p->opts.reserved_cus;
-  const long long min_steps = p->opts.wgrad_target_blocks > 0 ? 2 : 24;
+  // one round of the CUs the kernel may use: fewest split-K partials; a chunk is at least 24 steps long — every chunk
+  // writes a 288 KB partial tile — unless the caller asks for MORE workgroups than the chip has (the tests of the chunk
+  // seams do: short chunks on purpose).  The two-stream engine's CU cap (wgrad_target_blocks = 176) keeps 24.
+  long long blocks = p->opts.wgrad_target_blocks > 0 ? p->opts.wgrad_target_blocks : rn_num_cus() - p->opts.reserved_cus;
+  const long long min_steps = p->opts.wgrad_target_blocks > rn_num_cus() ? 2 : 24;
   long long chunks = blocks / tiles;
   if (chunks < 1) chunks = 1;
   if (chunks > rn_cdiv(steps, min_steps)) chunks = rn_cdiv(steps, min_steps);
@@ -424,11 +425,10 @@ size_t rn_wgrad_halo_workspace_bytes(const WhArgs& a) {
 
 template <int VAR, int STAGES = WH_STAGES_DEFAULT>
 static int wh_launch(const WhArgs& a, dim3 grid, hipStream_t st) {
-  static bool attr_set = false;
+  static unsigned long long attr_set = 0;   // per template instantiation, one bit per device
   constexpr int WH_LDS = STAGES * WH_STAGE;
-  if (!attr_set) {
+  if (RN_FIRST_ON_DEVICE(attr_set)) {
     RN_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_halo_kernel<VAR, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, WH_LDS));
-    attr_set = true;
   }
   hipLaunchKernelGGL((wgrad_halo_kernel<VAR, STAGES>), grid, dim3(512), WH_LDS, st, a);
   RN_CHECK_LAUNCH();

@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("RNET_HIP_LIB") or os.path.join(_HERE, "librnet_hip.so
 LIB_PATH_F16 = os.environ.get("RNET_HIP_LIB_F16") or os.path.join(_HERE, "librnet_hip_f16.so")
 
 RN_DT_F32, RN_DT_BF16 = 0, 1
+RN_OK, RN_EINVAL, RN_ENOMEM, RN_EHIP, RN_ECOMM, RN_EUNSUPPORTED = 0, -1, -2, -3, -4, -5   # rn_status
 RN_ACT_NONE, RN_ACT_RELU, RN_ACT_RELU6, RN_ACT_SWISH = 0, 1, 2, 3
 RN_CONV_MAX_SEGMENTS = 10
 ABI_VERSION = 5
@@ -185,6 +186,7 @@ _SIGNATURES = {
     "rn_pack_conv_weight_dgrad": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rn_pack_conv_weight_dgrad_batch": (c_int, [POINTER(DgradPack), c_int, c_void_p]),
     "rn_cast_pad_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "rn_reduce_rows_f32": (c_int, [c_void_p, c_int, c_int64, c_int, c_float, c_void_p, c_void_p]),
     "rn_upsample_zero2x": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rn_scatter_add2x": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rn_depth_to_space2x": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
@@ -231,6 +233,7 @@ _SIGNATURES = {
     "rn_handle_get_launch_opts": (c_int, [c_void_p, POINTER(LaunchOpts)]),
     "rn_handle_comm_init": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int]),
     "rn_handle_comm": (c_void_p, [c_void_p, c_int]),
+    "rn_handle_comm_destroy": (c_int, [c_void_p, c_int]),
     "rn_comm_available": (c_int, []),
     "rn_comm_unique_id_bytes": (c_int, []),
     "rn_comm_unique_id": (c_int, [c_void_p]),

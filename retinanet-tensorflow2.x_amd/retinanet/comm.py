@@ -45,7 +45,8 @@ class NativeComm:
         import torch.distributed as dist
         lib = lib if lib is not None else (handle.lib if handle is not None else _C.lib())
         self._h, self.rank, self.world, self.device, self._lib = None, rank, world, device, lib
-        self._owned = handle is None      # a communicator created through an rn_handle is destroyed with it
+        self._owned = handle is None      # a communicator created through an rn_handle lives in its slot ...
+        self._handle, self._slot = handle, int(slot)   # ... and close() frees that slot (rn_handle_comm_destroy)
         self.ok, self.error = False, ""
         # stage 0 — local preconditions, agreed on before anything collective in RCCL
         try:
@@ -96,8 +97,14 @@ class NativeComm:
                  "rn_allreduce_bucket")
 
     def close(self):
+        """Abandon the communicator: destroyed here, not at rn_destroy — after a bootstrap that failed on some rank the
+        peers have given up too, and ncclCommDestroy at process exit on such a communicator can hang."""
         if self._h and self._owned:
             self._lib.rn_comm_destroy(self._h)
+        elif self._handle is not None:
+            # also when rn_handle_comm_init succeeded here and another rank failed (self._h may be None on this rank only
+            # when ITS init failed: the slot is then empty and the call is a no-op)
+            self._lib.rn_handle_comm_destroy(self._handle.h, self._slot)
         self._h = None
         self.ok = False
 

@@ -193,15 +193,19 @@ def _jpeg_decode(data):
     lib = _C.lib()
     buf = np.frombuffer(data, dtype=np.uint8)
     w, h, c = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
-    if lib.rn_jpeg_info(buf.ctypes.data, buf.size, ctypes.byref(w), ctypes.byref(h), ctypes.byref(c)) != 0:
+    # RN_EUNSUPPORTED (a status code, not message text): a well-formed file of a kind the native decoder does not
+    # implement goes to Pillow; anything else non-zero is corrupt input
+    rc = lib.rn_jpeg_info(buf.ctypes.data, buf.size, ctypes.byref(w), ctypes.byref(h), ctypes.byref(c))
+    if rc != 0:
         why = lib.rn_last_error().decode()
-        if "not supported" in why or "unsupported" in why or "must be sampled" in why:
+        if rc == _C.RN_EUNSUPPORTED:
             return _jpeg_decode_pillow(data, why)
         raise ImageDecodeError(why)
     out = np.empty((h.value, w.value, 3), np.uint8)
-    if lib.rn_jpeg_decode(buf.ctypes.data, buf.size, out.ctypes.data, out.size) != 0:
+    rc = lib.rn_jpeg_decode(buf.ctypes.data, buf.size, out.ctypes.data, out.size)
+    if rc != 0:
         why = lib.rn_last_error().decode()
-        if "not supported" in why:
+        if rc == _C.RN_EUNSUPPORTED:
             return _jpeg_decode_pillow(data, why)
         raise ImageDecodeError(why)
     return out

@@ -443,7 +443,7 @@ class Executor:
         multi = self.num_replicas > 1
         for i, results in enumerate(self._gathered_eval_results(total_steps)):
             start = time()
-            if len(results["image_id"]):
+            if len(results["image_id"]) and self._is_chief:     # only the chief evaluates: the others need no copy
                 evaluator.accumulate_results(results)
             execution_time = max(np.round(time() - start, 2), 1e-2)
             meter.accumulate(1 / execution_time)
@@ -452,9 +452,21 @@ class Executor:
                          i + 1, total_steps, format_eta((total_steps - (i + 1)) / sps), sps * self.batch_size["val"])
         # every rank holds the same gathered detections; the chief alone writes the prediction file and runs COCOeval
         # (all ranks opening `<name>.json` with 'w' and reading it back is a truncate / read race), then shares the scores
-        scores = evaluator.evaluate() if self._is_chief else None
+        # A failure on the chief (no detections, COCOeval, file I/O) must not leave the other ranks waiting in the broadcast:
+        # the chief sends (ok, scores | error text) and every rank raises together.
+        scores, err = None, None
+        if self._is_chief:
+            try:
+                scores = evaluator.evaluate()
+            except Exception as e:   # noqa: BLE001 — re-raised on every rank below
+                if not multi:
+                    raise
+                err = f"{type(e).__name__}: {e}"
         if multi:
-            scores = self.distribute_strategy.broadcast_object(scores, src=0)
+            ok, payload = self.distribute_strategy.broadcast_object((err is None, scores if err is None else err), src=0)
+            if not ok:
+                raise RuntimeError(f"evaluation failed on the chief replica: {payload}")
+            scores = payload
         if "eval" in self._summary_writers:
             self._summary_writers["eval"].scalars(current_step, {k: scores[k] for k in (
                 "AP-IoU=0.50:0.95", "AP-IoU=0.50", "AP-IoU=0.75", "AR-(all)-IoU=0.50:0.95", "AR-(L)-IoU=0.50:0.95")})

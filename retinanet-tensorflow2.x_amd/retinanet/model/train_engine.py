@@ -1252,9 +1252,10 @@ class TrainEngine:
                 db = self._pview(cname + "/bias", self.G)
                 self._keep += [pb2, bs, ws2]
 
-                def bias_grad(st, pr=ctypes.byref(pb2), ws2=ws2, bs=bs, db=db, n=c["cout"]):
+                def bias_grad(st, pr=ctypes.byref(pb2), ws2=ws2, bs=bs, db=db, n=c["cout"], rows=len(cops), stride=2 * cw):
                     _C.check(lib.rn_bn_stats(pr, _C.ptr(ws2), ws2.numel(), st), "bias colsum")
-                    torch.sum(bs[:, 0, :n], dim=0, out=db)
+                    # sum of the per-level column sums (row 0 of every [2][cw] block), levels in order
+                    _C.check(lib.rn_reduce_rows_f32(_C.ptr(bs), rows, stride, n, 0.0, _C.ptr(db), st), "bias grad")
                 self.bwd_steps.append(self._side(bias_grad, writes=[cname + "/bias"]))
         # (c) data gradients.  Segments of one launch must write distinct gradient buffers (both
         # heads read the same pyramid level): split the group into launches with unique inputs.
@@ -1847,7 +1848,12 @@ class TrainEngine:
             self._small_msgs = 0
             self._c2_local, self._c2_sent, self.c2_normalizer = None, False, None
             if self.sync_bn:    # sum(num-positives) + 1 of this rank (retinanet_loss.py:38): folded into SyncBN traffic
-                self._c2_local = (targets["num-positives"].sum() + 1.0).reshape(1).to(torch.float32)
+                npos = targets["num-positives"]
+                if npos.dtype != torch.float32 or not npos.is_contiguous():
+                    npos = npos.to(torch.float32).contiguous()
+                self._c2_local = torch.empty((1,), dtype=torch.float32, device=self.dev)
+                _C.check(self.lib.rn_reduce_rows_f32(_C.ptr(npos), npos.numel(), 1, 1, 1.0, _C.ptr(self._c2_local),
+                                                     _C.current_stream()), "num-positives + 1")
             preds = self.forward(images)
             self._c2_local = None
             # per_replica_loss = total / replicas, times the loss scale under mixed_float16 (executor.py:421-425)

@@ -84,6 +84,7 @@ class _FakeCommLib:
     def __init__(self, rank, fail_stage, fail_rank):
         self.rank, self.fail_stage, self.fail_rank = rank, fail_stage, fail_rank
         self.inits = 0
+        self.slots, self.destroyed = {}, 0
 
     def _fails(self, stage):
         return self.fail_stage == stage and self.rank == self.fail_rank
@@ -110,6 +111,22 @@ class _FakeCommLib:
     def rn_last_error(self):
         return b"injected failure"
 
+    # the same communicator created through an rn_handle: it lives in a slot of the handle
+    def rn_handle_comm_init(self, h, slot, uid, rank, world):
+        self.inits += 1
+        if self._fails("init"):
+            return -4
+        assert self.slots.get(slot) is None, "slot already holds a communicator"
+        self.slots[slot] = 0x2000 + rank
+        return 0
+
+    def rn_handle_comm(self, h, slot):
+        return self.slots.get(slot)
+
+    def rn_handle_comm_destroy(self, h, slot):
+        self.destroyed += int(self.slots.pop(slot, None) is not None)
+        return 0
+
 
 def _worker_comm_failure(rank, world, port, out):
     sys.path.insert(0, PKG)
@@ -126,6 +143,16 @@ def _worker_comm_failure(rank, world, port, out):
             lib = _FakeCommLib(rank, stage, who)
             comm = NativeComm(rank, world, torch.device("cpu"), None, lib=lib)
             res[f"{stage}@{who}"] = (comm.ok, lib.inits, comm._h is not None)
+        # through an rn_handle (what Executor / bench do): after a failure on EITHER rank the slot is empty on BOTH — the
+        # survivor's communicator is destroyed now, a later rn_handle_comm_init finds the slot free
+        from types import SimpleNamespace
+        for stage, who in [("none", 0), ("init", 0), ("init", 1)]:
+            lib = _FakeCommLib(rank, stage, who)
+            comm = NativeComm(rank, world, torch.device("cpu"), None, handle=SimpleNamespace(h=1, lib=lib), slot=2)
+            res[f"handle:{stage}@{who}"] = (comm.ok, lib.slots.get(2) is not None, lib.destroyed)
+            if comm.ok:
+                comm.close()
+                res[f"handle:{stage}@{who}:closed"] = (lib.slots.get(2) is not None, lib.destroyed)
     # the ranks are still in lockstep: one more collective completes
     t = torch.ones(1)
     dist.all_reduce(t)
@@ -152,6 +179,13 @@ def test_native_comm_construction_is_collective_safe():
     for key in ("init@0", "init@1"):
         # every rank entered the init; the status is agreed on afterwards and the survivor drops its communicator
         assert r0[key] == r1[key] == (False, 1, False), (key, r0[key], r1[key])
+    assert r0["handle:none@0"] == r1["handle:none@0"] == (True, True, 0)
+    assert r0["handle:none@0:closed"] == r1["handle:none@0:closed"] == (False, 1)
+    for who in (0, 1):
+        key = f"handle:init@{who}"
+        survivor, failed = (r1, r0) if who == 0 else (r0, r1)
+        assert failed[key] == (False, False, 0), (key, failed[key])        # its init failed: the slot was never filled
+        assert survivor[key] == (False, False, 1), (key, survivor[key])    # created, then destroyed when the job bailed
 
 
 def _worker_eval_loop(rank, world, port, out):

@@ -279,7 +279,7 @@ def test_every_distinct_launch_of_the_bench_engine(cuda, size, B, splitk_env):
     for name, p in convs:
         k = (name.split(":")[0], eng.lib.rn_conv_kernel_id(ctypes.byref(p)))
         kinds[k] = kinds.get(k, 0) + 1
-        n_split += int(eng.lib.rn_conv_splitk_workspace_bytes(ctypes.byref(p)) > 0)
+        n_split += int(bool(p.splitk_ws) and eng.lib.rn_conv_splitk_workspace_bytes(ctypes.byref(p)) > 0)
     assert (n_split >= 4) if splitk_env == "split" else (n_split == 0), n_split   # towers / FPN / stage 4 split their last round
     # the engine at this size runs all three forward kernel families, as forward and as data-gradient launches
     for k in (("fwd", 0), ("fwd", 1), ("fwd", 2), ("dgrad", 0), ("dgrad", 1), ("dgrad", 2)):
