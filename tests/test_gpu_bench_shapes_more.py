@@ -201,9 +201,10 @@ def _check_bn_problem(cuda, lib, h16, p, name):
             v = rb(v + t["res"].double())
         want_z = _act_fwd_gate(v, p.act)
         got_z = z.double()
-        tol = want_z.abs().max().item() / 256
-        assert (got_z - want_z).abs().max().item() <= tol, (name, i)
-        assert (got_z != want_z).double().mean().item() < 0.02, (name, i)      # an fp32 fma vs float64 rounding boundary
+        tol = want_z.abs().max().item() / 128       # one 16-bit step in the top binade
+        assert (got_z - want_z).abs().max().item() <= tol, (name, i, "z", (got_z - want_z).abs().max().item(), tol)
+        # an fp32 multiply-add against float64 at a rounding boundary
+        assert (got_z != want_z).double().mean().item() < 0.02, (name, i, "z mismatches", (got_z != want_z).double().mean().item())
         # backward from the STORED z (what the kernels gate on)
         if p.act == _C.RN_ACT_RELU:
             gate = (got_z > 0).double()
@@ -225,13 +226,13 @@ def _check_bn_problem(cuda, lib, h16, p, name):
         want_dy = fwd[2] * (gg - bs[0] / n - xhat * bs[1] / n)
         got_dy = t["dy"].double()
         scale_dy = want_dy.abs().max().item()
-        assert (got_dy - rb(want_dy)).abs().max().item() <= scale_dy / 128, (name, i)
-        assert (got_dy != rb(want_dy)).double().mean().item() < 0.03, (name, i)
+        assert (got_dy - rb(want_dy)).abs().max().item() <= scale_dy / 128, (name, i, "dy", (got_dy - rb(want_dy)).abs().max().item(), scale_dy)
+        assert (got_dy != rb(want_dy)).double().mean().item() < 0.03, (name, i, "dy mismatches", (got_dy != rb(want_dy)).double().mean().item())
         if "dres" in t:
             want_r = rb(gg + (t["dres0"].double() if p.seg[i].dres_accumulate else 0.0))
             got_r = t["dres"].double()
-            assert (got_r - want_r).abs().max().item() <= want_r.abs().max().item() / 128, (name, i)
-            assert (got_r != want_r).double().mean().item() < 0.01, (name, i)
+            assert (got_r - want_r).abs().max().item() <= want_r.abs().max().item() / 128, (name, i, "dres")
+            assert (got_r != want_r).double().mean().item() < 0.01, (name, i, "dres mismatches", (got_r != want_r).double().mean().item())
         del y, v, want_z, got_z, gg, xhat, want_dy, got_dy
 
 
@@ -258,7 +259,7 @@ def test_batchnorm_passes_at_bench_geometries(cuda):
         try:
             _check_bn_problem(cuda, lib, h16, pb, name)
         except AssertionError as e:
-            failures.append((name, _bn_sig(pb), str(e).splitlines()[0][:200] if str(e) else "assert"))
+            failures.append((name, _bn_sig(pb)[:3], str(e).splitlines()[0][:300] if str(e) else "assert"))
         torch.cuda.empty_cache()
     print(f"{len(probs)} distinct BatchNorm problems checked")
     assert not failures, failures
