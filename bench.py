@@ -90,6 +90,8 @@ def conv_variant(engine, step_name):
             res = "true" if any(p.seg[i].residual for i in range(p.num_segments)) else "false"
             if kid == 2:
                 return f"conv_halo_kernel<false, {res}, false> (256x256x32, 3x3 halo patch)"
+            if kid == 3:
+                return f"conv_halo_kernel<false, {res}, false, false, 4> (512x128x32, 3x3 halo patch)"
             if kid == 1:
                 return f"conv_big_kernel<false, {res}, false> (256x256x32)"
             return "conv_fwd_kernel<128,128,64,bf16>" if c["cout"] > 64 and c["cin"] % 64 == 0 else None

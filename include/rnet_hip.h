@@ -248,7 +248,8 @@ typedef struct {
    * 128-pixel row block b of the output writes its per-channel partial sums of the STORED bf16 values:
    * bn_partial[(b*2 + 0)*Cout + c] = sum, [(b*2 + 1)*Cout + c] = sum of squares — the stage-1 layout of
    * rn_bn_stats (rn_bn_segment.ext_chunks).  Blocks written: b = 0 .. 2*ceil(N*Ho*Wo/256)-1 when the launch runs on
-   * the 256-row kernels (rn_conv_tile_rows() == 256), b = 0 .. ceil(N*Ho*Wo/128)-1 on the 128-row kernel: set
+   * the 256-row kernels (rn_conv_tile_rows() == 256; 4*ceil(N*Ho*Wo/512) blocks for 512: in general (rows / 128) *
+   * ceil(N*Ho*Wo / rows)), b = 0 .. ceil(N*Ho*Wo/128)-1 on the 128-row kernel: set
    * ext_chunks accordingly. */
   float* bn_partial;
   const float* bias;    /* f32[Cout] or NULL: the Conv2D layer's bias, added to the fp32 accumulator */
@@ -300,12 +301,14 @@ size_t rn_conv_splitk_workspace_max_bytes(void);
 /* HWIO f32 [R,S,Cin,Cout] (the Keras kernel layout, resnet.py:137-144) -> bf16
  * [Cout_pad,R,S,Cin_pad], zero padded.  Cout_pad = rn_conv_cout_pad(Cout). */
 int rn_conv_cout_pad(int Cout);
-/* M-tile height the dispatcher picks for this problem: 256 = conv_big_kernel (256x256x32, rn_conv_big.hip),
- * 128 = conv_fwd_kernel<128,...>; 0 on a malformed problem.  For profilers (bench.py roofline). */
+/* M-tile height the dispatcher picks for this problem: 256 = conv_big_kernel / conv_halo_kernel (256x256x32), 512 =
+ * conv_halo_kernel's 512x128 form (3x3, 64 < Cout <= 128), 128 = conv_fwd_kernel<128,...>; 0 on a malformed problem.  A
+ * launch with fused BatchNorm partial sums writes (rows / 128) * ceil(N*Ho*Wo / rows) 128-pixel row blocks per segment. */
 int rn_conv_tile_rows(const rn_conv_problem* problem);
 /* Which kernel rn_conv2d_nhwc_fwd runs for `problem`: 0 = 128-row tiles (conv_fwd_kernel), 1 = conv_big_kernel
  * (256 x 256 x 32, persistent), 2 = conv_halo_kernel (256 x 256 x 32 for 3x3 / stride 1 / pad 1: pixels staged
- * once per channel chunk as a halo patch).  Profiling / bench bookkeeping only. */
+ * once per channel chunk as a halo patch), 3 = conv_halo_kernel with 512 x 128 tiles (the same for 64 < Cout <= 128).
+ * Profiling / bench bookkeeping only. */
 int rn_conv_kernel_id(const rn_conv_problem* problem);
 /* channel count of the packed weights: Cin rounded up to the kernel's K step (zero columns) */
 int rn_conv_cin_pad(int Cin);

@@ -426,7 +426,7 @@ static int splitk_parts(int total, int min_chunks, int G0, long long* bytes) {
   return S;
 }
 
-static bool conv_halo_shape(const rn_conv_problem* p);
+static bool conv_halo_shape(const rn_conv_problem* p, int BM);
 static int conv_min_chunks(const rn_conv_problem* p);
 
 static bool conv_use_big(const rn_conv_problem* p) {
@@ -442,7 +442,7 @@ static bool conv_use_big(const rn_conv_problem* p) {
   // A launch of fewer tiles than compute units (batch-8 inference, ResNet stage 3 / 4; stage 4 at any batch) used to go
   // to the 128-row kernel because whole 256-row tiles would leave most of the chip idle.  With a split-K workspace the
   // halo kernel cuts every tile into S parts (all tiles are "last round"): enough workgroups again, on the faster kernel.
-  if (p->splitk_ws && p->opts.conv_big_min_tiles == 0 && conv_halo_shape(p)) {
+  if (p->splitk_ws && p->opts.conv_big_min_tiles == 0 && conv_halo_shape(p, 256)) {
     long long bytes = 0;
     const int G0 = rn_persistent_grid(0x7fffffff, rn_num_cus(), p->opts);
     const int S = tiles256 < G0 ? splitk_parts((int)tiles256, conv_min_chunks(p), G0, &bytes) : 1;
@@ -453,12 +453,12 @@ static bool conv_use_big(const rn_conv_problem* p) {
 
 // 3x3 / stride 1 / pad 1 launches of the 256-row class go to the halo kernel (rn_conv_halo.hip) when every
 // segment's worst tile fits its patch buffer.
-static bool conv_halo_shape(const rn_conv_problem* p) {
+static bool conv_halo_shape(const rn_conv_problem* p, int BM) {   // BM: pixels per tile (256, or 512 for the narrow form)
   if (p->opts.conv_no_halo) return false;
   if (p->R != 3 || p->S != 3 || p->stride_h != 1 || p->stride_w != 1 || p->pad_top != 1 || p->pad_left != 1)
     return false;
   static std::mutex mu;
-  static std::map<std::tuple<int, int, int, int>, int> patch_px;   // (N, H, W, pitch) -> worst patch, computed once
+  static std::map<std::tuple<int, int, int, int>, int> patch_px;   // (N, H, W, pitch * 1024 + BM) -> worst patch, computed once
   for (int i = 0; i < p->num_segments; ++i) {
     const rn_conv_segment& s = p->seg[i];
     if (s.Ho != s.H || s.Wo != s.W || s.Cin % 32 != 0) return false;
@@ -468,18 +468,36 @@ static bool conv_halo_shape(const rn_conv_problem* p) {
       std::lock_guard<std::mutex> lock(mu);
       // the wide pitch when its patch fits, else the tight one (the kernel is told per segment: halo_pitch)
       for (int pitch : {rn_conv_halo_pitch(s.W), s.W + 1}) {
-        auto key = std::make_tuple(s.N, s.H, s.W, pitch);
+        auto key = std::make_tuple(s.N, s.H, s.W, pitch * 1024 + BM);
         auto it = patch_px.find(key);
-        if (it == patch_px.end()) it = patch_px.emplace(key, rn_conv_halo_patch_pixels(s.N, s.H, s.W, pitch)).first;
+        if (it == patch_px.end()) it = patch_px.emplace(key, rn_conv_halo_patch_pixels(s.N, s.H, s.W, pitch, BM)).first;
         px = it->second;
-        if (px <= rn_conv_halo_capacity()) break;
+        if (px <= rn_conv_halo_capacity(BM)) break;
       }
     }
-    if (px > rn_conv_halo_capacity()) return false;
+    if (px > rn_conv_halo_capacity(BM)) return false;
   }
   return true;
 }
-static bool conv_use_halo(const rn_conv_problem* p) { return conv_halo_shape(p) && conv_use_big(p); }
+static bool conv_use_halo(const rn_conv_problem* p) { return conv_halo_shape(p, 256) && conv_use_big(p); }
+
+// 3x3 / stride 1 / pad 1 layers with 64 < Cout <= 128 (ResNet stage 2: 128 -> 128 at 80 x 80, forward and data gradient):
+// the halo kernel with 512 x 128 tiles (rn_conv_halo.hip, HaloGeo<4>: 4 x 2 waves of 128 pixels x 64 channels).  On the
+// 128-row kernel such a layer staged its pixels once per tap (the LDS-DMA path bound it at ~550 TFLOP/s); in a 256-wide
+// tile of the halo kernel half the waves multiply zero rows.
+static bool conv_use_halo512(const rn_conv_problem* p) {
+  if (p->opts.conv_tile == 1 || p->opts.conv_no_halo) return false;
+  long long tiles = 0;
+  for (int i = 0; i < p->num_segments; ++i) {
+    const rn_conv_segment& s = p->seg[i];
+    if (rn_conv_cout_pad(s.Cout) != 128 || s.Cout % 8 != 0) return false;
+    if (s.bias && s.residual) return false;   // as for the 256-row kernels: the residual variants carry no bias path
+    tiles += rn_cdiv((long long)s.N * s.Ho * s.Wo, 512);
+  }
+  if (!conv_halo_shape(p, 512)) return false;
+  // enough tiles to fill the chip once (opts.conv_tile = 2 forces the form: tests at small sizes)
+  return p->opts.conv_tile == 2 || tiles >= (p->opts.conv_big_min_tiles > 0 ? p->opts.conv_big_min_tiles : 128);
+}
 
 int rn_splitk_plan(ConvArgs& a, int min_chunks, void* ws, long long ws_bytes, const rn_launch_opts& opts) {
   const int total = a.total_tiles;
@@ -526,12 +544,12 @@ extern "C" size_t rn_conv_splitk_workspace_bytes(const rn_conv_problem* p) {
 /* 0: 128-row kernel, 1: conv_big_kernel, 2: conv_halo_kernel */
 extern "C" int rn_conv_kernel_id(const rn_conv_problem* p) {
   if (!p || p->num_segments < 1 || p->num_segments > RN_CONV_MAX_SEGMENTS) return -1;
-  return conv_use_halo(p) ? 2 : (conv_use_big(p) ? 1 : 0);
+  return conv_use_halo(p) ? 2 : (conv_use_big(p) ? 1 : (conv_use_halo512(p) ? 3 : 0));
 }
 
 extern "C" int rn_conv_tile_rows(const rn_conv_problem* p) {
   if (!p || p->num_segments < 1 || p->num_segments > RN_CONV_MAX_SEGMENTS) return 0;
-  return conv_use_big(p) ? 256 : 128;
+  return conv_use_big(p) ? 256 : (conv_use_halo512(p) ? 512 : 128);
 }
 
 extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
@@ -552,8 +570,9 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
   // zero-padded weight columns, so it contributes nothing.
   const int BK = rn_conv_cin_pad(p->seg[0].Cin) % 64 == 0 ? 64 : 32;
   const bool big = conv_use_big(p);
-  const int BM = big ? 256 : 128;
-  if (!big && BN == 128) {
+  const bool halo512 = !big && conv_use_halo512(p);   // 3x3, 64 < Cout <= 128: 512 x 128 tiles of the halo kernel
+  const int BM = big ? 256 : (halo512 ? 512 : 128);
+  if (!big && !halo512 && BN == 128) {
     // Small launches (batch-8 inference, ResNet stage 4: 100 tiles of 128 x 128 on 256 CUs): 128 x 64 tiles put the work
     // on twice as many CUs and read 12 KB instead of 16 KB of LDS fragments per wave and K step — the 128-row kernel is
     // bound by fragment bandwidth at one workgroup per CU (DESIGN.md section 4, round-3 probes).  Only while the
@@ -607,7 +626,7 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
     d.cwrap = rn_conv_cin_pad(s.Cin);
     d.CinP = terms * d.cwrap;
     d.halo_pitch = s.W + 1;
-    if (rn_conv_halo_patch_pixels(s.N, s.H, s.W, rn_conv_halo_pitch(s.W)) <= rn_conv_halo_capacity())
+    if (rn_conv_halo_patch_pixels(s.N, s.H, s.W, rn_conv_halo_pitch(s.W), halo512 ? 512 : 256) <= rn_conv_halo_capacity(halo512 ? 512 : 256))
       d.halo_pitch = rn_conv_halo_pitch(s.W);
     tiles += (int)rn_cdiv(M, BM) * d.n_tiles;
   }
@@ -633,6 +652,7 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
       default: break;
     }
   }
+  if (halo512) return rn_launch_conv_halo(a, f32, p->opts, st, 4);
   if (big && conv_use_halo(p)) {
     rn_splitk_plan(a, conv_splitk_min_chunks(p), p->splitk_ws, p->splitk_ws_bytes, p->opts);
     return rn_launch_conv_halo(a, f32, p->opts, st);

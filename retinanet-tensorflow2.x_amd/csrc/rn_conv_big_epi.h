@@ -81,14 +81,14 @@ __device__ __forceinline__ bool big_bias_in_acc(const ConvArgs& args, const Conv
 // accumulators of a new tile: zero, or the bias of the lane's channels (see the layout at the top).  The 64
 // floats of the wave come through the scalar cache (uniform address, constant address space): no vector memory
 // operation, so the counted vmcnt waits of the DMA stream are not disturbed.
-template <bool OUT_F32, bool HAS_RES>
+template <bool OUT_F32, bool HAS_RES, int WM = 2>   // WM: waves along the pixels (8 / WM along the channels)
 __device__ __forceinline__ void big_acc_init(f32x16_t (&acc)[4][2], const ConvArgs& args, int c_si, int c_n0, int wave,
                                              bool with_bias = true) {   // false: parts 1.. of a split tile start from zero
   const ConvSegDev& sg = args.seg[c_si];
   if (with_bias && big_bias_in_acc<OUT_F32, HAS_RES>(args, sg)) {
     typedef const float __attribute__((address_space(4))) cfloat;
     const cfloat* b = (const cfloat*)(unsigned long long)sg.bias;
-    const int nw0 = c_n0 + (wave & 3) * 64;
+    const int nw0 = c_n0 + (wave % (8 / WM)) * 64;
     const int Cout = sg.Cout;
     const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const bool hi = lane >= 32;
@@ -167,12 +167,12 @@ __device__ __forceinline__ void big_epi_rebuild(f32x16_t* t, const BigEpiSrc& sr
     }
 }
 
-template <bool OUT_F32, bool HAS_RES, bool BN_BWD = false, bool FROM_WS = false>
+template <bool OUT_F32, bool HAS_RES, bool BN_BWD = false, bool FROM_WS = false, int WM = 2>
 __device__ __forceinline__ void big_epilogue(f32x16_t (&acc)[4][2], const ConvArgs& args, int c_si, int c_m0,
                                              int c_n0, int wave, char* patch, const BigEpiSrc src = BigEpiSrc()) {
   static_assert(!(BN_BWD && (OUT_F32 || HAS_RES)), "BN_BWD: plain bf16 launches only");
   constexpr bool LOADS = HAS_RES || BN_BWD;   // the epilogue prefetches a second [M][Cout] bf16 tensor
-  const int wave_m = wave >> 2, wave_n = wave & 3;
+  const int wave_m = wave / (8 / WM), wave_n = wave % (8 / WM);   // WM x 8/WM waves of 128 pixels x 64 channels
   const ConvSegDev& sg = args.seg[c_si];
   const int Cout = sg.Cout, M = sg.M;
   const int nw0 = c_n0 + wave_n * 64;
@@ -383,7 +383,7 @@ _Pragma("unroll") for (int pass = 0; pass < (LOADS ? 4 : 0); ++pass) {          
         }
       }
       if (rrow == 0 && nok) {
-        float* dst = sg.bn_partial + ((long long)(c_m0 / 256) * 2 + wave_m) * 2 * Cout + nr;
+        float* dst = sg.bn_partial + ((long long)(c_m0 / 128) + wave_m) * 2 * Cout + nr;   // one row per 128 pixels
         *(float4*)(dst) = make_float4(st0[0], st0[1], st0[2], st0[3]);
         *(float4*)(dst + 4) = make_float4(st0[4], st0[5], st0[6], st0[7]);
         *(float4*)(dst + Cout) = make_float4(st1[0], st1[1], st1[2], st1[3]);

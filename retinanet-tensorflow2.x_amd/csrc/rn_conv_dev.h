@@ -66,11 +66,11 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wav
 // rn_conv_big.hip
 int rn_launch_conv_big(const ConvArgs& a, bool out_f32, const rn_launch_opts& opts, hipStream_t st);   // (bn_y set on segment 0: the BN_BWD variant)
 // rn_conv_halo.hip (3x3 / stride 1 / pad 1)
-int rn_launch_conv_halo(const ConvArgs& a, bool out_f32, const rn_launch_opts& opts, hipStream_t st);
+int rn_launch_conv_halo(const ConvArgs& a, bool out_f32, const rn_launch_opts& opts, hipStream_t st, int wm = 2);   // wm = 4: 512 x 128 tiles
 // plan of the last-round split for a persistent launch of `total_tiles` tiles whose shortest tile has `min_chunks`
 // K chunks; fills a.split_f / split_s / vtotal / ws (no split when ws is null or too small) and returns the grid
 int rn_splitk_plan(ConvArgs& a, int min_chunks, void* ws, long long ws_bytes, const rn_launch_opts& opts);
-int rn_conv_halo_patch_pixels(int N, int H, int W, int pitch);
+int rn_conv_halo_patch_pixels(int N, int H, int W, int pitch, int BM = 256);
 int rn_conv_halo_pitch(int W);
-int rn_conv_halo_capacity();
+int rn_conv_halo_capacity(int BM = 256);
 #endif  // RN_CONV_DEV_H_

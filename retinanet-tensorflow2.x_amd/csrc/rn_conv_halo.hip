@@ -40,17 +40,34 @@ extern "C" __attribute__((visibility("default"))) int rn_debug_halo_clocks(unsig
 
 namespace {
 
-constexpr int BM = 256, BN = 256, BK = 32, NW = 8;
-constexpr int PIX_PX = 640, PIX_BYTES = PIX_PX * 64;     // one halo patch (40 KB)
-constexpr int PIECES = PIX_PX / 16 / NW;                 // 5 patch DMA pieces per wave per chunk
-constexpr int PLANE = PIX_PX * 16;                       // the patch is 4 planes [16-byte channel slot][pixel]
-constexpr int W_STAGE = BN * BK * 2;                     // 16 KB of weights per K step
+constexpr int BK = 32, NW = 8;
 constexpr int W_STAGES = 3;                              // 9 taps = 3 x 3: the ring stage of a tap is tap % 3
-constexpr int W_RING = 2 * PIX_BYTES;
-constexpr int PA_TABLE = W_RING + W_STAGES * W_STAGE;    // source offset of every patch pixel (plane 0), one dword each
-constexpr int BASE_TABLE = PA_TABLE + PIX_PX * 4;        // 2 x 256 dwords: patch offset of every tile pixel, a ring of two tiles
-constexpr int SEG_TABLE = BASE_TABLE + 2 * BM * 4;       // segment descriptors the tile set-ups need (see HaloSeg)
-constexpr int LDS_BYTES = SEG_TABLE + 16 * 4 + RN_CONV_MAX_SEGMENTS * 64;   // 80 + 48 + 2.5 + 2 + <1 = 133 KB
+// Tile geometry by wave grid.  The eight waves always own 128 pixels x 64 channels each (4 x 2 MFMA tiles); WM of them
+// stack along the pixels, 8 / WM along the channels:
+//   WM = 2: 256 pixels x 256 channels — every layer with Cout >= 256 (the round-1..3 kernel);
+//   WM = 4: 512 pixels x 128 channels — 3x3 layers with 64 < Cout <= 128 (ResNet stage 2, 128 -> 128 at 80 x 80): in the
+//           256-wide tile half of the waves multiplied zero weight rows, and on the 128-row kernel the layer re-staged
+//           its pixels once per tap (round 4).
+template <int WM>
+struct HaloGeo {
+  static constexpr int WN = 8 / WM;
+  static constexpr int BM = 128 * WM, BN = 64 * WN;
+  static constexpr int PIX_PX = WM == 2 ? 640 : 896;       // patch capacity in pixels (a multiple of 64): a 512-pixel tile of an
+                                                           // 80 x 80 level that straddles two images needs 11 rows x 81 + 1 = 892
+  static constexpr int PIX_BYTES = PIX_PX * 64;            // one halo patch (40 / 56 KB)
+  static constexpr int BLOCKS = PIX_PX / 64;               // 64-pixel blocks per plane
+  static constexpr int PIECES = (BLOCKS * 4 + NW - 1) / NW;   // patch DMA pieces per wave per chunk: 5 / 7
+  static constexpr int PLANE = PIX_PX * 16;                // the patch is 4 planes [16-byte channel slot][pixel]
+  static constexpr int W_STAGE = BN * BK * 2;              // 16 / 8 KB of weights per K step
+  static constexpr int W_PIECES = W_STAGE / 1024 / NW;     // weight DMA pieces per wave per K step: 2 / 1
+  static constexpr int W_RING = 2 * PIX_BYTES;
+  static constexpr int PA_TABLE = W_RING + W_STAGES * W_STAGE;   // source offset of every patch pixel (plane 0), one dword each
+  static constexpr int BASE_TABLE = PA_TABLE + PIX_PX * 4;       // 2 x BM dwords: patch offset of every tile pixel, a ring of two tiles
+  static constexpr int SEG_TABLE = BASE_TABLE + 2 * BM * 4;      // segment descriptors the tile set-ups need (see HaloSeg)
+  static constexpr int LDS_BYTES = SEG_TABLE + 16 * 4 + RN_CONV_MAX_SEGMENTS * 64;   // 133 / 148 KB
+  static_assert(PIECES <= 8, "one patch piece per load segment of taps 1..8");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+};
 
 // What the three tile set-ups read of a segment, copied into LDS once per kernel: reading ConvArgs through the
 // scalar cache cost each set-up a chain of dependent s_loads (the segment search alone one per segment) — measured
@@ -61,6 +78,7 @@ struct HaloSeg {
   int N, H, W, pix_stride, Cout, M, tile_begin, n_tiles, CinP, cwrap, pitch;
 };
 // layout: 16 dwords of tile_begin (INT_MAX past the last segment), then 16 dwords per segment
+template <int SEG_TABLE>
 __device__ __forceinline__ void halo_seg_table_fill(char* smem, const ConvArgs& args, int tid) {
   int* tb = (int*)(smem + SEG_TABLE);
   if (tid < 16) tb[tid] = tid < args.nseg ? args.seg[tid < RN_CONV_MAX_SEGMENTS ? tid : 0].tile_begin : 0x7fffffff;
@@ -74,6 +92,7 @@ __device__ __forceinline__ void halo_seg_table_fill(char* smem, const ConvArgs& 
     d[12] = g.CinP; d[13] = g.cwrap; d[14] = g.halo_pitch; d[15] = 0;
   }
 }
+template <int SEG_TABLE>
 __device__ __forceinline__ int halo_seg_of_tile(const char* smem, int tile) {
   const int4* tb = (const int4*)(smem + SEG_TABLE);
   const int4 a = tb[0], b = tb[1], c = tb[2];
@@ -81,6 +100,7 @@ __device__ __forceinline__ int halo_seg_of_tile(const char* smem, int tile) {
            (tile >= b.w) + (tile >= c.x) + (tile >= c.y);
   return __builtin_amdgcn_readfirstlane(si);
 }
+template <int SEG_TABLE>
 __device__ __forceinline__ HaloSeg halo_seg(const char* smem, int si) {
   const uint4* d = (const uint4*)(smem + SEG_TABLE + 64 + si * 64);
   const uint4 q0 = d[0], q1 = d[1], q2 = d[2], q3 = d[3];
@@ -186,14 +206,20 @@ __device__ __forceinline__ bool halo_split_exchange(f32x16_t (&acc)[4][2], const
   return true;
 }
 
-template <bool OUT_F32, bool HAS_RES, bool BN_BWD = false, bool SPLIT = false>   // BN_BWD: rn_conv_big_epi.h
+template <bool OUT_F32, bool HAS_RES, bool BN_BWD = false, bool SPLIT = false, int WM = 2>   // BN_BWD: rn_conv_big_epi.h
 __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
+  using GE = HaloGeo<WM>;
+  constexpr int WN = GE::WN, BM = GE::BM, BN = GE::BN, PIX_PX = GE::PIX_PX, PIX_BYTES = GE::PIX_BYTES, BLOCKS = GE::BLOCKS;
+  constexpr int PIECES = GE::PIECES, PLANE = GE::PLANE, W_STAGE = GE::W_STAGE, W_PIECES = GE::W_PIECES, W_RING = GE::W_RING;
+  constexpr int PA_TABLE = GE::PA_TABLE, BASE_TABLE = GE::BASE_TABLE, SEG_TABLE = GE::SEG_TABLE;
+  static_assert(!SPLIT || WM == 2, "the split last round exists for the 256 x 256 tiles only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int total = SPLIT ? args.vtotal : args.total_tiles;   // work units: tiles, or the parts of the split last round
   const int G = gridDim.x;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wave_m = wave >> 2, wave_n = wave & 3;   // wave_m is also the ping-pong group
+  const int wave_m = wave / WN, wave_n = wave % WN;
+  const int grp = wave >> 2;   // ping-pong group: waves w and w + 4 share a SIMD (WM = 2: the group is wave_m)
 
   // ---- issue side, pixels: the chunk whose patch is being DMA'd (one chunk ahead of the weights' chunk) ----
 #ifdef HALO_PROF
@@ -228,8 +254,8 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
 #define HALO_SETUP_PIX()                                                                              \
   do {                                                                                                \
     const int tile__ = halo_tile_of<SPLIT>(p_v, args, total);                                         \
-    const int si__ = halo_seg_of_tile(smem, tile__);                                                  \
-    const HaloSeg sg__ = halo_seg(smem, si__);                                                        \
+    const int si__ = halo_seg_of_tile<SEG_TABLE>(smem, tile__);                                                  \
+    const HaloSeg sg__ = halo_seg<SEG_TABLE>(smem, si__);                                                        \
     const int lt__ = tile__ - sg__.tile_begin;                                                        \
     const int m0__ = rn_fdiv(lt__, sg__.n_tiles, rn_rcp((float)sg__.n_tiles)) * BM;                \
     const int H__ = sg__.H, W__ = sg__.W, PS__ = sg__.pix_stride, W1__ = sg__.pitch, H1__ = H__ + 1;  \
@@ -265,23 +291,26 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
                       n < sg__.N;                                                                     \
       HALO_PA_PX(p) = ok ? (unsigned)((((n * H__ + iy) * W__ + ix) * PS__) * 2) : RN_OOB;   /* < 2 GiB: checked by the host */ \
     }                                                                                                 \
-    if (wave >= 4) {   /* base table of this tile (ring slot = ordinal parity): tile pixel t - 256 */  \
-      int m = m0__ + t__ - 256;                                                                       \
+    if (WM == 4 || wave >= 4) {   /* base table of this tile (ring slot = ordinal parity): one tile pixel per thread */ \
+      const int ml0__ = WM == 4 ? t__ : t__ - 256;   /* 256-pixel tiles: the second half of the threads */  \
+      int m = m0__ + ml0__;                                                                           \
       m = m < sg__.M ? m : sg__.M - 1;                                                                \
       const int n = rn_fdiv(m, HW__, rHW__);                                                          \
       const int rem = m - n * HW__;                                                                   \
       const int oy = rn_fdiv(rem, W__, rW__), ox = rem - oy * W__;                                    \
-      HALO_BASE_AT((p_par >> 1) & 1, t__ - 256) = ((n * H1__ + oy + 1 - Gf__) * W1__ + ox) * 16;      \
+      HALO_BASE_AT((p_par >> 1) & 1, ml0__) = ((n * H1__ + oy + 1 - Gf__) * W1__ + ox) * 16;          \
     }                                                                                                 \
     p_par ^= 2;                                                                                       \
   } while (0)
 
+// piece j of this wave = pixel block 2j + wave/4: past the patch for the last piece of waves 4..7 when the block count is odd
+#define HALO_PIECE_LIVE(j_) (2 * (j_) + 1 < BLOCKS || 2 * (j_) + (wave >> 2) < BLOCKS)
 // one piece of the next chunk's patch (piece index compile time); after the last piece the stream advances
 #define HALO_ISSUE_PIX(j_, pa_)                                                                       \
   do {                                                                                                \
     const int pc__ = p_chunk < p_wrap ? p_chunk : (p_chunk < 2 * p_wrap ? p_chunk - p_wrap : p_chunk - 2 * p_wrap); \
     const unsigned v__ = (pa_) == RN_OOB ? RN_OOB : (pa_) + (unsigned)(pc__ * (BK * 2) + (wave & 3) * 16); \
-    if (!(HALO_ABLATE & 2))                                                                           \
+    if (!(HALO_ABLATE & 2) && HALO_PIECE_LIVE(j_))                                                    \
       dma16(rs_x, smem + (p_par & 1) * PIX_BYTES + (wave & 3) * PLANE + (2 * (j_) + (wave >> 2)) * 1024, v__); \
     if ((j_) == PIECES - 1 && p_v < total) {                                                          \
       p_par ^= 1;                                                                                     \
@@ -312,8 +341,8 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
 #define HALO_SETUP_W()                                                                                \
   do {                                                                                                \
     const int tile__ = halo_tile_of<SPLIT>(w_v, args, total);                                         \
-    const int si__ = halo_seg_of_tile(smem, tile__);                                                  \
-    const HaloSeg sg__ = halo_seg(smem, si__);                                                        \
+    const int si__ = halo_seg_of_tile<SEG_TABLE>(smem, tile__);                                                  \
+    const HaloSeg sg__ = halo_seg<SEG_TABLE>(smem, si__);                                                        \
     const int lt__ = tile__ - sg__.tile_begin;                                                        \
     const int n0__ = (lt__ - rn_fdiv(lt__, sg__.n_tiles, rn_rcp((float)sg__.n_tiles)) * sg__.n_tiles) * BN; \
     w_nch = sg__.CinP / BK;                                                                           \
@@ -344,7 +373,8 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
     char* st__ = smem + W_RING + ((tap_) % 3) * W_STAGE;                                              \
     if (!(HALO_ABLATE & 2)) {                                                                         \
       dma16(rs_w, st__ + wave * 1024, b_off + koff__);                                                \
-      dma16(rs_w, st__ + (NW + wave) * 1024, w_step1 == RN_OOB ? RN_OOB : b_off + koff__ + w_step1);  \
+      if (W_PIECES == 2)   /* a 256-row stage; the 128-row stage of the 512 x 128 tiles is one piece per wave */ \
+        dma16(rs_w, st__ + (NW + wave) * 1024, w_step1 == RN_OOB ? RN_OOB : b_off + koff__ + w_step1); \
     }                                                                                                 \
     if ((tap_) == 8) {                                                                                \
       if (++w_chunk == (SPLIT ? w_end : w_nch)) {                                                     \
@@ -374,8 +404,8 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
 #define HALO_SETUP_COMPUTE()                                                                          \
   do {                                                                                                \
     const int tile__ = halo_tile_of<SPLIT>(c_v, args, total);                                         \
-    c_si = halo_seg_of_tile(smem, tile__);                                                            \
-    const HaloSeg sg__ = halo_seg(smem, c_si);                                                        \
+    c_si = halo_seg_of_tile<SEG_TABLE>(smem, tile__);                                                            \
+    const HaloSeg sg__ = halo_seg<SEG_TABLE>(smem, c_si);                                                        \
     const int lt__ = tile__ - sg__.tile_begin;                                                        \
     const int mt__ = rn_fdiv(lt__, sg__.n_tiles, rn_rcp((float)sg__.n_tiles));                     \
     c_m0 = mt__ * BM;                                                                                 \
@@ -428,9 +458,15 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
     if (w_v < total) {                                                                                \
       HALO_ISSUE_W(((tap_) + 2) % 9);                                                                 \
       if (pix__) HALO_ISSUE_PIX((tap_) - 1, pa_next);                                                 \
+      /* the counted wait: everything but this segment's own pieces (W_PIECES of weights + a live patch piece) */ \
       if (HALO_ABLATE & 3) {                                                                          \
-      } else if (pix__) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                              \
-      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                           \
+      } else if (pix__ && HALO_PIECE_LIVE((tap_) - 1)) {                                              \
+        if (W_PIECES == 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                           \
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                         \
+      } else {                                                                                        \
+        if (W_PIECES == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                           \
+        else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");                                         \
+      }                                                                                               \
     } else {                                                                                          \
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
     }                                                                                                 \
@@ -463,13 +499,13 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
   if (blockIdx.x == 0 && tid == 0) { g_halo_clk[0] = clock64(); g_halo_clk[1] = wall_clock64(); for (int q = 8; q < 48; ++q) g_halo_clk[q] = 0; }
 #endif
   // ---- prologue -------------------------------------------------------------------------------------------
-  halo_seg_table_fill(smem, args, tid);
+  halo_seg_table_fill<SEG_TABLE>(smem, args, tid);
   __syncthreads();
   HALO_SETUP_PIX();
   HALO_SETUP_W();
   __syncthreads();   // the PA / base tables are written by all waves
   HALO_SETUP_COMPUTE();
-  big_acc_init<OUT_F32, HAS_RES>(acc, args, c_si, c_n0, wave, !SPLIT || c_chunk == 0);   // the bias belongs to part 0 of a split tile
+  big_acc_init<OUT_F32, HAS_RES, WM>(acc, args, c_si, c_n0, wave, !SPLIT || c_chunk == 0);   // the bias belongs to part 0 of a split tile
   // patch of the unit's first chunk (5 pieces), then the weights of stream steps 0 and 1
   {
     unsigned pa0[PIECES];
@@ -480,13 +516,17 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
     __syncthreads();   // a one-chunk tile: the last piece below already sets up the NEXT tile's tables
     HALO_ISSUE_PIX(0, pa0[0]); HALO_ISSUE_PIX(1, pa0[1]); HALO_ISSUE_PIX(2, pa0[2]); HALO_ISSUE_PIX(3, pa0[3]);
     HALO_ISSUE_PIX(4, pa0[4]);
+    if (PIECES == 7) { HALO_ISSUE_PIX(5, pa0[PIECES == 7 ? 5 : 0]); HALO_ISSUE_PIX(6, pa0[PIECES == 7 ? 6 : 0]); }
+    static_assert(PIECES == 5 || PIECES == 7, "prologue issues the first chunk's pieces by hand");
   }
   HALO_ISSUE_W(0); HALO_ISSUE_W(1);
-  asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // the patch and step 0 have landed
+  // the patch and step 0 have landed (step 1's weight pieces may still fly)
+  if (W_PIECES == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
   HALO_BARRIER();
   // pre-roll: both groups read step 0 and issue step 2; group 1 does so as its slot-0 load segment
   HALO_LOADSEG(0);
-  if (wave_m == 1) HALO_BARRIER();
+  if (grp == 1) HALO_BARRIER();
 
   // ---- main loop: nine taps per pass, one loop body for both groups --------------------------------------------
   // slot 2g: group 0 compute(g) | group 1 load(read g, issue g+3); slot 2g+1: group 0 load(read g+1, issue g+4)
@@ -497,7 +537,7 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
   if (__builtin_expect(++c_chunk == c_nch, 0)) {                                          \
     if (SPLIT) break;   /* a part of a split tile, the workgroup's only unit: handled behind the loop */ \
     HALO_EPI_PROBE(8);                                                                    \
-    big_epilogue<OUT_F32, HAS_RES, BN_BWD>(acc, args, c_si, c_m0, c_n0, wave,                              \
+    big_epilogue<OUT_F32, HAS_RES, BN_BWD, false, WM>(acc, args, c_si, c_m0, c_n0, wave,                   \
                           smem + ((c_par ^ 1) & 1) * PIX_BYTES + wave * 4096 /* 32 KB of the dead 40 KB patch */); \
     HALO_EPI_PROBE(9);                                                                    \
     HALO_EPI_COUNT();                                                                     \
@@ -505,7 +545,7 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
     c_v += G;                                                                             \
     HALO_LANE_CONSTS();                                                                   \
     HALO_SETUP_COMPUTE();                                                                 \
-    big_acc_init<OUT_F32, HAS_RES>(acc, args, c_si, c_n0, wave, !SPLIT || c_chunk == 0);  \
+    big_acc_init<OUT_F32, HAS_RES, WM>(acc, args, c_si, c_n0, wave, !SPLIT || c_chunk == 0);  \
     HALO_EPI_PROBE_AT(11, 2);                                                             \
   }
 // One loop body for both groups (the barrier that follows the compute segment sits before the tile-end work for
@@ -513,9 +553,9 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
 // than the instruction cache, and every tile's epilogue / set-up code is fetched again.
 #define HALO_STEP(next_tap_)                     \
   HALO_COMPUTESEG();                             \
-  if (wave_m == 0) HALO_BARRIER();               \
+  if (grp == 0) HALO_BARRIER();               \
   if ((next_tap_) == 0) { HALO_CHUNK_END() }     \
-  if (wave_m == 1) HALO_BARRIER();               \
+  if (grp == 1) HALO_BARRIER();               \
   HALO_LOADSEG(next_tap_);                       \
   if ((next_tap_) == 0) { HALO_EPI_PROBE2() }    \
   HALO_BARRIER();
@@ -550,7 +590,7 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
     HALO_STEP(8) HALO_STEP(0)
   }
   if (SPLIT) {   // partial accumulators through the workspace; part 0 then runs the tile's epilogue
-    if (wave_m == 1) HALO_BARRIER();   // group 0 left the loop one barrier ahead of group 1
+    if (grp == 1) HALO_BARRIER();   // group 0 left the loop one barrier ahead of group 1
     if (halo_split_exchange(acc, args, c_v, wave)) {
       BigEpiSrc src;
       unsigned lane2_;
@@ -558,7 +598,7 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
       src.slots = (const char*)args.ws + RN_SPLITK_HEADER_BYTES + (size_t)c_v * RN_SPLITK_SLOT_BYTES;   // part 0: c_v = l * S
       src.nparts = args.split_s;
       src.voff = (int)(wave * 32768 + lane2_ * 16);
-      big_epilogue<OUT_F32, HAS_RES, BN_BWD, true>(acc, args, c_si, c_m0, c_n0, wave,
+      big_epilogue<OUT_F32, HAS_RES, BN_BWD, true, WM>(acc, args, c_si, c_m0, c_n0, wave,
                                                    smem + ((c_par ^ 1) & 1) * PIX_BYTES + wave * 4096, src);
     }
   }
@@ -569,32 +609,33 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
 
 }  // namespace
 
-template <bool SPLIT>
+template <bool SPLIT, int WM>
 static int halo_launch(const ConvArgs& a, bool out_f32, int grid, hipStream_t st) {
+  constexpr int LDS = HaloGeo<WM>::LDS_BYTES;
   static unsigned long long attr_set = 0;   // per template instantiation, one bit per device
   if (RN_FIRST_ON_DEVICE(attr_set)) {
-    RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<false, false, false, SPLIT>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<false, true, false, SPLIT>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<true, false, false, SPLIT>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<true, true, false, SPLIT>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<false, false, true, SPLIT>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<false, false, false, SPLIT, WM>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<false, true, false, SPLIT, WM>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<true, false, false, SPLIT, WM>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<true, true, false, SPLIT, WM>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<false, false, true, SPLIT, WM>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
   }
   bool has_res = false;   // one residual input anywhere -> the variant that carries the residual path
   for (int i = 0; i < a.nseg; ++i) has_res = has_res || a.seg[i].residual != nullptr;
   const dim3 g3(grid), b3(512);
   if (a.seg[0].bn_y) {   // data gradient + stage 1 of the BatchNorm backward reduction (validated by the caller)
-    hipLaunchKernelGGL((conv_halo_kernel<false, false, true, SPLIT>), g3, b3, LDS_BYTES, st, a);
+    hipLaunchKernelGGL((conv_halo_kernel<false, false, true, SPLIT, WM>), g3, b3, LDS, st, a);
   } else if (out_f32) {
-    if (has_res) hipLaunchKernelGGL((conv_halo_kernel<true, true, false, SPLIT>), g3, b3, LDS_BYTES, st, a);
-    else hipLaunchKernelGGL((conv_halo_kernel<true, false, false, SPLIT>), g3, b3, LDS_BYTES, st, a);
+    if (has_res) hipLaunchKernelGGL((conv_halo_kernel<true, true, false, SPLIT, WM>), g3, b3, LDS, st, a);
+    else hipLaunchKernelGGL((conv_halo_kernel<true, false, false, SPLIT, WM>), g3, b3, LDS, st, a);
   } else {
-    if (has_res) hipLaunchKernelGGL((conv_halo_kernel<false, true, false, SPLIT>), g3, b3, LDS_BYTES, st, a);
-    else hipLaunchKernelGGL((conv_halo_kernel<false, false, false, SPLIT>), g3, b3, LDS_BYTES, st, a);
+    if (has_res) hipLaunchKernelGGL((conv_halo_kernel<false, true, false, SPLIT, WM>), g3, b3, LDS, st, a);
+    else hipLaunchKernelGGL((conv_halo_kernel<false, false, false, SPLIT, WM>), g3, b3, LDS, st, a);
   }
   RN_CHECK_LAUNCH();
   return RN_OK;
@@ -604,15 +645,17 @@ static int halo_launch(const ConvArgs& a, bool out_f32, int grid, hipStream_t st
 // split plan (rn_splitk_plan: a.split_s > 1) the launch is TWO kernels: the full rounds — tiles [0, split_f), the
 // round-3 kernel untouched — and the SPLIT instantiation for the tiles of the last round, one part per workgroup.  (The
 // unit mapping inside the persistent loop cost the whole-tile kernel 10 % — registers — for a 5 % shorter tail.)
-int rn_launch_conv_halo(const ConvArgs& a, bool out_f32, const rn_launch_opts& opts, hipStream_t st) {
-  if (a.split_s <= 1) return halo_launch<false>(a, out_f32, rn_persistent_grid(a.total_tiles, rn_num_cus(), opts), st);
+// wm = 4: the 512 x 128 tiles of the narrow layers (whole tiles only).
+int rn_launch_conv_halo(const ConvArgs& a, bool out_f32, const rn_launch_opts& opts, hipStream_t st, int wm) {
+  if (wm == 4) return halo_launch<false, 4>(a, out_f32, rn_persistent_grid(a.total_tiles, rn_num_cus(), opts), st);
+  if (a.split_s <= 1) return halo_launch<false, 2>(a, out_f32, rn_persistent_grid(a.total_tiles, rn_num_cus(), opts), st);
   if (a.split_f > 0) {
     ConvArgs full = a;
     full.total_tiles = a.split_f;   // tile_of() then numbers the first split_f tiles
-    const int rc = halo_launch<false>(full, out_f32, rn_persistent_grid(full.total_tiles, rn_num_cus(), opts), st);
+    const int rc = halo_launch<false, 2>(full, out_f32, rn_persistent_grid(full.total_tiles, rn_num_cus(), opts), st);
     if (rc != RN_OK) return rc;
   }
-  return halo_launch<true>(a, out_f32, a.vtotal, st);
+  return halo_launch<true, 2>(a, out_f32, a.vtotal, st);
 }
 
 // patch pixels the worst tile of an [N, H, W] tensor needs (rows from one above its first pixel row to one below
@@ -624,7 +667,7 @@ int rn_launch_conv_halo(const ConvArgs& a, bool out_f32, const rn_launch_opts& o
 // -> 35.11 / 35.13 ms: the 9 % more patch bytes through the LDS-DMA cost more than the conflicts did) and was removed.
 int rn_conv_halo_pitch(int W) { return W + 1; }
 
-int rn_conv_halo_patch_pixels(int N, int H, int W, int pitch) {
+int rn_conv_halo_patch_pixels(int N, int H, int W, int pitch, int BM) {   // BM: pixels per tile, 256 or 512
   const long long M = (long long)N * H * W, HW = (long long)H * W;
   long long worst = 0;
   for (long long m0 = 0; m0 < M; m0 += BM) {
@@ -635,4 +678,4 @@ int rn_conv_halo_patch_pixels(int N, int H, int W, int pitch) {
   }
   return (int)(worst * pitch + 1);
 }
-int rn_conv_halo_capacity() { return PIX_PX; }
+int rn_conv_halo_capacity(int BM) { return BM == 512 ? HaloGeo<4>::PIX_PX : HaloGeo<2>::PIX_PX; }

@@ -230,67 +230,38 @@ __device__ __forceinline__ void bn_finalize_channel(const BnArgs& a, const BnSeg
   }
 }
 
-// 1024 threads = 4 channel quads x 256 chunk lanes over the workgroup's 16 channels: a lane sums its chunks (k = lane,
-// lane + 256, ...) in double from 16-byte loads, the 16 lanes of a wave that share a channel quad are folded by a fixed
-// shuffle tree, the 16 wave sums are added in wave order — the same bits on every run.  (The 16 channels x 64 lanes form
-// read 4 bytes per lane with a 2*C*4-byte stride, 100 dependent rounds on the stage-1 layers' 13 MB of partials: up to
-// 34 us per launch, 115 launches per step.)
+// 1024 threads = 16 channels x 64 chunk lanes (the 32 x 32 form spent most of its ~9 us per launch in 50-deep serial
+// load chains on 8 workgroups); every lane sums its chunks in double, the 64 lane sums are added in lane order
 __global__ void __launch_bounds__(1024) bn_colreduce_final_kernel(const BnArgs a) {
   const BnSegDev& s = a.seg[blockIdx.y];
-  __shared__ double red[2][16][17];
-  const int cq = threadIdx.x & 3, lane = threadIdx.x >> 2, wave = threadIdx.x >> 6;
-  const int c0 = blockIdx.x * 16 + cq * 4;
-  double t0[4] = {0.0, 0.0, 0.0, 0.0}, t1[4] = {0.0, 0.0, 0.0, 0.0};
-  if (c0 < s.C) {
-    const float* p = a.ws + a.ws_off[blockIdx.y];
-    if ((s.C & 3) == 0 && (a.ws_off[blockIdx.y] & 3) == 0) {   // 16-byte aligned rows
-#pragma unroll 4
-      for (int k = lane; k < s.chunks; k += 256) {
-        const float4 u = *(const float4*)(p + ((long long)k * 2 + 0) * s.C + c0);
-        const float4 v = *(const float4*)(p + ((long long)k * 2 + 1) * s.C + c0);
-        t0[0] += (double)u.x; t0[1] += (double)u.y; t0[2] += (double)u.z; t0[3] += (double)u.w;
-        t1[0] += (double)v.x; t1[1] += (double)v.y; t1[2] += (double)v.z; t1[3] += (double)v.w;
-      }
-    } else {   // a channel count that is no multiple of 4: element loads
-      for (int k = lane; k < s.chunks; k += 256)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (c0 + q < s.C) {
-            t0[q] += (double)p[((long long)k * 2 + 0) * s.C + c0 + q];
-            t1[q] += (double)p[((long long)k * 2 + 1) * s.C + c0 + q];
-          }
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-#pragma unroll
-    for (int o = 4; o < 64; o <<= 1) {   // the 16 lanes of this wave with the same channel quad (lane bits 2..5)
-      t0[q] += __shfl_xor(t0[q], o, 64);
-      t1[q] += __shfl_xor(t1[q], o, 64);
-    }
-  }
-  if ((threadIdx.x & 63) < 4) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      red[0][wave][cq * 4 + q] = t0[q];
-      red[1][wave][cq * 4 + q] = t1[q];
-    }
-  }
-  __syncthreads();
-  const int cl = threadIdx.x & 15;
+  __shared__ double red[2][64][17];
+  const int cl = threadIdx.x & 15, lane = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
+  double t0 = 0.0, t1 = 0.0;
+  if (c < s.C) {
+    const float* p = a.ws + a.ws_off[blockIdx.y];
+#pragma unroll 4
+    for (int k = lane; k < s.chunks; k += 64) {
+      t0 += (double)p[((long long)k * 2 + 0) * s.C + c];
+      t1 += (double)p[((long long)k * 2 + 1) * s.C + c];
+    }
+  }
+  red[0][lane][cl] = t0;
+  red[1][lane][cl] = t1;
+  __syncthreads();
   if (threadIdx.x < 32) {
     const int which = threadIdx.x >> 4;
-    if (c < s.C) {
+    const int cc = blockIdx.x * 16 + cl;
+    if (cc < s.C) {
       double t = 0.0;
-      for (int j = 0; j < 16; ++j) t += red[which][j][cl];
+      for (int j = 0; j < 64; ++j) t += red[which][j][cl];
       float* out = a.mode == 0 ? s.sums : s.bsums;
-      out[which * s.C + c] = (float)t;
+      out[which * s.C + cc] = (float)t;
       // gamma / beta gradients are THIS replica's sums (tf.gradients of SyncBatchNormalization: only the
       // optimizer's all-reduce makes them global) — written here, before the caller all-reduces bsums
       if (a.mode == 1) {
         float* gp = which == 0 ? s.dbeta : s.dgamma;
-        if (gp) gp[c] = (float)t;
+        if (gp) gp[cc] = (float)t;
       }
       red[which][0][cl] = (double)(float)t;   // for the fused finalize below (same value the unfused path reads)
     }

@@ -563,6 +563,8 @@ class TrainEngine:
                 f"{'true' if bnb else 'false'}>")
         if kid == 2:
             variant = "conv_halo_kernel" + tmpl + " (256x256x32, 3x3 halo patch)"
+        elif kid == 3:     # the same kernel template with 4 x 2 waves: 512 x 128 tiles (64 < Cout <= 128)
+            variant = "conv_halo_kernel" + tmpl[:-1] + ", false, 4> (512x128x32, 3x3 halo patch)"
         elif kid == 1:
             variant = "conv_big_kernel" + tmpl + " (256x256x32)"
         elif dom:
@@ -759,7 +761,7 @@ class TrainEngine:
             rows = self.lib.rn_conv_tile_rows(ctypes.byref(conv_problem))   # the kernel the dispatcher will run
             for i in range(len(ops)):
                 P = p.seg[i].P
-                p.seg[i].ext_chunks = 2 * ((P + 255) // 256) if rows == 256 else (P + 127) // 128
+                p.seg[i].ext_chunks = (rows // 128) * ((P + rows - 1) // rows)     # one row of partial sums per 128 output pixels
         ws = torch.empty((max(self.lib.rn_bn_workspace_bytes(ctypes.byref(p)), 256),), dtype=torch.uint8,
                          device=self.dev)
         if fused:
@@ -1509,7 +1511,7 @@ class TrainEngine:
                 pend["done"] = True
                 for j, (_, _, _, r) in pend["seg"].items():
                     P = int(pb.seg[j].P)
-                    pb.seg[j].ext_chunks_bwd = 2 * ((P + 255) // 256) if r == 256 else (P + 127) // 128
+                    pb.seg[j].ext_chunks_bwd = (r // 128) * ((P + r - 1) // r)
                 wsb = torch.empty((max(lib.rn_bn_workspace_bytes(ctypes.byref(pb)), 256),), dtype=torch.uint8, device=self.dev)
                 self.bn_bwd_ws[key] = wsb
                 for j, (cp, ci, name, _) in pend["seg"].items():

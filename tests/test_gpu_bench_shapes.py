@@ -123,7 +123,7 @@ def _check_conv_launch(cuda, eng, name, p):
             if s.residual == s.y:            # the accumulating data-gradient launches: residual = the gradient buffer itself
                 y.copy_(t["residual"])
         P = s.N * s.Ho * s.Wo
-        chunks = 2 * ((P + 255) // 256) if rows == 256 else (P + 127) // 128
+        chunks = (rows // 128) * ((P + rows - 1) // rows)
         if s.bn_partial:
             t["partial"] = torch.full((chunks, 2, s.Cout), float("nan"), dtype=torch.float32, device=cuda)
         if s.bn_bwd_y:

@@ -320,6 +320,53 @@ def test_conv_halo_split_last_round(cuda, build, case):
         assert (runs[0] != whole).float().mean().item() < 0.02
 
 
+HALO512_CASES = [
+    # N, H, W, Cin, Cout, act, residual, out_f32, persistent workgroups   (3x3 / stride 1 / pad 1, 64 < Cout <= 128)
+    (2, 80, 80, 128, 128, "relu", False, False, 0),    # ResNet stage 2 at its own width: 6.4 rows per 512-pixel tile, 4 chunks
+    (3, 24, 24, 128, 128, "relu", True, False, 2),     # tiles straddle images; 4 tiles over 2 workgroups (two rounds)
+    (5, 5, 5, 64, 96, None, False, False, 0),          # one tile over five tiny images (many pad rows); Cout tail (96 of 128)
+    (1, 40, 40, 256, 128, "relu6", False, False, 3),   # 8 chunks, M tail (1600 = 3 tiles + 64 pixels)
+    (2, 13, 9, 96, 72, "swish", True, False, 0),       # odd sizes, 3 chunks, Cout = 72
+    (1, 20, 20, 64, 128, None, False, True, 0),        # f32 output
+    (40, 3, 3, 32, 128, None, False, False, 0),        # single chunk; 56 images per tile
+    (2, 1, 7, 64, 128, None, False, False, 0),         # H = 1
+]
+
+
+@pytest.mark.parametrize("build,case", _builds(HALO512_CASES, HALO512_CASES[:5], "halo512-"))
+def test_conv_halo_kernel_512x128_tiles(cuda, build, case):
+    """3x3 / stride 1 / pad 1 with 64 < Cout <= 128 through the halo kernel's 512 x 128 form (rn_conv_halo.hip, HaloGeo<4>:
+    4 x 2 waves, 13-block patches, one weight piece per wave), against the float64 reference and against the 128-row
+    kernel on the same inputs (same products, other summation order)."""
+    from retinanet import _C
+    lib = _lib()
+    N, H, W, Cin, Cout, act, use_res, out_f32, wgs = case
+    g = torch.Generator().manual_seed(_seed(case))
+    s = {"x": torch.randn((N, H, W, Cin), generator=g),
+         "w": torch.randn((3, 3, Cin, Cout), generator=g) / math.sqrt(9 * Cin),
+         "scale": torch.rand((Cout,), generator=g) + 0.5, "shift": torch.randn((Cout,), generator=g) * 0.1}
+    if use_res:
+        s["residual"] = torch.randn((N, H, W, Cout), generator=g)
+    p = _C.ConvProblem()
+    p.R = p.S = 3
+    p.stride_h = p.stride_w = p.pad_top = p.pad_left = 1
+    p.out_dtype, p.num_segments = (_C.RN_DT_F32 if out_f32 else _C.RN_DT_BF16), 1
+    sg = p.seg[0]
+    sg.N, sg.H, sg.W, sg.Cin, sg.pix_stride, sg.Ho, sg.Wo, sg.Cout = N, H, W, Cin, Cin, H, W, Cout
+    p.opts = _C.LaunchOpts(conv_tile=2)
+    assert lib.rn_conv_kernel_id(ctypes.byref(p)) == 3 and lib.rn_conv_tile_rows(ctypes.byref(p)) == 512
+    got = _conv_gpu(cuda, [s], 3, 1, 1, act, out_f32, dict(conv_tile=2, max_workgroups=wgs))[0]
+    p.opts = _C.LaunchOpts(conv_tile=1)
+    assert lib.rn_conv_kernel_id(ctypes.byref(p)) == 0
+    small = _conv_gpu(cuda, [s], 3, 1, 1, act, out_f32, dict(conv_tile=1))[0]
+    want = _conv_ref(s, 3, 1, 1, act, out_f32)
+    _close(got, want, out_f32)
+    scale = want.abs().max().item() + 1e-6
+    torch.testing.assert_close(got, small, rtol=1.0 / 128 if not out_f32 else 1e-4, atol=scale * (1 / 256 if not out_f32 else 1e-5))
+    if not out_f32:
+        assert (got != small).float().mean().item() < 0.02
+
+
 BIAS_CASES = [
     # N, H, W, Cin, Cout, k, act, persistent workgroups (0 = one per CU)
     (2, 24, 24, 64, 256, 3, "relu", 0),

@@ -485,8 +485,8 @@ def test_bn_train_forward_backward(cuda, build, act, use_res):
         torch.testing.assert_close(d["moving_var"].cpu().double(), mv, rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("build,k,tile", [("bf16", 1, 2), ("bf16", 3, 2), ("bf16", 1, 1), ("bf16", 3, 1),
-                                          ("f16", 1, 2), ("f16", 3, 2), ("f16", 3, 1)])
+@pytest.mark.parametrize("build,k,tile", [("bf16", 1, 2), ("bf16", 3, 2), ("bf16", 1, 1), ("bf16", 3, 1), ("bf16", 3, 3),
+                                          ("f16", 1, 2), ("f16", 3, 2), ("f16", 3, 1), ("f16", 3, 3)])
 def test_bn_forward_stats_fused_into_conv_epilogue(cuda, build, k, tile):
     """rn_conv_segment.bn_partial + rn_bn_segment.ext_chunks: the 256-row conv kernel writes the per-128-row partial
     sums, rn_bn_stats only runs the final reduction.  Must give the statistics of the unfused path on the same
@@ -495,6 +495,8 @@ def test_bn_forward_stats_fused_into_conv_epilogue(cuda, build, k, tile):
     lib = _lib()
     g = torch.Generator().manual_seed(23)
     shapes = [(2, 19, 21, 128, 256), (1, 16, 16, 128, 320), (3, 7, 5, 128, 512)]   # N, H, W, Cin, Cout
+    if tile == 3:   # 64 < Cout <= 128: the halo kernel's 512 x 128 tiles (4 row blocks of partial sums per tile)
+        shapes = [(2, 19, 21, 128, 128), (1, 26, 26, 64, 96), (3, 7, 5, 128, 120)]
     pc = _C.ConvProblem()
     pc.R = pc.S = k            # k = 3: the halo-patch kernel (rn_conv_halo.hip), same epilogue
     pc.stride_h = pc.stride_w = 1
@@ -515,12 +517,12 @@ def test_bn_forward_stats_fused_into_conv_epilogue(cuda, build, k, tile):
         segs.append({"y": torch.zeros((N, H, W, cout)), "gamma": torch.ones((cout,)), "beta": torch.zeros((cout,)),
                      "moving_mean": torch.zeros((cout,)), "moving_var": torch.ones((cout,))})
     st = _C.current_stream()
-    pc.opts = _C.LaunchOpts(conv_tile=tile)       # 2: the 256-row kernels, 1: the 128-row kernel (one partial row per tile)
+    pc.opts = _C.LaunchOpts(conv_tile=min(tile, 2))   # 2 / 3: the 256- / 512-row kernels, 1: the 128-row kernel (one partial row per tile)
     if True:
         rows = lib.rn_conv_tile_rows(ctypes.byref(pc))
-        assert rows == (256 if tile == 2 else 128)
-        if tile == 2:
-            assert lib.rn_conv_kernel_id(ctypes.byref(pc)) == (2 if k == 3 else 1)
+        assert rows == {1: 128, 2: 256, 3: 512}[tile]
+        if tile >= 2:
+            assert lib.rn_conv_kernel_id(ctypes.byref(pc)) == (3 if tile == 3 else (2 if k == 3 else 1))
         sums = {}
         for fused in (False, True):
             p, dev = _bn_problem(cuda, segs, None)
@@ -528,7 +530,7 @@ def test_bn_forward_stats_fused_into_conv_epilogue(cuda, build, k, tile):
                 p.seg[i].y = y.data_ptr()
                 if fused:
                     P = p.seg[i].P
-                    p.seg[i].ext_chunks = 2 * ((P + 255) // 256) if rows == 256 else (P + 127) // 128
+                    p.seg[i].ext_chunks = (rows // 128) * ((P + rows - 1) // rows)
             ws = _ws(lib.rn_bn_workspace_bytes(ctypes.byref(p)), cuda)
             ws.fill_(0x7f)    # stale bytes must not leak into the sums
             for i in range(len(ys)):
@@ -546,8 +548,8 @@ def test_bn_forward_stats_fused_into_conv_epilogue(cuda, build, k, tile):
         torch.testing.assert_close(sums[True][i], want, rtol=1e-5, atol=tol)
 
 
-@pytest.mark.parametrize("build,k,tile", [("bf16", 1, 2), ("bf16", 3, 2), ("bf16", 1, 1), ("bf16", 3, 1),
-                                          ("f16", 1, 2), ("f16", 3, 2), ("f16", 3, 1)])
+@pytest.mark.parametrize("build,k,tile", [("bf16", 1, 2), ("bf16", 3, 2), ("bf16", 1, 1), ("bf16", 3, 1), ("bf16", 3, 3),
+                                          ("f16", 1, 2), ("f16", 3, 2), ("f16", 3, 1), ("f16", 3, 3)])
 def test_bn_backward_reduction_fused_into_the_data_gradient(cuda, build, k, tile):
     """rn_conv_segment.bn_bwd_y + rn_bn_segment.ext_chunks_bwd: the launch that writes dz of a BatchNorm + ReLU layer
     also writes stage 1 of that layer's backward reduction (sum g, sum g*xhat); rn_bn_bwd_reduce only runs the ordered
@@ -558,6 +560,8 @@ def test_bn_backward_reduction_fused_into_the_data_gradient(cuda, build, k, tile
     lib = _lib()
     g = torch.Generator().manual_seed(29)
     shapes = [(2, 19, 21, 128, 256), (1, 16, 16, 128, 320), (3, 7, 5, 128, 512)]   # N, H, W, Cin, Cout
+    if tile == 3:   # 64 < Cout <= 128: the halo kernel's 512 x 128 tiles (4 row blocks of partial sums per tile)
+        shapes = [(2, 19, 21, 128, 128), (1, 26, 26, 64, 96), (3, 7, 5, 128, 120)]
     pc = _C.ConvProblem()
     pc.R = pc.S = k
     pc.stride_h = pc.stride_w = 1
@@ -582,12 +586,12 @@ def test_bn_backward_reduction_fused_into_the_data_gradient(cuda, build, k, tile
                      "gamma": torch.rand((cout,), generator=g) + 0.5, "beta": torch.randn((cout,), generator=g) * 0.3,
                      "moving_mean": torch.zeros((cout,)), "moving_var": torch.ones((cout,))})
     st = _C.current_stream()
-    pc.opts = _C.LaunchOpts(conv_tile=tile)
+    pc.opts = _C.LaunchOpts(conv_tile=min(tile, 2))
     if True:
         rows = lib.rn_conv_tile_rows(ctypes.byref(pc))
-        assert rows == (256 if tile == 2 else 128)
-        if tile == 2:
-            assert lib.rn_conv_kernel_id(ctypes.byref(pc)) == (2 if k == 3 else 1)
+        assert rows == {1: 128, 2: 256, 3: 512}[tile]
+        if tile >= 2:
+            assert lib.rn_conv_kernel_id(ctypes.byref(pc)) == (3 if tile == 3 else (2 if k == 3 else 1))
         out = {}
         for fused in (False, True):
             p, dev = _bn_problem(cuda, segs, "relu")
@@ -596,7 +600,7 @@ def test_bn_backward_reduction_fused_into_the_data_gradient(cuda, build, k, tile
                 p.seg[i].dz = dz.data_ptr()
                 if fused:
                     P = p.seg[i].P
-                    p.seg[i].ext_chunks_bwd = 2 * ((P + 255) // 256) if rows == 256 else (P + 127) // 128
+                    p.seg[i].ext_chunks_bwd = (rows // 128) * ((P + rows - 1) // rows)
             ws = _ws(lib.rn_bn_workspace_bytes(ctypes.byref(p)), cuda)
             _C.check(lib.rn_bn_stats_finalize(ctypes.byref(p), _C.ptr(ws), ws.numel(), st))   # mean | invstd | scale | shift
             _C.check(lib.rn_bn_apply(ctypes.byref(p), st))
