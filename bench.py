@@ -89,7 +89,7 @@ def conv_variant(engine, step_name):
             kid = engine.lib.rn_conv_kernel_id(ctypes.byref(p))
             res = "true" if any(p.seg[i].residual for i in range(p.num_segments)) else "false"
             if kid == 2:
-                return f"conv_halo_kernel<false, {res}, false> (256x256x32, 3x3 halo patch)"
+                return f"conv_halo_kernel<false, {res}, false, false, 2> (256x256x32, 3x3 halo patch)"
             if kid == 3:
                 return f"conv_halo_kernel<false, {res}, false, false, 4> (512x128x32, 3x3 halo patch)"
             if kid == 1:
@@ -173,7 +173,7 @@ def run_train(args, dev, rank, world, params=None):
     # another kernel — same K loop, same tiles — so its two device symbols are ONE roofline entry, with the
     # per-symbol figures kept under `symbols` (what a rocprof kernel-stats row can be matched against).
     def family(variant):
-        return re.sub(r"^(conv_(?:halo|big)_kernel<\w+, \w+), \w+>", r"\1, *>", variant)
+        return re.sub(r"^(conv_(?:halo|big)_kernel<\w+, \w+), \w+([,>])", r"\1, *\2", variant)
 
     def per_kernel(events, key=family):
         acc_by = {}

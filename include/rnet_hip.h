@@ -178,7 +178,8 @@ int rn_rowmax_argmax(const float* scores, int64_t rows, int K, float* max_out, i
  */
 typedef struct {
   int32_t conv_tile;           /* 0: auto | 1: the 128-row conv_fwd_kernel with its full 128-column tiles (auto narrows them to 64
-                                * columns for launches of at most half a tile per CU) | 2: the 256-row kernels wherever the shape allows */
+                                * columns for launches of at most half a tile per CU) | 2: the 256-row kernels wherever the shape allows
+                                * | 3: the 512 x 128 form of conv_halo_kernel for any Cout that is a multiple of 128 (A/B of tile shapes) */
   int32_t conv_no_halo;        /* 1: conv_big_kernel where conv_halo_kernel would run (A/B, tests) */
   int32_t conv_big_min_tiles;  /* > 0: 256-row tiles a launch needs to go to the 256-row kernels (default 192) */
   int32_t max_workgroups;      /* > 0: cap on the persistent grids of conv_big / conv_halo (default: one per CU) */
@@ -233,12 +234,19 @@ int rn_handle_comm_destroy(rn_handle* h, int slot);
  * (w = w_hi + w_lo [+ w_lo2]); the kernel walks the same input channels once per plane, so a bf16 activation times
  * an f32 weight is accumulated to 16 (24) weight mantissa bits in fp32 — how the f32 prediction convs keep their
  * f32 kernels on a bf16 MFMA.
+ * w_pair = 1 (f32 output only; instead of w_terms = 2): the two planes are stacked along COUT — packed rows
+ * [64b, 64b + 32) = w_hi of channels [32b, 32b + 32), rows [64b + 32, 64b + 64) = w_lo of the same channels
+ * (rn_pack_conv_weight_pair, rn_conv_pair_rows(Cout) rows) — the input is walked once, hi and lo products land in two
+ * accumulator tiles of one wave and are added in the epilogue: y = (bias + sum x*w_hi) + sum x*w_lo.  For NARROW f32
+ * layers (the 36-channel box prediction conv: 72 of 128 GEMM columns used, on the 512 x 128 tiles of the halo kernel,
+ * instead of a 64-column tile of the 128-row kernel that stages the pixels once per tap and plane).  Only the 256- / 512-row
+ * kernels take it: ask rn_conv_kernel_id() on the problem (0 -> RN_EINVAL at launch).
  */
 #define RN_CONV_MAX_SEGMENTS 10
 
 typedef struct {
   const void* x;        /* bf16 [N,H,W,pix_stride] (pix_stride >= Cin elements between pixels) */
-  const void* w;        /* bf16 [Cout_pad, R, S, w_terms*Cin_pad] */
+  const void* w;        /* bf16 [Cout_pad, R, S, w_terms*Cin_pad]; w_pair: [rn_conv_pair_rows(Cout), R, S, Cin_pad] */
   void* y;              /* bf16 or f32 [N,Ho,Wo,Cout] */
   const float* scale;   /* f32[Cout] or NULL (=1) */
   const float* shift;   /* f32[Cout] or NULL (=0) */
@@ -254,7 +262,7 @@ typedef struct {
   float* bn_partial;
   const float* bias;    /* f32[Cout] or NULL: the Conv2D layer's bias, added to the fp32 accumulator */
   int32_t w_terms;      /* 0 or 1: plain bf16 weights; 2 / 3: split-bf16 planes along Cin (see above) */
-  int32_t pad_;
+  int32_t w_pair;       /* 1: two split-bf16 planes along Cout (see above; w_terms must be 0 / 1, f32 output) */
   /* optional: stage 1 of rn_bn_bwd_reduce fused into a DATA-GRADIENT launch.  The launch's output is dz, the gradient
    * that arrives at a BatchNorm + ReLU layer with no residual input (y = that layer's raw conv output, same shape as
    * this launch's output; bn_bwd_fwd = its rn_bn_segment.fwd: mean | invstd | scale | shift).  With both set (and
@@ -319,6 +327,11 @@ int rn_pack_conv_weight(const float* w_hwio, int R, int S, int Cin, int Cout, in
  * (the training engine's master layout). */
 int rn_pack_conv_weight_split(const float* w, int layout_ohwi, int R, int S, int Cin, int Cout, int Cin_pad, int terms,
                               void* w_packed, void* stream);
+/* Packing for rn_conv_segment.w_pair: bf16 [rn_conv_pair_rows(Cout)][R][S][Cin_pad], rows as described there
+ * (plane 0 = rb(w), plane 1 = rb(w - plane 0)); rn_conv_pair_rows(Cout) = 128 * ceil(Cout / 64). */
+int rn_conv_pair_rows(int Cout);
+int rn_pack_conv_weight_pair(const float* w, int layout_ohwi, int R, int S, int Cin, int Cout, int Cin_pad,
+                             void* w_packed, void* stream);
 /* Stem repack: 7x7x3 HWIO -> bf16 [64][7][32] rows = (kernel row r) x (8 taps x 4 channels),
  * tap 7 and channel 3 zero, matching rn_pack_stem_input's padded NHWC4 image. */
 /* The same packing from the training engine's f32 master layout [Cout][R][S][Cin]. */

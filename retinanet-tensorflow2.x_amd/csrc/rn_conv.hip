@@ -412,6 +412,14 @@ static int launch_ablate(const ConvArgs& a, hipStream_t st) {
 // rounds; the L = total mod G0 tiles of the last round are each cut into S = min(G0 / L, chunks / 4, 4) parts along K, so
 // that round keeps L * S workgroups busy for 1/S of a tile (+ the exchange of L * (S - 1) accumulator tiles through the
 // workspace) instead of L workgroups for a whole one.
+// GEMM columns of a segment: its output channels, or for w_pair (two weight planes along Cout) the packed rows
+extern "C" int rn_conv_pair_rows(int Cout) { return Cout > 0 ? 128 * ((Cout + 63) / 64) : 0; }
+static int seg_cols(const rn_conv_segment& s) { return s.w_pair ? rn_conv_pair_rows(s.Cout) : s.Cout; }
+// channel granularity of the 256- / 512-row epilogues: 16-byte rows of bf16, or of f32 (float4 stores)
+static bool seg_cout_ok(const rn_conv_problem* p, const rn_conv_segment& s) {
+  return s.Cout % (p->out_dtype == RN_DT_F32 && s.w_pair ? 4 : 8) == 0;
+}
+
 static int splitk_parts(int total, int min_chunks, int G0, long long* bytes) {
   const int L = total % G0;
   if (bytes) *bytes = 0;
@@ -430,13 +438,13 @@ static bool conv_halo_shape(const rn_conv_problem* p, int BM);
 static int conv_min_chunks(const rn_conv_problem* p);
 
 static bool conv_use_big(const rn_conv_problem* p) {
-  if (p->opts.conv_tile == 1) return false;
+  if (p->opts.conv_tile == 1 || p->opts.conv_tile == 3) return false;
   long long tiles256 = 0;
   for (int i = 0; i < p->num_segments; ++i) {
     const rn_conv_segment& s = p->seg[i];
-    if (rn_conv_cout_pad(s.Cout) < 256 || s.Cout % 8 != 0) return false;
+    if (rn_conv_cout_pad(seg_cols(s)) < 256 || !seg_cout_ok(p, s)) return false;
     if (s.bias && s.residual) return false;   // the residual variants of the 256-row kernels carry no bias path
-    tiles256 += rn_cdiv((long long)s.N * s.Ho * s.Wo, 256) * rn_cdiv(s.Cout, 256);
+    tiles256 += rn_cdiv((long long)s.N * s.Ho * s.Wo, 256) * rn_cdiv(seg_cols(s), 256);
   }
   if (p->opts.conv_tile == 2 || tiles256 >= (p->opts.conv_big_min_tiles > 0 ? p->opts.conv_big_min_tiles : 192)) return true;
   // A launch of fewer tiles than compute units (batch-8 inference, ResNet stage 3 / 4; stage 4 at any batch) used to go
@@ -490,13 +498,14 @@ static bool conv_use_halo512(const rn_conv_problem* p) {
   long long tiles = 0;
   for (int i = 0; i < p->num_segments; ++i) {
     const rn_conv_segment& s = p->seg[i];
-    if (rn_conv_cout_pad(s.Cout) != 128 || s.Cout % 8 != 0) return false;
+    const int cp = rn_conv_cout_pad(seg_cols(s));
+    if (cp % 128 != 0 || (cp != 128 && p->opts.conv_tile != 3) || !seg_cout_ok(p, s)) return false;   // conv_tile = 3: any width
     if (s.bias && s.residual) return false;   // as for the 256-row kernels: the residual variants carry no bias path
-    tiles += rn_cdiv((long long)s.N * s.Ho * s.Wo, 512);
+    tiles += rn_cdiv((long long)s.N * s.Ho * s.Wo, 512) * (cp / 128);
   }
   if (!conv_halo_shape(p, 512)) return false;
   // enough tiles to fill the chip once (opts.conv_tile = 2 forces the form: tests at small sizes)
-  return p->opts.conv_tile == 2 || tiles >= (p->opts.conv_big_min_tiles > 0 ? p->opts.conv_big_min_tiles : 128);
+  return p->opts.conv_tile >= 2 || tiles >= (p->opts.conv_big_min_tiles > 0 ? p->opts.conv_big_min_tiles : 128);
 }
 
 int rn_splitk_plan(ConvArgs& a, int min_chunks, void* ws, long long ws_bytes, const rn_launch_opts& opts) {
@@ -534,7 +543,7 @@ extern "C" size_t rn_conv_splitk_workspace_bytes(const rn_conv_problem* p) {
   long long tiles = 0;
   for (int i = 0; i < p->num_segments; ++i) {
     const rn_conv_segment& s = p->seg[i];
-    tiles += rn_cdiv((long long)s.N * s.Ho * s.Wo, 256) * rn_cdiv(rn_conv_cout_pad(s.Cout), 256);
+    tiles += rn_cdiv((long long)s.N * s.Ho * s.Wo, 256) * rn_cdiv(rn_conv_cout_pad(seg_cols(s)), 256);
   }
   long long bytes = 0;
   splitk_parts((int)tiles, mc, rn_persistent_grid(0x7fffffff, rn_num_cus(), p->opts), &bytes);
@@ -563,7 +572,7 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
   ConvArgs a;
   a.R = p->R; a.S = p->S; a.sh = p->stride_h; a.sw = p->stride_w; a.pt = p->pad_top; a.pl = p->pad_left;
   a.act = p->act; a.nseg = p->num_segments; a.pad_ = 0;
-  const int cout_pad0 = rn_conv_cout_pad(p->seg[0].Cout);
+  const int cout_pad0 = rn_conv_cout_pad(seg_cols(p->seg[0]));
   int BN = cout_pad0 <= 64 ? 64 : 128;
   // K step: 64 unless the (padded) channel count is small; Cin need only be a multiple of 8 — the
   // tail of the last K step reads past the pixel's channels (or out of range -> zeros) and meets the
@@ -579,7 +588,7 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
     // narrower tiles still fit one per CU: at two per CU they share that bandwidth again.
     long long t128 = 0;
     for (int i = 0; i < p->num_segments; ++i)
-      t128 += rn_cdiv((long long)p->seg[i].N * p->seg[i].Ho * p->seg[i].Wo, 128) * rn_cdiv(rn_conv_cout_pad(p->seg[i].Cout), 128);
+      t128 += rn_cdiv((long long)p->seg[i].N * p->seg[i].Ho * p->seg[i].Wo, 128) * rn_cdiv(rn_conv_cout_pad(seg_cols(p->seg[i])), 128);
     if (2 * t128 <= rn_num_cus() && !p->opts.ablate && p->opts.conv_tile != 1) BN = 64;   // conv_tile = 1 keeps 128 x 128 (tests)
   }
   const int BNT = big ? 256 : BN;   // n-tile width
@@ -594,8 +603,12 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
     RN_CHECK_ARG(s.pix_stride % 4 == 0 && s.pix_stride > 0,
                  "rn_conv2d_nhwc_fwd: segment %d pix_stride=%d must be a positive multiple of 4", i, s.pix_stride);
     RN_CHECK_ARG(s.Cout % 4 == 0, "rn_conv2d_nhwc_fwd: segment %d Cout=%d not a multiple of 4", i, s.Cout);
-    const int cp = rn_conv_cout_pad(s.Cout);
+    const int cp = rn_conv_cout_pad(seg_cols(s));
     RN_CHECK_ARG((cp <= 64) == (cout_pad0 <= 64), "rn_conv2d_nhwc_fwd: segments mix Cout tile widths");
+    RN_CHECK_ARG(!s.w_pair || ((big || halo512) && p->out_dtype == RN_DT_F32 && s.w_terms <= 1 && !s.scale && !s.shift &&
+                               !s.residual && !s.bn_partial),
+                 "rn_conv2d_nhwc_fwd: segment %d: w_pair needs an f32 launch without scale / shift / residual that the 256- / "
+                 "512-row kernels take (rn_conv_kernel_id() != 0)", i);
     RN_CHECK_ARG(((uintptr_t)s.x | (uintptr_t)s.w | (uintptr_t)s.y | (uintptr_t)s.residual) % 16 == 0,
                  "rn_conv2d_nhwc_fwd: segment %d tensors must be 16-byte aligned", i);
     const long long M = (long long)s.N * s.Ho * s.Wo;
@@ -617,7 +630,8 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
                  "rn_conv2d_nhwc_fwd: bn_bwd_y must be set on all segments or none");
     d.bias = s.bias;
     d.N = s.N; d.H = s.H; d.W = s.W; d.Cin = s.Cin; d.pix_stride = s.pix_stride;
-    d.Ho = s.Ho; d.Wo = s.Wo; d.Cout = s.Cout;
+    d.Ho = s.Ho; d.Wo = s.Wo; d.Cout = seg_cols(s);
+    d.pair_cout = s.w_pair ? s.Cout : 0; d.pad_ = 0;
     d.M = (int)M;
     d.tile_begin = tiles;
     d.n_tiles = (int)rn_cdiv(cp, BNT);
@@ -746,6 +760,36 @@ __global__ void pack_weight_split_kernel(const float* __restrict__ w, int ohwi, 
       v -= rn_bf16_to_f32(b);   // exact: the residual of a round-to-nearest is representable in fp32
     }
   }
+}
+
+// rn_conv_segment.w_pair: the two planes along Cout — packed row 64b + 32h + c = plane h of channel 32b + c
+__global__ void pack_weight_pair_kernel(const float* __restrict__ w, int ohwi, int RS, int Cin, int Cout, int Cin_pad,
+                                        int rows, uint16_t* __restrict__ out) {
+  const long long total = (long long)rows * RS * Cin_pad;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cin_pad);
+    const long long t = i / Cin_pad;   // = row * RS + tap
+    const int tap = (int)(t % RS), row = (int)(t / RS);
+    const int o = (row >> 6) * 32 + (row & 31), plane = (row >> 5) & 1;
+    float v = 0.0f;
+    if (o < Cout && c < Cin) v = ohwi ? w[((long long)o * RS + tap) * Cin + c] : w[((long long)tap * Cin + c) * Cout + o];
+    const uint16_t b = rn_f32_to_bf16(v);
+    out[i] = plane ? rn_f32_to_bf16(v - rn_bf16_to_f32(b)) : b;
+  }
+}
+
+extern "C" int rn_pack_conv_weight_pair(const float* w, int layout_ohwi, int R, int S, int Cin, int Cout, int Cin_pad,
+                                        void* w_packed, void* stream) {
+  RN_CHECK_ARG(w && w_packed && R > 0 && S > 0 && Cin > 0 && Cout > 0 && Cin_pad >= Cin,
+               "rn_pack_conv_weight_pair: bad argument");
+  const int rows = rn_conv_pair_rows(Cout);
+  const long long total = (long long)rows * R * S * Cin_pad;
+  int blocks = (int)(rn_cdiv(total, 256) < 4096 ? rn_cdiv(total, 256) : 4096);
+  hipLaunchKernelGGL(pack_weight_pair_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, layout_ohwi, R * S,
+                     Cin, Cout, Cin_pad, rows, (uint16_t*)w_packed);
+  RN_CHECK_LAUNCH();
+  return RN_OK;
 }
 
 extern "C" int rn_pack_conv_weight_split(const float* w, int layout_ohwi, int R, int S, int Cin, int Cout, int Cin_pad,

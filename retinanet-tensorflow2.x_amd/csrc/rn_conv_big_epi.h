@@ -85,6 +85,27 @@ template <bool OUT_F32, bool HAS_RES, int WM = 2>   // WM: waves along the pixel
 __device__ __forceinline__ void big_acc_init(f32x16_t (&acc)[4][2], const ConvArgs& args, int c_si, int c_n0, int wave,
                                              bool with_bias = true) {   // false: parts 1.. of a split tile start from zero
   const ConvSegDev& sg = args.seg[c_si];
+  if (OUT_F32 && with_bias && sg.pair_cout && sg.bias != nullptr) {
+    // w_pair: accumulator tile j = 0 (hi plane) of the wave's column block starts from the bias of channels
+    // [nw0 / 2, nw0 / 2 + 32), tile j = 1 (lo plane) from zero; Cout need only be a multiple of 4 here
+    typedef const float __attribute__((address_space(4))) cfloat;
+    const cfloat* b = (const cfloat*)(unsigned long long)sg.bias;
+    const int cw0 = (c_n0 + (wave % (8 / WM)) * 64) >> 1;
+    const int C = sg.pair_cout;
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const bool hi = lane >= 32;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int ca = cw0 + g * 8 + q, cb = ca + 4;
+        const float lo_v = b[ca < C ? ca : 0], hi_v = b[cb < C ? cb : 0];   // channels past C are never stored
+        const float v = hi ? hi_v : lo_v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { acc[i][0][g * 4 + q] = v; acc[i][1][g * 4 + q] = 0.0f; }
+      }
+    return;
+  }
   if (with_bias && big_bias_in_acc<OUT_F32, HAS_RES>(args, sg)) {
     typedef const float __attribute__((address_space(4))) cfloat;
     const cfloat* b = (const cfloat*)(unsigned long long)sg.bias;
@@ -393,10 +414,14 @@ _Pragma("unroll") for (int pass = 0; pass < (LOADS ? 4 : 0); ++pass) {          
 #undef BIG_RES_PREFETCH
   } else {
     // f32 output (prediction convs): f32 patch of 32 pixels x 32 channels per j (128 B rows)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int nr = nw0 + j * 32 + ru * 4;      // this lane's 4 channels on the read-back side
-      const bool nok = nr < Cout;
+    // w_pair: tile j = 1 holds the lo-plane products of tile j = 0's channels — one 32-channel block per wave,
+    // channels [nw0 / 2, nw0 / 2 + 32) of a pair_cout-channel output
+    const int pairC = sg.pair_cout;
+    const int CoutY = pairC ? pairC : Cout;
+    auto half = [&](auto j_c) __attribute__((always_inline)) {
+      constexpr int j = decltype(j_c)::value;
+      const int nr = (pairC ? (nw0 >> 1) : nw0 + j * 32) + ru * 4;      // this lane's 4 channels on the read-back side
+      const bool nok = nr < CoutY;
       float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sf = make_float4(0.f, 0.f, 0.f, 0.f);
       if (nok && sg.scale) sc = *(const float4*)(sg.scale + nr);
       if (nok && sg.shift) sf = *(const float4*)(sg.shift + nr);
@@ -404,6 +429,11 @@ _Pragma("unroll") for (int pass = 0; pass < (LOADS ? 4 : 0); ++pass) {          
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if (FROM_WS) big_epi_rebuild<1>(&acc[i][j], src, i, j);
+        if (j == 0 && pairC) {
+          if (FROM_WS) big_epi_rebuild<1>(&acc[i][1], src, i, 1);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][0][r] += acc[i][1][r];
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           float4 v;
@@ -416,7 +446,7 @@ _Pragma("unroll") for (int pass = 0; pass < (LOADS ? 4 : 0); ++pass) {          
           float4 v = *(const float4*)(patch + row * 128 + ((ru ^ (row & 7)) << 4));
           const int m = mw0 + i * 32 + row;
           if (m < M && nok) {
-            const long long o = (long long)m * Cout + nr;
+            const long long o = (long long)m * CoutY + nr;
             v.x = v.x * sc.x + sf.x; v.y = v.y * sc.y + sf.y; v.z = v.z * sc.z + sf.z; v.w = v.w * sc.w + sf.w;
             if (sg.residual) {
               const uint2 r2 = *(const uint2*)(sg.residual + o);
@@ -431,7 +461,9 @@ _Pragma("unroll") for (int pass = 0; pass < (LOADS ? 4 : 0); ++pass) {          
           }
         }
       }
-    }
+    };
+    half(std::integral_constant<int, 0>{});
+    if (!pairC) half(std::integral_constant<int, 1>{});
   }
 }
 #endif  // RN_CONV_BIG_EPI_H_

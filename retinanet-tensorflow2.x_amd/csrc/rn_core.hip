@@ -14,7 +14,7 @@ void rn_set_error(const char* fmt, ...) {
 
 extern "C" const char* rn_last_error(void) { return g_rn_err; }
 
-extern "C" int rn_abi_version(void) { return 5; }
+extern "C" int rn_abi_version(void) { return 6; }
 
 // 0: bfloat16 storage (librnet_hip.so), 1: IEEE half (librnet_hip_f16.so, built with -DRN_F16)
 extern "C" int rn_storage_dtype(void) {
@@ -47,7 +47,7 @@ struct rn_handle {
 };
 
 static int rn_check_opts(const rn_launch_opts& o, const char* who) {
-  RN_CHECK_ARG(o.conv_tile >= 0 && o.conv_tile <= 2, "%s: conv_tile=%d (0..2)", who, o.conv_tile);
+  RN_CHECK_ARG(o.conv_tile >= 0 && o.conv_tile <= 3, "%s: conv_tile=%d (0..3)", who, o.conv_tile);
   RN_CHECK_ARG(o.wgrad_kernel >= 0 && o.wgrad_kernel <= 3, "%s: wgrad_kernel=%d (0..3)", who, o.wgrad_kernel);
   RN_CHECK_ARG(o.reserved_cus >= 0 && o.reserved_cus <= 128, "%s: reserved_cus=%d out of range (0..128)", who,
                o.reserved_cus);

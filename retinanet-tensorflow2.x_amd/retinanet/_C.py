@@ -19,7 +19,7 @@ RN_DT_F32, RN_DT_BF16 = 0, 1
 RN_OK, RN_EINVAL, RN_ENOMEM, RN_EHIP, RN_ECOMM, RN_EUNSUPPORTED = 0, -1, -2, -3, -4, -5   # rn_status
 RN_ACT_NONE, RN_ACT_RELU, RN_ACT_RELU6, RN_ACT_SWISH = 0, 1, 2, 3
 RN_CONV_MAX_SEGMENTS = 10
-ABI_VERSION = 5
+ABI_VERSION = 6
 # f32 kernels of the dtype=float32 prediction convs (detection_head.py:80-88) as split-bf16 planes (rn_conv_segment.w_terms)
 PRED_W_TERMS = int(os.environ.get("RNET_PRED_W_TERMS", "2"))
 ACT_IDS = {None: RN_ACT_NONE, "none": RN_ACT_NONE, "relu": RN_ACT_RELU, "relu6": RN_ACT_RELU6,
@@ -64,7 +64,7 @@ class ConvSegment(Structure):
     _fields_ = [("x", c_void_p), ("w", c_void_p), ("y", c_void_p), ("scale", c_void_p), ("shift", c_void_p),
                 ("residual", c_void_p), ("N", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32),
                 ("pix_stride", c_int32), ("Ho", c_int32), ("Wo", c_int32), ("Cout", c_int32), ("bn_partial", c_void_p),
-                ("bias", c_void_p), ("w_terms", c_int32), ("pad_", c_int32), ("bn_bwd_y", c_void_p),
+                ("bias", c_void_p), ("w_terms", c_int32), ("w_pair", c_int32), ("bn_bwd_y", c_void_p),
                 ("bn_bwd_fwd", c_void_p)]
 
 
@@ -169,6 +169,8 @@ _SIGNATURES = {
     "rn_squeeze_excite_inplace": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_int, c_void_p, c_size_t, c_void_p]),
     "rn_pack_conv_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rn_conv_pair_rows": (c_int, [c_int]),
+    "rn_pack_conv_weight_pair": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rn_pack_conv_weight_split": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                           c_void_p]),
     "rn_pack_stem_weight": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
@@ -385,6 +387,26 @@ def new_splitk_workspace(lib_, device):
     if os.environ.get("RNET_SPLITK", "0") != "1":
         return None
     return torch.zeros((int(lib_.rn_conv_splitk_workspace_max_bytes()),), dtype=torch.uint8, device=device)
+
+
+def pair_form_kernel(lib_, batch, k, stride, pad, cin, cout, shapes, opts):
+    """Kernel id (rn_conv_kernel_id) an f32 conv launch would get with its two split-bf16 weight planes stacked along Cout
+    (rn_conv_segment.w_pair) — 0: the 256- / 512-row kernels do not take it, keep the planes along Cin (w_terms).
+    shapes: one (H, W, pix_stride, Ho, Wo) per segment of the grouped launch.  Shapes only, no tensor is touched."""
+    if PRED_W_TERMS != 2 or os.environ.get("RNET_PRED_PAIR", "1") == "0" or len(shapes) > RN_CONV_MAX_SEGMENTS:
+        return 0
+    p = ConvProblem()
+    p.opts = opts
+    p.R = p.S = k
+    p.stride_h = p.stride_w = stride
+    p.pad_top = p.pad_left = pad
+    p.act, p.out_dtype, p.num_segments = RN_ACT_NONE, RN_DT_F32, len(shapes)
+    for i, (H, W, ps, Ho, Wo) in enumerate(shapes):
+        s = p.seg[i]
+        s.N, s.H, s.W, s.Cin, s.pix_stride, s.Ho, s.Wo, s.Cout = batch, H, W, cin, ps, Ho, Wo, cout
+        s.w_pair = 1
+    kid = lib_.rn_conv_kernel_id(ctypes.byref(p))
+    return kid if kid > 0 else 0
 
 
 def attach_splitk_workspace(problem, ws):

@@ -64,6 +64,7 @@ class InferenceEngine:
         self.steps = []     # list of (callable, name)
         self.t = {}         # tensor name -> torch tensor
         self.packed = {}    # conv name -> packed bf16 weight
+        self._pair = {}     # f32 conv name -> its weight planes are stacked along Cout (rn_conv_segment.w_pair)
         self._graph = None
         self._capture = bool(capture_graph)
         with torch.cuda.device(self.dev):
@@ -144,6 +145,15 @@ class InferenceEngine:
                     buf = self.packed.get(cname)
                     cin_pad = lib.rn_conv_cin_pad(c["cin"])
                     terms = self._w_terms(op)
+                    if self._w_pair(op):   # narrow f32 layer (box prediction): the two planes along Cout
+                        if buf is None:
+                            buf = torch.empty((lib.rn_conv_pair_rows(c["cout"]), c["k"], c["k"], cin_pad), dtype=self.h16,
+                                              device=self.dev)
+                        _C.check(lib.rn_pack_conv_weight_pair(_C.ptr(w), 0, c["k"], c["k"], c["cin"], c["cout"], cin_pad,
+                                                              _C.ptr(buf), st), "rn_pack_conv_weight_pair")
+                        self.packed[cname] = buf
+                        self._fold(op["out"], variables, op.get("bn"), variables.get(cname + "/bias"))
+                        continue
                     if buf is None:
                         buf = torch.empty((cout_pad, c["k"], c["k"], terms * cin_pad), dtype=self.h16,
                                           device=self.dev)
@@ -158,7 +168,28 @@ class InferenceEngine:
 
     def _w_terms(self, op):
         """split-bf16 weight planes of the dtype=float32 prediction convs (rn_conv_segment.w_terms); 1 elsewhere"""
+        if self._w_pair(op):
+            return 1
         return _C.PRED_W_TERMS if op.get("out_dtype") == "f32" and op["op"] == "conv" else 1
+
+    def _w_pair(self, op):
+        """True for a narrow f32 conv whose two weight planes go along Cout (rn_conv_segment.w_pair; the reasoning is in
+        train_engine.TrainEngine._pair_form): decided once per conv from the shapes of the grouped launch it runs in."""
+        if op.get("out_dtype") != "f32" or op["op"] != "conv":
+            return False
+        cname = op["conv"]
+        if cname not in self._pair:
+            c = self.g.convs[cname]
+            ops = [o for o in self.g.ops if o["op"] == "conv" and o["conv"] == cname]
+            groups = {o.get("group") for o in ops}
+            ok = self.lib.rn_conv_cout_pad(c["cout"]) <= 64 and len(groups) == 1 and None not in groups
+            if ok:
+                tn = self.g.tensors
+                shapes = [tn[o["inp"]][:2] + (tn[o["inp"]][2],) + tn[o["out"]][:2] for o in ops]
+                ok = _C.pair_form_kernel(self.lib, self.B, c["k"], c["stride"], ops[0]["pad"], c["cin"], c["cout"], shapes,
+                                         self.launch_opts) > 0
+            self._pair[cname] = ok
+        return self._pair[cname]
 
     def _fold(self, key, variables, bn, bias):
         """(scale, shift, bias) of the conv epilogue: the Conv2D layer's bias stays separate (it is added before the
@@ -194,6 +225,7 @@ class InferenceEngine:
         seg.shift = shift.data_ptr() if shift is not None else None
         seg.bias = bias.data_ptr() if bias is not None else None
         seg.w_terms = self._w_terms(op)
+        seg.w_pair = 1 if self._w_pair(op) else 0
         seg.residual = self.t[op["residual"]].data_ptr() if op.get("residual") else None
         seg.N, seg.H, seg.W, seg.Cin = self.B, x.shape[1], x.shape[2], c["cin"]
         seg.pix_stride = x.shape[3]

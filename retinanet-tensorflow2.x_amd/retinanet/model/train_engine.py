@@ -241,6 +241,7 @@ class TrainEngine:
         self.fwd_pack_of = {}
         self.split_packs = []                # live f32 convs (prediction layers): split-bf16 planes, repacked per step
         self.split_pack_of = {}
+        self.pair_packs = set()              # ... those of them whose two planes are stacked along Cout (w_pair)
         f32_convs = {o["conv"] for o in self.ops if o["op"] == "conv" and o.get("out_dtype") == "f32"}
         for i, k in enumerate(names):
             n = v[k].numel()
@@ -252,8 +253,13 @@ class TrainEngine:
                     pass                                        # first-layer conv: its own packed form
                 elif layer in f32_convs and _C.PRED_W_TERMS > 1:
                     cinp = lib.rn_conv_cin_pad(c["cin"])        # detection_head.py:80-88: the layer keeps its f32 kernel
-                    buf = torch.zeros((lib.rn_conv_cout_pad(c["cout"]), c["k"], c["k"], _C.PRED_W_TERMS * cinp),
-                                      dtype=self.h16, device=self.dev)
+                    if self._pair_form(layer):                  # narrow layer (box prediction): the planes along Cout
+                        buf = torch.zeros((lib.rn_conv_pair_rows(c["cout"]), c["k"], c["k"], cinp), dtype=self.h16,
+                                          device=self.dev)
+                        self.pair_packs.add(layer)
+                    else:
+                        buf = torch.zeros((lib.rn_conv_cout_pad(c["cout"]), c["k"], c["k"], _C.PRED_W_TERMS * cinp),
+                                          dtype=self.h16, device=self.dev)
                     self.split_packs.append((k, c, cinp, buf))
                     self.split_pack_of[layer] = buf
                 elif lib.rn_conv_cin_pad(c["cin"]) == c["cin"]:
@@ -347,6 +353,10 @@ class TrainEngine:
                                                        cinp, buf.data_ptr(), st), "rn_pack_conv_weight_ohwi")
         for (kname, c, cinp, buf) in self.split_packs:
             off, _ = self.p_off[kname]
+            if self.var_kind[kname][1] in self.pair_packs:
+                _C.check(self.lib.rn_pack_conv_weight_pair(self.P.data_ptr() + 4 * off, 1, c["k"], c["k"], c["cin"],
+                                                           c["cout"], cinp, buf.data_ptr(), st), "rn_pack_conv_weight_pair")
+                continue
             _C.check(self.lib.rn_pack_conv_weight_split(self.P.data_ptr() + 4 * off, 1, c["k"], c["k"], c["cin"],
                                                         c["cout"], cinp, _C.PRED_W_TERMS, buf.data_ptr(), st),
                      "rn_pack_conv_weight_split")
@@ -561,8 +571,9 @@ class TrainEngine:
         bnb = bool(p.seg[0].bn_bwd_y)   # the BN_BWD variants (stage 1 of a BatchNorm backward reduction in the epilogue)
         tmpl = (f"<{'true' if p.out_dtype == _C.RN_DT_F32 else 'false'}, {'true' if has_res else 'false'}, "
                 f"{'true' if bnb else 'false'}>")
+        # (device symbols: conv_halo_kernel<f32 out, residual, BN_BWD, SPLIT, waves along the pixels>)
         if kid == 2:
-            variant = "conv_halo_kernel" + tmpl + " (256x256x32, 3x3 halo patch)"
+            variant = "conv_halo_kernel" + tmpl[:-1] + ", false, 2> (256x256x32, 3x3 halo patch)"
         elif kid == 3:     # the same kernel template with 4 x 2 waves: 512 x 128 tiles (64 < Cout <= 128)
             variant = "conv_halo_kernel" + tmpl[:-1] + ", false, 4> (512x128x32, 3x3 halo patch)"
         elif kid == 1:
@@ -595,6 +606,29 @@ class TrainEngine:
             return self.split_pack_of[cname].data_ptr()
         return self.Pbf.data_ptr() + 2 * self.bf_off[cname]
 
+    def _pair_form(self, layer):
+        """True when the f32 conv `layer` (one kernel shared by the pyramid levels of a grouped launch) is narrow enough that
+        its two weight planes go along Cout (rn_conv_segment.w_pair): 36 box-regression channels fill 72 of the 128 columns
+        of the halo kernel's 512 x 128 tiles; along Cin they were a 64-column tile of the 128-row kernel at 2 x the K depth."""
+        c = self.g.convs[layer]
+        if self.lib.rn_conv_cout_pad(c["cout"]) > 64:
+            return False                                        # wide layers (class prediction) already run 256-row tiles
+        ops = [o for o in self.ops if o["op"] == "conv" and o["conv"] == layer]
+        groups = {o.get("group") for o in ops}
+        if len(groups) != 1 or None in groups:
+            return False
+        shapes = [self.tensors[o["inp"]][:2] + (self.tensors[o["inp"]][2],) + self.tensors[o["out"]][:2] for o in ops]
+        return _C.pair_form_kernel(self.lib, self.B, c["k"], c["stride"], ops[0]["pad"], c["cin"], c["cout"], shapes,
+                                   self.launch_opts) > 0
+
+    def _group_ops(self, kind, grp):
+        """The ops of one grouped launch, in graph order.  (Round 4 measured "longest K first" for the one group that mixes K
+        depths, the FPN lateral 1x1 convs with 512 / 1024 / 2048 input channels: 229 -> 295 us.  The persistent kernels give
+        every XCD a CONTIGUOUS range of tiles, so whichever segment order is chosen one XCD holds all 50 of the 64-step tiles;
+        first in the list they also all start at once.  Balancing that launch needs a tile numbering that deals the segments
+        round-robin over the XCDs, not another order.)"""
+        return [o for o in self.ops if o["op"] == kind and o.get("group") == grp]
+
     def _conv_problem(self, ops, dst_of, raw_mode):
         """forward conv launch over `ops`; raw_mode: write pre-BN output (+bias) without activation."""
         first = ops[0]
@@ -622,7 +656,8 @@ class TrainEngine:
                 s.bias = bs.data_ptr() if bs is not None else None
             if not raw_mode:
                 s.residual = self.t[op["residual"]].data_ptr() if op.get("residual") else None
-            s.w_terms = _C.PRED_W_TERMS if op["conv"] in self.split_pack_of else 1
+            s.w_terms = _C.PRED_W_TERMS if op["conv"] in self.split_pack_of and op["conv"] not in self.pair_packs else 1
+            s.w_pair = 1 if op["conv"] in self.pair_packs else 0
             s.N, s.H, s.W, s.Cin, s.pix_stride = self.B, x.shape[1], x.shape[2], c["cin"], x.shape[3]
             s.Ho, s.Wo, s.Cout = y.shape[1], y.shape[2], c["cout"]
         self._keep.append(p)
@@ -836,7 +871,7 @@ class TrainEngine:
                     if grp in done:
                         continue
                     done.add(grp)
-                    ops = [o for o in self.ops if o["op"] == "conv" and o.get("group") == grp]
+                    ops = self._group_ops("conv", grp)
                 else:
                     ops = [op]
                 live_bn = bool(self._bn_trainable(ops[0]))
@@ -959,7 +994,7 @@ class TrainEngine:
                 if grp is None:
                     plan.append((op["op"], [op]))
                 elif first_of_group[(op["op"], grp)] == i:
-                    plan.append((op["op"], [o for o in ops if o["op"] == op["op"] and o.get("group") == grp]))
+                    plan.append((op["op"], self._group_ops(op["op"], grp)))
             elif op["op"] in ("maxpool", "topdown", "balance", "stem", "se"):
                 plan.append((op["op"], op))
         # which tensor gradients get more than one contribution is decided at build time

@@ -47,7 +47,7 @@ def splitk_env(request, monkeypatch):
 
 def _conv_sig(eng, name, p):
     segs = tuple((s.N, s.H, s.W, s.Cin, s.pix_stride, s.Ho, s.Wo, s.Cout, bool(s.scale), bool(s.shift), bool(s.bias),
-                  bool(s.residual), bool(s.residual) and s.residual == s.y, s.w_terms, bool(s.bn_partial),
+                  bool(s.residual), bool(s.residual) and s.residual == s.y, s.w_terms, s.w_pair, bool(s.bn_partial),
                   bool(s.bn_bwd_y)) for s in (p.seg[i] for i in range(p.num_segments)))
     return (p.R, p.S, p.stride_h, p.pad_top, p.act, p.out_dtype, eng.lib.rn_conv_kernel_id(ctypes.byref(p)), segs)
 
@@ -105,7 +105,12 @@ def _check_conv_launch(cuda, eng, name, p):
         w = torch.randn((p.R, p.S, s.Cin, s.Cout), generator=g, device=cuda) * ((0.01 if f32 else 1.0) / math.sqrt(K))
         cinp = lib.rn_conv_cin_pad(s.Cin)
         wp = torch.empty((lib.rn_conv_cout_pad(s.Cout), p.R, p.S, terms * cinp), dtype=h16, device=cuda)
-        if terms > 1:
+        if s.w_pair:     # the two planes of an f32 kernel stacked along Cout (narrow prediction conv)
+            assert terms == 1 and f32, name
+            wp = torch.empty((lib.rn_conv_pair_rows(s.Cout), p.R, p.S, cinp), dtype=h16, device=cuda)
+            _C.check(lib.rn_pack_conv_weight_pair(_C.ptr(w), 0, p.R, p.S, s.Cin, s.Cout, cinp, _C.ptr(wp), _C.current_stream()))
+            terms = 2    # the reference below: both planes
+        elif terms > 1:
             _C.check(lib.rn_pack_conv_weight_split(_C.ptr(w), 0, p.R, p.S, s.Cin, s.Cout, cinp, terms, _C.ptr(wp),
                                                    _C.current_stream()))
         else:
@@ -141,7 +146,7 @@ def _check_conv_launch(cuda, eng, name, p):
         d.bn_partial = t["partial"].data_ptr() if "partial" in t else None
         d.bn_bwd_y = t["bn_y"].data_ptr() if "bn_y" in t else None
         d.bn_bwd_fwd = t["bn_fwd"].data_ptr() if "bn_fwd" in t else None
-        d.w_terms = s.w_terms
+        d.w_terms, d.w_pair = s.w_terms, s.w_pair
         d.N, d.H, d.W, d.Cin, d.pix_stride, d.Ho, d.Wo, d.Cout = s.N, s.H, s.W, s.Cin, s.pix_stride, s.Ho, s.Wo, s.Cout
         keep.append(wp)
         per_seg.append(t)

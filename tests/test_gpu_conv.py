@@ -74,7 +74,11 @@ def _conv_gpu(cuda, segs, k, stride, pad, act, out_f32, opts=None, splitk_ws=Non
         cinp = lib.rn_conv_cin_pad(cin)
         terms = int(s.get("w_terms", 1))
         wp = torch.empty((lib.rn_conv_cout_pad(cout), kk, kk, terms * cinp), dtype=H16, device=cuda)
-        if terms > 1:
+        if s.get("w_pair"):     # the two planes along Cout (rn_conv_segment.w_pair)
+            assert terms == 1
+            wp = torch.full((lib.rn_conv_pair_rows(cout), kk, kk, cinp), float("nan"), dtype=H16, device=cuda)
+            _C.check(lib.rn_pack_conv_weight_pair(_C.ptr(w), 0, kk, kk, cin, cout, cinp, _C.ptr(wp), _C.current_stream()))
+        elif terms > 1:
             _C.check(lib.rn_pack_conv_weight_split(_C.ptr(w), 0, kk, kk, cin, cout, cinp, terms, _C.ptr(wp),
                                                    _C.current_stream()))
         else:
@@ -94,6 +98,7 @@ def _conv_gpu(cuda, segs, k, stride, pad, act, out_f32, opts=None, splitk_ws=Non
         g.residual = res.data_ptr() if res is not None else None
         g.bias = bs.data_ptr() if bs is not None else None
         g.w_terms = terms
+        g.w_pair = 1 if s.get("w_pair") else 0
         g.N, g.H, g.W, g.Cin, g.pix_stride, g.Ho, g.Wo, g.Cout = N, H, W, cin, cin, Ho, Wo, cout
         keep += [x, wp, sc, sh, res, bs]
         outs.append(y)
@@ -473,6 +478,58 @@ def test_conv_f32_weights_as_split_bf16_planes(cuda, build, case):
     assert (got - exact).abs().max().item() <= 3e-5 * spread
     # what the split buys: plain bf16 weights are two orders of magnitude further from the f32 layer
     assert (one - exact).abs().max().item() > 10 * (got - exact).abs().max().item()
+
+
+PAIR_CASES = [
+    # per segment (N, H, W); Cin, Cout, k, conv_tile, no_halo -> kernel id
+    ([(2, 24, 24), (2, 12, 12), (3, 5, 5)], 256, 36, 3, 2, 0, 3),    # the box prediction conv: 512 x 128 halo tiles, 3 levels
+    ([(1, 33, 17)], 64, 4, 3, 2, 0, 3),                              # one 4-channel group; ragged rows
+    ([(2, 20, 20)], 96, 64, 3, 2, 0, 3),                             # both 32-channel blocks full
+    ([(1, 16, 16)], 128, 100, 3, 2, 0, 2),                           # 256 GEMM columns: the 256 x 256 halo tiles
+    ([(1, 16, 16)], 128, 132, 1, 2, 0, 1),                           # 1x1: conv_big_kernel, 384 columns (the last block half used)
+]
+
+
+@pytest.mark.parametrize("build,case", _builds(PAIR_CASES, PAIR_CASES[:2], "pair-"))
+def test_conv_f32_weight_planes_along_cout(cuda, build, case):
+    """rn_conv_segment.w_pair: the two split-bf16 planes of an f32 kernel as GEMM columns (hi | lo per 32-channel block),
+    added in the epilogue.  Same bar as the planes-along-Cin form (test_conv_f32_weights_as_split_bf16_planes): against the
+    float64 product with the same planes only fp32 summation order is left; against the untouched f32 kernel 2^-16 per
+    weight.  Channel counts that are multiples of 4 only (36 box-regression channels), several pyramid levels per launch,
+    and a launch the 128-row kernel would get is refused."""
+    from retinanet import _C
+    lib = _lib()
+    shapes, Cin, Cout, k, tile, no_halo, kid = case
+    g = torch.Generator().manual_seed(_seed(case))
+    segs = [{"x": torch.randn((N, H, W, Cin), generator=g).relu(),
+             "w": torch.randn((k, k, Cin, Cout), generator=g) * 0.01,
+             "bias": torch.randn((Cout,), generator=g) * 0.1, "w_pair": 1} for (N, H, W) in shapes]
+    for s in segs[1:]:
+        s["w"], s["bias"] = segs[0]["w"], segs[0]["bias"]             # one kernel shared by the levels
+    pad = (k - 1) // 2
+    opts = dict(conv_tile=tile, conv_no_halo=no_halo)
+    p = _C.ConvProblem()
+    p.R = p.S = k
+    p.stride_h = p.stride_w = 1
+    p.pad_top = p.pad_left = pad
+    p.out_dtype, p.num_segments = _C.RN_DT_F32, len(shapes)
+    for i, (N, H, W) in enumerate(shapes):
+        sg = p.seg[i]
+        sg.N, sg.H, sg.W, sg.Cin, sg.pix_stride, sg.Ho, sg.Wo, sg.Cout, sg.w_pair = N, H, W, Cin, Cin, H, W, Cout, 1
+    p.opts = _C.LaunchOpts(**opts)
+    assert lib.rn_conv_kernel_id(ctypes.byref(p)) == kid
+    assert lib.rn_conv_pair_rows(Cout) == 128 * ((Cout + 63) // 64)
+    gots = _conv_gpu(cuda, segs, k, 1, pad, None, True, opts)
+    for s, got in zip(segs, gots):
+        same_planes = _conv_ref(dict(s, w_terms=2), k, 1, pad, None, True)
+        exact = _conv_ref(dict(s, w_terms=3), k, 1, pad, None, True)
+        spread = (exact - s["bias"].double()).abs().max().item() + 1e-9
+        assert torch.isfinite(got).all()
+        assert (got - same_planes).abs().max().item() <= 2e-5 * spread
+        assert (got - exact).abs().max().item() <= 3e-5 * spread
+    # the 128-row kernel has no such epilogue: refused, not silently wrong
+    with pytest.raises(_C.RnetError):
+        _conv_gpu(cuda, segs[:1], k, 1, pad, None, True, dict(conv_tile=1))
 
 
 def test_conv_halo_asymmetric_weights(cuda):

@@ -248,7 +248,7 @@ def test_two_engines_in_one_process_do_not_share_launch_options(cuda):
     oa, ob = a.launch_opts(), b.launch_opts()
     assert (oa.conv_tile, oa.reserved_cus, ob.conv_tile, ob.reserved_cus) == (2, 8, 1, 0)
     with pytest.raises(_C.RnetError):
-        a.set_launch_opts(_C.LaunchOpts(conv_tile=3))
+        a.set_launch_opts(_C.LaunchOpts(conv_tile=4))
     assert a.launch_opts().conv_tile == 2           # a refused update leaves the handle as it was
     p = _C.ConvProblem()
     p.R = p.S = 3

@@ -148,7 +148,7 @@ def test_input_pipeline_ranks_see_disjoint_records_on_one_host(tmp_path, params)
 def test_ctypes_structs_match_the_c_header(tmp_path):
     """sizeof / offsetof of every struct the binding mirrors, taken from the C compiler's view of include/rnet_hip.h"""
     from retinanet import _C
-    structs = {"rn_conv_segment": (_C.ConvSegment, ["x", "bias", "w_terms", "Cout", "bn_partial"]),
+    structs = {"rn_conv_segment": (_C.ConvSegment, ["x", "bias", "w_terms", "w_pair", "Cout", "bn_partial"]),
                "rn_launch_opts": (_C.LaunchOpts, ["conv_tile", "reserved_cus", "wgrad_kernel", "ablate"]),
                "rn_conv_problem": (_C.ConvProblem, ["seg", "num_segments", "out_dtype", "opts"]),
                "rn_wgrad_segment": (_C.WgradSegment, ["dy_pix_stride", "x_pix_stride"]),

@@ -60,7 +60,7 @@ def main():
     ap.add_argument("--raw", action="store_true", help="no scale / shift / activation (the training forward's raw conv output)")
     ap.add_argument("--bias", action="store_true", help="shift only (bias + relu: the head towers)")
     ap.add_argument("--no-halo", action="store_true", help="3x3 launches on conv_big_kernel instead of conv_halo_kernel")
-    ap.add_argument("--tile", type=int, default=0, help="1 = force 128-row kernel, 2 = force the 256x256 kernel")
+    ap.add_argument("--tile", type=int, default=0, help="1 = force 128-row kernel, 2 = force the 256x256 kernel, 3 = force 512x128 halo tiles")
     a = ap.parse_args()
     lib = _C.lib()
     opts = _C.LaunchOpts(ablate=a.ablate or 0, conv_tile=a.tile or 0, conv_no_halo=1 if a.no_halo else 0,
