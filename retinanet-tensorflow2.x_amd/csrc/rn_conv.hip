@@ -487,7 +487,6 @@ static bool conv_halo_shape(const rn_conv_problem* p, int BM) {   // BM: pixels 
   }
   return true;
 }
-static bool conv_use_halo(const rn_conv_problem* p) { return conv_halo_shape(p, 256) && conv_use_big(p); }
 
 // 3x3 / stride 1 / pad 1 layers with 64 < Cout <= 128 (ResNet stage 2: 128 -> 128 at 80 x 80, forward and data gradient):
 // the halo kernel with 512 x 128 tiles (rn_conv_halo.hip, HaloGeo<4>: 4 x 2 waves of 128 pixels x 64 channels).  On the
@@ -506,6 +505,27 @@ static bool conv_use_halo512(const rn_conv_problem* p) {
   if (!conv_halo_shape(p, 512)) return false;
   // enough tiles to fill the chip once (opts.conv_tile = 2 forces the form: tests at small sizes)
   return p->opts.conv_tile >= 2 || tiles >= (p->opts.conv_big_min_tiles > 0 ? p->opts.conv_big_min_tiles : 128);
+}
+
+// Which kernel a problem runs on (rn_conv_kernel_id): 0 = 128-row conv_fwd_kernel, 1 = conv_big_kernel, 2 = conv_halo_kernel
+// with 256 x 256 tiles, 3 = conv_halo_kernel with 512 x 128 tiles.
+// A 3x3 / stride 1 launch that qualifies for the 256 x 256 halo tiles runs as 512 x 128 tiles instead when its channel
+// count is a multiple of 128 and the longer patches fit: the same number of tiles and MACs per tile, but a K chunk stages
+// ~117 KB instead of ~171 KB per workgroup (one 8 KB weight piece per tap instead of 16 KB; the patch of 512 consecutive
+// pixels has relatively fewer halo rows).  Measured inside the step on one box (round 4): head-tower launches 564 -> 511 us,
+// class prediction 1460 -> 1333, ResNet stage-3 3x3 (200 tiles) 59.8 -> 56.8, batch-8 towers 157 -> 152.  The last-round
+// split (splitk_ws) exists for the 256 x 256 form only and keeps it; conv_tile = 2 keeps it too (tests, A/B).
+static int conv_pick(const rn_conv_problem* p) {
+  if (conv_use_big(p)) {
+    if (!conv_halo_shape(p, 256)) return 1;
+    if (p->opts.conv_tile == 0 && !p->splitk_ws && p->opts.conv_big_min_tiles == 0) {
+      rn_conv_problem q = *p;
+      q.opts.conv_tile = 3;
+      if (conv_use_halo512(&q)) return 3;
+    }
+    return 2;
+  }
+  return conv_use_halo512(p) ? 3 : 0;
 }
 
 int rn_splitk_plan(ConvArgs& a, int min_chunks, void* ws, long long ws_bytes, const rn_launch_opts& opts) {
@@ -531,7 +551,7 @@ static int conv_min_chunks(const rn_conv_problem* p) {
   return mc;
 }
 // ... or 0 when this launch cannot split (conv_big_kernel: whole tiles only — its 1x1 layers are HBM-bound)
-static int conv_splitk_min_chunks(const rn_conv_problem* p) { return conv_use_halo(p) ? conv_min_chunks(p) : 0; }
+static int conv_splitk_min_chunks(const rn_conv_problem* p) { return conv_pick(p) == 2 ? conv_min_chunks(p) : 0; }
 
 // what any problem can use on any grid: 4 KB header + 256 accumulator slots (one per part: L * S <= 256 workgroups)
 extern "C" size_t rn_conv_splitk_workspace_max_bytes(void) { return RN_SPLITK_HEADER_BYTES + 256ull * RN_SPLITK_SLOT_BYTES; }
@@ -553,12 +573,13 @@ extern "C" size_t rn_conv_splitk_workspace_bytes(const rn_conv_problem* p) {
 /* 0: 128-row kernel, 1: conv_big_kernel, 2: conv_halo_kernel */
 extern "C" int rn_conv_kernel_id(const rn_conv_problem* p) {
   if (!p || p->num_segments < 1 || p->num_segments > RN_CONV_MAX_SEGMENTS) return -1;
-  return conv_use_halo(p) ? 2 : (conv_use_big(p) ? 1 : (conv_use_halo512(p) ? 3 : 0));
+  return conv_pick(p);
 }
 
 extern "C" int rn_conv_tile_rows(const rn_conv_problem* p) {
   if (!p || p->num_segments < 1 || p->num_segments > RN_CONV_MAX_SEGMENTS) return 0;
-  return conv_use_big(p) ? 256 : (conv_use_halo512(p) ? 512 : 128);
+  const int kid = conv_pick(p);
+  return kid == 3 ? 512 : (kid ? 256 : 128);
 }
 
 extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
@@ -578,8 +599,9 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
   // tail of the last K step reads past the pixel's channels (or out of range -> zeros) and meets the
   // zero-padded weight columns, so it contributes nothing.
   const int BK = rn_conv_cin_pad(p->seg[0].Cin) % 64 == 0 ? 64 : 32;
-  const bool big = conv_use_big(p);
-  const bool halo512 = !big && conv_use_halo512(p);   // 3x3, 64 < Cout <= 128: 512 x 128 tiles of the halo kernel
+  const int kid = conv_pick(p);
+  const bool big = kid == 1 || kid == 2;
+  const bool halo512 = kid == 3;   // 512 x 128 tiles of the halo kernel
   const int BM = big ? 256 : (halo512 ? 512 : 128);
   if (!big && !halo512 && BN == 128) {
     // Small launches (batch-8 inference, ResNet stage 4: 100 tiles of 128 x 128 on 256 CUs): 128 x 64 tiles put the work
@@ -667,7 +689,7 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
     }
   }
   if (halo512) return rn_launch_conv_halo(a, f32, p->opts, st, 4);
-  if (big && conv_use_halo(p)) {
+  if (kid == 2) {
     rn_splitk_plan(a, conv_splitk_min_chunks(p), p->splitk_ws, p->splitk_ws_bytes, p->opts);
     return rn_launch_conv_halo(a, f32, p->opts, st);
   }

@@ -24,6 +24,21 @@ def _conv_out_hw(H, W, k, s, pad):
     return (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
 
 
+def split_by_depth(g, ops):
+    """A grouped forward launch whose segments differ in K depth by 2x or more (the FPN lateral 1x1 convs: 512 / 1024 /
+    2048 input channels) as two launches, the deep segments first.  The persistent kernels hand every XCD a contiguous range
+    of tiles, so in one launch a single XCD ends up with all 50 of the 64-step tiles and most of the 32-step ones (181 K
+    steps per CU there against 87 on average: 229 us for 103 us of work at B = 32).  On their own the deep segments are
+    one round of tiles; the rest is a homogeneous launch.  Forward launches without BatchNorm only (a group with live
+    BatchNorm shares one statistics message); RNET_GROUP_SPLIT=0 keeps one launch (A/B)."""
+    if len(ops) < 2 or os.environ.get("RNET_GROUP_SPLIT", "1") == "0":
+        return [ops]
+    depth = [g.convs[o["conv"]]["k"] ** 2 * g.convs[o["conv"]]["cin"] for o in ops]
+    deep = [o for o, d in zip(ops, depth) if d >= 2 * min(depth)]
+    rest = [o for o, d in zip(ops, depth) if d < 2 * min(depth)]
+    return [deep, rest] if deep and rest else [ops]
+
+
 def stem_pool_partner(g, stem_op, stem_k):
     """The MaxPool op that rn_stem_conv_bn_relu_pool can absorb: the ResNet stem (7x7/2, 64 channels, relu | relu6)
     whose only consumer is a 3x3 / stride-2 pool with SAME pads (resnet.py:288-307); None otherwise (EfficientNet's
@@ -253,6 +268,8 @@ class InferenceEngine:
         pref = ctypes.byref(p)
         name = first.get("group") or first["out"]
         self.conv_problems = getattr(self, "conv_problems", {})
+        if "conv:" + name in self.conv_problems:      # second launch of a split group (split_by_depth)
+            name += ":rest"
         self.conv_problems["conv:" + name] = p   # for profilers: lib.rn_conv_tile_rows(byref(p))
 
         def run(st):
@@ -340,7 +357,8 @@ class InferenceEngine:
                     self._add_conv_launch([op])
                 elif grp not in done_groups:
                     done_groups.add(grp)
-                    self._add_conv_launch([o for o in self.g.ops if o["op"] == "conv" and o.get("group") == grp])
+                    for sub in split_by_depth(self.g, [o for o in self.g.ops if o["op"] == "conv" and o.get("group") == grp]):
+                        self._add_conv_launch(sub)
             elif kind == "dwconv":
                 grp = op.get("group")
                 if grp is None:

@@ -32,6 +32,7 @@ import numpy as np
 import torch
 
 from retinanet import _C
+from .engine import split_by_depth
 
 _DT = {"bf16": torch.bfloat16, "f32": torch.float32}
 _SEG_DTYPE = np.dtype([("offset", "<i8"), ("size", "<i8"), ("wd", "<i4"), ("bb", "<i4"), ("nb", "<i4"),
@@ -661,7 +662,10 @@ class TrainEngine:
             s.N, s.H, s.W, s.Cin, s.pix_stride = self.B, x.shape[1], x.shape[2], c["cin"], x.shape[3]
             s.Ho, s.Wo, s.Cout = y.shape[1], y.shape[2], c["cout"]
         self._keep.append(p)
-        self.conv_launches.append(("fwd:" + (first.get("group") or first["out"]), p))
+        name = "fwd:" + (first.get("group") or first["out"])
+        if any(n == name for n, _ in self.conv_launches):   # second launch of a split group (engine.split_by_depth)
+            name += ":rest"
+        self.conv_launches.append((name, p))
         return p
 
     def _dw_problem(self, ops, dst_of):
@@ -889,8 +893,9 @@ class TrainEngine:
                         self._bn_pass("bn_apply", pb, lambda: _C.check(lib.rn_bn_apply(prb, st), "rn_bn_apply"))
                     self.fwd_steps.append(run)
                 else:
-                    pc = self._conv_problem(ops, lambda o: self.t[o["out"]], raw_mode=False)
-                    self.fwd_steps.append(lambda st, pc=pc: self._launch_conv(pc, st, "conv"))
+                    for sub in split_by_depth(self.g, ops):
+                        pc = self._conv_problem(sub, lambda o: self.t[o["out"]], raw_mode=False)
+                        self.fwd_steps.append(lambda st, pc=pc: self._launch_conv(pc, st, "conv"))
             elif kind == "dwconv":
                 grp = op.get("group")
                 if grp is not None:

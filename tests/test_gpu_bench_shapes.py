@@ -286,9 +286,14 @@ def test_every_distinct_launch_of_the_bench_engine(cuda, size, B, splitk_env):
         kinds[k] = kinds.get(k, 0) + 1
         n_split += int(bool(p.splitk_ws) and eng.lib.rn_conv_splitk_workspace_bytes(ctypes.byref(p)) > 0)
     assert (n_split >= 4) if splitk_env == "split" else (n_split == 0), n_split   # towers / FPN / stage 4 split their last round
-    # the engine at this size runs all three forward kernel families, as forward and as data-gradient launches
-    for k in (("fwd", 0), ("fwd", 1), ("fwd", 2), ("dgrad", 0), ("dgrad", 1), ("dgrad", 2)):
+    # the engine at this size runs all three forward kernel families, as forward and as data-gradient launches; the halo
+    # kernel in its 512 x 128 form (kernel id 3: the dispatcher's choice wherever the channel count is a multiple of 128),
+    # or in the 256 x 256 form when the launches carry a split-K workspace
+    halo = 2 if splitk_env == "split" else 3
+    for k in (("fwd", 0), ("fwd", 1), ("fwd", halo), ("dgrad", 0), ("dgrad", 1), ("dgrad", halo)):
         assert kinds.get(k, 0) >= 1, kinds
+    pair = [eng.lib.rn_conv_kernel_id(ctypes.byref(p)) for _, p in convs if p.seg[0].w_pair]
+    assert pair == [3], pair      # the box prediction conv: two weight planes as GEMM columns on the 512 x 128 tiles
     assert len(convs) >= 40 and len(wgrads) >= 25, (len(convs), len(wgrads))
     # free the engine's tensors before the float64 references are built
     eng_lib, eng_h16 = eng.lib, eng.h16

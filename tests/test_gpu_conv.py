@@ -372,6 +372,52 @@ def test_conv_halo_kernel_512x128_tiles(cuda, build, case):
         assert (got != small).float().mean().item() < 0.02
 
 
+HALO512_WIDE_CASES = [
+    # N, H, W, Cin, Cout, act, residual, f32 output, bias (instead of scale / shift), w_terms, persistent workgroups
+    (2, 40, 40, 64, 256, "relu", False, False, True, 1, 0),     # head tower: two column tiles per pixel tile, bias + relu
+    (1, 33, 31, 96, 256, "relu", True, False, False, 1, 3),     # folded BatchNorm + residual + relu, 3 workgroups (4 rounds)
+    (2, 20, 20, 64, 720, None, False, True, True, 2, 0),        # class prediction: f32, two weight planes along Cin, 6 column tiles (the last 80 channels live)
+    (3, 16, 16, 128, 384, None, False, False, False, 1, 2),     # three column tiles, raw output
+    (2, 24, 24, 64, 320, "relu6", False, False, True, 1, 0),    # Cout tail: the third column tile has 64 live channels
+]
+
+
+@pytest.mark.parametrize("build,case", _builds(HALO512_WIDE_CASES, HALO512_WIDE_CASES[:3], "halo512w-"))
+def test_conv_halo_kernel_512x128_tiles_wide_layers(cuda, build, case):
+    """The 512 x 128 form on layers of 256 and more channels (what the dispatcher picks for the head towers, the FPN output
+    convs and the class prediction conv from three rounds of tiles on; forced here with conv_tile = 3): several column tiles
+    per pixel tile, against the float64 reference and against the 256 x 256 form on the same inputs."""
+    from retinanet import _C
+    lib = _lib()
+    N, H, W, Cin, Cout, act, use_res, out_f32, use_bias, terms, wgs = case
+    g = torch.Generator().manual_seed(_seed(case))
+    s = {"x": torch.randn((N, H, W, Cin), generator=g),
+         "w": torch.randn((3, 3, Cin, Cout), generator=g) / math.sqrt(9 * Cin), "w_terms": terms}
+    if use_bias:
+        s["bias"] = torch.randn((Cout,), generator=g) * 0.5
+    elif act is not None:
+        s["scale"], s["shift"] = torch.rand((Cout,), generator=g) + 0.5, torch.randn((Cout,), generator=g) * 0.1
+    if use_res:
+        s["residual"] = torch.randn((N, H, W, Cout), generator=g)
+    p = _C.ConvProblem()
+    p.R = p.S = 3
+    p.stride_h = p.stride_w = p.pad_top = p.pad_left = 1
+    p.out_dtype, p.num_segments = (_C.RN_DT_F32 if out_f32 else _C.RN_DT_BF16), 1
+    sg = p.seg[0]
+    sg.N, sg.H, sg.W, sg.Cin, sg.pix_stride, sg.Ho, sg.Wo, sg.Cout = N, H, W, Cin, Cin, H, W, Cout
+    sg.w_terms = terms
+    p.opts = _C.LaunchOpts(conv_tile=3)
+    assert lib.rn_conv_kernel_id(ctypes.byref(p)) == 3 and lib.rn_conv_tile_rows(ctypes.byref(p)) == 512
+    got = _conv_gpu(cuda, [s], 3, 1, 1, act, out_f32, dict(conv_tile=3, max_workgroups=wgs))[0]
+    p.opts = _C.LaunchOpts(conv_tile=2)
+    assert lib.rn_conv_kernel_id(ctypes.byref(p)) == 2
+    wide = _conv_gpu(cuda, [s], 3, 1, 1, act, out_f32, dict(conv_tile=2))[0]
+    want = _conv_ref(s, 3, 1, 1, act, out_f32)
+    _close(got, want, out_f32)
+    # the same products in the same K order per accumulator: the two tile shapes agree to the bit
+    assert torch.equal(got, wide)
+
+
 BIAS_CASES = [
     # N, H, W, Cin, Cout, k, act, persistent workgroups (0 = one per CU)
     (2, 24, 24, 64, 256, 3, "relu", 0),

@@ -486,7 +486,7 @@ def test_bn_train_forward_backward(cuda, build, act, use_res):
 
 
 @pytest.mark.parametrize("build,k,tile", [("bf16", 1, 2), ("bf16", 3, 2), ("bf16", 1, 1), ("bf16", 3, 1), ("bf16", 3, 3),
-                                          ("f16", 1, 2), ("f16", 3, 2), ("f16", 3, 1), ("f16", 3, 3)])
+                                          ("bf16", 3, 4), ("f16", 1, 2), ("f16", 3, 2), ("f16", 3, 1), ("f16", 3, 3), ("f16", 3, 4)])
 def test_bn_forward_stats_fused_into_conv_epilogue(cuda, build, k, tile):
     """rn_conv_segment.bn_partial + rn_bn_segment.ext_chunks: the 256-row conv kernel writes the per-128-row partial
     sums, rn_bn_stats only runs the final reduction.  Must give the statistics of the unfused path on the same
@@ -517,12 +517,14 @@ def test_bn_forward_stats_fused_into_conv_epilogue(cuda, build, k, tile):
         segs.append({"y": torch.zeros((N, H, W, cout)), "gamma": torch.ones((cout,)), "beta": torch.zeros((cout,)),
                      "moving_mean": torch.zeros((cout,)), "moving_var": torch.ones((cout,))})
     st = _C.current_stream()
-    pc.opts = _C.LaunchOpts(conv_tile=min(tile, 2))   # 2 / 3: the 256- / 512-row kernels, 1: the 128-row kernel (one partial row per tile)
+    # tile 1: the 128-row kernel (one partial row per tile) | 2: the 256-row kernels | 3: 512 x 128 halo tiles, narrow layers |
+    # 4: 512 x 128 halo tiles on the wide shapes (what the dispatcher itself picks for them; several column tiles per row block)
+    pc.opts = _C.LaunchOpts(conv_tile={1: 1, 2: 2, 3: 2, 4: 3}[tile])
     if True:
         rows = lib.rn_conv_tile_rows(ctypes.byref(pc))
-        assert rows == {1: 128, 2: 256, 3: 512}[tile]
+        assert rows == {1: 128, 2: 256, 3: 512, 4: 512}[tile]
         if tile >= 2:
-            assert lib.rn_conv_kernel_id(ctypes.byref(pc)) == (3 if tile == 3 else (2 if k == 3 else 1))
+            assert lib.rn_conv_kernel_id(ctypes.byref(pc)) == (3 if tile >= 3 else (2 if k == 3 else 1))
         sums = {}
         for fused in (False, True):
             p, dev = _bn_problem(cuda, segs, None)
@@ -549,7 +551,7 @@ def test_bn_forward_stats_fused_into_conv_epilogue(cuda, build, k, tile):
 
 
 @pytest.mark.parametrize("build,k,tile", [("bf16", 1, 2), ("bf16", 3, 2), ("bf16", 1, 1), ("bf16", 3, 1), ("bf16", 3, 3),
-                                          ("f16", 1, 2), ("f16", 3, 2), ("f16", 3, 1), ("f16", 3, 3)])
+                                          ("bf16", 3, 4), ("f16", 1, 2), ("f16", 3, 2), ("f16", 3, 1), ("f16", 3, 3), ("f16", 3, 4)])
 def test_bn_backward_reduction_fused_into_the_data_gradient(cuda, build, k, tile):
     """rn_conv_segment.bn_bwd_y + rn_bn_segment.ext_chunks_bwd: the launch that writes dz of a BatchNorm + ReLU layer
     also writes stage 1 of that layer's backward reduction (sum g, sum g*xhat); rn_bn_bwd_reduce only runs the ordered
@@ -586,12 +588,12 @@ def test_bn_backward_reduction_fused_into_the_data_gradient(cuda, build, k, tile
                      "gamma": torch.rand((cout,), generator=g) + 0.5, "beta": torch.randn((cout,), generator=g) * 0.3,
                      "moving_mean": torch.zeros((cout,)), "moving_var": torch.ones((cout,))})
     st = _C.current_stream()
-    pc.opts = _C.LaunchOpts(conv_tile=min(tile, 2))
+    pc.opts = _C.LaunchOpts(conv_tile={1: 1, 2: 2, 3: 2, 4: 3}[tile])   # (as in the forward-statistics test above)
     if True:
         rows = lib.rn_conv_tile_rows(ctypes.byref(pc))
-        assert rows == {1: 128, 2: 256, 3: 512}[tile]
+        assert rows == {1: 128, 2: 256, 3: 512, 4: 512}[tile]
         if tile >= 2:
-            assert lib.rn_conv_kernel_id(ctypes.byref(pc)) == (3 if tile == 3 else (2 if k == 3 else 1))
+            assert lib.rn_conv_kernel_id(ctypes.byref(pc)) == (3 if tile >= 3 else (2 if k == 3 else 1))
         out = {}
         for fused in (False, True):
             p, dev = _bn_problem(cuda, segs, "relu")
