@@ -498,9 +498,11 @@ static bool conv_use_halo512(const rn_conv_problem* p) {
   for (int i = 0; i < p->num_segments; ++i) {
     const rn_conv_segment& s = p->seg[i];
     const int cp = rn_conv_cout_pad(seg_cols(s));
-    if (cp % 128 != 0 || (cp != 128 && p->opts.conv_tile != 3) || !seg_cout_ok(p, s)) return false;   // conv_tile = 3: any width
+    // conv_tile = 3: any width, also <= 64 channels (half of the tile's columns are then zero weights)
+    if ((cp % 128 != 0 && !(cp == 64 && p->opts.conv_tile == 3)) || (cp != 128 && p->opts.conv_tile != 3) || !seg_cout_ok(p, s))
+      return false;
     if (s.bias && s.residual) return false;   // as for the 256-row kernels: the residual variants carry no bias path
-    tiles += rn_cdiv((long long)s.N * s.Ho * s.Wo, 512) * (cp / 128);
+    tiles += rn_cdiv((long long)s.N * s.Ho * s.Wo, 512) * rn_cdiv(cp, 128);
   }
   if (!conv_halo_shape(p, 512)) return false;
   // enough tiles to fill the chip once (opts.conv_tile = 2 forces the form: tests at small sizes)

@@ -352,7 +352,7 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
       if (SPLIT) w_end = un__.end;                                                                    \
     }                                                                                                 \
     const int Ktot__ = 9 * sg__.CinP;                                                                 \
-    const int rows__ = ((sg__.Cout + 127) / 128) * 128; /* packed weight rows */                      \
+    const int rows__ = sg__.Cout <= 64 ? 64 : ((sg__.Cout + 127) / 128) * 128; /* packed weight rows (rn_conv_cout_pad) */ \
     rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)sg__.w, 0, (int)((long long)rows__ * Ktot__ * 2), \
                                              0x00020000);                                             \
     {                                                                                                 \

@@ -418,6 +418,43 @@ def test_conv_halo_kernel_512x128_tiles_wide_layers(cuda, build, case):
     assert torch.equal(got, wide)
 
 
+HALO512_NARROW_CASES = [
+    # N, H, W, Cin, Cout, act, residual
+    (2, 40, 40, 64, 64, "relu", False),      # ResNet stage 1 3x3 at its own width: half of the tile's columns are zero weights
+    (1, 33, 31, 64, 40, None, False),        # Cout tail inside the live half
+    (3, 16, 16, 32, 64, "relu", True),       # one chunk, residual
+]
+
+
+@pytest.mark.parametrize("case", HALO512_NARROW_CASES, ids=lambda c: "halo512n-" + "x".join(str(v) for v in c))
+def test_conv_halo_kernel_512x128_tiles_narrow_layers(cuda, case):
+    """Cout <= 64 on the 512 x 128 form (conv_tile = 3): the packed weights have 64 rows, the tile's other 64 columns read
+    zeros through the buffer bounds.  Against the float64 reference and the 128-row kernel."""
+    from retinanet import _C
+    lib = _lib()
+    N, H, W, Cin, Cout, act, use_res = case
+    g = torch.Generator().manual_seed(_seed(case))
+    s = {"x": torch.randn((N, H, W, Cin), generator=g),
+         "w": torch.randn((3, 3, Cin, Cout), generator=g) / math.sqrt(9 * Cin),
+         "scale": torch.rand((Cout,), generator=g) + 0.5, "shift": torch.randn((Cout,), generator=g) * 0.1}
+    if use_res:
+        s["residual"] = torch.randn((N, H, W, Cout), generator=g)
+    p = _C.ConvProblem()
+    p.R = p.S = 3
+    p.stride_h = p.stride_w = p.pad_top = p.pad_left = 1
+    p.out_dtype, p.num_segments = _C.RN_DT_BF16, 1
+    sg = p.seg[0]
+    sg.N, sg.H, sg.W, sg.Cin, sg.pix_stride, sg.Ho, sg.Wo, sg.Cout = N, H, W, Cin, Cin, H, W, Cout
+    p.opts = _C.LaunchOpts(conv_tile=3)
+    assert lib.rn_conv_kernel_id(ctypes.byref(p)) == 3 and lib.rn_conv_tile_rows(ctypes.byref(p)) == 512
+    got = _conv_gpu(cuda, [s], 3, 1, 1, act, False, dict(conv_tile=3))[0]
+    small = _conv_gpu(cuda, [s], 3, 1, 1, act, False, dict(conv_tile=1))[0]
+    want = _conv_ref(s, 3, 1, 1, act, False)
+    _close(got, want, False)
+    scale = want.abs().max().item() + 1e-6
+    torch.testing.assert_close(got, small, rtol=1.0 / 128, atol=scale / 256)
+
+
 BIAS_CASES = [
     # N, H, W, Cin, Cout, k, act, persistent workgroups (0 = one per CU)
     (2, 24, 24, 64, 256, 3, "relu", 0),
