@@ -420,6 +420,22 @@ __device__ __forceinline__ float4 shfl_box(float4 v, int src) {
   return r;
 }
 
+// max over the 64 lanes of a wave, returned to every lane: six DPP steps (quad swaps, row rotations, row broadcasts — the
+// gfx9 wave-reduction sequence) and one v_readlane; a __shfl_xor tree is six ds_bpermute round trips through the LDS crossbar
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_max_step(float v) {
+  return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false)));
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+  v = dpp_max_step<0xb1, 0xf>(v);    // quad_perm [1,0,3,2]
+  v = dpp_max_step<0x4e, 0xf>(v);    // quad_perm [2,3,0,1]
+  v = dpp_max_step<0x124, 0xf>(v);   // row_ror:4
+  v = dpp_max_step<0x128, 0xf>(v);   // row_ror:8   -> every lane holds its row's max
+  v = dpp_max_step<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+  v = dpp_max_step<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's max
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 // One workgroup per (image, class).  Dynamic LDS: keys[RN_SORT_CAP] | sel boxes | sel scores
 // | soft-NMS state | hist.
 struct NmsParams {
@@ -427,6 +443,7 @@ struct NmsParams {
   float iou_thr, score_thr, soft_scale;  // soft_scale = -0.5/(sigma/2) when soft, else 0
   int soft;
   long long cap;
+  int soft_off, pad_;   // soft: byte offset of the soft-NMS state in LDS (the sort buffer's unused tail, or behind everything)
 };
 
 __global__ void __launch_bounds__(RN_PP_THREADS)
@@ -441,8 +458,12 @@ nms_per_class_kernel(NmsParams p, const int* __restrict__ counts, const unsigned
   int* s_hist = (int*)((char*)s_selidx + (size_t)RN_MAX_DET * 4);              // 256 * 4
   unsigned long long* s_prefix = (unsigned long long*)((char*)s_hist + 1024);  // 8
   int* s_misc = (int*)((char*)s_prefix + 8);                                   // [0]=k scratch [1]=fill [2]=nsel
-  float* s_cur = (float*)((char*)s_misc + 16);                                 // soft: RN_SORT_CAP * 4
-  unsigned short* s_sbi = (unsigned short*)((char*)s_cur + (p.soft ? (size_t)RN_SORT_CAP * 4 : 0));
+  // soft NMS state (sized by nms_lds_bytes below): two cached blocks of candidate boxes | per block (best score, its
+  // position) | one byte per candidate.  A candidate's CURRENT score lives in the score half of its sorted key.
+  float4* s_cbox = (float4*)(smem + p.soft_off);                               // 2 * 64 * 16
+  int2* s_blk = (int2*)((char*)s_cbox + 2048);                                 // RN_SORT_CAP / 64 * 8: (best score, its position)
+  unsigned char* s_sbi = (unsigned char*)((char*)s_blk + RN_SORT_CAP / 64 * 8 + 16);   // candidates (<= max_det - 1 <= 255 each)
+  float* s_cur2 = (float*)skeys;                                               // score of candidate i: s_cur2[2 * i + 1]
 
   const int list = blockIdx.x;  // b*K + c
   const int b = list / p.K, c = list - b * p.K;
@@ -511,36 +532,59 @@ nms_per_class_kernel(NmsParams p, const int* __restrict__ counts, const unsigned
         }
       } else {
         // ---- soft NMS: exact emulation of NonMaxSuppressionV5's priority queue ------------
-        for (int i = lane; i < m; i += 64) {
-          s_cur[i] = key_score(skeys[i]);
-          s_sbi[i] = 0;
+        // The queue is the sorted chunk itself: candidate i keeps its position, its CURRENT score replaces the score half
+        // of its key (-1: popped for good, or fell to the threshold).  Per block j of 64 candidates: s_blk[j] = (the
+        // block's best score, the lowest position inside the block holding it).  A pop is the argmax over the
+        // block maxima (lowest block on ties) — the queue's (score desc, position asc) order — in a handful of LDS reads and
+        // two DPP wave reductions.  The boxes of a block's 64 candidates are fetched together, one per lane, when the block
+        // first leads (two blocks cached: pops walk the sorted order, re-inserted candidates sit in the blocks behind).
+        // Round 4: until then every pop scanned all m candidates (~60 dependent LDS reads), multiplied the weights
+        // through up to 100 dependent ds_bpermute's and fetched its box from memory; on clustered detections — a pop per
+        // candidate, most of them decayed to death by their selected neighbours — EfficientNet-B3's batch-8 serving
+        // step spent 140 of its 147 ms in this loop (now ~7).  The LDS footprint dropped from 122 KB to 73 KB (state in
+        // the sort buffer's unused tail): two lists per compute unit.
+        const int nblk = (m + 63) >> 6;
+        for (int j = 0; j < nblk; ++j) {
+          const int i = j * 64 + lane;
+          float sc = -1.0f;
+          if (i < m) {
+            sc = key_score(skeys[i]);
+            s_sbi[i] = 0;
+          }
+          __builtin_amdgcn_s_waitcnt(0xc07f);   // the key is read before its score half is rewritten
+          if (i < m) s_cur2[2 * i + 1] = sc;
+          const float mx = wave_max_f32(sc);
+          const int pos = (int)__builtin_ctzll(__ballot(sc == mx));
+          if (lane == 0) s_blk[j] = make_int2(__float_as_int(mx), pos);
         }
+        int tag0 = -1, tag1 = -1;   // the blocks whose boxes sit in the two cache slots (wave-uniform)
         __builtin_amdgcn_s_waitcnt(0xc07f);
         while (nsel < p.max_det) {
-          // argmax (score, then lowest position) over live candidates (score > thr)
-          float best = -1.0f;
-          int besti = 0x7fffffff;
-          for (int i = lane; i < m; i += 64) {
-            const float sc = s_cur[i];
-            if (sc > p.score_thr && (sc > best)) {  // ascending i per lane -> first max kept
-              best = sc;
-              besti = i;
-            }
+          // lane l looks at blocks l and l + 64 (m <= RN_SORT_CAP = 128 blocks); the lowest block holding the maximum
+          const int2 e0 = lane < nblk ? s_blk[lane] : make_int2(__float_as_int(-1.0f), 0);
+          const int2 e1 = lane + 64 < nblk ? s_blk[lane + 64] : make_int2(__float_as_int(-1.0f), 0);
+          const float b0 = __int_as_float(e0.x), b1 = __int_as_float(e1.x);
+          const float best = wave_max_f32(fmaxf(b0, b1));
+          if (!(best > p.score_thr)) break;  // queue empty
+          const unsigned long long h0 = __ballot(b0 == best), h1 = __ballot(b1 == best);
+          const int bl = __builtin_amdgcn_readfirstlane(h0 ? (int)__builtin_ctzll(h0) : (int)__builtin_ctzll(h1));
+          const int blk = h0 ? bl : 64 + bl;
+          const int pos = h0 ? __builtin_amdgcn_readlane(e0.y, bl) : __builtin_amdgcn_readlane(e1.y, bl);
+          const int i0 = blk * 64 + lane;
+          const int e = blk & 1;
+          if ((e ? tag1 : tag0) != blk) {   // (uniform) this block's boxes: 64 fetches in flight instead of one per pop
+            float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i0 < m) bx = fetch_clipped(bs, b, c, key_index(skeys[i0]));
+            s_cbox[e * 64 + lane] = bx;
+            if (e) tag1 = blk; else tag0 = blk;
+            __builtin_amdgcn_s_waitcnt(0xc07f);
           }
-          for (int o = 32; o > 0; o >>= 1) {
-            const float ob = __shfl_xor(best, o, 64);
-            const int oi = __shfl_xor(besti, o, 64);
-            if (ob > best || (ob == best && oi < besti)) {
-              best = ob;
-              besti = oi;
-            }
-          }
-          if (besti == 0x7fffffff) break;  // queue empty
-          const unsigned int idx = key_index(skeys[besti]);
-          const float4 box = fetch_clipped(bs, b, c, idx);
+          const int besti = blk * 64 + pos;
+          const float4 box = s_cbox[e * 64 + pos];
+          const float mine = i0 < m ? s_cur2[2 * i0 + 1] : -1.0f;
           const int begin = s_sbi[besti];
           float score = best;
-          // newest -> oldest; weights computed 64 at a time, multiplied in order by all lanes
+          // newest -> oldest; weights computed 64 at a time, multiplied in order
           for (int hi = nsel - 1; hi >= begin && score > p.score_thr; hi -= 64) {
             const int j = hi - lane;
             float w = 1.0f;
@@ -548,22 +592,30 @@ nms_per_class_kernel(NmsParams p, const int* __restrict__ counts, const unsigned
               const float sim = nms_iou(box, s_selbox[j]);
               w = rn_expf(p.soft_scale * sim * sim);
             }
-            const int cnt = (hi - begin + 1) < 64 ? (hi - begin + 1) : 64;
-            for (int q = 0; q < cnt; ++q) {
-              score = score * __shfl(w, q, 64);
+            // the weights multiply the score in lane order (newest selected box first); a weight of exactly 1 (no overlap:
+            // the common case) leaves the score as it is, so only the other lanes are visited — each step one v_readlane
+            unsigned long long nz = __ballot(w != 1.0f);
+            while (nz) {
+              const int q = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(nz));
+              nz &= nz - 1;
+              score = score * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w), q));
               if (score <= p.score_thr) break;
             }
           }
+          // selected (score unchanged), re-inserted with its lower score, or dropped
+          const float back = (score == best || !(score > p.score_thr)) ? -1.0f : score;
+          const float now = lane == pos ? back : mine;       // the block's scores after this pop
+          const float mx = wave_max_f32(now);
+          const int npos = (int)__builtin_ctzll(__ballot(now == mx));
           if (lane == 0) {
-            s_sbi[besti] = (unsigned short)nsel;
+            s_sbi[besti] = (unsigned char)nsel;
             if (score == best) {
               s_selbox[nsel] = box;
               s_selscore[nsel] = score;
-              s_selidx[nsel] = (int)idx;
-              s_cur[besti] = -1.0f;  // popped for good
-            } else {
-              s_cur[besti] = score > p.score_thr ? score : -1.0f;
+              s_selidx[nsel] = (int)key_index(skeys[besti]);
             }
+            s_cur2[2 * besti + 1] = back;
+            s_blk[blk] = make_int2(__float_as_int(mx), npos);
           }
           if (score == best) ++nsel;
           __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -687,10 +739,21 @@ extern "C" int rn_rowmax_argmax(const float* scores, int64_t rows, int K, float*
 }
 
 // ------------------------------------------------------------------------------------------
-static size_t nms_lds_bytes(int soft) {
-  size_t s = (size_t)RN_SORT_CAP * 8 + (size_t)RN_MAX_DET * 16 + (size_t)RN_MAX_DET * 8 + 1024 + 8 + 16;
-  if (soft) s += (size_t)RN_SORT_CAP * 4 + (size_t)RN_SORT_CAP * 2;
-  return rn_align_up(s, 16);
+// LDS of nms_per_class_kernel.  Soft NMS keeps its state (2 KB box cache, 1 KB block maxima / leaders, one byte per
+// candidate) in the tail of the sort buffer that the single sorted chunk of at most `max_cands` keys leaves unused, or
+// behind everything when that tail is too short: *soft_off = its byte offset.
+static size_t nms_lds_bytes(int soft, long long max_cands, int* soft_off) {
+  const size_t base = rn_align_up((size_t)RN_SORT_CAP * 8 + (size_t)RN_MAX_DET * 16 + (size_t)RN_MAX_DET * 8 + 1024 + 8 + 16, 16);
+  *soft_off = 0;
+  if (!soft) return base;
+  const size_t cands = rn_align_up((size_t)(max_cands < RN_SORT_CAP ? max_cands : RN_SORT_CAP), 64);
+  const size_t state = rn_align_up(2048 + (size_t)RN_SORT_CAP / 64 * 8 + 16 + cands, 16);
+  if (cands * 8 + state <= (size_t)RN_SORT_CAP * 8) {
+    *soft_off = (int)(cands * 8);
+    return base;
+  }
+  *soft_off = (int)base;
+  return base + state;
 }
 
 struct DetectWs {
@@ -745,7 +808,8 @@ static int run_nms_stage(const DetectWs& w, int B, long long cap, int K, const B
   p.iou_thr = iou_threshold;
   p.score_thr = score_threshold;
   p.cap = cap;
-  const size_t lds = nms_lds_bytes(p.soft);
+  p.pad_ = 0;
+  const size_t lds = nms_lds_bytes(p.soft, top_k > 0 ? (long long)top_k : cap, &p.soft_off);
   RN_CHECK_HIP(hipFuncSetAttribute((const void*)nms_per_class_kernel,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(nms_per_class_kernel, dim3(B * K), dim3(RN_PP_THREADS), lds, st, p, w.counts, w.keys, bs,
