@@ -541,8 +541,13 @@ nms_per_class_kernel(NmsParams p, const int* __restrict__ counts, const unsigned
         // Round 4: until then every pop scanned all m candidates (~60 dependent LDS reads), multiplied the weights
         // through up to 100 dependent ds_bpermute's and fetched its box from memory; on clustered detections — a pop per
         // candidate, most of them decayed to death by their selected neighbours — EfficientNet-B3's batch-8 serving
-        // step spent 140 of its 147 ms in this loop (now ~7).  The LDS footprint dropped from 122 KB to 73 KB (state in
-        // the sort buffer's unused tail): two lists per compute unit.
+        // step spent 140 of its 147 ms in this loop (now ~11: 2 000 - 8 000 pops per class at ~2 200 cycles each, a chain
+        // of dependent LDS reads and VALU operations on one wave).  The LDS footprint dropped from 122 KB to 73 KB (state
+        // in the sort buffer's unused tail): two lists per compute unit.
+        // Tried and dropped: pops in batches (one candidate of the leading block per lane, re-scored in parallel, a scalar
+        // walk in queue order up to the next selection — pops between two selections are independent).  Bit-identical, 17
+        // pops per batch on the clustered lists, and slower (27 - 50 ms): re-inserted candidates make the queue's top jump
+        // between many blocks, each visit needing that block's boxes and overlap masks for one or two pops.
         const int nblk = (m + 63) >> 6;
         for (int j = 0; j < nblk; ++j) {
           const int i = j * 64 + lane;
