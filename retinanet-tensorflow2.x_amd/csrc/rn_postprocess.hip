@@ -328,7 +328,8 @@ struct ScoreKeys {  // keys built on the fly from a dense score array (merge sta
 // k-th largest (1-based) among keys[0..n) that are < upper.  Keys are unique.
 template <class Loader>
 __device__ unsigned long long radix_select_desc(Loader keys, int n, unsigned long long upper, int kth,
-                                                int* hist /*256*/, unsigned long long* s_prefix, int* s_k) {
+                                                int* hist /*256*/, unsigned long long* s_prefix, int* s_k,
+                                                int* s_wtot /*4: per-wave bin totals*/) {
   if (threadIdx.x == 0) {
     *s_prefix = 0ull;
     *s_k = kth;
@@ -343,14 +344,28 @@ __device__ unsigned long long radix_select_desc(Loader keys, int n, unsigned lon
       if (key < upper && (key & mask) == prefix) atomicAdd(&hist[(int)((key >> shift) & 255ull)], 1);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-      int kk = *s_k, cum = 0, d = 255;
-      for (; d > 0; --d) {
-        if (cum + hist[d] >= kk) break;
-        cum += hist[d];
+    {
+      // the bin that holds the kk-th largest key: thread d owns bin d (the workgroup has 256 threads) and needs the number
+      // of keys in the bins above it — a suffix sum inside the wave plus the totals of the waves above.  (One thread
+      // walking the 256 bins cost ~5 us per pass, 8 passes per selection: a third of merge_kernel and a quarter of a
+      // hard-NMS list at batch 8.)
+      const int d = threadIdx.x, ln = d & 63, wv = d >> 6;
+      const int h = hist[d];
+      const int kk = *s_k;
+      int v = h;                                   // -> sum of the bins ln .. 63 of this wave
+      for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_down(v, o, 64);
+        if (ln + o < 64) v += u;
       }
-      *s_k = kk - cum;
-      *s_prefix = prefix | (((unsigned long long)d) << shift);
+      if (ln == 0) s_wtot[wv] = v;
+      __syncthreads();
+      int above = v - h;
+      for (int w = wv + 1; w < 4; ++w) above += s_wtot[w];
+      // bin 0 takes what is left (as the serial walk did when the bins above hold fewer than kk keys)
+      if (above < kk && (d == 0 || kk <= above + h)) {
+        *s_k = kk - above;
+        *s_prefix = prefix | (((unsigned long long)d) << shift);
+      }
     }
     mask |= 255ull << shift;
     __syncthreads();
@@ -365,7 +380,7 @@ __device__ unsigned long long next_chunk_sorted(Loader keys, int n, int remainin
                                                 unsigned long long upper, unsigned long long* skeys,
                                                 int* s_hist, unsigned long long* s_prefix, int* s_misc) {
   unsigned long long lower = 0ull;
-  if (remaining > take) lower = radix_select_desc(keys, n, upper, take, s_hist, s_prefix, &s_misc[0]);
+  if (remaining > take) lower = radix_select_desc(keys, n, upper, take, s_hist, s_prefix, &s_misc[0], &s_misc[4]);
   int N2 = 64;
   while (N2 < take) N2 <<= 1;
   if (threadIdx.x == 0) s_misc[1] = 0;
@@ -443,7 +458,8 @@ struct NmsParams {
   float iou_thr, score_thr, soft_scale;  // soft_scale = -0.5/(sigma/2) when soft, else 0
   int soft;
   long long cap;
-  int soft_off, pad_;   // soft: byte offset of the soft-NMS state in LDS (the sort buffer's unused tail, or behind everything)
+  int soft_off;         // soft: byte offset of the soft-NMS state in LDS (the sort buffer's unused tail, or behind everything)
+  int chunk_cap;        // keys the LDS sort buffer holds: RN_SORT_CAP for soft NMS (the whole list is one chunk), RN_HARD_CHUNK else
 };
 
 __global__ void __launch_bounds__(RN_PP_THREADS)
@@ -451,13 +467,13 @@ nms_per_class_kernel(NmsParams p, const int* __restrict__ counts, const unsigned
                      BoxSrc bs, float* __restrict__ sel_scores, float4* __restrict__ sel_boxes,
                      int* __restrict__ sel_idx) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  unsigned long long* skeys = (unsigned long long*)smem;                       // RN_SORT_CAP * 8
-  float4* s_selbox = (float4*)(smem + (size_t)RN_SORT_CAP * 8);                // RN_MAX_DET * 16
+  unsigned long long* skeys = (unsigned long long*)smem;                       // chunk_cap * 8
+  float4* s_selbox = (float4*)(smem + (size_t)p.chunk_cap * 8);                // RN_MAX_DET * 16
   float* s_selscore = (float*)((char*)s_selbox + (size_t)RN_MAX_DET * 16);     // RN_MAX_DET * 4
   int* s_selidx = (int*)((char*)s_selscore + (size_t)RN_MAX_DET * 4);          // RN_MAX_DET * 4
   int* s_hist = (int*)((char*)s_selidx + (size_t)RN_MAX_DET * 4);              // 256 * 4
   unsigned long long* s_prefix = (unsigned long long*)((char*)s_hist + 1024);  // 8
-  int* s_misc = (int*)((char*)s_prefix + 8);                                   // [0]=k scratch [1]=fill [2]=nsel
+  int* s_misc = (int*)((char*)s_prefix + 8);                                   // [0]=k scratch [1]=fill [2]=nsel [4..7]=wave totals (radix select)
   // soft NMS state (sized by nms_lds_bytes below): two cached blocks of candidate boxes | per block (best score, its
   // position) | one byte per candidate.  A candidate's CURRENT score lives in the score half of its sorted key.
   float4* s_cbox = (float4*)(smem + p.soft_off);                               // 2 * 64 * 16
@@ -486,7 +502,7 @@ nms_per_class_kernel(NmsParams p, const int* __restrict__ counts, const unsigned
     if (s_misc[2] >= p.max_det) break;
     // hard NMS usually fills max_det from the first few hundred candidates: sort a small first
     // chunk, fall back to full LDS-sized chunks only when suppression eats through it
-    int cap_chunk = RN_SORT_CAP;
+    int cap_chunk = p.chunk_cap;
     if (!p.soft && processed == 0) cap_chunk = 1024;
     const int take = (limit - processed) < cap_chunk ? (limit - processed) : cap_chunk;
     const unsigned long long lower =
@@ -510,9 +526,15 @@ nms_per_class_kernel(NmsParams p, const int* __restrict__ counts, const unsigned
             const float4 sb = s_selbox[j];
             if (alive && nms_iou(box, sb) > p.iou_thr) alive = false;
           }
-          unsigned long long mask = 0ull;  // earlier lanes of this group that suppress me
+          // earlier lanes of this group that suppress me.  The group's 64 boxes go through LDS (the histogram of the
+          // sort, idle here): 63 independent broadcast reads per lane pipeline, where a shuffle of lane j's box is four
+          // ds_bpermute round trips per step (hard NMS at batch 8: 260 -> 180 us)
+          float4* s_gbox = (float4*)s_hist;
+          s_gbox[lane] = box;
+          __builtin_amdgcn_s_waitcnt(0xc07f);
+          unsigned long long mask = 0ull;
           for (int j = 0; j < 63; ++j) {
-            const float4 ob = shfl_box(box, j);
+            const float4 ob = s_gbox[j];
             if (j < lane && nms_iou(box, ob) > p.iou_thr) mask |= 1ull << j;
           }
           unsigned long long alive_mask = __ballot(alive);
@@ -747,8 +769,13 @@ extern "C" int rn_rowmax_argmax(const float* scores, int64_t rows, int K, float*
 // LDS of nms_per_class_kernel.  Soft NMS keeps its state (2 KB box cache, 1 KB block maxima / leaders, one byte per
 // candidate) in the tail of the sort buffer that the single sorted chunk of at most `max_cands` keys leaves unused, or
 // behind everything when that tail is too short: *soft_off = its byte offset.
-static size_t nms_lds_bytes(int soft, long long max_cands, int* soft_off) {
-  const size_t base = rn_align_up((size_t)RN_SORT_CAP * 8 + (size_t)RN_MAX_DET * 16 + (size_t)RN_MAX_DET * 8 + 1024 + 8 + 16, 16);
+// Hard NMS takes its candidates in sorted chunks (1 024 first — it usually fills max_det from a few hundred — then
+// RN_HARD_CHUNK at a time): 4 096 keys = 39 KB of LDS = four lists per compute unit, where RN_SORT_CAP keys (73 KB) allowed two:
+// the 640 lists of a batch of 8 run in one round instead of two.
+#define RN_HARD_CHUNK 4096
+static size_t nms_lds_bytes(int soft, long long max_cands, int* soft_off, int* chunk_cap) {
+  *chunk_cap = soft ? RN_SORT_CAP : RN_HARD_CHUNK;
+  const size_t base = rn_align_up((size_t)*chunk_cap * 8 + (size_t)RN_MAX_DET * 16 + (size_t)RN_MAX_DET * 8 + 1024 + 8 + 32, 16);
   *soft_off = 0;
   if (!soft) return base;
   const size_t cands = rn_align_up((size_t)(max_cands < RN_SORT_CAP ? max_cands : RN_SORT_CAP), 64);
@@ -813,14 +840,13 @@ static int run_nms_stage(const DetectWs& w, int B, long long cap, int K, const B
   p.iou_thr = iou_threshold;
   p.score_thr = score_threshold;
   p.cap = cap;
-  p.pad_ = 0;
-  const size_t lds = nms_lds_bytes(p.soft, top_k > 0 ? (long long)top_k : cap, &p.soft_off);
+  const size_t lds = nms_lds_bytes(p.soft, top_k > 0 ? (long long)top_k : cap, &p.soft_off, &p.chunk_cap);
   RN_CHECK_HIP(hipFuncSetAttribute((const void*)nms_per_class_kernel,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(nms_per_class_kernel, dim3(B * K), dim3(RN_PP_THREADS), lds, st, p, w.counts, w.keys, bs,
                      w.sel_scores, w.sel_boxes, w.sel_idx);
   RN_CHECK_LAUNCH();
-  const size_t lds_m = (size_t)RN_MAX_DET * 8 + 1024 + 8 + 16;
+  const size_t lds_m = (size_t)RN_MAX_DET * 8 + 1024 + 8 + 32;
   hipLaunchKernelGGL(merge_kernel, dim3(B), dim3(RN_PP_THREADS), lds_m, st, K, max_det, w.sel_scores,
                      w.sel_boxes, w.sel_idx, (float4*)det_boxes, det_scores, det_classes, det_index, valid);
   RN_CHECK_LAUNCH();
@@ -927,7 +953,7 @@ extern "C" int rn_topk_per_class(const float* scores, int B, int64_t A, int K, i
                      scores, B, (long long)A, K, 0.0f, 0, counts, keys, (long long)A);
   RN_CHECK_LAUNCH();
   const int k_out = top_k < A ? top_k : (int)A;
-  const size_t lds = rn_align_up((size_t)RN_SORT_CAP * 8 + 1024 + 8 + 16, 16);
+  const size_t lds = rn_align_up((size_t)RN_SORT_CAP * 8 + 1024 + 8 + 32, 16);
   RN_CHECK_HIP(hipFuncSetAttribute((const void*)topk_emit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds));
   hipLaunchKernelGGL(topk_emit_kernel, dim3(B * K), dim3(RN_PP_THREADS), lds, st, K, k_out, counts, keys,
