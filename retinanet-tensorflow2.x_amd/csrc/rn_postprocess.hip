@@ -460,6 +460,7 @@ struct NmsParams {
   long long cap;
   int soft_off;         // soft: byte offset of the soft-NMS state in LDS (the sort buffer's unused tail, or behind everything)
   int chunk_cap;        // keys the LDS sort buffer holds: RN_SORT_CAP for soft NMS (the whole list is one chunk), RN_HARD_CHUNK else
+  int part_off, pad_;   // hard: byte offset of the four waves' partial results (32 + 512 B)
 };
 
 __global__ void __launch_bounds__(RN_PP_THREADS)
@@ -509,35 +510,48 @@ nms_per_class_kernel(NmsParams p, const int* __restrict__ counts, const unsigned
         next_chunk_sorted(kload, n, n - processed, take, upper, skeys, s_hist, s_prefix, s_misc);
     const int m = take;
 
-    if (wave == 0) {
+    if (!p.soft) {
+      // ---- greedy hard NMS, 64 candidates per step, all four waves ---------------------------------
+      // Every wave holds the group (one candidate per lane).  The two quadratic parts are split four ways — wave w tests
+      // its candidates against the selected boxes w, w + 4, ... and against the group's lanes 16w .. 16w + 15 — and meet in
+      // LDS; wave 0 then runs the sequential selection.  (Measured: batch-8 inference 3.76 -> 3.74 ms.  Tried beside it and
+      // dropped: wave-aggregated histogram updates in the radix select — the high-byte passes put every key of a list into
+      // one bin — 3.76 -> 3.90 ms: the ballots in the loop keep the key loads from overlapping.)
+      unsigned long long* s_av = (unsigned long long*)(smem + p.part_off);       // [4] alive lanes per wave
+      unsigned short* s_pm = (unsigned short*)(smem + p.part_off + 32);         // [4][64] 16 mask bits per wave and lane
+      float4* s_gbox = (float4*)s_hist;                                         // [64] the group's boxes (histogram idle here)
       int nsel = s_misc[2];
-      if (!p.soft) {
-        // ---- greedy hard NMS, 64 candidates per step --------------------------------------
-        for (int base = 0; base < m && nsel < p.max_det; base += 64) {
-          const int i = base + lane;
-          const bool valid = i < m;
-          const unsigned long long key = valid ? skeys[i] : 0ull;
-          const float score = key_score(key);
-          const unsigned int idx = key_index(key);
-          float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (valid) box = fetch_clipped(bs, b, c, idx);
-          bool alive = valid;
-          for (int j = 0; j < nsel; ++j) {
-            const float4 sb = s_selbox[j];
-            if (alive && nms_iou(box, sb) > p.iou_thr) alive = false;
-          }
-          // earlier lanes of this group that suppress me.  The group's 64 boxes go through LDS (the histogram of the
-          // sort, idle here): 63 independent broadcast reads per lane pipeline, where a shuffle of lane j's box is four
-          // ds_bpermute round trips per step (hard NMS at batch 8: 260 -> 180 us)
-          float4* s_gbox = (float4*)s_hist;
-          s_gbox[lane] = box;
-          __builtin_amdgcn_s_waitcnt(0xc07f);
-          unsigned long long mask = 0ull;
-          for (int j = 0; j < 63; ++j) {
-            const float4 ob = s_gbox[j];
-            if (j < lane && nms_iou(box, ob) > p.iou_thr) mask |= 1ull << j;
-          }
-          unsigned long long alive_mask = __ballot(alive);
+      for (int base = 0; base < m && nsel < p.max_det; base += 64) {
+        const int i = base + lane;
+        const bool valid = i < m;
+        const unsigned long long key = valid ? skeys[i] : 0ull;
+        const float score = key_score(key);
+        const unsigned int idx = key_index(key);
+        float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) box = fetch_clipped(bs, b, c, idx);
+        bool alive = valid;
+        for (int j = wave; j < nsel; j += 4) {
+          const float4 sb = s_selbox[j];
+          if (alive && nms_iou(box, sb) > p.iou_thr) alive = false;
+        }
+        // earlier lanes of the group that suppress me: the wave's 16 lanes of the group go through its own slice of LDS
+        // (independent broadcast reads pipeline; a shuffle of lane j's box is four ds_bpermute round trips per step)
+        if ((lane >> 4) == wave) s_gbox[lane] = box;
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        unsigned int part = 0u;
+        for (int q = 0; q < 16; ++q) {
+          const int j = wave * 16 + q;
+          const float4 ob = s_gbox[j];
+          if (j < lane && nms_iou(box, ob) > p.iou_thr) part |= 1u << q;
+        }
+        const unsigned long long av = __ballot(alive);
+        if (lane == 0) s_av[wave] = av;
+        s_pm[wave * 64 + lane] = (unsigned short)part;
+        __syncthreads();
+        if (wave == 0) {
+          unsigned long long alive_mask = s_av[0] & s_av[1] & s_av[2] & s_av[3];
+          const unsigned long long mask = (unsigned long long)s_pm[lane] | ((unsigned long long)s_pm[64 + lane] << 16) |
+                                          ((unsigned long long)s_pm[128 + lane] << 32) | ((unsigned long long)s_pm[192 + lane] << 48);
           for (int j = 0; j < 64; ++j) {
             if (!((alive_mask >> j) & 1ull)) continue;
             if (nsel >= p.max_det) break;
@@ -550,9 +564,14 @@ nms_per_class_kernel(NmsParams p, const int* __restrict__ counts, const unsigned
             const unsigned long long kill = __ballot((mask >> j) & 1ull);
             alive_mask &= ~kill;
           }
-          __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): selected boxes visible to the wave
+          if (lane == 0) s_misc[2] = nsel;
         }
-      } else {
+        __syncthreads();
+        nsel = s_misc[2];
+      }
+    } else if (wave == 0) {
+      int nsel = s_misc[2];
+      {
         // ---- soft NMS: exact emulation of NonMaxSuppressionV5's priority queue ------------
         // The queue is the sorted chunk itself: candidate i keeps its position, its CURRENT score replaces the score half
         // of its key (-1: popped for good, or fell to the threshold).  Per block j of 64 candidates: s_blk[j] = (the
@@ -773,11 +792,12 @@ extern "C" int rn_rowmax_argmax(const float* scores, int64_t rows, int K, float*
 // RN_HARD_CHUNK at a time): 4 096 keys = 39 KB of LDS = four lists per compute unit, where RN_SORT_CAP keys (73 KB) allowed two:
 // the 640 lists of a batch of 8 run in one round instead of two.
 #define RN_HARD_CHUNK 4096
-static size_t nms_lds_bytes(int soft, long long max_cands, int* soft_off, int* chunk_cap) {
+static size_t nms_lds_bytes(int soft, long long max_cands, int* soft_off, int* chunk_cap, int* part_off) {
   *chunk_cap = soft ? RN_SORT_CAP : RN_HARD_CHUNK;
   const size_t base = rn_align_up((size_t)*chunk_cap * 8 + (size_t)RN_MAX_DET * 16 + (size_t)RN_MAX_DET * 8 + 1024 + 8 + 32, 16);
   *soft_off = 0;
-  if (!soft) return base;
+  *part_off = (int)base;
+  if (!soft) return base + 32 + 512;   // (4 x 40 520 B: four lists still fit the 160 KB of a CU)
   const size_t cands = rn_align_up((size_t)(max_cands < RN_SORT_CAP ? max_cands : RN_SORT_CAP), 64);
   const size_t state = rn_align_up(2048 + (size_t)RN_SORT_CAP / 64 * 8 + 16 + cands, 16);
   if (cands * 8 + state <= (size_t)RN_SORT_CAP * 8) {
@@ -840,7 +860,8 @@ static int run_nms_stage(const DetectWs& w, int B, long long cap, int K, const B
   p.iou_thr = iou_threshold;
   p.score_thr = score_threshold;
   p.cap = cap;
-  const size_t lds = nms_lds_bytes(p.soft, top_k > 0 ? (long long)top_k : cap, &p.soft_off, &p.chunk_cap);
+  p.pad_ = 0;
+  const size_t lds = nms_lds_bytes(p.soft, top_k > 0 ? (long long)top_k : cap, &p.soft_off, &p.chunk_cap, &p.part_off);
   RN_CHECK_HIP(hipFuncSetAttribute((const void*)nms_per_class_kernel,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(nms_per_class_kernel, dim3(B * K), dim3(RN_PP_THREADS), lds, st, p, w.counts, w.keys, bs,
