@@ -350,6 +350,7 @@ __device__ unsigned long long radix_select_desc(Loader keys, int n, unsigned lon
   if (threadIdx.x == 0) {
     *s_prefix = 0ull;
     *s_k = kth;
+    s_k[3] = 0;   // (s_misc[3]) set when the selected bin is taken whole: the remaining digits do not matter
   }
   unsigned long long mask = 0ull;
   for (int shift = 56; shift >= 0; shift -= 8) {
@@ -382,10 +383,14 @@ __device__ unsigned long long radix_select_desc(Loader keys, int n, unsigned lon
       if (above < kk && (d == 0 || kk <= above + h)) {
         *s_k = kk - above;
         *s_prefix = prefix | (((unsigned long long)d) << shift);
+        // every key of this bin is among the kk largest: prefix (lower digits zero) is already the bound.  With distinct
+        // scores that happens after the four or five score digits — the index digits of the 64-bit keys are never walked
+        if (kk - above == h) s_k[3] = 1;
       }
     }
     mask |= 255ull << shift;
     __syncthreads();
+    if (s_k[3]) break;
   }
   return *s_prefix;
 }
