@@ -293,8 +293,12 @@ typedef struct {
    * rn_conv_splitk_workspace_bytes() = what this problem can use on the current device (0: it would not split).
    * Launches that share a workspace must be ordered on one stream.  Word 1023 of the workspace is set to 1 if a part
    * ever gave up waiting (2 s) for its partners: results of that launch are then invalid (never seen; the tests read it).
-   * Measured (round 4): correct, deterministic — and not faster: the 256 KB a part hands over cost what its half tile of
-   * MFMA work saves, so the Python engines attach a workspace only under RNET_SPLITK=1. */
+   * Measured (round 4): for the last round of a BIG launch not faster — the 256 KB a part hands over cost what its half
+   * tile of MFMA work saves — and the dispatcher does not do it (such launches run whole 512 x 128 tiles whenever that form
+   * takes them).  For SMALL launches it pays: a 3x3 / stride 1 layer of fewer tiles than the 256-row kernels normally take
+   * (ResNet stage 4 at batch 8: 26 tiles on 256 CUs) runs here with EVERY tile cut into up to four parts instead of on the
+   * 128-row kernel: 68 -> 48 us.  The Python inference engine attaches a workspace by default, the two-stream training
+   * engine under RNET_SPLITK=1. */
   void* splitk_ws;
   int64_t splitk_ws_bytes;
 } rn_conv_problem;

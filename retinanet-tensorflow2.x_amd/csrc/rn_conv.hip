@@ -454,7 +454,7 @@ static bool conv_use_big(const rn_conv_problem* p) {
     long long bytes = 0;
     const int G0 = rn_persistent_grid(0x7fffffff, rn_num_cus(), p->opts);
     const int S = tiles256 < G0 ? splitk_parts((int)tiles256, conv_min_chunks(p), G0, &bytes) : 1;
-    return S >= 2 && tiles256 * S >= G0 / 2 && bytes <= p->splitk_ws_bytes;
+    return S >= 2 && tiles256 * S >= G0 / 4 && bytes <= p->splitk_ws_bytes;
   }
   return false;
 }
@@ -515,12 +515,19 @@ static bool conv_use_halo512(const rn_conv_problem* p) {
 // count is a multiple of 128 and the longer patches fit: the same number of tiles and MACs per tile, but a K chunk stages
 // ~117 KB instead of ~171 KB per workgroup (one 8 KB weight piece per tap instead of 16 KB; the patch of 512 consecutive
 // pixels has relatively fewer halo rows).  Measured inside the step on one box (round 4): head-tower launches 564 -> 511 us,
-// class prediction 1460 -> 1333, ResNet stage-3 3x3 (200 tiles) 59.8 -> 56.8, batch-8 towers 157 -> 152.  The last-round
-// split (splitk_ws) exists for the 256 x 256 form only and keeps it; conv_tile = 2 keeps it too (tests, A/B).
+// class prediction 1460 -> 1333, ResNet stage-3 3x3 (200 tiles) 59.8 -> 56.8, batch-8 towers 157 -> 152.  conv_tile = 2
+// keeps the 256 x 256 form (tests, A/B), and so do the small launches that only run here because a split-K workspace lets
+// every tile be cut along K.
 static int conv_pick(const rn_conv_problem* p) {
   if (conv_use_big(p)) {
     if (!conv_halo_shape(p, 256)) return 1;
-    if (p->opts.conv_tile == 0 && !p->splitk_ws && p->opts.conv_big_min_tiles == 0) {
+    if (p->opts.conv_tile == 0 && p->opts.conv_big_min_tiles == 0) {
+      // (a launch of fewer tiles than the 256-row kernels normally take got here through its split-K workspace: every
+      // tile cut along K on the 256 x 256 form)
+      long long tiles256 = 0;
+      for (int i = 0; i < p->num_segments; ++i)
+        tiles256 += rn_cdiv((long long)p->seg[i].N * p->seg[i].Ho * p->seg[i].Wo, 256) * rn_cdiv(seg_cols(p->seg[i]), 256);
+      if (tiles256 < 192) return 2;
       rn_conv_problem q = *p;
       q.opts.conv_tile = 3;
       if (conv_use_halo512(&q)) return 3;

@@ -375,16 +375,21 @@ def current_stream():
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def new_splitk_workspace(lib_, device):
+def new_splitk_workspace(lib_, device, default_on=False):
     """The zero-filled split-K workspace (rn_conv_problem.splitk_ws) of ONE engine: its conv launches are ordered on one
     stream, so they share it.  Attach it to every rn_conv_problem when the problem is created — the dispatcher looks at
     it (rn_conv_kernel_id / rn_conv_tile_rows).
-    OFF unless RNET_SPLITK=1: measured on MI355X (round 4) the split last round does not pay — a part
-    hands its tile over as 256 KB of fp32 accumulators, and writing + reading them back costs as much as the half tile of
-    MFMA work it saves (head towers at B = 32: 556 - 565 us against 540 - 550 us with whole tiles; batch-8 inference:
-    171 against 166 us).  The capability stays built and tested (tests/test_gpu_conv.py, tests/test_gpu_bench_shapes.py)."""
+    What it buys, measured on MI355X (round 4): the LAST ROUND of a big launch split along K does not
+    pay — a part hands its tile over as 256 KB of fp32 accumulators, which costs what the half tile of MFMA work saves — and
+    the dispatcher no longer does it (big 3x3 launches run 512 x 128 tiles, whole).  SMALL launches do gain: a 3x3 layer
+    of fewer tiles than the 256-row kernels normally take (ResNet stage 4 at batch 8: 26 tiles on 256 CUs) runs on the halo
+    kernel with every tile cut into up to four parts instead of on the 128-row kernel: 68 -> 48 us, batch-8 inference
+    3.74 -> 3.69 ms.  The inference engine therefore attaches one by default; the training engine (two streams: a part
+    that polls for its partner holds a CU the other stream may be waiting for) only under RNET_SPLITK=1, where it
+    measured 30.60 -> 30.57 ms.  RNET_SPLITK=0 / 1 overrides either default."""
     import torch
-    if os.environ.get("RNET_SPLITK", "0") != "1":
+    on = os.environ.get("RNET_SPLITK", "1" if default_on else "0") == "1"
+    if not on:
         return None
     return torch.zeros((int(lib_.rn_conv_splitk_workspace_max_bytes()),), dtype=torch.uint8, device=device)
 

@@ -86,7 +86,7 @@ class InferenceEngine:
             self._alloc()
             self.load_variables(variables)
             # split-K of the persistent conv kernels' last round: the launches of this engine run in order on one stream
-            self.splitk_ws = _C.new_splitk_workspace(self.lib, self.dev)
+            self.splitk_ws = _C.new_splitk_workspace(self.lib, self.dev, default_on=True)
             self._build()
 
     # ---- buffers ---------------------------------------------------------------------------
