@@ -32,6 +32,7 @@
 #include <mutex>
 #include <tuple>
 
+#include <algorithm>
 #include "rn_conv_dev.h"
 
 // ABL: ablation mask for tools/bench_conv.py (0 in production): 1 = B tile loaded once,
@@ -624,7 +625,32 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
   }
   const int BNT = big ? 256 : BN;   // n-tile width
   int tiles = 0;
-  for (int i = 0; i < p->num_segments; ++i) {
+  // conv_big_kernel launch whose segments are all one column tile wide but differ 2x or more in K depth (the FPN lateral 1x1
+  // convs: 512 / 1024 / 2048 input channels): tiles numbered deepest segment first and dealt to the workgroups round-robin
+  // (identity numbering) instead of in the XCD-contiguous ranges that keep neighbouring column tiles on one L2 — there are
+  // no neighbouring column tiles here, and a contiguous range hands one XCD all of the 64-step tiles (181 K steps per CU
+  // there against 87 on average).  The order is internal to the launch: every tile's result is what it was.
+  int order[RN_CONV_MAX_SEGMENTS];
+  for (int i = 0; i < p->num_segments; ++i) order[i] = i;
+  bool deal = false;
+  if (kid == 1 && p->num_segments > 1) {
+    long long dmin = 1ll << 60, dmax = 0;
+    bool one_col = true;
+    for (int i = 0; i < p->num_segments; ++i) {
+      const long long depth = (long long)p->R * p->S * rn_conv_cin_pad(p->seg[i].Cin) * (p->seg[i].w_terms > 1 ? p->seg[i].w_terms : 1);
+      dmin = depth < dmin ? depth : dmin;
+      dmax = depth > dmax ? depth : dmax;
+      one_col = one_col && rn_conv_cout_pad(seg_cols(p->seg[i])) <= 256;
+    }
+    deal = one_col && dmax >= 2 * dmin;
+    if (deal)
+      std::stable_sort(order, order + p->num_segments, [&](int x, int y) {
+        return rn_conv_cin_pad(p->seg[x].Cin) * (p->seg[x].w_terms > 1 ? p->seg[x].w_terms : 1) >
+               rn_conv_cin_pad(p->seg[y].Cin) * (p->seg[y].w_terms > 1 ? p->seg[y].w_terms : 1);
+      });
+  }
+  for (int ii = 0; ii < p->num_segments; ++ii) {
+    const int i = order[ii];
     const rn_conv_segment& s = p->seg[i];
     RN_CHECK_ARG(s.x && s.w && s.y, "rn_conv2d_nhwc_fwd: segment %d has a null tensor", i);
     RN_CHECK_ARG(s.N > 0 && s.H > 0 && s.W > 0 && s.Ho > 0 && s.Wo > 0 && s.Cout > 0 && s.Cin > 0,
@@ -646,7 +672,7 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
     RN_CHECK_ARG(M < (1ll << 31) && (long long)s.N * s.H * s.W * s.pix_stride * 2 < (1ll << 31),
                  "rn_conv2d_nhwc_fwd: segment %d input exceeds the 2 GiB buffer-addressing limit", i);
     // the last input row/col a valid tap may touch must be inside the image
-    ConvSegDev& d = a.seg[i];
+    ConvSegDev& d = a.seg[ii];
     d.x = (const uint16_t*)s.x; d.w = (const uint16_t*)s.w; d.y = s.y;
     d.scale = s.scale; d.shift = s.shift; d.residual = (const uint16_t*)s.residual;
     d.bn_partial = s.bn_partial;
@@ -703,9 +729,10 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
     return rn_launch_conv_halo(a, f32, p->opts, st);
   }
   if (big) {
-    a.pad_ = 1;   // float-reciprocal index arithmetic in the tile set-up, valid while every M < 2^22
+    a.pad_ = 1;   // bit 0: float-reciprocal index arithmetic in the tile set-up, valid while every M < 2^22
     for (int i = 0; i < a.nseg; ++i)
       if (a.seg[i].M >= (1 << 22)) a.pad_ = 0;
+    if (deal) a.pad_ |= 2;   // bit 1: tiles dealt round-robin (see above)
     return rn_launch_conv_big(a, f32, p->opts, st);
   }
   if (BN == 128 && BK == 64) return f32 ? launch_conv<128, 128, 64, true>(a, st) : launch_conv<128, 128, 64, false>(a, st);

@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(512) conv_big_kernel(const ConvArgs args) {
 
 #define BIG_SETUP_ISSUE()                                                                             \
   do {                                                                                                \
-    const int tile__ = tile_of(i_v, total);                                                           \
+    const int tile__ = (args.pad_ & 2) ? i_v : tile_of(i_v, total); /* bit 1: dealt round-robin */     \
     int si__ = 0;                                                                                     \
     _Pragma("unroll 1") for (int i = 1; i < args.nseg; ++i)                                           \
       if (tile__ >= args.seg[i].tile_begin) si__ = i;                                                 \
@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(512) conv_big_kernel(const ConvArgs args) {
       const int m = m0__ + row;                                                                       \
       const int mm = m < sg__.M ? m : 0;                                                              \
       int ox, oy, n;                                                                                  \
-      if (args.pad_) {   /* every M < 2^22: float-reciprocal division (~8 VALU instead of ~45 each) */ \
+      if (args.pad_ & 1) {   /* every M < 2^22: float-reciprocal division (~8 VALU instead of ~45 each) */ \
         const int t2 = rn_fdiv(mm, sg__.Wo, rWo__);                                                   \
         ox = mm - t2 * sg__.Wo;                                                                       \
         n = rn_fdiv(t2, sg__.Ho, rHo__);                                                              \
@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(512) conv_big_kernel(const ConvArgs args) {
   int c_ksteps, c_m0, c_n0, c_si;
 #define BIG_SETUP_COMPUTE()                                                                           \
   do {                                                                                                \
-    const int tile__ = tile_of(c_v, total);                                                           \
+    const int tile__ = (args.pad_ & 2) ? c_v : tile_of(c_v, total);                                   \
     c_si = 0;                                                                                         \
     _Pragma("unroll 1") for (int i = 1; i < args.nseg; ++i)                                           \
       if (tile__ >= args.seg[i].tile_begin) c_si = i;                                                 \
