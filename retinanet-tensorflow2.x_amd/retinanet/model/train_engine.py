@@ -623,11 +623,9 @@ class TrainEngine:
                                    self.launch_opts) > 0
 
     def _group_ops(self, kind, grp):
-        """The ops of one grouped launch, in graph order.  (Round 4 measured "longest K first" for the one group that mixes K
-        depths, the FPN lateral 1x1 convs with 512 / 1024 / 2048 input channels: 229 -> 295 us.  The persistent kernels give
-        every XCD a CONTIGUOUS range of tiles, so whichever segment order is chosen one XCD holds all 50 of the 64-step tiles;
-        first in the list they also all start at once.  Balancing that launch needs a tile numbering that deals the segments
-        round-robin over the XCDs, not another order.)"""
+        """The ops of one grouped launch, in graph order.  (The one group that mixes K depths — the FPN lateral 1x1 convs with
+        512 / 1024 / 2048 input channels — is balanced inside rn_conv2d_nhwc_fwd: tiles numbered deepest segment first and
+        dealt to the workgroups round-robin; sorting the list here alone made that launch slower)"""
         return [o for o in self.ops if o["op"] == kind and o.get("group") == grp]
 
     def _conv_problem(self, ops, dst_of, raw_mode):
