@@ -69,7 +69,8 @@ __device__ __forceinline__ void focal_elem(float x, bool pos, float alpha, float
   const float omp = x >= 0.0f ? t * inv : inv;      // 1 - sigmoid(x)
   const float q = pos ? omp : p;
   const float a_t = pos ? alpha : 1.0f - alpha;
-  const float mod = q > 0.0f ? hw_exp2(gamma * hw_log2(q)) : 0.0f;  // q^gamma
+  // q^gamma: every shipped config has gamma = 1.5 -> q * sqrt(q), one transcendental instead of log2 + exp2
+  const float mod = gamma == 1.5f ? q * __builtin_amdgcn_sqrtf(q) : (q > 0.0f ? hw_exp2(gamma * hw_log2(q)) : 0.0f);
   loss = a_t * mod * ce;
   const float dmod = pos ? -gamma * p * mod : gamma * omp * mod;
   grad = a_t * (mod * (p - ys) + ce * dmod);
