@@ -899,8 +899,12 @@ struct BalBwd {
 
 // d_avg = sum over levels of R_l^T(dout_l): finer levels sum their children, coarser levels
 // route to the first maximum of avg inside the pooling window.
+// MID_ / L_ >= 0: compile-time pyramid (the reference's five levels balanced at the third: the window loops unroll and a
+// thread keeps its 16 + 4 + 1 loads in flight; with run-time trip counts they went out one at a time: 0.18 -> 0.07 ms)
+template <int MID_, int L_>
 __global__ void __launch_bounds__(TR_THREADS) balance_bwd_avg_kernel(BalBwd b) {
-  const int Hm = b.H0 >> b.mid, Wm = b.W0 >> b.mid;
+  const int mid = MID_ >= 0 ? MID_ : b.mid, L = L_ >= 0 ? L_ : b.L;
+  const int Hm = b.H0 >> mid, Wm = b.W0 >> mid;
   const long long total = (long long)b.N * Hm * Wm * b.C8;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
@@ -913,11 +917,14 @@ __global__ void __launch_bounds__(TR_THREADS) balance_bwd_avg_kernel(BalBwd b) {
     bf8 acc;
 #pragma unroll
     for (int q = 0; q < 8; ++q) acc.v[q] = 0.0f;
-    for (int l = 0; l < b.L; ++l) {
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
       const int Hl = b.H0 >> l, Wl = b.W0 >> l;
-      if (l <= b.mid) {
-        const int f = 1 << (b.mid - l);
+      if (l <= mid) {
+        const int f = 1 << (mid - l);
+#pragma unroll
         for (int dy = 0; dy < f; ++dy)
+#pragma unroll
           for (int dx = 0; dx < f; ++dx) {
             const bf8 v = unpack8(b.dout[l][(((long long)n * Hl) + y * f + dy) * Wl * b.C8 +
                                             (long long)(x * f + dx) * b.C8 + c]);
@@ -925,13 +932,15 @@ __global__ void __launch_bounds__(TR_THREADS) balance_bwd_avg_kernel(BalBwd b) {
             for (int q = 0; q < 8; ++q) acc.v[q] += v.v[q];
           }
       } else {
-        const int f = 1 << (l - b.mid);
+        const int f = 1 << (l - mid);
         const int wy = y / f, wx = x / f;
         float best[8];
         int arg[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) { best[q] = -INFINITY; arg[q] = 0; }
+#pragma unroll
         for (int dy = 0; dy < f; ++dy)
+#pragma unroll
           for (int dx = 0; dx < f; ++dx) {
             const bf8 v = unpack8(b.avg[(((long long)n * Hm) + wy * f + dy) * Wm * b.C8 +
                                         (long long)(wx * f + dx) * b.C8 + c]);
@@ -951,10 +960,12 @@ __global__ void __launch_bounds__(TR_THREADS) balance_bwd_avg_kernel(BalBwd b) {
 }
 
 // din_l = dout_l + S_l^T(d_avg / L)
+template <int MID_, int L_>
 __global__ void __launch_bounds__(TR_THREADS) balance_bwd_in_kernel(BalBwd b) {
-  const int Hm = b.H0 >> b.mid, Wm = b.W0 >> b.mid;
-  const long long total = b.begin[b.L];
-  const float invL = 1.0f / (float)b.L;
+  const int mid = MID_ >= 0 ? MID_ : b.mid, L = L_ >= 0 ? L_ : b.L;
+  const int Hm = b.H0 >> mid, Wm = b.W0 >> mid;
+  const long long total = b.begin[L];
+  const float invL = 1.0f / (float)L;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     int l = 0;
@@ -969,8 +980,8 @@ __global__ void __launch_bounds__(TR_THREADS) balance_bwd_in_kernel(BalBwd b) {
     const int n = (int)(t / Hl);
     const long long o = (((long long)n * Hl) + y) * Wl * b.C8 + (long long)x * b.C8 + c;
     bf8 g = unpack8(b.dout[l][o]);
-    if (l >= b.mid) {
-      const int f = 1 << (l - b.mid);
+    if (l >= mid) {
+      const int f = 1 << (l - mid);
       for (int dy = 0; dy < f; ++dy)
         for (int dx = 0; dx < f; ++dx) {
           const bf8 v = unpack8(b.davg[(((long long)n * Hm) + y * f + dy) * Wm * b.C8 +
@@ -979,7 +990,7 @@ __global__ void __launch_bounds__(TR_THREADS) balance_bwd_in_kernel(BalBwd b) {
           for (int q = 0; q < 8; ++q) g.v[q] += v.v[q] * invL;
         }
     } else {
-      const int f = 1 << (b.mid - l);
+      const int f = 1 << (mid - l);
       const int wy = y / f, wx = x / f;
       float best[8];
       int arg[8];
@@ -1024,10 +1035,16 @@ extern "C" int rn_balance_features_bwd(void* const* dout, void* const* in, void*
     b.begin[l + 1] = b.begin[l] + (long long)N * (H0 >> l) * (W0 >> l) * (C / 8);
   }
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(balance_bwd_avg_kernel, dim3(tr_blocks((long long)N * (H0 >> mid) * (W0 >> mid) * (C / 8))),
-                     dim3(TR_THREADS), 0, st, b);
-  RN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(balance_bwd_in_kernel, dim3(tr_blocks(b.begin[num_levels])), dim3(TR_THREADS), 0, st, b);
+  const dim3 g_avg(tr_blocks((long long)N * (H0 >> mid) * (W0 >> mid) * (C / 8))), g_in(tr_blocks(b.begin[num_levels]));
+  if (num_levels == 5 && mid == 2) {   // P3..P7 balanced at P5 (balance_features.py: the reference's only configuration)
+    hipLaunchKernelGGL((balance_bwd_avg_kernel<2, 5>), g_avg, dim3(TR_THREADS), 0, st, b);
+    RN_CHECK_LAUNCH();
+    hipLaunchKernelGGL((balance_bwd_in_kernel<2, 5>), g_in, dim3(TR_THREADS), 0, st, b);
+  } else {
+    hipLaunchKernelGGL((balance_bwd_avg_kernel<-1, -1>), g_avg, dim3(TR_THREADS), 0, st, b);
+    RN_CHECK_LAUNCH();
+    hipLaunchKernelGGL((balance_bwd_in_kernel<-1, -1>), g_in, dim3(TR_THREADS), 0, st, b);
+  }
   RN_CHECK_LAUNCH();
   return RN_OK;
 }
