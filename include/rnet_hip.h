@@ -192,6 +192,10 @@ typedef struct {
                                 * pixel count (tests at small sizes) | 3: as 2 but never wgrad_halo_kernel (A/B timing) */
   int32_t wgrad_target_blocks; /* > 0: workgroups a weight-gradient launch aims for (split-K plan; A/B timing) */
   int32_t ablate;              /* tools/bench_conv.py: ablated variants of conv_fwd_kernel<128,128,64> — timing only */
+  int32_t splitk_target_blocks; /* > 0: workgroups a split-K launch of the 128-row conv kernel aims for (default: one per
+                                * compute unit; rn_conv_problem.splitk_ws; A/B timing) */
+  int32_t conv_stream;         /* 0: auto | 1: never the weights-resident streaming kernel for 1x1 layers (conv_stream_kernel)
+                                * | 2: that kernel wherever the shape allows (tests at small sizes, A/B timing) */
 } rn_launch_opts;
 
 /* Opaque per-device context: device id, compute-unit count, the default rn_launch_opts of the engine that owns it and
@@ -283,16 +287,17 @@ typedef struct {
   rn_conv_segment seg[RN_CONV_MAX_SEGMENTS];
   rn_launch_opts opts;
   /* optional split-K workspace (device memory, 16-byte aligned, ZERO-FILLED once by the caller; the kernels leave its
-   * first 4 KB — arrival counters and a status word — zero again after every launch).  The persistent 256-row kernels
+   * first 16 KB — the arrival counters — zero again after every launch).  The persistent 256-row kernels
    * walk their tiles in rounds of one tile per compute unit; the last round of a launch whose tile count is not a
    * multiple of the grid leaves most of the chip idle for a whole tile (8.3 rounds run as 9; a 100-tile launch uses 100
    * of 256 CUs).  With a workspace the halo kernel (3x3 / stride 1) runs the full rounds as before and the tiles of the
    * last round in a second launch, each cut along K (input-channel chunks, >= 4 per part, <= 4 parts) over several
-   * workgroups: every part writes its fp32 accumulators here, part 0 adds them IN PART ORDER (deterministic: the same bits
-   * on every run) and runs the normal epilogue.  NULL / too small: whole tiles only (the round-3 behaviour).
+   * workgroups: every part writes its fp32 accumulators here and counts itself in; the part that arrives LAST adds them
+   * IN PART ORDER (deterministic: the same bits on every run, whoever arrives last) and runs the normal epilogue.  Nobody
+   * waits for a partner: no spin, no timeout.  The 128-row kernel splits the same way (rn_conv.hip: small launches of
+   * deep layers, every tile cut along K).  NULL / too small: whole tiles only.
    * rn_conv_splitk_workspace_bytes() = what this problem can use on the current device (0: it would not split).
-   * Launches that share a workspace must be ordered on one stream.  Word 1023 of the workspace is set to 1 if a part
-   * ever gave up waiting (2 s) for its partners: results of that launch are then invalid (never seen; the tests read it).
+   * Launches that share a workspace must be ordered on one stream.
    * Measured (round 4): for the last round of a BIG launch not faster — the 256 KB a part hands over cost what its half
    * tile of MFMA work saves — and the dispatcher does not do it (such launches run whole 512 x 128 tiles whenever that form
    * takes them).  For SMALL launches it pays: a 3x3 / stride 1 layer of fewer tiles than the 256-row kernels normally take
@@ -305,7 +310,7 @@ typedef struct {
 
 int rn_conv2d_nhwc_fwd(const rn_conv_problem* problem /* host */, void* stream);
 size_t rn_conv_splitk_workspace_bytes(const rn_conv_problem* problem /* host */);
-/* enough for any problem on any device (64 MB + 4 KB).  The dispatcher also looks at splitk_ws: a 3x3 / stride 1 launch
+/* enough for any problem on any device (64 MB + 16 KB).  The dispatcher also looks at splitk_ws: a 3x3 / stride 1 launch
  * of fewer 256-row tiles than compute units (ResNet stage 3 / 4 at batch 8) goes to the halo kernel, every tile split,
  * only when a workspace is attached — set it BEFORE asking rn_conv_kernel_id / rn_conv_tile_rows. */
 size_t rn_conv_splitk_workspace_max_bytes(void);

@@ -14,8 +14,12 @@ int rn_num_cus();
 // index of the current device, 0..63 (rn_core.hip).  Kernel function attributes (hipFuncSetAttribute) are PER DEVICE: a
 // process-wide `static bool attr_set` left the second GPU of a process without its dynamic-LDS limit.
 int rn_device_slot();
-// true the first time it is evaluated for the current device with this flag word (benign race: setting twice is harmless)
-#define RN_FIRST_ON_DEVICE(mask_) (!(((mask_) >> rn_device_slot()) & 1ull) && (((mask_) |= 1ull << rn_device_slot()), true))
+// Per-device "kernel attributes are set" flag words.  RN_ATTRS_NEEDED: the bit of the current device is still clear;
+// RN_ATTRS_DONE marks it (atomically) AFTER every hipFuncSetAttribute call succeeded — a failed call returns early through
+// RN_CHECK_HIP and leaves the bit clear, so the next launch retries instead of failing with an opaque launch error, and a
+// second host thread that gets here before the first one is done sets the (idempotent) attributes itself.
+#define RN_ATTRS_NEEDED(mask_) (!((__atomic_load_n(&(mask_), __ATOMIC_ACQUIRE) >> rn_device_slot()) & 1ull))
+#define RN_ATTRS_DONE(mask_) ((void)__atomic_fetch_or(&(mask_), 1ull << rn_device_slot(), __ATOMIC_RELEASE))
 int rn_validate_launch_opts(const rn_launch_opts& opts, const char* who);
 
 #define RN_CHECK_ARG(cond, ...)  \

@@ -39,7 +39,14 @@
 // 2 = A tile loaded once, 4 = no MFMA.
 // WM x WN wavefronts (64 x (BN/WN) wave tiles), two LDS stages: 128 x {128,64} x {64,32}, 2x2 waves
 // (64 KB LDS, 2 workgroups/CU) for the narrow / small launches; the wide layers go to rn_conv_big.hip.
-template <int BM, int BN, int BK, bool OUT_F32, int ABL = 0, int WM = 2, int WN = 2, int STAGES = 2>
+// SPLIT (rnet_hip.h: rn_conv_problem.splitk_ws; small launches of deep layers — batch-1 / batch-8 inference): every tile is
+// cut along K into args.split_s parts, one workgroup each (grid = total_tiles * split_s, the parts of a tile neighbours in
+// the XCD-aware numbering).  A part writes its raw fp32 accumulators — in the [BM][BN] row layout the epilogue's second
+// stage reads — to its slot of the workspace with write-through (sc1) stores, drains them, and counts itself in on the
+// tile's counter with a returning agent-scope atomic; the part that arrives LAST (whichever it is: nobody waits) reads
+// all slots back with sc1 loads, adds them IN PART ORDER (the same bits on every run), zeroes the counter and runs the
+// epilogue arithmetic (bias, rounding points, BatchNorm affine, residual, activation) on the sums.
+template <int BM, int BN, int BK, bool OUT_F32, int ABL = 0, int WM = 2, int WN = 2, int STAGES = 2, bool SPLIT = false>
 __global__ void __launch_bounds__(64 * WM * WN, 2) conv_fwd_kernel(const ConvArgs args) {
   constexpr int NWAVES = WM * WN;
   constexpr int NTHREADS = 64 * NWAVES;
@@ -57,13 +64,18 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_fwd_kernel(const ConvArg
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   // ---- tile lookup (XCD-aware remap of the linear block id) ---------------------------------
-  int tile;
+  int tile, part = 0;
   {
-    const int total = args.total_tiles;
+    const int total = SPLIT ? args.vtotal : args.total_tiles;   // work units: tiles, or (tile, part) pairs
     const int bid = blockIdx.x;
     const int xcd = bid & 7, slot = bid >> 3;
     const int q = total >> 3, r = total & 7;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    if (SPLIT) {
+      const int v = tile;
+      tile = v / args.split_s;
+      part = v - tile * args.split_s;
+    }
   }
   int si = 0;
 #pragma unroll 1
@@ -146,7 +158,10 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_fwd_kernel(const ConvArg
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  const int ksteps = R * S * (Cin / BK);
+  const int ksteps_all = R * S * (Cin / BK);
+  // K steps [kbeg, ksteps) of this workgroup: all of them, or the part's share
+  const int kbeg = SPLIT ? (int)((long long)part * ksteps_all / args.split_s) : 0;
+  const int ksteps = SPLIT ? (int)((long long)(part + 1) * ksteps_all / args.split_s) : ksteps_all;
 
 #define RN_ISSUE_TILE(buf, tap_, c0_)                                                         \
   do {                                                                                        \
@@ -168,6 +183,11 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_fwd_kernel(const ConvArg
   } while (0)
 
   int tap = 0, c0 = 0;   // coordinates of the NEXT tile to issue
+  if (SPLIT) {
+    const int cpk = Cin / BK;
+    tap = kbeg / cpk;
+    c0 = (kbeg - tap * cpk) * BK;
+  }
 #define RN_ADVANCE()  \
   do {                \
     c0 += BK;         \
@@ -180,13 +200,13 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_fwd_kernel(const ConvArg
   if (ABL & 32) {
     // ablation: no main loop at all (launch + prologue + epilogue cost)
   } else if (STAGES == 2) {
-    RN_ISSUE_TILE(0, 0, 0);
+    RN_ISSUE_TILE(0, tap, c0);
     RN_ADVANCE();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cur = 0;
 #pragma unroll 1
-    for (int kt = 0; kt < ksteps; ++kt) {
+    for (int kt = kbeg; kt < ksteps; ++kt) {
       if (kt + 1 < ksteps) {
         RN_ISSUE_TILE(cur ^ 1, tap, c0);
         RN_ADVANCE();
@@ -265,16 +285,16 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_fwd_kernel(const ConvArg
     for (int i = 0; i < TM; ++i) {
       float t[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) t[r] = acc[i][j][r] + bs;
-      if (round1) {   // uniform branches per stage, not per element
+      for (int r = 0; r < 16; ++r) t[r] = SPLIT ? acc[i][j][r] : acc[i][j][r] + bs;   // SPLIT: raw partial sums
+      if (!SPLIT && round1) {   // uniform branches per stage, not per element
 #pragma unroll
         for (int r = 0; r < 16; ++r) t[r] = rn_rb(t[r]);
       }
-      if (affine) {
+      if (!SPLIT && affine) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) t[r] = t[r] * sc + sf;
       }
-      if (round2) {
+      if (!SPLIT && round2) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) t[r] = rn_rb(t[r]);
       }
@@ -291,6 +311,41 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_fwd_kernel(const ConvArg
   constexpr int ROWS = NTHREADS / TPR;        // rows per pass
   const int er = tid / TPR, ec = (tid % TPR) * 4;
   const int n = n0 + ec;
+  // ---- SPLIT: partial tile -> workspace, count in; only the last part to arrive carries on (see the kernel's header) ----
+  typedef unsigned cf_u32x4_t __attribute__((ext_vector_type(4)));
+  constexpr int SLOT_BYTES = BM * BN * 4;
+  __amdgpu_buffer_rsrc_t rs_parts = __builtin_amdgcn_make_buffer_rsrc((void*)sg.y, 0, 0, 0x00020000);   // (set below; unused unless SPLIT)
+  float ssc[4] = {1.f, 1.f, 1.f, 1.f}, ssf[4] = {0.f, 0.f, 0.f, 0.f}, sbs[4] = {0.f, 0.f, 0.f, 0.f};
+  if (SPLIT) {
+    const int S_ = args.split_s;
+    char* const slot0 = (char*)args.ws + RN_SPLITK_HEADER_BYTES + (size_t)tile * S_ * SLOT_BYTES;
+    const __amdgpu_buffer_rsrc_t rs_mine =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(slot0 + (size_t)part * SLOT_BYTES), 0, SLOT_BYTES, 0x00020000);
+#pragma unroll
+    for (int it = 0; it < E_NIT; ++it) {
+      const int rr = er + it * ROWS;
+      const float4 v = *(const float4*)(cl + rr * BN + ec);
+      const cf_u32x4_t u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+      __builtin_amdgcn_raw_buffer_store_b128(u, rs_mine, (rr * BN + ec) * 4, 0, 16);   // aux 16 = sc1: write-through
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();            // every thread's stores have drained; nobody reads cl any more
+    if (tid == 0) {
+      unsigned* const cnt = (unsigned*)args.ws + tile;
+      const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old == (unsigned)(S_ - 1)) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch
+      *(volatile unsigned*)smem = old;
+    }
+    __syncthreads();
+    if (*(volatile unsigned*)smem != (unsigned)(S_ - 1)) return;
+    __syncthreads();            // (the statistics reduction below reuses smem)
+    rs_parts = __builtin_amdgcn_make_buffer_rsrc((void*)slot0, 0, S_ * SLOT_BYTES, 0x00020000);
+    if (n < sg.Cout) {          // this thread's four channels: the arithmetic stage 1 skipped
+      if (sg.scale) { const float4 a = *(const float4*)(sg.scale + n); ssc[0] = a.x; ssc[1] = a.y; ssc[2] = a.z; ssc[3] = a.w; }
+      if (sg.shift) { const float4 a = *(const float4*)(sg.shift + n); ssf[0] = a.x; ssf[1] = a.y; ssf[2] = a.z; ssf[3] = a.w; }
+      if (sg.bias) { const float4 a = *(const float4*)(sg.bias + n); sbs[0] = a.x; sbs[1] = a.y; sbs[2] = a.z; sbs[3] = a.w; }
+    }
+  }
   // fused BatchNorm forward statistics (rn_conv_segment.bn_partial): sums of the STORED bf16 values of this
   // thread's 4 channels over its rows; reduced over the workgroup's 128 rows below
   const bool stats = !OUT_F32 && sg.bn_partial != nullptr;
@@ -313,7 +368,32 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_fwd_kernel(const ConvArg
       const int rr = er + it * ROWS;
       const int m = m0 + rr;
       if (m >= M) break;
-      float4 v = *(const float4*)(cl + rr * BN + ec);
+      float4 v;
+      if (SPLIT) {
+        // all parts' loads in flight before the first add; parts past split_s lie outside the descriptor and read as
+        // zeros (at most 8 parts: the host's plan)
+        cf_u32x4_t pv[8];
+#pragma unroll
+        for (int p_ = 0; p_ < 8; ++p_)
+          pv[p_] = __builtin_amdgcn_raw_buffer_load_b128(rs_parts, (rr * BN + ec) * 4 + p_ * SLOT_BYTES, 0, 16);   // sc1
+        float f4[4] = {__uint_as_float(pv[0].x), __uint_as_float(pv[0].y), __uint_as_float(pv[0].z), __uint_as_float(pv[0].w)};
+#pragma unroll
+        for (int p_ = 1; p_ < 8; ++p_) {
+          f4[0] += __uint_as_float(pv[p_].x); f4[1] += __uint_as_float(pv[p_].y);
+          f4[2] += __uint_as_float(pv[p_].z); f4[3] += __uint_as_float(pv[p_].w);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float t = f4[q] + sbs[q];
+          if (round1) t = rn_rb(t);
+          if (affine) t = t * ssc[q] + ssf[q];
+          if (round2) t = rn_rb(t);
+          f4[q] = t;
+        }
+        v = make_float4(f4[0], f4[1], f4[2], f4[3]);
+      } else {
+        v = *(const float4*)(cl + rr * BN + ec);
+      }
       const long long o = (long long)m * Cout + n;
       if (sg.residual) {
         const uint2 rv = *(const uint2*)(sg.residual + o);
@@ -383,17 +463,25 @@ extern "C" int rn_conv_cout_pad(int Cout) { return Cout <= 64 ? 64 : (int)rn_ali
 // packed-weight channel count: Cin rounded up to the K step (32 below 64 channels, 64 above)
 extern "C" int rn_conv_cin_pad(int Cin) { return Cin <= 32 ? 32 : (int)rn_align_up((size_t)Cin, 64); }
 
-template <int BM, int BN, int BK, bool F32, int WM = 2, int WN = 2, int STAGES = 2>
+template <int BM, int BN, int BK, bool F32, bool SPLIT = false>
 static int launch_conv(const ConvArgs& a, hipStream_t st) {
   constexpr int stage = (BM + BN) * BK * 2;
   constexpr int epi = BM * BN * 4;
-  constexpr int lds = (STAGES * stage > epi) ? STAGES * stage : epi;
-  auto kern = conv_fwd_kernel<BM, BN, BK, F32, 0, WM, WN, STAGES>;
+  constexpr int lds = (2 * stage > epi) ? 2 * stage : epi;
+  auto kern = conv_fwd_kernel<BM, BN, BK, F32, 0, 2, 2, 2, SPLIT>;
   if (lds > 48 * 1024)
     RN_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  hipLaunchKernelGGL(kern, dim3(a.total_tiles), dim3(64 * WM * WN), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3(SPLIT ? a.vtotal : a.total_tiles), dim3(256), lds, st, a);
   RN_CHECK_LAUNCH();
   return RN_OK;
+}
+// the 128-row kernel by tile shape / output type / split
+template <bool SPLIT>
+static int launch_conv128(const ConvArgs& a, int BN, int BK, bool f32, hipStream_t st) {
+  if (BN == 128 && BK == 64) return f32 ? launch_conv<128, 128, 64, true, SPLIT>(a, st) : launch_conv<128, 128, 64, false, SPLIT>(a, st);
+  if (BN == 64 && BK == 64) return f32 ? launch_conv<128, 64, 64, true, SPLIT>(a, st) : launch_conv<128, 64, 64, false, SPLIT>(a, st);
+  if (BN == 128 && BK == 32) return f32 ? launch_conv<128, 128, 32, true, SPLIT>(a, st) : launch_conv<128, 128, 32, false, SPLIT>(a, st);
+  return f32 ? launch_conv<128, 64, 32, true, SPLIT>(a, st) : launch_conv<128, 64, 32, false, SPLIT>(a, st);
 }
 
 template <int ABL>
@@ -424,7 +512,7 @@ static bool seg_cout_ok(const rn_conv_problem* p, const rn_conv_segment& s) {
 static int splitk_parts(int total, int min_chunks, int G0, long long* bytes) {
   const int L = total % G0;
   if (bytes) *bytes = 0;
-  if (L == 0 || L > 1023 || min_chunks < 8) return 1;
+  if (L == 0 || L > 511 || min_chunks < 8) return 1;   // 8 arrival counters per leftover tile in a 4096-word header
   // every part costs its tile one more 256 KB slot to write and part 0 one more to read (~4 us each): at least 4 chunks
   // (36 K steps, ~20 us) per part, at most 4 parts
   int S = G0 / L;
@@ -538,6 +626,45 @@ static int conv_pick(const rn_conv_problem* p) {
   return conv_use_halo512(p) ? 3 : 0;
 }
 
+// Tile shape the 128-row kernel runs a problem with: BN = 64 for Cout <= 64 and for small launches (see
+// rn_conv2d_nhwc_fwd), BK = 64 unless the padded channel count is not a multiple of 64; returns the tile count.
+static int conv128_shape(const rn_conv_problem* p, int* BN_out, int* BK_out) {
+  int BN = rn_conv_cout_pad(seg_cols(p->seg[0])) <= 64 ? 64 : 128;
+  const int BK = rn_conv_cin_pad(p->seg[0].Cin) % 64 == 0 ? 64 : 32;
+  if (BN == 128) {
+    long long t128 = 0;
+    for (int i = 0; i < p->num_segments; ++i)
+      t128 += rn_cdiv((long long)p->seg[i].N * p->seg[i].Ho * p->seg[i].Wo, 128) * rn_cdiv(rn_conv_cout_pad(seg_cols(p->seg[i])), 128);
+    if (2 * t128 <= rn_num_cus() && !p->opts.ablate && p->opts.conv_tile != 1) BN = 64;   // conv_tile = 1 keeps 128 x 128 (tests)
+  }
+  long long tiles = 0;
+  for (int i = 0; i < p->num_segments; ++i)
+    tiles += rn_cdiv((long long)p->seg[i].N * p->seg[i].Ho * p->seg[i].Wo, 128) * rn_cdiv(rn_conv_cout_pad(seg_cols(p->seg[i])), BN);
+  *BN_out = BN; *BK_out = BK;
+  return tiles > 0x7fffffff ? 0x7fffffff : (int)tiles;
+}
+// Parts every tile of a 128-row launch is cut into along K (1: whole tiles).  Enough parts to put about one workgroup on
+// every compute unit (opts.splitk_target_blocks moves the target), at least RN_SPLIT128_MIN_STEPS K steps per part (a
+// part costs a 32 - 64 KB partial tile written and read back and a ~2 us hand-off), at most 8 parts (the last arriver
+// keeps one 16-byte load per part in flight), the slots must fit the workspace and the tiles its 4096 counters.
+#define RN_SPLIT128_MIN_STEPS 4
+static int conv128_split_parts(const rn_conv_problem* p, int tiles, int BN, int BK) {
+  if (!p->splitk_ws || p->opts.ablate || p->opts.conv_tile == 1 || tiles < 1 || tiles > 4096) return 1;
+  int ksteps = 0x7fffffff;   // of the launch's shallowest segment
+  for (int i = 0; i < p->num_segments; ++i) {
+    const int terms = p->seg[i].w_terms > 1 ? p->seg[i].w_terms : 1;
+    const int ks = p->R * p->S * (terms * rn_conv_cin_pad(p->seg[i].Cin) / BK);
+    ksteps = ks < ksteps ? ks : ksteps;
+  }
+  const int target = p->opts.splitk_target_blocks > 0 ? p->opts.splitk_target_blocks : rn_num_cus();
+  int S = target / tiles;
+  if (S > ksteps / RN_SPLIT128_MIN_STEPS) S = ksteps / RN_SPLIT128_MIN_STEPS;
+  if (S > 8) S = 8;
+  const long long slot = 128ll * BN * 4;
+  while (S >= 2 && RN_SPLITK_HEADER_BYTES + (long long)tiles * S * slot > p->splitk_ws_bytes) --S;
+  return S >= 2 ? S : 1;
+}
+
 int rn_splitk_plan(ConvArgs& a, int min_chunks, void* ws, long long ws_bytes, const rn_launch_opts& opts) {
   const int total = a.total_tiles;
   a.split_f = total; a.split_s = 1; a.vtotal = total; a.pad2_ = 0; a.ws = nullptr;
@@ -563,11 +690,19 @@ static int conv_min_chunks(const rn_conv_problem* p) {
 // ... or 0 when this launch cannot split (conv_big_kernel: whole tiles only — its 1x1 layers are HBM-bound)
 static int conv_splitk_min_chunks(const rn_conv_problem* p) { return conv_pick(p) == 2 ? conv_min_chunks(p) : 0; }
 
-// what any problem can use on any grid: 4 KB header + 256 accumulator slots (one per part: L * S <= 256 workgroups)
+// what any problem can use on any grid: 16 KB header + 256 accumulator slots (one per part: L * S <= 256 workgroups)
 extern "C" size_t rn_conv_splitk_workspace_max_bytes(void) { return RN_SPLITK_HEADER_BYTES + 256ull * RN_SPLITK_SLOT_BYTES; }
 
 extern "C" size_t rn_conv_splitk_workspace_bytes(const rn_conv_problem* p) {
   if (!p || p->num_segments < 1 || p->num_segments > RN_CONV_MAX_SEGMENTS) return 0;
+  if (conv_pick(p) == 0) {   // 128-row kernel: every tile cut into S parts of one [128][BN] fp32 slot each
+    int BN, BK;
+    const int tiles = conv128_shape(p, &BN, &BK);
+    rn_conv_problem q = *p;
+    if (!q.splitk_ws) { q.splitk_ws = (void*)16; q.splitk_ws_bytes = (long long)rn_conv_splitk_workspace_max_bytes(); }   // "if one were attached"
+    const int S = conv128_split_parts(&q, tiles, BN, BK);
+    return S >= 2 ? (size_t)(RN_SPLITK_HEADER_BYTES + (long long)tiles * S * 128 * BN * 4) : 0;
+  }
   const int mc = conv_splitk_min_chunks(p);
   if (!mc) return 0;
   long long tiles = 0;
@@ -613,15 +748,13 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
   const bool big = kid == 1 || kid == 2;
   const bool halo512 = kid == 3;   // 512 x 128 tiles of the halo kernel
   const int BM = big ? 256 : (halo512 ? 512 : 128);
-  if (!big && !halo512 && BN == 128) {
+  if (!big && !halo512) {
     // Small launches (batch-8 inference, ResNet stage 4: 100 tiles of 128 x 128 on 256 CUs): 128 x 64 tiles put the work
     // on twice as many CUs and read 12 KB instead of 16 KB of LDS fragments per wave and K step — the 128-row kernel is
     // bound by fragment bandwidth at one workgroup per CU (DESIGN.md section 4, round-3 probes).  Only while the
-    // narrower tiles still fit one per CU: at two per CU they share that bandwidth again.
-    long long t128 = 0;
-    for (int i = 0; i < p->num_segments; ++i)
-      t128 += rn_cdiv((long long)p->seg[i].N * p->seg[i].Ho * p->seg[i].Wo, 128) * rn_cdiv(rn_conv_cout_pad(seg_cols(p->seg[i])), 128);
-    if (2 * t128 <= rn_num_cus() && !p->opts.ablate && p->opts.conv_tile != 1) BN = 64;   // conv_tile = 1 keeps 128 x 128 (tests)
+    // narrower tiles still fit one per CU: at two per CU they share that bandwidth again.  (conv128_shape)
+    int bk_;
+    conv128_shape(p, &BN, &bk_);
   }
   const int BNT = big ? 256 : BN;   // n-tile width
   int tiles = 0;
@@ -735,10 +868,14 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
     if (deal) a.pad_ |= 2;   // bit 1: tiles dealt round-robin (see above)
     return rn_launch_conv_big(a, f32, p->opts, st);
   }
-  if (BN == 128 && BK == 64) return f32 ? launch_conv<128, 128, 64, true>(a, st) : launch_conv<128, 128, 64, false>(a, st);
-  if (BN == 64 && BK == 64) return f32 ? launch_conv<128, 64, 64, true>(a, st) : launch_conv<128, 64, 64, false>(a, st);
-  if (BN == 128 && BK == 32) return f32 ? launch_conv<128, 128, 32, true>(a, st) : launch_conv<128, 128, 32, false>(a, st);
-  return f32 ? launch_conv<128, 64, 32, true>(a, st) : launch_conv<128, 64, 32, false>(a, st);
+  // 128-row kernel.  With a split-K workspace a SMALL launch of a deep layer (fewer tiles than the chip has compute units:
+  // batch-1 / batch-8 inference, ResNet stage 3 / 4, the FPN laterals) cuts every tile along K (conv128_split_parts).
+  const int S128 = conv128_split_parts(p, tiles, BN, BK);
+  if (S128 >= 2) {
+    a.split_s = S128; a.vtotal = tiles * S128; a.ws = (float*)p->splitk_ws;
+    return launch_conv128<true>(a, BN, BK, f32, st);
+  }
+  return launch_conv128<false>(a, BN, BK, f32, st);
 }
 
 // ---- weight / input packing ----------------------------------------------------------------

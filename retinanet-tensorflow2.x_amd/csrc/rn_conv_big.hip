@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(512) conv_big_kernel(const ConvArgs args) {
 
 int rn_launch_conv_big(const ConvArgs& a, bool out_f32, const rn_launch_opts& opts, hipStream_t st) {
   static unsigned long long attr_set = 0;   // one bit per device
-  if (RN_FIRST_ON_DEVICE(attr_set)) {
+  if (RN_ATTRS_NEEDED(attr_set)) {
     RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_big_kernel<false, false>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_big_kernel<false, true>,
@@ -284,6 +284,7 @@ int rn_launch_conv_big(const ConvArgs& a, bool out_f32, const rn_launch_opts& op
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_big_kernel<false, false, true>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    RN_ATTRS_DONE(attr_set);
   }
   // one persistent workgroup per CU (minus the CUs kept for RCCL; opts.max_workgroups caps it)
   const int grid = rn_persistent_grid(a.total_tiles, rn_num_cus(), opts);

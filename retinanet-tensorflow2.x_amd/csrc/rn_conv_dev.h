@@ -36,11 +36,11 @@ struct ConvArgs {
   // workgroup l * split_s + part computes the channel chunks [part * nch / split_s, (part + 1) * nch / split_s) of tile
   // split_f + l.  No split: split_s = 1.
   int split_f, split_s, vtotal, pad2_;
-  float* ws;   // [1024 words: arrival counter per leftover tile, word 1023 = status][slot (l, part - 1): 65536 floats]
+  float* ws;   // [4096 words: arrival counter (leftover tile l, wave w) at word l * 8 + w][slot (l, part): 65536 floats]
   ConvSegDev seg[RN_CONV_MAX_SEGMENTS];
 };
 
-#define RN_SPLITK_HEADER_BYTES 4096
+#define RN_SPLITK_HEADER_BYTES 16384
 #define RN_SPLITK_SLOT_BYTES (256 * 256 * 4)
 
 template <int BK>

@@ -143,21 +143,25 @@ __device__ __forceinline__ int halo_tile_of(int v, const ConvArgs& a, int total)
 }
 
 // ---- a part of a split tile (rnet_hip.h: rn_conv_problem.splitk_ws) ------------------------------------------------
-// EVERY part stores its raw fp32 accumulators (lane-linear, 16 B per lane and store) into its slot; parts 1.. then count
-// themselves in and are done.  Part 0 waits for the count; its epilogue then REBUILDS the accumulators from the slots, one
-// 32-pixel block at a time, parts added in order (deterministic) — its own slot included, so that the registers the K loop
-// accumulated in are dead after the stores (big_epilogue<.., FROM_WS>): `acc += slot` on the live registers, and all eight
-// blocks rebuilt up front, both made the allocator spill 130 - 350 bytes per lane, and a kernel with scratch pays ~40 us
-// per LAUNCH on this stack (the runtime attaches scratch memory per dispatch: measured, gpurun_out/r04c).  The hand-off
-// uses no cache-wide operation: the slots are written with WRITE-THROUGH stores (sc1) and read back with sc1 loads
-// (cdna_hip_programming.md section 6, guideline 16, R1): every storing wave drains its stores, a barrier, ONE lane bumps
-// the tile's arrival counter (relaxed, agent scope); part 0 polls the counter relaxed, a barrier, then sc1 loads.  (The
-// first version released / acquired at agent scope: buffer_wbl2 writes back the whole L2 of the XCD — the previous launch's
-// output tiles — and buffer_inv drops it, weights included, for every workgroup on that XCD: +30 us per launch.)
-// Producers never wait, so the owner's wait cannot deadlock; it is bounded all the same (2 s of the 100 MHz clock -> status
-// word 1023 = 1).  Called by all eight waves with their barrier counts aligned.  Returns true for part 0 (the caller runs
-// the tile's epilogue).
-// One slot = 256 KB = [wave][32 x (64 lanes x 16 B)]; buffer addressing: ONE lane offset register, the piece is a scalar offset.
+// EVERY part stores its raw fp32 accumulators (lane-linear, 16 B per lane and store) into its slot and counts itself in;
+// whoever arrives LAST runs the tile's epilogue, which REBUILDS the accumulators from the slots, one 32-pixel block at a
+// time, parts added in PART order (deterministic whoever the last arriver is) — the own slot included, so that the
+// registers the K loop accumulated in are dead after the stores (big_epilogue<.., FROM_WS>): `acc += slot` on the live
+// registers, and all eight blocks rebuilt up front, both made the allocator spill 130 - 350 bytes per lane, and a kernel
+// with scratch pays ~40 us per LAUNCH on this stack (the runtime attaches scratch memory per dispatch: measured,
+// gpurun_out/r04c).  Nobody waits for anybody (round 4: part 0 polled the counter, bounded by a 2 s timeout whose exit
+// left the counter in a state that poisoned later launches — ADVICE r4), so there is no timeout and no status word.
+// The hand-off is PER WAVE: a slot is [wave][32 x (64 lanes x 16 B)] and the epilogue of wave w reads only the w-th
+// eighth of every part's slot, so wave w of each part counts itself in on counter (tile, w) and the last wave w to arrive
+// — of whichever part — finishes that eighth of the tile; no workgroup barrier.  It uses no cache-wide operation: the
+// slots are written with WRITE-THROUGH stores (sc1) and read back with sc1 loads (cdna_hip_programming.md section 6,
+// guideline 16, R1): the storing wave drains its stores (vmcnt 0), ONE lane bumps the counter with a returning agent-scope
+// atomic, and the value it gets back (S - 1: every other part's wave w has drained and counted) gates the sc1 loads.
+// (The first version released / acquired at agent scope: buffer_wbl2 writes back the whole L2 of the XCD — the previous
+// launch's output tiles — and buffer_inv drops it, weights included, for every workgroup on that XCD: +30 us per launch.)
+// The last arriver zeroes the counter: the header is all zero again when the launch completes.  Returns the tile's first
+// slot (l * S) to the wave that runs the epilogue, -1 to the others.
+// One slot = 256 KB; buffer addressing: ONE lane offset register, the piece is a scalar offset.
 typedef unsigned halo_u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void halo_split_store(const f32x16_t (&acc)[4][2], const ConvArgs& args, int slot, int voff) {
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -173,37 +177,22 @@ __device__ __forceinline__ void halo_split_store(const f32x16_t (&acc)[4][2], co
         __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, ((i * 2 + j) * 4 + q) * 1024, 16);   // aux 16 = sc1: write-through
       }
 }
-__device__ __forceinline__ bool halo_split_exchange(f32x16_t (&acc)[4][2], const ConvArgs& args, int c_v, int wave) {
+__device__ __forceinline__ int halo_split_exchange(f32x16_t (&acc)[4][2], const ConvArgs& args, int c_v, int wave) {
   const int S = args.split_s;
   const int l = c_v / S;     // leftover tile index (scalar division, once)
   const int part = c_v - l * S;
-  unsigned* const head = (unsigned*)args.ws;
-  unsigned* const cnt = head + l;
+  unsigned* const cnt = (unsigned*)args.ws + l * 8 + wave;   // header: one counter per (tile, wave)
   const unsigned lane_ = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-  const bool first = wave == 0 && lane_ == 0;
   const int voff = (int)(wave * 32768 + lane_ * 16);
   halo_split_store(acc, args, l * S + part, voff);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
+  unsigned old = 0;
+  if (lane_ == 0) old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+  if (old != (unsigned)(S - 1)) return -1;
+  if (lane_ == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
   asm volatile("" ::: "memory");
-  if (part > 0) {
-    if (first) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return false;
-  }
-  if (first) {
-    const unsigned long long t0 = wall_clock64();
-    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)(S - 1)) {
-      __builtin_amdgcn_s_sleep(16);
-      if (wall_clock64() - t0 > 200000000ull) {
-        __hip_atomic_store(head + 1023, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
-    }
-    __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-  }
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  return true;
+  return l * S;
 }
 
 template <bool OUT_F32, bool HAS_RES, bool BN_BWD = false, bool SPLIT = false, int WM = 2>   // BN_BWD: rn_conv_big_epi.h
@@ -589,13 +578,14 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs args) {
     HALO_STEP(1) HALO_STEP(2) HALO_STEP(3) HALO_STEP(4) HALO_STEP(5) HALO_STEP(6) HALO_STEP(7)
     HALO_STEP(8) HALO_STEP(0)
   }
-  if (SPLIT) {   // partial accumulators through the workspace; part 0 then runs the tile's epilogue
-    if (grp == 1) HALO_BARRIER();   // group 0 left the loop one barrier ahead of group 1
-    if (halo_split_exchange(acc, args, c_v, wave)) {
+  if (SPLIT) {   // partial accumulators through the workspace; per wave, the last part to arrive runs the epilogue
+    if (grp == 1) HALO_BARRIER();   // group 0 left the loop one barrier ahead of group 1: every wave's MFMAs are done
+    const int slot0 = halo_split_exchange(acc, args, c_v, wave);
+    if (slot0 >= 0) {
       BigEpiSrc src;
       unsigned lane2_;
       HALO_LANE(lane2_);
-      src.slots = (const char*)args.ws + RN_SPLITK_HEADER_BYTES + (size_t)c_v * RN_SPLITK_SLOT_BYTES;   // part 0: c_v = l * S
+      src.slots = (const char*)args.ws + RN_SPLITK_HEADER_BYTES + (size_t)slot0 * RN_SPLITK_SLOT_BYTES;
       src.nparts = args.split_s;
       src.voff = (int)(wave * 32768 + lane2_ * 16);
       big_epilogue<OUT_F32, HAS_RES, BN_BWD, true, WM>(acc, args, c_si, c_m0, c_n0, wave,
@@ -613,7 +603,7 @@ template <bool SPLIT, int WM>
 static int halo_launch(const ConvArgs& a, bool out_f32, int grid, hipStream_t st) {
   constexpr int LDS = HaloGeo<WM>::LDS_BYTES;
   static unsigned long long attr_set = 0;   // per template instantiation, one bit per device
-  if (RN_FIRST_ON_DEVICE(attr_set)) {
+  if (RN_ATTRS_NEEDED(attr_set)) {
     RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<false, false, false, SPLIT, WM>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<false, true, false, SPLIT, WM>,
@@ -624,6 +614,7 @@ static int halo_launch(const ConvArgs& a, bool out_f32, int grid, hipStream_t st
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     RN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<false, false, true, SPLIT, WM>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    RN_ATTRS_DONE(attr_set);
   }
   bool has_res = false;   // one residual input anywhere -> the variant that carries the residual path
   for (int i = 0; i < a.nseg; ++i) has_res = has_res || a.seg[i].residual != nullptr;

@@ -14,7 +14,7 @@ void rn_set_error(const char* fmt, ...) {
 
 extern "C" const char* rn_last_error(void) { return g_rn_err; }
 
-extern "C" int rn_abi_version(void) { return 6; }
+extern "C" int rn_abi_version(void) { return 7; }
 
 // 0: bfloat16 storage (librnet_hip.so), 1: IEEE half (librnet_hip_f16.so, built with -DRN_F16)
 extern "C" int rn_storage_dtype(void) {
@@ -51,8 +51,9 @@ static int rn_check_opts(const rn_launch_opts& o, const char* who) {
   RN_CHECK_ARG(o.wgrad_kernel >= 0 && o.wgrad_kernel <= 3, "%s: wgrad_kernel=%d (0..3)", who, o.wgrad_kernel);
   RN_CHECK_ARG(o.reserved_cus >= 0 && o.reserved_cus <= 128, "%s: reserved_cus=%d out of range (0..128)", who,
                o.reserved_cus);
-  RN_CHECK_ARG(o.max_workgroups >= 0 && o.conv_big_min_tiles >= 0 && o.wgrad_target_blocks >= 0,
-               "%s: negative max_workgroups / conv_big_min_tiles / wgrad_target_blocks", who);
+  RN_CHECK_ARG(o.max_workgroups >= 0 && o.conv_big_min_tiles >= 0 && o.wgrad_target_blocks >= 0 && o.splitk_target_blocks >= 0,
+               "%s: negative max_workgroups / conv_big_min_tiles / wgrad_target_blocks / splitk_target_blocks", who);
+  RN_CHECK_ARG(o.conv_stream >= 0 && o.conv_stream <= 2, "%s: conv_stream=%d (0..2)", who, o.conv_stream);
   return RN_OK;
 }
 int rn_validate_launch_opts(const rn_launch_opts& o, const char* who) { return rn_check_opts(o, who); }

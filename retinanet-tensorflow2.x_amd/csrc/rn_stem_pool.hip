@@ -203,8 +203,10 @@ extern "C" int rn_stem_conv_bn_relu_pool(const void* x, const void* w_packed, co
                "rn_stem_conv_bn_relu_pool: pooled size %d x %d against conv output %d x %d", Po, Qo, Hs, Ws);
   RN_CHECK_ARG(((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)y) % 16 == 0, "rn_stem_conv_bn_relu_pool: alignment");
   static unsigned long long attr_set = 0;   // one bit per device
-  if (RN_FIRST_ON_DEVICE(attr_set))
+  if (RN_ATTRS_NEEDED(attr_set)) {
     RN_CHECK_HIP(hipFuncSetAttribute((const void*)stem_pool_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    RN_ATTRS_DONE(attr_set);
+  }
   const int num_cu = rn_num_cus();
   StemPoolArgs a;
   a.x = (const uint16_t*)x; a.w = (const uint16_t*)w_packed; a.scale = scale; a.shift = shift; a.y = (uint16_t*)y;

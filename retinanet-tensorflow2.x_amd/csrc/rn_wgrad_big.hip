@@ -401,11 +401,12 @@ bool rn_wgrad_big_plan(const rn_wgrad_problem* p, WgArgs& a) {
 
 int rn_launch_wgrad_big(const WgArgs& a, const rn_launch_opts& opts, hipStream_t st) {
   static unsigned long long attr_set = 0;   // one bit per device
-  if (RN_FIRST_ON_DEVICE(attr_set)) {
+  if (RN_ATTRS_NEEDED(attr_set)) {
     RN_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_big_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      LDS_BYTES));
     RN_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_big_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      LDS_BYTES));
+    RN_ATTRS_DONE(attr_set);
   }
   bool linear = a.sh == 1 && a.sw == 1 && a.pt == (a.R - 1) / 2 && a.pl == (a.S - 1) / 2 && (a.R & 1) && (a.S & 1);
   for (int i = 0; i < a.nseg; ++i) {

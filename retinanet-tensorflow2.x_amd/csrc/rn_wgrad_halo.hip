@@ -427,8 +427,9 @@ template <int VAR, int STAGES = WH_STAGES_DEFAULT>
 static int wh_launch(const WhArgs& a, dim3 grid, hipStream_t st) {
   static unsigned long long attr_set = 0;   // per template instantiation, one bit per device
   constexpr int WH_LDS = STAGES * WH_STAGE;
-  if (RN_FIRST_ON_DEVICE(attr_set)) {
+  if (RN_ATTRS_NEEDED(attr_set)) {
     RN_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_halo_kernel<VAR, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, WH_LDS));
+    RN_ATTRS_DONE(attr_set);
   }
   hipLaunchKernelGGL((wgrad_halo_kernel<VAR, STAGES>), grid, dim3(512), WH_LDS, st, a);
   RN_CHECK_LAUNCH();

@@ -47,7 +47,7 @@ class NativeComm:
         self._h, self.rank, self.world, self.device, self._lib = None, rank, world, device, lib
         self._owned = handle is None      # a communicator created through an rn_handle lives in its slot ...
         self._handle, self._slot = handle, int(slot)   # ... and close() frees that slot (rn_handle_comm_destroy)
-        self.ok, self.error = False, ""
+        self.ok, self.error, self._slot_mine = False, "", False
         # stage 0 — local preconditions, agreed on before anything collective in RCCL
         try:
             local = lib.rn_comm_available() == 1
@@ -81,6 +81,9 @@ class NativeComm:
         if status != 0 and not self.error:
             self.error = (lib.rn_last_error() or b"").decode()
         self._h = comm if status == 0 else None
+        # only a communicator THIS object put into the handle's slot may be freed by close(): RN_EINVAL because the slot was
+        # already taken means it belongs to another NativeComm / engine and may be in use
+        self._slot_mine = handle is not None and status == 0
         if not _agree(status == 0, device, group):
             self.error = self.error or "rn_comm_init failed on another rank"
             self.close()
@@ -101,10 +104,11 @@ class NativeComm:
         peers have given up too, and ncclCommDestroy at process exit on such a communicator can hang."""
         if self._h and self._owned:
             self._lib.rn_comm_destroy(self._h)
-        elif self._handle is not None:
-            # also when rn_handle_comm_init succeeded here and another rank failed (self._h may be None on this rank only
-            # when ITS init failed: the slot is then empty and the call is a no-op)
+        elif self._handle is not None and getattr(self, "_slot_mine", False):
+            # also when rn_handle_comm_init succeeded here and another rank failed; never when this object's own init
+            # failed — the slot is then empty, or holds somebody else's communicator
             self._lib.rn_handle_comm_destroy(self._handle.h, self._slot)
+            self._slot_mine = False
         self._h = None
         self.ok = False
 

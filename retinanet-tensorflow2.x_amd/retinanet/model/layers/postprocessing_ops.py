@@ -64,10 +64,12 @@ class TransformBoxesAndScores:
         self._var = (list(params.encoder_params.box_variance)
                      if params.encoder_params.scale_box_targets else None)
 
-    def decode(self, box_levels, offs, B):
+    def decode(self, box_levels, offs, B, out=None):
+        """out: a [B, A, 4] f32 buffer to decode into (the serving stage keeps one: no allocation per call, stable
+        addresses for a captured HIP graph)"""
         lib = _C.lib()
         A = offs[-1]
-        boxes = torch.empty((B, A, 4), dtype=torch.float32, device=box_levels[0].device)
+        boxes = out if out is not None else torch.empty((B, A, 4), dtype=torch.float32, device=box_levels[0].device)
         with torch.cuda.device(boxes.device):
             _C.check(lib.rn_decode_boxes(_C.ptr_array(box_levels), _C.i64_array(offs), len(box_levels), B,
                                          _C.ptr(self._anchors.boxes), _C.f32_array(self._var), self._h, self._w,
@@ -260,7 +262,9 @@ class DetectionPostProcess:
             raise ValueError("class and box predictions disagree on anchors per level")
         A = offs[-1]
         dev = box_levels[0].device
-        boxes = self._tb.decode(box_levels, offs, B)
+        if self._boxes is None or tuple(self._boxes.shape) != (B, A, 4) or self._boxes.device != dev:
+            self._boxes = torch.empty((B, A, 4), dtype=torch.float32, device=dev)
+        boxes = self._tb.decode(box_levels, offs, B, out=self._boxes)
         if not self._fused:
             # stage-by-stage path for the modes no shipped config selects (a15)
             lib0 = _C.lib()

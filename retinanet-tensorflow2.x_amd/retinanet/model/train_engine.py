@@ -1888,9 +1888,8 @@ class TrainEngine:
             self._small_msgs = 0
             self._c2_local, self._c2_sent, self.c2_normalizer = None, False, None
             if self.sync_bn:    # sum(num-positives) + 1 of this rank (retinanet_loss.py:38): folded into SyncBN traffic
-                npos = targets["num-positives"]
-                if npos.dtype != torch.float32 or not npos.is_contiguous():
-                    npos = npos.to(torch.float32).contiguous()
+                # (a device kernel reads it: a host tensor, or one on another GPU, must be moved first — ADVICE r4)
+                npos = targets["num-positives"].to(self.dev, torch.float32).contiguous()
                 self._c2_local = torch.empty((1,), dtype=torch.float32, device=self.dev)
                 _C.check(self.lib.rn_reduce_rows_f32(_C.ptr(npos), npos.numel(), 1, 1, 1.0, _C.ptr(self._c2_local),
                                                      _C.current_stream()), "num-positives + 1")

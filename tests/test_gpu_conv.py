@@ -298,9 +298,9 @@ SPLITK_CASES = [
 @pytest.mark.parametrize("build,case", _builds(SPLITK_CASES, SPLITK_CASES[:3], "splitk-"))
 def test_conv_halo_split_last_round(cuda, build, case):
     """rn_conv_problem.splitk_ws: the tiles of a persistent launch's last round are cut along K over several workgroups
-    (parts 1.. hand their fp32 accumulators to part 0 through the workspace).  Same float64 reference as the whole-tile
+    (every part writes its fp32 accumulators to the workspace; per wave, the part that arrives last adds them in part order).  Same float64 reference as the whole-tile
     launch; the exchange adds in part order, so repeats are bit-identical; the workspace header is zero again afterwards
-    (arrival counters consumed, status word clear)."""
+    (every arrival counter consumed by the last arriver)."""
     N, H, W, Cin, Cout, act, use_res, out_f32, use_bias, terms, wgs = case
     g = torch.Generator().manual_seed(_seed(case))
     s = {"x": torch.randn((N, H, W, Cin), generator=g),
@@ -318,11 +318,75 @@ def test_conv_halo_split_last_round(cuda, build, case):
     _close(runs[0], want, out_f32)
     for r in runs[1:]:
         assert torch.equal(r, runs[0])
-    assert int(ws[:4096].view(torch.int32).abs().sum().item()) == 0
+    assert int(ws[:16384].view(torch.int32).abs().sum().item()) == 0
     whole = _conv_gpu(cuda, [s], 3, 1, 1, act, out_f32, opts)[0]          # no workspace: whole tiles, another sum order
     _close(whole, want, out_f32)
     if not out_f32:
         assert (runs[0] != whole).float().mean().item() < 0.02
+
+
+SPLIT128_CASES = [
+    # N, H, W, Cin, Cout, k, stride, act, residual, out_f32, bias, w_terms, splitk_target_blocks   (the 128-row kernel, every tile cut along K)
+    (1, 20, 20, 512, 512, 3, 1, "relu", False, False, False, 1, 0),     # ResNet stage 4 3x3 at batch 1: 32 tiles of 128 x 64, 72 K steps, 8 parts
+    (1, 20, 20, 2048, 512, 1, 1, "relu", False, False, False, 1, 0),    # stage 4 first 1x1: 32 K steps, 8 parts of 4
+    (1, 20, 20, 512, 2048, 1, 1, "relu", True, False, False, 1, 0),     # stage 4 last 1x1 + residual: 8 K steps, 2 parts
+    (1, 40, 40, 256, 256, 3, 2, "relu6", False, False, False, 1, 0),    # stride 2; M tail (400 = 3 tiles + 16 pixels)
+    (2, 13, 11, 192, 72, 3, 1, "swish", True, False, False, 1, 64),     # odd sizes, Cout tail, two images, swish + residual
+    (1, 10, 10, 256, 36, 3, 1, None, False, True, True, 2, 0),          # f32 output, two weight planes, bias (box prediction, P6)
+    (1, 25, 25, 96, 128, 1, 1, None, False, False, True, 1, 40),        # 96 channels (padded to 128: two K steps), bias only: too shallow, whole tiles
+    (3, 9, 9, 1024, 256, 1, 1, "relu", False, False, False, 1, 24),     # 3 parts of 5 / 5 / 6 K steps (uneven shares)
+]
+
+
+@pytest.mark.parametrize("build,case", _builds(SPLIT128_CASES, SPLIT128_CASES[:4], "split128-"))
+def test_conv_128_row_kernel_split_k(cuda, build, case):
+    """rn_conv_problem.splitk_ws on the 128-row kernel (conv_fwd_kernel<..., SPLIT>): a small launch of a deep layer cuts
+    every tile along K, each part writes its fp32 partial tile to the workspace and the part that arrives last adds them
+    in part order and runs the epilogue.  Against the float64 reference; repeats are bit-identical (the sum order does not
+    depend on who arrives last); the arrival counters are zero again afterwards; and the unsplit launch of the same
+    problem (no workspace) differs only by summation order."""
+    N, H, W, Cin, Cout, k, stride, act, use_res, out_f32, use_bias, terms, target = case
+    pad = (k - 1) // 2
+    g = torch.Generator().manual_seed(_seed(case))
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    s = {"x": torch.randn((N, H, W, Cin), generator=g),
+         "w": torch.randn((k, k, Cin, Cout), generator=g) / math.sqrt(k * k * Cin), "w_terms": terms}
+    if use_bias:
+        s["bias"] = torch.randn((Cout,), generator=g)
+    else:
+        s["scale"], s["shift"] = torch.rand((Cout,), generator=g) + 0.5, torch.randn((Cout,), generator=g) * 0.1
+    if use_res:
+        s["residual"] = torch.randn((N, Ho, Wo, Cout), generator=g)
+    opts = dict(splitk_target_blocks=target)
+    ws = torch.zeros((80 << 20,), dtype=torch.uint8, device=cuda)
+    want = _conv_ref(s, k, stride, pad, act, out_f32)
+    expect = Cin * k * k * terms // (64 if Cin % 64 == 0 else 32) >= 8     # two parts of four K steps at least
+    runs = [_conv_gpu(cuda, [s], k, stride, pad, act, out_f32, opts, splitk_ws=ws, expect_split=expect)[0] for _ in range(3)]
+    _close(runs[0], want, out_f32)
+    for r in runs[1:]:
+        assert torch.equal(r, runs[0])
+    assert int(ws[:16384].view(torch.int32).abs().sum().item()) == 0
+    whole = _conv_gpu(cuda, [s], k, stride, pad, act, out_f32, opts)[0]
+    _close(whole, want, out_f32)
+    if not expect:
+        assert torch.equal(whole, runs[0])
+
+
+def test_conv_128_row_split_k_grouped_levels(cuda):
+    """A grouped launch (three pyramid levels of a shared 1x1 conv, different depths: the FPN laterals at batch 1) split
+    along K: the part count follows the shallowest segment, every segment's tiles exchange through their own slots."""
+    g = torch.Generator().manual_seed(77)
+    segs = []
+    for (H, Cin) in ((20, 2048), (40, 1024), (10, 512)):
+        segs.append({"x": torch.randn((1, H, H, Cin), generator=g), "w": torch.randn((1, 1, Cin, 256), generator=g) / math.sqrt(Cin),
+                     "bias": torch.randn((256,), generator=g)})
+    ws = torch.zeros((80 << 20,), dtype=torch.uint8, device=cuda)
+    got = _conv_gpu(cuda, segs, 1, 1, 0, None, False, None, splitk_ws=ws, expect_split=True)
+    again = _conv_gpu(cuda, segs, 1, 1, 0, None, False, None, splitk_ws=ws, expect_split=True)
+    for s, y, y2 in zip(segs, got, again):
+        _close(y, _conv_ref(s, 1, 1, 0, None, False), False)
+        assert torch.equal(y, y2)
+    assert int(ws[:16384].view(torch.int32).abs().sum().item()) == 0
 
 
 HALO512_CASES = [

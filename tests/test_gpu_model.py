@@ -1,5 +1,7 @@
 """GPU parity: whole-network inference forward (a5-a8) and the end-to-end serving path
 (a16) against the PyTorch-CPU restatement in oracle/model_ref.py."""
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -104,6 +106,49 @@ def test_forward_at_baseline_sizes(cuda, size, B):
         # stage 1 at 1024^2: 4 x 256 x 256 = 262 144 pixels per launch < 2^22 (rn_fdiv's validity bound)
         assert B * (size // 4) ** 2 < (1 << 22)
     _check_predictions(preds, RefModel(p, model.variables, emulate_bf16=True)(images))
+
+
+def test_config0_single_image_resnet50_640(cuda):
+    """BASELINE configs[0] — the reference's own inference protocol (README.md:31-32, evaluate_saved_model.py:60-72): ONE
+    640 x 640 image through ResNet50-RetinaNet at full depth on the HIP path.  (i) head outputs against the bf16-emulating
+    CPU restatement at the tolerance of test_forward_at_baseline_sizes; (ii) the post-processing stage on the SAME head
+    outputs bit-exact against the oracle; (iii) the HIP-graph replay of `serving_default` equal to the eager launch list
+    bit for bit.  At batch 1 nearly every launch is below one round of tiles: the deep layers must be cut along K
+    (rn_conv_problem.splitk_ws on the 128-row kernel) — checked on the launches that dominate the batch-1 latency."""
+    from retinanet import _C
+    from retinanet.cfg import default_params
+    from retinanet.model import ModelBuilder
+    p = default_params(input_size=640, balanced=True, inference_batch=1)
+    assert int(p.architecture.backbone.depth) == 50
+    p.inference.score_threshold = 0.005   # random weights score ~0.01: let candidates through
+    b = ModelBuilder(p, "val", device=cuda)
+    model = b()
+    _randomize(model, 1)
+    images = torch.randn((1, 640, 640, 3), generator=torch.Generator().manual_seed(1337))
+    preds = model(images.to(cuda), training=False)
+    torch.cuda.synchronize()
+    eng = model.inference_engine(1)
+    lib = _C.lib()
+    split = {n: int(lib.rn_conv_splitk_workspace_bytes(ctypes.byref(q))) for n, q in eng.conv_problems.items()}
+    for n in ("conv:g4b0_b", "conv:g4b1_a", "conv:g3b1_b", "conv:g3b1_a"):
+        assert split[n] > 0, (n, split)
+    _check_predictions(preds, RefModel(p, model.variables, emulate_bf16=True)(images))
+    logits = np.concatenate([preds["class-predictions"][l].cpu().numpy().reshape(1, -1, 80) for l in "34567"], axis=1)
+    enc = np.concatenate([preds["box-predictions"][l].cpu().numpy().reshape(1, -1, 4) for l in "34567"], axis=1)
+    infer = b.add_post_processing_stage(model)
+    out = {k: v.cpu().numpy().copy() for k, v in infer(images.to(cuda)).items()}
+    an = o.generate_anchors(640, 640, 3, 7, p.anchor_params.areas, p.anchor_params.aspect_ratios, p.anchor_params.scales)
+    wb, ws, wc, wv = o.postprocess(logits, enc, an, 640, 640, score_threshold=0.005)
+    assert wv.min() > 0
+    np.testing.assert_array_equal(out["valid_detections"], wv)
+    np.testing.assert_array_equal(out["classes"], wc)
+    np.testing.assert_array_equal(out["scores"], ws)
+    np.testing.assert_array_equal(out["boxes"], wb)
+    infer_g = b.add_post_processing_stage(model, capture_graph=True)
+    for _ in range(3):
+        outg = {k: v.cpu().numpy().copy() for k, v in infer_g(images.to(cuda)).items()}
+    for k in out:
+        np.testing.assert_array_equal(out[k], outg[k])
 
 
 def test_serving_path_end_to_end(cuda):
