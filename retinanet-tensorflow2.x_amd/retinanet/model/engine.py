@@ -87,7 +87,16 @@ class InferenceEngine:
             self.load_variables(variables)
             # split-K of the persistent conv kernels' last round: the launches of this engine run in order on one stream
             self.splitk_ws = _C.new_splitk_workspace(self.lib, self.dev, default_on=True)
+            # second stream (see _side_launch): its conv launches need a split-K workspace of their own — launches
+            # that share one must be ordered on one stream
+            self.two_streams = os.environ.get("RNET_INFER_STREAMS", "2") != "1"
+            self.splitk_ws_side = (_C.new_splitk_workspace(self.lib, self.dev, default_on=True)
+                                   if self.two_streams else None)
+            self.side_steps = set()   # names of the launches that go to the second stream
+            self.step_io = {}         # step name -> (tensor names read, tensor names written)
             self._build()
+            self._side_stream = torch.cuda.Stream(device=self.dev) if self.side_steps else None
+            self._events = [torch.cuda.Event() for _ in range(2 * len(self.side_steps))]
 
     # ---- buffers ---------------------------------------------------------------------------
     def _alloc(self):
@@ -246,10 +255,51 @@ class InferenceEngine:
         seg.pix_stride = x.shape[3]
         seg.Ho, seg.Wo, seg.Cout = y.shape[1], y.shape[2], c["cout"]
 
-    def _add_conv_launch(self, ops):
+    def _tensor_users(self, tname):
+        """(op, role) of every op of the graph that reads tensor `tname`; role = the op field that names it"""
+        users = []
+        for o in self.g.ops:
+            for k, v in o.items():
+                if k in ("op", "out", "outs", "conv", "bn", "act", "group", "dw", "se", "out_dtype"):
+                    continue
+                if o["op"] in ("balance", "se") and k in ("tensors", "tensor"):
+                    k = "inplace"
+                for t in (v if isinstance(v, (list, tuple)) else [v]):
+                    if isinstance(t, str) and t == tname:
+                        users.append((o, k))
+        return users
+
+    def _side_launch(self, ops, second_of_split):
+        """Launches that leave the main stream.  At batch 1 (BASELINE configs[0]: the reference's latency protocol) every
+        launch is a fraction of the chip wide and ~15 us of fixed latency long, so a launch that nothing on the critical
+        path waits for can run BESIDE it on a second stream — in a captured graph a parallel branch:
+          * the projection shortcut of a ResNet stage's first block (resnet.py:220-228): read again only as the `residual`
+            of the block's last conv, three launches later;
+          * a prediction conv whose outputs are network outputs, next to the other head's (detection_head.py:80-88);
+          * the second launch of a grouped launch that split_by_depth cut in two.
+        Results are what they were: every launch computes the same tiles from the same inputs.  RNET_INFER_STREAMS=1
+        keeps one stream (A/B)."""
+        if not self.two_streams:
+            return False
+        if second_of_split:
+            return True
+        outs_ = [o["out"] for o in ops]
+        roles = [r for t in outs_ for _, r in self._tensor_users(t)]
+        if roles and all(r == "residual" for r in roles):
+            return True
+        net_outs = {n for d in self.g.outputs.values() for n in d.values()}
+        if not roles and all(t in net_outs for t in outs_):
+            # only when another launch follows that does not need it (the class head's prediction conv)
+            later = [o for o in self.g.ops if o["op"] == "conv" and o["out"] in net_outs and o["out"] not in outs_]
+            idx = {id(o): i for i, o in enumerate(self.g.ops)}
+            return any(idx[id(o)] > max(idx[id(q)] for q in ops) for o in later)
+        return False
+
+    def _add_conv_launch(self, ops, second_of_split=False):
         first = ops[0]
         c0 = self.g.convs[first["conv"]]
-        p = _C.attach_splitk_workspace(_C.ConvProblem(), self.splitk_ws)
+        side = self._side_launch(ops, second_of_split)
+        p = _C.attach_splitk_workspace(_C.ConvProblem(), self.splitk_ws_side if side else self.splitk_ws)
         p.opts = self.launch_opts
         p.R = p.S = c0["k"]
         p.stride_h = p.stride_w = c0["stride"]
@@ -275,6 +325,9 @@ class InferenceEngine:
         def run(st):
             _C.check(lib.rn_conv2d_nhwc_fwd(pref, st), f"rn_conv2d_nhwc_fwd[{name}]")
         self.steps.append((run, "conv:" + name))
+        self.step_io["conv:" + name] = ({t for o in ops for t in (o["inp"], o.get("residual")) if t}, {o["out"] for o in ops})
+        if side:
+            self.side_steps.add("conv:" + name)
 
     def _add_dw_launch(self, ops):
         first = ops[0]
@@ -303,6 +356,7 @@ class InferenceEngine:
         def run(st):
             _C.check(lib.rn_depthwise_conv2d_nhwc_fwd(pref, st), f"rn_depthwise_conv2d_nhwc_fwd[{name}]")
         self.steps.append((run, "dwconv:" + name))
+        self.step_io["dwconv:" + name] = ({o["inp"] for o in ops}, {o["out"] for o in ops})
 
     def _build(self):
         lib = self.lib
@@ -322,6 +376,7 @@ class InferenceEngine:
                     _C.check(lib.rn_pack_image_nhwc4(pimg, B, H, W, pt, pl, self.Hp, self.Wp, pin, st),
                              "rn_pack_image_nhwc4")
                 self.steps.append((pack, "pack_stem_input"))
+                self.step_io["pack_stem_input"] = ({"images"}, {":stem_in"})
                 p = _C.attach_splitk_workspace(_C.ConvProblem(), self.splitk_ws)
                 p.opts = self.launch_opts
                 p.R, p.S, p.stride_h, p.stride_w, p.pad_top, p.pad_left = self.stem_k, 1, 2, 2, 0, 0
@@ -346,19 +401,21 @@ class InferenceEngine:
                     def stem_pool(st, fa=fa):
                         _C.check(lib.rn_stem_conv_bn_relu_pool(*fa, st), "rn_stem_conv_bn_relu_pool")
                     self.steps.append((stem_pool, "conv:stem"))
+                    self.step_io["conv:stem"] = ({":stem_in"}, {pool["out"]})
                     continue
 
                 def stem(st, pref=pref):
                     _C.check(lib.rn_conv2d_nhwc_fwd(pref, st), "rn_conv2d_nhwc_fwd[stem]")
                 self.steps.append((stem, "conv:stem"))
+                self.step_io["conv:stem"] = ({":stem_in"}, {op["out"]})
             elif kind == "conv":
                 grp = op.get("group")
                 if grp is None:
                     self._add_conv_launch([op])
                 elif grp not in done_groups:
                     done_groups.add(grp)
-                    for sub in split_by_depth(self.g, [o for o in self.g.ops if o["op"] == "conv" and o.get("group") == grp]):
-                        self._add_conv_launch(sub)
+                    for j, sub in enumerate(split_by_depth(self.g, [o for o in self.g.ops if o["op"] == "conv" and o.get("group") == grp])):
+                        self._add_conv_launch(sub, second_of_split=j > 0)
             elif kind == "dwconv":
                 grp = op.get("group")
                 if grp is None:
@@ -376,6 +433,7 @@ class InferenceEngine:
                 def se_run(st, args=args, name=name):
                     _C.check(lib.rn_squeeze_excite_inplace(*args, st), f"rn_squeeze_excite_inplace[{name}]")
                 self.steps.append((se_run, "se:" + op["tensor"]))
+                self.step_io["se:" + op["tensor"]] = ({op["tensor"]}, {op["tensor"]})
             elif kind == "maxpool":
                 if op["out"] in fused_pools:
                     continue
@@ -386,6 +444,7 @@ class InferenceEngine:
                 def pool(st, args=args):
                     _C.check(lib.rn_maxpool2d_nhwc(*args, st), "rn_maxpool2d_nhwc")
                 self.steps.append((pool, "maxpool:" + op["out"]))
+                self.step_io["maxpool:" + op["out"]] = ({op["inp"]}, {op["out"]})
             elif kind == "topdown":
                 ins = [self.t[n] for n in op["ins"]]
                 outs = [self.t[n] for n in op["outs"]]
@@ -397,6 +456,7 @@ class InferenceEngine:
                 def td(st, pin=pin, pout=pout, L=len(ins), H0=H0, W0=W0, C=C, act=act):
                     _C.check(lib.rn_fpn_topdown(pin, pout, L, B, H0, W0, C, act, st), "rn_fpn_topdown")
                 self.steps.append((td, "fpn_topdown"))
+                self.step_io["fpn_topdown"] = (set(op["ins"]), set(op["outs"]))
             elif kind == "balance":
                 ts = [self.t[n] for n in op["tensors"]]
                 pin = _C.ptr_array(ts)
@@ -410,6 +470,7 @@ class InferenceEngine:
                     _C.check(lib.rn_balance_features(pin, pin, L, mid, B, H0, W0, C, sp, st),
                              "rn_balance_features")
                 self.steps.append((bal, "balance_features"))
+                self.step_io["balance_features"] = (set(op["tensors"]), set(op["tensors"]))
             else:
                 raise ValueError(kind)
         self.outputs = {k: {lv: self.t[n] for lv, n in d.items()} for k, d in self.g.outputs.items()}
@@ -417,8 +478,37 @@ class InferenceEngine:
     # ---- run -----------------------------------------------------------------------------------
     def _launch_all(self):
         st = _C.current_stream()
-        for fn, _ in self.steps:
+        if not self.side_steps:
+            for fn, _ in self.steps:
+                fn(st)
+            return
+        # two streams (see _side_launch): a side launch is ordered behind everything the main stream has enqueued so far
+        # (event fork), the main stream waits for it in front of the first launch that touches what it wrote (or
+        # overwrites what it read), and at the end.  Under torch.cuda.graph the events become graph edges.
+        main, side = torch.cuda.current_stream(), self._side_stream
+        sst = ctypes.c_void_p(side.cuda_stream)
+        pending, ne = [], 0
+        for fn, name in self.steps:
+            reads, writes = self.step_io.get(name, (None, None))
+            if name in self.side_steps:
+                fork, done = self._events[ne], self._events[ne + 1]
+                ne += 2
+                fork.record(main)
+                side.wait_event(fork)
+                fn(sst)
+                done.record(side)
+                pending.append((done, reads, writes))
+                continue
+            keep = []
+            for done, r_s, w_s in pending:
+                if reads is None or (w_s & (reads | writes)) or (r_s & writes):
+                    main.wait_event(done)
+                else:
+                    keep.append((done, r_s, w_s))
+            pending = keep
             fn(st)
+        for done, _, _ in pending:
+            main.wait_event(done)
 
     def __call__(self, images):
         """images f32[B,H,W,3] (already normalised) -> prediction dict of static output buffers."""
