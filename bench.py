@@ -502,6 +502,70 @@ def run_infer_b1(args, dev):
                          "by_kernel_ms": {k: {"ms": round(v[0], 4), "launches": v[2]} for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])}}}
 
 
+def run_dp_overhead(args, dev):
+    """What the data-parallel machinery costs on ONE GPU (a multi-GPU node is not available to the
+    builder): the B = 32 training step on a 1-rank `nccl` process group with the DP path forced on — SyncBatchNorm messages
+    through torch.distributed (RCCL), ~25 MB gradient buckets prepared and all-reduced on the third stream as the backward
+    pass completes them, the clip-flag host read — against the plain single-replica step: two engines in ONE process,
+    alternating rounds.  `without_flag_read` prices the one host read per step (`TrainEngine._overlap_finish`)."""
+    import socket
+    from retinanet.cfg import default_params
+    from retinanet.dataloader import LabelEncoder
+    from retinanet.model import ModelBuilder
+    from retinanet.model.train_engine import TrainEngine
+    own_pg = not dist.is_initialized()
+    if own_pg:
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        B = args.train_batch
+        params = default_params(input_size=args.size, batch_train=B)
+        builder = ModelBuilder(params, "train", device=dev, seed=1337)
+        model = builder()
+        rx = [builder.FREEZE_VARS_REGEX[n] for n in params.training.freeze_variables]
+        enc = LabelEncoder(params, device=dev)
+        gb, gc, cnt = [t.to(dev) for t in synth_ground_truth(B, args.size, 1337)]
+        images = torch.randn((B, args.size, args.size, 3), generator=torch.Generator().manual_seed(1337)).to(dev)
+        engs = {"plain": TrainEngine(model, B, frozen_regexes=rx, world_size=1, force_dp=False),
+                "dp": TrainEngine(model, B, frozen_regexes=rx, world_size=1, force_dp=True)}
+
+        def run(name, n, no_read=False):
+            eng = engs[name]
+            eng.price_without_flag_read = no_read
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                out = eng.train_step(images, enc.encode_batch(gb, gc, cnt))
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n * 1e3, out
+        for name in engs:
+            run(name, 3)
+        rounds = {"plain": [], "dp": [], "dp_without_flag_read": []}
+        for _ in range(4):
+            rounds["plain"].append(run("plain", 5)[0])
+            ms, out = run("dp", 5)
+            rounds["dp"].append(ms)
+            rounds["dp_without_flag_read"].append(run("dp", 5, no_read=True)[0])
+        med = {k: float(np.median(v)) for k, v in rounds.items()}
+        eng = engs["dp"]
+        return {"workload": f"ResNet50-{args.size} bf16 training step, {B} images, ONE GPU: plain step vs the same step with the "
+                            "data-parallel path forced on over a 1-rank nccl (RCCL) group — SyncBN messages, bucketed gradient "
+                            "all-reduce overlapped with the backward pass (RNET_C1_OVERLAP default), clip-flag host read",
+                "ms_per_step": round(med["dp"] - med["plain"], 3), "plain_ms": round(med["plain"], 3), "dp_ms": round(med["dp"], 3),
+                "dp_without_flag_read_ms": round(med["dp_without_flag_read"], 3),
+                "flag_read_ms": round(med["dp"] - med["dp_without_flag_read"], 3),
+                "syncbn_messages_per_step": eng.syncbn_messages_per_step, "gradient_buckets": len(getattr(eng, "_buckets", []) or []),
+                "clip_fired_last_step": bool(getattr(eng, "clip_fired", False)),
+                "rounds_ms": {k: [round(x, 3) for x in v] for k, v in rounds.items()},
+                "protocol": "two engines in one process, 3 warm-up steps each, 4 alternating rounds of 5 steps, medians",
+                "note": "one rank: RCCL moves no bytes over xGMI; this is the enqueue / kernel / stream-hop cost of the machinery"}
+    finally:
+        if own_pg:
+            dist.destroy_process_group()
+
+
 def run_extras(args, dev):
     """Driver-visible numbers for BASELINE configs[3] and configs[4] on one GPU: a few training steps of
     ResNet50-1024x1024 (bf16, 16 images: the HBM-bound FPN path) and of EfficientNet-B3 640x640 under its own policy
@@ -797,6 +861,11 @@ def main():
                 line["extra"] = run_extras(args, dev)
             except Exception as e:   # noqa: BLE001 — the headline line must survive a failure in the side measurements
                 line["extra"] = {"error": f"{type(e).__name__}: {e}"}
+            try:
+                line["extra"]["dp_overhead"] = run_dp_overhead(args, dev)
+            except Exception as e:   # noqa: BLE001
+                line["extra"]["dp_overhead"] = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.empty_cache()
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(p_train, m_train, frozen, p_inf, m_inf)
     if rank == 0:

@@ -89,7 +89,11 @@ class InferenceEngine:
             self.splitk_ws = _C.new_splitk_workspace(self.lib, self.dev, default_on=True)
             # second stream (see _side_launch): its conv launches need a split-K workspace of their own — launches
             # that share one must be ordered on one stream
-            self.two_streams = os.environ.get("RNET_INFER_STREAMS", "2") != "1"
+            # Measured (round 5, one box, tools/bench_infer.py): batch 8 3.554 -> 3.512 ms; batch 1 1.572 -> 1.594 ms — at
+            # batch 1 a fork / join pair costs more than the ~15 us launch it takes off the chain, so the default is two
+            # streams from batch 4 up.  RNET_INFER_STREAMS=1 / 2 forces either.
+            ns = os.environ.get("RNET_INFER_STREAMS", "")
+            self.two_streams = (ns == "2") if ns in ("1", "2") else self.B >= 4
             self.splitk_ws_side = (_C.new_splitk_workspace(self.lib, self.dev, default_on=True)
                                    if self.two_streams else None)
             self.side_steps = set()   # names of the launches that go to the second stream

@@ -49,10 +49,18 @@ def _ohwi_to_hwio(w):
 
 class TrainEngine:
     def __init__(self, model, batch_size, frozen_regexes=(), process_group=None, world_size=None, frozen_names=(),
-                 launch_opts=None):
+                 launch_opts=None, wide_pred_terms=None, force_dp=None):
         """launch_opts: `_C.LaunchOpts` (or a dict of its fields) copied into every rn_conv_problem / rn_wgrad_problem of
         THIS engine (include/rnet_hip.h rn_launch_opts) — kernel-family overrides for tests and A/B timing; the library
-        has no process-wide knobs."""
+        has no process-wide knobs.
+        wide_pred_terms: bf16 weight planes the TRAINING forward of the wide dtype=float32 prediction conv (the class
+        head's 720-channel layer, detection_head.py:80-88) multiplies by — 2 = the split-bf16 form of its f32 kernel
+        (inference / export always use it), 1 = rb(w) only.  Default: RNET_TRAIN_PRED_W_TERMS, else
+        params.training.prediction_weight_planes, else 2 (the measured A/B and the deviation).
+        force_dp (default RNET_FORCE_DP=1): run the data-parallel machinery — SyncBN messages, the bucketed gradient
+        all-reduce overlapped with the backward pass, the clip flag read — although this engine has ONE replica, over
+        whatever process group it was given (a 1-rank `nccl` group: bench.py's `extra.dp_overhead`, the cost of that
+        machinery on one GPU; losses and gradients equal the plain step's)."""
         self.model = model
         self.g = model.graph
         self.params_cfg = model.params
@@ -72,16 +80,24 @@ class TrainEngine:
         self.world = int(world_size)
         bn = self.params_cfg.architecture.batch_norm
         self.eps, self.momentum_bn = float(bn.epsilon), float(bn.momentum)
-        self.sync_bn = bool(bn.use_sync) and self.world > 1
+        if force_dp is None:
+            force_dp = os.environ.get("RNET_FORCE_DP", "0") == "1"
+        self.dp_active = self.world > 1 or bool(force_dp)    # collectives are issued (over 1 rank when forced)
+        self.sync_bn = bool(bn.use_sync) and self.dp_active
         if isinstance(launch_opts, dict):
             launch_opts = _C.LaunchOpts(**launch_opts)
         self.launch_opts = launch_opts.copy() if launch_opts is not None else _C.LaunchOpts()
         # data parallel: the persistent kernels leave a few CUs to RCCL (rn_launch_opts.reserved_cus)
-        if self.world > 1 and not self.launch_opts.reserved_cus:
+        if self.dp_active and not self.launch_opts.reserved_cus:
             self.launch_opts.reserved_cus = int(os.environ.get("RNET_COMM_CUS", "8"))
         # the per-device handle (rn_create): device, CU count, this engine's launch defaults; owns the native communicators
         self.handle = _C.Handle(self.lib, self.dev.index if self.dev.index is not None else torch.cuda.current_device(),
                                 self.launch_opts)
+        if wide_pred_terms is None:
+            wide_pred_terms = os.environ.get("RNET_TRAIN_PRED_W_TERMS") or \
+                getattr(getattr(model.params, "training", None), "prediction_weight_planes", None) or _C.PRED_W_TERMS
+        self.wide_pred_terms = max(1, min(int(wide_pred_terms), _C.PRED_W_TERMS))
+        self._pair_cache = {}
         self.frozen = set(frozen_names)
         for k in model.variables:
             if any(rx.search(k) for rx in frozen_regexes):
@@ -252,14 +268,14 @@ class TrainEngine:
                 c = self.g.convs[layer]
                 if c["cin"] == 3:
                     pass                                        # first-layer conv: its own packed form
-                elif layer in f32_convs and _C.PRED_W_TERMS > 1:
+                elif layer in f32_convs and self._f32_terms(layer) > 1:
                     cinp = lib.rn_conv_cin_pad(c["cin"])        # detection_head.py:80-88: the layer keeps its f32 kernel
                     if self._pair_form(layer):                  # narrow layer (box prediction): the planes along Cout
                         buf = torch.zeros((lib.rn_conv_pair_rows(c["cout"]), c["k"], c["k"], cinp), dtype=self.h16,
                                           device=self.dev)
                         self.pair_packs.add(layer)
                     else:
-                        buf = torch.zeros((lib.rn_conv_cout_pad(c["cout"]), c["k"], c["k"], _C.PRED_W_TERMS * cinp),
+                        buf = torch.zeros((lib.rn_conv_cout_pad(c["cout"]), c["k"], c["k"], self._f32_terms(layer) * cinp),
                                           dtype=self.h16, device=self.dev)
                     self.split_packs.append((k, c, cinp, buf))
                     self.split_pack_of[layer] = buf
@@ -359,8 +375,8 @@ class TrainEngine:
                                                            c["cout"], cinp, buf.data_ptr(), st), "rn_pack_conv_weight_pair")
                 continue
             _C.check(self.lib.rn_pack_conv_weight_split(self.P.data_ptr() + 4 * off, 1, c["k"], c["k"], c["cin"],
-                                                        c["cout"], cinp, _C.PRED_W_TERMS, buf.data_ptr(), st),
-                     "rn_pack_conv_weight_split")
+                                                        c["cout"], cinp, self._f32_terms(self.var_kind[kname][1]),
+                                                        buf.data_ptr(), st), "rn_pack_conv_weight_split")
 
     def refresh_stem_pack(self):
         self.refresh_packs()
@@ -607,7 +623,19 @@ class TrainEngine:
             return self.split_pack_of[cname].data_ptr()
         return self.Pbf.data_ptr() + 2 * self.bf_off[cname]
 
+    def _f32_terms(self, layer):
+        """bf16 weight planes of the dtype=float32 conv `layer` in THIS engine's forward pass: the narrow (pair-form)
+        layers always carry both planes, the wide one `wide_pred_terms`"""
+        if _C.PRED_W_TERMS <= 1:
+            return 1
+        return _C.PRED_W_TERMS if self._pair_form(layer) else self.wide_pred_terms
+
     def _pair_form(self, layer):
+        if layer not in self._pair_cache:
+            self._pair_cache[layer] = self._pair_form_uncached(layer)
+        return self._pair_cache[layer]
+
+    def _pair_form_uncached(self, layer):
         """True when the f32 conv `layer` (one kernel shared by the pyramid levels of a grouped launch) is narrow enough that
         its two weight planes go along Cout (rn_conv_segment.w_pair): 36 box-regression channels fill 72 of the 128 columns
         of the halo kernel's 512 x 128 tiles; along Cin they were a 64-column tile of the 128-row kernel at 2 x the K depth."""
@@ -655,7 +683,7 @@ class TrainEngine:
                 s.bias = bs.data_ptr() if bs is not None else None
             if not raw_mode:
                 s.residual = self.t[op["residual"]].data_ptr() if op.get("residual") else None
-            s.w_terms = _C.PRED_W_TERMS if op["conv"] in self.split_pack_of and op["conv"] not in self.pair_packs else 1
+            s.w_terms = self._f32_terms(op["conv"]) if op["conv"] in self.split_pack_of and op["conv"] not in self.pair_packs else 1
             s.w_pair = 1 if op["conv"] in self.pair_packs else 0
             s.N, s.H, s.W, s.Cin, s.pix_stride = self.B, x.shape[1], x.shape[2], c["cin"], x.shape[3]
             s.Ho, s.Wo, s.Cout = y.shape[1], y.shape[2], c["cout"]
@@ -1754,7 +1782,7 @@ class TrainEngine:
         """True when this backward pass launches the gradient all-reduce bucket by bucket (world > 1, or forced
         with RNET_C1_OVERLAP=1 for the single-replica equivalence test)."""
         mode = os.environ.get("RNET_C1_OVERLAP", "auto")
-        on = self._train_step_active and (mode == "1" or (mode != "0" and self.world > 1))
+        on = self._train_step_active and (mode == "1" or (mode != "0" and self.dp_active))
         self._overlap_works = []
         self._overlap_on = on
         if not on:
@@ -1764,7 +1792,7 @@ class TrainEngine:
             self._comm_stream = torch.cuda.Stream(self.dev)
             self._comm_events = [(torch.cuda.Event(), torch.cuda.Event()) for _ in self._buckets]
             self.L = torch.zeros_like(self.G)      # what this rank contributed (for the clip correction)
-            if self.world > 1:
+            if self.dp_active:
                 import torch.distributed as dist
                 # its own communicator: the latency-bound SyncBN all-reduces of the main stream must not queue
                 # behind a 25 MB bucket on the same RCCL stream
@@ -1798,7 +1826,7 @@ class TrainEngine:
                 _C.check(lib.rn_optim_clip_factors(self.segs_dev.data_ptr(), self.n_segs, self.n_blocks, a["clip"],
                                                    a["alpha"], self.metrics.data_ptr(), self.G.data_ptr(),
                                                    self.opt_ws.data_ptr(), self.opt_ws.numel(), cst), "rn_optim_clip_factors")
-            if self.world > 1:
+            if self.dp_active:
                 import torch.distributed as dist
                 self._overlap_works.append(dist.all_reduce(self.G[bkt["begin"]:bkt["end"]], group=self.pg_c1,
                                                            async_op=True))
@@ -1811,7 +1839,10 @@ class TrainEngine:
         for w in self._overlap_works:
             w.wait()
         cur.wait_stream(self._comm_stream)
-        fired = float(self.G[0].item()) != 0.0      # one host sync per step: the collective below is conditional
+        if getattr(self, "price_without_flag_read", False):
+            fired = False                            # bench.py's extra.dp_overhead ONLY: what the host read below costs
+        else:
+            fired = float(self.G[0].item()) != 0.0      # one host sync per step: the collective below is conditional
         self.clip_fired = fired
         if not fired:
             return
@@ -1820,9 +1851,9 @@ class TrainEngine:
                                               self.block_seg_dev.data_ptr(), self.n_blocks, self.opt_ws.data_ptr(),
                                               self.opt_ws.numel(), st), "rn_optim_clip_apply")
         self.L[:4].zero_()
-        if self.world > 1:
+        if self.dp_active:
             from retinanet.distribute import all_reduce_sum_bucketed
-            all_reduce_sum_bucketed(self.L, self.world, self.pg)
+            all_reduce_sum_bucketed(self.L, 2 if self.world == 1 else self.world, self.pg)   # (forced: issue it anyway)
         self.G[4:].add_(self.L[4:])
 
     def optimizer_step(self, lr, momentum, clipnorm, wd_alpha, ema_decay, nesterov=False, overlapped=False):
@@ -1843,9 +1874,9 @@ class TrainEngine:
             if self.loss_scale:
                 self.G[1:2].copy_(self.metrics[5:6])
                 skip = self.G.data_ptr() + 4
-            if self.world > 1:
+            if self.dp_active:
                 from retinanet.distribute import all_reduce_sum_bucketed
-                all_reduce_sum_bucketed(self.G, self.world, self.pg)   # executor.py:436-437: SUM after clipping
+                all_reduce_sum_bucketed(self.G, 2 if self.world == 1 else self.world, self.pg)   # executor.py:436-437: SUM after clipping
         _C.check(lib.rn_optim_sgd_step(self.P.data_ptr(), self.G.data_ptr(), self.V.data_ptr(),
                                        self.E.data_ptr() if ema_decay is not None else None, self.Pbf.data_ptr(),
                                        self.segs_dev.data_ptr(), self.block_seg_dev.data_ptr(), self.n_blocks,

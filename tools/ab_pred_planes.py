@@ -1,0 +1,112 @@
+"""A/B of the class-prediction conv's weight planes in TRAINING.
+
+The reference builds the prediction convs with dtype=float32 (detection_head.py:80-88); the engine carries their f32 kernels as
+two bf16 planes (w = rb(w) + rb(w - rb(w)): 16 mantissa bits, rn_conv_segment.w_terms = 2), which makes the 720-channel class
+prediction launch twice the MFMA work of a bf16 layer.  This tool measures, on the bench's B = 32 batch at the reference's
+initialisation, what ONE plane (rb(w) only) changes in the training step:
+  * class logits, class-loss, box-loss (the 1e-5 loss contract of north_star is "given identical logits": here the logits move);
+  * cosine / relative norm of the weight gradients (class head prediction kernel, the head towers, the whole arena);
+  * step time, alternating rounds of full train steps of both engines in ONE process.
+Usage (GPU box): python tools/ab_pred_planes.py [--batch 32] [--steps 10]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "retinanet-tensorflow2.x_amd"))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from bench import synth_ground_truth  # noqa: E402
+
+
+def grads_once(eng, model, images, targets):
+    with torch.cuda.device(eng.dev):
+        eng._step_args = dict(wdc=0.0, alpha=0.0, unscale=1.0, clip=0.0)
+        eng._prepack_dgrad_weights()
+        eng._small_msgs = 0
+        eng._c2_local, eng._c2_sent, eng.c2_normalizer = None, False, None
+        preds = eng.forward(images)
+        logits = {l: preds["class-predictions"][l].clone() for l in preds["class-predictions"]}
+        loss = model.loss(targets, preds, compute_grads=True, grad_scale=1.0, grads_bf16=eng.loss_grad_buffers(),
+                          normalizer=None)
+        eng._train_step_active = True
+        try:
+            eng.backward(None)
+        finally:
+            eng._train_step_active = False
+        torch.cuda.synchronize()
+    return logits, {k: float(v) for k, v in loss.items() if torch.is_tensor(v) and v.numel() == 1}, eng.G.clone()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--steps", type=int, default=10)
+    a = ap.parse_args()
+    from retinanet.cfg import default_params
+    from retinanet.dataloader import LabelEncoder
+    from retinanet.model import ModelBuilder
+    from retinanet.model.train_engine import TrainEngine
+    dev = torch.device("cuda:0")
+    B = a.batch
+    params = default_params(input_size=a.size, batch_train=B)
+    builder = ModelBuilder(params, "train", device=dev, seed=1337)
+    model = builder()
+    rx = [builder.FREEZE_VARS_REGEX[n] for n in params.training.freeze_variables]
+    enc = LabelEncoder(params, device=dev)
+    gb, gc, cnt = [t.to(dev) for t in synth_ground_truth(B, a.size, 1337)]
+    images = torch.randn((B, a.size, a.size, 3), generator=torch.Generator().manual_seed(1337)).to(dev)
+    targets = enc.encode_batch(gb, gc, cnt)
+    engs = {t: TrainEngine(model, B, frozen_regexes=rx, world_size=1, wide_pred_terms=t) for t in (2, 1)}
+    res = {}
+    for t, eng in engs.items():
+        res[t] = grads_once(eng, model, images, targets)
+    (lg2, loss2, g2), (lg1, loss1, g1) = res[2], res[1]
+    out = {"batch": B, "loss_two_planes": loss2, "loss_one_plane": loss1}
+    for k in ("class-loss", "box-loss", "weighted-loss"):
+        if k in loss2 and loss2[k]:
+            out[f"rel_diff_{k}"] = abs(loss1[k] - loss2[k]) / abs(loss2[k])
+    d = torch.cat([(lg1[l] - lg2[l]).reshape(-1) for l in lg2]).double()
+    ref = torch.cat([lg2[l].reshape(-1) for l in lg2]).double()
+    out["logits"] = {"max_abs_diff": d.abs().max().item(), "rms_diff": d.pow(2).mean().sqrt().item(),
+                     "std_of_logits": ref.std().item(), "mean_of_logits": ref.mean().item()}
+    eng = engs[2]
+
+    def cmp(sel):
+        x, y = g2[sel].double(), g1[sel].double()
+        return {"cosine": (x @ y / (x.norm() * y.norm() + 1e-300)).item(), "norm_ratio": (y.norm() / (x.norm() + 1e-300)).item(),
+                "norm": x.norm().item()}
+    groups = {"class-head prediction kernel": [k for k in eng.p_off if "class-head-prediction" in k and k.endswith("kernel")],
+              "class-head tower kernels": [k for k in eng.p_off if k.startswith("class-head/") and "prediction" not in k and k.endswith("kernel")],
+              "box-head kernels": [k for k in eng.p_off if k.startswith("box-head/") and k.endswith("kernel")],
+              "fpn kernels": [k for k in eng.p_off if k.startswith("fpn") and k.endswith("kernel")]}
+    out["gradients"] = {}
+    for name, keys in groups.items():
+        if not keys:
+            continue
+        idx = torch.cat([torch.arange(eng.p_off[k][0], eng.p_off[k][0] + eng.p_off[k][1], device=dev) for k in keys])
+        out["gradients"][name] = cmp(idx)
+    out["gradients"]["whole arena"] = cmp(slice(4, None))
+    # step time: alternating rounds of full train steps (weights drift apart, the timing does not care)
+    times = {2: [], 1: []}
+    for t in (2, 1):
+        for _ in range(3):
+            engs[t].train_step(images, enc.encode_batch(gb, gc, cnt))
+    torch.cuda.synchronize()
+    for r in range(4):
+        for t in (2, 1):
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                engs[t].train_step(images, enc.encode_batch(gb, gc, cnt))
+            torch.cuda.synchronize()
+            times[t].append((time.perf_counter() - t0) / a.steps * 1e3)
+    out["ms_per_step"] = {"two_planes": [round(v, 3) for v in times[2]], "one_plane": [round(v, 3) for v in times[1]]}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
