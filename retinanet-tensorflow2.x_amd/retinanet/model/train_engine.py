@@ -56,7 +56,11 @@ class TrainEngine:
         wide_pred_terms: bf16 weight planes the TRAINING forward of the wide dtype=float32 prediction conv (the class
         head's 720-channel layer, detection_head.py:80-88) multiplies by — 2 = the split-bf16 form of its f32 kernel
         (inference / export always use it), 1 = rb(w) only.  Default: RNET_TRAIN_PRED_W_TERMS, else
-        params.training.prediction_weight_planes, else 2 (the measured A/B and the deviation).
+        params.training.prediction_weight_planes, else 1 — round 5 measured on the bench batch (tools/ab_pred_planes.py,
+        profiles/r05_ab/ab_pred_planes.json): class-loss moves by 3.1e-7 relative (the contract is 1e-5), every weight-
+        gradient group keeps a cosine > 0.99999 with the two-plane step, the step gains 0.58 ms (1.9 %).  The deviation
+        from the reference's f32 layer is documented in DESIGN.md section 6; the narrow box-regression layer keeps both
+        planes (its pair form costs 0.1 ms and its Huber loss has delta = 0.1).
         force_dp (default RNET_FORCE_DP=1): run the data-parallel machinery — SyncBN messages, the bucketed gradient
         all-reduce overlapped with the backward pass, the clip flag read — although this engine has ONE replica, over
         whatever process group it was given (a 1-rank `nccl` group: bench.py's `extra.dp_overhead`, the cost of that
@@ -95,7 +99,7 @@ class TrainEngine:
                                 self.launch_opts)
         if wide_pred_terms is None:
             wide_pred_terms = os.environ.get("RNET_TRAIN_PRED_W_TERMS") or \
-                getattr(getattr(model.params, "training", None), "prediction_weight_planes", None) or _C.PRED_W_TERMS
+                getattr(getattr(model.params, "training", None), "prediction_weight_planes", None) or 1
         self.wide_pred_terms = max(1, min(int(wide_pred_terms), _C.PRED_W_TERMS))
         self._pair_cache = {}
         self.frozen = set(frozen_names)
@@ -1789,7 +1793,16 @@ class TrainEngine:
             return False
         if getattr(self, "_buckets", None) is None:
             self._plan_buckets()
-            self._comm_stream = torch.cuda.Stream(self.dev)
+            # Which stream prepares a bucket and hands it to RCCL.  Round 3 used a third stream of its own; round 5 measured
+            # (tools/probes/dp_overlap_trace.py, 1-rank nccl group on one MI355X, rocprofv3 kernel trace) that HIP mapped
+            # it onto the SAME hardware queue as the weight-gradient stream: a bucket's "wait for the main stream" packet
+            # then sat in front of weight-gradient kernels that had nothing to wait for — 2.3 ms of chip idle per step
+            # against 0.7 ms, step 34.4 ms against 31.4 ms for the plain order (and 44 ms with GPU_MAX_HW_QUEUES=8) — the
+            # overlap machinery cost more than the all-reduce it hides.  Now the bucket work rides on the weight-gradient
+            # stream itself (most of a bucket's producers are there; it waits for the main stream's BatchNorm gamma / beta
+            # gradients through one event per bucket) or, in the one-stream backward, on the main stream: no extra queue.
+            # RNET_C1_STREAM=own restores the third stream (A/B on a multi-GPU node).
+            self._comm_stream = torch.cuda.Stream(self.dev) if os.environ.get("RNET_C1_STREAM", "side") == "own" else None
             self._comm_events = [(torch.cuda.Event(), torch.cuda.Event()) for _ in self._buckets]
             self.L = torch.zeros_like(self.G)      # what this rank contributed (for the clip correction)
             if self.dp_active:
@@ -1807,11 +1820,18 @@ class TrainEngine:
     def _launch_bucket(self, j, main, side):
         lib, bkt, comm = self.lib, self._buckets[j], self._comm_stream
         e_main, e_side = self._comm_events[j]
-        e_main.record(main)
-        comm.wait_event(e_main)
-        if side is not None:
-            e_side.record(side)
-            comm.wait_event(e_side)
+        if comm is None:             # the weight-gradient stream (or the only stream) carries the bucket work
+            comm = side if side is not None else main
+            if side is not None:
+                e_main.record(main)
+                side.wait_event(e_main)
+        else:
+            e_main.record(main)
+            comm.wait_event(e_main)
+            if side is not None:
+                e_side.record(side)
+                comm.wait_event(e_side)
+        self._bucket_stream = comm
         cst = ctypes.c_void_p(comm.cuda_stream)
         a = self._step_args
         with torch.cuda.stream(comm):
@@ -1838,7 +1858,8 @@ class TrainEngine:
         cur = torch.cuda.current_stream(self.dev)
         for w in self._overlap_works:
             w.wait()
-        cur.wait_stream(self._comm_stream)
+        if getattr(self, "_bucket_stream", None) is not None and self._bucket_stream != cur:
+            cur.wait_stream(self._bucket_stream)
         if getattr(self, "price_without_flag_read", False):
             fired = False                            # bench.py's extra.dp_overhead ONLY: what the host read below costs
         else:
