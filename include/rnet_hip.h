@@ -322,6 +322,12 @@ int rn_conv_cout_pad(int Cout);
  * conv_halo_kernel's 512x128 form (3x3, 64 < Cout <= 128), 128 = conv_fwd_kernel<128,...>; 0 on a malformed problem.  A
  * launch with fused BatchNorm partial sums writes (rows / 128) * ceil(N*Ho*Wo / rows) 128-pixel row blocks per segment. */
 int rn_conv_tile_rows(const rn_conv_problem* problem);
+/* 128-pixel row blocks of fused BatchNorm partial sums (rn_conv_segment.bn_partial / bn_bwd_y) the launch writes for
+ * `segment` — what rn_bn_segment.ext_chunks / ext_chunks_bwd must be set to.  (rows / 128) * ceil(N*Ho*Wo / rows) with
+ * rows = rn_conv_tile_rows(), except for conv_big_kernel launches that run BALANCED tiles (HBM-bound single-segment 1x1
+ * layers whose 256-row tiles would leave the last round of the persistent grid mostly idle are cut into tiles of fewer
+ * rows, same number of rounds: two blocks per tile, the second one short).  0 on a malformed problem. */
+int rn_conv_bn_row_blocks(const rn_conv_problem* problem, int segment);
 /* Which kernel rn_conv2d_nhwc_fwd runs for `problem`: 0 = 128-row tiles (conv_fwd_kernel), 1 = conv_big_kernel
  * (256 x 256 x 32, persistent), 2 = conv_halo_kernel (256 x 256 x 32 for 3x3 / stride 1 / pad 1: pixels staged
  * once per channel chunk as a halo patch), 3 = conv_halo_kernel with 512 x 128 tiles (the same for 64 < Cout <= 128).

@@ -665,6 +665,38 @@ static int conv128_split_parts(const rn_conv_problem* p, int tiles, int BN, int 
   return S >= 2 ? S : 1;
 }
 
+// Balanced tiles for conv_big_kernel's HBM-bound 1x1 launches.  The persistent grid walks its 256-row tiles in rounds of one
+// per workgroup; a launch of 3.1 rounds runs as 4 with most of the chip idle in the last one (ResNet stage 3 `*_out` at
+// B = 32: 800 tiles on 256 workgroups), and a tile's time there is set by its bytes, not by its MFMAs (four to sixteen K
+// steps between a pipeline refill and a 128 KB epilogue).  A 1x1 tile's rows are independent, so the SAME number of rounds
+// can be cut finer: rows = ceil(M / floor(rounds * grid / column tiles)) pixels per tile instead of 256 — every workgroup
+// then walks `rounds` tiles of rows/256 of the bytes each (the rows a tile does not cover are masked: zero-filled by the
+// DMA, never stored; their MFMAs run on zeros).  The busiest workgroup of the 256-row plan keeps its tile count and moves
+// fewer bytes; nobody moves more.  Single-segment 1x1 / stride 1 launches only, shallow enough that bytes set the pace
+// (K <= 512), and only when it shortens the tiles by 8 % or more; opts.conv_tile / conv_big_min_tiles / max_workgroups
+// (tests, A/B) keep whole tiles.  Results are the same values: a tile's accumulation order does not depend on its rows.
+// Returns the rows per tile, 0 = whole 256-row tiles.  The fused BatchNorm partial sums are still written per (tile,
+// half): rn_conv_bn_row_blocks() tells how many 128-row blocks a segment writes.
+static int conv_big_balanced_rows(const rn_conv_problem* p) {
+  if (p->num_segments != 1 || p->R != 1 || p->S != 1 || p->stride_h != 1 || p->stride_w != 1) return 0;
+  if (p->opts.conv_tile || p->opts.conv_big_min_tiles || p->opts.max_workgroups || p->splitk_ws) return 0;
+  const rn_conv_segment& s = p->seg[0];
+  const int terms = s.w_terms > 1 ? s.w_terms : 1;
+  if (terms * rn_conv_cin_pad(s.Cin) > 512) return 0;
+  const long long M = (long long)s.N * s.Ho * s.Wo;
+  const int n_tiles = (int)rn_cdiv(rn_conv_cout_pad(seg_cols(s)), 256);
+  const int G = rn_persistent_grid(0x7fffffff, rn_num_cus(), p->opts);
+  const long long T = rn_cdiv(M, 256) * n_tiles;
+  if (T <= 0 || G <= 0) return 0;
+  const long long rounds = rn_cdiv(T, G);
+  const long long m_tiles = rounds * G / n_tiles;   // row blocks that fit `rounds` rounds
+  if (m_tiles < 1) return 0;
+  long long rows = rn_cdiv(M, m_tiles);
+  rows = (rows + 3) / 4 * 4;
+  if (rows < 64 || rows > 236) return 0;            // (236 = 0.92 * 256)
+  return (int)rows;
+}
+
 int rn_splitk_plan(ConvArgs& a, int min_chunks, void* ws, long long ws_bytes, const rn_launch_opts& opts) {
   const int total = a.total_tiles;
   a.split_f = total; a.split_s = 1; a.vtotal = total; a.pad2_ = 0; a.ws = nullptr;
@@ -721,6 +753,18 @@ extern "C" int rn_conv_kernel_id(const rn_conv_problem* p) {
   return conv_pick(p);
 }
 
+extern "C" int rn_conv_bn_row_blocks(const rn_conv_problem* p, int segment) {
+  if (!p || p->num_segments < 1 || p->num_segments > RN_CONV_MAX_SEGMENTS || segment < 0 || segment >= p->num_segments) return 0;
+  const int kid = conv_pick(p);
+  const long long M = (long long)p->seg[segment].N * p->seg[segment].Ho * p->seg[segment].Wo;
+  if (kid == 1) {
+    const int r = conv_big_balanced_rows(p);
+    if (r) return (int)(2 * rn_cdiv(M, r));
+  }
+  const int rows = kid == 3 ? 512 : (kid ? 256 : 128);
+  return (int)((rows / 128) * rn_cdiv(M, rows));
+}
+
 extern "C" int rn_conv_tile_rows(const rn_conv_problem* p) {
   if (!p || p->num_segments < 1 || p->num_segments > RN_CONV_MAX_SEGMENTS) return 0;
   const int kid = conv_pick(p);
@@ -757,6 +801,7 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
     conv128_shape(p, &BN, &bk_);
   }
   const int BNT = big ? 256 : BN;   // n-tile width
+  const int bal_rows = kid == 1 ? conv_big_balanced_rows(p) : 0;
   int tiles = 0;
   // conv_big_kernel launch whose segments are all one column tile wide but differ 2x or more in K depth (the FPN lateral 1x1
   // convs: 512 / 1024 / 2048 input channels): tiles numbered deepest segment first and dealt to the workgroups round-robin
@@ -821,7 +866,8 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
     d.bias = s.bias;
     d.N = s.N; d.H = s.H; d.W = s.W; d.Cin = s.Cin; d.pix_stride = s.pix_stride;
     d.Ho = s.Ho; d.Wo = s.Wo; d.Cout = seg_cols(s);
-    d.pair_cout = s.w_pair ? s.Cout : 0; d.pad_ = 0;
+    d.pair_cout = s.w_pair ? s.Cout : 0;
+    d.rows = kid == 1 ? bal_rows : 0;   // conv_big_kernel: balanced tiles (single-segment launches only)
     d.M = (int)M;
     d.tile_begin = tiles;
     d.n_tiles = (int)rn_cdiv(cp, BNT);
@@ -832,7 +878,7 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
     d.halo_pitch = s.W + 1;
     if (rn_conv_halo_patch_pixels(s.N, s.H, s.W, rn_conv_halo_pitch(s.W), halo512 ? 512 : 256) <= rn_conv_halo_capacity(halo512 ? 512 : 256))
       d.halo_pitch = rn_conv_halo_pitch(s.W);
-    tiles += (int)rn_cdiv(M, BM) * d.n_tiles;
+    tiles += (int)rn_cdiv(M, d.rows ? d.rows : BM) * d.n_tiles;
   }
   a.total_tiles = tiles;
   a.split_f = a.vtotal = tiles; a.split_s = 1; a.pad2_ = 0; a.ws = nullptr;

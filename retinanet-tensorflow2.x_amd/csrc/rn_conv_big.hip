@@ -67,7 +67,9 @@ __global__ void __launch_bounds__(512) conv_big_kernel(const ConvArgs args) {
     const ConvSegDev& sg__ = args.seg[si__];                                                          \
     const int lt__ = tile__ - sg__.tile_begin;                                                        \
     const int mt__ = rn_fdiv(lt__, sg__.n_tiles, rn_rcp((float)sg__.n_tiles)); /* < 2^22 tiles */  \
-    const int m0__ = mt__ * BM, n0__ = (lt__ - mt__ * sg__.n_tiles) * BN;                             \
+    const int rows_t__ = sg__.rows ? sg__.rows : BM;     /* pixels a tile covers (balanced tiles: < 256) */ \
+    const int m0__ = mt__ * rows_t__, n0__ = (lt__ - mt__ * sg__.n_tiles) * BN;                       \
+    const int mend__ = m0__ + rows_t__ < sg__.M ? m0__ + rows_t__ : sg__.M;                           \
     i_W = sg__.W; i_PS = sg__.pix_stride; i_Cin = sg__.CinP; i_cw = sg__.cwrap;                       \
     const int H__ = sg__.H, Ktot__ = RS * i_Cin;                                                      \
     const int rows__ = sg__.Cout <= 64 ? 64 : ((sg__.Cout + 127) / 128) * 128; /* packed weight rows */ \
@@ -80,7 +82,7 @@ __global__ void __launch_bounds__(512) conv_big_kernel(const ConvArgs args) {
       const int row = (j * NW + wave) * 16 + d_row;                                                   \
       const int chunk = d_pos ^ lds_swz<BK>(row);                                                     \
       const int m = m0__ + row;                                                                       \
-      const int mm = m < sg__.M ? m : 0;                                                              \
+      const int mm = m < mend__ ? m : 0;                                                              \
       int ox, oy, n;                                                                                  \
       if (args.pad_ & 1) {   /* every M < 2^22: float-reciprocal division (~8 VALU instead of ~45 each) */ \
         const int t2 = rn_fdiv(mm, sg__.Wo, rWo__);                                                   \
@@ -96,7 +98,7 @@ __global__ void __launch_bounds__(512) conv_big_kernel(const ConvArgs args) {
       const int iy0 = oy * args.sh - args.pt, ix0 = ox * args.sw - args.pl;                           \
       a_off[j] = (unsigned)(((((long long)n * H__ + iy0) * i_W + ix0) * i_PS + chunk * 8) * 2);       \
       unsigned mask = 0;                                                                              \
-      if (m < sg__.M) {                                                                               \
+      if (m < mend__) {                                                                               \
         for (int r = 0; r < R; ++r)                                                                   \
           for (int s = 0; s < S; ++s) {                                                               \
             const bool ok = (unsigned)(iy0 + r) < (unsigned)H__ && (unsigned)(ix0 + s) < (unsigned)i_W; \
@@ -200,7 +202,7 @@ __global__ void __launch_bounds__(512) conv_big_kernel(const ConvArgs args) {
   // ---- compute side: the tile being accumulated --------------------------------------------------
   int c_v = blockIdx.x;   // virtual id
   int c_k = 0;            // K steps of it already accumulated
-  int c_ksteps, c_m0, c_n0, c_si;
+  int c_ksteps, c_m0, c_n0, c_si, c_mend, c_chunk0;   // c_mend: end of the tile's rows; c_chunk0: its first 128-row block
 #define BIG_SETUP_COMPUTE()                                                                           \
   do {                                                                                                \
     const int tile__ = (args.pad_ & 2) ? c_v : tile_of(c_v, total);                                   \
@@ -210,7 +212,10 @@ __global__ void __launch_bounds__(512) conv_big_kernel(const ConvArgs args) {
     const ConvSegDev& sg__ = args.seg[c_si];                                                          \
     const int lt__ = tile__ - sg__.tile_begin;                                                        \
     const int mt__ = rn_fdiv(lt__, sg__.n_tiles, rn_rcp((float)sg__.n_tiles)); /* < 2^22 tiles */  \
-    c_m0 = mt__ * BM;                                                                                 \
+    const int rows_t__ = sg__.rows ? sg__.rows : BM;                                                  \
+    c_m0 = mt__ * rows_t__;                                                                           \
+    c_mend = c_m0 + rows_t__ < sg__.M ? c_m0 + rows_t__ : sg__.M;                                     \
+    c_chunk0 = mt__ * 2;                                                                              \
     c_n0 = (lt__ - mt__ * sg__.n_tiles) * BN;                                                         \
     c_ksteps = RS * (sg__.CinP / BK);                                                                 \
     c_k = 0;                                                                                          \
@@ -218,7 +223,8 @@ __global__ void __launch_bounds__(512) conv_big_kernel(const ConvArgs args) {
 
   // ---- epilogue of the compute-side tile (per wave; acc is re-initialised for the next tile afterwards) --------------------
   auto epilogue = [&]() __attribute__((always_inline)) {
-    big_epilogue<OUT_F32, HAS_RES, BN_BWD>(acc, args, c_si, c_m0, c_n0, wave, smem + RING_BYTES + wave * PATCH_BYTES);
+    big_epilogue<OUT_F32, HAS_RES, BN_BWD>(acc, args, c_si, c_m0, c_n0, wave, smem + RING_BYTES + wave * PATCH_BYTES,
+                                           BigEpiSrc(), c_mend, c_chunk0);
   };
 
   // ---- prologue ------------------------------------------------------------------------------------

@@ -190,12 +190,15 @@ __device__ __forceinline__ void big_epi_rebuild(f32x16_t* t, const BigEpiSrc& sr
 
 template <bool OUT_F32, bool HAS_RES, bool BN_BWD = false, bool FROM_WS = false, int WM = 2>
 __device__ __forceinline__ void big_epilogue(f32x16_t (&acc)[4][2], const ConvArgs& args, int c_si, int c_m0,
-                                             int c_n0, int wave, char* patch, const BigEpiSrc src = BigEpiSrc()) {
+                                             int c_n0, int wave, char* patch, const BigEpiSrc src = BigEpiSrc(),
+                                             int m_end = -1, int chunk0 = -1) {
+  // m_end / chunk0 (conv_big_kernel's balanced tiles): the tile's rows end at m_end (< c_m0 + 256) and its 128-row blocks
+  // of fused BatchNorm partial sums are numbered from chunk0; -1: whole tiles, blocks numbered by c_m0 / 128
   static_assert(!(BN_BWD && (OUT_F32 || HAS_RES)), "BN_BWD: plain bf16 launches only");
   constexpr bool LOADS = HAS_RES || BN_BWD;   // the epilogue prefetches a second [M][Cout] bf16 tensor
   const int wave_m = wave / (8 / WM), wave_n = wave % (8 / WM);   // WM x 8/WM waves of 128 pixels x 64 channels
   const ConvSegDev& sg = args.seg[c_si];
-  const int Cout = sg.Cout, M = sg.M;
+  const int Cout = sg.Cout, M = m_end >= 0 ? m_end : sg.M;
   const int nw0 = c_n0 + wave_n * 64;
   const int mw0 = c_m0 + wave_m * 128;
   // a fresh lane id, so that nothing the epilogue needs stays live across the main loop
@@ -404,7 +407,7 @@ _Pragma("unroll") for (int pass = 0; pass < (LOADS ? 4 : 0); ++pass) {          
         }
       }
       if (rrow == 0 && nok) {
-        float* dst = sg.bn_partial + ((long long)(c_m0 / 128) + wave_m) * 2 * Cout + nr;   // one row per 128 pixels
+        float* dst = sg.bn_partial + ((long long)(chunk0 >= 0 ? chunk0 : c_m0 / 128) + wave_m) * 2 * Cout + nr;   // one row per 128 pixels
         *(float4*)(dst) = make_float4(st0[0], st0[1], st0[2], st0[3]);
         *(float4*)(dst + 4) = make_float4(st0[4], st0[5], st0[6], st0[7]);
         *(float4*)(dst + Cout) = make_float4(st1[0], st1[1], st1[2], st1[3]);

@@ -24,8 +24,10 @@ struct ConvSegDev {
   int M, tile_begin, n_tiles, CinP;  // CinP = K extent per tap = w_terms * (Cin rounded up to the K step)
   int cwrap, halo_pitch;             // input channels wrap at cwrap (= CinP / w_terms): split-bf16 weight planes;
                                      // halo kernel: patch pixels per image row (W + 1, or that rounded up to 8)
-  int pair_cout, pad_;               // rn_conv_segment.w_pair: Cout above = the GEMM's columns (rn_conv_pair_rows), this =
+  int pair_cout, rows;               // rn_conv_segment.w_pair: Cout above = the GEMM's columns (rn_conv_pair_rows), this =
                                      // the channels of y / bias; 0 = off (256- / 512-row kernels, f32 epilogue only)
+                                     // rows (conv_big_kernel): output pixels a tile really covers, 0 = all 256 — balanced
+                                     // tiles of the HBM-bound 1x1 layers (rn_conv.hip: conv_big_balanced_rows)
 };
 
 

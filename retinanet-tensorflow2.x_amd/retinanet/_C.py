@@ -150,6 +150,7 @@ _SIGNATURES = {
     "rn_conv2d_nhwc_fwd": (c_int, [POINTER(ConvProblem), c_void_p]),
     "rn_conv_cout_pad": (c_int, [c_int]),
     "rn_conv_tile_rows": (c_int, [POINTER(ConvProblem)]),
+    "rn_conv_bn_row_blocks": (c_int, [POINTER(ConvProblem), c_int]),
     "rn_conv_kernel_id": (c_int, [POINTER(ConvProblem)]),
     "rn_conv_splitk_workspace_bytes": (c_size_t, [POINTER(ConvProblem)]),
     "rn_conv_splitk_workspace_max_bytes": (c_size_t, []),

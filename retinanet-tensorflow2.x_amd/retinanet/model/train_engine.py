@@ -827,10 +827,8 @@ class TrainEngine:
             off += C
         fused = conv_problem is not None and self.fuse_bn_stats and conv_problem.out_dtype == _C.RN_DT_BF16
         if fused:
-            rows = self.lib.rn_conv_tile_rows(ctypes.byref(conv_problem))   # the kernel the dispatcher will run
-            for i in range(len(ops)):
-                P = p.seg[i].P
-                p.seg[i].ext_chunks = (rows // 128) * ((P + rows - 1) // rows)     # one row of partial sums per 128 output pixels
+            for i in range(len(ops)):   # one row of partial sums per 128 output pixels of the kernel the dispatcher will run
+                p.seg[i].ext_chunks = self.lib.rn_conv_bn_row_blocks(ctypes.byref(conv_problem), i)
         ws = torch.empty((max(self.lib.rn_bn_workspace_bytes(ctypes.byref(p)), 256),), dtype=torch.uint8,
                          device=self.dev)
         if fused:
@@ -1567,21 +1565,19 @@ class TrainEngine:
         # together for depth 3.  Until then the assignments wait in self._bn_bwd_pending; the rn_conv_problem structs
         # are read at launch time, so they can still be patched when the last segment turns up.
         if hits and all(h is not None for h in hits):
-            rows = lib.rn_conv_tile_rows(ctypes.byref(p))
             for i, (op, (pb, j)) in enumerate(zip(need, hits)):
                 pend = self._bn_bwd_pending.setdefault(id(pb), {"pb": pb, "seg": {}})
                 if j in pend["seg"]:          # a second writer: not a single-consumer layer after all
                     pend["dead"] = True
-                pend["seg"][j] = (p, i, op["inp"], rows)
+                pend["seg"][j] = (p, i, op["inp"], None)
             for key in {id(pb) for pb, _ in hits}:
                 pend = self._bn_bwd_pending[key]
                 pb = pend["pb"]
                 if pend.get("dead") or pend.get("done") or sorted(pend["seg"]) != list(range(pb.num_segments)):
                     continue
                 pend["done"] = True
-                for j, (_, _, _, r) in pend["seg"].items():
-                    P = int(pb.seg[j].P)
-                    pb.seg[j].ext_chunks_bwd = (r // 128) * ((P + r - 1) // r)
+                for j, (pc_, i_, _, _) in pend["seg"].items():
+                    pb.seg[j].ext_chunks_bwd = lib.rn_conv_bn_row_blocks(ctypes.byref(pc_), i_)
                 wsb = torch.empty((max(lib.rn_bn_workspace_bytes(ctypes.byref(pb)), 256),), dtype=torch.uint8, device=self.dev)
                 self.bn_bwd_ws[key] = wsb
                 for j, (cp, ci, name, _) in pend["seg"].items():

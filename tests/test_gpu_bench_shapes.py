@@ -128,7 +128,8 @@ def _check_conv_launch(cuda, eng, name, p):
             if s.residual == s.y:            # the accumulating data-gradient launches: residual = the gradient buffer itself
                 y.copy_(t["residual"])
         P = s.N * s.Ho * s.Wo
-        chunks = (rows // 128) * ((P + rows - 1) // rows)
+        chunks = lib.rn_conv_bn_row_blocks(ctypes.byref(p), i)     # (rows // 128) * ceil(P / rows), or two per balanced tile
+        assert chunks >= (rows // 128) * ((P + rows - 1) // rows), name
         if s.bn_partial:
             t["partial"] = torch.full((chunks, 2, s.Cout), float("nan"), dtype=torch.float32, device=cuda)
         if s.bn_bwd_y:

@@ -389,6 +389,86 @@ def test_conv_128_row_split_k_grouped_levels(cuda):
     assert int(ws[:16384].view(torch.int32).abs().sum().item()) == 0
 
 
+BALANCED_CASES = [
+    # N, H, W, Cin, Cout, act, residual, bias, fused statistics   (1x1 / stride 1 on conv_big_kernel, dispatcher's own choice)
+    (2, 160, 160, 64, 256, "relu", True, False, False),    # 200 tiles in one round of 256 workgroups -> 256 tiles of 200 rows
+    (8, 80, 80, 128, 512, None, False, False, True),       # raw output + fused BatchNorm statistics: two short blocks per tile
+    (5, 80, 80, 256, 1024, None, False, True, False),      # 500 tiles = 1.95 rounds -> whole tiles already fit (no balancing)
+    (3, 96, 96, 128, 256, "relu6", False, False, True),    # 108 tiles: fewer than the 256-row kernels take -> 128-row kernel
+]
+
+
+@pytest.mark.parametrize("case", BALANCED_CASES, ids=["x".join(str(v) for v in c) for c in BALANCED_CASES])
+def test_conv_big_balanced_tiles(cuda, case):
+    """conv_big_kernel's balanced tiles (rn_conv.hip: conv_big_balanced_rows): an HBM-bound 1x1 launch whose 256-row tiles
+    would leave the last round of the persistent grid mostly idle runs the same number of rounds with tiles of fewer rows.
+    Same values as whole tiles (forced with conv_tile = 2); the fused BatchNorm partial sums come as two blocks per tile
+    (rn_conv_bn_row_blocks) and add up to the sums over the stored tensor."""
+    from retinanet import _C
+    lib = _lib()
+    N, H, W, Cin, Cout, act, use_res, use_bias, stats = case
+    g = torch.Generator().manual_seed(_seed(case))
+    s = {"x": torch.randn((N, H, W, Cin), generator=g), "w": torch.randn((1, 1, Cin, Cout), generator=g) / math.sqrt(Cin)}
+    if use_bias:
+        s["bias"] = torch.randn((Cout,), generator=g)
+    elif not stats:
+        s["scale"], s["shift"] = torch.rand((Cout,), generator=g) + 0.5, torch.randn((Cout,), generator=g) * 0.1
+    if use_res:
+        s["residual"] = torch.randn((N, H, W, Cout), generator=g)
+    outs = {}
+    for tag, opts in (("auto", None), ("whole", dict(conv_tile=2))):
+        p = _C.ConvProblem()
+        if opts:
+            p.opts = _C.LaunchOpts(**opts)
+        p.R = p.S = 1
+        p.stride_h = p.stride_w = 1
+        p.act, p.out_dtype, p.num_segments = _C.ACT_IDS[act], _C.RN_DT_BF16, 1
+        x = _bf(s["x"]).to(cuda).contiguous()
+        w = s["w"].to(cuda).float().contiguous()
+        wp = torch.empty((lib.rn_conv_cout_pad(Cout), 1, 1, lib.rn_conv_cin_pad(Cin)), dtype=H16, device=cuda)
+        _C.check(lib.rn_pack_conv_weight(_C.ptr(w), 1, 1, Cin, Cout, lib.rn_conv_cin_pad(Cin), _C.ptr(wp), _C.current_stream()))
+        y = torch.empty((N, H, W, Cout), dtype=H16, device=cuda)
+        keep = [x, w, wp]
+        sg = p.seg[0]
+        sg.x, sg.w, sg.y = x.data_ptr(), wp.data_ptr(), y.data_ptr()
+        for k in ("scale", "shift", "bias"):
+            if k in s:
+                t = s[k].to(cuda).float().contiguous()
+                keep.append(t)
+                setattr(sg, k, t.data_ptr())
+        if use_res:
+            r = _bf(s["residual"]).to(cuda).contiguous()
+            keep.append(r)
+            sg.residual = r.data_ptr()
+        sg.N, sg.H, sg.W, sg.Cin, sg.pix_stride, sg.Ho, sg.Wo, sg.Cout = N, H, W, Cin, Cin, H, W, Cout
+        blocks = lib.rn_conv_bn_row_blocks(ctypes.byref(p), 0)
+        part = None
+        if stats:
+            part = torch.full((blocks, 2, Cout), float("nan"), dtype=torch.float32, device=cuda)
+            sg.bn_partial = part.data_ptr()
+        kid = lib.rn_conv_kernel_id(ctypes.byref(p))
+        _C.check(lib.rn_conv2d_nhwc_fwd(ctypes.byref(p), _C.current_stream()), "conv")
+        torch.cuda.synchronize()
+        outs[tag] = (y.float().cpu(), None if part is None else part.double().cpu(), blocks, kid)
+    M = N * H * W
+    ya, pa, ba, ka = outs["auto"]
+    yw, pw, bw, kw = outs["whole"]
+    assert kw == 1 and bw == 2 * ((M + 255) // 256)
+    if ka == 1:
+        balanced = ba != bw
+        assert balanced == (case in BALANCED_CASES[:2]), (ba, bw)
+        assert torch.equal(ya, yw)          # a tile's accumulation order does not depend on the rows it covers
+    else:
+        assert ka == 0 and case == BALANCED_CASES[3]
+    _close(ya, _conv_ref(s, 1, 1, 0, act, False), False)
+    if stats:
+        stored = ya.double().reshape(-1, Cout)
+        want = torch.stack([stored.sum(0), (stored * stored).sum(0)])
+        for part in (pa, pw):
+            assert torch.isfinite(part).all()
+            torch.testing.assert_close(part.sum(0), want, rtol=2e-5, atol=2e-5 * want.abs().max().item())
+
+
 HALO512_CASES = [
     # N, H, W, Cin, Cout, act, residual, out_f32, persistent workgroups   (3x3 / stride 1 / pad 1, 64 < Cout <= 128)
     (2, 80, 80, 128, 128, "relu", False, False, 0),    # ResNet stage 2 at its own width: 6.4 rows per 512-pixel tile, 4 chunks
