@@ -1306,7 +1306,7 @@ class TrainEngine:
             step = self._side(wgrad, writes=[c.get("kvar", cname + "/kernel")])
             step.wgrad_item = (p, dw, ws, flw)      # _group_wgrad_steps may merge it with same-shape layers
             self.bwd_steps.append(step)
-            if c["bias"]:
+            if c["bias"] and not (os.environ.get("RNET_DEBUG_SKIP_BIAS_GRAD") == "1"):   # (debug switch: timing probe only)
                 # bias gradient = column sums of dy over every segment (two-stage reduction kernel)
                 pb2 = _C.BnProblem()
                 pb2.num_segments, pb2.act, pb2.bessel, pb2.eps, pb2.momentum, pb2.count_scale = len(cops), 0, 0, 0.0, 0.0, 1.0

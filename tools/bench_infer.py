@@ -11,6 +11,7 @@ def main():
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--big-min-tiles", type=int, default=0, help="override the 256-row kernels' minimum tile count")
+    ap.add_argument("--split-target", type=int, default=0, help="rn_launch_opts.splitk_target_blocks (128-row split-K)")
     a = ap.parse_args()
     from retinanet.cfg import default_params
     from retinanet.model import ModelBuilder
@@ -18,7 +19,7 @@ def main():
     p = default_params(input_size=a.size, inference_batch=a.batch)
     b = ModelBuilder(p, "val", device=dev, seed=1337)
     model = b()
-    model.launch_opts = dict(conv_big_min_tiles=a.big_min_tiles or 0)
+    model.launch_opts = dict(conv_big_min_tiles=a.big_min_tiles or 0, splitk_target_blocks=a.split_target)
     x = torch.randn((a.batch, a.size, a.size, 3), device=dev)
     preds = model(x)
     std = torch.cat([preds["class-predictions"][l].reshape(-1) for l in "34567"]).std().item()
