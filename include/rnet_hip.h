@@ -496,6 +496,12 @@ typedef struct {
    * byte (p*C + c)/8 = [act'(z) != 0] for the bf16 z it stores; with it set on every segment rn_bn_bwd_reduce and
    * rn_bn_bwd_apply read these P*C/8 bytes instead of z (2*P*C bytes) — same gate, same results. */
   void* act_mask;
+  /* optional, f32: rn_bn_bwd_apply also writes the column sums of the bf16 dy it STORES, per workgroup chunk, in the
+   * stage-1 layout of rn_bn_stats — row (chunk*2 + 0)*C + c, rn_bn_bwd_colsum_chunks() chunks (the second row of each
+   * chunk is not touched).  The bias of a Conv2D in front of this BatchNorm has the gradient sum_p dy[p][c]
+   * (tape.gradient, executor.py:427-428): with this the engine finishes it with rn_bn_stats(ext_chunks) on the partials
+   * instead of reading the whole dy tensor again.  Same values as summing the stored tensor, up to fp32 association. */
+  float* dy_colsum_partial;
 } rn_bn_segment;
 
 typedef struct {
@@ -519,6 +525,10 @@ int rn_bn_finalize(const rn_bn_problem* problem, void* stream);
 int rn_bn_apply(const rn_bn_problem* problem, void* stream);
 int rn_bn_bwd_reduce(const rn_bn_problem* problem, void* workspace, size_t workspace_bytes, void* stream);
 int rn_bn_bwd_apply(const rn_bn_problem* problem, void* stream);
+/* chunks rn_bn_bwd_apply writes per segment when rn_bn_segment.dy_colsum_partial is set (ceil(P * C/8 / 2048): one per
+ * workgroup of the chunked elementwise form); 0 = this problem runs the grid-stride form (a segment's C/8 does not divide
+ * 256), which does not support it — leave dy_colsum_partial NULL then. */
+int rn_bn_bwd_colsum_chunks(const rn_bn_problem* problem, int segment);
 
 /* backward of K6/K7/K8 */
 int rn_maxpool2d_nhwc_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int k, int stride,

@@ -123,6 +123,7 @@ struct BnSegDev {
   int C, dres_accumulate, chunks, rows_per_chunk;
   const float* sample_scale; long long rows_per_sample;
   unsigned char* mask;   // one bit per element: act'(z) != 0 (written by bn_apply, read by the G_MASK backward passes)
+  float* colsum;         // rn_bn_segment.dy_colsum_partial: per-chunk column sums of the stored dy (bn_bwd_apply), or null
 };
 struct BnArgs {
   int nseg, act, bessel, mode, fuse_finalize;
@@ -286,14 +287,19 @@ __global__ void bn_finalize_kernel(const BnArgs a) {
 //     them (same channel group again: the launcher picks this form only when C/8 divides 256).  Not persistent: the
 //     hardware hands out the chunks in address order as workgroups retire, and the pass streams at 5.6 - 6.0 TB/s where the
 //     grid-stride form of the same loop body reaches 4.9 - 5.5 (tools/probes/stream_probe.hip).
-#define BN_ELEMENTWISE_RANGE()                                                                        \
+#define BN_ELEMENTWISE_RANGE() BN_ELEMENTWISE_RANGE_(false)
+// keep_: threads without work stay (first = last) instead of returning — a workgroup barrier follows the loop
+#define BN_ELEMENTWISE_RANGE_(keep_)                                                                  \
   long long first, last, step;                                                                        \
   if (a.chunk_u > 0) {                                                                                \
     const long long span = 256ll * a.chunk_u;                                                         \
     first = blockIdx.x * span + threadIdx.x;                                                          \
     last = (blockIdx.x + 1) * span < total ? (blockIdx.x + 1) * span : total;                         \
     step = 256;                                                                                       \
-    if (first >= last) return;                                                                        \
+    if (first >= last) {                                                                              \
+      if (!(keep_) || blockIdx.x * span >= total) return;   /* (a whole chunk past the end: uniform) */ \
+      first = last;                                                                                   \
+    }                                                                                                 \
   } else {                                                                                            \
     const long long nthreads = (long long)gridDim.x * blockDim.x;                                     \
     step = nthreads / C8 * C8;                                                                        \
@@ -366,8 +372,10 @@ __global__ void __launch_bounds__(TR_THREADS) bn_bwd_apply_kernel(const BnArgs a
   const int C8 = s.C >> 3;
   const long long total = s.P * C8;
   const float inv_n = (float)(1.0 / ((double)s.P * (double)a.count_scale));
-  BN_ELEMENTWISE_RANGE();
-  const int c8 = (int)(first % C8);
+  // rn_bn_segment.dy_colsum_partial (chunked form only: the host checks): column sums of the dy this workgroup STORES
+  const bool colsum = s.colsum != nullptr;
+  BN_ELEMENTWISE_RANGE_(colsum);
+  const int c8 = a.chunk_u > 0 ? (int)(threadIdx.x % C8) : (int)(first % C8);   // (the same value; valid for first == last too)
   float mean[8], istd[8], sc[8], shq[8], k1[8], k2[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
@@ -379,6 +387,9 @@ __global__ void __launch_bounds__(TR_THREADS) bn_bwd_apply_kernel(const BnArgs a
     k1[q] = s.bsums[c] * inv_n;
     k2[q] = s.bsums[s.C + c] * inv_n;
   }
+  float cs[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) cs[q] = 0.0f;
   for (long long i = first; i < last; i += step) {
     const bf8 y = unpack8(s.y[i]);
     const bf8 dz = unpack8(s.dz[i]);
@@ -398,7 +409,13 @@ __global__ void __launch_bounds__(TR_THREADS) bn_bwd_apply_kernel(const BnArgs a
       const float xh = (y.v[q] - mean[q]) * istd[q];
       o.v[q] = sc[q] * (g.v[q] * m - k1[q] - xh * k2[q]);
     }
-    s.dy[i] = pack8(o);
+    const uint4 dyp = pack8(o);
+    s.dy[i] = dyp;
+    if (colsum) {
+      const bf8 st = unpack8(dyp);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) cs[q] += st.v[q];
+    }
     if (s.dres) {
       if (s.dres_accumulate) {
         const bf8 old = unpack8(s.dres[i]);
@@ -406,6 +423,25 @@ __global__ void __launch_bounds__(TR_THREADS) bn_bwd_apply_kernel(const BnArgs a
         for (int q = 0; q < 8; ++q) g.v[q] += old.v[q];
       }
       s.dres[i] = pack8(g);
+    }
+  }
+  if (colsum) {
+    // chunked form: thread t of every chunk holds channel group t % C8 (C8 divides 256 and the chunk's first unit is a
+    // multiple of 256); the 256 / C8 threads of a group are added in thread order: deterministic
+    __shared__ float red[TR_THREADS][9];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) red[threadIdx.x][q] = cs[q];
+    __syncthreads();
+    if ((int)threadIdx.x < C8) {
+      float t[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t[q] = 0.0f;
+      for (int j = threadIdx.x; j < TR_THREADS; j += C8)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] += red[j][q];
+      float* dst = s.colsum + ((long long)blockIdx.x * 2) * s.C + threadIdx.x * 8;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) dst[q] = t[q];
     }
   }
 }
@@ -427,6 +463,7 @@ static int bn_fill(const rn_bn_problem* p, BnArgs& a, int need_ws, int mode = 1)
     d.P = s.P; d.C = s.C; d.dres_accumulate = s.dres_accumulate;
     d.sample_scale = s.sample_scale; d.rows_per_sample = s.rows_per_sample > 0 ? s.rows_per_sample : 1;
     d.mask = (unsigned char*)s.act_mask;
+    d.colsum = s.dy_colsum_partial;
     if (s.sample_scale && p->act == RN_ACT_SWISH) return -1;   // swish' is recomputed without the factor
     // ~2048 workgroups per segment over (row chunks x 64-channel slabs): narrow layers (EfficientNet: 24..144
     // channels = 1..3 slabs) get more row chunks, so the reduction still fills the chip
@@ -575,6 +612,19 @@ extern "C" int rn_bn_apply(const rn_bn_problem* p, void* stream) {
   return RN_OK;
 }
 
+extern "C" int rn_bn_bwd_colsum_chunks(const rn_bn_problem* p, int segment) {
+  BnArgs a;
+  if (bn_fill(p, a, 0) || segment < 0 || segment >= a.nseg) return 0;
+  long long mx = 0;
+  for (int i = 0; i < a.nseg; ++i) {
+    const long long t = a.seg[i].P * (a.seg[i].C / 8);
+    if (t > mx) mx = t;
+  }
+  bn_elementwise_grid(a, mx);
+  if (a.chunk_u <= 0) return 0;
+  return (int)rn_cdiv(a.seg[segment].P * (a.seg[segment].C / 8), 256ll * a.chunk_u);
+}
+
 extern "C" int rn_bn_bwd_apply(const rn_bn_problem* p, void* stream) {
   BnArgs a;
   RN_CHECK_ARG(bn_fill(p, a, 0) == 0, "rn_bn_bwd_apply: bad problem");
@@ -588,6 +638,9 @@ extern "C" int rn_bn_bwd_apply(const rn_bn_problem* p, void* stream) {
   }
   {
     const dim3 grid(bn_elementwise_grid(a, mx), a.nseg), block(TR_THREADS);
+    for (int i = 0; i < a.nseg; ++i)
+      RN_CHECK_ARG(!a.seg[i].colsum || a.chunk_u > 0,
+                   "rn_bn_bwd_apply: dy_colsum_partial needs the chunked form (rn_bn_bwd_colsum_chunks() > 0)");
 #define BN_CALL_(G_) hipLaunchKernelGGL(bn_bwd_apply_kernel<G_>, grid, block, 0, (hipStream_t)stream, a)
     BN_DISPATCH_GATE(bn_gate_mode(p), BN_CALL_)
 #undef BN_CALL_

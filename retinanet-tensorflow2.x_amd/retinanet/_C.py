@@ -105,7 +105,8 @@ class BnSegment(Structure):
                 ("gamma", c_void_p), ("beta", c_void_p), ("moving_mean", c_void_p), ("moving_var", c_void_p),
                 ("dgamma", c_void_p), ("dbeta", c_void_p), ("P", c_int64), ("C", c_int32),
                 ("dres_accumulate", c_int32), ("sample_scale", c_void_p), ("rows_per_sample", c_int64),
-                ("ext_chunks", c_int32), ("ext_chunks_bwd", c_int32), ("act_mask", c_void_p)]
+                ("ext_chunks", c_int32), ("ext_chunks_bwd", c_int32), ("act_mask", c_void_p),
+                ("dy_colsum_partial", c_void_p)]
 
 
 class BnProblem(Structure):
@@ -205,6 +206,7 @@ _SIGNATURES = {
     "rn_bn_apply": (c_int, [POINTER(BnProblem), c_void_p]),
     "rn_bn_bwd_reduce": (c_int, [POINTER(BnProblem), c_void_p, c_size_t, c_void_p]),
     "rn_bn_bwd_apply": (c_int, [POINTER(BnProblem), c_void_p]),
+    "rn_bn_bwd_colsum_chunks": (c_int, [POINTER(BnProblem), c_int]),
     "rn_maxpool2d_nhwc_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                       c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rn_fpn_topdown_bwd_level": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

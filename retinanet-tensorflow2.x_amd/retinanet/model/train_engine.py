@@ -1317,8 +1317,24 @@ class TrainEngine:
                     s = pb2.seg[i]
                     s.y, s.sums = dy.data_ptr(), bs[i].data_ptr()
                     s.P, s.C = dy.shape[0] * dy.shape[1] * dy.shape[2], cw
-                ws2 = torch.empty((max(lib.rn_bn_workspace_bytes(ctypes.byref(pb2)), 256),), dtype=torch.uint8,
+                # A conv in front of a live BatchNorm: its dy is written by rn_bn_bwd_apply, which can sum the columns of
+                # what it stores on the way out (rn_bn_segment.dy_colsum_partial) — stage 1 of this reduction then never
+                # reads the dy tensor again (FPN + head-tower convs: 17 launches, ~1 ms of side-stream HBM reads per step;
+                # same-process A/B of the step with / without ANY bias-gradient launch: 29.73 / 29.50 ms).
+                # RNET_FUSE_BIAS_GRAD=0 keeps the separate pass.
+                fused_cs = False
+                if live_bn and os.environ.get("RNET_FUSE_BIAS_GRAD", "1") != "0":
+                    seg_of = [ops.index(op) for op in cops]
+                    chunks = [lib.rn_bn_bwd_colsum_chunks(ctypes.byref(pb), j) for j in seg_of]
+                    if all(ch > 0 for ch in chunks):
+                        fused_cs = True
+                        for i, ch in enumerate(chunks):
+                            pb2.seg[i].ext_chunks = ch
+                ws2 = torch.zeros((max(lib.rn_bn_workspace_bytes(ctypes.byref(pb2)), 256),), dtype=torch.uint8,
                                   device=self.dev)
+                if fused_cs:
+                    for i, j in enumerate(seg_of):
+                        pb.seg[j].dy_colsum_partial = ws2.data_ptr() + lib.rn_bn_partial_offset_bytes(ctypes.byref(pb2), i)
                 db = self._pview(cname + "/bias", self.G)
                 self._keep += [pb2, bs, ws2]
 

@@ -485,6 +485,71 @@ def test_bn_train_forward_backward(cuda, build, act, use_res):
         torch.testing.assert_close(d["moving_var"].cpu().double(), mv, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("build,use_res", [("bf16", False), ("bf16", True), ("f16", False)])
+def test_bn_backward_apply_column_sums_of_dy(cuda, build, use_res):
+    """rn_bn_segment.dy_colsum_partial: rn_bn_bwd_apply also sums the columns of the dy it stores (the bias gradient of a
+    Conv2D in front of a training-mode BatchNorm: the engine finishes it with rn_bn_stats(ext_chunks) on the per-chunk
+    partials instead of reading dy again).  dy and every other output bit-identical to the plain call; the finished sums
+    equal the column sums of the stored tensor to fp32 accumulation error; repeats bit-identical; a problem whose channel
+    groups do not divide 256 reports 0 chunks and refuses the field."""
+    from retinanet import _C
+    lib = _lib()
+    g = torch.Generator().manual_seed(23)
+    shapes = [(2, 40, 40, 256), (1, 80, 80, 256), (3, 10, 10, 256), (1, 3, 3, 64)]      # 2048-unit chunks: 50 / 100 / 4.7 / 0.04
+    segs = [{"y": torch.randn((N, H, W, C), generator=g) * 2 + 0.5,
+             "residual": torch.randn((N, H, W, C), generator=g) if use_res else None,
+             "dz": torch.randn((N, H, W, C), generator=g), "gamma": torch.rand((C,), generator=g) + 0.5,
+             "beta": torch.randn((C,), generator=g) * 0.2, "moving_mean": torch.zeros((C,)), "moving_var": torch.ones((C,))}
+            for (N, H, W, C) in shapes]
+    out = {}
+    for fused in (False, True, True):
+        p, dev = _bn_problem(cuda, segs, "relu")
+        st = _C.current_stream()
+        ws = _ws(lib.rn_bn_workspace_bytes(ctypes.byref(p)), cuda)
+        sums, keep = [], []
+        if fused:
+            p2 = _C.BnProblem()
+            p2.num_segments, p2.act, p2.bessel, p2.eps, p2.momentum, p2.count_scale = len(segs), 0, 0, 0.0, 0.0, 1.0
+            for i, d in enumerate(dev):
+                ch = lib.rn_bn_bwd_colsum_chunks(ctypes.byref(p), i)
+                C = d["y"].shape[3]
+                assert ch == -(-(d["y"].numel() // 8) // 2048)
+                sums.append(torch.zeros((2, C), dtype=torch.float32, device=cuda))
+                q = p2.seg[i]
+                q.y, q.sums, q.P, q.C, q.ext_chunks = d["dy"].data_ptr(), sums[-1].data_ptr(), d["y"].numel() // C, C, ch
+            ws2 = torch.zeros((lib.rn_bn_workspace_bytes(ctypes.byref(p2)),), dtype=torch.uint8, device=cuda)
+            for i in range(len(dev)):
+                p.seg[i].dy_colsum_partial = ws2.data_ptr() + lib.rn_bn_partial_offset_bytes(ctypes.byref(p2), i)
+            keep += [p2, ws2]
+        _C.check(lib.rn_bn_stats_finalize(ctypes.byref(p), _C.ptr(ws), ws.numel(), st))
+        _C.check(lib.rn_bn_apply(ctypes.byref(p), st))
+        _C.check(lib.rn_bn_bwd_reduce(ctypes.byref(p), _C.ptr(ws), ws.numel(), st))
+        _C.check(lib.rn_bn_bwd_apply(ctypes.byref(p), st))
+        if fused:
+            _C.check(lib.rn_bn_stats(ctypes.byref(p2), _C.ptr(ws2), ws2.numel(), st))
+        torch.cuda.synchronize()
+        res = [{k: d[k].clone() for k in ("dy", "dres", "bsums")} for d in dev]
+        if fused:
+            for r, sm in zip(res, sums):
+                r["colsum"] = sm[0].clone()
+        out.setdefault(fused, []).append(res)
+    plain, (f1, f2) = out[False][0], out[True]
+    for a, b, c in zip(plain, f1, f2):
+        for k in ("dy", "dres", "bsums"):
+            assert torch.equal(a[k].float(), b[k].float()), k
+        assert torch.equal(b["colsum"], c["colsum"])
+        want = b["dy"].double().reshape(-1, b["dy"].shape[3]).sum(0)
+        scale = b["dy"].double().abs().sum(dim=(0, 1, 2)).max().item()
+        torch.testing.assert_close(b["colsum"].double(), want, rtol=0, atol=2e-6 * scale)
+    # channel groups that do not divide 256 (144 channels = 18 groups): the grid-stride form, no column sums
+    odd = [{"y": torch.randn((1, 6, 6, 144), generator=g), "residual": None, "dz": torch.randn((1, 6, 6, 144), generator=g),
+            "gamma": torch.ones((144,)), "beta": torch.zeros((144,)), "moving_mean": torch.zeros((144,)), "moving_var": torch.ones((144,))}]
+    p, dev = _bn_problem(cuda, odd, "relu")
+    assert lib.rn_bn_bwd_colsum_chunks(ctypes.byref(p), 0) == 0
+    p.seg[0].dy_colsum_partial = dev[0]["fwd"].data_ptr()
+    assert lib.rn_bn_bwd_apply(ctypes.byref(p), _C.current_stream()) == _C.RN_EINVAL
+
+
 @pytest.mark.parametrize("build,k,tile", [("bf16", 1, 2), ("bf16", 3, 2), ("bf16", 1, 1), ("bf16", 3, 1), ("bf16", 3, 3),
                                           ("bf16", 3, 4), ("f16", 1, 2), ("f16", 3, 2), ("f16", 3, 1), ("f16", 3, 3), ("f16", 3, 4)])
 def test_bn_forward_stats_fused_into_conv_epilogue(cuda, build, k, tile):
