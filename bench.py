@@ -769,6 +769,12 @@ def main():
         # — no exec, no in-process retry —, lets rank 0's JSON line through on the inherited stdout and exits with the
         # child's status.
         sys.exit(launch_ranks(args.gpus))
+    # The contract is ONE JSON line on stdout.  Native libraries write there too (librccl prints its version banner
+    # through C stdio when a communicator comes up, flushed at exit — after the line): keep a private handle on the real
+    # stdout for the line and point file descriptor 1 at stderr for everything else in this process.
+    sys.stdout.flush()
+    line_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with `python -m torch.distributed.run "
@@ -869,7 +875,8 @@ def main():
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(p_train, m_train, frozen, p_inf, m_inf)
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        line_out.write(json.dumps(line) + "\n")
+        line_out.flush()
     if world > 1:
         dist.destroy_process_group()
 

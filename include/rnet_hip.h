@@ -605,6 +605,10 @@ int rn_allreduce_small(void* comm, float* ptr /* device */, int count, void* str
  * 100 MHz wall clock at the same points: (c1 - c0) / ((w1 - w0) / 100) = core clock in MHz.  rn_probe_mfma_flops(iters) =
  * FLOPs of one launch on the current device. */
 long long rn_probe_mfma_flops(int iters);
+/* One wavefront that idles for `microseconds` (0..100000) on `stream`: the probe behind the engines' choice of side streams
+ * — HIP maps streams onto a few hardware queues by creation order, and two streams on one queue do not overlap (a kernel
+ * launched on stream B after a spin on stream A finishes first only when A and B run side by side). */
+int rn_probe_spin(int microseconds, void* stream);
 int rn_probe_mfma(const float* table, float* out, int iters, unsigned long long* clocks, void* stream);
 
 /* ---------------------------------------------------------------------------------------

@@ -71,3 +71,23 @@ extern "C" int rn_probe_mfma(const float* table, float* out, int iters, unsigned
   RN_CHECK_LAUNCH();
   return RN_OK;
 }
+
+// ---- do two streams really run side by side? ---------------------------------------------------------------------
+// HIP maps every stream onto one of a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default) by creation order; two streams
+// that share a queue execute strictly in submission order, and a "wait for that event" packet of one of them then blocks the
+// other's kernels too.  Measured (round 5, profiles/r05_ab): the data-parallel step's third stream landed on the weight-
+// gradient stream's queue in one process (+3 ms per step) and on a worse one inside bench.py (+6.5 ms) — which streams
+// alias depends on how many streams the process created before.  rn_probe_spin is the probe the engines pick their side
+// streams with (retinanet/_C.py::concurrent_stream): one wave that does nothing for `microseconds`; launched on stream A,
+// a second, short one on stream B finishes first only if A and B are on different queues.
+__global__ void probe_spin_kernel(unsigned long long ticks) {
+  const unsigned long long t0 = wall_clock64();   // 100 MHz
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
+extern "C" int rn_probe_spin(int microseconds, void* stream) {
+  RN_CHECK_ARG(microseconds >= 0 && microseconds <= 100000, "rn_probe_spin: %d us (0..100000)", microseconds);
+  hipLaunchKernelGGL(probe_spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long)microseconds * 100ull);
+  RN_CHECK_LAUNCH();
+  return RN_OK;
+}

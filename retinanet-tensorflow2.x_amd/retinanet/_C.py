@@ -152,6 +152,7 @@ _SIGNATURES = {
     "rn_conv_cout_pad": (c_int, [c_int]),
     "rn_conv_tile_rows": (c_int, [POINTER(ConvProblem)]),
     "rn_conv_bn_row_blocks": (c_int, [POINTER(ConvProblem), c_int]),
+    "rn_probe_spin": (c_int, [c_int, c_void_p]),
     "rn_conv_kernel_id": (c_int, [POINTER(ConvProblem)]),
     "rn_conv_splitk_workspace_bytes": (c_size_t, [POINTER(ConvProblem)]),
     "rn_conv_splitk_workspace_max_bytes": (c_size_t, []),
@@ -377,6 +378,38 @@ def i64_array(values):
 def current_stream():
     import torch
     return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def streams_overlap(lib_, a, b, spin_us=400):
+    """True when a kernel launched on torch stream `b` runs while a longer one on `a` is still busy — i.e. the two streams
+    sit on different hardware queues (csrc/rn_probe.hip: rn_probe_spin).  Synchronises the device."""
+    import torch
+    torch.cuda.synchronize(a.device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    check(lib_.rn_probe_spin(int(spin_us), c_void_p(a.cuda_stream)), "rn_probe_spin")
+    e0.record(b)
+    check(lib_.rn_probe_spin(1, c_void_p(b.cuda_stream)), "rn_probe_spin")
+    e1.record(b)
+    torch.cuda.synchronize(a.device)
+    return e0.elapsed_time(e1) * 1e3 < 0.5 * spin_us
+
+
+def concurrent_stream(lib_, device, others, attempts=12):
+    """A new torch stream on `device` that overlaps with every stream in `others` (the caller's main stream, its other
+    side streams), or the last candidate when none of `attempts` does.  HIP hands out hardware queues by stream creation
+    order, so which streams alias depends on the process's history: probe instead of assuming.  RNET_STREAM_PROBE=0:
+    take the first stream unprobed.  Returns (stream, probed_ok)."""
+    import torch
+    if os.environ.get("RNET_STREAM_PROBE", "1") == "0":
+        return torch.cuda.Stream(device), None
+    held, s = [], None
+    with torch.cuda.device(device):
+        for _ in range(attempts):
+            s = torch.cuda.Stream(device)
+            if all(streams_overlap(lib_, o, s) and streams_overlap(lib_, s, o) for o in others):
+                return s, True
+            held.append(s)     # keep the rejected ones alive so the pool hands out a different stream next time
+    return s, False
 
 
 def new_splitk_workspace(lib_, device, default_on=False):

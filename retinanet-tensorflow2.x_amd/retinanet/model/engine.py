@@ -99,7 +99,8 @@ class InferenceEngine:
             self.side_steps = set()   # names of the launches that go to the second stream
             self.step_io = {}         # step name -> (tensor names read, tensor names written)
             self._build()
-            self._side_stream = torch.cuda.Stream(device=self.dev) if self.side_steps else None
+            self._side_stream = (_C.concurrent_stream(self.lib, self.dev, [torch.cuda.current_stream(self.dev)])[0]
+                                 if self.side_steps else None)
             self._events = [torch.cuda.Event() for _ in range(2 * len(self.side_steps))]
 
     # ---- buffers ---------------------------------------------------------------------------

@@ -1684,7 +1684,10 @@ class TrainEngine:
 
     def _ensure_side_stream(self):
         if self._side_stream is None:
-            self._side_stream = torch.cuda.Stream(self.dev)
+            # a stream that really runs beside the caller's (probed: HIP's stream -> hardware-queue map depends on how
+            # many streams the process created before — _C.concurrent_stream)
+            self._side_stream, self.side_stream_probed = _C.concurrent_stream(
+                self.lib, self.dev, [torch.cuda.current_stream(self.dev)])
             self._side_events = [torch.cuda.Event() for _ in self.bwd_steps]
         return self._side_stream
 
@@ -1814,7 +1817,10 @@ class TrainEngine:
             # stream itself (most of a bucket's producers are there; it waits for the main stream's BatchNorm gamma / beta
             # gradients through one event per bucket) or, in the one-stream backward, on the main stream: no extra queue.
             # RNET_C1_STREAM=own restores the third stream (A/B on a multi-GPU node).
-            self._comm_stream = torch.cuda.Stream(self.dev) if os.environ.get("RNET_C1_STREAM", "side") == "own" else None
+            self._comm_stream = None
+            if os.environ.get("RNET_C1_STREAM", "side") == "own":
+                self._comm_stream, _ = _C.concurrent_stream(
+                    self.lib, self.dev, [torch.cuda.current_stream(self.dev)] + ([self._side_stream] if self._side_stream else []))
             self._comm_events = [(torch.cuda.Event(), torch.cuda.Event()) for _ in self._buckets]
             self.L = torch.zeros_like(self.G)      # what this rank contributed (for the clip correction)
             if self.dp_active:
