@@ -380,33 +380,61 @@ def current_stream():
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def streams_overlap(lib_, a, b, spin_us=400):
-    """True when a kernel launched on torch stream `b` runs while a longer one on `a` is still busy — i.e. the two streams
-    sit on different hardware queues (csrc/rn_probe.hip: rn_probe_spin).  Synchronises the device."""
+def wait_blocks(lib_, a, probe, main, helper, spin_us=600):
+    """True when an event-wait pending on torch stream `a` stalls `probe()` — a callable that enqueues something short
+    from stream `main` (a kernel, a c10d collective) — i.e. when whatever `probe` uses shares a hardware queue with `a`.
+    HIP maps streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default) by creation order.  Kernels of two
+    streams on one queue still overlap, but a `wait_event` is a barrier packet: everything submitted to that QUEUE
+    afterwards — the other stream's kernels included — waits until it is satisfied.  Round 5 measured what that does to
+    the data-parallel step (profiles/r05_ab): SyncBN all-reduces hop main -> c10d's stream -> main, the weight-gradient
+    stream is full of "wait for the main stream" packets, and when the two shared a queue every message waited for the
+    weight gradients queued before it: +6.4 ms per step inside bench.py, +1.2 ms in a fresh process (other queue map).
+    `helper`: a third stream that idles for `spin_us` and then releases the wait.  Synchronises the device."""
     import torch
     torch.cuda.synchronize(a.device)
+    gate = torch.cuda.Event()
+    check(lib_.rn_probe_spin(int(spin_us), c_void_p(helper.cuda_stream)), "rn_probe_spin")
+    gate.record(helper)
+    a.wait_event(gate)                       # a's queue now holds a barrier that stays shut for ~spin_us
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    check(lib_.rn_probe_spin(int(spin_us), c_void_p(a.cuda_stream)), "rn_probe_spin")
-    e0.record(b)
-    check(lib_.rn_probe_spin(1, c_void_p(b.cuda_stream)), "rn_probe_spin")
-    e1.record(b)
+    e0.record(main)
+    probe()
+    e1.record(main)
     torch.cuda.synchronize(a.device)
-    return e0.elapsed_time(e1) * 1e3 < 0.5 * spin_us
+    return e0.elapsed_time(e1) * 1e3 > 0.5 * spin_us
 
 
-def concurrent_stream(lib_, device, others, attempts=12):
-    """A new torch stream on `device` that overlaps with every stream in `others` (the caller's main stream, its other
-    side streams), or the last candidate when none of `attempts` does.  HIP hands out hardware queues by stream creation
-    order, so which streams alias depends on the process's history: probe instead of assuming.  RNET_STREAM_PROBE=0:
-    take the first stream unprobed.  Returns (stream, probed_ok)."""
+def concurrent_stream(lib_, device, others, attempts=12, probes=(), agree=None):
+    """A new torch stream on `device` whose pending event-waits stall neither a kernel on any stream of `others` (and vice
+    versa) nor any of `probes` (callables enqueued from others[0], e.g. a small c10d all-reduce) — or the last candidate
+    when none of `attempts` qualifies.  Which streams share a hardware queue depends on the process's history (how many
+    streams exist): probe instead of assuming.  RNET_STREAM_PROBE=0: first stream, unprobed.  Returns (stream, ok).
+    When `probes` are collectives every rank must take the same decisions: each candidate runs every probe (no short cut)
+    and `agree(ok)` — a MIN over the ranks — settles the verdict, so all ranks try the same number of candidates."""
     import torch
-    if os.environ.get("RNET_STREAM_PROBE", "1") == "0":
+    if os.environ.get("RNET_STREAM_PROBE", "1") == "0" or not others:
         return torch.cuda.Stream(device), None
     held, s = [], None
     with torch.cuda.device(device):
+        helper = torch.cuda.Stream(device)
+        held.append(helper)
+        main = others[0]
         for _ in range(attempts):
             s = torch.cuda.Stream(device)
-            if all(streams_overlap(lib_, o, s) and streams_overlap(lib_, s, o) for o in others):
+            ok = True
+            for o in others:
+                kern_o = lambda o=o: check(lib_.rn_probe_spin(1, c_void_p(o.cuda_stream)), "rn_probe_spin")
+                kern_s = lambda s=s: check(lib_.rn_probe_spin(1, c_void_p(s.cuda_stream)), "rn_probe_spin")
+                # (the timing events sit on the stream the probe kernel goes to)
+                ok = ok and not wait_blocks(lib_, s, kern_o, o, helper) and not wait_blocks(lib_, o, kern_s, s, helper)
+                if not ok:
+                    break
+            for pr in probes:
+                blocked = wait_blocks(lib_, s, pr, main, helper)      # always issued: `pr` may be a collective
+                ok = ok and not blocked
+            if agree is not None:
+                ok = bool(agree(ok))
+            if ok:
                 return s, True
             held.append(s)     # keep the rejected ones alive so the pool hands out a different stream next time
     return s, False

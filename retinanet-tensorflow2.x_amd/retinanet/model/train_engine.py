@@ -1686,8 +1686,22 @@ class TrainEngine:
         if self._side_stream is None:
             # a stream that really runs beside the caller's (probed: HIP's stream -> hardware-queue map depends on how
             # many streams the process created before — _C.concurrent_stream)
+            probes, agree = [], None
+            if self.dp_active and self.sync_bn and self.native_comm is None:
+                import torch.distributed as dist
+                if dist.is_available() and dist.is_initialized() and dist.get_backend(self.pg) == "nccl":
+                    # the SyncBN messages hop main -> c10d's stream -> main: that stream must not share a queue with this
+                    # one either (its packets would wait behind every weight gradient queued before them)
+                    tiny = torch.zeros((64,), dtype=torch.float32, device=self.dev)
+                    dist.all_reduce(tiny, group=self.pg)      # (c10d picks its stream at the first collective)
+                    probes.append(lambda tiny=tiny: dist.all_reduce(tiny, group=self.pg))
+
+                    def agree(ok, dist=dist):          # every rank keeps or drops the candidate together
+                        v = torch.tensor([1.0 if ok else 0.0], device=self.dev)
+                        dist.all_reduce(v, op=dist.ReduceOp.MIN, group=self.pg)
+                        return bool(v.item() == 1.0)
             self._side_stream, self.side_stream_probed = _C.concurrent_stream(
-                self.lib, self.dev, [torch.cuda.current_stream(self.dev)])
+                self.lib, self.dev, [torch.cuda.current_stream(self.dev)], probes=probes, agree=agree)
             self._side_events = [torch.cuda.Event() for _ in self.bwd_steps]
         return self._side_stream
 
@@ -1825,11 +1839,53 @@ class TrainEngine:
             self.L = torch.zeros_like(self.G)      # what this rank contributed (for the clip correction)
             if self.dp_active:
                 import torch.distributed as dist
+                self._probe_bucket_group = True
                 # its own communicator: the latency-bound SyncBN all-reduces of the main stream must not queue
                 # behind a 25 MB bucket on the same RCCL stream
                 self.pg_c1 = dist.new_group(backend=dist.get_backend(self.pg))
+        if getattr(self, "_probe_bucket_group", False):
+            self._probe_bucket_group = False
+            if not self._bucket_group_is_safe():
+                # c10d's stream for the bucket group shares a hardware queue with the main stream: every bucket's "wait for
+                # the weight-gradient stream" packet would stall the main stream's kernels behind it.  All ranks agreed
+                # (MIN): this job keeps the plain order — all-reduce after the backward pass.
+                import logging
+                logging.warning("gradient-bucket overlap disabled: c10d's stream for the bucket group blocks the main stream "
+                                "on this process's hardware-queue map (RNET_STREAM_PROBE=0 skips the probe)")
+                self._overlap_unsafe = True
+        if getattr(self, "_overlap_unsafe", False):
+            self._overlap_on = False
+            return False
         self._overlap_done = 0
         return True
+
+    def _bucket_group_is_safe(self):
+        """Does an async all-reduce of the bucket group, issued from the weight-gradient stream while that stream still
+        waits for something, leave the main stream's kernels alone?  (_C.wait_blocks; collective: the ranks agree.)"""
+        import torch.distributed as dist
+        side = self._side_stream
+        if side is None or os.environ.get("RNET_STREAM_PROBE", "1") == "0" or dist.get_backend(self.pg_c1) != "nccl":
+            return True
+        main = torch.cuda.current_stream(self.dev)
+        tiny = torch.zeros((64,), dtype=torch.float32, device=self.dev)
+        with torch.cuda.stream(side):
+            dist.all_reduce(tiny, group=self.pg_c1)          # c10d picks the group's stream at its first collective
+        torch.cuda.synchronize(self.dev)
+        helper = torch.cuda.Stream(self.dev)
+        works = []
+
+        def probe():
+            with torch.cuda.stream(side):
+                works.append(dist.all_reduce(tiny, group=self.pg_c1, async_op=True))
+            _C.check(self.lib.rn_probe_spin(1, ctypes.c_void_p(main.cuda_stream)), "rn_probe_spin")
+        blocked = _C.wait_blocks(self.lib, side, probe, main, helper)
+        with torch.cuda.stream(side):
+            for w in works:
+                w.wait()
+        torch.cuda.synchronize(self.dev)
+        v = torch.tensor([0.0 if blocked else 1.0], device=self.dev)
+        dist.all_reduce(v, op=dist.ReduceOp.MIN, group=self.pg)
+        return bool(v.item() == 1.0)
 
     def _overlap_after_step(self, i, main, side):
         for j in self._bucket_at.get(i, ()):
