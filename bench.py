@@ -531,23 +531,33 @@ def run_dp_overhead(args, dev):
         engs = {"plain": TrainEngine(model, B, frozen_regexes=rx, world_size=1, force_dp=False),
                 "dp": TrainEngine(model, B, frozen_regexes=rx, world_size=1, force_dp=True)}
 
-        def run(name, n, no_read=False):
+        def run(name, n, no_read=False, overlap=None):
             eng = engs[name]
             eng.price_without_flag_read = no_read
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(n):
-                out = eng.train_step(images, enc.encode_batch(gb, gc, cnt))
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t0) / n * 1e3, out
+            old = os.environ.get("RNET_C1_OVERLAP")
+            if overlap is not None:
+                os.environ["RNET_C1_OVERLAP"] = overlap        # read at the head of every backward pass
+            try:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    out = eng.train_step(images, enc.encode_batch(gb, gc, cnt))
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / n * 1e3, out
+            finally:
+                if overlap is not None:
+                    os.environ.pop("RNET_C1_OVERLAP", None)
+                    if old is not None:
+                        os.environ["RNET_C1_OVERLAP"] = old
         for name in engs:
             run(name, 3)
-        rounds = {"plain": [], "dp": [], "dp_without_flag_read": []}
+        rounds = {"plain": [], "dp": [], "dp_without_flag_read": [], "dp_plain_order": []}
         for _ in range(4):
             rounds["plain"].append(run("plain", 5)[0])
             ms, out = run("dp", 5)
             rounds["dp"].append(ms)
             rounds["dp_without_flag_read"].append(run("dp", 5, no_read=True)[0])
+            rounds["dp_plain_order"].append(run("dp", 5, overlap="0")[0])
         med = {k: float(np.median(v)) for k, v in rounds.items()}
         eng = engs["dp"]
         return {"workload": f"ResNet50-{args.size} bf16 training step, {B} images, ONE GPU: plain step vs the same step with the "
@@ -555,6 +565,8 @@ def run_dp_overhead(args, dev):
                             "all-reduce overlapped with the backward pass (RNET_C1_OVERLAP default), clip-flag host read",
                 "ms_per_step": round(med["dp"] - med["plain"], 3), "plain_ms": round(med["plain"], 3), "dp_ms": round(med["dp"], 3),
                 "dp_without_flag_read_ms": round(med["dp_without_flag_read"], 3),
+                "dp_plain_order_ms": round(med["dp_plain_order"], 3),     # RNET_C1_OVERLAP=0: all-reduce after the backward pass
+                "overlap_enabled": not bool(getattr(engs["dp"], "_overlap_unsafe", False)),
                 "flag_read_ms": round(med["dp"] - med["dp_without_flag_read"], 3),
                 "syncbn_messages_per_step": eng.syncbn_messages_per_step, "gradient_buckets": len(getattr(eng, "_buckets", []) or []),
                 "clip_fired_last_step": bool(getattr(eng, "clip_fired", False)),

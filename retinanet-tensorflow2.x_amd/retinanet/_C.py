@@ -380,7 +380,7 @@ def current_stream():
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def wait_blocks(lib_, a, probe, main, helper, spin_us=600):
+def wait_blocks(lib_, a, probe, main, helper, spin_us=600, pre=None):
     """True when an event-wait pending on torch stream `a` stalls `probe()` — a callable that enqueues something short
     from stream `main` (a kernel, a c10d collective) — i.e. when whatever `probe` uses shares a hardware queue with `a`.
     HIP maps streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default) by creation order.  Kernels of two
@@ -389,13 +389,16 @@ def wait_blocks(lib_, a, probe, main, helper, spin_us=600):
     the data-parallel step (profiles/r05_ab): SyncBN all-reduces hop main -> c10d's stream -> main, the weight-gradient
     stream is full of "wait for the main stream" packets, and when the two shared a queue every message waited for the
     weight gradients queued before it: +6.4 ms per step inside bench.py, +1.2 ms in a fresh process (other queue map).
-    `helper`: a third stream that idles for `spin_us` and then releases the wait.  Synchronises the device."""
+    `helper`: a third stream that idles for `spin_us` and then releases the wait; `pre()`: enqueued behind the wait but in
+    front of the timed region (host time spent in it does not count).  Synchronises the device."""
     import torch
     torch.cuda.synchronize(a.device)
     gate = torch.cuda.Event()
     check(lib_.rn_probe_spin(int(spin_us), c_void_p(helper.cuda_stream)), "rn_probe_spin")
     gate.record(helper)
     a.wait_event(gate)                       # a's queue now holds a barrier that stays shut for ~spin_us
+    if pre is not None:
+        pre()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(main)
     probe()

@@ -1874,11 +1874,13 @@ class TrainEngine:
         helper = torch.cuda.Stream(self.dev)
         works = []
 
-        def probe():
+        def pre():       # the group's stream now waits for the weight-gradient stream, which waits for the helper
             with torch.cuda.stream(side):
                 works.append(dist.all_reduce(tiny, group=self.pg_c1, async_op=True))
+
+        def probe():
             _C.check(self.lib.rn_probe_spin(1, ctypes.c_void_p(main.cuda_stream)), "rn_probe_spin")
-        blocked = _C.wait_blocks(self.lib, side, probe, main, helper)
+        blocked = _C.wait_blocks(self.lib, side, probe, main, helper, pre=pre)
         with torch.cuda.stream(side):
             for w in works:
                 w.wait()
