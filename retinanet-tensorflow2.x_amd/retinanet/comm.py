@@ -118,7 +118,7 @@ def maybe_enable_native(engine):
     Collective over engine.pg: every rank returns a communicator or every rank returns None."""
     import torch.distributed as dist
     mode = os.environ.get("RNET_COMM", "torch")
-    if engine.world <= 1 or mode != "native" or not dist.is_initialized():
+    if not getattr(engine, "dp_active", engine.world > 1) or mode != "native" or not dist.is_initialized():
         return None
     if dist.get_backend(engine.pg) != "nccl":     # gloo (CPU / one-device functional runs): nothing to take over
         return None
@@ -147,4 +147,29 @@ def maybe_enable_native(engine):
         return None
     engine.native_comm = comm
     logging.info("SyncBN / normaliser messages go through rn_comm (RCCL on the compute stream)")
+    # C1: a second communicator for the gradient buckets (one communicator per stream that carries collectives): with it
+    # a bucket's all-reduce is ONE rn_allreduce_bucket enqueued on the stream that prepared the bucket, in program order —
+    # no c10d stream, no event hop (TrainEngine._launch_bucket).  Its construction is collective like the first one's; a
+    # failure anywhere leaves the buckets on torch.distributed.
+    comm2 = NativeComm(dist.get_rank(engine.pg), engine.world, engine.dev, engine.pg,
+                       handle=getattr(engine, "handle", None), slot=1)
+    good2 = False
+    if comm2.ok:
+        try:
+            x = torch.arange(1031, dtype=torch.float32, device=engine.dev) * (1 + comm2.rank)
+            want = x.clone()
+            dist.all_reduce(want, group=engine.pg)
+            with torch.cuda.device(engine.dev):
+                comm2.all_reduce_bucket(x)
+                torch.cuda.synchronize()
+            good2 = bool(torch.allclose(x, want, rtol=1e-5, atol=1e-5))
+        except Exception:   # noqa: BLE001 — the verdict below is still collective
+            good2 = False
+    if _agree(comm2.ok and good2, engine.dev, engine.pg):
+        engine.native_comm_buckets = comm2
+        logging.info("gradient buckets go through rn_allreduce_bucket (RCCL on the bucket's own stream)")
+    else:
+        if comm2.ok:
+            comm2.close()
+        engine.native_comm_buckets = None
     return comm

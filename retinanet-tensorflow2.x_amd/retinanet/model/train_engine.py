@@ -113,6 +113,7 @@ class TrainEngine:
         self._overlap_done = 0
         self._step_args = dict(wdc=0.0, alpha=0.0, unscale=1.0, clip=0.0)
         self.native_comm = None   # retinanet.comm.NativeComm for the small per-layer messages (SyncBN, normaliser)
+        self.native_comm_buckets = None   # ... and a second one for the gradient buckets (rn_allreduce_bucket), or None
         self._small_msgs = 0      # C3 messages (SyncBN sums; C2 rides in the first) sent since the step began
         self.syncbn_messages_per_step = None   # their count in the last train_step (bench.py: config.syncbn_messages)
         self._algo = {}           # id(rn_conv_problem) -> (algorithmic FLOPs, algorithmic bytes) where the launch executes more
@@ -1845,7 +1846,7 @@ class TrainEngine:
                 self.pg_c1 = dist.new_group(backend=dist.get_backend(self.pg))
         if getattr(self, "_probe_bucket_group", False):
             self._probe_bucket_group = False
-            if not self._bucket_group_is_safe():
+            if self.native_comm_buckets is None and not self._bucket_group_is_safe():
                 # c10d's stream for the bucket group shares a hardware queue with the main stream: every bucket's "wait for
                 # the weight-gradient stream" packet would stall the main stream's kernels behind it.  All ranks agreed
                 # (MIN): this job keeps the plain order — all-reduce after the backward pass.
@@ -1922,7 +1923,10 @@ class TrainEngine:
                 _C.check(lib.rn_optim_clip_factors(self.segs_dev.data_ptr(), self.n_segs, self.n_blocks, a["clip"],
                                                    a["alpha"], self.metrics.data_ptr(), self.G.data_ptr(),
                                                    self.opt_ws.data_ptr(), self.opt_ws.numel(), cst), "rn_optim_clip_factors")
-            if self.dp_active:
+            if self.dp_active and getattr(self, "native_comm_buckets", None) is not None:
+                # rn_allreduce_bucket (rn_comm.hip): one ncclAllReduce on the bucket's stream, behind its prepare kernel
+                self.native_comm_buckets.all_reduce_bucket(self.G[bkt["begin"]:bkt["end"]])
+            elif self.dp_active:
                 import torch.distributed as dist
                 self._overlap_works.append(dist.all_reduce(self.G[bkt["begin"]:bkt["end"]], group=self.pg_c1,
                                                            async_op=True))

@@ -24,7 +24,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _build(world, rank, clipnorm=1e9):
+def _build(world, rank, clipnorm=1e9, force_dp=None):
     sys.path.insert(0, PKG)
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
     from make_golden import synth_gt
@@ -39,7 +39,7 @@ def _build(world, rank, clipnorm=1e9):
     builder = ModelBuilder(p, "train", device=dev, seed=SEED)
     model = builder()
     per = B // world
-    eng = TrainEngine(model, per, frozen_regexes=[], world_size=world)
+    eng = TrainEngine(model, per, frozen_regexes=[], world_size=world, force_dp=force_dp)
     enc = LabelEncoder(p, device=dev)
     rng = np.random.default_rng(SEED)
     gts = [synth_gt(rng, int(rng.integers(2, 6)), SIZE) for _ in range(B)]
@@ -195,3 +195,54 @@ def test_native_comm_single_rank_plumbing(cuda):
     out = mgr.dict()
     mp.spawn(_worker_native_comm, args=(1, _free_port(), out), nprocs=1, join=True)
     assert out[0] is True
+
+
+def _worker_forced_dp(rank, world, port, out):
+    """ONE rank on a real `nccl` (RCCL) process group: the plain step, the data-parallel machinery forced on over
+    torch.distributed, and forced on over rn_comm (RNET_COMM=native: SyncBN messages through rn_allreduce_small on the
+    compute stream, gradient buckets through rn_allreduce_bucket on the weight-gradient stream)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, PKG)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
+    from retinanet import comm
+    res = {}
+    for tag, force, mode in (("plain", False, "torch"), ("dp_torch", True, "torch"), ("dp_native", True, "native")):
+        os.environ["RNET_COMM"] = mode
+        model, eng, images, targets = _build(1, 0, force_dp=force)
+        native = comm.maybe_enable_native(eng)
+        r = _step(model, eng, images, targets)
+        r["sync_bn"], r["native"] = bool(eng.sync_bn), native is not None
+        r["native_buckets"] = getattr(eng, "native_comm_buckets", None) is not None
+        r["messages"] = eng.syncbn_messages_per_step
+        r["side_stream_probed"] = getattr(eng, "side_stream_probed", None)
+        res[tag] = r
+        if native is not None:
+            if eng.native_comm_buckets is not None:
+                eng.native_comm_buckets.close()
+            native.close()
+        del model, eng
+        torch.cuda.empty_cache()
+    os.environ.pop("RNET_COMM", None)
+    out[rank] = res
+    dist.destroy_process_group()
+
+
+def test_forced_data_parallel_path_on_one_rank_of_rccl(cuda):
+    """TrainEngine(force_dp=True) on a 1-rank nccl group (what bench.py's extra.dp_overhead times): SyncBN messages, gradient
+    buckets prepared and all-reduced while the backward pass runs, the clip-flag read — through torch.distributed and
+    through rn_comm (rn_allreduce_small / rn_allreduce_bucket have a product caller: RNET_COMM=native).  A sum over one rank
+    is the identity, so all three land on bit-identical weights and the same loss; the side stream came out of the
+    queue-independence probe."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_forced_dp, args=(1, _free_port(), out), nprocs=1, join=True)
+    r = out[0]
+    assert not r["plain"]["sync_bn"] and not r["plain"]["overlapped"] and r["plain"]["messages"] == 0
+    for tag in ("dp_torch", "dp_native"):
+        assert r[tag]["sync_bn"] and r[tag]["overlapped"] and r[tag]["messages"] > 10, (tag, r[tag]["messages"])
+        assert not r[tag]["clip_fired"]
+        np.testing.assert_array_equal(r[tag]["P"], r["plain"]["P"])
+        assert r[tag]["loss"] == r["plain"]["loss"]
+        assert r[tag]["side_stream_probed"] in (True, False)        # probed (None = RNET_STREAM_PROBE=0)
+    assert not r["dp_torch"]["native"] and r["dp_native"]["native"] and r["dp_native"]["native_buckets"]
