@@ -469,6 +469,75 @@ def test_conv_big_balanced_tiles(cuda, case):
             torch.testing.assert_close(part.sum(0), want, rtol=2e-5, atol=2e-5 * want.abs().max().item())
 
 
+def test_split_k_hand_off_under_uneven_load(cuda):
+    """The split-K hand-offs (128-row kernel: per-tile ticket, last arriver reduces; halo kernel: per-wave tickets) use
+    write-through stores, a drained vmcnt, one returning agent-scope atomic and sc1 loads — no cache-wide release / acquire
+    (cdna_hip_programming.md guideline 16, R1).  Such a protocol has to be tested where it can fail: uneven load (a second
+    stream streams HBM and keeps part of the chip busy, so the parts of a tile arrive far apart), slots that are L2 / L1
+    warm from the previous launch, every output word checked.  300 launches of each form, alternating two different
+    inputs on the same workspace: every result must equal the first result of its input bit for bit."""
+    from retinanet import _C
+    lib = _lib()
+    g = torch.Generator().manual_seed(99)
+    cases = [(1, 20, 20, 512, 512, 3, dict()),                     # 128-row kernel, 8 parts per tile
+             (1, 30, 30, 512, 256, 3, dict(conv_tile=2)),          # halo kernel, 4 tiles x 4 parts, per-wave tickets
+             (1, 20, 20, 2048, 512, 1, dict())]                    # 128-row kernel, 1x1, 8 parts of 4 K steps
+    side = torch.cuda.Stream(cuda)
+    noise_a = torch.randn((64 << 20,), device=cuda)
+    noise_b = torch.empty_like(noise_a)
+    for (N, H, W, Cin, Cout, k, opts) in cases:
+        ws = torch.zeros((80 << 20,), dtype=torch.uint8, device=cuda)
+        inputs = []
+        for _ in range(2):
+            s = {"x": torch.randn((N, H, W, Cin), generator=g), "w": torch.randn((k, k, Cin, Cout), generator=g) / math.sqrt(k * k * Cin),
+                 "scale": torch.rand((Cout,), generator=g) + 0.5, "shift": torch.randn((Cout,), generator=g) * 0.1}
+            inputs.append(s)
+        # build both problems once (device tensors stay alive), then alternate launches
+        built = []
+        for s in inputs:
+            p = _C.ConvProblem()
+            p.opts = _C.LaunchOpts(**opts)
+            p.R = p.S = k
+            p.stride_h = p.stride_w = 1
+            p.pad_top = p.pad_left = (k - 1) // 2
+            p.act, p.out_dtype, p.num_segments = _C.ACT_IDS["relu"], _C.RN_DT_BF16, 1
+            x = _bf(s["x"]).to(cuda).contiguous()
+            w = s["w"].to(cuda).float().contiguous()
+            cinp = lib.rn_conv_cin_pad(Cin)
+            wp = torch.empty((lib.rn_conv_cout_pad(Cout), k, k, cinp), dtype=H16, device=cuda)
+            _C.check(lib.rn_pack_conv_weight(_C.ptr(w), k, k, Cin, Cout, cinp, _C.ptr(wp), _C.current_stream()))
+            y = torch.empty((N, H, W, Cout), dtype=H16, device=cuda)
+            sc, sh = s["scale"].to(cuda), s["shift"].to(cuda)
+            sg = p.seg[0]
+            sg.x, sg.w, sg.y, sg.scale, sg.shift = x.data_ptr(), wp.data_ptr(), y.data_ptr(), sc.data_ptr(), sh.data_ptr()
+            sg.N, sg.H, sg.W, sg.Cin, sg.pix_stride, sg.Ho, sg.Wo, sg.Cout = N, H, W, Cin, Cin, H, W, Cout
+            p.splitk_ws, p.splitk_ws_bytes = ws.data_ptr(), ws.numel()
+            assert lib.rn_conv_splitk_workspace_bytes(ctypes.byref(p)) > 0
+            built.append((p, y, [x, w, wp, sc, sh]))
+        torch.cuda.synchronize()
+        first = [None, None]
+        st = _C.current_stream()
+        for it in range(300):
+            if it % 3 == 0:
+                with torch.cuda.stream(side):                      # uneven load: 256 MB streamed beside the launches
+                    torch.add(noise_a, 1.0, out=noise_b)
+            j = it & 1
+            p, y, _ = built[j]
+            _C.check(lib.rn_conv2d_nhwc_fwd(ctypes.byref(p), st), "conv")
+            if it < 2 or it % 25 == 0 or it >= 296:
+                got = y.clone()
+                torch.cuda.synchronize()
+                if first[j] is None:
+                    first[j] = got
+                else:
+                    assert torch.equal(got, first[j]), (k, Cin, Cout, it)
+        torch.cuda.synchronize()
+        for j in (0, 1):
+            assert torch.equal(built[j][1], first[j])
+            _close(first[j].float().cpu(), _conv_ref(inputs[j], k, 1, (k - 1) // 2, "relu", False), False)
+        assert int(ws[:16384].view(torch.int32).abs().sum().item()) == 0
+
+
 HALO512_CASES = [
     # N, H, W, Cin, Cout, act, residual, out_f32, persistent workgroups   (3x3 / stride 1 / pad 1, 64 < Cout <= 128)
     (2, 80, 80, 128, 128, "relu", False, False, 0),    # ResNet stage 2 at its own width: 6.4 rows per 512-pixel tile, 4 chunks

@@ -43,4 +43,14 @@ run(dp, 3)
 print("dp:", [run(dp) for _ in range(3)], "plain after dp engine exists:", [run(plain) for _ in range(3)], flush=True)
 os.environ["RNET_C1_OVERLAP"] = "0"
 print("dp, plain order (no overlap):", [run(dp) for _ in range(3)], flush=True)
+os.environ.pop("RNET_C1_OVERLAP", None)
+os.environ["RNET_COMM"] = "native"
+from retinanet import comm
+dpn = TrainEngine(model, B, frozen_regexes=rx, world_size=1, force_dp=True)
+nat = comm.maybe_enable_native(dpn)
+run(dpn, 3)
+print("dp, rn_comm (native small messages + native buckets):", nat is not None, dpn.native_comm_buckets is not None,
+      [run(dpn) for _ in range(3)], flush=True)
+dpn.native_comm = None      # small messages back on torch.distributed, buckets stay native
+print("dp, torch small messages + native buckets:", [run(dpn) for _ in range(3)], flush=True)
 dist.destroy_process_group()
