@@ -39,6 +39,50 @@ def split_by_depth(g, ops):
     return [deep, rest] if deep and rest else [ops]
 
 
+def pixel_pair_kernel(w):
+    """HWIO [3, 3, C, C] kernel of a 3x3 / stride-1 convolution -> the [3, 3, 2C, 2C] kernel of the SAME convolution over
+    pixel pairs: two horizontally adjacent pixels of the NHWC tensor seen as one pixel of 2C channels ([N, H, W, C] and
+    [N, H, W/2, 2C] are the same bytes).  Output pixel 2X + a (a = 0, 1), tap s reads input pixel 2X + a + s - 1 =
+    2(X + S - 1) + b: pair column S = (a + s - 1) // 2 + 1, half b = (a + s - 1) % 2; every other entry is zero."""
+    import torch
+    C = w.shape[2]
+    out = torch.zeros((3, 3, 2 * C, 2 * C), dtype=w.dtype, device=w.device)
+    for a in (0, 1):
+        for s_ in (0, 1, 2):
+            t = a + s_ - 1
+            S, b = t // 2 + 1, t % 2
+            out[:, S, b * C:(b + 1) * C, a * C:(a + 1) * C] = w[:, s_]
+    return out
+
+
+def pixel_pair_ok(lib, g, op, B, opts, splitk_ws=None):
+    """Does conv `op` run in pixel-pair form?  The 64-channel 3x3 layers of ResNet stage 1 (resnet.py:236-239 at 160 x 160)
+    fill half a 128-column tile of every MFMA kernel here; on the 128-row kernel, which stages the pixels once per tap,
+    they ran at 2.9x their HBM time (round 4: 120 - 131 us against 43 at B = 32).  As a convolution over pixel pairs the
+    layer is 128 -> 128 channels on half as many pixels — the shape the halo kernel's 512 x 128 tiles take: twice the MACs
+    (half of the paired kernel is zeros), one staging of the pixels per channel chunk.  Same products in the same order
+    per output, so the same values.  Only where that kernel takes the paired shape (rn_conv_kernel_id == 3: enough tiles)
+    and the layer runs in inference form (frozen `resnet_initial` layers in training, every layer when serving).
+    RNET_PIXEL_PAIR=0 keeps the plain form."""
+    import ctypes
+    if os.environ.get("RNET_PIXEL_PAIR", "1") == "0" or op.get("op") != "conv":
+        return False
+    c = g.convs[op["conv"]]
+    H, W, C, _ = g.tensors[op["inp"]]
+    if (c["k"], c["stride"], op["pad"]) != (3, 1, 1) or c["cin"] != c["cout"] or c["cout"] > 64 or c["cin"] % 8 or W % 2:
+        return False
+    if op.get("group") is not None or op.get("residual") or op.get("out_dtype", "bf16") != "bf16" or C != c["cin"]:
+        return False
+    p = _C.attach_splitk_workspace(_C.ConvProblem(), splitk_ws)
+    p.opts = opts
+    p.R = p.S = 3
+    p.stride_h = p.stride_w = p.pad_top = p.pad_left = 1
+    p.act, p.out_dtype, p.num_segments = _C.RN_ACT_NONE, _C.RN_DT_BF16, 1
+    s = p.seg[0]
+    s.N, s.H, s.W, s.Cin, s.pix_stride, s.Ho, s.Wo, s.Cout = B, H, W // 2, 2 * C, 2 * C, H, W // 2, 2 * C
+    return lib.rn_conv_kernel_id(ctypes.byref(p)) == 3
+
+
 def stem_pool_partner(g, stem_op, stem_k):
     """The MaxPool op that rn_stem_conv_bn_relu_pool can absorb: the ResNet stem (7x7/2, 64 channels, relu | relu6)
     whose only consumer is a 3x3 / stride-2 pool with SAME pads (resnet.py:288-307); None otherwise (EfficientNet's
@@ -84,9 +128,9 @@ class InferenceEngine:
         self._capture = bool(capture_graph)
         with torch.cuda.device(self.dev):
             self._alloc()
-            self.load_variables(variables)
             # split-K of the persistent conv kernels' last round: the launches of this engine run in order on one stream
             self.splitk_ws = _C.new_splitk_workspace(self.lib, self.dev, default_on=True)
+            self.load_variables(variables)
             # second stream (see _side_launch): its conv launches need a split-K workspace of their own — launches
             # that share one must be ordered on one stream
             # Measured (round 5, one box, tools/bench_infer.py): batch 8 3.554 -> 3.512 ms; batch 1 1.572 -> 1.594 ms — at
@@ -162,6 +206,17 @@ class InferenceEngine:
             c = self.g.convs[cname]
             w = variables[c.get("kvar", cname + "/kernel")].to(self.dev, torch.float32).contiguous()
             cout_pad = lib.rn_conv_cout_pad(c["cout"])
+            if self._pixel_pair(op):    # 64-channel 3x3 layer as a 128 -> 128 convolution over pixel pairs
+                w2 = pixel_pair_kernel(w).contiguous()
+                buf = self.packed.get(cname)
+                if buf is None:
+                    buf = torch.empty((lib.rn_conv_cout_pad(2 * c["cout"]), 3, 3, lib.rn_conv_cin_pad(2 * c["cin"])),
+                                      dtype=self.h16, device=self.dev)
+                _C.check(lib.rn_pack_conv_weight(_C.ptr(w2), 3, 3, 2 * c["cin"], 2 * c["cout"],
+                                                 lib.rn_conv_cin_pad(2 * c["cin"]), _C.ptr(buf), st), "rn_pack_conv_weight")
+                self.packed[cname] = buf
+                self._fold(op["out"], variables, op.get("bn"), variables.get(cname + "/bias"), repeat=2)
+                continue
             if cname not in self.packed or True:
                 if op["op"] == "stem":
                     buf = self.packed.get(cname)
@@ -195,6 +250,15 @@ class InferenceEngine:
                 self.packed[cname] = buf
             self._fold(op["out"], variables, op.get("bn"), variables.get(cname + "/bias"))
 
+    def _pixel_pair(self, op):
+        """True when conv `op` runs in pixel-pair form (pixel_pair_ok): decided once per op"""
+        self._ppair = getattr(self, "_ppair", {})
+        key = op["out"]
+        if key not in self._ppair:
+            self._ppair[key] = pixel_pair_ok(self.lib, self.g, op, self.B, self.launch_opts,
+                                             getattr(self, "splitk_ws", None))
+        return self._ppair[key]
+
     def _w_terms(self, op):
         """split-bf16 weight planes of the dtype=float32 prediction convs (rn_conv_segment.w_terms); 1 elsewhere"""
         if self._w_pair(op):
@@ -220,7 +284,7 @@ class InferenceEngine:
             self._pair[cname] = ok
         return self._pair[cname]
 
-    def _fold(self, key, variables, bn, bias):
+    def _fold(self, key, variables, bn, bias, repeat=1):
         """(scale, shift, bias) of the conv epilogue: the Conv2D layer's bias stays separate (it is added before the
         layer's output is rounded to bf16), BN inference = x*scale + shift with scale = gamma/sqrt(var+eps),
         shift = beta - mean*scale."""
@@ -233,6 +297,8 @@ class InferenceEngine:
             var = variables[bn + "/moving_variance"].to(self.dev, torch.float32)
             scale = gamma / torch.sqrt(var + self.eps)
             shift = beta - mean * scale
+        if repeat > 1:     # pixel-pair form: the per-channel vectors once per pixel of the pair
+            scale, shift, bias = [None if t is None else t.repeat(repeat) for t in (scale, shift, bias)]
         new = (scale, shift, bias)
         old = self.fold.get(key)
         if old is None:
@@ -259,6 +325,8 @@ class InferenceEngine:
         seg.N, seg.H, seg.W, seg.Cin = self.B, x.shape[1], x.shape[2], c["cin"]
         seg.pix_stride = x.shape[3]
         seg.Ho, seg.Wo, seg.Cout = y.shape[1], y.shape[2], c["cout"]
+        if self._pixel_pair(op):       # the same bytes as [N, H, W/2, 2C]
+            seg.W, seg.Wo, seg.Cin, seg.Cout, seg.pix_stride = x.shape[2] // 2, y.shape[2] // 2, 2 * c["cin"], 2 * c["cout"], 2 * x.shape[3]
 
     def _tensor_users(self, tname):
         """(op, role) of every op of the graph that reads tensor `tname`; role = the op field that names it"""

@@ -537,6 +537,13 @@ class TrainEngine:
                 buf = torch.empty((cp, c["k"], 32), dtype=self.h16, device=self.dev)
                 _C.check(lib.rn_pack_stem_weight_rs(_C.ptr(w), c["k"], c["k"], c["cout"], _C.ptr(buf), st),
                          "rn_pack_stem_weight_rs")
+            elif self._pixel_pair(op):     # 64-channel 3x3 layer as a 128 -> 128 convolution over pixel pairs (engine.pixel_pair_ok)
+                from .engine import pixel_pair_kernel
+                w2 = pixel_pair_kernel(w).contiguous()
+                cinp = lib.rn_conv_cin_pad(2 * c["cin"])
+                buf = torch.empty((lib.rn_conv_cout_pad(2 * c["cout"]), 3, 3, cinp), dtype=self.h16, device=self.dev)
+                _C.check(lib.rn_pack_conv_weight(_C.ptr(w2), 3, 3, 2 * c["cin"], 2 * c["cout"], cinp, _C.ptr(buf), st),
+                         "rn_pack_conv_weight")
             else:
                 cinp = lib.rn_conv_cin_pad(c["cin"])
                 buf = torch.empty((cp, c["k"], c["k"], cinp), dtype=self.h16, device=self.dev)
@@ -553,6 +560,8 @@ class TrainEngine:
                 shift = (bta - mean * scale).contiguous()
             # the Conv2D bias stays separate: it is added before the layer's output is rounded (rn_conv_segment)
             bias = None if bias is None else bias.to(self.dev).float().contiguous()
+            if op["op"] == "conv" and self._pixel_pair(op):     # per-channel vectors once per pixel of the pair
+                scale, shift, bias = [None if t is None else t.repeat(2).contiguous() for t in (scale, shift, bias)]
             self.fold[op["out"]] = (scale, shift, bias)
         if old_fold is not None:
             # a refold after a restore: the launch descriptors hold the first buffers' addresses -> copy in place
@@ -628,6 +637,16 @@ class TrainEngine:
             return self.split_pack_of[cname].data_ptr()
         return self.Pbf.data_ptr() + 2 * self.bf_off[cname]
 
+    def _pixel_pair(self, op):
+        """True when the FROZEN conv `op` (inference form) runs as a convolution over pixel pairs (engine.pixel_pair_ok)"""
+        from .engine import pixel_pair_ok
+        self._ppair = getattr(self, "_ppair", {})
+        key = op["out"]
+        if key not in self._ppair:
+            ok = op["op"] == "conv" and not self._conv_trainable(op) and not self.requires.get(op["inp"])
+            self._ppair[key] = ok and pixel_pair_ok(self.lib, self.g, op, self.B, self.launch_opts, getattr(self, "splitk_ws", None))
+        return self._ppair[key]
+
     def _f32_terms(self, layer):
         """bf16 weight planes of the dtype=float32 conv `layer` in THIS engine's forward pass: the narrow (pair-form)
         layers always carry both planes, the wide one `wide_pred_terms`"""
@@ -692,6 +711,10 @@ class TrainEngine:
             s.w_pair = 1 if op["conv"] in self.pair_packs else 0
             s.N, s.H, s.W, s.Cin, s.pix_stride = self.B, x.shape[1], x.shape[2], c["cin"], x.shape[3]
             s.Ho, s.Wo, s.Cout = y.shape[1], y.shape[2], c["cout"]
+            if not raw_mode and self._pixel_pair(op):      # the same bytes as [N, H, W/2, 2C]; algorithmic work: the layer's own
+                self._algo[id(p)] = (2 * self.B * y.shape[1] * y.shape[2] * 9 * c["cin"] * c["cout"],
+                                     2 * x.numel() + 2 * y.numel() + 2 * 9 * c["cin"] * c["cout"])
+                s.W, s.Wo, s.Cin, s.Cout, s.pix_stride = x.shape[2] // 2, y.shape[2] // 2, 2 * c["cin"], 2 * c["cout"], 2 * x.shape[3]
         self._keep.append(p)
         name = "fwd:" + (first.get("group") or first["out"])
         if any(n == name for n, _ in self.conv_launches):   # second launch of a split group (engine.split_by_depth)
