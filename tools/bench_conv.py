@@ -44,6 +44,11 @@ PRESETS = {
     "e_proj40": ([(40, 816, 136)], 1, 1, False, True),
     "e_proj20": ([(20, 1392, 232)], 1, 1, False, True),
     "g3_sc": ([(40, 512, 1024)], 1, 1, False, False),
+    # pixel-pair forms of the narrow 1x1 layers (run at HALF the batch: the same bytes as the plain layer at the full one)
+    "g2_a_pair": ([(80, 1024, 256)], 1, 1, False, False),
+    "g2b0_a": ([(160, 256, 128)], 1, 1, False, False),
+    "g2b0_a_pair": ([(160, 512, 256)], 1, 1, False, False),
+    "g1_a_pair": ([(160, 512, 128)], 1, 1, False, False),
     "fpn_out": ([(s, 256, 256) for s in (80, 40, 20, 10, 5)], 3, 1, False, False),
     "fpn_lat": ([(80, 512, 256), (40, 1024, 256), (20, 2048, 256)], 1, 1, False, False),
 }
