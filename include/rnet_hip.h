@@ -194,8 +194,6 @@ typedef struct {
   int32_t ablate;              /* tools/bench_conv.py: ablated variants of conv_fwd_kernel<128,128,64> — timing only */
   int32_t splitk_target_blocks; /* > 0: workgroups a split-K launch of the 128-row conv kernel aims for (default: one per
                                 * compute unit; rn_conv_problem.splitk_ws; A/B timing) */
-  int32_t conv_stream;         /* 0: auto | 1: never the weights-resident streaming kernel for 1x1 layers (conv_stream_kernel)
-                                * | 2: that kernel wherever the shape allows (tests at small sizes, A/B timing) */
 } rn_launch_opts;
 
 /* Opaque per-device context: device id, compute-unit count, the default rn_launch_opts of the engine that owns it and

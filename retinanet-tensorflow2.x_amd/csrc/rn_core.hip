@@ -53,7 +53,6 @@ static int rn_check_opts(const rn_launch_opts& o, const char* who) {
                o.reserved_cus);
   RN_CHECK_ARG(o.max_workgroups >= 0 && o.conv_big_min_tiles >= 0 && o.wgrad_target_blocks >= 0 && o.splitk_target_blocks >= 0,
                "%s: negative max_workgroups / conv_big_min_tiles / wgrad_target_blocks / splitk_target_blocks", who);
-  RN_CHECK_ARG(o.conv_stream >= 0 && o.conv_stream <= 2, "%s: conv_stream=%d (0..2)", who, o.conv_stream);
   return RN_OK;
 }
 int rn_validate_launch_opts(const rn_launch_opts& o, const char* who) { return rn_check_opts(o, who); }

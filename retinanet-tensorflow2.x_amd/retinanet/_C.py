@@ -44,8 +44,7 @@ class ExampleInfo(Structure):   # rn_example_info
 class LaunchOpts(Structure):   # rn_launch_opts: per-call options of the MFMA kernels (all zero = the dispatcher's choice)
     _fields_ = [("conv_tile", c_int32), ("conv_no_halo", c_int32), ("conv_big_min_tiles", c_int32),
                 ("max_workgroups", c_int32), ("reserved_cus", c_int32), ("wgrad_kernel", c_int32),
-                ("wgrad_target_blocks", c_int32), ("ablate", c_int32), ("splitk_target_blocks", c_int32),
-                ("conv_stream", c_int32)]
+                ("wgrad_target_blocks", c_int32), ("ablate", c_int32), ("splitk_target_blocks", c_int32)]
 
     def __init__(self, **kw):
         super().__init__()

@@ -47,7 +47,7 @@ def test_no_mutable_process_wide_state_setters():
     no process-wide setter"""
     assert not [n for n in _declared() if n.startswith(("rn_set_", "rn_debug"))]
     from retinanet import _C
-    assert _C.ConvProblem.opts.size == _C.WgradProblem.opts.size == ctypes.sizeof(_C.LaunchOpts) == 40
+    assert _C.ConvProblem.opts.size == _C.WgradProblem.opts.size == ctypes.sizeof(_C.LaunchOpts) == 36
 
 
 def test_half_build_exports_the_same_interface():
