@@ -112,10 +112,19 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_fwd_kernel(const ConvArg
     const int chunk = d_pos ^ lds_swz<BK>(row);
     const int m = m0 + row;
     const int mm = m < M ? m : 0;
-    const int ox = mm % sg.Wo;
-    const int t2 = mm / sg.Wo;
-    const int oy = t2 % sg.Ho;
-    const int n = t2 / sg.Ho;
+    int ox, oy, n;
+    if (args.pad_ & 1) {   // every M < 2^22: float-reciprocal divisions (~8 VALU instead of ~45 each; four rows x two per thread
+                           // were ~1 us of every launch's prologue — a tenth of a batch-1 layer)
+      const int t2 = rn_fdiv(mm, sg.Wo, rn_rcp((float)sg.Wo));
+      ox = mm - t2 * sg.Wo;
+      n = rn_fdiv(t2, sg.Ho, rn_rcp((float)sg.Ho));
+      oy = t2 - n * sg.Ho;
+    } else {
+      ox = mm % sg.Wo;
+      const int t2 = mm / sg.Wo;
+      oy = t2 % sg.Ho;
+      n = t2 / sg.Ho;
+    }
     const int iy0 = oy * args.sh - args.pt, ix0 = ox * args.sw - args.pl;
     a_off[j] = (unsigned)(((((long long)n * H + iy0) * W + ix0) * PS + chunk * 8) * 2);
     unsigned mask = 0;
@@ -914,6 +923,9 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
     if (deal) a.pad_ |= 2;   // bit 1: tiles dealt round-robin (see above)
     return rn_launch_conv_big(a, f32, p->opts, st);
   }
+  a.pad_ = 1;   // bit 0: float-reciprocal index arithmetic in the prologue, valid while every M < 2^22
+  for (int i = 0; i < a.nseg; ++i)
+    if (a.seg[i].M >= (1 << 22)) a.pad_ = 0;
   // 128-row kernel.  With a split-K workspace a SMALL launch of a deep layer (fewer tiles than the chip has compute units:
   // batch-1 / batch-8 inference, ResNet stage 3 / 4, the FPN laterals) cuts every tile along K (conv128_split_parts).
   const int S128 = conv128_split_parts(p, tiles, BN, BK);
