@@ -45,6 +45,34 @@ def main():
         if f:
             shutil.copy(f, os.path.join(out, dst))
             print("copied", f, "->", dst)
+    # round 5: BASELINE configs[3] / configs[4] (tools/run_profiles_r05.sh) — kernel stats + FETCH_SIZE per kernel
+    for sub, dst in (("c3", f"{a.round}_train_1024_b16_kernel_stats.csv"), ("c4", f"{a.round}_effnet_b3_f16_kernel_stats.csv")):
+        f = newest(os.path.join(a.src, sub, "**", "*kernel_stats.csv"))
+        if f:
+            shutil.copy(f, os.path.join(out, dst))
+            print("copied", f, "->", dst)
+    for sub, dst in (("c3_pmc_fetch", f"{a.round}_pmc_train_1024_b16_fetch_per_kernel.csv"),
+                     ("c4_pmc_fetch", f"{a.round}_pmc_effnet_b3_f16_fetch_per_kernel.csv")):
+        f = newest(os.path.join(a.src, sub, "**", "*counter_collection.csv"))
+        if not f:
+            continue
+        acc = defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == "FETCH_SIZE":
+                acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+        with open(os.path.join(out, dst), "w") as fo:
+            fo.write("Kernel_Name,Counter_Name,Dispatches,Mean_KB,Sum_KB,HBM_read_bytes_per_launch(x2 gfx950 correction)\n")
+            for k in sorted(acc, key=lambda k: -sum(acc[k])):
+                v = acc[k]
+                fo.write(f'"{k}",FETCH_SIZE,{len(v)},{sum(v) / len(v):.1f},{sum(v):.1f},{int(2000 * sum(v) / len(v))}\n')
+        print("wrote", dst)
+    for name in ("layers_b1.txt", "layers_b8.txt"):
+        f = os.path.join(a.src, name)
+        if os.path.exists(f):
+            shutil.copy(f, os.path.join(out, f"{a.round}_infer_{name}"))
+    f = os.path.join(a.src, "bench_line.json")
+    if os.path.exists(f) and os.path.getsize(f) > 100:
+        shutil.copy(f, os.path.join(out, f"{a.round}_bench_line.json"))
     per = defaultdict(lambda: defaultdict(list))    # kernel -> counter -> values
     clock = defaultdict(list)                        # kernel -> (GRBM_GUI_ACTIVE, duration ns) per dispatch
     for sub in ("pmc_fetch", "pmc_write", "pmc_mfma"):
