@@ -1885,33 +1885,45 @@ class TrainEngine:
 
     def _bucket_group_is_safe(self):
         """Does an async all-reduce of the bucket group, issued from the weight-gradient stream while that stream still
-        waits for something, leave the main stream's kernels alone?  (_C.wait_blocks; collective: the ranks agree.)"""
+        waits for something, leave the main stream alone — its kernels AND the SyncBN all-reduces it issues through the
+        other group (two c10d streams on one hardware queue: every SyncBN message would wait for the bucket's producers)?
+        (_C.wait_blocks; collective: the ranks agree.)  c10d picks a group's stream when the group is first used, so a group
+        that fails is replaced by a fresh one, three times at most."""
         import torch.distributed as dist
         side = self._side_stream
         if side is None or os.environ.get("RNET_STREAM_PROBE", "1") == "0" or dist.get_backend(self.pg_c1) != "nccl":
             return True
         main = torch.cuda.current_stream(self.dev)
         tiny = torch.zeros((64,), dtype=torch.float32, device=self.dev)
-        with torch.cuda.stream(side):
-            dist.all_reduce(tiny, group=self.pg_c1)          # c10d picks the group's stream at its first collective
-        torch.cuda.synchronize(self.dev)
+        tiny2 = torch.zeros((64,), dtype=torch.float32, device=self.dev)
         helper = torch.cuda.Stream(self.dev)
-        works = []
-
-        def pre():       # the group's stream now waits for the weight-gradient stream, which waits for the helper
+        self._keep.append(helper)
+        for attempt in range(4):
             with torch.cuda.stream(side):
-                works.append(dist.all_reduce(tiny, group=self.pg_c1, async_op=True))
+                dist.all_reduce(tiny, group=self.pg_c1)          # c10d picks the group's stream at its first collective
+            torch.cuda.synchronize(self.dev)
+            blocked = False
+            probes = [lambda: _C.check(self.lib.rn_probe_spin(1, ctypes.c_void_p(main.cuda_stream)), "rn_probe_spin")]
+            if self.sync_bn and self.native_comm is None:
+                probes.append(lambda: dist.all_reduce(tiny2, group=self.pg))
+            for probe in probes:                                 # (every probe on every rank: they may be collectives)
+                works = []
 
-        def probe():
-            _C.check(self.lib.rn_probe_spin(1, ctypes.c_void_p(main.cuda_stream)), "rn_probe_spin")
-        blocked = _C.wait_blocks(self.lib, side, probe, main, helper, pre=pre)
-        with torch.cuda.stream(side):
-            for w in works:
-                w.wait()
-        torch.cuda.synchronize(self.dev)
-        v = torch.tensor([0.0 if blocked else 1.0], device=self.dev)
-        dist.all_reduce(v, op=dist.ReduceOp.MIN, group=self.pg)
-        return bool(v.item() == 1.0)
+                def pre(works=works):   # the group's stream now waits for the weight-gradient stream, which waits for the helper
+                    with torch.cuda.stream(side):
+                        works.append(dist.all_reduce(tiny, group=self.pg_c1, async_op=True))
+                blocked = _C.wait_blocks(self.lib, side, probe, main, helper, pre=pre) or blocked
+                with torch.cuda.stream(side):
+                    for w in works:
+                        w.wait()
+                torch.cuda.synchronize(self.dev)
+            v = torch.tensor([0.0 if blocked else 1.0], device=self.dev)
+            dist.all_reduce(v, op=dist.ReduceOp.MIN, group=self.pg)
+            if bool(v.item() == 1.0):
+                return True
+            if attempt < 3:
+                self.pg_c1 = dist.new_group(backend=dist.get_backend(self.pg))
+        return False
 
     def _overlap_after_step(self, i, main, side):
         for j in self._bucket_at.get(i, ()):
