@@ -567,6 +567,7 @@ def run_dp_overhead(args, dev):
                 "dp_without_flag_read_ms": round(med["dp_without_flag_read"], 3),
                 "dp_plain_order_ms": round(med["dp_plain_order"], 3),     # RNET_C1_OVERLAP=0: all-reduce after the backward pass
                 "overlap_enabled": not bool(getattr(engs["dp"], "_overlap_unsafe", False)),
+                "max_host_ms_in_a_bucket_all_reduce_call": round(float(getattr(engs["dp"], "bucket_host_ms", 0.0)), 3),
                 "flag_read_ms": round(med["dp"] - med["dp_without_flag_read"], 3),
                 "syncbn_messages_per_step": eng.syncbn_messages_per_step, "gradient_buckets": len(getattr(eng, "_buckets", []) or []),
                 "clip_fired_last_step": bool(getattr(eng, "clip_fired", False)),

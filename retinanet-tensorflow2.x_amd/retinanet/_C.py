@@ -388,18 +388,18 @@ def wait_blocks(lib_, a, probe, main, helper, spin_us=600, pre=None):
     the data-parallel step (profiles/r05_ab): SyncBN all-reduces hop main -> c10d's stream -> main, the weight-gradient
     stream is full of "wait for the main stream" packets, and when the two shared a queue every message waited for the
     weight gradients queued before it: +6.4 ms per step inside bench.py, +1.2 ms in a fresh process (other queue map).
-    `helper`: a third stream that idles for `spin_us` and then releases the wait; `pre()`: enqueued behind the wait but in
-    front of the timed region (host time spent in it does not count).  Synchronises the device."""
+    `helper`: a third stream that idles for `spin_us` and then releases the wait; `pre()`: enqueued behind the wait, in front
+    of the probe (keep it warm: its host time counts against the 0.5 * spin_us threshold).  Synchronises the device."""
     import torch
     torch.cuda.synchronize(a.device)
     gate = torch.cuda.Event()
     check(lib_.rn_probe_spin(int(spin_us), c_void_p(helper.cuda_stream)), "rn_probe_spin")
     gate.record(helper)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(main)                          # BEFORE the barrier goes in: on a shared queue a later record waits behind it too
     a.wait_event(gate)                       # a's queue now holds a barrier that stays shut for ~spin_us
     if pre is not None:
         pre()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(main)
     probe()
     e1.record(main)
     torch.cuda.synchronize(a.device)

@@ -1962,9 +1962,12 @@ class TrainEngine:
                 # rn_allreduce_bucket (rn_comm.hip): one ncclAllReduce on the bucket's stream, behind its prepare kernel
                 self.native_comm_buckets.all_reduce_bucket(self.G[bkt["begin"]:bkt["end"]])
             elif self.dp_active:
+                import time as _time
                 import torch.distributed as dist
+                t0 = _time.perf_counter()
                 self._overlap_works.append(dist.all_reduce(self.G[bkt["begin"]:bkt["end"]], group=self.pg_c1,
                                                            async_op=True))
+                self.bucket_host_ms = max(getattr(self, "bucket_host_ms", 0.0), (_time.perf_counter() - t0) * 1e3)
         self._overlap_last_event = torch.cuda.Event()
         self._overlap_last_event.record(comm)
 
