@@ -215,6 +215,7 @@ def _worker_forced_dp(rank, world, port, out):
         r["sync_bn"], r["native"] = bool(eng.sync_bn), native is not None
         r["native_buckets"] = getattr(eng, "native_comm_buckets", None) is not None
         r["messages"] = eng.syncbn_messages_per_step
+        r["overlap_unsafe"] = bool(getattr(eng, "_overlap_unsafe", False))
         r["side_stream_probed"] = getattr(eng, "side_stream_probed", None)
         res[tag] = r
         if native is not None:
@@ -240,7 +241,10 @@ def test_forced_data_parallel_path_on_one_rank_of_rccl(cuda):
     r = out[0]
     assert not r["plain"]["sync_bn"] and not r["plain"]["overlapped"] and r["plain"]["messages"] == 0
     for tag in ("dp_torch", "dp_native"):
-        assert r[tag]["sync_bn"] and r[tag]["overlapped"] and r[tag]["messages"] > 10, (tag, r[tag]["messages"])
+        assert r[tag]["sync_bn"] and r[tag]["messages"] > 10, (tag, r[tag]["messages"])
+        # buckets go out during the backward pass — unless the queue probe found c10d's bucket stream on the main
+        # stream's hardware queue in this process: then the job keeps the plain order (and says so)
+        assert r[tag]["overlapped"] or r[tag]["overlap_unsafe"], tag
         assert not r[tag]["clip_fired"]
         np.testing.assert_array_equal(r[tag]["P"], r["plain"]["P"])
         assert r[tag]["loss"] == r["plain"]["loss"]
