@@ -105,3 +105,23 @@ def test_lr_schedules_match_oracle():
     for s in (0, 250, 499, 500, 998, 999, 1000, 1998, 1999, 2000, 2999):
         assert opt.lr(s) == pytest.approx(o.piecewise_constant_with_warmup(s, 0.0067, 500, [1000, 2000], [0.08, 0.008, 0.0008]))
     assert opt.lr(999) == 0.08 and opt.lr(1000) == 0.008     # boundaries shifted by -1 (piecewise...py:8-9)
+
+
+def test_pixel_pair_kernel_is_the_same_convolution():
+    """engine.pixel_pair_kernel: a 3x3 / stride 1 / pad 1 convolution on [N, H, W, C] equals the convolution with the paired
+    kernel on the same bytes seen as [N, H, W/2, 2C] (two adjacent pixels = one pixel of 2C channels) — checked against
+    torch's CPU conv in float64, including the left / right image borders (a pair column that is half padding)."""
+    import torch
+    import torch.nn.functional as F
+    from retinanet.model.engine import pixel_pair_kernel
+    g = torch.Generator().manual_seed(4)
+    for (N, H, W, C) in ((2, 5, 8, 3), (1, 4, 6, 8), (1, 1, 2, 4)):
+        x = torch.randn((N, H, W, C), generator=g, dtype=torch.float64)
+        w = torch.randn((3, 3, C, C), generator=g, dtype=torch.float64)        # HWIO
+        want = F.conv2d(x.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), padding=1).permute(0, 2, 3, 1)
+        w2 = pixel_pair_kernel(w)
+        assert w2.shape == (3, 3, 2 * C, 2 * C)
+        assert int((w2 != 0).sum()) == int((w != 0).sum()) * 2                 # every tap once per pixel of the pair
+        x2 = x.reshape(N, H, W // 2, 2 * C)
+        got = F.conv2d(x2.permute(0, 3, 1, 2), w2.permute(3, 2, 0, 1), padding=1).permute(0, 2, 3, 1).reshape(N, H, W, C)
+        torch.testing.assert_close(got, want, rtol=1e-12, atol=1e-12)
