@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--bias", action="store_true", help="shift only (bias + relu: the head towers)")
     ap.add_argument("--no-halo", action="store_true", help="3x3 launches on conv_big_kernel instead of conv_halo_kernel")
     ap.add_argument("--tile", type=int, default=0, help="1 = force 128-row kernel, 2 = force the 256x256 kernel, 3 = force 512x128 halo tiles")
+    ap.add_argument("--splitk", action="store_true", help="attach a split-K workspace (rn_conv_problem.splitk_ws)")
     a = ap.parse_args()
     lib = _C.lib()
     opts = _C.LaunchOpts(ablate=a.ablate or 0, conv_tile=a.tile or 0, conv_no_halo=1 if a.no_halo else 0,
@@ -101,6 +102,11 @@ def main():
             keep += [x, w, y, sc, sh, res]
             flops += 2 * a.batch * Ho * Ho * k * k * cin * cout
             byts += x.numel() * 2 + y.numel() * y.element_size() + (res.numel() * 2 if use_res else 0) + k * k * cin * cout * 2
+        if a.splitk:
+            ws = torch.zeros((int(lib.rn_conv_splitk_workspace_max_bytes()),), dtype=torch.uint8, device=dev)
+            p.splitk_ws, p.splitk_ws_bytes = ws.data_ptr(), ws.numel()
+            keep.append(ws)
+            print(f"  kernel id {lib.rn_conv_kernel_id(ctypes.byref(p))}, split workspace {lib.rn_conv_splitk_workspace_bytes(ctypes.byref(p))} bytes")
         st = _C.current_stream()
         for _ in range(3):
             _C.check(lib.rn_conv2d_nhwc_fwd(ctypes.byref(p), st))
