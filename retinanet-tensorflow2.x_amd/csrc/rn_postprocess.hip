@@ -487,7 +487,7 @@ struct NmsParams {
   long long cap;
   int soft_off;         // soft: byte offset of the soft-NMS state in LDS (the sort buffer's unused tail, or behind everything)
   int chunk_cap;        // keys the LDS sort buffer holds: RN_SORT_CAP for soft NMS (the whole list is one chunk), RN_HARD_CHUNK else
-  int part_off, pad_;   // hard: byte offset of the four waves' partial results (32 + 512 B)
+  int part_off, first_chunk;   // hard: byte offset of the four waves' partial results (32 + 512 B); keys of the first sorted chunk
 };
 
 __global__ void __launch_bounds__(RN_PP_THREADS)
@@ -529,9 +529,9 @@ nms_per_class_kernel(NmsParams p, const int* __restrict__ counts, const unsigned
   while (processed < limit) {
     if (s_misc[2] >= p.max_det) break;
     // hard NMS usually fills max_det from the first few hundred candidates: sort a small first
-    // chunk, fall back to full LDS-sized chunks only when suppression eats through it
+    // chunk (NmsParams.first_chunk), fall back to full LDS-sized chunks only when suppression eats through it
     int cap_chunk = p.chunk_cap;
-    if (!p.soft && processed == 0) cap_chunk = 1024;
+    if (!p.soft && processed == 0) cap_chunk = p.first_chunk;
     const int take = (limit - processed) < cap_chunk ? (limit - processed) : cap_chunk;
     const unsigned long long lower =
         next_chunk_sorted(kload, n, n - processed, take, upper, skeys, s_hist, s_prefix, s_misc);
@@ -887,8 +887,10 @@ static int run_nms_stage(const DetectWs& w, int B, long long cap, int K, const B
   p.iou_thr = iou_threshold;
   p.score_thr = score_threshold;
   p.cap = cap;
-  p.pad_ = 0;
   const size_t lds = nms_lds_bytes(p.soft, top_k > 0 ? (long long)top_k : cap, &p.soft_off, &p.chunk_cap, &p.part_off);
+  // first sorted chunk of a hard-NMS list: 512 keys (round 5, same box: 1024 -> 512 keys batch-1 serving 1.571 -> 1.552 ms,
+  // batch 8 3.551 -> 3.546; 256 / 128 keys 1.66 / 3.57 - 3.60: a second chunk — another radix select — too often)
+  p.first_chunk = 512 < p.chunk_cap ? 512 : p.chunk_cap;
   RN_CHECK_HIP(hipFuncSetAttribute((const void*)nms_per_class_kernel,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(nms_per_class_kernel, dim3(B * K), dim3(RN_PP_THREADS), lds, st, p, w.counts, w.keys, bs,
