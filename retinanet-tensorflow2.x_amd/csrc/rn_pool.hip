@@ -229,13 +229,25 @@ __global__ void __launch_bounds__(POOL_THREADS) balance_add_kernel(Balance b) {
       const int f = 1 << (l - b.mid);
 #pragma unroll
       for (int q = 0; q < 8; ++q) a.v[q] = -INFINITY;
-      for (int dy = 0; dy < f; ++dy)
-        for (int dx = 0; dx < f; ++dx) {
-          const bf8 u =
-              unpack8(b.avg[(((long long)n * Hm) + (y * f + dy)) * Wm * p.C8 + (long long)(x * f + dx) * p.C8 + c]);
+      // A coarse-level thread pools f x f values of the average (64 for the coarsest level of a five-level pyramid).  As a
+      // rolled loop that is 64 dependent L2 round trips — 25 us of batch-1 serving, whatever the tensor sizes; in rows of
+      // up to eight independent loads the latency is paid f times.
+      const uint4* row0 = b.avg + (((long long)n * Hm) + (long long)y * f) * Wm * p.C8 + (long long)(x * f) * p.C8 + c;
+      for (int dy = 0; dy < f; ++dy) {
+        const uint4* rp = row0 + (long long)dy * Wm * p.C8;
+        for (int dx0 = 0; dx0 < f; dx0 += 8) {
+          uint4 raw[8];
 #pragma unroll
-          for (int q = 0; q < 8; ++q) a.v[q] = fmaxf(a.v[q], u.v[q]);
+          for (int j = 0; j < 8; ++j)   // f is a power of two: below 8 the extra lanes re-read a column of the window (max unchanged)
+            raw[j] = rp[(long long)(f >= 8 ? dx0 + j : (j & (f - 1))) * p.C8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const bf8 u = unpack8(raw[j]);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a.v[q] = fmaxf(a.v[q], u.v[q]);
+          }
         }
+      }
     }
     const long long o = (((long long)n * Hl) + y) * Wl * p.C8 + (long long)x * p.C8 + c;
     const bf8 f = unpack8(p.in[l][o]);
