@@ -534,9 +534,13 @@ int rn_maxpool2d_nhwc_bwd(const void* x, const void* dy, void* dx, int N, int H,
 /* one level of the FPN top-down backward: din = (dout + sum2x2(din_finer)) * act'(out) */
 int rn_fpn_topdown_bwd_level(const void* dout, const void* din_finer, const void* out, void* din, int N, int H,
                              int W, int C, int act, void* stream);
+/* davg_scratch: rn_balance_features_bwd_scratch_bytes() bytes — d_avg at the intermediate level, then one byte per (pixel,
+ * channel) of every coarser level: where in its pooling window the average has its first maximum, found once per coarse
+ * pixel instead of by every fine pixel of the window.  RN_ENOMEM when too small. */
+size_t rn_balance_features_bwd_scratch_bytes(int num_levels, int mid, int N, int H0, int W0, int C);
 int rn_balance_features_bwd(void* const* dout, void* const* in, void* const* din, const void* avg,
-                            void* davg_scratch, int num_levels, int mid, int N, int H0, int W0, int C,
-                            void* stream);
+                            void* davg_scratch, size_t scratch_bytes, int num_levels, int mid, int N, int H0, int W0,
+                            int C, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * a10  Executor._train_step's optimizer side (executor.py:296-327,401-441; optimizers/builder.py:27-71)

@@ -211,7 +211,8 @@ _SIGNATURES = {
                                       c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rn_fpn_topdown_bwd_level": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                          c_int, c_void_p]),
-    "rn_balance_features_bwd": (c_int, [_PP, _PP, _PP, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+    "rn_balance_features_bwd_scratch_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "rn_balance_features_bwd": (c_int, [_PP, _PP, _PP, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int,
                                         c_int, c_void_p]),
     "rn_optim_chunk": (c_int, []),
     "rn_optim_workspace_bytes": (c_size_t, [c_int, c_int]),

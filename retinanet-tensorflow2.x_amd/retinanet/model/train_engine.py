@@ -1145,10 +1145,12 @@ class TrainEngine:
                 din = [self.grad[n] for n in names]
                 for n in names:
                     mark(n)
-                scratch = torch.empty_like(self.bal_avg)
+                nsc = lib.rn_balance_features_bwd_scratch_bytes(len(names), op["mid"], B, ins[0].shape[1], ins[0].shape[2],
+                                                                ins[0].shape[3])
+                scratch = torch.empty((max(int(nsc), 256),), dtype=torch.uint8, device=self.dev)
                 pd, pi, pn = _C.ptr_array(dout), _C.ptr_array(ins), _C.ptr_array(din)
                 self._keep += [pd, pi, pn, scratch]
-                a = (pd, pi, pn, self.bal_avg.data_ptr(), scratch.data_ptr(), len(names), op["mid"], B,
+                a = (pd, pi, pn, self.bal_avg.data_ptr(), scratch.data_ptr(), scratch.numel(), len(names), op["mid"], B,
                      ins[0].shape[1], ins[0].shape[2], ins[0].shape[3])
                 self.bwd_steps.append(lambda st, a=a: _C.check(lib.rn_balance_features_bwd(*a, st), "balance_bwd"))
 

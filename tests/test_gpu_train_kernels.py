@@ -766,9 +766,11 @@ def test_pool_topdown_balance_backward(cuda, build):
     d_d = [t.to(cuda) for t in douts]
     din = [torch.empty_like(t) for t in d_d]
     avg_d = avg.detach().permute(0, 2, 3, 1).contiguous().to(H16).to(cuda)
-    scratch = torch.empty_like(avg_d)
+    scratch = torch.empty((lib.rn_balance_features_bwd_scratch_bytes(L, mid, N, H0, H0, C),), dtype=torch.uint8, device=cuda)
+    assert lib.rn_balance_features_bwd(_C.ptr_array(d_d), _C.ptr_array(ins_d), _C.ptr_array(din), _C.ptr(avg_d),
+                                       _C.ptr(scratch), avg_d.numel() * 2, L, mid, N, H0, H0, C, st) == _C.RN_ENOMEM
     _C.check(lib.rn_balance_features_bwd(_C.ptr_array(d_d), _C.ptr_array(ins_d), _C.ptr_array(din), _C.ptr(avg_d),
-                                         _C.ptr(scratch), L, mid, N, H0, H0, C, st))
+                                         _C.ptr(scratch), scratch.numel(), L, mid, N, H0, H0, C, st))
     torch.cuda.synchronize()
     for l in range(L):
         ref = leaves[l].grad.permute(0, 2, 3, 1)
