@@ -512,6 +512,10 @@ typedef struct {
   rn_bn_segment seg[RN_CONV_MAX_SEGMENTS];
 } rn_bn_problem;
 
+/* Workspace of the reduction passes: [per-chunk partial sums][ticket counters][part slots].  A segment with more than
+ * 512 rows of partial sums has its stage-2 reduction cut into parts whose last arriver (an atomic ticket) adds the parts
+ * in part order; the ticket counters must be ZERO before the first launch on a workspace — zero the workspace once after
+ * allocating it — and every launch leaves them zero (the contract of rn_conv_problem.splitk_ws). */
 size_t rn_bn_workspace_bytes(const rn_bn_problem* problem /* host */);
 size_t rn_bn_partial_offset_bytes(const rn_bn_problem* problem, int segment);   /* forward-stats partials in the workspace */
 size_t rn_bn_bwd_partial_offset_bytes(const rn_bn_problem* problem, int segment);   /* backward partials (ext_chunks_bwd) */

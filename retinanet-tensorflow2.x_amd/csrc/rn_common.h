@@ -123,3 +123,57 @@ __device__ __forceinline__ unsigned long long rn_wave_max_u64(unsigned long long
   }
   return v;
 }
+
+// a / b for 0 <= a < 2^22, b > 0, through the float reciprocal (rcp_b ~ 1 / b): the estimate is off by at most
+// one, fixed up with the exact remainder — ~8 VALU instructions against ~45 for the compiler's integer division.
+// The tile set-up code of the persistent kernels runs a few dozen of these per lane per tile, on all eight waves.
+// the reciprocal estimate for rn_fdiv: v_rcp_f32 (1 ulp).  a * rcp is then within 0.75 of a / b for a < 2^22, which the
+// +-1 fix-up covers; __frcp_rn (correctly rounded under -fhip-fp32-correctly-rounded-divide-sqrt) compiled to a
+// 12-instruction v_div_scale / v_div_fmas / v_div_fixup sequence per call, ~60 instructions per tile set-up
+__device__ __forceinline__ float rn_rcp(float b) { return __builtin_amdgcn_rcpf(b); }
+__device__ __forceinline__ int rn_fdiv(int a, int b, float rcp_b) {
+  int q = (int)((float)a * rcp_b);
+  const int r = a - q * b;
+  q += (r >= b ? 1 : 0) - (r < 0 ? 1 : 0);
+  return q;
+}
+
+// (n, y, x, 16-byte channel group) of a flat index into an [N][H][W][C8] tensor, for the elementwise NHWC kernels (one
+// thread per 16 bytes).  Six integer divisions by run-time values per thread made those kernels VALU-bound: ~100
+// instructions each as 64-bit divisions, ~25 as 32-bit ones; the kernels ran at ~2 TB/s.  mode (uniform, from the
+// tensor's size): 0 = 64-bit divisions (2^31 elements or more), 1 = 32-bit divisions, 2 = fewer than 2^22 pixels:
+// the channel group by mask / shift when C8 is a power of two, rows and images through rn_fdiv (~8 instructions each).
+struct RnIdx4 { int n, y, x, c; };
+__device__ __forceinline__ int rn_decode_mode(long long total, int C8) {
+  return total >= (1ll << 31) ? 0 : (total < ((long long)C8 << 22) ? 2 : 1);
+}
+__device__ __forceinline__ RnIdx4 rn_decode4(long long t, int C8, int W, int H, int mode) {
+  RnIdx4 r;
+  if (mode == 2) {
+    const unsigned u = (unsigned)t;
+    unsigned pix;
+    if ((C8 & (C8 - 1)) == 0) {
+      r.c = (int)(u & (unsigned)(C8 - 1));
+      pix = u >> (31 - __builtin_clz((unsigned)C8));
+    } else {
+      pix = u / (unsigned)C8;
+      r.c = (int)(u - pix * (unsigned)C8);
+    }
+    const int row = rn_fdiv((int)pix, W, rn_rcp((float)W));
+    r.x = (int)pix - row * W;
+    r.n = rn_fdiv(row, H, rn_rcp((float)H));
+    r.y = row - r.n * H;
+  } else if (mode == 1) {
+    unsigned u = (unsigned)t;
+    r.c = (int)(u % (unsigned)C8); u /= (unsigned)C8;
+    r.x = (int)(u % (unsigned)W); u /= (unsigned)W;
+    r.y = (int)(u % (unsigned)H);
+    r.n = (int)(u / (unsigned)H);
+  } else {
+    r.c = (int)(t % C8); t /= C8;
+    r.x = (int)(t % W); t /= W;
+    r.y = (int)(t % H);
+    r.n = (int)(t / H);
+  }
+  return r;
+}

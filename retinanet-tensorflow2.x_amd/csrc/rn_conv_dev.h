@@ -64,20 +64,7 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wav
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)lds_wave_base, 16, (int)voff, 0, 0, 0);
 }
 
-// a / b for 0 <= a < 2^22, b > 0, through the float reciprocal (rcp_b ~ 1 / b): the estimate is off by at most
-// one, fixed up with the exact remainder — ~8 VALU instructions against ~45 for the compiler's integer division.
-// The tile set-up code of the persistent kernels runs a few dozen of these per lane per tile, on all eight waves.
-// the reciprocal estimate for rn_fdiv: v_rcp_f32 (1 ulp).  a * rcp is then within 0.75 of a / b for a < 2^22, which the
-// +-1 fix-up covers; __frcp_rn (correctly rounded under -fhip-fp32-correctly-rounded-divide-sqrt) compiled to a
-// 12-instruction v_div_scale / v_div_fmas / v_div_fixup sequence per call, ~60 instructions per tile set-up
-__device__ __forceinline__ float rn_rcp(float b) { return __builtin_amdgcn_rcpf(b); }
-__device__ __forceinline__ int rn_fdiv(int a, int b, float rcp_b) {
-  int q = (int)((float)a * rcp_b);
-  const int r = a - q * b;
-  q += (r >= b ? 1 : 0) - (r < 0 ? 1 : 0);
-  return q;
-}
-
+// (rn_rcp / rn_fdiv: rn_common.h)
 #define RN_OOB 0x80000000u
 
 

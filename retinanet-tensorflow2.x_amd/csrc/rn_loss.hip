@@ -31,6 +31,8 @@ struct LossLevels {
   int cls_stride16, box_stride16, na;
   long long off[RN_LOSS_MAX_LEVELS + 1];   // anchor boundaries
   long long vbeg[RN_LOSS_MAX_LEVELS + 1];  // prefix of B*n_l*(K/V) work items
+  int cb[RN_LOSS_MAX_LEVELS + 1];          // focal4_kernel: prefix of the levels' workgroups (a workgroup never crosses a level)
+  unsigned chunk;                          // focal4_kernel: work items (4 logits each) per workgroup, a multiple of the block size
 };
 
 // The kernel is VALU-bound, not HBM-bound, when exp / log / pow / the divisions are the software routines of
@@ -75,6 +77,132 @@ __device__ __forceinline__ void focal_elem(float x, bool pos, float alpha, float
   const float dmod = pos ? -gamma * p * mod : gamma * omp * mod;
   grad = a_t * (mod * (p - ys) + ce * dmod);
 }
+
+// ---- K % 4 == 0 (every shipped config: 80 / 90 / 20 classes): four logits per thread and iteration ------------------
+// The first version (focal_kernel<4> below, kept for V = 1) found its level with a loop over lv.vbeg and fetched the
+// level's pointers / sizes with dynamically indexed loads from the kernel-argument segment IN FRONT of every logit load
+// (two dependent memory round trips per iteration), divided three times per iteration, and spent ~62 VALU issue cycles
+// per logit: 0.43 ms for the 196 M logits of the bench batch, the sum of its VALU time and its HBM time rather than
+// the larger of the two.  Here
+//   * a workgroup = (level, chunk of lv.chunk consecutive float4s of that level's [B * n_l][K] logits): everything that
+//     depends on the level is uniform and read once; a thread's (image, anchor, class quad, pixel) indices advance
+//     incrementally by the block stride (no division inside the loop);
+//   * the logits / targets of iteration i + 1 are loaded before iteration i is computed;
+//   * two logits at a time through the packed fp32 pipe (v_pk_mul / add / fma_f32: the log1p series, the products of the
+//     loss and its gradient — 2 results per issue cycle), ONE reciprocal r = 1 / ((1 + t)(2 + t)) for both
+//     1 / (1 + t) = r (2 + t) (the sigmoid) and 1 / (2 + t) = r (1 + t) (the log1p argument).
+typedef float loss_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ loss_f2 f2_fma(loss_f2 a, loss_f2 b, loss_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ loss_f2 f2_splat(float v) { return loss_f2{v, v}; }
+
+template <bool G15>
+__device__ __forceinline__ void focal_pair(loss_f2 x, bool pos0, bool pos1, float alpha, float gamma, float ls,
+                                           loss_f2& loss, loss_f2& grad) {
+  const loss_f2 y = {pos0 ? 1.0f : 0.0f, pos1 ? 1.0f : 0.0f};
+  const loss_f2 ys = y * f2_splat(1.0f - ls) + f2_splat(0.5f * ls);
+  const loss_f2 t = {hw_exp2(-fabsf(x.x) * 1.44269504088896341f), hw_exp2(-fabsf(x.y) * 1.44269504088896341f)};
+  const loss_f2 xp = {fmaxf(x.x, 0.0f), fmaxf(x.y, 0.0f)};
+  const loss_f2 d1 = f2_splat(1.0f) + t, d2 = f2_splat(2.0f) + t;
+  const loss_f2 dd = d1 * d2;                       // in (2, 6]
+  const loss_f2 r = {hw_rcp(dd.x), hw_rcp(dd.y)};
+  const loss_f2 inv = r * d2;                       // 1 / (1 + t)
+  const loss_f2 s = t * (r * d1);                   // t / (2 + t) <= 1/3
+  const loss_f2 z = s * s;
+  loss_f2 pl = f2_splat(1.0f / 15.0f);              // log1p(t) = 2 atanh(s) = 2 s (1 + z/3 + z^2/5 + ...)
+  pl = f2_fma(pl, z, f2_splat(1.0f / 13.0f));
+  pl = f2_fma(pl, z, f2_splat(1.0f / 11.0f));
+  pl = f2_fma(pl, z, f2_splat(1.0f / 9.0f));
+  pl = f2_fma(pl, z, f2_splat(1.0f / 7.0f));
+  pl = f2_fma(pl, z, f2_splat(1.0f / 5.0f));
+  pl = f2_fma(pl, z, f2_splat(1.0f / 3.0f));
+  pl = f2_fma(pl, z, f2_splat(1.0f));
+  const loss_f2 l1p = f2_splat(2.0f) * s * pl;
+  const loss_f2 ce = xp - x * ys + l1p;
+  const loss_f2 ti = t * inv;
+  const loss_f2 p = {x.x >= 0.0f ? inv.x : ti.x, x.y >= 0.0f ? inv.y : ti.y};       // sigmoid(x), stable both signs
+  const loss_f2 omp = {x.x >= 0.0f ? ti.x : inv.x, x.y >= 0.0f ? ti.y : inv.y};     // 1 - sigmoid(x)
+  const loss_f2 q = {pos0 ? omp.x : p.x, pos1 ? omp.y : p.y};
+  const loss_f2 a_t = {pos0 ? alpha : 1.0f - alpha, pos1 ? alpha : 1.0f - alpha};
+  loss_f2 mod;
+  if (G15) {   // q^1.5 = q sqrt(q): one transcendental instead of log2 + exp2
+    mod = q * loss_f2{__builtin_amdgcn_sqrtf(q.x), __builtin_amdgcn_sqrtf(q.y)};
+  } else {
+    mod.x = q.x > 0.0f ? hw_exp2(gamma * hw_log2(q.x)) : 0.0f;
+    mod.y = q.y > 0.0f ? hw_exp2(gamma * hw_log2(q.y)) : 0.0f;
+  }
+  loss = a_t * mod * ce;
+  const loss_f2 dm = {pos0 ? -p.x : omp.x, pos1 ? -p.y : omp.y};
+  const loss_f2 dmod = f2_splat(gamma) * dm * mod;
+  grad = a_t * (mod * (p - ys) + ce * dmod);
+}
+
+template <bool G15>
+__global__ void __launch_bounds__(RN_LOSS_THREADS)
+focal4_kernel(LossLevels lv, int K, long long A, const float* __restrict__ class_targets,
+              const float* __restrict__ normalizer, float alpha, float gamma, float ls, float gscale,
+              int write_grad, double* __restrict__ partials) {
+  int l = 0;
+  while (l + 1 < lv.num_levels && (int)blockIdx.x >= lv.cb[l + 1]) ++l;
+  const unsigned KV = (unsigned)K >> 2;
+  const unsigned n_l = (unsigned)(lv.off[l + 1] - lv.off[l]);
+  const unsigned items = (unsigned)(lv.vbeg[l + 1] - lv.vbeg[l]);   // B * n_l * KV < 2^32 (the launcher checks)
+  const unsigned start = ((unsigned)blockIdx.x - (unsigned)lv.cb[l]) * lv.chunk;
+  const unsigned end = items - start > lv.chunk ? start + lv.chunk : items;
+  const float4* __restrict__ src = (const float4*)lv.cls[l];
+  const float* __restrict__ tgt = class_targets + lv.off[l];
+  const unsigned PK = (unsigned)lv.na * KV;                           // float4s per pixel (write_grad == 2)
+  // block stride in (row, class quad) and (pixel, quad inside the pixel) steps
+  const unsigned dq = RN_LOSS_THREADS / KV, dr = RN_LOSS_THREADS - dq * KV;
+  const unsigned pq = write_grad == 2 ? RN_LOSS_THREADS / PK : 0, pr = write_grad == 2 ? RN_LOSS_THREADS - pq * PK : 0;
+  const float gs = gscale / normalizer[0];
+  unsigned local = start + threadIdx.x;
+  unsigned row = local / KV, kv = local - row * KV;
+  unsigned b = row / n_l, j = row - b * n_l;
+  unsigned pix = 0, prem = 0;
+  if (write_grad == 2) { pix = local / PK; prem = local - pix * PK; }
+  float acc = 0.0f;
+  float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  float ct = -1.0f;
+  if (local < end) { v = src[local]; ct = tgt[(long long)b * A + j]; }
+  while (local < end) {
+    // the next iteration's indices and loads first
+    const unsigned nlocal = local + RN_LOSS_THREADS;
+    unsigned nkv = kv + dr, nj = j + dq, nb = b;
+    if (nkv >= KV) { nkv -= KV; ++nj; }
+    while (nj >= n_l) { nj -= n_l; ++nb; }
+    float4 vn = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float ctn = -1.0f;
+    if (nlocal < end) { vn = src[nlocal]; ctn = tgt[(long long)nb * A + nj]; }
+    const bool ignore = (ct == -2.0f);
+    const int c0 = (int)ct - (int)(kv * 4);     // the positive class relative to this quad
+    loss_f2 lo0, gr0, lo1, gr1;
+    focal_pair<G15>(loss_f2{v.x, v.y}, c0 == 0, c0 == 1, alpha, gamma, ls, lo0, gr0);
+    focal_pair<G15>(loss_f2{v.z, v.w}, c0 == 2, c0 == 3, alpha, gamma, ls, lo1, gr1);
+    if (ignore) { lo0 = f2_splat(0.0f); lo1 = lo0; gr0 = lo0; gr1 = lo0; }
+    acc += lo0.x; acc += lo0.y; acc += lo1.x; acc += lo1.y;
+    gr0 = gr0 * f2_splat(gs);
+    gr1 = gr1 * f2_splat(gs);
+    if (write_grad == 1) {
+      ((float4*)lv.dcls[l])[local] = make_float4(gr0.x, gr0.y, gr1.x, gr1.y);
+    } else if (write_grad == 2) {
+      uint16_t* dst = lv.dcls16[l] + (long long)pix * lv.cls_stride16 + prem * 4;
+      *(uint2*)dst = make_uint2(rn_pack_bf16x2(gr0.x, gr0.y), rn_pack_bf16x2(gr1.x, gr1.y));
+      prem += pr; pix += pq;
+      if (prem >= PK) { prem -= PK; ++pix; }
+    }
+    local = nlocal; kv = nkv; j = nj; b = nb; v = vn; ct = ctn;
+  }
+  __shared__ double sred[RN_LOSS_THREADS / 64];
+  double d = rn_wave_sum_d((double)acc);
+  if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = d;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int w = 0; w < RN_LOSS_THREADS / 64; ++w) s += sred[w];
+    partials[blockIdx.x] = s;
+  }
+}
+
 
 template <int V>
 __global__ void __launch_bounds__(RN_LOSS_THREADS)
@@ -242,7 +370,7 @@ static int loss_launch(const float* const* class_logits, const float* const* box
   }
   const int V = (K % 4 == 0) ? 4 : 1;
   const int write_grad = (d_class_bf16 && d_box_bf16) ? 2 : (d_class_logits && d_box_preds) ? 1 : 0;
-  LossLevels lv;
+  LossLevels lv = {};
   lv.cls_stride16 = class_pix_stride; lv.box_stride16 = box_pix_stride; lv.na = anchors_per_location;
   if (write_grad == 2) {
     RN_CHECK_ARG(anchors_per_location > 0 && class_pix_stride >= anchors_per_location * K &&
@@ -276,16 +404,38 @@ static int loss_launch(const float* const* class_logits, const float* const* box
   double* box_part = cls_part + 2048;
   for (int l = 0; l < num_levels; ++l)
     RN_CHECK_ARG(lv.vbeg[l + 1] - lv.vbeg[l] < (1ll << 32), "rn_retinanet_loss: level %d has >= 2^32 logit vectors", l);
-  const int nb_cls = loss_blocks(lv.vbeg[num_levels]);
+  int nb_cls = loss_blocks(lv.vbeg[num_levels]);
   const int nb_box = loss_blocks((long long)B * A);
-  if (V == 4)
-    hipLaunchKernelGGL(focal_kernel<4>, dim3(nb_cls), dim3(RN_LOSS_THREADS), 0, st, lv, B, K, A, class_targets,
-                       normalizer, alpha, gamma, label_smoothing, class_loss_weight * grad_scale, write_grad,
-                       cls_part);
-  else
+  if (V == 4) {
+    // workgroup = (level, chunk): the chunk is the smallest multiple of the block size that keeps the launch inside the
+    // 2048 partial sums of the workspace
+    long long iters = rn_cdiv(lv.vbeg[num_levels], 2000ll * RN_LOSS_THREADS);
+    if (iters < 1) iters = 1;
+    for (;; ++iters) {
+      long long nb = 0;
+      lv.cb[0] = 0;
+      for (int l = 0; l < num_levels; ++l) {
+        nb += rn_cdiv(lv.vbeg[l + 1] - lv.vbeg[l], iters * RN_LOSS_THREADS);
+        lv.cb[l + 1] = (int)nb;
+      }
+      if (nb <= 2048) break;
+    }
+    RN_CHECK_ARG(iters * RN_LOSS_THREADS < (1ll << 31), "rn_retinanet_loss: too many logits");
+    for (int l = 0; l < num_levels; ++l)   // a thread's index may run one block stride past the level's end
+      RN_CHECK_ARG(lv.vbeg[l + 1] - lv.vbeg[l] < (1ll << 32) - (1ll << 16), "rn_retinanet_loss: level %d has too many logits", l);
+    lv.chunk = (unsigned)(iters * RN_LOSS_THREADS);
+    nb_cls = lv.cb[num_levels];
+    if (gamma == 1.5f)
+      hipLaunchKernelGGL(focal4_kernel<true>, dim3(nb_cls), dim3(RN_LOSS_THREADS), 0, st, lv, K, A, class_targets,
+                         normalizer, alpha, gamma, label_smoothing, class_loss_weight * grad_scale, write_grad, cls_part);
+    else
+      hipLaunchKernelGGL(focal4_kernel<false>, dim3(nb_cls), dim3(RN_LOSS_THREADS), 0, st, lv, K, A, class_targets,
+                         normalizer, alpha, gamma, label_smoothing, class_loss_weight * grad_scale, write_grad, cls_part);
+  } else {
     hipLaunchKernelGGL(focal_kernel<1>, dim3(nb_cls), dim3(RN_LOSS_THREADS), 0, st, lv, B, K, A, class_targets,
                        normalizer, alpha, gamma, label_smoothing, class_loss_weight * grad_scale, write_grad,
                        cls_part);
+  }
   RN_CHECK_LAUNCH();
   hipLaunchKernelGGL(huber_kernel, dim3(nb_box), dim3(RN_LOSS_THREADS), 0, st, lv, B, A,
                      (const float4*)box_targets, normalizer, delta, box_loss_weight * grad_scale / 4.0f,

@@ -32,17 +32,48 @@ optim_sqnorm_kernel(float* __restrict__ g, const float* __restrict__ w, const Op
   if (b1 > s.size) b1 = s.size;
   float acc = 0.0f, accw = 0.0f;
   const bool touch = s.wd || unscale != 1.0f;
-  for (long long i = b0 + threadIdx.x; i < b1; i += OPT_THREADS) {
-    float v = g[s.offset + i] * unscale;   // LossScaleOptimizer.get_unscaled_gradients (executor.py:429-430)
-    if (s.wd) {
-      const float wv = w[s.offset + i];
-      v += wdc * wv;
-      accw += wv * wv;
+  // LossScaleOptimizer.get_unscaled_gradients (executor.py:429-430), then the l2 gradient of the decayed tensors
+#define SQNORM_ELEM(gv_, wv_)                 \
+  do {                                        \
+    float v__ = (gv_) * unscale;              \
+    if (s.wd) {                               \
+      v__ += wdc * (wv_);                     \
+      accw += (wv_) * (wv_);                  \
+    }                                         \
+    (gv_) = v__;                              \
+    acc += v__ * v__;                         \
+  } while (0)
+  if (((s.offset + b0) & 3) == 0) {   // 16 bytes per lane (the arena aligns every tensor to 4 elements); scalar tail
+    const long long base = s.offset + b0;
+    const int n = (int)(b1 - b0), n4 = n >> 2;
+    float4* g4 = (float4*)(g + base);
+    const float4* w4 = (const float4*)(w + base);
+    float4* l4 = local_copy ? (float4*)(local_copy + base) : nullptr;   // this rank's gradient, kept for the clip correction
+    for (int i = threadIdx.x; i < n4; i += OPT_THREADS) {
+      float4 gv = g4[i], wv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (s.wd) wv = w4[i];
+      SQNORM_ELEM(gv.x, wv.x); SQNORM_ELEM(gv.y, wv.y); SQNORM_ELEM(gv.z, wv.z); SQNORM_ELEM(gv.w, wv.w);
+      if (touch) g4[i] = gv;
+      if (l4) l4[i] = gv;
     }
-    if (touch) g[s.offset + i] = v;
-    if (local_copy) local_copy[s.offset + i] = v;   // this rank's gradient, kept for the clip correction
-    acc += v * v;
+    if ((int)threadIdx.x < (n & 3)) {
+      const long long o = base + 4 * n4 + threadIdx.x;
+      float gv = g[o];
+      const float wv = s.wd ? w[o] : 0.0f;
+      SQNORM_ELEM(gv, wv);
+      if (touch) g[o] = gv;
+      if (local_copy) local_copy[o] = gv;
+    }
+  } else {
+    for (long long i = b0 + threadIdx.x; i < b1; i += OPT_THREADS) {
+      float gv = g[s.offset + i];
+      const float wv = s.wd ? w[s.offset + i] : 0.0f;
+      SQNORM_ELEM(gv, wv);
+      if (touch) g[s.offset + i] = gv;
+      if (local_copy) local_copy[s.offset + i] = gv;
+    }
   }
+#undef SQNORM_ELEM
   __shared__ double red[2][OPT_THREADS / 64];
   const double d = rn_wave_sum_d((double)acc), dw = rn_wave_sum_d((double)accw);
   if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = d; red[1][threadIdx.x >> 6] = dw; }
@@ -71,6 +102,9 @@ optim_factors_kernel(const OptSeg* __restrict__ segs, int nseg, const double* __
   for (int t = threadIdx.x; t < nseg; t += blockDim.x) {
     const OptSeg s = segs[t];
     double sq = 0.0, sw = 0.0;
+    // (the adds stay in block order; unrolled so that eight loads are in flight — the thread that owns the largest
+    // tensor walks ~300 partials, one memory round trip each before)
+#pragma unroll 8
     for (int b = 0; b < s.nblocks; ++b) { sq += partial[s.block_begin + b]; sw += partial_w[s.block_begin + b]; }
     const float norm = (float)sqrt(sq);
     const float f = clip > 0.0f ? clip / fmaxf(norm, clip) : 1.0f;  // tf.clip_by_norm
@@ -137,19 +171,57 @@ optim_sgd_kernel(float* __restrict__ w, const float* __restrict__ g, float* __re
   const long long b0 = (long long)(blockIdx.x - s.block_begin) * OPT_CHUNK;
   long long b1 = b0 + OPT_CHUNK;
   if (b1 > s.size) b1 = s.size;
-  for (long long i = b0 + threadIdx.x; i < b1; i += OPT_THREADS) {
-    const long long o = s.offset + i;
-    const float vel = momentum * v[o] - lr * g[o];
-    // Keras SGD: w += v  (momentum), or w += momentum * v - lr * g with the NEW v (nesterov=True)
-    const float nw = w[o] + (nesterov ? momentum * vel - lr * g[o] : vel);
-    v[o] = vel;
-    w[o] = nw;
-    if (use_ema) {
-      const float e = ema[o];
-      ema[o] = e - (1.0f - ema_decay) * (e - nw);
+#define SGD_ELEM(w_, g_, v_, e_)                                                                       \
+  do {                                                                                                 \
+    const float vel__ = momentum * (v_) - lr * (g_);                                                   \
+    /* Keras SGD: w += v  (momentum), or w += momentum * v - lr * g with the NEW v (nesterov=True) */   \
+    const float nw__ = (w_) + (nesterov ? momentum * vel__ - lr * (g_) : vel__);                       \
+    (v_) = vel__;                                                                                      \
+    (w_) = nw__;                                                                                       \
+    if (use_ema) (e_) = (e_) - (1.0f - ema_decay) * ((e_) - nw__);                                     \
+  } while (0)
+  const bool vec = ((s.offset + b0) & 3) == 0 && (s.bf16_offset < 0 || ((s.bf16_offset + b0) & 3) == 0);
+  if (vec) {   // 16 bytes per lane and array; scalar tail
+    const long long base = s.offset + b0;
+    const int n = (int)(b1 - b0), n4 = n >> 2;
+    float4* w4 = (float4*)(w + base);
+    const float4* g4 = (const float4*)(g + base);
+    float4* v4 = (float4*)(v + base);
+    float4* e4 = use_ema ? (float4*)(ema + base) : nullptr;
+    uint2* h4 = s.bf16_offset >= 0 ? (uint2*)(wbf16 + s.bf16_offset + b0) : nullptr;
+    for (int i = threadIdx.x; i < n4; i += OPT_THREADS) {
+      float4 wv = w4[i], vv = v4[i], ev = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      const float4 gv = g4[i];
+      if (use_ema) ev = e4[i];
+      SGD_ELEM(wv.x, gv.x, vv.x, ev.x); SGD_ELEM(wv.y, gv.y, vv.y, ev.y);
+      SGD_ELEM(wv.z, gv.z, vv.z, ev.z); SGD_ELEM(wv.w, gv.w, vv.w, ev.w);
+      v4[i] = vv;
+      w4[i] = wv;
+      if (use_ema) e4[i] = ev;
+      if (h4) h4[i] = make_uint2((unsigned)rn_f32_to_bf16(wv.x) | ((unsigned)rn_f32_to_bf16(wv.y) << 16),
+                                 (unsigned)rn_f32_to_bf16(wv.z) | ((unsigned)rn_f32_to_bf16(wv.w) << 16));
     }
-    if (s.bf16_offset >= 0) wbf16[s.bf16_offset + i] = rn_f32_to_bf16(nw);
+    if ((int)threadIdx.x < (n & 3)) {
+      const long long i = b0 + 4 * n4 + threadIdx.x, o = s.offset + i;
+      float wv = w[o], vv = v[o], ev = use_ema ? ema[o] : 0.0f;
+      SGD_ELEM(wv, g[o], vv, ev);
+      v[o] = vv;
+      w[o] = wv;
+      if (use_ema) ema[o] = ev;
+      if (s.bf16_offset >= 0) wbf16[s.bf16_offset + i] = rn_f32_to_bf16(wv);
+    }
+  } else {
+    for (long long i = b0 + threadIdx.x; i < b1; i += OPT_THREADS) {
+      const long long o = s.offset + i;
+      float wv = w[o], vv = v[o], ev = use_ema ? ema[o] : 0.0f;
+      SGD_ELEM(wv, g[o], vv, ev);
+      v[o] = vv;
+      w[o] = wv;
+      if (use_ema) ema[o] = ev;
+      if (s.bf16_offset >= 0) wbf16[s.bf16_offset + i] = rn_f32_to_bf16(wv);
+    }
   }
+#undef SGD_ELEM
 }
 
 extern "C" size_t rn_optim_workspace_bytes(int num_blocks, int num_segments) {

@@ -34,23 +34,8 @@ __device__ __forceinline__ void round8(bf8& r) {
 // (n, y, x, channel group) of a flat element index.  These kernels are latency-bound at serving batch sizes, and six
 // 64-bit integer divisions by run-time values (~100 instructions each) were most of a thread's work: batch-1 serving spent
 // 25 us in balance_add_kernel.  32-bit divisions whenever the tensor has fewer than 2^31 elements (uniform branch).
-struct Idx4 { int n, y, x, c; };
-__device__ __forceinline__ Idx4 decode4(long long t, int C8, int Wl, int Hl, bool small) {
-  Idx4 r;
-  if (small) {
-    unsigned u = (unsigned)t;
-    r.c = (int)(u % (unsigned)C8); u /= (unsigned)C8;
-    r.x = (int)(u % (unsigned)Wl); u /= (unsigned)Wl;
-    r.y = (int)(u % (unsigned)Hl);
-    r.n = (int)(u / (unsigned)Hl);
-  } else {
-    r.c = (int)(t % C8); t /= C8;
-    r.x = (int)(t % Wl); t /= Wl;
-    r.y = (int)(t % Hl);
-    r.n = (int)(t / Hl);
-  }
-  return r;
-}
+typedef RnIdx4 Idx4;   // rn_common.h: rn_decode4 (mask / shift + float-reciprocal divisions below 2^22 pixels)
+__device__ __forceinline__ Idx4 decode4(long long t, int C8, int Wl, int Hl, int mode) { return rn_decode4(t, C8, Wl, Hl, mode); }
 
 static int pool_blocks(long long items) {
   long long b = rn_cdiv(items, POOL_THREADS);
@@ -66,7 +51,7 @@ maxpool_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int N, int H,
   const long long total = (long long)N * Ho * Wo * C8;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
-    const Idx4 d = decode4(i, C8, Wo, Ho, total < (1ll << 31));
+    const Idx4 d = decode4(i, C8, Wo, Ho, rn_decode_mode(total, C8));
     const int c = d.c, ox = d.x, oy = d.y, n = d.n;
     bf8 m;
 #pragma unroll
@@ -117,7 +102,7 @@ __global__ void __launch_bounds__(POOL_THREADS) fpn_topdown_kernel(Pyramid p) {
     int l = 0;
     while (i >= p.begin[l + 1]) ++l;
     const int Wl = p.W0 >> l, Hl = p.H0 >> l;
-    const Idx4 d = decode4(i - p.begin[l], p.C8, Wl, Hl, total < (1ll << 31));
+    const Idx4 d = decode4(i - p.begin[l], p.C8, Wl, Hl, rn_decode_mode(total, p.C8));
     const int c = d.c, x = d.x, y = d.y, n = d.n;
     const int top = p.L - 1;
     bf8 v = unpack8(p.in[top][(((long long)n * (p.H0 >> top)) + (y >> (top - l))) * (p.W0 >> top) * p.C8 +
@@ -178,7 +163,7 @@ __global__ void __launch_bounds__(POOL_THREADS) balance_avg_kernel(Balance b) {
   const long long total = (long long)p.N * Hm * Wm * p.C8;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
-    const Idx4 d = decode4(i, p.C8, Wm, Hm, total < (1ll << 31));
+    const Idx4 d = decode4(i, p.C8, Wm, Hm, rn_decode_mode(total, p.C8));
     const int c = d.c, x = d.x, y = d.y, n = d.n;
     bf8 acc;
 #pragma unroll
@@ -219,7 +204,7 @@ __global__ void __launch_bounds__(POOL_THREADS) balance_add_kernel(Balance b) {
     int l = 0;
     while (i >= p.begin[l + 1]) ++l;
     const int Wl = p.W0 >> l, Hl = p.H0 >> l;
-    const Idx4 d = decode4(i - p.begin[l], p.C8, Wl, Hl, total < (1ll << 31));
+    const Idx4 d = decode4(i - p.begin[l], p.C8, Wl, Hl, rn_decode_mode(total, p.C8));
     const int c = d.c, x = d.x, y = d.y, n = d.n;
     bf8 a;
     if (l <= b.mid) {

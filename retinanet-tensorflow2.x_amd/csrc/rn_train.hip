@@ -131,8 +131,14 @@ struct BnArgs {
   float eps, momentum, count_scale;
   float* ws;           // partials: [seg][chunk][2][C] laid out with ws_off
   long long ws_off[RN_CONV_MAX_SEGMENTS];
+  // the split form of the stage-2 reduction (bn_colreduce_final_split_kernel): parts per segment (1 = not split), byte
+  // offsets of the segment's ticket counters / part slots in the workspace tail, total workspace bytes of this mode
+  int ks[RN_CONV_MAX_SEGMENTS];
+  long long cnt_off[RN_CONV_MAX_SEGMENTS], slot_off[RN_CONV_MAX_SEGMENTS], total_bytes;
   BnSegDev seg[RN_CONV_MAX_SEGMENTS];
 };
+#define BN_KS_MAX 32        // parts of a split stage-2 reduction
+#define BN_KS_CHUNKS 512    // segments with more partial rows than this are split, ~256 rows per part
 
 // mode 0: (sum y, sum y^2); mode 1: (sum g, sum g*xhat), g = dz*mask(z), xhat = (y-mean)*invstd
 template <int G>   // G < 0: mode 0 (forward statistics); else the gradient gate of mode 1
@@ -231,18 +237,27 @@ __device__ __forceinline__ void bn_finalize_channel(const BnArgs& a, const BnSeg
   }
 }
 
-// 1024 threads = 16 channels x 64 chunk lanes (the 32 x 32 form spent most of its ~9 us per launch in 50-deep serial
-// load chains on 8 workgroups); every lane sums its chunks in double, the 64 lane sums are added in lane order
+// 1024 threads = CH channels x (1024 / CH) chunk lanes; every lane sums its chunks in double (chunk order), the lane sums
+// are added in two fixed levels (16 groups of consecutive lanes, then the 16 group sums in order): deterministic.
+//   CH = 16 (64 lanes): short reductions — a lane reads 64 contiguous bytes per chunk;
+//   CH = 4 (256 lanes, four times the workgroups): launches with more than 512 chunks on a segment.  The partials of a
+//     convolution epilogue are per 32-row block (6 400 on the 80 x 80 head level of the bench batch, 25 600 on a 160 x 160
+//     layer): with 64 lanes the 100- to 400-deep chains of dependent loads made 26 of the 115 launches of a step take
+//     8 - 33 us (the other 89: ~4 us, the floor of a dependent launch).
+// History: 32 channels x 8 lanes ~12 us per launch; 32 x 32 ~9 us.
+template <int CH>
 __global__ void __launch_bounds__(1024) bn_colreduce_final_kernel(const BnArgs a) {
+  constexpr int LANES = 1024 / CH, PER = LANES / 16;
   const BnSegDev& s = a.seg[blockIdx.y];
-  __shared__ double red[2][64][17];
-  const int cl = threadIdx.x & 15, lane = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
+  __shared__ double red[2][LANES][CH + 1];
+  __shared__ double red2[2][16][CH + 1];
+  const int cl = threadIdx.x & (CH - 1), lane = threadIdx.x / CH;
+  const int c = blockIdx.x * CH + cl;
   double t0 = 0.0, t1 = 0.0;
   if (c < s.C) {
     const float* p = a.ws + a.ws_off[blockIdx.y];
-#pragma unroll 4
-    for (int k = lane; k < s.chunks; k += 64) {
+#pragma unroll 8
+    for (int k = lane; k < s.chunks; k += LANES) {
       t0 += (double)p[((long long)k * 2 + 0) * s.C + c];
       t1 += (double)p[((long long)k * 2 + 1) * s.C + c];
     }
@@ -250,12 +265,22 @@ __global__ void __launch_bounds__(1024) bn_colreduce_final_kernel(const BnArgs a
   red[0][lane][cl] = t0;
   red[1][lane][cl] = t1;
   __syncthreads();
-  if (threadIdx.x < 32) {
-    const int which = threadIdx.x >> 4;
-    const int cc = blockIdx.x * 16 + cl;
+  if (threadIdx.x < 2 * 16 * CH) {   // (which, group of PER consecutive lanes, channel)
+    const int which = threadIdx.x / (16 * CH), rem = threadIdx.x - which * (16 * CH);
+    const int grp = rem / CH, ch = rem - grp * CH;
+    double t = 0.0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) t += red[which][grp * PER + j][ch];
+    red2[which][grp][ch] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * CH) {
+    const int which = threadIdx.x / CH, ch = threadIdx.x - which * CH;
+    const int cc = blockIdx.x * CH + ch;
     if (cc < s.C) {
       double t = 0.0;
-      for (int j = 0; j < 64; ++j) t += red[which][j][cl];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) t += red2[which][j][ch];
       float* out = a.mode == 0 ? s.sums : s.bsums;
       out[which * s.C + cc] = (float)t;
       // gamma / beta gradients are THIS replica's sums (tf.gradients of SyncBatchNormalization: only the
@@ -264,12 +289,111 @@ __global__ void __launch_bounds__(1024) bn_colreduce_final_kernel(const BnArgs a
         float* gp = which == 0 ? s.dbeta : s.dgamma;
         if (gp) gp[cc] = (float)t;
       }
-      red[which][0][cl] = (double)(float)t;   // for the fused finalize below (same value the unfused path reads)
+      red2[which][0][ch] = (double)(float)t;   // for the fused finalize below (same value the unfused path reads)
     }
   }
   if (a.fuse_finalize) {   // single-replica BatchNorm: bn_finalize_kernel's arithmetic without a second launch
     __syncthreads();
-    if (threadIdx.x < 16 && c < s.C) bn_finalize_channel(a, s, c, red[0][0][cl], red[1][0][cl]);
+    if (threadIdx.x < CH && c < s.C) bn_finalize_channel(a, s, c, red2[0][0][cl], red2[1][0][cl]);
+  }
+}
+
+// The split form for long reductions.  The partial sums of a convolution epilogue are per 128-row block: 1 600 rows of
+// partials on the 80 x 80 head level of the bench batch, 6 400 on a 160 x 160 layer (3 - 13 MB), read ONCE, cold (another
+// XCD wrote them) — and a workgroup pulls ~50 GB/s of cold lines, so the C / 16 workgroups of the form above took 11 - 41 us
+// on such launches whatever their thread layout (64 or 256 lanes per channel, 4-byte or 16-byte loads: measured,
+// tools/probes/bn_final_probe.py) where the reduction of a short segment takes 4.  Here a segment with more than
+// BN_KS_CHUNKS partial rows is cut into ks parts of ~256 rows (blockIdx.z): 1024 threads = 4 float4 columns (16 channels)
+// x 256 chunk lanes, a wave reads 16 rows x 64 contiguous bytes per load instruction; the 16 lanes of a wave that share a
+// column are added by a butterfly (xor 4 .. 32), the 16 wave sums in wave order.  Every part stores its 2 x 16 doubles
+// into its slot with write-through (sc1) stores, drains them and takes a ticket with one returning agent-scope atomic
+// (the split-K hand-off of the convolution kernels, rn_conv_halo.hip); the part that arrives LAST adds the slots in PART
+// order (the same bits whoever is last), zeroes the counter and finishes the channels.  Unsplit segments of the same
+// launch (ks = 1) finish directly.
+typedef unsigned bn_u32x2_t __attribute__((ext_vector_type(2)));
+__global__ void __launch_bounds__(1024) bn_colreduce_final_split_kernel(const BnArgs a) {
+  const BnSegDev& s = a.seg[blockIdx.y];
+  const int ks = a.ks[blockIdx.y], part = blockIdx.z;
+  if (part >= ks || (int)blockIdx.x * 16 >= s.C) return;
+  __shared__ double red[16][2][16];
+  __shared__ unsigned s_old;
+  const int col = threadIdx.x & 3, lane = threadIdx.x >> 2, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 16 + col * 4;
+  double t[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) t[q] = 0.0;
+  if (c < s.C) {
+    const float* p = a.ws + a.ws_off[blockIdx.y] + c;
+    const int per = (s.chunks + ks - 1) / ks;
+    const int k1 = (part + 1) * per < s.chunks ? (part + 1) * per : s.chunks;
+#pragma unroll 2
+    for (int k = part * per + lane; k < k1; k += 256) {
+      const float4 v0 = *(const float4*)(p + ((long long)k * 2 + 0) * s.C);
+      const float4 v1 = *(const float4*)(p + ((long long)k * 2 + 1) * s.C);
+      t[0] += (double)v0.x; t[1] += (double)v0.y; t[2] += (double)v0.z; t[3] += (double)v0.w;
+      t[4] += (double)v1.x; t[5] += (double)v1.y; t[6] += (double)v1.z; t[7] += (double)v1.w;
+    }
+  }
+#pragma unroll
+  for (int m = 4; m < 64; m <<= 1)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t[q] += __shfl_xor(t[q], m, 64);
+  if ((threadIdx.x & 63) < 4) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) red[wave][q >> 2][col * 4 + (q & 3)] = t[q];
+  }
+  __syncthreads();
+  const int which = (threadIdx.x >> 4) & 1, ch = threadIdx.x & 15;   // threads 0..31 finish the 2 x 16 sums
+  double r = 0.0;
+  if (threadIdx.x < 32) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) r += red[j][which][ch];
+  }
+  if (ks > 1) {
+    char* const slots = (char*)a.ws + a.slot_off[blockIdx.y] + (size_t)blockIdx.x * ks * 256;
+    if (threadIdx.x < 64) {   // wave 0: 32 stores, drained, one ticket
+      if (threadIdx.x < 32) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(slots + part * 256), 0, 256, 0x00020000);
+        const unsigned long long bits = __builtin_bit_cast(unsigned long long, r);
+        __builtin_amdgcn_raw_buffer_store_b64(bn_u32x2_t{(unsigned)bits, (unsigned)(bits >> 32)}, rs, threadIdx.x * 8, 0, 16);   // sc1
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (threadIdx.x == 0) {
+        unsigned* const cnt = (unsigned*)((char*)a.ws + a.cnt_off[blockIdx.y]) + blockIdx.x;
+        const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == (unsigned)(ks - 1)) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch
+        s_old = old;
+      }
+    }
+    __syncthreads();
+    if (s_old != (unsigned)(ks - 1)) return;
+    if (threadIdx.x < 32) {   // every part's loads in flight, then the adds in part order; slots past ks read as zeros
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)slots, 0, ks * 256, 0x00020000);
+      bn_u32x2_t pv[BN_KS_MAX];
+#pragma unroll
+      for (int j = 0; j < BN_KS_MAX; ++j) pv[j] = __builtin_amdgcn_raw_buffer_load_b64(rs, j * 256 + threadIdx.x * 8, 0, 16);   // sc1
+      r = 0.0;
+#pragma unroll
+      for (int j = 0; j < BN_KS_MAX; ++j)
+        r += __builtin_bit_cast(double, ((unsigned long long)pv[j].y << 32) | pv[j].x);
+    }
+  }
+  if (threadIdx.x < 32) {
+    const int cc = blockIdx.x * 16 + ch;
+    if (cc < s.C) {
+      float* out = a.mode == 0 ? s.sums : s.bsums;
+      out[which * s.C + cc] = (float)r;
+      if (a.mode == 1) {   // (see bn_colreduce_final_kernel)
+        float* gp = which == 0 ? s.dbeta : s.dgamma;
+        if (gp) gp[cc] = (float)r;
+      }
+    }
+    red[0][which][ch] = (double)(float)r;
+  }
+  if (a.fuse_finalize) {
+    __syncthreads();
+    const int cc = blockIdx.x * 16 + threadIdx.x;
+    if (threadIdx.x < 16 && cc < s.C) bn_finalize_channel(a, s, cc, red[0][0][threadIdx.x], red[0][1][threadIdx.x]);
   }
 }
 
@@ -446,6 +570,20 @@ __global__ void __launch_bounds__(TR_THREADS) bn_bwd_apply_kernel(const BnArgs a
   }
 }
 
+// row chunks of the stage-1 partial sums of a segment: ~2048 workgroups per segment over (row chunks x 64-channel
+// slabs) — narrow layers (EfficientNet: 24..144 channels = 1..3 slabs) get more row chunks, so the reduction still fills
+// the chip — or what the producing convolution wrote (rn_bn_segment.ext_chunks / ext_chunks_bwd)
+static int bn_chunks_of(const rn_bn_segment& s, int mode, int* rows_per_chunk) {
+  const long long want_chunks = 2048 / rn_cdiv(s.C, 64) < 256 ? 256 : 2048 / rn_cdiv(s.C, 64);
+  long long rpc = rn_cdiv(rn_cdiv(s.P, want_chunks), 32) * 32;  // multiple of 32 rows
+  if (rpc < 32) rpc = 32;
+  if (rows_per_chunk) *rows_per_chunk = (int)rpc;
+  int chunks = (int)rn_cdiv(s.P, rpc);
+  if (mode == 0 && s.ext_chunks > 0) chunks = s.ext_chunks;
+  if (mode == 1 && s.ext_chunks_bwd > 0) chunks = s.ext_chunks_bwd;
+  return chunks;
+}
+
 // mode 0 (forward statistics) honours rn_bn_segment.ext_chunks: stage-1 partials written by the conv epilogue
 static int bn_fill(const rn_bn_problem* p, BnArgs& a, int need_ws, int mode = 1) {
   if (!p || p->num_segments < 1 || p->num_segments > RN_CONV_MAX_SEGMENTS) return -1;
@@ -465,30 +603,41 @@ static int bn_fill(const rn_bn_problem* p, BnArgs& a, int need_ws, int mode = 1)
     d.mask = (unsigned char*)s.act_mask;
     d.colsum = s.dy_colsum_partial;
     if (s.sample_scale && p->act == RN_ACT_SWISH) return -1;   // swish' is recomputed without the factor
-    // ~2048 workgroups per segment over (row chunks x 64-channel slabs): narrow layers (EfficientNet: 24..144
-    // channels = 1..3 slabs) get more row chunks, so the reduction still fills the chip
-    const long long want_chunks = 2048 / rn_cdiv(s.C, 64) < 256 ? 256 : 2048 / rn_cdiv(s.C, 64);
-    long long rpc = rn_cdiv(rn_cdiv(s.P, want_chunks), 32) * 32;  // multiple of 32 rows
-    if (rpc < 32) rpc = 32;
-    d.rows_per_chunk = (int)rpc;
-    d.chunks = (int)rn_cdiv(s.P, rpc);
-    if (mode == 0 && s.ext_chunks > 0) d.chunks = s.ext_chunks;
-    if (mode == 1 && s.ext_chunks_bwd > 0) d.chunks = s.ext_chunks_bwd;
+    d.chunks = bn_chunks_of(s, mode, &d.rows_per_chunk);
     a.ws_off[i] = off;
     off += (long long)d.chunks * 2 * s.C;
   }
+  // Workspace tail, behind the partials of WHICHEVER mode needs more of them (the ticket counters must never be written
+  // by a partial sum): one counter per (segment, 16-channel block), then the part slots of the split segments.
+  long long other = 0;
+  for (int i = 0; i < p->num_segments; ++i) other += (long long)bn_chunks_of(p->seg[i], 1 - mode, nullptr) * 2 * p->seg[i].C;
+  long long tail = ((off > other ? off : other) * 4 + 255) / 256 * 256;
+  for (int i = 0; i < p->num_segments; ++i) {
+    a.cnt_off[i] = tail;
+    tail += rn_cdiv(p->seg[i].C, 16) * 4;
+  }
+  tail = (tail + 255) / 256 * 256;
+  for (int i = 0; i < p->num_segments; ++i) {
+    const int ch = a.seg[i].chunks;
+    int ks = ch > BN_KS_CHUNKS ? (int)rn_cdiv(ch, 256) : 1;
+    if (ks > BN_KS_MAX) ks = BN_KS_MAX;
+    a.ks[i] = ks;
+    a.slot_off[i] = tail;
+    if (ks > 1) tail += rn_cdiv(p->seg[i].C, 16) * ks * 256;   // 2 x 16 doubles per (block, part)
+  }
+  a.total_bytes = tail;
   (void)need_ws;
   return 0;
 }
 
+// [partial sums of the mode that needs more][ticket counters][part slots].  The ticket counters must be ZERO before the
+// first launch on a workspace (zero the workspace once after allocating it); every launch leaves them zero.
 extern "C" size_t rn_bn_workspace_bytes(const rn_bn_problem* p) {
   size_t need = 0;
   for (int mode = 0; mode < 2; ++mode) {     // forward (possibly external partials) and backward chunking
     BnArgs a;
     if (bn_fill(p, a, 1, mode)) return 0;
-    const BnSegDev& l = a.seg[a.nseg - 1];
-    const size_t b = (size_t)(a.ws_off[a.nseg - 1] + (long long)l.chunks * 2 * l.C) * sizeof(float);
-    if (b > need) need = b;
+    if ((size_t)a.total_bytes > need) need = (size_t)a.total_bytes;
   }
   return need;
 }
@@ -550,7 +699,13 @@ static int bn_colreduce(const rn_bn_problem* p, int mode, void* ws, size_t ws_by
     }
     RN_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(bn_colreduce_final_kernel, dim3((max_c + 15) / 16, a.nseg), dim3(1024), 0, st, a);
+  int max_ks = 1;
+  for (int i = 0; i < a.nseg; ++i) max_ks = a.ks[i] > max_ks ? a.ks[i] : max_ks;
+  static const int final_form = getenv("RNET_BN_FINAL") ? atoi(getenv("RNET_BN_FINAL")) : 0;   // A/B probe: 1 = never split
+  if (max_ks > 1 && final_form != 1 && (((uintptr_t)a.ws) & 15) == 0)
+    hipLaunchKernelGGL(bn_colreduce_final_split_kernel, dim3((max_c + 15) / 16, a.nseg, max_ks), dim3(1024), 0, st, a);
+  else
+    hipLaunchKernelGGL(bn_colreduce_final_kernel<16>, dim3((max_c + 15) / 16, a.nseg), dim3(1024), 0, st, a);
   RN_CHECK_LAUNCH();
   return RN_OK;
 }
@@ -733,12 +888,8 @@ upsample_zero_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int N, 
   const long long total = (long long)N * Ho * Wo * C8;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C8);
-    long long t = i / C8;
-    const int ox = (int)(t % Wo);
-    t /= Wo;
-    const int oy = (int)(t % Ho);
-    const int n = (int)(t / Ho);
+    const RnIdx4 d_ = rn_decode4(i, C8, Wo, Ho, rn_decode_mode(total, C8));
+    const int c = d_.c, ox = d_.x, oy = d_.y, n = d_.n;
     uint4 v = make_uint4(0u, 0u, 0u, 0u);
     if (!(ox & 1) && !(oy & 1) && (oy >> 1) < H && (ox >> 1) < W)
       v = x[(((long long)n * H + (oy >> 1)) * W + (ox >> 1)) * C8 + c];
@@ -762,12 +913,8 @@ scatter_add2x_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int N, 
   const long long total = (long long)N * H * W * C8;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C8);
-    long long t = i / C8;
-    const int w = (int)(t % W);
-    t /= W;
-    const int h = (int)(t % H);
-    const int n = (int)(t / H);
+    const RnIdx4 d_ = rn_decode4(i, C8, W, H, rn_decode_mode(total, C8));
+    const int c = d_.c, w = d_.x, h = d_.y, n = d_.n;
     if (2 * h >= Ho || 2 * w >= Wo) continue;
     const long long o = (((long long)n * Ho + 2 * h) * Wo + 2 * w) * C8 + c;
     const bf8 a = unpack8(x[i]), b = unpack8(y[o]);
@@ -795,14 +942,9 @@ depth_to_space2x_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int 
   const long long total = (long long)N * H * W * 4 * C8;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C8);
-    long long t = i / C8;
-    const int ph = (int)(t & 3);
-    t >>= 2;
-    const int w = (int)(t % W);
-    t /= W;
-    const int h = (int)(t % H);
-    const int n = (int)(t / H);
+    // [N][H][W][4 phases][C8] = an [N][H][4 W][C8] tensor whose column is 4 w + phase
+    const RnIdx4 d_ = rn_decode4(i, C8, 4 * W, H, rn_decode_mode(total, C8));
+    const int c = d_.c, ph = d_.x & 3, w = d_.x >> 2, h = d_.y, n = d_.n;
     const long long o = (((long long)n * 2 * H + 2 * h + (ph >> 1)) * 2 * W + 2 * w + (ph & 1)) * C8 + c;
     uint4 v = x[i];
     if (accumulate) {
@@ -840,12 +982,8 @@ maxpool_bwd_kernel(const uint4* __restrict__ x, const uint4* __restrict__ dy, ui
   const long long total = (long long)N * H * W * C8;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C8);
-    long long t = i / C8;
-    const int ix = (int)(t % W);
-    t /= W;
-    const int iy = (int)(t % H);
-    const int n = (int)(t / H);
+    const RnIdx4 d_ = rn_decode4(i, C8, W, H, rn_decode_mode(total, C8));
+    const int c = d_.c, ix = d_.x, iy = d_.y, n = d_.n;
     const bf8 me = unpack8(x[i]);
     bf8 g;
     if (accumulate) g = unpack8(dx[i]);
@@ -905,12 +1043,8 @@ topdown_bwd_kernel(const uint4* __restrict__ dout, const uint4* __restrict__ din
   const long long total = (long long)N * H * W * C8;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C8);
-    long long t = i / C8;
-    const int x = (int)(t % W);
-    t /= W;
-    const int y = (int)(t % H);
-    const int n = (int)(t / H);
+    const RnIdx4 d_ = rn_decode4(i, C8, W, H, rn_decode_mode(total, C8));
+    const int c = d_.c, x = d_.x, y = d_.y, n = d_.n;
     bf8 g = unpack8(dout[i]);
     if (din_finer) {
       for (int dy = 0; dy < 2; ++dy)
@@ -942,23 +1076,8 @@ extern "C" int rn_fpn_topdown_bwd_level(const void* dout, const void* din_finer,
 #define RN_PYR_MAX 8
 // (n, y, x, channel group) of a flat element index with 32-bit divisions when the tensor has fewer than 2^31 elements:
 // six 64-bit divisions by run-time values per thread made balance_bwd_in_kernel VALU-bound (8.7 M threads at B = 32)
-struct TrIdx4 { int n, y, x, c; };
-__device__ __forceinline__ TrIdx4 tr_decode4(long long t, int C8, int Wl, int Hl, bool small) {
-  TrIdx4 r;
-  if (small) {
-    unsigned u = (unsigned)t;
-    r.c = (int)(u % (unsigned)C8); u /= (unsigned)C8;
-    r.x = (int)(u % (unsigned)Wl); u /= (unsigned)Wl;
-    r.y = (int)(u % (unsigned)Hl);
-    r.n = (int)(u / (unsigned)Hl);
-  } else {
-    r.c = (int)(t % C8); t /= C8;
-    r.x = (int)(t % Wl); t /= Wl;
-    r.y = (int)(t % Hl);
-    r.n = (int)(t / Hl);
-  }
-  return r;
-}
+typedef RnIdx4 TrIdx4;   // rn_common.h: rn_decode4
+__device__ __forceinline__ TrIdx4 tr_decode4(long long t, int C8, int Wl, int Hl, int mode) { return rn_decode4(t, C8, Wl, Hl, mode); }
 
 struct BalBwd {
   int L, mid, N, H0, W0, C8;
@@ -1036,7 +1155,7 @@ __global__ void __launch_bounds__(TR_THREADS) balance_bwd_avg_kernel(BalBwd b) {
   const long long total = (long long)b.N * Hm * Wm * b.C8;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
-    const TrIdx4 d_ = tr_decode4(i, b.C8, Wm, Hm, total < (1ll << 31));
+    const TrIdx4 d_ = tr_decode4(i, b.C8, Wm, Hm, rn_decode_mode(total, b.C8));
     const int c = d_.c, x = d_.x, y = d_.y, n = d_.n;
     bf8 acc;
 #pragma unroll
@@ -1083,7 +1202,7 @@ __global__ void __launch_bounds__(TR_THREADS) balance_bwd_in_kernel(BalBwd b) {
     int l = 0;
     while (i >= b.begin[l + 1]) ++l;
     const int Wl = b.W0 >> l, Hl = b.H0 >> l;
-    const TrIdx4 d_ = tr_decode4(i - b.begin[l], b.C8, Wl, Hl, total < (1ll << 31));
+    const TrIdx4 d_ = tr_decode4(i - b.begin[l], b.C8, Wl, Hl, rn_decode_mode(total, b.C8));
     const int c = d_.c, x = d_.x, y = d_.y, n = d_.n;
     const long long o = (((long long)n * Hl) + y) * Wl * b.C8 + (long long)x * b.C8 + c;
     bf8 g = unpack8(b.dout[l][o]);

@@ -853,7 +853,8 @@ class TrainEngine:
         if fused:
             for i in range(len(ops)):   # one row of partial sums per 128 output pixels of the kernel the dispatcher will run
                 p.seg[i].ext_chunks = self.lib.rn_conv_bn_row_blocks(ctypes.byref(conv_problem), i)
-        ws = torch.empty((max(self.lib.rn_bn_workspace_bytes(ctypes.byref(p)), 256),), dtype=torch.uint8,
+        # (zeros: the ticket counters in the workspace tail start at zero, rnet_hip.h: rn_bn_workspace_bytes)
+        ws = torch.zeros((max(self.lib.rn_bn_workspace_bytes(ctypes.byref(p)), 256),), dtype=torch.uint8,
                          device=self.dev)
         if fused:
             for i in range(len(ops)):
@@ -1620,7 +1621,7 @@ class TrainEngine:
                 pend["done"] = True
                 for j, (pc_, i_, _, _) in pend["seg"].items():
                     pb.seg[j].ext_chunks_bwd = lib.rn_conv_bn_row_blocks(ctypes.byref(pc_), i_)
-                wsb = torch.empty((max(lib.rn_bn_workspace_bytes(ctypes.byref(pb)), 256),), dtype=torch.uint8, device=self.dev)
+                wsb = torch.zeros((max(lib.rn_bn_workspace_bytes(ctypes.byref(pb)), 256),), dtype=torch.uint8, device=self.dev)
                 self.bn_bwd_ws[key] = wsb
                 for j, (cp, ci, name, _) in pend["seg"].items():
                     sg = cp.seg[ci]

@@ -163,7 +163,7 @@ def _check_bn_problem(cuda, lib, h16, p, name):
         d.dgamma, d.dbeta = t["dgamma"].data_ptr(), t["dbeta"].data_ptr()
         d.P, d.C, d.dres_accumulate = P, C, s.dres_accumulate
         T.append(t)
-    ws = torch.empty((max(lib.rn_bn_workspace_bytes(ctypes.byref(q)), 256),), dtype=torch.uint8, device=cuda)
+    ws = torch.zeros((max(lib.rn_bn_workspace_bytes(ctypes.byref(q)), 256),), dtype=torch.uint8, device=cuda)
     st = _C.current_stream()
     _C.check(lib.rn_bn_stats_finalize(ctypes.byref(q), _C.ptr(ws), ws.numel(), st), name)
     _C.check(lib.rn_bn_apply(ctypes.byref(q), st), name)

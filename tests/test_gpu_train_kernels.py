@@ -37,7 +37,8 @@ def _bf(x):
 
 
 def _ws(nbytes, dev):
-    return torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=dev)
+    # zeros: the workspaces of the BatchNorm passes and the split-K convolutions hold ticket counters that start at zero
+    return torch.zeros((max(int(nbytes), 256),), dtype=torch.uint8, device=dev)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -785,8 +786,8 @@ def test_optimizer_step(cuda, build):
     from retinanet import _C
     lib = _lib()
     g = torch.Generator().manual_seed(5)
-    sizes = [64, 36864, 256, 70000, 8]
-    wd = [0, 1, 0, 1, 0]
+    sizes = [64, 36864, 256, 70001, 8, 13]   # 70001: a scalar tail behind the 16-byte body; then unaligned tensors
+    wd = [0, 1, 0, 1, 0, 1]
     chunk = lib.rn_optim_chunk()
     offs, segs, block_seg, o, b = [], [], [], 0, 0
     for i, n in enumerate(sizes):
@@ -798,7 +799,7 @@ def test_optimizer_step(cuda, build):
         b += nb
     total = o
     w = torch.randn((total,), generator=g)
-    gr = torch.randn((total,), generator=g) * torch.cat([torch.full((n,), s) for n, s in zip(sizes, [0.1, 0.2, 30.0, 0.05, 1.0])])
+    gr = torch.randn((total,), generator=g) * torch.cat([torch.full((n,), s) for n, s in zip(sizes, [0.1, 0.2, 30.0, 0.05, 1.0, 0.5])])
     v = torch.randn((total,), generator=g) * 0.01
     ema = w.clone() + 0.01
     seg_np = np.zeros((len(sizes),), dtype=np.dtype([("offset", "<i8"), ("size", "<i8"), ("wd", "<i4"), ("bb", "<i4"),
