@@ -65,12 +65,12 @@ typedef __bf16 rn_h16;
 #define RN_SIX_X2 0x40c040c0u   /* 6.0 twice */
 // ---- bf16 <-> f32 (round to nearest even), device side ------------------------------------
 __device__ __forceinline__ float rn_bf16_to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ uint16_t rn_f32_to_bf16(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);  // quiet NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
-}
+// v_cvt_pk_bf16_f32 (gfx950): round to nearest even, the values of the integer sequence
+//   u += 0x7fff + ((u >> 16) & 1); u >>= 16
+// for every finite input and the infinities; a NaN stays a quiet NaN.  The integer form cost ~7 VALU instructions per
+// element and was most of the arithmetic of every elementwise bf16 kernel (the 16-byte pack of fpn_topdown_kernel's
+// four chained levels: 139 us, VALU-bound).
+__device__ __forceinline__ uint16_t rn_f32_to_bf16(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
 __device__ __forceinline__ float rn_lo16(uint32_t u) { return __uint_as_float(u << 16); }          // low / high element
 __device__ __forceinline__ float rn_hi16(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }  // of a packed pair
 #endif
@@ -78,9 +78,17 @@ __device__ __forceinline__ float rn_hi16(uint32_t u) { return __uint_as_float(u 
 // conversion (v_cvt_pk_bf16_f32, round to nearest even — the same values as rn_f32_to_bf16 for every finite input)
 // instead of the ~6-instruction integer sequence: the 128-row conv epilogue applies it to every accumulator.
 __device__ __forceinline__ float rn_rb(float v) { return (float)(rn_h16)v; }
+#ifdef RN_F16
 __device__ __forceinline__ uint32_t rn_pack_bf16x2(float lo, float hi) {
   return (uint32_t)rn_f32_to_bf16(lo) | ((uint32_t)rn_f32_to_bf16(hi) << 16);
 }
+#else
+typedef __bf16 rn_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float rn_f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t rn_pack_bf16x2(float lo, float hi) {   // one v_cvt_pk_bf16_f32
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(rn_f32x2_t{lo, hi}, rn_bf16x2_t));
+}
+#endif
 
 // Activation of N values with a wave-uniform selector.  One branch per CALL (not per element: a `switch` inside an
 // unrolled element loop compiles to a chain of scalar compares and taken branches per element — measured 25 000

@@ -95,19 +95,23 @@ struct Pyramid {
   long long begin[RN_PYR_MAX + 1];
 };
 
-__global__ void __launch_bounds__(POOL_THREADS) fpn_topdown_kernel(Pyramid p) {
-  const long long total = p.begin[p.L - 1];  // the coarsest level is not rewritten
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+// One launch writes the levels [lo, hi): its chains start from level hi — the coarsest input (hi = L - 1) or an output an
+// earlier launch finished.  A thread of the finest level re-evaluates L - 1 stages (unpack, add, activation, rounding:
+// ~60 VALU instructions each): at training batch sizes the single launch is VALU-bound (109 us for 275 MB at B = 32), so
+// the host cuts the pyramid into launches of ONE stage per element there (rn_fpn_topdown).
+__global__ void __launch_bounds__(POOL_THREADS) fpn_topdown_kernel(Pyramid p, int lo, int hi) {
+  const long long first = p.begin[lo], total = p.begin[hi];
+  const uint4* __restrict__ src_hi = hi == p.L - 1 ? p.in[hi] : p.out[hi];
+  for (long long i = first + blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
-    int l = 0;
+    int l = lo;
     while (i >= p.begin[l + 1]) ++l;
     const int Wl = p.W0 >> l, Hl = p.H0 >> l;
     const Idx4 d = decode4(i - p.begin[l], p.C8, Wl, Hl, rn_decode_mode(total, p.C8));
     const int c = d.c, x = d.x, y = d.y, n = d.n;
-    const int top = p.L - 1;
-    bf8 v = unpack8(p.in[top][(((long long)n * (p.H0 >> top)) + (y >> (top - l))) * (p.W0 >> top) * p.C8 +
-                               (long long)(x >> (top - l)) * p.C8 + c]);
-    for (int k = top - 1; k >= l; --k) {
+    bf8 v = unpack8(src_hi[(((long long)n * (p.H0 >> hi)) + (y >> (hi - l))) * (p.W0 >> hi) * p.C8 +
+                           (long long)(x >> (hi - l)) * p.C8 + c]);
+    for (int k = hi - 1; k >= l; --k) {
       const int Hk = p.H0 >> k, Wk = p.W0 >> k;
       const bf8 u = unpack8(p.in[k][(((long long)n * Hk) + (y >> (k - l))) * Wk * p.C8 +
                                    (long long)(x >> (k - l)) * p.C8 + c]);
@@ -141,9 +145,22 @@ extern "C" int rn_fpn_topdown(void* const* p_in, void* const* p_out, int num_lev
   RN_CHECK_ARG(fill_pyramid(p, p_in, p_out, num_levels, N, H0, W0, C) == 0,
                "rn_fpn_topdown: bad pyramid (levels must halve exactly, C %% 8 == 0)");
   p.act = act;
-  hipLaunchKernelGGL(fpn_topdown_kernel, dim3(pool_blocks(p.begin[num_levels - 1])), dim3(POOL_THREADS), 0,
-                     (hipStream_t)stream, p);
-  RN_CHECK_LAUNCH();
+  // small pyramids (serving): one launch, every thread walks its chain from the coarsest level.  Large ones: the two
+  // finest levels (80 of every 85 elements of a five-level pyramid) as launches of ONE stage per element, behind a first
+  // launch for the coarse rest
+  int cuts[4] = {num_levels - 1, 0, 0, 0}, ncuts = 1;
+  if (num_levels >= 3 && p.begin[1] >= (1ll << 21)) {
+    ncuts = 0;
+    if (num_levels > 3) cuts[ncuts++] = num_levels - 1;   // levels [2, L - 1) from the coarsest input
+    cuts[ncuts++] = 2;
+    cuts[ncuts++] = 1;
+  }
+  for (int q = 0; q < ncuts; ++q) {
+    const int hi = cuts[q], lo = q + 1 < ncuts ? cuts[q + 1] : 0;
+    hipLaunchKernelGGL(fpn_topdown_kernel, dim3(pool_blocks(p.begin[hi] - p.begin[lo])), dim3(POOL_THREADS), 0,
+                       (hipStream_t)stream, p, lo, hi);
+    RN_CHECK_LAUNCH();
+  }
   return RN_OK;
 }
 

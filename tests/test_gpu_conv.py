@@ -930,24 +930,26 @@ def _pyramid(g, N, H0, C, L=5):
     return [_bf(torch.randn((N, H0 >> l, H0 >> l, C), generator=g)) for l in range(L)]
 
 
-@pytest.mark.parametrize("act", ["relu", "relu6"])
-def test_fpn_topdown(cuda, act):
+@pytest.mark.parametrize("act,N,H0,C,L", [("relu", 2, 32, 64, 5), ("relu6", 2, 32, 64, 5),
+                                          ("relu", 16, 80, 256, 5),    # >= 2^21 16-byte items on the finest level: the
+                                          ("relu6", 24, 64, 256, 3)])  # pyramid is cut into one-stage launches
+def test_fpn_topdown(cuda, act, N, H0, C, L):
     from retinanet import _C
     lib = _lib()
     g = torch.Generator().manual_seed(3)
-    pyr = _pyramid(g, 2, 32, 64)
+    pyr = _pyramid(g, N, H0, C, L)
     ins = [p.to(cuda) for p in pyr]
     outs = [torch.empty_like(t) for t in ins[:-1]] + [ins[-1]]
-    _C.check(lib.rn_fpn_topdown(_C.ptr_array(ins), _C.ptr_array(outs), 5, 2, 32, 32, 64, _C.ACT_IDS[act], _C.current_stream()))
+    _C.check(lib.rn_fpn_topdown(_C.ptr_array(ins), _C.ptr_array(outs), L, N, H0, H0, C, _C.ACT_IDS[act], _C.current_stream()))
     torch.cuda.synchronize()
     ref = [p.float() for p in pyr]
-    for l in range(4, 0, -1):   # fpn.py:93-98
+    for l in range(L - 1, 0, -1):   # fpn.py:93-98
         up = F.interpolate(ref[l].permute(0, 3, 1, 2), scale_factor=2, mode="nearest").permute(0, 2, 3, 1)
         v = ref[l - 1] + up
         v = F.relu(v) if act == "relu" else F.relu6(v)
         ref[l - 1] = _bf(v).float()
-    for l in range(5):
-        torch.testing.assert_close(outs[l].float().cpu(), ref[l], rtol=0, atol=0)
+    for l in range(L):
+        assert torch.equal(outs[l].float().cpu(), ref[l]), l
 
 
 def test_balance_features(cuda):
