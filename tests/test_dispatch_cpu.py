@@ -93,3 +93,44 @@ def test_forced_tile_shapes_keep_whole_tiles():
     assert _q(p)[:3] == (1, 256, 400)
     p.opts = _C.LaunchOpts(max_workgroups=64)
     assert _q(p)[2] == 400
+
+
+def _bn_problem(segs):
+    p = _C.BnProblem()
+    p.num_segments, p.act, p.bessel, p.eps, p.momentum, p.count_scale = len(segs), 0, 0, 1e-3, 0.9, 1.0
+    for i, (P, C, ext, ext_bwd) in enumerate(segs):
+        q = p.seg[i]
+        q.P, q.C, q.ext_chunks, q.ext_chunks_bwd = P, C, ext, ext_bwd
+    return p
+
+
+def test_bn_workspace_layout():
+    """rn_bn_workspace_bytes = [partial sums of the mode that needs more][one ticket counter per (segment, 16 channels)]
+    [part slots of the split segments] (rnet_hip.h).  The partial offsets of both modes stay inside the partial region —
+    the counters must never be written by a partial sum — and only segments with more than 512 rows of partials get slots."""
+    lib = _C.lib()
+    def parts(segs, mode):
+        return [(ext if mode == 0 else ext_bwd) or None for (_, _, ext, ext_bwd) in segs]
+    # a 160 x 160 stage-1 layer at batch 32: 6 400 rows of epilogue partials forward, the library's own chunking backward
+    segs = [(819200, 256, 6400, 0)]
+    p = _bn_problem(segs)
+    need = lib.rn_bn_workspace_bytes(ctypes.byref(p))
+    partial = 6400 * 2 * 256 * 4
+    counters = 256 // 16 * 4
+    slots = 256 // 16 * 25 * 256                       # 25 parts of 256 rows, 2 x 16 doubles each
+    assert need == partial + 256 + slots, (need, partial, counters, slots)   # counters padded to 256 bytes
+    # the five head levels: only the two finest are split (1 600 and 400 rows > 512? no: 400 is not)
+    head = [(32 * h * h, 256, 2 * -(-(32 * h * h) // 256), 0) for h in (80, 40, 20, 10, 5)]
+    p = _bn_problem(head)
+    need = lib.rn_bn_workspace_bytes(ctypes.byref(p))
+    partial = sum(c * 2 * 256 * 4 for (_, _, c, _) in head)
+    assert [c for (_, _, c, _) in head] == [1600, 400, 100, 26, 8]
+    slots = 256 // 16 * 7 * 256                        # level 0: ceil(1600 / 256) = 7 parts
+    assert need == (partial + 255) // 256 * 256 + 5 * 64 // 256 * 256 + 256 * (5 * 64 % 256 > 0) + slots
+    for i in range(5):
+        assert lib.rn_bn_partial_offset_bytes(ctypes.byref(p), i) < partial
+        assert lib.rn_bn_bwd_partial_offset_bytes(ctypes.byref(p), i) < partial
+    # a small layer: no slots, just the counters behind the partials of the mode that needs more of them (backward: the
+    # library's own chunking, 200 chunks of 64 rows, against the 100 rows of epilogue partials forward)
+    p = _bn_problem([(12800, 2048, 100, 0)])
+    assert lib.rn_bn_workspace_bytes(ctypes.byref(p)) == 200 * 2 * 2048 * 4 + 2048 // 16 * 4
