@@ -551,6 +551,50 @@ def test_bn_backward_apply_column_sums_of_dy(cuda, build, use_res):
     assert lib.rn_bn_bwd_apply(ctypes.byref(p), _C.current_stream()) == _C.RN_EINVAL
 
 
+def test_bn_stage2_reduction_in_parts(cuda):
+    """rn_bn_stats on external partial sums (rn_bn_segment.ext_chunks): a segment with more than 512 rows of partials has its
+    stage-2 reduction cut into parts — write-through slots, a ticket per (segment, 16 channels), the last arriver adds the
+    parts in part order.  Against float64 sums of the same partials; bit-equal over repeated launches (the counters return
+    to zero) and against the unsplit form of the same rows; segments of one launch mix split and unsplit reductions."""
+    from retinanet import _C
+    lib = _lib()
+    g = torch.Generator().manual_seed(11)
+    segs = [(256, 1600), (256, 400), (64, 6400), (136, 700), (2048, 26)]   # (C, rows of partial sums)
+    p = _C.BnProblem()
+    p.num_segments, p.act, p.bessel, p.eps, p.momentum, p.count_scale = len(segs), 0, 0, 1e-3, 0.9, 1.0
+    sums = []
+    for i, (C, ch) in enumerate(segs):
+        sums.append(torch.zeros((2, C), dtype=torch.float32, device=cuda))
+        q = p.seg[i]
+        q.y, q.sums, q.P, q.C, q.ext_chunks = sums[-1].data_ptr(), sums[-1].data_ptr(), ch * 128, C, ch
+    nbytes = lib.rn_bn_workspace_bytes(ctypes.byref(p))
+    ws = torch.zeros((nbytes // 4,), dtype=torch.float32, device=cuda)
+    parts = []
+    for i, (C, ch) in enumerate(segs):
+        off = lib.rn_bn_partial_offset_bytes(ctypes.byref(p), i) // 4
+        t = torch.randn((ch, 2, C), generator=g) * torch.rand((1, 1, C), generator=g) * 50.0
+        ws[off:off + t.numel()] = t.reshape(-1).to(cuda)
+        parts.append(t)
+    st = _C.current_stream()
+    runs = []
+    for _ in range(3):
+        _C.check(lib.rn_bn_stats(ctypes.byref(p), _C.ptr(ws), nbytes, st))
+        torch.cuda.synchronize()
+        runs.append([s_.clone() for s_ in sums])
+    for r in runs[1:]:
+        for a, b in zip(runs[0], r):
+            assert torch.equal(a, b)
+    for (C, ch), t, got in zip(segs, parts, runs[0]):
+        want = t.double().sum(0)
+        scale = t.double().abs().sum(0)
+        assert ((got.cpu().double() - want).abs() <= 1e-7 * scale + 1e-30).all(), (C, ch)
+    # the tail of the workspace (counters) is zero again
+    tail0 = sum(2 * C * ch for C, ch in segs)
+    n_cnt = sum(-(-C // 16) for C, _ in segs)
+    tail = ws[(tail0 * 4 + 255) // 256 * 64:][:n_cnt].view(torch.int32)
+    assert int(tail.abs().sum().item()) == 0
+
+
 @pytest.mark.parametrize("build,k,tile", [("bf16", 1, 2), ("bf16", 3, 2), ("bf16", 1, 1), ("bf16", 3, 1), ("bf16", 3, 3),
                                           ("bf16", 3, 4), ("f16", 1, 2), ("f16", 3, 2), ("f16", 3, 1), ("f16", 3, 3), ("f16", 3, 4)])
 def test_bn_forward_stats_fused_into_conv_epilogue(cuda, build, k, tile):

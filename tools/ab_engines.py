@@ -18,7 +18,7 @@ from bench import synth_ground_truth  # noqa: E402
 
 
 def with_env(spec, fn):
-    kv = dict(x.split("=", 1) for x in spec.split(",") if x)
+    kv = dict(x.split("=", 1) for x in spec.split(";" if ";" in spec else ",") if x)   # ";" when a value holds commas
     old = {k: os.environ.get(k) for k in kv}
     os.environ.update(kv)
     try:
