@@ -548,7 +548,10 @@ static bool conv_use_big(const rn_conv_problem* p) {
   // A launch of fewer tiles than compute units (batch-8 inference, ResNet stage 3 / 4; stage 4 at any batch) used to go
   // to the 128-row kernel because whole 256-row tiles would leave most of the chip idle.  With a split-K workspace the
   // halo kernel cuts every tile into S parts (all tiles are "last round"): enough workgroups again, on the faster kernel.
-  if (p->splitk_ws && p->opts.conv_big_min_tiles == 0 && conv_halo_shape(p, 256)) {
+  // (Single-segment launches only: on the five-level pyramids of the heads / FPN outputs at batch 1 - 2 the 128-row kernel is
+  // faster than the halo kernel's split tiles — towers 43.9 vs 46.6 us, class prediction 47.0 vs 63.9, FPN outputs 32.9
+  // vs 41.8 at batch 1, tools/probes/ab_b1_heads.sh: a quarter of their tiles hold a few dozen pixels.)
+  if (p->splitk_ws && p->opts.conv_big_min_tiles == 0 && p->num_segments == 1 && conv_halo_shape(p, 256)) {
     long long bytes = 0;
     const int G0 = rn_persistent_grid(0x7fffffff, rn_num_cus(), p->opts);
     const int S = tiles256 < G0 ? splitk_parts((int)tiles256, conv_min_chunks(p), G0, &bytes) : 1;

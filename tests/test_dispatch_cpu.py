@@ -59,7 +59,8 @@ CASES = [
     ("B1 stage-4 3x3 512: 128-row kernel, split along K", dict(B=1, H=20, W=20, Cin=512, Cout=512, k=3, ws=True), (0, 128), False, True),
     ("B1 stage-4 first 1x1 2048->512: split", dict(B=1, H=20, W=20, Cin=2048, Cout=512, k=1, ws=True), (0, 128), False, True),
     ("B1 stage-1 1x1 64->64 (one K step: nothing to split)", dict(B=1, H=160, W=160, Cin=64, Cout=64, k=1, ws=True), (0, 128), False, False),
-    ("B1 head tower 3x3: halo kernel, tiles split", dict(B=1, H=0, W=0, Cin=0, Cout=0, k=3, ws=True, segs=[(h, w, 256, 256) for h, w in PYR] * 2), (2, 256), False, True),
+    ("B1 head tower 3x3: 128-row kernel (the pyramid launches stay off the halo kernel's split tiles)", dict(B=1, H=0, W=0, Cin=0, Cout=0, k=3, ws=True, segs=[(h, w, 256, 256) for h, w in PYR] * 2), (0, 128), False, False),
+    ("B1 FPN output 3x3: 128-row kernel", dict(B=1, H=0, W=0, Cin=0, Cout=0, k=3, ws=True, segs=[(h, w, 256, 256) for h, w in PYR]), (0, 128), False, False),
 ]
 
 
@@ -109,8 +110,6 @@ def test_bn_workspace_layout():
     [part slots of the split segments] (rnet_hip.h).  The partial offsets of both modes stay inside the partial region —
     the counters must never be written by a partial sum — and only segments with more than 512 rows of partials get slots."""
     lib = _C.lib()
-    def parts(segs, mode):
-        return [(ext if mode == 0 else ext_bwd) or None for (_, _, ext, ext_bwd) in segs]
     # a 160 x 160 stage-1 layer at batch 32: 6 400 rows of epilogue partials forward, the library's own chunking backward
     segs = [(819200, 256, 6400, 0)]
     p = _bn_problem(segs)
@@ -119,7 +118,7 @@ def test_bn_workspace_layout():
     counters = 256 // 16 * 4
     slots = 256 // 16 * 25 * 256                       # 25 parts of 256 rows, 2 x 16 doubles each
     assert need == partial + 256 + slots, (need, partial, counters, slots)   # counters padded to 256 bytes
-    # the five head levels: only the two finest are split (1 600 and 400 rows > 512? no: 400 is not)
+    # the five head levels: only the finest (1 600 rows of partials) is split
     head = [(32 * h * h, 256, 2 * -(-(32 * h * h) // 256), 0) for h in (80, 40, 20, 10, 5)]
     p = _bn_problem(head)
     need = lib.rn_bn_workspace_bytes(ctypes.byref(p))
