@@ -243,6 +243,51 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_fwd_kernel(const ConvArg
       cur ^= 1;
     }
   }
+  else if (STAGES >= 3) {
+    // STAGES LDS stages, counted waits: the DMA of step kt + STAGES - 1 is issued while step kt is multiplied, so a tile's
+    // bytes have STAGES - 1 steps to arrive instead of one (the two-stage loop waits for ALL outstanding pieces — i.e. for
+    // the round trip of the tile it issued at the top of the same step — before every barrier: ~1.2 us per K step whatever
+    // the step computes).  One s_barrier per step (no fence: __syncthreads() would put s_waitcnt vmcnt(0) in front of it):
+    // behind it every wave's pieces of step kt have landed and every wave has finished reading step kt - 1, whose stage
+    // the next issue overwrites.
+    constexpr int PIECES = A_INSTR + B_INSTR;   // DMA instructions per wave and K step
+    constexpr int AHEAD = STAGES - 1;
+#pragma unroll
+    for (int q = 0; q < AHEAD; ++q)
+      if (kbeg + q < ksteps) {
+        RN_ISSUE_TILE(q, tap, c0);
+        RN_ADVANCE();
+      }
+    int cur = 0;
+#pragma unroll 1
+    for (int kt = kbeg; kt < ksteps; ++kt) {
+      // everything but the pieces of the AHEAD - 1 newest steps has landed (at the tail, where fewer are in flight: all)
+      if (kt + AHEAD - 1 < ksteps) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((AHEAD - 1) * PIECES) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kt + AHEAD < ksteps) {
+        const int nxt = cur >= 1 ? cur - 1 : STAGES - 1;   // (cur + STAGES - 1) % STAGES
+        RN_ISSUE_TILE(nxt, tap, c0);
+        RN_ADVANCE();
+      }
+      const char* base = smem + cur * STAGE_BYTES;
+#pragma unroll
+      for (int kk = 0; kk < KSUB; ++kk) {
+        bf16x8_t fa[TM], fb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = *(const bf16x8_t*)(base + rd_a[i][kk]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[j] = *(const bf16x8_t*)(base + rd_b[j][kk]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = RN_MFMA_32x32x16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+      cur = cur == STAGES - 1 ? 0 : cur + 1;
+    }
+    __syncthreads();   // the epilogue reuses the stages
+  }
 #undef RN_ADVANCE
 #undef RN_ISSUE_TILE
 
@@ -476,8 +521,21 @@ template <int BM, int BN, int BK, bool F32, bool SPLIT = false>
 static int launch_conv(const ConvArgs& a, hipStream_t st) {
   constexpr int stage = (BM + BN) * BK * 2;
   constexpr int epi = BM * BN * 4;
-  constexpr int lds = (2 * stage > epi) ? 2 * stage : epi;
-  auto kern = conv_fwd_kernel<BM, BN, BK, F32, 0, 2, 2, 2, SPLIT>;
+  // as many stages (up to four) as leave two workgroups per CU: 128 x 64 x 64: three (72 KB); 128 x 128 x 32: four (64 KB);
+  // 128 x 64 x 32: four (48 KB); 128 x 128 x 64 keeps two (three would be 96 KB: one workgroup per CU)
+  constexpr int STAGES = (4 * stage <= 72 * 1024) ? 4 : ((3 * stage <= 72 * 1024) ? 3 : 2);
+  static const bool two_stages = getenv("RNET_CONV128_STAGES") && atoi(getenv("RNET_CONV128_STAGES")) == 2;   // A/B probe
+  if (STAGES == 3 && two_stages) {
+    constexpr int lds2 = (2 * stage > epi) ? 2 * stage : epi;
+    auto kern2 = conv_fwd_kernel<BM, BN, BK, F32, 0, 2, 2, 2, SPLIT>;
+    if (lds2 > 48 * 1024)
+      RN_CHECK_HIP(hipFuncSetAttribute((const void*)kern2, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
+    hipLaunchKernelGGL(kern2, dim3(SPLIT ? a.vtotal : a.total_tiles), dim3(256), lds2, st, a);
+    RN_CHECK_LAUNCH();
+    return RN_OK;
+  }
+  constexpr int lds = (STAGES * stage > epi) ? STAGES * stage : epi;
+  auto kern = conv_fwd_kernel<BM, BN, BK, F32, 0, 2, 2, STAGES, SPLIT>;
   if (lds > 48 * 1024)
     RN_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   hipLaunchKernelGGL(kern, dim3(SPLIT ? a.vtotal : a.total_tiles), dim3(256), lds, st, a);
@@ -638,11 +696,23 @@ static int conv_pick(const rn_conv_problem* p) {
   return conv_use_halo512(p) ? 3 : 0;
 }
 
+// K step of the 128-row kernel: 64, or 32 when the padded channel count is not a multiple of 64 — and for the shallow
+// layers (K = R S Cin <= 256: ResNet stage 1's 256 -> 64, the first 1x1 of stage 2), which are HBM-bound: four stages of half
+// the size stream better than two or three (tools/probes/ab_conv128_bk.sh: 256 -> 64 at 160 x 160, batch 32, 133.9 -> 119.3 us;
+// 256 -> 128 194.0 -> 183.0) while every deeper layer loses 10 - 15 % to the second barrier per 16 MFMAs.
+// RNET_CONV128_BK=32 / 64 (A/B probe) forces one of them where the channel count allows.
+static int conv128_bk(const rn_conv_problem* p) {
+  static const int forced = getenv("RNET_CONV128_BK") ? atoi(getenv("RNET_CONV128_BK")) : 0;
+  const int cin = rn_conv_cin_pad(p->seg[0].Cin);
+  if (cin % 64 != 0 || forced == 32) return 32;
+  if (forced == 64) return 64;
+  return (long long)p->R * p->S * cin <= 256 ? 32 : 64;
+}
 // Tile shape the 128-row kernel runs a problem with: BN = 64 for Cout <= 64 and for small launches (see
 // rn_conv2d_nhwc_fwd), BK = 64 unless the padded channel count is not a multiple of 64; returns the tile count.
 static int conv128_shape(const rn_conv_problem* p, int* BN_out, int* BK_out) {
   int BN = rn_conv_cout_pad(seg_cols(p->seg[0])) <= 64 ? 64 : 128;
-  const int BK = rn_conv_cin_pad(p->seg[0].Cin) % 64 == 0 ? 64 : 32;
+  const int BK = conv128_bk(p);
   if (BN == 128) {
     long long t128 = 0;
     for (int i = 0; i < p->num_segments; ++i)
@@ -799,7 +869,7 @@ extern "C" int rn_conv2d_nhwc_fwd(const rn_conv_problem* p, void* stream) {
   // K step: 64 unless the (padded) channel count is small; Cin need only be a multiple of 8 — the
   // tail of the last K step reads past the pixel's channels (or out of range -> zeros) and meets the
   // zero-padded weight columns, so it contributes nothing.
-  const int BK = rn_conv_cin_pad(p->seg[0].Cin) % 64 == 0 ? 64 : 32;
+  const int BK = conv128_bk(p);
   const int kid = conv_pick(p);
   const bool big = kid == 1 || kid == 2;
   const bool halo512 = kid == 3;   // 512 x 128 tiles of the halo kernel
