@@ -522,10 +522,11 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
   constexpr int stage = (BM + BN) * BK * 2;
   constexpr int epi = BM * BN * 4;
   // as many stages (up to four) as leave two workgroups per CU: 128 x 64 x 64: three (72 KB); 128 x 128 x 32: four (64 KB);
-  // 128 x 64 x 32: four (48 KB); 128 x 128 x 64 keeps two (three would be 96 KB: one workgroup per CU)
+  // 128 x 64 x 32: four (48 KB); 128 x 128 x 64 keeps two (three would be 96 KB, one workgroup per CU: measured 35 - 45 %
+  // slower wherever a launch has more tiles than compute units, equal below)
   constexpr int STAGES = (4 * stage <= 72 * 1024) ? 4 : ((3 * stage <= 72 * 1024) ? 3 : 2);
   static const bool two_stages = getenv("RNET_CONV128_STAGES") && atoi(getenv("RNET_CONV128_STAGES")) == 2;   // A/B probe
-  if (STAGES == 3 && two_stages) {
+  if (STAGES >= 3 && two_stages) {
     constexpr int lds2 = (2 * stage > epi) ? 2 * stage : epi;
     auto kern2 = conv_fwd_kernel<BM, BN, BK, F32, 0, 2, 2, 2, SPLIT>;
     if (lds2 > 48 * 1024)
