@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_fwd_kernel(const ConvArg
       cur ^= 1;
     }
   }
-  else if (STAGES >= 3) {
+  else if (STAGES >= 3 && STAGES <= 8) {
     // STAGES LDS stages, counted waits: the DMA of step kt + STAGES - 1 is issued while step kt is multiplied, so a tile's
     // bytes have STAGES - 1 steps to arrive instead of one (the two-stage loop waits for ALL outstanding pieces — i.e. for
     // the round trip of the tile it issued at the top of the same step — before every barrier: ~1.2 us per K step whatever
@@ -287,6 +287,69 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_fwd_kernel(const ConvArg
       cur = cur == STAGES - 1 ? 0 : cur + 1;
     }
     __syncthreads();   // the epilogue reuses the stages
+  }
+  else if (STAGES == 32) {
+    // 128 x 128 x 64 (32 KB per K step; three whole stages would leave one workgroup per CU): THREE stages of pixels, TWO of
+    // weights, 80 KB — two workgroups per CU.  The pixels come from HBM (or another XCD's L2) and get two steps to arrive; the
+    // weights are L2-resident and get one.  Issue order per step: weights of step kt + 1, THEN pixels of step kt + 2, so that
+    // "everything but the last A_INSTR pieces" (loads retire in order) = pixels and weights of step kt + 1.
+    constexpr int B0 = 3 * A_BYTES;   // the weight stages sit behind the three pixel stages
+    int tap_a = tap, c0_a = c0, tap_b = tap, c0_b = c0;   // the pixel stream runs one step ahead of the weight stream
+#define RN_ISSUE_A(buf, tap_, c0_)                                                            \
+  do {                                                                                        \
+    const int r__ = (tap_) / S, s__ = (tap_) - r__ * S;                                       \
+    const int cw__ = (c0_) < cwrap ? (c0_) : ((c0_) < 2 * cwrap ? (c0_) - cwrap : (c0_) - 2 * cwrap);   \
+    const unsigned tap_off__ = (unsigned)((((long long)r__ * W + s__) * PS + cw__) * 2);      \
+    _Pragma("unroll") for (int j = 0; j < A_INSTR; ++j) {                                     \
+      const unsigned v__ = ((a_mask[j] >> (tap_)) & 1u) ? a_off[j] + tap_off__ : RN_OOB;      \
+      dma16(rs_x, smem + (buf) * A_BYTES + (j * NWAVES + wave) * 1024, v__);                   \
+    }                                                                                         \
+  } while (0)
+#define RN_ISSUE_B(buf, tap_, c0_)                                                            \
+  do {                                                                                        \
+    const unsigned koff__ = (unsigned)(((long long)(tap_) * Cin + (c0_)) * 2);                \
+    _Pragma("unroll") for (int j = 0; j < B_INSTR; ++j)                                       \
+      dma16(rs_w, smem + B0 + (buf) * B_BYTES + (j * NWAVES + wave) * 1024, b_off[j] + koff__); \
+  } while (0)
+#define RN_ADV(tap_, c0_) do { c0_ += BK; if (c0_ >= Cin) { c0_ = 0; ++tap_; } } while (0)
+    // prologue: pixels of steps 0 and 1, weights of step 0 (weights first where both are issued)
+    RN_ISSUE_B(0, tap_b, c0_b); RN_ADV(tap_b, c0_b);
+    RN_ISSUE_A(0, tap_a, c0_a); RN_ADV(tap_a, c0_a);
+    if (kbeg + 1 < ksteps) { RN_ISSUE_A(1, tap_a, c0_a); RN_ADV(tap_a, c0_a); }
+    int cur_a = 0, cur_b = 0;
+#pragma unroll 1
+    for (int kt = kbeg; kt < ksteps; ++kt) {
+      // pixels and weights of step kt have landed: everything but the pixel pieces of step kt + 1 (the newest issue)
+      if (kt + 1 < ksteps) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(A_INSTR) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kt + 1 < ksteps) { RN_ISSUE_B(cur_b ^ 1, tap_b, c0_b); RN_ADV(tap_b, c0_b); }
+      if (kt + 2 < ksteps) {
+        const int nxt = cur_a >= 1 ? cur_a - 1 : 2;   // (cur_a + 2) % 3
+        RN_ISSUE_A(nxt, tap_a, c0_a); RN_ADV(tap_a, c0_a);
+      }
+      const char* base_a = smem + cur_a * A_BYTES;
+      const char* base_b = smem + B0 + cur_b * B_BYTES - A_BYTES;   // rd_b carries + A_BYTES
+#pragma unroll
+      for (int kk = 0; kk < KSUB; ++kk) {
+        bf16x8_t fa[TM], fb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = *(const bf16x8_t*)(base_a + rd_a[i][kk]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[j] = *(const bf16x8_t*)(base_b + rd_b[j][kk]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = RN_MFMA_32x32x16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+      cur_a = cur_a == 2 ? 0 : cur_a + 1;
+      cur_b ^= 1;
+    }
+    __syncthreads();   // the epilogue reuses the stages
+#undef RN_ADV
+#undef RN_ISSUE_B
+#undef RN_ISSUE_A
   }
 #undef RN_ADVANCE
 #undef RN_ISSUE_TILE
@@ -524,7 +587,8 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
   // as many stages (up to four) as leave two workgroups per CU: 128 x 64 x 64: three (72 KB); 128 x 128 x 32: four (64 KB);
   // 128 x 64 x 32: four (48 KB); 128 x 128 x 64 keeps two (three would be 96 KB, one workgroup per CU: measured 35 - 45 %
   // slower wherever a launch has more tiles than compute units, equal below)
-  constexpr int STAGES = (4 * stage <= 72 * 1024) ? 4 : ((3 * stage <= 72 * 1024) ? 3 : 2);
+  // (32 = three stages of pixels + two of weights, 80 KB, for the 32 KB steps of 128 x 128 x 64)
+  constexpr int STAGES = (4 * stage <= 72 * 1024) ? 4 : ((3 * stage <= 72 * 1024) ? 3 : ((BM == 128 && BN == 128 && BK == 64) ? 32 : 2));
   static const bool two_stages = getenv("RNET_CONV128_STAGES") && atoi(getenv("RNET_CONV128_STAGES")) == 2;   // A/B probe
   if (STAGES >= 3 && two_stages) {
     constexpr int lds2 = (2 * stage > epi) ? 2 * stage : epi;
@@ -535,7 +599,8 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
     RN_CHECK_LAUNCH();
     return RN_OK;
   }
-  constexpr int lds = (STAGES * stage > epi) ? STAGES * stage : epi;
+  constexpr int ring = STAGES == 32 ? 3 * BM * BK * 2 + 2 * BN * BK * 2 : STAGES * stage;
+  constexpr int lds = (ring > epi) ? ring : epi;
   auto kern = conv_fwd_kernel<BM, BN, BK, F32, 0, 2, 2, STAGES, SPLIT>;
   if (lds > 48 * 1024)
     RN_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
