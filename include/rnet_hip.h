@@ -192,8 +192,8 @@ typedef struct {
                                 * pixel count (tests at small sizes) | 3: as 2 but never wgrad_halo_kernel (A/B timing) */
   int32_t wgrad_target_blocks; /* > 0: workgroups a weight-gradient launch aims for (split-K plan; A/B timing) */
   int32_t ablate;              /* tools/bench_conv.py: ablated variants of conv_fwd_kernel<128,128,64> — timing only */
-  int32_t splitk_target_blocks; /* > 0: workgroups a split-K launch of the 128-row conv kernel aims for (default: one per
-                                * compute unit; rn_conv_problem.splitk_ws; A/B timing) */
+  int32_t splitk_target_blocks; /* > 0: workgroups a split-K launch of the 128-row conv kernel aims for (default: three per
+                                * four compute units; rn_conv_problem.splitk_ws; A/B timing) */
 } rn_launch_opts;
 
 /* Opaque per-device context: device id, compute-unit count, the default rn_launch_opts of the engine that owns it and

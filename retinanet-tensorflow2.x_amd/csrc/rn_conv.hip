@@ -792,7 +792,7 @@ static int conv128_shape(const rn_conv_problem* p, int* BN_out, int* BK_out) {
   return tiles > 0x7fffffff ? 0x7fffffff : (int)tiles;
 }
 // Parts every tile of a 128-row launch is cut into along K (1: whole tiles).  Enough parts to put about one workgroup on
-// every compute unit (opts.splitk_target_blocks moves the target), at least RN_SPLIT128_MIN_STEPS K steps per part (a
+// three of every four compute units (opts.splitk_target_blocks moves the target), at least RN_SPLIT128_MIN_STEPS K steps per part (a
 // part costs a 32 - 64 KB partial tile written and read back and a ~2 us hand-off), at most 8 parts (the last arriver
 // keeps one 16-byte load per part in flight), the slots must fit the workspace and the tiles its 4096 counters.
 #define RN_SPLIT128_MIN_STEPS 4
@@ -804,7 +804,10 @@ static int conv128_split_parts(const rn_conv_problem* p, int tiles, int BN, int 
     const int ks = p->R * p->S * (terms * rn_conv_cin_pad(p->seg[i].Cin) / BK);
     ksteps = ks < ksteps ? ks : ksteps;
   }
-  const int target = p->opts.splitk_target_blocks > 0 ? p->opts.splitk_target_blocks : rn_num_cus();
+  // default target: three quarters of the compute units.  Same-box sweep with the counted-wait K loop, three rounds
+  // (tools/bench_infer.py --split-target): batch-1 serving 1.357 / 1.360 / 1.353 ms at 256 workgroups, 1.322 / 1.310 / 1.318 at
+  // 192, 1.323 / 1.323 / 1.315 at 160; batch 8 within +-0.4 % of each other (fewer, longer parts: less exchange traffic).
+  const int target = p->opts.splitk_target_blocks > 0 ? p->opts.splitk_target_blocks : rn_num_cus() * 3 / 4;
   int S = target / tiles;
   if (S > ksteps / RN_SPLIT128_MIN_STEPS) S = ksteps / RN_SPLIT128_MIN_STEPS;
   if (S > 8) S = 8;

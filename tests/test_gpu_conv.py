@@ -329,7 +329,7 @@ SPLIT128_CASES = [
     # N, H, W, Cin, Cout, k, stride, act, residual, out_f32, bias, w_terms, splitk_target_blocks   (the 128-row kernel, every tile cut along K)
     (1, 20, 20, 512, 512, 3, 1, "relu", False, False, False, 1, 0),     # ResNet stage 4 3x3 at batch 1: 32 tiles of 128 x 64, 72 K steps, 8 parts
     (1, 20, 20, 2048, 512, 1, 1, "relu", False, False, False, 1, 0),    # stage 4 first 1x1: 32 K steps, 8 parts of 4
-    (1, 20, 20, 512, 2048, 1, 1, "relu", True, False, False, 1, 0),     # stage 4 last 1x1 + residual: 8 K steps, 2 parts
+    (1, 20, 20, 512, 2048, 1, 1, "relu", True, False, False, 1, 256),   # stage 4 last 1x1 + residual: 128 tiles, 8 K steps, 2 parts (at the default target of 192 workgroups it runs whole)
     (1, 40, 40, 256, 256, 3, 2, "relu6", False, False, False, 1, 0),    # stride 2; M tail (400 = 3 tiles + 16 pixels)
     (2, 13, 11, 192, 72, 3, 1, "swish", True, False, False, 1, 64),     # odd sizes, Cout tail, two images, swish + residual
     (1, 10, 10, 256, 36, 3, 1, None, False, True, True, 2, 0),          # f32 output, two weight planes, bias (box prediction, P6)
