@@ -669,18 +669,12 @@ static bool conv_use_big(const rn_conv_problem* p) {
     tiles256 += rn_cdiv((long long)s.N * s.Ho * s.Wo, 256) * rn_cdiv(seg_cols(s), 256);
   }
   if (p->opts.conv_tile == 2 || tiles256 >= (p->opts.conv_big_min_tiles > 0 ? p->opts.conv_big_min_tiles : 192)) return true;
-  // A launch of fewer tiles than compute units (batch-8 inference, ResNet stage 3 / 4; stage 4 at any batch) used to go
-  // to the 128-row kernel because whole 256-row tiles would leave most of the chip idle.  With a split-K workspace the
-  // halo kernel cuts every tile into S parts (all tiles are "last round"): enough workgroups again, on the faster kernel.
-  // (Single-segment launches only: on the five-level pyramids of the heads / FPN outputs at batch 1 - 2 the 128-row kernel is
-  // faster than the halo kernel's split tiles — towers 43.9 vs 46.6 us, class prediction 47.0 vs 63.9, FPN outputs 32.9
-  // vs 41.8 at batch 1, tools/probes/ab_b1_heads.sh: a quarter of their tiles hold a few dozen pixels.)
-  if (p->splitk_ws && p->opts.conv_big_min_tiles == 0 && p->num_segments == 1 && conv_halo_shape(p, 256)) {
-    long long bytes = 0;
-    const int G0 = rn_persistent_grid(0x7fffffff, rn_num_cus(), p->opts);
-    const int S = tiles256 < G0 ? splitk_parts((int)tiles256, conv_min_chunks(p), G0, &bytes) : 1;
-    return S >= 2 && tiles256 * S >= G0 / 4 && bytes <= p->splitk_ws_bytes;
-  }
+  // A launch of fewer tiles than compute units (batch-8 inference, ResNet stage 3 / 4) stays on the 128-row kernel.  Round 4
+  // sent it to the halo kernel's 256 x 256 tiles, every tile cut along K, when a split-K workspace was attached; with the
+  // counted-wait K loop of the 128-row kernel (and its own split-K) that choice loses: stage-3 3x3 at batch 8 43.7 vs 36.0 us,
+  // batch 16 53.2 vs 46.1; stage-4 3x3 45.3 vs 42.6 at batch 8, 59.4 vs 61.4 at batch 16 (tools/probes/ab_small_3x3.sh); the
+  // five-level head / FPN launches at batch 1: 46.6 vs 43.9, 63.9 vs 47.0, 41.8 vs 32.9 (tools/probes/ab_b1_heads.sh).
+  // rn_launch_opts.conv_tile = 2 still takes a small launch to the halo kernel, split when a workspace is attached.
   return false;
 }
 

@@ -54,7 +54,8 @@ CASES = [
     ("B32 stage-4 first 1x1 2048->512 (100 256-row tiles: 128-row kernel)", dict(B=32, H=20, W=20, Cin=2048, Cout=512, k=1), (0, 128), False, False),
     ("B32 class prediction 3x3, one plane (training)", dict(B=32, H=0, W=0, Cin=0, Cout=0, k=3, f32=True, segs=[(h, w, 256, 720) for h, w in PYR]), (3, 512), False, False),
     ("B32 box prediction 3x3, planes along Cout", dict(B=32, H=0, W=0, Cin=0, Cout=0, k=3, f32=True, w_pair=1, segs=[(h, w, 256, 36) for h, w in PYR]), (3, 512), False, False),
-    ("B8 stage-4 3x3 512 with a workspace: halo kernel, every tile split", dict(B=8, H=20, W=20, Cin=512, Cout=512, k=3, ws=True), (2, 256), False, True),
+    ("B8 stage-4 3x3 512 with a workspace: 128-row kernel (200 tiles of 128 x 64: nothing to split)", dict(B=8, H=20, W=20, Cin=512, Cout=512, k=3, ws=True), (0, 128), False, False),
+    ("B8 stage-3 3x3 256 with a workspace: 128-row kernel", dict(B=8, H=40, W=40, Cin=256, Cout=256, k=3, ws=True), (0, 128), False, False),
     ("B8 stage-4 3x3 512 without a workspace: 128-row kernel", dict(B=8, H=20, W=20, Cin=512, Cout=512, k=3), (0, 128), False, False),
     ("B1 stage-4 3x3 512: 128-row kernel, split along K", dict(B=1, H=20, W=20, Cin=512, Cout=512, k=3, ws=True), (0, 128), False, True),
     ("B1 stage-4 first 1x1 2048->512: split", dict(B=1, H=20, W=20, Cin=2048, Cout=512, k=1, ws=True), (0, 128), False, True),

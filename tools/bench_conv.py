@@ -67,10 +67,11 @@ def main():
     ap.add_argument("--no-halo", action="store_true", help="3x3 launches on conv_big_kernel instead of conv_halo_kernel")
     ap.add_argument("--tile", type=int, default=0, help="1 = force 128-row kernel, 2 = force the 256x256 kernel, 3 = force 512x128 halo tiles")
     ap.add_argument("--splitk", action="store_true", help="attach a split-K workspace (rn_conv_problem.splitk_ws)")
+    ap.add_argument("--min-tiles", type=int, default=0, help="rn_launch_opts.conv_big_min_tiles (a large value keeps a small launch on the 128-row kernel, split-K allowed)")
     a = ap.parse_args()
     lib = _C.lib()
     opts = _C.LaunchOpts(ablate=a.ablate or 0, conv_tile=a.tile or 0, conv_no_halo=1 if a.no_halo else 0,
-                         max_workgroups=a.halo_grid or 0)   # rn_launch_opts of every launch below
+                         max_workgroups=a.halo_grid or 0, conv_big_min_tiles=a.min_tiles or 0)   # rn_launch_opts of every launch below
     dev = torch.device("cuda:0")
     for name in a.preset.split(","):
         segs, k, stride, f32, use_res = PRESETS[name]
