@@ -44,7 +44,7 @@ __device__ __forceinline__ bf16x8_t wg_frag(const char* tile, int kb, int lane, 
 // LINEAR: see wgrad_big_kernel — stride 1, same-size, symmetric padding: constant source-offset advance per K step
 template <bool LINEAR>
 __global__ void __launch_bounds__(WG_THREADS, 2) wgrad_kernel(const WgArgs args) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (A 16K + B 16K)
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // dy: 2 stages x 16 KB, then x: 3 stages x 16 KB
   // XCD-aware block -> (chunk, tile) map: blocks are dispatched round-robin over the 8 XCDs, so give
   // each XCD a contiguous range of logical ids with the tile index fastest — every (co, ci, tap)
   // tile of one pixel chunk then runs on the same XCD and re-reads that chunk's x / dy rows from its
@@ -136,17 +136,37 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wgrad_kernel(const WgArgs args)
   }
   const unsigned l_dy_step = (unsigned)(WG_BK * sg.dyS * 2), l_x_step = (unsigned)(WG_BK * sg.xS * 2);
 
-#define WG_ISSUE(buf, p0_)                                                                        \
+// The two operands ride in separate LDS rings (see the K loop): dy in two stages at smem, x in three behind them.
+#define WG_ISSUE_DY(buf, p0_)                                                                     \
   do {                                                                                            \
-    char* st__ = smem + (buf) * (2 * WG_TILE_BYTES);                                              \
+    char* st__ = smem + (buf) * WG_TILE_BYTES;                                                    \
     if (LINEAR) {                                                                                 \
       const int left__ = p_end - (p0_);                                                           \
       _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                             \
         const bool in__ = (j * 4 + wave) * 4 + d_row < left__;                                    \
         wg_dma16(rs_dy, st__ + (j * 4 + wave) * 1024, in__ ? l_dy[j] : WG_OOB);                   \
-        const bool ok__ = in__ && r_oy[j] != y_bad && r_ox[j] != x_bad;                           \
-        wg_dma16(rs_x, st__ + WG_TILE_BYTES + (j * 4 + wave) * 1024, ok__ ? l_x[j] : WG_OOB);     \
         l_dy[j] += l_dy_step;                                                                     \
+      }                                                                                           \
+    } else                                                                                        \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
+      const int row__ = (j * 4 + wave) * 4 + d_row;                                               \
+      const int chunk__ = d_pos ^ ((row__ & 3) << 2);                                             \
+      const int p__ = (p0_) + row__;                                                              \
+      const bool in__ = p__ < p_end;                                                              \
+      const unsigned va__ = in__ ? (__umul24((unsigned)p__, (unsigned)sg.dyS) + co0 + chunk__ * 8) * 2u : WG_OOB; \
+      wg_dma16(rs_dy, st__ + (j * 4 + wave) * 1024, va__);                                        \
+    }                                                                                             \
+  } while (0)
+// (the (n, oy, ox) trackers belong to the x stream: they advance with every x issue)
+#define WG_ISSUE_X(buf, p0_)                                                                      \
+  do {                                                                                            \
+    char* st__ = smem + 2 * WG_TILE_BYTES + (buf) * WG_TILE_BYTES;                                \
+    if (LINEAR) {                                                                                 \
+      const int left__ = p_end - (p0_);                                                           \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                             \
+        const bool in__ = (j * 4 + wave) * 4 + d_row < left__;                                    \
+        const bool ok__ = in__ && r_oy[j] != y_bad && r_ox[j] != x_bad;                           \
+        wg_dma16(rs_x, st__ + (j * 4 + wave) * 1024, ok__ ? l_x[j] : WG_OOB);                     \
         l_x[j] += l_x_step;                                                                       \
         int ox__ = r_ox[j] + adv_r, oy__ = r_oy[j] + adv_qr;                                      \
         const int c1__ = ox__ >= Wo;                                                              \
@@ -160,14 +180,12 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wgrad_kernel(const WgArgs args)
       const int chunk__ = d_pos ^ ((row__ & 3) << 2);                                             \
       const int p__ = (p0_) + row__;                                                              \
       const bool in__ = p__ < p_end;                                                              \
-      const unsigned va__ = in__ ? (__umul24((unsigned)p__, (unsigned)sg.dyS) + co0 + chunk__ * 8) * 2u : WG_OOB; \
-      wg_dma16(rs_dy, st__ + (j * 4 + wave) * 1024, va__);                                        \
       const int iy__ = r_oy[j] * args.sh - args.pt + r, ix__ = r_ox[j] * args.sw - args.pl + s;   \
       const bool ok__ = in__ && (unsigned)iy__ < (unsigned)H && (unsigned)ix__ < (unsigned)W;     \
       /* 24-bit multiplies (full rate): every factor is < 2^24 (host check), the byte offset < 2^31 */ \
       const unsigned pix__ = __umul24(__umul24((unsigned)r_n[j], (unsigned)H) + (unsigned)iy__, (unsigned)W) + (unsigned)ix__; \
       const unsigned vb__ = ok__ ? (__umul24(pix__, (unsigned)sg.xS) + ci0 + chunk__ * 8) * 2u : WG_OOB; \
-      wg_dma16(rs_x, st__ + WG_TILE_BYTES + (j * 4 + wave) * 1024, vb__);                         \
+      wg_dma16(rs_x, st__ + (j * 4 + wave) * 1024, vb__);                                         \
       /* advance this row by one K step */                                                        \
       int ox__ = r_ox[j] + adv_r, oy__ = r_oy[j] + adv_qr, n__ = r_n[j] + adv_qn;                 \
       const int c1__ = ox__ >= Wo;                                                                \
@@ -192,14 +210,14 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wgrad_kernel(const WgArgs args)
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int col = (t < 2 ? wave_m : wave_n) * 64 + (t & 1) * 32 + 16 * (g & 1) + 4 * (i & 3);
-      fbase[t] = (unsigned)((t < 2 ? 0 : WG_TILE_BYTES) + row0 * 256 + (((col >> 3) ^ ((row0 & 3) << 2)) << 4) + (col & 7) * 2);
+      fbase[t] = (unsigned)(row0 * 256 + (((col >> 3) ^ ((row0 & 3) << 2)) << 4) + (col & 7) * 2);   // inside its operand's tile
     }
   }
   const unsigned lds0 = rn_lds_addr(smem);
 #define WG_READS(q_, st_, kk_)                                                                     \
   do {                                                                                             \
     _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                \
-      const unsigned a__ = (st_) + fbase[t];                                                       \
+      const unsigned a__ = (t < 2 ? st_##_dy : st_##_x) + fbase[t];                                \
       RN_TR_ISSUE(q_[2 * t], a__, (kk_) * 4096);                                                   \
       RN_TR_ISSUE(q_[2 * t + 1], a__, (kk_) * 4096 + 1024);                                        \
     }                                                                                              \
@@ -219,14 +237,24 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wgrad_kernel(const WgArgs args)
     acc[1][1] = RN_MFMA_32x32x16(fa1__, fb1__, acc[1][1], 0, 0, 0);                                \
   } while (0)
 
-  WG_ISSUE(0, p_begin);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  int cur = 0;
+  // K loop.  Two LDS rings with counted waits: dy in TWO stages, x in THREE (80 KB: two workgroups per CU).  Per step: dy of
+  // step kt + 1, THEN x of step kt + 2 are issued, so that "everything but the last four pieces" (loads retire in order) is
+  // exactly what step kt needs; one barrier per step.  (Until round 5: two whole stages and `s_waitcnt vmcnt(0)` before every
+  // barrier — each step waited for the round trip of the tile issued at its own top, as the 128-row forward kernel did.)
+  WG_ISSUE_DY(0, p_begin);
+  WG_ISSUE_X(0, p_begin);
+  if (1 < ksteps) WG_ISSUE_X(1, p_begin + WG_BK);
+  int cur_x = 0;
 #pragma unroll 1
   for (int kt = 0; kt < ksteps; ++kt) {
-    if (kt + 1 < ksteps) WG_ISSUE(cur ^ 1, p_begin + (kt + 1) * WG_BK);   // lands under this step's reads and MFMAs
-    const unsigned st = lds0 + (unsigned)(cur * (2 * WG_TILE_BYTES));
+    if (kt + 1 < ksteps) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but the x pieces of step kt + 1
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // everyone's pieces of step kt have landed; everyone is done reading step kt - 1
+    asm volatile("" ::: "memory");
+    if (kt + 1 < ksteps) WG_ISSUE_DY((kt + 1) & 1, p_begin + (kt + 1) * WG_BK);
+    if (kt + 2 < ksteps) WG_ISSUE_X(cur_x >= 1 ? cur_x - 1 : 2, p_begin + (kt + 2) * WG_BK);   // (cur_x + 2) % 3
+    const unsigned st_dy = lds0 + (unsigned)((kt & 1) * WG_TILE_BYTES);
+    const unsigned st_x = lds0 + (unsigned)((2 + cur_x) * WG_TILE_BYTES);
     // four K slices, reads of slice k + 1 in flight under the MFMAs of slice k (LDS reads return in order: a counted wait)
     rn_u32x2_t qa[8], qb[8];
     WG_READS(qa, st, 0);
@@ -241,15 +269,13 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wgrad_kernel(const WgArgs args)
     WG_MFMAS(qa);
     WG_WAIT(qb, 0);
     WG_MFMAS(qb);
-    // the next stage has landed and every wave is done reading this one before it is overwritten
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    cur ^= 1;
+    cur_x = cur_x == 2 ? 0 : cur_x + 1;
   }
 #undef WG_MFMAS
 #undef WG_WAIT
 #undef WG_READS
-#undef WG_ISSUE
+#undef WG_ISSUE_X
+#undef WG_ISSUE_DY
 
   // partial tile -> workspace[chunk][co][tap][ci]
   const int taps = args.R * args.S;
@@ -429,7 +455,7 @@ extern "C" int rn_conv2d_nhwc_wgrad(const rn_wgrad_problem* p, float* dw, float 
     RN_CHECK_LAUNCH();
     return RN_OK;
   }
-  const int lds = 4 * WG_TILE_BYTES;
+  const int lds = 5 * WG_TILE_BYTES;
   RN_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   RN_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   dim3 grid((unsigned)(a.gco * a.ci_tiles * a.R * a.S * a.co_groups * a.total_chunks));
