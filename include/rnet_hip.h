@@ -560,7 +560,7 @@ int rn_balance_features_bwd(void* const* dout, void* const* in, void* const* din
  *                      gradient all-reduce bucket by bucket while the backward pass is still running, on UNclipped
  *                      gradients (the clip factors need every gradient): `prepare` runs per bucket (blocks
  *                      [block_begin, block_begin + block_count)), `factors` once at the end and also writes
- *                      flags[0] = "a factor != 1 on this rank", flags[1] = "not finite" (slots that ride in the
+ *                      flags[0] = "a factor != 1 on this rank, or its gradient norm is not finite", flags[1] = "not finite" (slots that ride in the
  *                      last bucket's all-reduce); if some rank's clip fired, `apply` with correction != NULL writes
  *                      (factor - 1) * g, which is all-reduced and added — the sum then equals the reference's
  *                      clip-then-all-reduce order (executor.py:432-437).

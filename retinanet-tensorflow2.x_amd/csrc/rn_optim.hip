@@ -89,8 +89,8 @@ optim_sqnorm_kernel(float* __restrict__ g, const float* __restrict__ w, const Op
 // metrics f32[8]: [0] global norm after clipping, [1] before the global clip, [2] the global factor,
 // [3] l2-regularization = alpha * sum over decayed tensors of ||w||^2 / 2, [4] 1 if any per-tensor or the global
 // factor != 1 on this rank ("the clip fired"), [5] 1 if the gradient norm is not finite (LossScaleOptimizer skips
-// the step).  flags (optional, device f32[2]): [0] += metrics[4], [1] += metrics[5] — the slots that ride in the
-// last gradient bucket of the overlapped all-reduce.
+// the step).  flags (optional, device f32[2]): [0] = metrics[4] or metrics[5], [1] = metrics[5] — the slots that ride in
+// the last gradient bucket of the overlapped all-reduce.
 __global__ void __launch_bounds__(256)
 optim_factors_kernel(const OptSeg* __restrict__ segs, int nseg, const double* __restrict__ partial,
                      const double* __restrict__ partial_w, float clip, float wd_alpha, float* __restrict__ factor,
@@ -131,7 +131,9 @@ optim_factors_kernel(const OptSeg* __restrict__ segs, int nseg, const double* __
     metrics[3] = (float)(0.5 * (double)wd_alpha * totw);
     metrics[4] = (any || F != 1.0f) ? 1.0f : 0.0f;
     metrics[5] = finite ? 0.0f : 1.0f;
-    if (flags) { flags[0] = metrics[4]; flags[1] = metrics[5]; }
+    // flags[0] also fires on a non-finite norm (NaN makes no factor != 1: fmaxf drops it), so that "flags[0] == 0 on every
+    // rank" means "no correction AND nothing to skip": the predicate of the optimistic SGD launch (train_engine.py)
+    if (flags) { flags[0] = (metrics[4] != 0.0f || !finite) ? 1.0f : 0.0f; flags[1] = metrics[5]; }
     s_sq[0] = (double)F;
   }
   __syncthreads();
