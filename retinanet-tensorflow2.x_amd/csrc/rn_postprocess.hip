@@ -211,6 +211,24 @@ compact_logits_kernel(PPLevels lv, CompactTiles ct, int B, int K, float thr, flo
   // workgroups per image used to queue on each (image, class) counter: 43 of the kernel's 124 us at batch 8) and of the
   // barriers.  (Round 4 sized the list for exactly one sub-tile, so any survivor forced a flush and only EMPTY sub-tiles
   // were merged — ADVICE r4; what round 4 measured, 124 -> 104 us, came from the four times fewer workgroups.)
+  // K % 4 == 0 and at most NV 16-byte vectors per thread and sub-tile (K <= 96): the logits of sub-tile s + 1 are loaded
+  // before sub-tile s is tested and flushed — a sub-tile's loads used to be issued behind the previous sub-tile's barriers
+  // (three workgroups per CU, each stopping for a memory round trip per sub-tile: 1.9 TB/s over the 196 MB of a batch of 8)
+  constexpr int NV = 6;
+  const bool pre = (K & 3) == 0 && RN_CT_ANCHORS * K <= NV * RN_PP_THREADS * 4;
+  float4 nxt[NV];
+  auto load_sub = [&](int sub_) {
+    const int a0_ = (chunk * RN_CT_GROUP + sub_) * RN_CT_ANCHORS;
+    const int rows_ = (n_l - a0_) < RN_CT_ANCHORS ? (n_l - a0_) : RN_CT_ANCHORS;
+    const float* src_ = lv.ptr[l] + ((long long)b * n_l + a0_) * K;
+    const int total_ = rows_ > 0 ? rows_ * K : 0;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      const int i = (q * RN_PP_THREADS + (int)threadIdx.x) * 4;
+      nxt[q] = i < total_ ? *(const float4*)(src_ + i) : make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
+    }
+  };
+  if (pre) load_sub(0);
   for (int sub = 0; sub < RN_CT_GROUP; ++sub) {
     const int a0 = (chunk * RN_CT_GROUP + sub) * RN_CT_ANCHORS;
     const int rows = (n_l - a0) < RN_CT_ANCHORS ? (n_l - a0) : RN_CT_ANCHORS;
@@ -220,7 +238,27 @@ compact_logits_kernel(PPLevels lv, CompactTiles ct, int B, int K, float thr, flo
       const int total = rows * K;
       const int r0 = sub * RN_CT_ANCHORS;
       // ---- A: stream + pre-test ---------------------------------------------------------------
-      if ((K & 3) == 0) {
+      if (pre) {
+        float4 cur[NV];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) cur[q] = nxt[q];
+        if (!last) load_sub(sub + 1);
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+          const int i = (q * RN_PP_THREADS + (int)threadIdx.x) * 4;
+          if (i >= total) break;
+          const float x4[4] = {cur[q].x, cur[q].y, cur[q].z, cur[q].w};
+          const int r = i / K, c = i - r * K;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (!(x4[u] < x_skip)) {
+              const int slot = atomicAdd(l_n, 1);
+              l_val[slot] = x4[u];
+              l_meta[slot] = (unsigned short)(((r0 + r) << 8) | (c + u));
+            }
+          }
+        }
+      } else if ((K & 3) == 0) {
         for (int i = threadIdx.x * 4; i < total; i += RN_PP_THREADS * 4) {
           const float4 v = *(const float4*)(src + i);
           const float x4[4] = {v.x, v.y, v.z, v.w};
