@@ -515,8 +515,13 @@ typedef struct {
 /* Workspace of the reduction passes: [per-chunk partial sums][ticket counters][part slots].  A segment with more than
  * 512 rows of partial sums has its stage-2 reduction cut into parts whose last arriver (an atomic ticket) adds the parts
  * in part order; the ticket counters must be ZERO before the first launch on a workspace — zero the workspace once after
- * allocating it — and every launch leaves them zero (the contract of rn_conv_problem.splitk_ws). */
+ * allocating it — and every launch leaves them zero (the contract of rn_conv_problem.splitk_ws).
+ * Ordering: the counters are shared by the forward (rn_bn_stats*) and the backward (rn_bn_bwd_reduce) launches on one
+ * workspace, so all launches that use one workspace must be ordered on ONE stream (or by events). */
 size_t rn_bn_workspace_bytes(const rn_bn_problem* problem /* host */);
+/* zeroes the ticket counters only (a few hundred bytes, one asynchronous memset on `stream`): for a workspace that was
+ * not zero-filled at allocation.  RN_ENOMEM when the workspace is smaller than rn_bn_workspace_bytes(problem). */
+int rn_bn_workspace_init(const rn_bn_problem* problem, void* workspace, size_t workspace_bytes, void* stream);
 size_t rn_bn_partial_offset_bytes(const rn_bn_problem* problem, int segment);   /* forward-stats partials in the workspace */
 size_t rn_bn_bwd_partial_offset_bytes(const rn_bn_problem* problem, int segment);   /* backward partials (ext_chunks_bwd) */
 int rn_bn_stats(const rn_bn_problem* problem, void* workspace, size_t workspace_bytes, void* stream);

@@ -642,6 +642,24 @@ extern "C" size_t rn_bn_workspace_bytes(const rn_bn_problem* p) {
   return need;
 }
 
+// Zeroes the ticket counters (and nothing else) of a workspace allocated for `p`: the cheap way to honour the "counters
+// start at zero" contract for a workspace that came out of an uninitialised allocation.  The counter region is
+// the same for both modes (bn_fill places it behind the larger of the two partial areas).
+extern "C" int rn_bn_workspace_init(const rn_bn_problem* p, void* ws, size_t ws_bytes, void* stream) {
+  BnArgs a;
+  RN_CHECK_ARG(p && bn_fill(p, a, 1, 0) == 0, "rn_bn_workspace_init: bad problem (C %% 8 == 0, 1..10 segments)");
+  const size_t need = rn_bn_workspace_bytes(p);
+  if (!ws || ws_bytes < need) {
+    rn_set_error("rn_bn_workspace_init: workspace too small (%zu < %zu)", ws_bytes, need);
+    return RN_ENOMEM;
+  }
+  const long long begin = a.cnt_off[0];
+  long long end = begin;
+  for (int i = 0; i < p->num_segments; ++i) end = a.cnt_off[i] + rn_cdiv(p->seg[i].C, 16) * 4;
+  RN_CHECK_HIP(hipMemsetAsync((char*)ws + begin, 0, (size_t)(end - begin), (hipStream_t)stream));
+  return RN_OK;
+}
+
 extern "C" size_t rn_bn_partial_offset_bytes(const rn_bn_problem* p, int segment) {
   BnArgs a;
   if (bn_fill(p, a, 1, 0) || segment < 0 || segment >= a.nseg) return 0;

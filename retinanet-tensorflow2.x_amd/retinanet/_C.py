@@ -6,6 +6,7 @@ is missing, and every call raises `RnetError` on a non-zero status.
 from __future__ import annotations
 
 import ctypes
+import logging
 import os
 from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_longlong, c_size_t, c_uint32,
                     c_uint64, c_void_p)
@@ -198,6 +199,7 @@ _SIGNATURES = {
     "rn_cast_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "rn_act_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "rn_bn_workspace_bytes": (c_size_t, [POINTER(BnProblem)]),
+    "rn_bn_workspace_init": (c_int, [POINTER(BnProblem), c_void_p, c_size_t, c_void_p]),
     "rn_bn_partial_offset_bytes": (c_size_t, [POINTER(BnProblem), c_int]),
     "rn_bn_bwd_partial_offset_bytes": (c_size_t, [POINTER(BnProblem), c_int]),
     "rn_bn_stats": (c_int, [POINTER(BnProblem), c_void_p, c_size_t, c_void_p]),
@@ -391,7 +393,25 @@ def wait_blocks(lib_, a, probe, main, helper, spin_us=600, pre=None):
     weight gradients queued before it: +6.4 ms per step inside bench.py, +1.2 ms in a fresh process (other queue map).
     `helper`: a third stream that idles for `spin_us` and then releases the wait; `pre()`: enqueued behind the wait, in front
     of the probe (keep it warm: its host time counts against the 0.5 * spin_us threshold).  Synchronises the device."""
+    import time
     import torch
+    # ADVICE r5: the timed interval contains the HOST time of pre() and probe() — a first-call lazy init or a slow c10d
+    # enqueue read as "blocked".  So: one untimed warm call of both (always issued — `probe` may be a collective, every
+    # rank must run the same sequence), its host time measured, and the spin stretched so that the threshold (half the
+    # spin) stays at least 4 x that enqueue time.  The stretch is rank-local but only changes a kernel's duration, never
+    # the number of collectives.
+    t0 = time.perf_counter()
+    if pre is not None:
+        pre()
+    probe()
+    host_us = (time.perf_counter() - t0) * 1e6
+    torch.cuda.synchronize(a.device)
+    t0 = time.perf_counter()
+    if pre is not None:
+        pre()
+    probe()
+    host_us = min(host_us, (time.perf_counter() - t0) * 1e6)   # the second call is the warm one
+    spin_us = int(min(max(spin_us, 8.0 * host_us), 20000))
     torch.cuda.synchronize(a.device)
     gate = torch.cuda.Event()
     check(lib_.rn_probe_spin(int(spin_us), c_void_p(helper.cuda_stream)), "rn_probe_spin")
@@ -404,7 +424,11 @@ def wait_blocks(lib_, a, probe, main, helper, spin_us=600, pre=None):
     probe()
     e1.record(main)
     torch.cuda.synchronize(a.device)
-    return e0.elapsed_time(e1) * 1e3 > 0.5 * spin_us
+    took_us = e0.elapsed_time(e1) * 1e3
+    blocked = took_us > 0.5 * spin_us
+    logging.getLogger("retinanet").debug("wait_blocks: spin %d us, host enqueue %.0f us, probe took %.0f us -> %s",
+                                         spin_us, host_us, took_us, "blocked" if blocked else "free")
+    return blocked
 
 
 def concurrent_stream(lib_, device, others, attempts=12, probes=(), agree=None):

@@ -253,6 +253,11 @@ class ModelBuilder:
         return self.add_post_processing_stage(model, skip_decoding=skip_decoding, skip_nms=skip_nms)
 
     def add_post_processing_stage(self, model, skip_decoding=False, skip_nms=False, capture_graph=False):
+        """model/builder.py:153-190: images -> {'boxes', 'scores', 'classes', 'valid_detections'}.
+
+        The returned dict holds the stage's STATIC output buffers: the next call with the same batch size overwrites
+        them (with `capture_graph=True` asynchronously, by one graph replay).  A caller that keeps detections across
+        calls — an evaluation loop accumulating results — must `.clone()` them or copy them to the host first."""
         params = self.params
         logging.info("Postprocessing stage config:\n%s", json.dumps(params.inference, indent=4))
         if skip_decoding or skip_nms:
@@ -263,7 +268,12 @@ class ModelBuilder:
                                      device=model.device)
         post = DetectionPostProcess(params, anchors=anchors)
 
-        graphs = {}   # capture_graph: batch size -> (engine, HIP graph of forward + post-processing, static outputs)
+        # capture_graph: batch size -> (engine, HIP graph of forward + post-processing, static outputs, the stage).  A
+        # captured graph has the raw addresses of its DetectionPostProcess's boxes / workspace / outputs baked in and that
+        # object re-allocates them when the batch size changes, so every captured batch size gets its OWN stage object,
+        # kept alive here next to its graph (one shared stage left the first graph replaying into freed memory
+        # after a second batch size warmed up).
+        graphs = {}
 
         def inference_model(images, training=False):
             if not capture_graph:
@@ -280,15 +290,16 @@ class ModelBuilder:
                 eng = model.inference_engine(B)
                 if tuple(images.shape) != tuple(eng.t["images"].shape):
                     raise ValueError(f"expected images of shape {tuple(eng.t['images'].shape)}, got {tuple(images.shape)}")
+                post_b = DetectionPostProcess(params, anchors=anchors)
                 with torch.cuda.device(model.device):
-                    post(eng(images))                       # warm-up outside capture: lazy loads, workspace allocation
+                    post_b(eng(images))                     # warm-up outside capture: lazy loads, workspace allocation
                     torch.cuda.synchronize()
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g):
                         eng._launch_all()
-                        out = post(eng.outputs)
-                st = graphs[B] = (eng, g, out)
-            eng, g, out = st
+                        out = post_b(eng.outputs)
+                st = graphs[B] = (eng, g, out, post_b)
+            eng, g, out, _ = st
             if tuple(images.shape) != tuple(eng.t["images"].shape):
                 raise ValueError(f"expected images of shape {tuple(eng.t['images'].shape)}, got {tuple(images.shape)}")
             with torch.cuda.device(model.device):

@@ -643,7 +643,11 @@ class TrainEngine:
         self._ppair = getattr(self, "_ppair", {})
         key = op["out"]
         if key not in self._ppair:
-            ok = op["op"] == "conv" and not self._conv_trainable(op) and not self.requires.get(op["inp"])
+            # tied to the inference-form launch: a frozen kernel in front of a LIVE BatchNorm (custom freeze regexes) goes
+            # through _conv_problem(raw_mode=True), which keeps the layer's own shape — its weights must then not be the
+            # pair-packed [128,3,3,128] buffer
+            ok = (op["op"] == "conv" and not self._conv_trainable(op) and not self._bn_trainable(op)
+                  and not self.requires.get(op["inp"]))
             self._ppair[key] = ok and pixel_pair_ok(self.lib, self.g, op, self.B, self.launch_opts, getattr(self, "splitk_ws", None))
         return self._ppair[key]
 
@@ -684,6 +688,7 @@ class TrainEngine:
         """forward conv launch over `ops`; raw_mode: write pre-BN output (+bias) without activation."""
         first = ops[0]
         c0 = self.g.convs[first["conv"]]
+        assert not (raw_mode and any(self._pixel_pair(o) for o in ops)), "pair-packed weights behind a raw (pre-BN) launch"
         p = _C.attach_splitk_workspace(_C.ConvProblem(), self.splitk_ws)
         p.opts = self.launch_opts
         p.R = p.S = c0["k"]

@@ -181,3 +181,34 @@ def test_serving_path_end_to_end(cuda):
         outg = {k: v.cpu().numpy().copy() for k, v in infer_g(images).items()}
     for k in out:
         np.testing.assert_array_equal(out[k], outg[k])
+
+
+def test_captured_stage_alternating_batch_sizes(cuda):
+    """one `capture_graph=True` stage serving two batch sizes.  Each captured graph bakes in the addresses of its
+    post-processing buffers; warming up a second batch size must not free what the first graph replays into.  Alternate
+    B = 2 / B = 1 / B = 2 with allocator churn in between and compare every replay with the eager stage bit for bit."""
+    from retinanet.cfg import default_params
+    from retinanet.model import ModelBuilder
+    p = default_params(input_size=256)
+    p.inference.score_threshold = 0.005
+    b = ModelBuilder(p, "val", device=cuda)
+    model = b()
+    _randomize(model, 2)
+    eager = b.add_post_processing_stage(model)
+    g = torch.Generator().manual_seed(11)
+    im2 = torch.randn((2, 256, 256, 3), generator=g).to(cuda)
+    im1 = torch.randn((1, 256, 256, 3), generator=g).to(cuda)
+    im2b = torch.randn((2, 256, 256, 3), generator=g).to(cuda)
+    want = {}
+    for name, im in (("a", im2), ("b", im1), ("c", im2b)):
+        want[name] = {k: v.cpu().numpy().copy() for k, v in eager(im).items()}
+    infer_g = b.add_post_processing_stage(model, capture_graph=True)
+    seq = [("a", im2), ("b", im1), ("c", im2b), ("b", im1), ("a", im2)]
+    for name, im in seq:
+        got = {k: v.cpu().numpy().copy() for k, v in infer_g(im).items()}
+        # churn the caching allocator: freed blocks of a shared stage would be handed out and scribbled over here
+        junk = [torch.full((1 << 20,), float(i), device=cuda) for i in range(8)]
+        torch.cuda.synchronize()
+        del junk
+        for k in want[name]:
+            np.testing.assert_array_equal(want[name][k], got[k], err_msg=f"{name}:{k}")

@@ -593,6 +593,19 @@ def test_bn_stage2_reduction_in_parts(cuda):
     n_cnt = sum(-(-C // 16) for C, _ in segs)
     tail = ws[(tail0 * 4 + 255) // 256 * 64:][:n_cnt].view(torch.int32)
     assert int(tail.abs().sum().item()) == 0
+    # a workspace that was NOT zero-filled at allocation: rn_bn_workspace_init zeroes the counters (and only them)
+    ws2 = torch.full((nbytes // 4,), float("nan"), dtype=torch.float32, device=cuda)
+    ws2.view(torch.int32).fill_(0x7FC12345)
+    ws2[:tail0] = ws[:tail0]
+    _C.check(lib.rn_bn_workspace_init(ctypes.byref(p), _C.ptr(ws2), nbytes, st))
+    assert torch.equal(ws2[:tail0], ws[:tail0])                      # the partial sums are untouched
+    for s_ in sums:
+        s_.zero_()
+    _C.check(lib.rn_bn_stats(ctypes.byref(p), _C.ptr(ws2), nbytes, st))
+    torch.cuda.synchronize()
+    for a, b in zip(runs[0], sums):
+        assert torch.equal(a, b)
+    assert lib.rn_bn_workspace_init(ctypes.byref(p), _C.ptr(ws2), nbytes - 4, st) == _C.RN_ENOMEM
 
 
 @pytest.mark.parametrize("build,k,tile", [("bf16", 1, 2), ("bf16", 3, 2), ("bf16", 1, 1), ("bf16", 3, 1), ("bf16", 3, 3),
