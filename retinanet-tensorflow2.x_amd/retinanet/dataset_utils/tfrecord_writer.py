@@ -1,9 +1,11 @@
-"""`TFrecordWriter` with the reference's surface and sharding arithmetic
-(retinanet/dataset_utils/tfrecord_writer.py:7-80) — SURVEY §8(f)-4.
+"""`TFrecordWriter`: the reference's public surface (constructor arguments, `push`, `flush_last`, file names) and its shard
+sizes (retinanet/dataset_utils/tfrecord_writer.py:7-80) — SURVEY §8(f)-4 — as a STREAMING writer.
 
-`push(image_bytes, boxes[n,4] normalised (xmin,ymin,xmax,ymax), classes[n], image_id)` buffers samples and writes
-`<prefix>-NNNN.tfrecord` every `n_samples // n_shards` samples (the last shard also takes the remainder);
-`flush_last()` writes what is left.  Examples are serialised and framed natively (`rn_example_serialize`,
+`push(image_bytes, boxes[n,4] normalised (xmin,ymin,xmax,ymax), classes[n], image_id)` serialises and frames the sample
+at once and appends it to the open shard `<prefix>-NNNN.tfrecord` (numbered from 1); shard i of `n_shards` closes after
+`n_samples // n_shards` records, the last one after that plus the remainder; `flush_last()` closes a shard that is still
+open (fewer samples pushed than announced).  Nothing but the current record is held in memory (the reference keeps a
+whole shard of encoded images in a Python list before it writes).  Examples are serialised and framed natively (`rn_example_serialize`,
 `rn_tfrecord_frame`): same features and dtypes as `_make_example` (:27-44), keys in sorted order, packed lists —
 any protobuf reader (TensorFlow's included) parses them.
 """
@@ -41,48 +43,46 @@ def frame_record(payload):
 
 class TFrecordWriter:
     def __init__(self, n_samples, n_shards, output_dir="", prefix=""):
-        self.n_samples = n_samples
-        self.n_shards = n_shards
-        self._step_size = self.n_samples // self.n_shards
-        self.prefix = prefix
-        self.output_dir = output_dir
-        self._buffer = []
-        self._file_count = 1
-        self._remainder = self.n_samples - (self._step_size * self.n_shards)
-        logging.info("writing %d samples in each tfrecord", self._step_size)
-        if self._remainder:
-            logging.warning("writing %d remaining samples in last tfrecord", self._remainder)
+        if n_shards < 1 or n_samples < n_shards:
+            raise ValueError(f"cannot cut {n_samples} samples into {n_shards} shards")
+        self.n_samples, self.n_shards = int(n_samples), int(n_shards)
+        self.output_dir, self.prefix = output_dir, prefix
+        per_shard, extra = divmod(self.n_samples, self.n_shards)
+        # records each shard takes, in file order: the remainder rides in the last file (reference :14-15, :62-64)
+        self._plan = [per_shard] * (self.n_shards - 1) + [per_shard + extra]
+        self._shard = 0          # index into _plan of the shard being written
+        self._in_shard = 0       # records already in it
+        self._file = None
+        logging.info("%d samples per tfrecord%s", per_shard, f", {extra} more in the last one" if extra else "")
 
     @staticmethod
     def _make_example(image, boxes, classes, image_id):
-        """Serialized tf.train.Example (the reference returns the message and serialises it in `_write_tfrecord`)."""
+        """Serialized tf.train.Example with the features of the reference's `_make_example` (:27-44)."""
         return serialize_example(image, boxes, classes, image_id)
 
-    def _write_tfrecord(self, tfrecord_path):
-        if not self._buffer:
-            logging.warning("no samples to be written")
-            return
-        logging.info("writing %d samples in %s", len(self._buffer), tfrecord_path)
-        with open(tfrecord_path, "wb") as f:
-            for (image, boxes, classes, image_id) in self._buffer:
-                f.write(frame_record(TFrecordWriter._make_example(image, boxes, classes, image_id)))
+    def shard_path(self, index):
+        """path of the index-th shard (0-based); the name carries the 1-based number in four digits"""
+        return os.path.join(self.output_dir, f"{self.prefix}-{index + 1:04d}.tfrecord")
 
-    def _clear_buffer(self):
-        self._buffer = []
-
-    def _path(self):
-        return os.path.join(self.output_dir, self.prefix + "-{:04.0f}".format(self._file_count) + ".tfrecord")
+    def _close(self):
+        if self._file is not None:
+            self._file.close()
+            logging.info("wrote %d samples to %s", self._in_shard, self._file.name)
+            self._file = None
+            self._shard += 1
+            self._in_shard = 0
 
     def push(self, image, boxes, classes, image_id):
-        self._buffer.append([image, boxes, classes, image_id])
-        max_buffer_size = self._step_size
-        if self._file_count == self.n_shards:
-            max_buffer_size += self._remainder
-        if len(self._buffer) == max_buffer_size:
-            self._write_tfrecord(self._path())
-            self._clear_buffer()
-            self._file_count += 1
+        if self._file is None:
+            # samples past the announced total go to further files of the regular size, like the reference's counter
+            self._file = open(self.shard_path(self._shard), "wb")
+        self._file.write(frame_record(self._make_example(image, boxes, classes, image_id)))
+        self._in_shard += 1
+        quota = self._plan[self._shard] if self._shard < self.n_shards else self._plan[0]
+        if self._in_shard == quota:
+            self._close()
 
     def flush_last(self):
-        if self._buffer:
-            self._write_tfrecord(self._path())
+        if self._file is None:
+            logging.warning("no samples to be written")
+        self._close()

@@ -208,3 +208,41 @@ def test_global_and_combined_modes(cuda, mode, topk, strict):
     _check(out, wb, ws, wc, wv)
     if strict:   # the reference quirk: nothing is suppressed, the output is simply the top scores
         assert (wv == 50).all()
+
+
+def test_soft_nms_kernel_vs_independent_transcription(cuda):
+    """VERDICT r5 next-3a on the GPU side: `rn_nms_per_class` against tests/test_soft_nms_independent.py's list-scan
+    transcription of TF's NonMaxSuppressionV5 (not the C oracle): every class of every image is one NMSV5 call in the
+    reference's soft shape (iou_threshold 1.0, sigma / 2 — postprocessing_ops.py:443-451) and in the hard shape; the merged
+    output is the union of the per-class selections in descending score order."""
+    from test_soft_nms_independent import _literal_v5, _oracle_expf, _random_case
+    from retinanet.model.layers import GenerateDetections
+    rng = np.random.default_rng(77)
+    B, K, n, md = 3, 4, 160, 30
+    scores = np.zeros((B, n, K), np.float32)
+    boxes = np.zeros((B, n, K, 4), np.float32)
+    for b in range(B):
+        for c in range(K):
+            bx, sc = _random_case(rng, ["spread", "clustered", "duplicates"][(b + c) % 3], n)
+            boxes[b, :, c], scores[b, :, c] = bx, sc
+    for mode, sigma in (("PerClassSoftNMS", 0.5), ("PerClassHardNMS", 0.0)):
+        gen = GenerateDetections(iou_threshold=0.5, score_threshold=0.05, max_detections=md, soft_nms_sigma=0.5,
+                                 num_classes=K, mode=mode)
+        out = {k: v.cpu().numpy() for k, v in gen({"scores": torch.from_numpy(scores).to(cuda),
+                                                   "boxes": torch.from_numpy(boxes).to(cuda)}).items()}
+        for b in range(B):
+            merged = []
+            for c in range(K):
+                wi, ws, wn = _literal_v5(boxes[b, :, c], scores[b, :, c], md, 1.0 if sigma else 0.5, 0.05, sigma / 2,
+                                         _oracle_expf)
+                merged += [(-float(ws[j]), c * md + j, c, int(wi[j]), ws[j]) for j in range(wn)]
+            merged.sort()
+            merged = merged[:md]
+            v = int(out["valid_detections"][b])
+            assert v == len(merged), (mode, b)
+            assert out["classes"][b, :v].tolist() == [m[2] for m in merged]
+            want_s = np.array([m[4] for m in merged], np.float32)
+            np.testing.assert_array_equal(out["scores"][b, :v].view(np.uint32), want_s.view(np.uint32))
+            want_b = np.stack([boxes[b, m[3], m[2]] for m in merged])
+            np.testing.assert_array_equal(out["boxes"][b, :v], np.clip(want_b, 0.0, 1.0))
+            assert (out["scores"][b, v:] == -1).all() and (out["classes"][b, v:] == -1).all()
