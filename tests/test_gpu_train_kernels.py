@@ -943,3 +943,183 @@ def test_scatter_add2x(cuda, N, H, W, C, Ho, Wo):
         hh, ww = (Ho + 1) // 2, (Wo + 1) // 2
         want[:, ::2, ::2, :] += x.float()[:, :hh, :ww, :]
         assert torch.equal(yd.float().cpu(), want.to(H16).float())
+
+
+# ---------------------------------------------------------------------------------------------
+# A tight test that spans several layers.  The whole-network gradient checks are bounded by the
+# restatement's own fp32-vs-fp64 noise (cosines ~0.93 at 640^2): they prove wiring, not numerics; the per-launch tests
+# are tight but span one kernel.  Here: one bottleneck tail of the REAL training engine at the bench geometry
+#   conv3x3 128->128 -> BN(train) -> ReLU -> conv1x1 128->512 -> BN(train) -> + residual -> ReLU   (80 x 80, B = 32)
+# = ResNet-50 `g2b1_b` -> `g2b1_out` at 640 x 640 (resnet.py:194-248), run through TrainEngine.forward / backward
+# with its defaults (fused BatchNorm statistics in the conv epilogues, RNET_FUSE_BN_BWD stage 1 in the data-gradient
+# epilogue, two streams, grouped weight gradients), and re-derived in float64 from the engine's OWN tensors at the
+# slice's boundary — the slice input x, the residual, the upstream gradient dz — with the rounding points the engine has
+# (every stored activation / gradient tensor is bf16).  Only what happens INSIDE the slice is compared, so no noise from
+# the other 100 layers enters, and the bounds are bf16 rounding: every gradient's cosine > 0.9999, bf16 tensors within
+# 2 ulp on all but a few elements (a flipped rounding upstream moves a neighbour's sum), fp32 gradients within 2e-3.
+def _f64(t):
+    return t.double()
+
+
+def _conv3x3_f64(x, w):
+    """x [N,H,W,C] f64 (device), w [3,3,C,K] f64 -> [N,H,W,K]: nine shifted GEMMs (rocBLAS dgemm), pad 1"""
+    N, H, W, C = x.shape
+    xp = torch.nn.functional.pad(x, (0, 0, 1, 1, 1, 1))
+    y = torch.zeros((N, H, W, w.shape[3]), dtype=torch.float64, device=x.device)
+    for r in range(3):
+        for s in range(3):
+            y += xp[:, r:r + H, s:s + W, :] @ w[r, s]
+    return y
+
+
+def _conv3x3_dgrad_f64(dy, w):
+    N, H, W, K = dy.shape
+    dp = torch.nn.functional.pad(dy, (0, 0, 1, 1, 1, 1))
+    dx = torch.zeros((N, H, W, w.shape[2]), dtype=torch.float64, device=dy.device)
+    for r in range(3):
+        for s in range(3):
+            dx += dp[:, 2 - r:2 - r + H, 2 - s:2 - s + W, :] @ w[r, s].t()
+    return dx
+
+
+def _conv3x3_wgrad_f64(x, dy):
+    N, H, W, C = x.shape
+    xp = torch.nn.functional.pad(x, (0, 0, 1, 1, 1, 1))
+    dw = torch.zeros((3, 3, C, dy.shape[3]), dtype=torch.float64, device=x.device)
+    d2 = dy.reshape(-1, dy.shape[3])
+    for r in range(3):
+        for s in range(3):
+            dw[r, s] = xp[:, r:r + H, s:s + W, :].reshape(-1, C).t() @ d2
+    return dw
+
+
+def _bn_train_f64(y, gamma, beta, eps):
+    mean = y.mean(dim=(0, 1, 2))
+    var = y.var(dim=(0, 1, 2), unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + eps)
+    xhat = (y - mean) * invstd
+    return xhat * gamma + beta, xhat, invstd
+
+
+def _bn_bwd_f64(g, xhat, invstd, gamma):
+    """g = gradient wrt the BatchNorm output (after the activation gate) -> (dy, dgamma, dbeta)"""
+    dbeta = g.sum(dim=(0, 1, 2))
+    dgamma = (g * xhat).sum(dim=(0, 1, 2))
+    n = g.shape[0] * g.shape[1] * g.shape[2]
+    dy = gamma * invstd * (g - dbeta / n - xhat * dgamma / n)
+    return dy, dgamma, dbeta
+
+
+def _ulp_outliers(got, want64, ulps=2.0):
+    """fraction of bf16 elements farther than `ulps` bf16 ulps from the float64 value (ulp of the element's own magnitude,
+    floored at 2^-8 of the tensor's rms: a sum that cancels to ~0 has the rounding of its terms, not of its value)"""
+    w = want64.abs()
+    rms = want64.pow(2).mean().sqrt()
+    mag = torch.maximum(w, rms * 2.0 ** -8)
+    ulp = torch.pow(2.0, torch.floor(torch.log2(mag)) - 7)
+    return ((got.double() - want64).abs() > ulps * ulp).double().mean().item()
+
+
+def test_bottleneck_tail_forward_backward_tight(cuda):
+    from retinanet.cfg import default_params
+    from retinanet.dataloader import LabelEncoder
+    from retinanet.model import ModelBuilder
+    from retinanet.model.train_engine import TrainEngine
+    from make_golden import synth_gt
+    size, B = 640, 32
+    p = default_params(input_size=size, balanced=True)
+    p.architecture.batch_norm.use_sync = False
+    builder = ModelBuilder(p, "train", device=cuda, seed=5)
+    model = builder()
+    gen = torch.Generator().manual_seed(5)
+    for k, v in model.variables.items():      # every branch carries signal (the reference zero-inits the last gamma of a block)
+        if k.endswith("/gamma"):
+            zero_init = model.graph.bns[k[:-len("/gamma")]]["gamma_zero"]
+            lo, span = (0.2, 0.3) if zero_init else (0.75, 0.5)
+            v.copy_((torch.rand(v.shape, generator=gen) * span + lo).to(cuda))
+        elif k.endswith("/beta"):
+            v.copy_((torch.randn(v.shape, generator=gen) * 0.1).to(cuda))
+    rx = [builder.FREEZE_VARS_REGEX[n] for n in p.training.freeze_variables]
+    eng = TrainEngine(model, B, frozen_regexes=rx, world_size=1)
+    assert eng.fuse_bn_stats and eng.fuse_bn_bwd and eng.side_stream_on      # the defaults the bench runs
+    enc = LabelEncoder(p, device=cuda)
+    rng = np.random.default_rng(5)
+    gts = [synth_gt(rng, int(rng.integers(2, 9)), size) for _ in range(B)]
+    Gmax = max(x[0].shape[0] for x in gts)
+    gb, gc, cnt = np.zeros([B, Gmax, 4], np.float32), np.zeros([B, Gmax], np.float32), np.zeros([B], np.int32)
+    for i, (b_, c_) in enumerate(gts):
+        gb[i, :len(b_)], gc[i, :len(c_)], cnt[i] = b_, c_, len(b_)
+    targets = enc.encode_batch(torch.from_numpy(gb), torch.from_numpy(gc), torch.from_numpy(cnt))
+    images = torch.randn((B, size, size, 3), generator=gen).to(cuda)
+    with torch.cuda.device(cuda):
+        eng._step_args = dict(wdc=0.0, alpha=0.0, unscale=1.0, clip=0.0)
+        eng._prepack_dgrad_weights()
+        preds = eng.forward(images)
+        model.loss(targets, preds, compute_grads=True, grad_scale=1.0, grads_bf16=eng.loss_grad_buffers(), normalizer=None)
+        eng._train_step_active = True
+        try:
+            eng.backward(None)
+        finally:
+            eng._train_step_active = False
+        torch.cuda.synchronize()
+    ops = {o["out"]: o for o in eng.ops if o["op"] == "conv"}
+    ob, oo = ops["g2b1_b"], ops["g2b1_out"]
+    assert eng.tensors["g2b1_b"][:3] == (80, 80, 128) and oo["residual"] == "g2b0_out"
+    eps = eng.eps
+    rb = lambda t: t.to(eng.h16).double()            # a stored bf16 tensor
+    var = model.variables
+    # ---- boundary tensors, taken from the engine -----------------------------------------------------------------
+    x = _f64(eng.t["g2b1_a"])                         # slice input (post BN + ReLU of g2b1_a)
+    res = _f64(eng.t["g2b0_out"])
+    dz = _f64(eng.grad["g2b1_out"])                  # gradient wrt the block output, all contributions summed
+    wb = rb(var[ob["conv"] + "/kernel"].to(cuda))     # kernels as the engine multiplies them: rounded to bf16
+    wo = rb(var[oo["conv"] + "/kernel"].to(cuda))[0, 0]
+    gam_b, bet_b = _f64(var[ob["bn"] + "/gamma"].to(cuda)), _f64(var[ob["bn"] + "/beta"].to(cuda))
+    gam_o, bet_o = _f64(var[oo["bn"] + "/gamma"].to(cuda)), _f64(var[oo["bn"] + "/beta"].to(cuda))
+    # ---- forward, float64 with the engine's rounding points ------------------------------------------------------
+    yb = rb(_conv3x3_f64(x, wb))                      # Conv2D output: a bf16 tensor
+    assert _ulp_outliers(eng.raw["g2b1_b"], _conv3x3_f64(x, wb), 1.0) < 1e-3
+    ub, xhat_b, inv_b = _bn_train_f64(yb, gam_b, bet_b, eps)
+    zb = rb(torch.relu(ub))
+    assert _ulp_outliers(eng.t["g2b1_b"], torch.relu(ub), 2.0) < 2e-3
+    yo64 = zb @ wo
+    yo = rb(yo64)
+    assert _ulp_outliers(eng.raw["g2b1_out"], yo64, 2.0) < 2e-3
+    uo, xhat_o, inv_o = _bn_train_f64(yo, gam_o, bet_o, eps)
+    so = rb(uo) + res                                 # BatchNorm output is a bf16 tensor, then the add, then ReLU
+    zo = torch.relu(so)
+    assert _ulp_outliers(eng.t["g2b1_out"], zo, 2.0) < 3e-3
+    # ---- backward ---------------------------------------------------------------------------------------------------
+    g_o = dz * (so > 0)
+    dyo, dgam_o, dbet_o = _bn_bwd_f64(g_o, xhat_o, inv_o, gam_o)
+    dyo_r = rb(dyo)
+    dzb64 = dyo_r @ wo.t()                            # data gradient of the 1x1 conv = dz of the 3x3 conv's BatchNorm
+    dwo = zb.reshape(-1, zb.shape[3]).t() @ dyo_r.reshape(-1, dyo_r.shape[3])
+    g_b = rb(dzb64) * (ub > 0)
+    dyb, dgam_b, dbet_b = _bn_bwd_f64(g_b, xhat_b, inv_b, gam_b)
+    dyb_r = rb(dyb)
+    dx64 = _conv3x3_dgrad_f64(dyb_r, wb)
+    dwb = _conv3x3_wgrad_f64(x, dyb_r)
+    # ---- the engine's gradients --------------------------------------------------------------------------------------
+    def cos(a, b):
+        a, b = a.double().reshape(-1), b.double().reshape(-1)
+        return (a @ b / (a.norm() * b.norm() + 1e-300)).item()
+
+    def rel(a, b):
+        return ((a.double() - b).norm() / (b.norm() + 1e-300)).item()
+
+    def kernel_grad(conv):
+        c = eng.g.convs[conv]
+        return eng._pview(conv + "/kernel", eng.G).reshape(c["cout"], c["k"], c["k"], c["cin"]).permute(1, 2, 3, 0)
+    report = {}
+    for name, got, want in (("dz(g2b1_b)", eng.grad["g2b1_b"], dzb64), ("dx(g2b1_a)", eng.grad["g2b1_a"], dx64)):
+        report[name] = (cos(got, want), _ulp_outliers(got, want, 2.0))
+        assert report[name][0] > 0.9999 and report[name][1] < 5e-3, report
+    for name, got, want in (("dW out", kernel_grad(oo["conv"])[0, 0], dwo), ("dW b", kernel_grad(ob["conv"]), dwb),
+                            ("dgamma out", eng._pview(oo["bn"] + "/gamma", eng.G), dgam_o),
+                            ("dbeta out", eng._pview(oo["bn"] + "/beta", eng.G), dbet_o),
+                            ("dgamma b", eng._pview(ob["bn"] + "/gamma", eng.G), dgam_b),
+                            ("dbeta b", eng._pview(ob["bn"] + "/beta", eng.G), dbet_b)):
+        report[name] = (cos(got, want), rel(got, want))
+        assert report[name][0] > 0.9999 and report[name][1] < 2e-3, report
+    print("bottleneck tail, engine vs float64:", {k: (round(v[0], 7), float(f"{v[1]:.3g}")) for k, v in report.items()})
