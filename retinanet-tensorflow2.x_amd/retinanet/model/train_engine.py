@@ -56,11 +56,13 @@ class TrainEngine:
         wide_pred_terms: bf16 weight planes the TRAINING forward of the wide dtype=float32 prediction conv (the class
         head's 720-channel layer, detection_head.py:80-88) multiplies by — 2 = the split-bf16 form of its f32 kernel
         (inference / export always use it), 1 = rb(w) only.  Default: RNET_TRAIN_PRED_W_TERMS, else
-        params.training.prediction_weight_planes, else 1 — round 5 measured on the bench batch (tools/ab_pred_planes.py,
-        profiles/r05_ab/ab_pred_planes.json): class-loss moves by 3.1e-7 relative (the contract is 1e-5), every weight-
-        gradient group keeps a cosine > 0.99999 with the two-plane step, the step gains 0.58 ms (1.9 %).  The deviation
-        from the reference's f32 layer is documented in DESIGN.md section 6; the narrow box-regression layer keeps both
-        planes (its pair form costs 0.1 ms and its Huber loss has delta = 0.1).
+        params.training.prediction_weight_planes, else 2 (the reference's f32 layer).  History: round 5 made ONE plane the
+        default on an A/B taken at the reference's initialisation, where the logits are bias + a small kernel term (spread
+        0.33): class-loss moved by 3.1e-7 relative.  Round 6 repeated the A/B in the trained-detector regime — the class-
+        prediction kernel scaled by 7, logit spread 2.3 (tools/ab_pred_planes.py --pred-scale 7,
+        profiles/r06_ab_pred_planes_scale7.json): the class-loss moves by 4.3e-5 relative, above the 1e-5 the contract
+        allows for the loss (gradient cosines stay > 0.99999) — so the default went back to two planes; one plane remains
+        a documented opt-in worth 0.8 ms of the 29 ms step.  The narrow box-regression layer always keeps both planes.
         force_dp (default RNET_FORCE_DP=1): run the data-parallel machinery — SyncBN messages, the bucketed gradient
         all-reduce overlapped with the backward pass, the clip flag read — although this engine has ONE replica, over
         whatever process group it was given (a 1-rank `nccl` group: bench.py's `extra.dp_overhead`, the cost of that
@@ -99,7 +101,7 @@ class TrainEngine:
                                 self.launch_opts)
         if wide_pred_terms is None:
             wide_pred_terms = os.environ.get("RNET_TRAIN_PRED_W_TERMS") or \
-                getattr(getattr(model.params, "training", None), "prediction_weight_planes", None) or 1
+                getattr(getattr(model.params, "training", None), "prediction_weight_planes", None) or 2
         self.wide_pred_terms = max(1, min(int(wide_pred_terms), _C.PRED_W_TERMS))
         self._pair_cache = {}
         self.frozen = set(frozen_names)

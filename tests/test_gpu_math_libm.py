@@ -48,10 +48,14 @@ def test_sigmoid_and_decode_against_float64_libm(cuda):
     scores, boxes = out["scores"].cpu().numpy(), out["boxes"].cpu().numpy()
     # (1) scores = sigmoid(logits)
     want = 1.0 / (1.0 + np.exp(-logits.astype(np.float64)))
-    u = _ulps(scores, want)
     assert np.isfinite(scores).all() and scores.min() >= 0.0 and scores.max() <= 1.0
+    body = np.abs(logits) <= 87.0          # e^-x stays a normal float32 here
+    u = _ulps(scores[body], want[body])
     assert u.max() <= 3.0, u.max()
     assert (u <= 1.0).mean() > 0.95
+    # beyond: 1 + e^-x overflows to +inf and the quotient is 0 where the true value is a denormal (< 1.2e-38); the upper
+    # tail is exactly 1
+    assert np.abs(scores[~body].astype(np.float64) - want[~body]).max() < 1.2e-38
     # (2) boxes: [xy - wh/2, xy + wh/2] / [H, W, H, W] with xy = t_xy * a_wh + a_xy, wh = exp(t_wh) * a_wh
     # (postprocessing_ops.py:87-117); error measured against the scale of the box (its largest |coordinate term|)
     t, a = enc.astype(np.float64), an.astype(np.float64)[None]
