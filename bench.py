@@ -148,7 +148,7 @@ def run_train(args, dev, rank, world, params=None):
     torch.cuda.synchronize()
     # HIP events bracket the conv launches of every 5th timed step (and the last one): two event records
     # per launch on ~90 launches cost ~1.5 ms, which would otherwise inflate every timed step
-    prof, hbm, wprof = [], [], []
+    prof, hbm, wprof, lprof = [], [], [], []
     sampled = 0
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -156,9 +156,10 @@ def run_train(args, dev, rank, world, params=None):
         eng.conv_profile = prof if sample else None
         eng.hbm_profile = hbm if sample else None
         eng.wgrad_profile = wprof if sample else None
+        eng.layer_profile = lprof if sample else None
         sampled += int(sample)
         out = step()
-    eng.conv_profile = eng.hbm_profile = eng.wgrad_profile = None
+    eng.conv_profile = eng.hbm_profile = eng.wgrad_profile = eng.layer_profile = None
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -222,18 +223,54 @@ def run_train(args, dev, rank, world, params=None):
                                 "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1) if v[0] else 0.0,
                                 "frac": round(v[1] / (v[0] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if v[0] else 0.0}
                             for k, v in sorted(by.items())}}
+    def layer_table(events, events_excl):
+        """`roofline.layers`: one row per implicit-GEMM launch of the training step — forward, data
+        gradient, weight gradient — from the same HIP-event samples: arithmetic intensity AI = algorithmic FLOPs /
+        algorithmic bytes decides the roof (MFMA when AI >= peak FLOP/s / peak B/s = 312 FLOP/B, else HBM), `achieved` /
+        `frac` are against THAT roof, in the timed two-stream steps and (`*_exclusive`) in the one-stream step."""
+        ridge = PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+        rows, order = {}, []
+        for tag, evs in (("in_step", events), ("exclusive", events_excl or [])):
+            for e0, e1, name, fl, by, kern in evs:
+                if name not in rows:
+                    rows[name] = {"layer": name, "kernel": kern, "gflop": fl / 1e9, "MB": by / 1e6, "ms": {}, "n": {}}
+                    order.append(name)
+                r = rows[name]
+                r["ms"][tag] = r["ms"].get(tag, 0.0) + e0.elapsed_time(e1)
+                r["n"][tag] = r["n"].get(tag, 0) + 1
+        out = []
+        for name in order:
+            r = rows[name]
+            ai = r["gflop"] * 1e9 / max(r["MB"] * 1e6, 1.0)
+            bound = "mfma" if ai >= ridge else "hbm"
+            row = {"layer": name, "kernel": r["kernel"], "AI": round(ai, 1), "bound": bound}
+            for tag, sfx in (("in_step", ""), ("exclusive", "_exclusive")):
+                if tag not in r["ms"] or not r["ms"][tag]:
+                    continue
+                us = r["ms"][tag] * 1e3 / r["n"][tag]
+                if bound == "mfma":
+                    ach, peak = r["gflop"] * 1e9 / (us * 1e-6) / 1e12, PEAK_BF16_TFLOPS
+                else:
+                    ach, peak = r["MB"] * 1e6 / (us * 1e-6) / 1e9, PEAK_HBM_GBS
+                row["us" + sfx] = round(us, 1)
+                row["achieved" + sfx] = round(ach, 1)
+                row["frac" + sfx] = round(ach / peak, 4)
+            row["unit"] = "TFLOP/s" if bound == "mfma" else "GB/s"
+            out.append(row)
+        return out
     wgrad_roof = wgrad_entry(wprof, sampled)
     if wgrad_roof:
         wgrad_roof["concurrency"] = ("second stream: these launches run beside the data-gradient chain of the main stream "
                                      "in the timed steps" if getattr(eng, "side_stream_on", False) else "one stream")
     exclusive = None
+    lprof1 = None
     if getattr(eng, "side_stream_on", False) and dom_name in by_kernel and not args.no_exclusive:
         eng.side_stream_on = False
         eng.set_wgrad_cap(False)     # the two-stream step caps the weight-gradient grids to leave CUs to the main stream
-        prof1, wprof1, hbm1 = [], [], []
-        eng.conv_profile, eng.wgrad_profile, eng.hbm_profile = prof1, wprof1, hbm1
+        prof1, wprof1, hbm1, lprof1 = [], [], [], []
+        eng.conv_profile, eng.wgrad_profile, eng.hbm_profile, eng.layer_profile = prof1, wprof1, hbm1, lprof1
         step()
-        eng.conv_profile = eng.wgrad_profile = eng.hbm_profile = None
+        eng.conv_profile = eng.wgrad_profile = eng.hbm_profile = eng.layer_profile = None
         torch.cuda.synchronize()
         eng.side_stream_on = True
         eng.set_wgrad_cap(True)
@@ -274,6 +311,7 @@ def run_train(args, dev, rank, world, params=None):
                                         if getattr(eng, "side_stream_on", False) else "one stream"),
                         "exclusive": exclusive,
                         "wgrad": wgrad_roof,
+                        "layers": layer_table(lprof, lprof1),
                         "hbm_kernels": {"bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s", "kernels": hbm_kernels,
                                         "stream_reference": stream_reference(dev)},
                         "other_conv_kernels": {k: {"ms_per_step": round(v[0] / max(sampled, 1), 3),

@@ -132,6 +132,9 @@ class TrainEngine:
         self.step_count = 0
         self.conv_profile = None
         self.wgrad_profile = None   # bench.py: list that collects (event0, event1, algorithmic FLOPs, kernel) per wgrad launch
+        # bench.py `roofline.layers`: list that collects (event0, event1, launch name, algorithmic FLOPs, algorithmic bytes,
+        # kernel) for EVERY implicit-GEMM launch of the step — forward, data gradient, weight gradient
+        self.layer_profile = None
         self.fuse_bn_stats = os.environ.get("RNET_FUSE_BN_STATS", "1") != "0"   # conv epilogue writes BN partial sums
         # data-gradient epilogue writes stage 1 of the BatchNorm backward reduction of the layer it produces dz for
         self.fuse_bn_bwd = os.environ.get("RNET_FUSE_BN_BWD", "1") != "0"
@@ -618,15 +621,22 @@ class TrainEngine:
     def _launch_conv(self, p, st, what):
         """All implicit-GEMM launches (forward and dgrad) go through here so bench.py can bracket the
         dominant kernel variant with HIP events on the launch stream."""
-        prof = self.conv_profile
-        if prof is not None:
+        prof, lprof = self.conv_profile, self.layer_profile
+        if prof is not None or lprof is not None:
             flops, byts, variant = self._conv_meta(p)
-            if variant:
+            if variant or lprof is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 _C.check(self.lib.rn_conv2d_nhwc_fwd(ctypes.byref(p), st), what)
                 e1.record()
-                prof.append((e0, e1, flops, byts, variant))
+                if prof is not None and variant:
+                    prof.append((e0, e1, flops, byts, variant))
+                if lprof is not None:
+                    if getattr(self, "_launch_names", None) is None or len(self._launch_names) != len(self.conv_launches):
+                        self._launch_names = {id(q): n for n, q in self.conv_launches}
+                    kid = self.lib.rn_conv_kernel_id(ctypes.byref(p))
+                    kname = variant or ("conv_fwd_kernel (128-row tiles)" if kid == 0 else f"kernel id {kid}")
+                    lprof.append((e0, e1, self._launch_names.get(id(p), what), flops, byts, kname))
                 return
         _C.check(self.lib.rn_conv2d_nhwc_fwd(ctypes.byref(p), st), what)
 
@@ -1168,6 +1178,15 @@ class TrainEngine:
         for p, cap in self._wgrad_capped:
             p.opts.wgrad_target_blocks = cap if on else 0
 
+    @staticmethod
+    def _wgrad_bytes(p):
+        """algorithmic HBM bytes of a weight-gradient launch: x and dy read once, dW (f32) written once"""
+        b = 0
+        for i in range(p.num_segments):
+            s = p.seg[i]
+            b += 2 * s.N * s.H * s.W * s.Cin + 2 * s.N * s.Ho * s.Wo * s.Cout
+        return b + 4 * p.R * p.S * p.seg[0].Cin * p.seg[0].Cout
+
     def _group_wgrad_steps(self):
         """Weight-gradient launches of layers with IDENTICAL geometry become one rn_conv2d_nhwc_wgrad_group call (the
         eight head-tower layers, the 3x3 layers of a ResNet stage: up to 8 per call), issued where the LAST of them
@@ -1216,9 +1235,13 @@ class TrainEngine:
                 a = (arr, len(grp), dws, 0.0, ws.data_ptr(), ws.numel())
                 wname = f"wgrad_halo_kernel ({len(grp)} layers per launch) + wgrad_reduce_kernel"
 
-                def wgrad_group(st, a=a, flw=flw, wname=wname):
-                    prof = self.wgrad_profile
-                    if prof is None:
+                byw = sum(self._wgrad_bytes(it[0]) for it in items)
+                lname = "wgrad:" + "+".join(n[len("wgrad:"):] for n, q in self.wgrad_launches
+                                            if any(q is it[0] for it in items))
+
+                def wgrad_group(st, a=a, flw=flw, wname=wname, byw=byw, lname=lname):
+                    prof, lprof = self.wgrad_profile, self.layer_profile
+                    if prof is None and lprof is None:
                         _C.check(lib.rn_conv2d_nhwc_wgrad_group(*a, st), "rn_conv2d_nhwc_wgrad_group")
                         return
                     cur = torch.cuda.current_stream(self.dev)
@@ -1226,7 +1249,10 @@ class TrainEngine:
                     e0.record(cur)
                     _C.check(lib.rn_conv2d_nhwc_wgrad_group(*a, st), "rn_conv2d_nhwc_wgrad_group")
                     e1.record(cur)
-                    prof.append((e0, e1, flw, wname))
+                    if prof is not None:
+                        prof.append((e0, e1, flw, wname))
+                    if lprof is not None:
+                        lprof.append((e0, e1, lname, flw, byw, wname))
                 self._keep += [arr, dws, ws]
                 old_ws = {id(it[2]) for it in items}
                 self._keep = [k for k in self._keep if id(k) not in old_ws]      # the per-layer workspaces are not needed
@@ -1325,9 +1351,11 @@ class TrainEngine:
             wname = ("wgrad_kernel (128x128 per-tap tiles)", "wgrad_big_kernel (256x256 per-tap tiles)",
                      "wgrad_halo_kernel")[max(lib.rn_wgrad_kernel_id(ctypes.byref(p)), 0)] + " + wgrad_reduce_kernel"
 
-            def wgrad(st, a=a, flw=flw, wname=wname):
-                prof = self.wgrad_profile
-                if prof is None:
+            byw = self._wgrad_bytes(p)
+
+            def wgrad(st, a=a, flw=flw, wname=wname, byw=byw, lname="wgrad:" + cname):
+                prof, lprof = self.wgrad_profile, self.layer_profile
+                if prof is None and lprof is None:
                     _C.check(lib.rn_conv2d_nhwc_wgrad(*a, st), "rn_conv2d_nhwc_wgrad")
                     return
                 # bench.py: HIP events on the stream the launch goes to (the side stream in the two-stream backward)
@@ -1336,7 +1364,10 @@ class TrainEngine:
                 e0.record(cur)
                 _C.check(lib.rn_conv2d_nhwc_wgrad(*a, st), "rn_conv2d_nhwc_wgrad")
                 e1.record(cur)
-                prof.append((e0, e1, flw, wname))
+                if prof is not None:
+                    prof.append((e0, e1, flw, wname))
+                if lprof is not None:
+                    lprof.append((e0, e1, lname, flw, byw, wname))
             step = self._side(wgrad, writes=[c.get("kvar", cname + "/kernel")])
             step.wgrad_item = (p, dw, ws, flw)      # _group_wgrad_steps may merge it with same-shape layers
             self.bwd_steps.append(step)

