@@ -639,6 +639,34 @@ int rn_stem_conv_bn_relu_pool(const void* x, const void* w_packed, const float* 
                               int N, int Hp, int Wp, int Hs, int Ws, int R, int Cout, int act, int pool_k,
                               int pool_stride, int pool_pad_top, int pool_pad_left, int Po, int Qo, void* stream);
 
+/* a5, cross-layer: ONE launch per bottleneck block of ResNet stage 1 with every BatchNorm in inference form (`resnet_initial`
+ * frozen, builder.py:28-29 — the layers executor.py:154-176 runs with training=False; every layer when serving):
+ * retinanet/model/backbone/resnet.py:194-248 `bottleneck_block` with filters = 64, strides = 1 (block_group1, :324-331)
+ *     a   = relu(BN(conv1x1 Cx -> 64 (x)));  b = relu(BN(conv3x3 64 -> 64 (a)))  (zero padding 1);
+ *     out = relu(BN(conv1x1 64 -> 256 (b)) + shortcut),  shortcut = x (Cx = 256) | BN(conv1x1 64 -> 256 (x)) (Cx = 64: the
+ *     projection shortcut of the group's first block, :220-228).
+ * a and b never go to HBM (rn_bneck.hip).  Rounding points = those of three (four) rn_conv2d_nhwc_fwd launches (Conv2D output
+ * -> bf16, BatchNorm -> bf16, + shortcut, relu -> bf16); the K orders differ, so results agree to fp32 summation order.
+ *   x: bf16 [N,H,W,Cx] contiguous; y: bf16 [N,H,W,256]; W % 32 == 0 and W <= 160 (rn_bottleneck64_supported; other shapes:
+ *   RN_EINVAL, callers keep the per-layer launches);
+ *   w_packed: rn_bottleneck64_pack of the layers' f32 HWIO kernels (Keras layout) = MFMA fragments [wa | wb | wo | wsc],
+ *   rn_bottleneck64_packed_bytes(Cx) bytes, 16-byte aligned; wsc_hwio = NULL iff Cx == 256;
+ *   affine: f32 [a_scale 64][a_shift 64][b_scale 64][b_shift 64][o_scale 256][o_shift 256] (+ [sc_scale 256][sc_shift 256]
+ *   when Cx == 64): BatchNorm folded to scale = gamma / sqrt(var + eps), shift = beta - mean * scale. */
+typedef struct {
+  const void* x;
+  void* y;
+  const void* w_packed;
+  const float* affine;
+  int32_t N, H, W, Cx;
+  rn_launch_opts opts;   /* reserved_cus / max_workgroups bound the grid (one workgroup per compute unit) */
+} rn_bottleneck64_problem;
+int rn_bottleneck64_supported(int N, int H, int W, int Cx);   /* 1 | 0, host only */
+size_t rn_bottleneck64_packed_bytes(int Cx);
+int rn_bottleneck64_pack(const float* wa_hwio, const float* wb_hwio, const float* wo_hwio, const float* wsc_hwio, int Cx,
+                         void* packed, void* stream);
+int rn_bottleneck64_fwd(const rn_bottleneck64_problem* problem, void* stream);
+
 /* K7 (a6)  FPN top-down path, FeatureFusion mode 'sum' + NearestUpsampling2D + activation
  * (fpn.py:93-98, feature_fusion.py:41-56, nearest_upsampling.py:19-21):
  * for l = num_levels-1 .. 1: out[l-1] = act(in[l-1] + up2(out[l])), out[top] = in[top] (not

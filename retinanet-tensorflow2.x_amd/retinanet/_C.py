@@ -61,6 +61,11 @@ class LaunchOpts(Structure):   # rn_launch_opts: per-call options of the MFMA ke
         return o
 
 
+class Bottleneck64Problem(Structure):   # rn_bottleneck64_problem
+    _fields_ = [("x", c_void_p), ("y", c_void_p), ("w_packed", c_void_p), ("affine", c_void_p), ("N", c_int32), ("H", c_int32),
+                ("W", c_int32), ("Cx", c_int32), ("opts", LaunchOpts)]
+
+
 class ConvSegment(Structure):
     _fields_ = [("x", c_void_p), ("w", c_void_p), ("y", c_void_p), ("scale", c_void_p), ("shift", c_void_p),
                 ("residual", c_void_p), ("N", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32),
@@ -229,6 +234,10 @@ _SIGNATURES = {
                                   c_float, c_float, c_float, c_int, c_void_p, c_void_p]),
     "rn_prepare_image": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, POINTER(c_float),
                                  POINTER(c_float), c_float, c_void_p]),
+    "rn_bottleneck64_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "rn_bottleneck64_packed_bytes": (c_size_t, [c_int]),
+    "rn_bottleneck64_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "rn_bottleneck64_fwd": (c_int, [POINTER(Bottleneck64Problem), c_void_p]),
     "rn_stem_conv_bn_relu_pool": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 14 + [c_void_p]),
     "rn_maxpool2d_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                   c_int, c_int, c_void_p]),

@@ -128,6 +128,15 @@ class InferenceEngine:
         self._capture = bool(capture_graph)
         with torch.cuda.device(self.dev):
             self._alloc()
+            # ResNet stage-1 bottleneck blocks as ONE launch each (rn_bottleneck64_fwd, retinanet/model/bottleneck.py)
+            from .bottleneck import Bottleneck64, find_blocks
+            self.bneck, self._bneck_skip = {}, set()      # first op's output name -> fused block; outputs of fused ops
+            for blk in find_blocks(self.g):
+                fb = Bottleneck64(self.lib, self.g, blk, self.B, self.dev, self.h16, self.launch_opts, self.t[blk["x"]],
+                                  self.t[blk["name"]])
+                if fb.ok:
+                    self.bneck[blk["ops"][0]["out"]] = fb
+                    self._bneck_skip.update(o["out"] for o in blk["ops"])
             # split-K of the persistent conv kernels' last round: the launches of this engine run in order on one stream
             self.splitk_ws = _C.new_splitk_workspace(self.lib, self.dev, default_on=True)
             self.load_variables(variables)
@@ -202,6 +211,8 @@ class InferenceEngine:
                 continue
             if op["op"] not in ("conv", "stem"):
                 continue
+            if op["out"] in self._bneck_skip:      # part of a fused bottleneck block: packed below
+                continue
             cname = op["conv"]
             c = self.g.convs[cname]
             w = variables[c.get("kvar", cname + "/kernel")].to(self.dev, torch.float32).contiguous()
@@ -249,6 +260,8 @@ class InferenceEngine:
                                                          _C.ptr(buf), st), "rn_pack_conv_weight")
                 self.packed[cname] = buf
             self._fold(op["out"], variables, op.get("bn"), variables.get(cname + "/bias"))
+        for fb in self.bneck.values():
+            fb.load(variables, self.eps)
 
     def _pixel_pair(self, op):
         """True when conv `op` runs in pixel-pair form (pixel_pair_ok): decided once per op"""
@@ -481,6 +494,11 @@ class InferenceEngine:
                     _C.check(lib.rn_conv2d_nhwc_fwd(pref, st), "rn_conv2d_nhwc_fwd[stem]")
                 self.steps.append((stem, "conv:stem"))
                 self.step_io["conv:stem"] = ({":stem_in"}, {op["out"]})
+            elif kind == "conv" and op["out"] in self._bneck_skip:
+                fb = self.bneck.get(op["out"])
+                if fb is not None:                 # the block's first op in graph order carries the launch
+                    self.steps.append((fb.launch, fb.name))
+                    self.step_io[fb.name] = ({fb.blk["x"]}, {fb.blk["name"]})
             elif kind == "conv":
                 grp = op.get("group")
                 if grp is None:

@@ -568,6 +568,24 @@ class TrainEngine:
             if op["op"] == "conv" and self._pixel_pair(op):     # per-channel vectors once per pixel of the pair
                 scale, shift, bias = [None if t is None else t.repeat(2).contiguous() for t in (scale, shift, bias)]
             self.fold[op["out"]] = (scale, shift, bias)
+        # frozen ResNet stage-1 bottleneck blocks as ONE launch each (retinanet/model/bottleneck.py): every layer of the block
+        # frozen with its BatchNorm, nothing below it needs a gradient
+        if getattr(self, "bneck", None) is None:
+            from .bottleneck import Bottleneck64, find_blocks
+            self.bneck, self._bneck_skip = {}, set()
+            mine = {o["out"]: o for o in self.ops}
+            for blk in find_blocks(self.g):
+                ops_ = [mine.get(o["out"]) for o in blk["ops"]]
+                if any(o is None or self._conv_trainable(o) or self._bn_trainable(o) or self.requires.get(o["out"])
+                       for o in ops_) or self.requires.get(blk["x"]):
+                    continue
+                fb = Bottleneck64(lib, self.g, blk, self.B, self.dev, self.h16, self.launch_opts, self.t[blk["x"]],
+                                  self.t[blk["name"]])
+                if fb.ok:
+                    self.bneck[blk["ops"][0]["out"]] = fb
+                    self._bneck_skip.update(o["out"] for o in blk["ops"])
+        for fb in self.bneck.values():
+            fb.load(v, self.eps)
         if old_fold is not None:
             # a refold after a restore: the launch descriptors hold the first buffers' addresses -> copy in place
             for k, buf in self.packed_frozen.items():
@@ -939,6 +957,20 @@ class TrainEngine:
                                                                          "rn_stem_conv_bn_relu_pool"))
                     else:
                         self.fwd_steps.append(lambda st, p=p: self._launch_conv(p, st, "stem"))
+            elif kind == "conv" and op["out"] in self._bneck_skip:
+                fb = self.bneck.get(op["out"])
+                if fb is not None:                 # the block's first op in graph order carries the launch
+                    def run_block(st, fb=fb):
+                        lprof = self.layer_profile
+                        if lprof is None:
+                            fb.launch(st)
+                            return
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        fb.launch(st)
+                        e1.record()
+                        lprof.append((e0, e1, "fwd:" + fb.name, fb.flops, fb.bytes, "bneck64_kernel (one launch per block)"))
+                    self.fwd_steps.append(run_block)
             elif kind == "conv":
                 grp = op.get("group")
                 if grp is not None:

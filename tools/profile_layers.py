@@ -46,6 +46,8 @@ def main():
     for (i, name), ms in sorted(tot.items()):
         ms /= a.iters
         fl = conv_flops(eng, name) if name.startswith("conv:") and name != "conv:stem" else 0
+        if name.startswith("bneck:"):
+            fl = next(fb.flops for fb in eng.bneck.values() if fb.name == name)
         if name == "conv:stem":
             fl = 2 * a.batch * (a.size // 2) ** 2 * 147 * 64
         total_ms += ms
