@@ -573,7 +573,7 @@ class TrainEngine:
         if getattr(self, "bneck", None) is None:
             from .bottleneck import Bottleneck64, find_blocks
             self.bneck, self._bneck_skip = {}, set()
-            mine = {o["out"]: o for o in self.ops}
+            mine = {o["out"]: o for o in self.ops if "out" in o}
             for blk in find_blocks(self.g):
                 ops_ = [mine.get(o["out"]) for o in blk["ops"]]
                 if any(o is None or self._conv_trainable(o) or self._bn_trainable(o) or self.requires.get(o["out"])
