@@ -92,6 +92,20 @@ def global_normalizer(num_positives_sum, world, group=None):
     return n
 
 
+def syncbn_merge(sums, world, all_reduce, c2_local=None):
+    """C3 (+ C2): the SyncBatchNorm statistics message of one BatchNorm group (model/utils.py:10-12: TF's
+    SyncBatchNormalization all-reduces the per-replica sums).  `sums` = f32 [sum x | sum x^2 per channel of every layer of the
+    group ..., one spare slot]: SUM-all-reduced in place through `all_reduce(tensor)`; the caller finalises with count x
+    `world`.  When `c2_local` (this replica's sum(num-positives) + 1, f32[1]) is given it rides in the spare slot of this
+    message — the step's first — instead of being a collective of its own (retinanet_loss.py:46-49), and the function
+    returns the loss normaliser all_reduce_sum(...) / replicas as a view of the message; otherwise None.
+    One function for TrainEngine._bn_stats_finalize and the world-size-2 CPU test."""
+    if c2_local is not None:
+        sums[-1:].copy_(c2_local)
+    all_reduce(sums)
+    return sums[-1:] / float(world) if c2_local is not None else None
+
+
 def all_reduce_sum_bucketed(flat, world, group=None, bucket_bytes=64 << 20):
     """In-place SUM all-reduce of a flat tensor in contiguous buckets (async, then wait)."""
     if world <= 1:

@@ -819,16 +819,14 @@ class TrainEngine:
             return
         _C.check(lib.rn_bn_stats(prb, _C.ptr(ws), ws.numel(), st), "rn_bn_stats")
         if self.sync_bn:
-            import torch.distributed as dist
+            from retinanet.distribute import syncbn_merge
+            # C2 (the loss normaliser's scalar all-reduce, retinanet_loss.py:46-49) rides in the spare slot of the step's
+            # FIRST SyncBN message instead of being a collective of its own
             fold = self._c2_local is not None and not self._c2_sent
-            if fold:
-                # C2 (the loss normaliser's scalar all-reduce, retinanet_loss.py:46-49) rides in the spare slot of
-                # the step's FIRST SyncBN message instead of being a collective of its own
-                sums[-1:].copy_(self._c2_local)
-            self._allreduce_small(sums)
+            norm = syncbn_merge(sums, self.world, self._allreduce_small, self._c2_local if fold else None)
             if fold:
                 self._c2_sent = True
-                self.c2_normalizer = sums[-1:] / float(self.world)
+                self.c2_normalizer = norm
         _C.check(lib.rn_bn_finalize(prb, st), "rn_bn_finalize")
 
     def _bn_problem(self, ops, conv_problem=None):

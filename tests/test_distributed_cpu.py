@@ -32,17 +32,21 @@ def _worker(rank, world, port, out):
     # C2: normaliser
     npos = torch.tensor(float(10 + 5 * rank))
     norm = global_normalizer(npos, world)
-    # C3: SyncBN: all-reduce [sum, sumsq] of this rank's activations, then finalise with count*world
+    # C3 (+ C2 folded into the step's first message): the engine's own merge helper (TrainEngine._bn_stats_finalize calls
+    # the same function) on this rank's [sum | sumsq | spare slot], then the finalisation with count * world
+    from retinanet.distribute import syncbn_merge
     x = torch.randn((64, 8), generator=g) * (1 + rank) + rank
-    sums = torch.stack([x.sum(0), (x * x).sum(0)])
-    dist.all_reduce(sums)
+    sums = torch.cat([x.sum(0), (x * x).sum(0), torch.zeros(1)])
+    norm_folded = syncbn_merge(sums, world, dist.all_reduce, c2_local=(npos + 1.0).reshape(1))
+    assert syncbn_merge(sums.clone(), world, dist.all_reduce) is None          # later messages carry no normaliser
     n = x.shape[0] * world
-    mean = sums[0] / n
-    var = sums[1] / n - mean * mean
+    mean = sums[0:8] / n
+    var = sums[8:16] / n - mean * mean
     st = Strategy("multi_gpu", torch.device("cpu"), rank, world)
     gathered = st.gather(x)
     metric = st.reduce_mean(torch.tensor([float(rank)]))
-    out[rank] = dict(mine=mine.numpy(), reduced=grads.numpy(), norm=norm.item(), mean=mean.numpy(), var=var.numpy(),
+    out[rank] = dict(mine=mine.numpy(), reduced=grads.numpy(), norm=norm.item(), norm_folded=norm_folded.item(),
+                     mean=mean.numpy(), var=var.numpy(),
                      x=x.numpy(), gathered=gathered.numpy(), metric=metric.item())
     dist.destroy_process_group()
 
@@ -57,6 +61,7 @@ def test_data_parallel_host_logic_world2():
     for i in range(world):
         np.testing.assert_allclose(r[i]["reduced"], total, rtol=1e-6, atol=1e-6)
         assert r[i]["norm"] == ((10 + 1) + (15 + 1)) / 2      # retinanet_loss.py:38-49
+        assert r[i]["norm_folded"] == r[i]["norm"]            # the same scalar when it rides in the first SyncBN message
         assert r[i]["metric"] == 0.5
     allx = np.concatenate([r[0]["x"], r[1]["x"]])
     np.testing.assert_allclose(r[0]["mean"], allx.mean(0), rtol=1e-5, atol=1e-6)

@@ -101,7 +101,13 @@ def test_forward_at_baseline_sizes(cuda, size, B):
     assert ids["conv:tower0"] == 3 and ids["conv:tower3"] == 3 and ids["conv:pred_class"] == 3, ids
     assert ids["conv:pred_box"] == 3, ids                      # two weight planes as GEMM columns on the 512 x 128 tiles
     assert ids["conv:fpn_out"] == 3, ids                       # halo patch: the 80x80 / 128x128 levels fit its capacity
-    assert ids["conv:g1b0_out"] == 1 and ids["conv:g2b1_out"] == 1, ids    # residual 1x1 layers: conv_big_kernel
+    assert ids["conv:g2b1_out"] == 1, ids                      # residual 1x1 layers: conv_big_kernel
+    eng = model.inference_engine(B)
+    fused = [n for _, n in eng.steps if n.startswith("bneck:")]
+    if size == 640:    # stage 1 (160 x 160) as one launch per bottleneck block (rn_bottleneck64_fwd); 1024^2 is wider than its LDS ring
+        assert fused == ["bneck:g1b0_out", "bneck:g1b1_out", "bneck:g1b2_out"] and "conv:g1b0_out" not in ids, (fused, ids)
+    else:
+        assert not fused and ids["conv:g1b0_out"] == 1, (fused, ids)
     if size == 1024:
         # stage 1 at 1024^2: 4 x 256 x 256 = 262 144 pixels per launch < 2^22 (rn_fdiv's validity bound)
         assert B * (size // 4) ** 2 < (1 << 22)
