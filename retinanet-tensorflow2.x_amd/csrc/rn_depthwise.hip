@@ -254,6 +254,7 @@ struct DwgSegDev {
 };
 struct DwgArgs {
   int stride, pt, pl, nseg, C, rows_per_chunk, total_chunks;
+  int slab_groups;   // channel groups (CPT channels each) per workgroup: min(C / CPT, 64)
   float* partial;
   DwgSegDev seg[RN_CONV_MAX_SEGMENTS];
 };
@@ -269,6 +270,24 @@ __device__ __forceinline__ void dwg_load_p(const uint16_t* p, dw_f2* v) {
     v[3] = dw_f2{rn_lo16(u.w), rn_hi16(u.w)};
   } else {
     const uint2 u = *(const uint2*)p;
+    v[0] = dw_f2{rn_lo16(u.x), rn_hi16(u.x)};
+    v[1] = dw_f2{rn_lo16(u.y), rn_hi16(u.y)};
+  }
+}
+// the same through a buffer descriptor: an offset past the descriptor's size (0x80000000) returns zeros — the hardware's
+// bounds check instead of a branch around the load
+typedef unsigned dwg_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned dwg_u32x2 __attribute__((ext_vector_type(2)));
+template <int CPT>
+__device__ __forceinline__ void dwg_bload(__amdgpu_buffer_rsrc_t rs, unsigned off, dw_f2* v) {
+  if (CPT == 8) {
+    const dwg_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
+    v[0] = dw_f2{rn_lo16(u.x), rn_hi16(u.x)};
+    v[1] = dw_f2{rn_lo16(u.y), rn_hi16(u.y)};
+    v[2] = dw_f2{rn_lo16(u.z), rn_hi16(u.z)};
+    v[3] = dw_f2{rn_lo16(u.w), rn_hi16(u.w)};
+  } else {
+    const dwg_u32x2 u = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 0, 0);
     v[0] = dw_f2{rn_lo16(u.x), rn_hi16(u.x)};
     v[1] = dw_f2{rn_lo16(u.y), rn_hi16(u.y)};
   }
@@ -292,18 +311,29 @@ __device__ __forceinline__ void dwg_load(const uint16_t* p, float* v) {
 // Work item = one strip of T = 4 consecutive output pixels of an image row; a chunk = rows_per_chunk items.
 // Per filter row the strip's (T-1)*S + K input vectors are loaded once and feed every (pixel, tap) pair that
 // touches them (the first version re-read x for each of the K*K taps: L2-bandwidth bound).
+//
+// Thread mapping (round 6).  A thread owns CPT consecutive channels — its K*K x CPT accumulators — and walks items; the
+// threads of a workgroup are (channel group cg, item lane rl).  Until round 5 a workgroup covered a fixed 64-channel slab
+// (8 groups x 32 item lanes): with EfficientNet's channel counts — 144, 288, 816, 1392: none a multiple of 64 — a pixel's
+// slab was a 128-byte piece at an odd offset of a 288-byte pixel (every piece straddles two cache lines, so the launch
+// fetched ~1.8 x its bytes) and the last slab ran with most of its channel lanes dead (144 = 64 + 64 + 16).  Now the
+// channel groups of a workgroup are min(C / CPT, 64) — the WHOLE pixel whenever it has at most 64 groups, so consecutive
+// lanes read consecutive bytes across pixel boundaries — and the 256 threads are cut into 256 / groups item lanes.
 template <int K, int CPT, int S>
 __global__ void __launch_bounds__(256) depthwise_wgrad_kernel(const DwgArgs a) {
-  constexpr int SLAB = 8 * CPT;   // channels per workgroup
   constexpr int T = 4;
   constexpr int WIN = (T - 1) * S + K;
   const int chunk = blockIdx.x, slab = blockIdx.y;
   int si = 0;
   while (si + 1 < a.nseg && chunk >= a.seg[si + 1].chunk_begin) ++si;
   const DwgSegDev& s = a.seg[si];
-  const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
-  const int c0 = slab * SLAB + cg * CPT;
-  const bool live = c0 < a.C;
+  const int CG = a.C / CPT;                                   // channel groups of a pixel
+  const int g0 = slab * a.slab_groups;                         // first group of this workgroup
+  const int SG = CG - g0 < a.slab_groups ? CG - g0 : a.slab_groups;   // its groups
+  const int RL = 256 / SG;                                     // item lanes
+  const int cg = threadIdx.x % SG, rl = threadIdx.x / SG;
+  const int c0 = (g0 + cg) * CPT;
+  const bool live = rl < RL;
   constexpr int CP2 = CPT / 2;
   dw_f2 acc[K * K][CP2];
 #pragma unroll
@@ -314,63 +344,75 @@ __global__ void __launch_bounds__(256) depthwise_wgrad_kernel(const DwgArgs a) {
   const int items = s.N * s.Ho * strips;           // s.P holds the item count of the segment
   const int i0 = (chunk - s.chunk_begin) * a.rows_per_chunk;
   const int i1 = i0 + a.rows_per_chunk < items ? i0 + a.rows_per_chunk : items;
+  // (tensors of at most 2 GB: checked by the host)
+  const __amdgpu_buffer_rsrc_t rs_x =
+      __builtin_amdgcn_make_buffer_rsrc((void*)s.x, 0, (int)((long long)s.N * s.H * s.W * a.C * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_dy =
+      __builtin_amdgcn_make_buffer_rsrc((void*)s.dy, 0, (int)((long long)s.N * s.Ho * s.Wo * a.C * 2), 0x00020000);
   if (live) {
-    for (int it = i0 + rl; it < i1; it += 32) {
+    for (int it = i0 + rl; it < i1; it += RL) {
       const int ox0 = (it % strips) * T;
       const int t2 = it / strips;
       const int oy = t2 % s.Ho;
       const int n = t2 / s.Ho;
+      // Every load of an item is UNCONDITIONAL: a buffer load whose offset is pushed out of range for a pixel outside the
+      // image, so the hardware returns zeros.  With the bounds tests as branches around the loads (until round 6) the
+      // compiler emitted `load; s_waitcnt vmcnt(0); branch` per load: 22 (K = 3) to 44 (K = 5) DEPENDENT L2 round trips
+      // per item, which is why these launches ran at 0.5 - 1.5 TB/s.
       dw_f2 g[T][CP2];
+      const unsigned dyoff = (unsigned)(((((long long)n * s.Ho + oy) * s.Wo + ox0) * a.C + c0) * 2);
 #pragma unroll
-      for (int tt = 0; tt < T; ++tt) {
-        if (ox0 + tt < s.Wo) {
-          dwg_load_p<CPT>(s.dy + (((long long)n * s.Ho + oy) * s.Wo + ox0 + tt) * a.C + c0, g[tt]);
-        } else {
-#pragma unroll
-          for (int q = 0; q < CP2; ++q) g[tt][q] = dw_f2{0.0f, 0.0f};
-        }
-      }
+      for (int tt = 0; tt < T; ++tt)
+        dwg_bload<CPT>(rs_dy, ox0 + tt < s.Wo ? dyoff + (unsigned)(tt * a.C * 2) : 0x80000000u, g[tt]);
       const int ix0 = ox0 * S - a.pl;
 #pragma unroll
       for (int r = 0; r < K; ++r) {
         const int iy = oy * S - a.pt + r;
-        if ((unsigned)iy >= (unsigned)s.H) continue;
-        const uint16_t* xrow = s.x + (((long long)n * s.H + iy) * s.W) * a.C + c0;
+        const bool rok = (unsigned)iy < (unsigned)s.H;
+        const unsigned xoff = (unsigned)(((((long long)n * s.H + iy) * s.W + ix0) * a.C + c0) * 2);   // (garbage when !rok: unused)
+        dw_f2 xv[WIN][CP2];
+#pragma unroll
+        for (int j = 0; j < WIN; ++j)
+          dwg_bload<CPT>(rs_x, rok && (unsigned)(ix0 + j) < (unsigned)s.W ? xoff + (unsigned)(j * a.C * 2) : 0x80000000u, xv[j]);
 #pragma unroll
         for (int j = 0; j < WIN; ++j) {
-          const int ix = ix0 + j;
-          dw_f2 xv[CP2];
-          if ((unsigned)ix < (unsigned)s.W) {
-            dwg_load_p<CPT>(xrow + (long long)ix * a.C, xv);
-          } else {
-#pragma unroll
-            for (int q = 0; q < CP2; ++q) xv[q] = dw_f2{0.0f, 0.0f};
-          }
 #pragma unroll
           for (int tt = 0; tt < T; ++tt) {
             const int ss = j - tt * S;     // compile-time after unrolling
             if (ss >= 0 && ss < K) {
 #pragma unroll
-              for (int q = 0; q < CP2; ++q) acc[r * K + ss][q] += g[tt][q] * xv[q];
+              for (int q = 0; q < CP2; ++q) acc[r * K + ss][q] += g[tt][q] * xv[j][q];
             }
           }
         }
       }
     }
   }
-  __shared__ float red[32][SLAB + 1];
+  // item lanes -> one partial row per tap.  K taps (one filter row) per round through red[tap][item lane][channel of the
+  // workgroup] (pitch SG * CPT + 1: bank spread): K rounds of two barriers where there were K * K, and the sums over the
+  // item lanes are spread over all 256 threads (tap, channel) instead of one thread per channel — with short chunks the
+  // old epilogue cost as much as the item loop.
+  constexpr int PLANE = 256 * CPT + 256;
+  __shared__ float red[K * PLANE];
+  const int pitch = SG * CPT + 1;
+  const int nch = SG * CPT;
   // fully unrolled: with a run-time tap index the accumulators are an indexed private array, i.e. they live in scratch
   // memory for the whole kernel (304 / 416 bytes per lane) and every accumulate goes through it
 #pragma unroll
-  for (int t = 0; t < K * K; ++t) {
+  for (int r = 0; r < K; ++r) {
+    if (live) {
 #pragma unroll
-    for (int q = 0; q < CPT; ++q) red[rl][cg * CPT + q] = acc[t][q >> 1][q & 1];
+      for (int ss = 0; ss < K; ++ss)
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) red[ss * PLANE + rl * pitch + cg * CPT + q] = acc[r * K + ss][q >> 1][q & 1];
+    }
     __syncthreads();
-    if (threadIdx.x < SLAB) {
+    for (int o = threadIdx.x; o < K * nch; o += 256) {
+      const int ss = o / nch, cl = o - ss * nch;
+      const float* col = red + ss * PLANE + cl;
       float sum = 0.0f;
-      for (int r = 0; r < 32; ++r) sum += red[r][threadIdx.x];
-      const int ch = slab * SLAB + threadIdx.x;
-      if (ch < a.C) a.partial[((long long)chunk * (K * K) + t) * a.C + ch] = sum;
+      for (int q = 0; q < RL; ++q) sum += col[q * pitch];
+      a.partial[((long long)chunk * (K * K) + r * K + ss) * a.C + g0 * CPT + cl] = sum;
     }
     __syncthreads();
   }
@@ -407,9 +449,16 @@ static int dwg_plan(const rn_dw_problem* p, DwgArgs& a) {
   for (int i = 0; i < p->num_segments; ++i) {
     const rn_dw_segment& s = p->seg[i];
     if (!s.x || !s.y || s.C != a.C) return -1;
+    if ((long long)s.N * s.H * s.W * s.C * 2 >= (1ll << 31)) return -1;   // the kernel addresses x / dy through 32-bit buffer offsets
     Ptot += (long long)s.N * s.Ho * ((s.Wo + 3) / 4);
   }
-  long long rows = rn_cdiv(Ptot, 512);          // ~512 chunks over the launch
+  // ~512 item chunks over the launch, as before (each chunk's workgroups write K*K*C partial sums and run the reduction
+  // epilogue: 2048 chunks measured 10 - 30 % slower than 512 although they fill the chip better)
+  const int cpt = p->k == 5 ? 4 : 8;             // channels per thread (25 taps x 8 channels would not fit the registers)
+  const int cg = a.C / cpt;
+  a.slab_groups = cg < 64 ? cg : 64;
+  const long long target = 512;
+  long long rows = rn_cdiv(Ptot, target);
   rows = rn_cdiv(rows, 32) * 32;
   if (rows < 32) rows = 32;
   a.rows_per_chunk = (int)rows;
@@ -444,7 +493,8 @@ extern "C" int rn_depthwise_conv2d_nhwc_wgrad(const rn_dw_problem* p, float* dw,
   }
   a.partial = (float*)workspace;
   hipStream_t st = (hipStream_t)stream;
-  const dim3 g8(a.total_chunks, (unsigned)rn_cdiv(a.C, 64)), g4(a.total_chunks, (unsigned)rn_cdiv(a.C, 32)), blk(256);
+  const int cg = a.C / (p->k == 5 ? 4 : 8);
+  const dim3 g8(a.total_chunks, (unsigned)rn_cdiv(cg, a.slab_groups)), g4 = g8, blk(256);
   switch (p->k * 10 + p->stride) {
     case 11: hipLaunchKernelGGL((depthwise_wgrad_kernel<1, 8, 1>), g8, blk, 0, st, a); break;
     case 12: hipLaunchKernelGGL((depthwise_wgrad_kernel<1, 8, 2>), g8, blk, 0, st, a); break;

@@ -98,7 +98,11 @@ def test_squeeze_excite(cuda, N, HW, C, se):
 
 
 @pytest.mark.parametrize("N,H,W,C,k,s", [(2, 16, 16, 144, 3, 1), (2, 20, 20, 96, 5, 2), (1, 9, 7, 64, 5, 1),
-                                         (2, 12, 12, 48, 3, 2), (1, 8, 8, 160, 1, 1)])
+                                         (2, 12, 12, 48, 3, 2), (1, 8, 8, 160, 1, 1),
+                                         # the weight gradient's workgroups cover min(C / channels-per-thread, 64) channel
+                                         # groups: one group, a whole odd-sized pixel, several slabs with a short last one
+                                         (1, 6, 6, 8, 3, 1), (2, 14, 14, 40, 3, 1), (1, 10, 10, 816, 5, 1),
+                                         (1, 6, 6, 1392, 5, 2), (1, 6, 6, 2304, 3, 1), (1, 8, 8, 288, 3, 2)])
 def test_depthwise_backward(cuda, N, H, W, C, k, s):
     """dgrad = the forward kernel on (zero-upsampled) dy with the tap-reversed filter; wgrad = the two-stage
     reduction kernel; both against torch autograd on the same bf16-rounded operands."""
