@@ -14,7 +14,7 @@ void rn_set_error(const char* fmt, ...) {
 
 extern "C" const char* rn_last_error(void) { return g_rn_err; }
 
-extern "C" int rn_abi_version(void) { return 7; }
+extern "C" int rn_abi_version(void) { return 8; }
 
 // 0: bfloat16 storage (librnet_hip.so), 1: IEEE half (librnet_hip_f16.so, built with -DRN_F16)
 extern "C" int rn_storage_dtype(void) {

@@ -20,7 +20,7 @@ RN_DT_F32, RN_DT_BF16 = 0, 1
 RN_OK, RN_EINVAL, RN_ENOMEM, RN_EHIP, RN_ECOMM, RN_EUNSUPPORTED = 0, -1, -2, -3, -4, -5   # rn_status
 RN_ACT_NONE, RN_ACT_RELU, RN_ACT_RELU6, RN_ACT_SWISH = 0, 1, 2, 3
 RN_CONV_MAX_SEGMENTS = 10
-ABI_VERSION = 7
+ABI_VERSION = 8
 # f32 kernels of the dtype=float32 prediction convs (detection_head.py:80-88) as split-bf16 planes (rn_conv_segment.w_terms)
 PRED_W_TERMS = int(os.environ.get("RNET_PRED_W_TERMS", "2"))
 ACT_IDS = {None: RN_ACT_NONE, "none": RN_ACT_NONE, "relu": RN_ACT_RELU, "relu6": RN_ACT_RELU6,
