@@ -125,3 +125,21 @@ def test_pixel_pair_kernel_is_the_same_convolution():
         x2 = x.reshape(N, H, W // 2, 2 * C)
         got = F.conv2d(x2.permute(0, 3, 1, 2), w2.permute(3, 2, 0, 1), padding=1).permute(0, 2, 3, 1).reshape(N, H, W, C)
         torch.testing.assert_close(got, want, rtol=1e-12, atol=1e-12)
+
+
+def test_bottleneck_blocks_are_found_structurally(monkeypatch):
+    """retinanet/model/bottleneck.py::find_blocks: the three 64-wide stride-1 bottleneck blocks of ResNet-50's first group
+    (resnet.py:194-248, :324-331) — the projection block with Cx = 64, two identity blocks with Cx = 256 — and nothing
+    else: not the 128-wide stages, no block of EfficientNet; RNET_FUSE_BOTTLENECK=0 switches the recognition off"""
+    from retinanet.cfg import default_params, efficientnet_params
+    from retinanet.model.bottleneck import find_blocks
+    from retinanet.model.graph import build_retinanet_graph
+    g = build_retinanet_graph(default_params(input_size=640))
+    blocks = find_blocks(g)
+    assert [b["name"] for b in blocks] == ["g1b0_out", "g1b1_out", "g1b2_out"]
+    assert [b["Cx"] for b in blocks] == [64, 256, 256]
+    assert [o["out"] for o in blocks[0]["ops"]] == ["g1b0_sc", "g1b0_a", "g1b0_b", "g1b0_out"]
+    assert blocks[0]["sc"] is not None and blocks[1]["sc"] is None and blocks[1]["x"] == "g1b0_out"
+    assert find_blocks(build_retinanet_graph(efficientnet_params("efficientnet-b3", input_size=640))) == []
+    monkeypatch.setenv("RNET_FUSE_BOTTLENECK", "0")
+    assert find_blocks(g) == []

@@ -158,6 +158,7 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
                "rn_bn_segment": (_C.BnSegment, ["sample_scale", "ext_chunks", "P"]),
                "rn_bn_problem": (_C.BnProblem, ["seg", "count_scale"]),
                "rn_dgrad_pack": (_C.DgradPack, ["Cout_pad"]),
+               "rn_bottleneck64_problem": (_C.Bottleneck64Problem, ["w_packed", "affine", "N", "Cx", "opts"]),
                "rn_example_info": (_C.ExampleInfo, ["n_classes"])}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "rnet_hip.h"', "int main(void) {"]
     for name, (_, fields) in structs.items():
