@@ -15,8 +15,8 @@
 // the workgroup walks its row segment top to bottom.  Per row and wave three chained MFMA GEMMs (v_mfma_f32_32x32x16,
 // weights = A operand, the wave's 32 pixels = B operand, so a lane's accumulators are channels of ONE pixel):
 //   A  a(row r + 2)   = Wa . x          x fragments straight from global memory: lane (pixel n, half h) loads the 16 bytes
-//                                       [16 s + 8 h, + 8) of its pixel for K step s — no LDS staging, the loads of the
-//                                       next row are in flight during stage B of the current one;
+//                                       [16 s + 8 h, + 8) of its pixel for K step s — no LDS staging; producer waves run
+//                                       this stage one row ahead of the consumers (below), four K chunks in flight;
 //                                       result -> bf16 -> BN -> bf16 -> relu -> the `a` ring in LDS (SLOTS rows of W + 2
 //                                       pixels x 128 B, 16-byte units XOR-swizzled by the pixel index: conflict-free
 //                                       ds_write_b128 / ds_read_b128), one zero pixel on either side, zero rows outside the image
@@ -103,7 +103,7 @@ __device__ __forceinline__ uint4 bneck_bn_relu(const f32x16_t& acc, int k, const
 }
 
 // DBG: timing probes, compiled into probe builds only (-DRN_PROBES, rn_launch_opts.ablate picks one; tools/bench_bneck.py):
-// 1 no residual loads, 2 no stores, 4 no Wo loads, 8 no x loads in stage A, 16 no warm loads, 32 no stage B, 64 no Wa loads —
+// 1 no residual loads, 2 no stores, 4 no Wo loads, 8 no x loads in stage A, 32 no stage B, 64 no Wa loads —
 // wrong results by construction.  The product build has DBG = 0 only.
 template <int CX, int SLOTS, int DBG = 0>
 __global__ void __launch_bounds__(768) bneck64_kernel(const BneckArgs args) {
@@ -158,21 +158,11 @@ __global__ void __launch_bounds__(768) bneck64_kernel(const BneckArgs args) {
   if (producer) {
     // ================= producer waves: stage A, one row ahead of what the consumers read ==============================
     const __amdgpu_buffer_rsrc_t rs_wa = __builtin_amdgcn_make_buffer_rsrc((void*)args.wa, 0, KSA * 2 * 1024, 0x00020000);
-    // HBM latency of the x rows: a row is WARMED two rows before stage A reads it — one 4-byte load per 128-byte line of
-    // the wave's 32 x CX block (lane -> line) pulls the lines into L2; stage A then reads its fragments from L2.  The warm
-    // values stay live (folded into `sink`, never stored) so the compiler's vmcnt bookkeeping covers the registers.
-    constexpr int LINES = 32 * CX * 2 / 128;        // 128 (CX = 256) | 32 (CX = 64) lines per wave and row
-    unsigned sink = 0;
-    auto warm_x = [&](int row) __attribute__((always_inline)) {
-      if (row >= 0 && row < H && !(DBG & 16)) {
-        const char* base = (const char*)(args.x + (img_px + (long long)row * W + wave * 32) * CX);
-#pragma unroll
-        for (int q = 0; q < (LINES + 63) / 64; ++q) {
-          const int line = q * 64 + lane;
-          if (LINES >= 64 || line < LINES) sink ^= *(const volatile unsigned*)(base + (long long)line * 128);
-        }
-      }
-    };
+    // (Until the round's last profile a row was "warmed" into L2 two rows ahead with one 4-byte load per line.  The FETCH_SIZE
+    // pass showed what that did — x crossed the fabric THREE times per launch, 1.3 GB for a 420 MB tensor: a CU streams 160 KB
+    // per row, 32 CUs share a 4 MB L2, so a warmed line is gone again before stage A reads it — and the ablation probe had
+    // already said the warm loads bought nothing (342.7 vs 346.0 us): the producers have slack, their chunk pipeline simply
+    // reads x from HBM.  Removed.)
     auto stage_a = [&](int row) __attribute__((always_inline)) {
       char* const dst = ring + slot_of(row) * rowb + pp * 128;
       const int sw = (pp >> 1) & 7;
@@ -218,18 +208,15 @@ __global__ void __launch_bounds__(768) bneck64_kernel(const BneckArgs args) {
           *(uint4*)(dst + (((c0 >> 3) ^ sw) << 4)) = o;
         }
     };
-    warm_x(r0 - 1); warm_x(r0); warm_x(r0 + 1); warm_x(r0 + 2); warm_x(r0 + 3);
 #pragma unroll 1
     for (int row = r0 - 1; row <= r0 + 1; ++row) stage_a(row);
     BN_BARRIER();                       // rows r0 - 1 .. r0 + 1 of a are in the ring
 #pragma unroll 1
     for (int r = r0; r < r1; ++r) {
-      if (r + 4 <= r1) warm_x(r + 4);
       if (SLOTS == 3) BN_BARRIER();     // the consumers have read row r - 1: its slot is the one a(r + 2) goes to
       if (r + 1 < r1) stage_a(r + 2);
       BN_BARRIER();                     // a(r + 2) is complete before stage B of row r + 1
     }
-    if (sink == 0x9e3779b9u && args.N < 0) args.y[0] = (uint16_t)sink;   // never true: keeps the warm loads accounted for
   } else {
     // ================= consumer waves: stage B (3x3 from the ring) and stage C (1x1 + shortcut + store) ===============
     const __amdgpu_buffer_rsrc_t rs_wo = __builtin_amdgcn_make_buffer_rsrc((void*)args.wo, 0, 32 * 1024, 0x00020000);
