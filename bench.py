@@ -199,6 +199,15 @@ def run_train(args, dev, rank, world, params=None):
                     "algorithmic_MB_per_launch": round(v[1] / max(v[2], 1) / 1e6, 2)}
                 for k, v in sorted(by.items())}
     hbm_kernels = hbm_table(hbm, by_kernel, sampled)
+    # the fused stage-1 bottleneck launches (rn_bottleneck64_fwd): HBM-bound by design — algorithmic bytes = block input +
+    # output — and the former home of the best-running residual 1x1 layers, which therefore left the conv_big row above
+    bn_ev = [(e0, e1, fl, by) for e0, e1, name, fl, by, kern in lprof if kern.startswith("bneck64")]
+    if bn_ev:
+        ms, byts = sum(e0.elapsed_time(e1) for e0, e1, _, _ in bn_ev), sum(b for _, _, _, b in bn_ev)
+        hbm_kernels["bneck64_kernel (one launch per stage-1 bottleneck block)"] = {
+            "GB/s": round(byts / (ms * 1e-3) / 1e9, 1), "frac": round(byts / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+            "ms_per_step": round(ms / max(sampled, 1), 3), "launches_per_step": len(bn_ev) // max(sampled, 1),
+            "algorithmic_MB_per_launch": round(byts / len(bn_ev) / 1e6, 2)}
     dom_name = max(by_kernel, key=lambda k: by_kernel[k][0]) if by_kernel else "none"
     dom_ms, dom_flops, dom_bytes, dom_n = by_kernel.get(dom_name, [0.0, 0, 0, 0])
     # The timed steps run the weight-gradient launches on a second stream (TrainEngine.backward), so the dgrad
