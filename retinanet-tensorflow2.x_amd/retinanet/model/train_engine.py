@@ -122,7 +122,7 @@ class TrainEngine:
         self.hbm_profile = None   # bench.py: list that collects (event0, event1, kernel name, algorithmic bytes)
         self.conv_launches = []   # (name, rn_conv_problem) of every implicit-GEMM launch: lib.rn_conv_kernel_id(byref(p))
         self.wgrad_launches = []  # (name, rn_wgrad_problem) of every weight-gradient launch
-        cus = os.environ.get("RNET_WGRAD_CUS", "176,256")
+        cus = os.environ.get("RNET_WGRAD_CUS", "160,208")   # round 6, same-box A/B (profiles/r06_ab/wgrad_cus.txt): 176,256 28.23, 160,208 28.01, 144,192 28.02, 112,192 30.3 ms
         self._wgrad_cap = tuple(int(v) for v in cus.split(",")) if cus not in ("0", "") else None
         if os.environ.get("RNET_WGRAD_STREAM", "1") == "0":
             self._wgrad_cap = None      # one-stream backward: nothing to leave CUs to
