@@ -18,6 +18,8 @@
 //     partial tile to the workspace, a second kernel adds the chunks in index order
 //     (deterministic; no float atomics).
 // MFMA-bound for large layers; the partial-tile traffic is chunks * |W| * 4 B.
+#include <string.h>
+
 #include "rn_wgrad_dev.h"
 
 __device__ __forceinline__ void wg_dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, unsigned voff) {
@@ -414,6 +416,39 @@ extern "C" size_t rn_wgrad_workspace_bytes(const rn_wgrad_problem* p) {
   return (size_t)a.total_chunks * a.Cout * a.R * a.S * a.Cin * sizeof(float);
 }
 
+// partial-tile launch of a planned problem (wgrad_big_kernel or wgrad_kernel) + the ordered reduction.  ngroups > 1: the
+// problem's segments are LAYERS of a grouped call (one segment each, equal chunk counts): segment g's partial tiles are the
+// chunks [g * total_chunks / ngroups, ...) of the workspace and its sum goes to dws.p[g].
+static int wgrad_launch_planned(WgArgs& a, const rn_launch_opts& opts, void* workspace, hipStream_t st, const WgDwPtrs& dws,
+                                int ngroups, float beta) {
+  a.ws = (float*)workspace;
+  const long long n4 = (long long)a.Cout * a.R * a.S * a.Cin / 4;
+  int blocks = (int)(rn_cdiv(n4, 64) < 4096 ? rn_cdiv(n4, 64) : 4096);
+  if (blocks * ngroups > 8192) blocks = 8192 / ngroups;
+  if (a.pad_ == 1) {
+    const int rc = rn_launch_wgrad_big(a, opts, st);
+    if (rc != RN_OK) return rc;
+  } else {
+    const int lds = 5 * WG_TILE_BYTES;
+    RN_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    RN_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    dim3 grid((unsigned)(a.gco * a.ci_tiles * a.R * a.S * a.co_groups * a.total_chunks));
+    bool linear = a.sh == 1 && a.sw == 1 && a.pt == (a.R - 1) / 2 && a.pl == (a.S - 1) / 2 && (a.R & 1) && (a.S & 1);
+    for (int i = 0; i < a.nseg; ++i) {
+      const WgSegDev& s = a.seg[i];
+      linear = linear && s.Ho == s.H && s.Wo == s.W &&
+               (long long)s.N * s.H * s.W * (s.xS > s.dyS ? s.xS : s.dyS) * 2 < (1ll << 31) - (1ll << 24);
+    }
+    if (linear) hipLaunchKernelGGL(wgrad_kernel<true>, grid, dim3(WG_THREADS), lds, st, a);
+    else hipLaunchKernelGGL(wgrad_kernel<false>, grid, dim3(WG_THREADS), lds, st, a);
+    RN_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks, ngroups), dim3(256), 0, st, (const float4*)workspace, n4,
+                     a.total_chunks / ngroups, dws, beta);
+  RN_CHECK_LAUNCH();
+  return RN_OK;
+}
+
 extern "C" int rn_conv2d_nhwc_wgrad(const rn_wgrad_problem* p, float* dw, float beta, void* workspace,
                                     size_t workspace_bytes, void* stream) {
   WgArgs a;
@@ -440,43 +475,9 @@ extern "C" int rn_conv2d_nhwc_wgrad(const rn_wgrad_problem* p, float* dw, float 
       return RN_OK;
     }
   }
-  a.ws = (float*)workspace;
-  hipStream_t st = (hipStream_t)stream;
-  if (a.pad_ == 1) {
-    const int rc = rn_launch_wgrad_big(a, p->opts, st);
-    if (rc != RN_OK) return rc;
-    const long long nb = (long long)a.Cout * a.R * a.S * a.Cin;
-    const long long nb4 = nb / 4;
-    int blocksb = (int)(rn_cdiv(nb4, 64) < 4096 ? rn_cdiv(nb4, 64) : 4096);
-    WgDwPtrs dwsb;
-    dwsb.p[0] = (float4*)dw;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocksb), dim3(256), 0, st, (const float4*)workspace, nb4,
-                       a.total_chunks, dwsb, beta);
-    RN_CHECK_LAUNCH();
-    return RN_OK;
-  }
-  const int lds = 5 * WG_TILE_BYTES;
-  RN_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  RN_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  dim3 grid((unsigned)(a.gco * a.ci_tiles * a.R * a.S * a.co_groups * a.total_chunks));
-  bool linear = a.sh == 1 && a.sw == 1 && a.pt == (a.R - 1) / 2 && a.pl == (a.S - 1) / 2 && (a.R & 1) && (a.S & 1);
-  for (int i = 0; i < a.nseg; ++i) {
-    const WgSegDev& s = a.seg[i];
-    linear = linear && s.Ho == s.H && s.Wo == s.W &&
-             (long long)s.N * s.H * s.W * (s.xS > s.dyS ? s.xS : s.dyS) * 2 < (1ll << 31) - (1ll << 24);
-  }
-  if (linear) hipLaunchKernelGGL(wgrad_kernel<true>, grid, dim3(WG_THREADS), lds, st, a);
-  else hipLaunchKernelGGL(wgrad_kernel<false>, grid, dim3(WG_THREADS), lds, st, a);
-  RN_CHECK_LAUNCH();
-  const long long n = (long long)a.Cout * a.R * a.S * a.Cin;
-  const long long n4 = n / 4;
-  int blocks = (int)(rn_cdiv(n4, 64) < 4096 ? rn_cdiv(n4, 64) : 4096);
-  WgDwPtrs dwss;
-  dwss.p[0] = (float4*)dw;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)workspace, n4,
-                     a.total_chunks, dwss, beta);
-  RN_CHECK_LAUNCH();
-  return RN_OK;
+  WgDwPtrs one;
+  one.p[0] = (float4*)dw;
+  return wgrad_launch_planned(a, p->opts, workspace, (hipStream_t)stream, one, 1, beta);
 }
 
 // ---- several layers of identical geometry in one launch -----------------------------------------------------------
@@ -485,6 +486,37 @@ extern "C" int rn_conv2d_nhwc_wgrad(const rn_wgrad_problem* p, float* dw, float 
 // (layer, co tile, ci tile): the split-K plan then cuts the pixels into 1/n of the chunks per layer — every workgroup
 // writes its whole accumulator (288 KB) as a partial tile, so a launch costs 75 MB of partials however small the layer —
 // and one reduction launch sums all layers.  Anything else falls back to the per-layer calls.
+// Round 6: layers that wgrad_halo_kernel does not serve (the 1x1 layers of a ResNet stage: five / six of identical geometry)
+// group too, WITHOUT another kernel: a layer of one segment becomes a SEGMENT of a merged problem.  The partial-tile kernels
+// already walk per-segment (x, dy) pointers and chunk ranges, and with identical geometry every segment gets the same
+// number of chunks, so segment g's partial tiles are a contiguous [chunks / n] slice of the workspace — exactly the
+// [group][chunk] layout the grouped reduction reads.  Same split-K effect as the halo group: the plan aims for the same
+// number of workgroups over n layers' pixels, i.e. 1/n of the partial tiles per layer, one launch + one reduction for n.
+static bool wgrad_layers_as_segments(const rn_wgrad_problem* const* ps, int n, rn_wgrad_problem& m) {
+  if (!ps || n < 2 || n > RN_WGRAD_MAX_GROUP || n > RN_CONV_MAX_SEGMENTS) return false;
+  const rn_wgrad_problem& p0 = *ps[0];
+  if (p0.num_segments != 1) return false;
+  m = p0;
+  m.num_segments = n;
+  const rn_wgrad_segment& s0 = p0.seg[0];
+  for (int i = 0; i < n; ++i) {
+    const rn_wgrad_problem& q = *ps[i];
+    if (q.num_segments != 1 || q.R != p0.R || q.S != p0.S || q.stride_h != p0.stride_h || q.stride_w != p0.stride_w ||
+        q.pad_top != p0.pad_top || q.pad_left != p0.pad_left || memcmp(&q.opts, &p0.opts, sizeof(rn_launch_opts)) != 0)
+      return false;
+    const rn_wgrad_segment& s = q.seg[0];
+    if (s.N != s0.N || s.H != s0.H || s.W != s0.W || s.Cin != s0.Cin || s.Ho != s0.Ho || s.Wo != s0.Wo || s.Cout != s0.Cout ||
+        s.dy_pix_stride != s0.dy_pix_stride || s.x_pix_stride != s0.x_pix_stride)
+      return false;
+    m.seg[i] = s;
+  }
+  WgArgs a;
+  if (wgrad_plan(&m, a) || a.total_chunks % n) return false;
+  for (int i = 0; i < n; ++i)
+    if (a.seg[i].chunk_begin != i * (a.total_chunks / n)) return false;
+  return true;
+}
+
 extern "C" size_t rn_wgrad_group_workspace_bytes(const rn_wgrad_problem* const* ps, int n) {
   if (!ps || n < 1) return 0;
   size_t need = 0;
@@ -498,13 +530,24 @@ extern "C" size_t rn_wgrad_group_workspace_bytes(const rn_wgrad_problem* const* 
   if (n > 1 && n <= RN_WGRAD_MAX_GROUP && rn_wgrad_halo_plan(ps, n, h)) {
     const size_t g = rn_wgrad_halo_workspace_bytes(h);
     need = g > need ? g : need;
+  } else {
+    rn_wgrad_problem m;
+    if (wgrad_layers_as_segments(ps, n, m)) {
+      const size_t g = rn_wgrad_workspace_bytes(&m);
+      need = g > need ? g : need;
+    }
   }
   return need;
 }
 
 extern "C" int rn_wgrad_group_fused(const rn_wgrad_problem* const* ps, int n) {   // 1: one grouped launch, 0: per-layer calls
+  if (!ps || n < 2 || n > RN_WGRAD_MAX_GROUP) return 0;
+  for (int i = 0; i < n; ++i)
+    if (!ps[i]) return 0;
   WhArgs h;
-  return (ps && n > 1 && n <= RN_WGRAD_MAX_GROUP && rn_wgrad_halo_plan(ps, n, h)) ? 1 : 0;
+  if (rn_wgrad_halo_plan(ps, n, h)) return 1;
+  rn_wgrad_problem m;
+  return wgrad_layers_as_segments(ps, n, m) ? 1 : 0;
 }
 
 extern "C" int rn_conv2d_nhwc_wgrad_group(const rn_wgrad_problem* const* ps, int n, float* const* dws, float beta,
@@ -531,6 +574,14 @@ extern "C" int rn_conv2d_nhwc_wgrad_group(const rn_wgrad_problem* const* ps, int
                        h.total_chunks, d, beta);
     RN_CHECK_LAUNCH();
     return RN_OK;
+  }
+  rn_wgrad_problem m;
+  if (wgrad_layers_as_segments(ps, n, m)) {
+    WgArgs a;
+    RN_CHECK_ARG(wgrad_plan(&m, a) == 0, "rn_conv2d_nhwc_wgrad_group: bad merged problem");
+    WgDwPtrs d;
+    for (int i = 0; i < n; ++i) d.p[i] = (float4*)dws[i];
+    return wgrad_launch_planned(a, m.opts, workspace, (hipStream_t)stream, d, n, beta);
   }
   for (int i = 0; i < n; ++i) {
     const int rc = rn_conv2d_nhwc_wgrad(ps[i], dws[i], beta, workspace, workspace_bytes, stream);

@@ -1248,6 +1248,15 @@ class TrainEngine:
                 arr = (ctypes.POINTER(_C.WgradProblem) * len(grp))(*[ctypes.pointer(it[0]) for it in items])
                 if lib.rn_wgrad_group_fused(arr, len(grp)) != 1:
                     continue
+                # Groups the halo kernel does not serve — the 1x1 layers of a ResNet stage, five / six of one geometry, which
+                # rn_conv2d_nhwc_wgrad_group runs as segments of one partial-tile launch since round 6 — are NOT grouped by
+                # default: same-box A/B (tools/probes/ab_env_r06.sh, profiles/r06_ab/wgrad_group_1x1.txt) 28.11 / 28.32 / 28.47
+                # grouped against 28.10 / 28.14 / 28.22 ms per step.  A group is issued where its LAST layer stood, which
+                # moves ~40 small launches' work to the end of the weight-gradient stream — the stream that already ends
+                # 0.5 ms after the main one.  RNET_WGRAD_GROUP=all groups them (the library path stays tested).
+                if os.environ.get("RNET_WGRAD_GROUP", "halo") != "all" and \
+                        lib.rn_wgrad_kernel_id(ctypes.byref(items[0][0])) != 2:
+                    continue
                 nws = lib.rn_wgrad_group_workspace_bytes(arr, len(grp))
                 caps = [int(it[0].opts.wgrad_target_blocks) for it in items]
                 if any(caps):          # the uncapped plan (set_wgrad_cap(False)) must fit too
@@ -1263,7 +1272,9 @@ class TrainEngine:
                 flw = sum(it[3] for it in items)
                 writes = [w for i in grp for w in self.bwd_steps[i].writes]
                 a = (arr, len(grp), dws, 0.0, ws.data_ptr(), ws.numel())
-                wname = f"wgrad_halo_kernel ({len(grp)} layers per launch) + wgrad_reduce_kernel"
+                kname = ("wgrad_kernel (128x128 per-tap tiles)", "wgrad_big_kernel (256x256 per-tap tiles)",
+                         "wgrad_halo_kernel")[max(lib.rn_wgrad_kernel_id(ctypes.byref(items[0][0])), 0)]
+                wname = f"{kname} ({len(grp)} layers per launch) + wgrad_reduce_kernel"
 
                 byw = sum(self._wgrad_bytes(it[0]) for it in items)
                 lname = "wgrad:" + "+".join(n[len("wgrad:"):] for n, q in self.wgrad_launches

@@ -125,6 +125,68 @@ def test_wgrad(cuda, build, shape_id, kernel_opt, target_blocks, want_kernel):
     torch.testing.assert_close(dw.cpu().double(), 2 * want, rtol=1e-3, atol=2e-3 * scale)
 
 
+@pytest.mark.parametrize("build,k,stride,cin,cout,n,kernel,target_blocks", [
+    ("bf16", 1, 1, 256, 64, 5, 0, 0),        # the dispatcher's own choice (128-tile kernel)
+    ("bf16", 1, 1, 256, 512, 6, 2, 0),       # wide layers: wgrad_big_kernel
+    ("bf16", 1, 1, 128, 256, 8, 1, 48),      # few workgroups: long pixel chunks
+    ("bf16", 3, 2, 128, 128, 3, 0, 0),       # a strided 3x3 group (not the halo kernel's)
+    ("f16", 1, 1, 256, 256, 4, 2, 0)])
+def test_wgrad_group_layers_as_segments(cuda, build, k, stride, cin, cout, n, kernel, target_blocks):
+    """Round 6: single-segment layers of identical geometry that the halo kernel does not serve (the 1x1 layers of a ResNet
+    stage) run as ONE partial-tile launch — each layer a segment of a merged problem — plus one grouped reduction.  Every
+    layer against float64, with beta, bit-identical repeats; a layer of different geometry breaks the group."""
+    from retinanet import _C
+    lib = _lib()
+    g = torch.Generator().manual_seed(7 * n + k + cin)
+    pad = (k - 1) // 2
+    N, H, W = 2, 18, 14
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    probs, keep, wants, dws, olds = [], [], [], [], []
+    for layer in range(n):
+        p = _C.WgradProblem()
+        p.R = p.S = k
+        p.stride_h = p.stride_w = stride
+        p.pad_top = p.pad_left = pad
+        p.num_segments = 1
+        p.opts = _C.LaunchOpts(wgrad_kernel=kernel, wgrad_target_blocks=target_blocks)
+        x = _bf(torch.randn((N, H, W, cin), generator=g))
+        dy = _bf(torch.randn((N, Ho, Wo, cout), generator=g))
+        xd, dyd = x.to(cuda), dy.to(cuda)
+        sg = p.seg[0]
+        sg.x, sg.dy = xd.data_ptr(), dyd.data_ptr()
+        sg.N, sg.H, sg.W, sg.Cin, sg.Ho, sg.Wo, sg.Cout = N, H, W, cin, Ho, Wo, cout
+        keep += [xd, dyd]
+        w = torch.zeros((cout, cin, k, k), dtype=torch.float64, requires_grad=True)
+        F.conv2d(x.double().permute(0, 3, 1, 2), w, stride=stride, padding=pad).backward(dy.double().permute(0, 3, 1, 2))
+        probs.append(p)
+        wants.append(w.grad.permute(0, 2, 3, 1))
+        old = torch.randn((cout, k, k, cin), generator=g)
+        olds.append(old)
+        dws.append(old.to(cuda).clone())
+    arr = (ctypes.POINTER(_C.WgradProblem) * n)(*[ctypes.pointer(p) for p in probs])
+    assert lib.rn_wgrad_group_fused(arr, n) == 1
+    if kernel == 2:
+        assert lib.rn_wgrad_kernel_id(ctypes.byref(probs[0])) == 1      # the 256-wide kernel really runs
+    ws = _ws(lib.rn_wgrad_group_workspace_bytes(arr, n), cuda)
+    ws.fill_(0x7f)
+    beta = 0.5
+    _C.check(lib.rn_conv2d_nhwc_wgrad_group(arr, n, _C.ptr_array(dws), beta, _C.ptr(ws), ws.numel(), _C.current_stream()))
+    torch.cuda.synchronize()
+    for layer in range(n):
+        want = wants[layer] + beta * olds[layer].double()
+        scale = wants[layer].abs().max().item()
+        torch.testing.assert_close(dws[layer].cpu().double(), want, rtol=1e-3, atol=1e-3 * scale)
+    first = [d.clone() for d in dws]
+    for d, old in zip(dws, olds):
+        d.copy_(old)
+    _C.check(lib.rn_conv2d_nhwc_wgrad_group(arr, n, _C.ptr_array(dws), beta, _C.ptr(ws), ws.numel(), _C.current_stream()))
+    torch.cuda.synchronize()
+    for a, b in zip(first, dws):
+        assert torch.equal(a, b)              # deterministic: ordered split-K reduction
+    probs[1].seg[0].N = 1
+    assert lib.rn_wgrad_group_fused(arr, n) == 0
+
+
 @pytest.mark.parametrize("build,k,n,target_blocks,fused", [("bf16", 3, 4, 0, 1), ("bf16", 3, 8, 0, 1), ("bf16", 3, 3, 64, 1),
                                                           ("f16", 3, 4, 0, 1), ("bf16", 1, 3, 0, 0)])
 def test_wgrad_group(cuda, build, k, n, target_blocks, fused):
