@@ -274,8 +274,9 @@ __device__ __forceinline__ void dwg_load_p(const uint16_t* p, dw_f2* v) {
     v[1] = dw_f2{rn_lo16(u.y), rn_hi16(u.y)};
   }
 }
-// the same through a buffer descriptor: an offset past the descriptor's size (0x80000000) returns zeros — the hardware's
-// bounds check instead of a branch around the load
+// the same through a buffer descriptor: an offset past the descriptor's size (DWG_OOB) returns zeros — the hardware's
+// bounds check instead of a branch around the load.  Tensors up to 4 GB - 64 B (32-bit record count / offsets).
+#define DWG_OOB 0xfffffff0u
 typedef unsigned dwg_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned dwg_u32x2 __attribute__((ext_vector_type(2)));
 template <int CPT>
@@ -344,11 +345,11 @@ __global__ void __launch_bounds__(256) depthwise_wgrad_kernel(const DwgArgs a) {
   const int items = s.N * s.Ho * strips;           // s.P holds the item count of the segment
   const int i0 = (chunk - s.chunk_begin) * a.rows_per_chunk;
   const int i1 = i0 + a.rows_per_chunk < items ? i0 + a.rows_per_chunk : items;
-  // (tensors of at most 2 GB: checked by the host)
+  // (tensors below 4 GB: checked by the host; the record count is an unsigned 32-bit field)
   const __amdgpu_buffer_rsrc_t rs_x =
-      __builtin_amdgcn_make_buffer_rsrc((void*)s.x, 0, (int)((long long)s.N * s.H * s.W * a.C * 2), 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc((void*)s.x, 0, (int)(unsigned)((long long)s.N * s.H * s.W * a.C * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_dy =
-      __builtin_amdgcn_make_buffer_rsrc((void*)s.dy, 0, (int)((long long)s.N * s.Ho * s.Wo * a.C * 2), 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc((void*)s.dy, 0, (int)(unsigned)((long long)s.N * s.Ho * s.Wo * a.C * 2), 0x00020000);
   if (live) {
     for (int it = i0 + rl; it < i1; it += RL) {
       const int ox0 = (it % strips) * T;
@@ -363,7 +364,7 @@ __global__ void __launch_bounds__(256) depthwise_wgrad_kernel(const DwgArgs a) {
       const unsigned dyoff = (unsigned)(((((long long)n * s.Ho + oy) * s.Wo + ox0) * a.C + c0) * 2);
 #pragma unroll
       for (int tt = 0; tt < T; ++tt)
-        dwg_bload<CPT>(rs_dy, ox0 + tt < s.Wo ? dyoff + (unsigned)(tt * a.C * 2) : 0x80000000u, g[tt]);
+        dwg_bload<CPT>(rs_dy, ox0 + tt < s.Wo ? dyoff + (unsigned)(tt * a.C * 2) : DWG_OOB, g[tt]);
       const int ix0 = ox0 * S - a.pl;
 #pragma unroll
       for (int r = 0; r < K; ++r) {
@@ -373,7 +374,7 @@ __global__ void __launch_bounds__(256) depthwise_wgrad_kernel(const DwgArgs a) {
         dw_f2 xv[WIN][CP2];
 #pragma unroll
         for (int j = 0; j < WIN; ++j)
-          dwg_bload<CPT>(rs_x, rok && (unsigned)(ix0 + j) < (unsigned)s.W ? xoff + (unsigned)(j * a.C * 2) : 0x80000000u, xv[j]);
+          dwg_bload<CPT>(rs_x, rok && (unsigned)(ix0 + j) < (unsigned)s.W ? xoff + (unsigned)(j * a.C * 2) : DWG_OOB, xv[j]);
 #pragma unroll
         for (int j = 0; j < WIN; ++j) {
 #pragma unroll
@@ -449,7 +450,8 @@ static int dwg_plan(const rn_dw_problem* p, DwgArgs& a) {
   for (int i = 0; i < p->num_segments; ++i) {
     const rn_dw_segment& s = p->seg[i];
     if (!s.x || !s.y || s.C != a.C) return -1;
-    if ((long long)s.N * s.H * s.W * s.C * 2 >= (1ll << 31)) return -1;   // the kernel addresses x / dy through 32-bit buffer offsets
+    if ((long long)s.N * s.H * s.W * s.C * 2 >= (1ll << 32) - 64 || (long long)s.N * s.Ho * s.Wo * s.C * 2 >= (1ll << 32) - 64)
+      return -1;   // the kernel addresses x / dy through 32-bit buffer offsets
     Ptot += (long long)s.N * s.Ho * ((s.Wo + 3) / 4);
   }
   // ~512 item chunks over the launch, as before (each chunk's workgroups write K*K*C partial sums and run the reduction
