@@ -25,17 +25,23 @@
 //   C  out(row r)     = Wo . b (+ Wsc . x)   b NEVER goes through LDS: the MFMA output rows are permuted (bits 2 and 3 of
 //                                       the row index swapped in the packed weights) so that a lane's accumulator
 //                                       registers 8k .. 8k + 7 are the 8 CONSECUTIVE channels 16k + 8h + i of its pixel —
-//                                       exactly the B-operand fragment of K step k of the next GEMM (and, for stage C
-//                                       itself, a 16-byte piece of the output row: residual load and store need no
-//                                       transpose either)
+//                                       exactly the B-operand fragment of K step k of the next GEMM.  The output (and the
+//                                       identity shortcut's input) passes through a 4 KB per-wave LDS patch, 64 channels
+//                                       at a time, so that global memory sees full 128-byte rows (consumer waves below)
 // Rounding points are the unfused path's (rnet_hip.h rn_conv_segment): Conv2D output -> bf16, BatchNorm -> bf16, (+ shortcut)
 // -> relu -> bf16.  K orders differ from the unfused kernels, so results agree to the last fp32 bit of the accumulations,
 // not bit for bit (tests: <= 1 bf16 ulp against the three-launch path on all but a few 1e-4 of the elements, and the
 // float64 reference).
 //
+// Producer waves (one per column block) run stage A one row ahead; consumer waves (one per column block) run stages B and
+// C; they meet at one or two LDS-only workgroup barriers per row.
+//
 // The work is HBM-bound by design: 139 KFLOP per pixel = 136 MFMAs per wave and row (~4 400 cycles) against ~17 000 cycles
 // of HBM time per row at one workgroup per CU; LDS = 72 KB (Wb) + 5 KB (folded BatchNorm vectors) + ring + 4 KB per consumer
 // wave <= 160 KB allows W <= 160 (3 ring rows and two barriers per row there; 4 rows and one barrier up to W = 128).
+// Measured (tools/probes/bneck_ablate.sh): it is bound by L2 <-> CU transactions — Wa / Wo / Wsc fragments
+// are re-read per wave and row because only Wb fits the LDS next to the ring — at 2.4 TB/s of algorithmic bytes: 1.26x (identity)
+// / 1.85x (projection) the three-launch path at 32 images, 1.8x / 2.3x at 8, ~2x / ~3x at one.
 #include "rn_conv_dev.h"
 
 namespace {
