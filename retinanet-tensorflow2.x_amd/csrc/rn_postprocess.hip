@@ -25,6 +25,7 @@
 #include "rn_common.h"
 #include "../../include/rn_math.h"
 #include <math.h>
+#include <stdlib.h>
 
 #define RN_PP_THREADS 256
 #define RN_PP_MAX_LEVELS 8
@@ -342,28 +343,36 @@ compact_scores_kernel(const float* __restrict__ scores, int B, long long n, int 
 
 // ------------------------------------------------------------------------------------------
 // block-level helpers over an LDS key array
-__device__ void bitonic_sort_desc(unsigned long long* s, int N) {
-  const int half = N >> 1;
-  for (int k = 2; k <= N; k <<= 1) {
+// Sorts s[0..n) descending, n any size.  The network is the bitonic sorter of the next power of two N2 in its
+// uniform-direction form — every merge stage opens with the mirrored step (t against k - 1 - t inside a block of k), then
+// the half-cleaners — so every compare-exchange wants the larger key at the LOWER index: positions n .. N2 - 1, imagined to
+// hold keys below every real one, never take part (a pair whose upper index is >= n is already in order) and need no
+// storage.  (The alternating-direction form moved the padding through the array: it needed N2 keys of LDS — 64 KB for the
+// 5 000 candidates of a soft-NMS list, two lists per compute unit where 5 056 keys allow three.)
+__device__ void bitonic_sort_desc(unsigned long long* s, int n) {
+  int N2 = 64;
+  while (N2 < n) N2 <<= 1;
+  const int half = N2 >> 1;
+  for (int k = 2; k <= N2; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
+      const bool mirror = j == (k >> 1);
       // 4 independent compare-exchanges per trip so the LDS reads pipeline
       for (int t0 = threadIdx.x; t0 < half; t0 += 4 * blockDim.x) {
         int ii[4], pp[4];
         unsigned long long a[4], b[4];
+        bool live[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int t = t0 + u * blockDim.x;
-          const int tt = t < half ? t : t0;
-          ii[u] = ((tt & ~(j - 1)) << 1) | (tt & (j - 1));
-          pp[u] = ii[u] | j;
-          a[u] = s[ii[u]];
-          b[u] = s[pp[u]];
+          ii[u] = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+          pp[u] = mirror ? (ii[u] | (k - 1)) - (t & (j - 1)) : (ii[u] | j);
+          live[u] = t < half && pp[u] < n;
+          a[u] = live[u] ? s[ii[u]] : 0ull;
+          b[u] = live[u] ? s[pp[u]] : 0ull;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const int t = t0 + u * blockDim.x;
-          const bool desc = (ii[u] & k) == 0;
-          if (t < half && (desc ? (a[u] < b[u]) : (a[u] > b[u]))) {
+          if (live[u] && a[u] < b[u]) {
             s[ii[u]] = b[u];
             s[pp[u]] = a[u];
           }
@@ -411,19 +420,20 @@ __device__ unsigned long long radix_select_desc(Loader keys, int n, unsigned lon
       // walking the 256 bins cost ~5 us per pass, 8 passes per selection: a third of merge_kernel and a quarter of a
       // hard-NMS list at batch 8.)
       const int d = threadIdx.x, ln = d & 63, wv = d >> 6;
-      const int h = hist[d];
+      const bool bin = d < 256;                    // (soft_nms_kernel runs 512 threads: the upper half only keeps the barriers)
+      const int h = bin ? hist[d] : 0;
       const int kk = *s_k;
       int v = h;                                   // -> sum of the bins ln .. 63 of this wave
       for (int o = 1; o < 64; o <<= 1) {
         const int u = __shfl_down(v, o, 64);
         if (ln + o < 64) v += u;
       }
-      if (ln == 0) s_wtot[wv] = v;
+      if (bin && ln == 0) s_wtot[wv] = v;
       __syncthreads();
       int above = v - h;
       for (int w = wv + 1; w < 4; ++w) above += s_wtot[w];
       // bin 0 takes what is left (as the serial walk did when the bins above hold fewer than kk keys)
-      if (above < kk && (d == 0 || kk <= above + h)) {
+      if (bin && above < kk && (d == 0 || kk <= above + h)) {
         *s_k = kk - above;
         *s_prefix = prefix | (((unsigned long long)d) << shift);
         // every key of this bin is among the kk largest: prefix (lower digits zero) is already the bound.  With distinct
@@ -446,20 +456,18 @@ __device__ unsigned long long next_chunk_sorted(Loader keys, int n, int remainin
                                                 int* s_hist, unsigned long long* s_prefix, int* s_misc) {
   unsigned long long lower = 0ull;
   if (remaining > take) lower = radix_select_desc(keys, n, upper, take, s_hist, s_prefix, &s_misc[0], &s_misc[4]);
-  int N2 = 64;
-  while (N2 < take) N2 <<= 1;
   if (threadIdx.x == 0) s_misc[1] = 0;
-  for (int t = threadIdx.x; t < N2; t += blockDim.x) skeys[t] = 0ull;
+  for (int t = threadIdx.x; t < take; t += blockDim.x) skeys[t] = 0ull;
   __syncthreads();
   for (int t = threadIdx.x; t < n; t += blockDim.x) {
     const unsigned long long key = keys(t);
     if (key >= lower && key < upper) {
       const int slot = atomicAdd(&s_misc[1], 1);
-      if (slot < N2) skeys[slot] = key;
+      if (slot < take) skeys[slot] = key;
     }
   }
   __syncthreads();
-  bitonic_sort_desc(skeys, N2);
+  bitonic_sort_desc(skeys, take);
   return lower;
 }
 
@@ -516,15 +524,16 @@ __device__ __forceinline__ float wave_max_f32(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-// One workgroup per (image, class).  Dynamic LDS: keys[RN_SORT_CAP] | sel boxes | sel scores
-// | soft-NMS state | hist.
+// One workgroup per (image, class).  Dynamic LDS: keys[chunk_cap] | sel boxes | sel scores | sel indices (sel_cap each)
+// | hist | soft-NMS state.
 struct NmsParams {
   int B, K, max_det, top_k;
   float iou_thr, score_thr, soft_scale;  // soft_scale = -0.5/(sigma/2) when soft, else 0
   int soft;
   long long cap;
-  int soft_off;         // soft: byte offset of the soft-NMS state in LDS (the sort buffer's unused tail, or behind everything)
-  int chunk_cap;        // keys the LDS sort buffer holds: RN_SORT_CAP for soft NMS (the whole list is one chunk), RN_HARD_CHUNK else
+  int soft_off;         // soft: byte offset of the soft-NMS state in LDS (behind everything else)
+  int chunk_cap;        // keys the LDS sort buffer holds: soft NMS, the whole list (one chunk, <= RN_SORT_CAP); RN_HARD_CHUNK else
+  int sel_cap;          // slots of the selected-box arrays (max_det rounded up to 4)
   int part_off, first_chunk;   // hard: byte offset of the four waves' partial results (32 + 512 B); keys of the first sorted chunk
 };
 
@@ -534,10 +543,10 @@ nms_per_class_kernel(NmsParams p, const int* __restrict__ counts, const unsigned
                      int* __restrict__ sel_idx) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned long long* skeys = (unsigned long long*)smem;                       // chunk_cap * 8
-  float4* s_selbox = (float4*)(smem + (size_t)p.chunk_cap * 8);                // RN_MAX_DET * 16
-  float* s_selscore = (float*)((char*)s_selbox + (size_t)RN_MAX_DET * 16);     // RN_MAX_DET * 4
-  int* s_selidx = (int*)((char*)s_selscore + (size_t)RN_MAX_DET * 4);          // RN_MAX_DET * 4
-  int* s_hist = (int*)((char*)s_selidx + (size_t)RN_MAX_DET * 4);              // 256 * 4
+  float4* s_selbox = (float4*)(smem + (size_t)p.chunk_cap * 8);                // sel_cap * 16
+  float* s_selscore = (float*)((char*)s_selbox + (size_t)p.sel_cap * 16);      // sel_cap * 4
+  int* s_selidx = (int*)((char*)s_selscore + (size_t)p.sel_cap * 4);           // sel_cap * 4
+  int* s_hist = (int*)((char*)s_selidx + (size_t)p.sel_cap * 4);               // 256 * 4
   unsigned long long* s_prefix = (unsigned long long*)((char*)s_hist + 1024);  // 8
   int* s_misc = (int*)((char*)s_prefix + 8);                                   // [0]=k scratch [1]=fill [2]=nsel [4..7]=wave totals (radix select)
   // soft NMS state (sized by nms_lds_bytes below): two cached blocks of candidate boxes | per block (best score, its
@@ -556,7 +565,7 @@ nms_per_class_kernel(NmsParams p, const int* __restrict__ counts, const unsigned
   const unsigned long long* keys = keys_g + (long long)list * p.cap;
   int limit = n;
   if (p.top_k > 0 && limit > p.top_k) limit = p.top_k;
-  if (p.soft && limit > RN_SORT_CAP) limit = RN_SORT_CAP;  // host rejects configs that could reach this
+  if (p.soft && limit > p.chunk_cap) limit = p.chunk_cap;  // host rejects configs that could reach this
 
   if (threadIdx.x == 0) s_misc[2] = 0;
   __syncthreads();
@@ -750,6 +759,278 @@ nms_per_class_kernel(NmsParams p, const int* __restrict__ counts, const unsigned
   }
 }
 
+// ---- soft NMS, one selection per step ------------------------------------------------------------------------------
+// NonMaxSuppressionV5's soft path is a lazy queue: a popped candidate is re-scored against the boxes selected since it was
+// last looked at (newest first, one float multiply per box); unchanged -> selected, lower -> pushed back.  On clustered
+// detections that is ~80 pops per selection, each a chain of dependent LDS reads and reductions on one wave (the loop in
+// nms_per_class_kernel above: 8 000 pops x ~2 200 cycles = 8 ms for one list of the configs[4] serving bench, with the
+// other three waves of the workgroup idle).  The same results — the same candidates in the same order with the same score
+// bits — come out of a form with ONE step per selected box and every thread busy:
+//   * a thread owns NC candidates (positions tid, tid + THREADS, ...: box, queue score q, and the weights != 1 of the boxes
+//     selected since the candidate was last re-scored — newest first, up to 4 — all in registers);
+//   * what the queue would hand back for a candidate now is r = q * w_newest * ... * w_oldest (the weights that are
+//     exactly 1 — no overlap, the common case — do not change a float product, so leaving them out is exact);
+//   * the next selected box is the candidate with the largest r (lowest position on ties: the queue's order), R = its r.
+//     Proof sketch: the queue pops in descending q; everything popped before the selection has q > R (or q = R and a lower
+//     position), is re-scored to its r <= R and pushed back; the first pop that comes back unchanged is that maximum;
+//   * exactly the candidates the queue popped on the way — q > R, or q = R at a lower position — take q := r and forget
+//     their weights; r <= score_threshold drops a candidate (the queue drops it when it pops it; it is never selected in
+//     between, so dropping it early changes nothing);
+//   * every live candidate then gets the weight of the new box; a fifth weight != 1 turns the candidate into the general
+//     case: its r is recomputed over the selected boxes [begin, nsel) as the queue does — only when it is popped (q > R),
+//     which is rare (tools/probes/soft_nms_sim.py: 1 - 500 of ~8 000 re-scorings per list).
+// Verified against the queue (oracle rn_o_nms_v5) bit for bit by the soft-NMS tests of tests/test_gpu_postprocess.py and
+// tests/test_soft_nms_independent.py.  Reference: postprocessing_ops.py:443-451 (tf.image.non_max_suppression_with_scores).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_min_step(int v) {
+  const int o = __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false);
+  return o < v ? o : v;
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+  v = dpp_min_step<0xb1, 0xf>(v);
+  v = dpp_min_step<0x4e, 0xf>(v);
+  v = dpp_min_step<0x124, 0xf>(v);
+  v = dpp_min_step<0x128, 0xf>(v);
+  v = dpp_min_step<0x142, 0xa>(v);
+  v = dpp_min_step<0x143, 0xc>(v);
+  return __builtin_amdgcn_readlane(v, 63);
+}
+#define RN_SOFT_PEND 4
+#define RN_SOFT_OVER 5      // more than RN_SOFT_PEND weights != 1 since the last re-scoring
+#define RN_SOFT_EVAL 6      // general case, re-scored in this step (the value sits in pend[0])
+// a candidate's box with its corners in order (nms_iou's first step).
+// Boxes reach this kernel through fetch_clipped: finite, in [0, 1] — min / max are written as compare + select (fminf / fmaxf
+// on values the compiler cannot prove canonical cost a v_max x, x each; the two forms differ for NaN and the sign of zero only,
+// and a zero of either sign leaves the weight at exp(0) = 1)
+struct SoftBox { float y0, x0, y1, x1; };
+__device__ __forceinline__ float sel_min(float a, float b) { return a < b ? a : b; }
+__device__ __forceinline__ float sel_max(float a, float b) { return a > b ? a : b; }
+__device__ __forceinline__ SoftBox soft_box(const float4 a) {
+  SoftBox s;
+  s.y0 = sel_min(a.x, a.z); s.x0 = sel_min(a.y, a.w); s.y1 = sel_max(a.x, a.z); s.x1 = sel_max(a.y, a.w);
+  return s;
+}
+// rn_expf for x <= 0 (not NaN): the same operations without the upper range tests
+__device__ __forceinline__ float soft_expf_nonpos(float x) {
+  const float n = rintf(x * 1.44269504088896341f);
+  float r = fmaf(n, -0.693359375f, x);
+  r = fmaf(n, 2.12194440e-4f, r);
+  float q = 1.9875691500e-4f;
+  q = fmaf(q, r, 1.3981999507e-3f);
+  q = fmaf(q, r, 8.3334519073e-3f);
+  q = fmaf(q, r, 4.1665795894e-2f);
+  q = fmaf(q, r, 1.6666665459e-1f);
+  q = fmaf(q, r, 5.0000001201e-1f);
+  const float r2 = r * r;
+  q = fmaf(q, r2, r);
+  q = q + 1.0f;
+  const float e = ldexpf(q, (int)n);
+  return x < -103.972084f ? 0.0f : e;
+}
+// exp(scale * iou^2), scale <= 0, with the arithmetic of nms_iou / rn_expf operation for operation
+__device__ __forceinline__ float soft_weight(const SoftBox& a, const SoftBox& b, float scale) {
+  const float iy0 = sel_max(a.y0, b.y0), ix0 = sel_max(a.x0, b.x0);
+  const float iy1 = sel_min(a.y1, b.y1), ix1 = sel_min(a.x1, b.x1);
+  const float inter = sel_max(iy1 - iy0, 0.0f) * sel_max(ix1 - ix0, 0.0f);
+  const float area_a = (a.y1 - a.y0) * (a.x1 - a.x0), area_b = (b.y1 - b.y0) * (b.x1 - b.x0);
+  float sim = inter / (area_a + area_b - inter);
+  sim = (area_a <= 0.0f || area_b <= 0.0f) ? 0.0f : sim;
+  return soft_expf_nonpos(scale * sim * sim);
+}
+template <int NC, int THREADS>
+__global__ void __launch_bounds__(THREADS, 4)
+soft_nms_kernel(NmsParams p, const int* __restrict__ counts, const unsigned long long* __restrict__ keys_g,
+                BoxSrc bs, float* __restrict__ sel_scores, float4* __restrict__ sel_boxes, int* __restrict__ sel_idx) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned long long* skeys = (unsigned long long*)smem;                       // chunk_cap * 8
+  float4* s_selbox = (float4*)(smem + (size_t)p.chunk_cap * 8);                // sel_cap * 16
+  float* s_selscore = (float*)((char*)s_selbox + (size_t)p.sel_cap * 16);      // sel_cap * 4
+  int* s_selidx = (int*)((char*)s_selscore + (size_t)p.sel_cap * 4);           // sel_cap * 4
+  int* s_hist = (int*)((char*)s_selidx + (size_t)p.sel_cap * 4);               // 256 * 4
+  unsigned long long* s_prefix = (unsigned long long*)((char*)s_hist + 1024);  // 8
+  int* s_misc = (int*)((char*)s_prefix + 8);                                   // 32
+  float* s_red = (float*)(smem + p.soft_off);                                  // [2][THREADS / 64][4]: per wave (best r, its position, max q of the general case, -)
+
+  const int list = blockIdx.x;
+  const int b = list / p.K, cls = list - b * p.K;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  long long n_ll = counts[list];
+  if (n_ll > p.cap) n_ll = p.cap;
+  const int n = (int)n_ll;
+  int m = n;
+  if (p.top_k > 0 && m > p.top_k) m = p.top_k;
+  if (m > p.chunk_cap) m = p.chunk_cap;   // host rejects configs that could reach this
+  int nsel = 0;
+  if (m > 0) {
+    next_chunk_sorted(GlobalKeys{keys_g + (long long)list * p.cap}, n, n, m, ~0ull, skeys, s_hist, s_prefix, s_misc);
+    const int ncu = (m + THREADS - 1) / THREADS;   // candidates per thread in use (uniform)
+    const float thr = p.score_thr;
+    SoftBox bx[NC];
+    float q[NC], pend[NC][RN_SOFT_PEND];   // q: the candidate's score in the queue (-1: gone); pend: weights != 1, newest first
+    int meta[NC];   // bits 0..2: weights held (0..4) | RN_SOFT_OVER | RN_SOFT_EVAL; bit 3 / 4: the box came with y0 > y1 / x0 > x1; bits 8..: begin
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int i = c * THREADS + (int)threadIdx.x;
+      q[c] = -1.0f;
+      meta[c] = 0;
+      bx[c] = soft_box(make_float4(0.f, 0.f, 0.f, 0.f));
+#pragma unroll
+      for (int k = 0; k < RN_SOFT_PEND; ++k) pend[c][k] = 1.0f;
+      if (c < ncu && i < m) {
+        const unsigned long long key = skeys[i];
+        const float sc = key_score(key);
+        if (sc > thr) {
+          q[c] = sc;
+          const float4 o = fetch_clipped(bs, b, cls, key_index(key));
+          bx[c] = soft_box(o);
+          meta[c] = (o.x > o.z ? 8 : 0) | (o.y > o.w ? 16 : 0);
+        }
+      }
+    }
+    // the first selection is the head of the sorted list
+    float R = key_score(skeys[0]);
+    int mpos = 0, par = 0;
+    while (R > thr) {
+      // the selected candidate's owner records it (its box as it came)
+      if ((mpos & (THREADS - 1)) == (int)threadIdx.x) {
+        const int cm = mpos / THREADS;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+          if (c == cm) {
+            const bool sy = meta[c] & 8, sx = meta[c] & 16;
+            s_selbox[nsel] = make_float4(sy ? bx[c].y1 : bx[c].y0, sx ? bx[c].x1 : bx[c].x0, sy ? bx[c].y0 : bx[c].y1,
+                                         sx ? bx[c].x0 : bx[c].x1);
+          }
+        s_selscore[nsel] = R;
+        s_selidx[nsel] = (int)key_index(skeys[mpos]);
+      }
+      __syncthreads();
+      const SoftBox nb = soft_box(s_selbox[nsel]);
+      const bool last = nsel + 1 >= p.max_det;
+      // one pass over this thread's candidates: (a) the ones the queue popped on its way to this selection take their new
+      // scores, (b) the weight of the new box, (c) what the queue would return now -> this thread's best
+      float br = -1.0f, oq = -1.0f;
+      int bp = 0x7fffffff;
+      if (!last) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          __builtin_amdgcn_sched_barrier(0);   // one candidate's temporaries at a time: the state fills the register file
+          if (c < ncu) {
+            const int i = c * THREADS + (int)threadIdx.x;
+            int mt = meta[c];
+            float qc = q[c];
+            {
+              const int st = mt & 7;
+              float r = qc;
+#pragma unroll
+              for (int k = 0; k < RN_SOFT_PEND; ++k) r = r * pend[c][k];
+              r = st == RN_SOFT_EVAL ? pend[c][0] : r;
+              const bool pop = qc > thr && (qc > R || (qc == R && i < mpos));
+              qc = i == mpos ? -1.0f : (pop ? r : qc);
+#pragma unroll
+              for (int k = 0; k < RN_SOFT_PEND; ++k) pend[c][k] = pop ? 1.0f : pend[c][k];
+              // popped: weights forgotten, begin = nsel; looked at but not popped: back to the general case
+              mt = pop ? (mt & 0x18) | (nsel << 8) : (st == RN_SOFT_EVAL ? (mt & ~7) | RN_SOFT_OVER : mt);
+            }
+            const bool live = qc > thr;
+            {
+              const float w = soft_weight(bx[c], nb, p.soft_scale);
+              const int st = mt & 7;
+              const bool add = w != 1.0f && live && st <= RN_SOFT_PEND;   // a fifth weight: the general case from here on
+              const bool keep = add && st < RN_SOFT_PEND;
+#pragma unroll
+              for (int k = RN_SOFT_PEND - 1; k > 0; --k) pend[c][k] = keep ? pend[c][k - 1] : pend[c][k];
+              pend[c][0] = keep ? w : pend[c][0];
+              mt += add ? 1 : 0;
+            }
+            {
+              float r = qc;
+#pragma unroll
+              for (int k = 0; k < RN_SOFT_PEND; ++k) r = r * pend[c][k];   // (once <= threshold it stays there: weights <= 1)
+              const bool general = (mt & 7) > RN_SOFT_PEND;
+              const bool ok = live && !general && r > thr;
+              qc = (live && !general && !(r > thr)) ? -1.0f : qc;          // the queue drops it when it pops it
+              const bool take = ok && r > br;
+              br = take ? r : br;
+              bp = take ? i : bp;
+              oq = sel_max(oq, (live && general) ? qc : -1.0f);
+            }
+            q[c] = qc;
+            meta[c] = mt;
+          }
+        }
+      }
+      ++nsel;
+      if (last) break;
+      float* red = s_red + par * (THREADS / 16);
+      par ^= 1;
+      {
+        const float wm = wave_max_f32(br);
+        const int wp = wave_min_i32(br == wm ? bp : 0x7fffffff);
+        const float wo = wave_max_f32(oq);
+        if (lane == 0) {
+          red[wave * 4 + 0] = wm;
+          red[wave * 4 + 1] = __int_as_float(wp);
+          red[wave * 4 + 2] = wo;
+        }
+      }
+      __syncthreads();
+      float OQ = -1.0f;
+      R = -1.0f;
+      mpos = 0x7fffffff;
+#pragma unroll
+      for (int w = 0; w < THREADS / 64; ++w) {
+        const float wm = red[w * 4 + 0];
+        const int wp = __float_as_int(red[w * 4 + 1]);
+        OQ = sel_max(OQ, red[w * 4 + 2]);
+        if (wm > R || (wm == R && wp < mpos)) { R = wm; mpos = wp; }
+      }
+      if (OQ >= R && OQ > thr) {   // (uniform) general-case candidates the queue would pop before the selection
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          __builtin_amdgcn_sched_barrier(0);
+          const int i = c * THREADS + (int)threadIdx.x;
+          if (c < ncu && q[c] > thr && (meta[c] & 7) == RN_SOFT_OVER && (q[c] > R || (q[c] == R && i < mpos))) {
+            float sc = q[c];
+            for (int j = nsel - 1; j >= (meta[c] >> 8) && sc > thr; --j)
+              sc = sc * soft_weight(bx[c], soft_box(s_selbox[j]), p.soft_scale);
+            if (!(sc > thr)) q[c] = -1.0f;
+            else {
+              pend[c][0] = sc;
+              meta[c] = (meta[c] & ~7) | RN_SOFT_EVAL;
+              if (sc > br || (sc == br && i < bp)) { br = sc; bp = i; }
+            }
+          }
+        }
+        red = s_red + par * (THREADS / 16);
+        par ^= 1;
+        const float wm = wave_max_f32(br);
+        const int wp = wave_min_i32(br == wm ? bp : 0x7fffffff);
+        if (lane == 0) {
+          red[wave * 4 + 0] = wm;
+          red[wave * 4 + 1] = __int_as_float(wp);
+        }
+        __syncthreads();
+        R = -1.0f;
+        mpos = 0x7fffffff;
+#pragma unroll
+        for (int w = 0; w < THREADS / 64; ++w) {
+          const float wm2 = red[w * 4 + 0];
+          const int wp2 = __float_as_int(red[w * 4 + 1]);
+          if (wm2 > R || (wm2 == R && wp2 < mpos)) { R = wm2; mpos = wp2; }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < p.max_det; t += blockDim.x) {
+    const bool ok = t < nsel;
+    sel_scores[(long long)list * p.max_det + t] = ok ? s_selscore[t] : 0.0f;
+    sel_boxes[(long long)list * p.max_det + t] = ok ? s_selbox[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+    sel_idx[(long long)list * p.max_det + t] = ok ? s_selidx[t] : 0;
+  }
+}
+
 // ---- merge: top max_det over K*max_det padded class results (postprocessing_ops.py:471-490)
 __global__ void __launch_bounds__(RN_PP_THREADS)
 merge_kernel(int K, int max_det, const float* __restrict__ sel_scores, const float4* __restrict__ sel_boxes,
@@ -850,25 +1131,27 @@ extern "C" int rn_rowmax_argmax(const float* scores, int64_t rows, int K, float*
 }
 
 // ------------------------------------------------------------------------------------------
-// LDS of nms_per_class_kernel.  Soft NMS keeps its state (2 KB box cache, 1 KB block maxima / leaders, one byte per
-// candidate) in the tail of the sort buffer that the single sorted chunk of at most `max_cands` keys leaves unused, or
-// behind everything when that tail is too short: *soft_off = its byte offset.
+// LDS of nms_per_class_kernel.  Soft NMS sorts its whole list (at most `max_cands` <= RN_SORT_CAP keys) as one chunk and
+// keeps its state (2 KB box cache, 1 KB block maxima / leaders, one byte per candidate) behind the other arrays:
+// *soft_off = its byte offset.  With pre_nms_top_k = 5 000 and max_det = 100 (the reference's soft-NMS configurations) that
+// is 52 KB — three lists per compute unit, the 640 lists of a batch of 8 resident at once; the sort buffer of 8 192 keys
+// (the bitonic network's power of two, before bitonic_sort_desc learnt other sizes) made it 73 KB: two per unit, two rounds.
 // Hard NMS takes its candidates in sorted chunks (1 024 first — it usually fills max_det from a few hundred — then
 // RN_HARD_CHUNK at a time): 4 096 keys = 39 KB of LDS = four lists per compute unit, where RN_SORT_CAP keys (73 KB) allowed two:
 // the 640 lists of a batch of 8 run in one round instead of two.
 #define RN_HARD_CHUNK 4096
-static size_t nms_lds_bytes(int soft, long long max_cands, int* soft_off, int* chunk_cap, int* part_off) {
-  *chunk_cap = soft ? RN_SORT_CAP : RN_HARD_CHUNK;
-  const size_t base = rn_align_up((size_t)*chunk_cap * 8 + (size_t)RN_MAX_DET * 16 + (size_t)RN_MAX_DET * 8 + 1024 + 8 + 32, 16);
+#define RN_SOFT_NC 10        // soft_nms_kernel: candidates per thread,
+#define RN_SOFT_THREADS 512  // threads per list: lists of up to 5 120 candidates, ~100 registers of state per thread
+static size_t nms_lds_bytes(int soft /* 0 hard, 1 nms_per_class_kernel's queue loop, 2 soft_nms_kernel */, long long max_cands,
+                            int max_det, int* soft_off, int* chunk_cap, int* sel_cap, int* part_off) {
+  const size_t cands = rn_align_up((size_t)(max_cands < RN_SORT_CAP ? max_cands : RN_SORT_CAP), 64);
+  *chunk_cap = soft ? (int)cands : RN_HARD_CHUNK;
+  *sel_cap = (int)rn_align_up((size_t)max_det, 4);
+  const size_t base = rn_align_up((size_t)*chunk_cap * 8 + (size_t)*sel_cap * 24 + 1024 + 8 + 32, 16);
   *soft_off = 0;
   *part_off = (int)base;
-  if (!soft) return base + 32 + 512;   // (4 x 40 520 B: four lists still fit the 160 KB of a CU)
-  const size_t cands = rn_align_up((size_t)(max_cands < RN_SORT_CAP ? max_cands : RN_SORT_CAP), 64);
-  const size_t state = rn_align_up(2048 + (size_t)RN_SORT_CAP / 64 * 8 + 16 + cands, 16);
-  if (cands * 8 + state <= (size_t)RN_SORT_CAP * 8) {
-    *soft_off = (int)(cands * 8);
-    return base;
-  }
+  if (!soft) return base + 32 + 512;   // (4 x <= 40 520 B: four lists fit the 160 KB of a CU)
+  const size_t state = soft == 2 ? 2 * (RN_SOFT_THREADS / 64) * 16 : rn_align_up(2048 + (size_t)RN_SORT_CAP / 64 * 8 + 16 + cands, 16);
   *soft_off = (int)base;
   return base + state;
 }
@@ -925,14 +1208,27 @@ static int run_nms_stage(const DetectWs& w, int B, long long cap, int K, const B
   p.iou_thr = iou_threshold;
   p.score_thr = score_threshold;
   p.cap = cap;
-  const size_t lds = nms_lds_bytes(p.soft, top_k > 0 ? (long long)top_k : cap, &p.soft_off, &p.chunk_cap, &p.part_off);
+  const long long max_cands = top_k > 0 ? (long long)top_k : cap;
+  // soft NMS: one selection per step (soft_nms_kernel) for lists of up to 5 120 candidates — every shipped configuration
+  // (pre_nms_top_k = 5 000); the queue loop of nms_per_class_kernel up to RN_SORT_CAP.  RNET_SOFT_NMS_QUEUE=1 forces the latter.
+  static const bool queue_env = [] { const char* e = getenv("RNET_SOFT_NMS_QUEUE"); return e && e[0] == '1'; }();
+  const bool stepwise = p.soft && max_cands <= (long long)RN_SOFT_NC * RN_SOFT_THREADS && !queue_env;
+  const size_t lds = nms_lds_bytes(p.soft ? (stepwise ? 2 : 1) : 0, max_cands, max_det, &p.soft_off, &p.chunk_cap, &p.sel_cap,
+                                   &p.part_off);
   // first sorted chunk of a hard-NMS list: 512 keys (round 5, same box: 1024 -> 512 keys batch-1 serving 1.571 -> 1.552 ms,
   // batch 8 3.551 -> 3.546; 256 / 128 keys 1.66 / 3.57 - 3.60: a second chunk — another radix select — too often)
   p.first_chunk = 512 < p.chunk_cap ? 512 : p.chunk_cap;
-  RN_CHECK_HIP(hipFuncSetAttribute((const void*)nms_per_class_kernel,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(nms_per_class_kernel, dim3(B * K), dim3(RN_PP_THREADS), lds, st, p, w.counts, w.keys, bs,
-                     w.sel_scores, w.sel_boxes, w.sel_idx);
+  if (stepwise) {
+    RN_CHECK_HIP(hipFuncSetAttribute((const void*)soft_nms_kernel<RN_SOFT_NC, RN_SOFT_THREADS>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((soft_nms_kernel<RN_SOFT_NC, RN_SOFT_THREADS>), dim3(B * K), dim3(RN_SOFT_THREADS), lds, st, p, w.counts,
+                       w.keys, bs, w.sel_scores, w.sel_boxes, w.sel_idx);
+  } else {
+    RN_CHECK_HIP(hipFuncSetAttribute((const void*)nms_per_class_kernel,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(nms_per_class_kernel, dim3(B * K), dim3(RN_PP_THREADS), lds, st, p, w.counts, w.keys, bs,
+                       w.sel_scores, w.sel_boxes, w.sel_idx);
+  }
   RN_CHECK_LAUNCH();
   const size_t lds_m = (size_t)RN_MAX_DET * 8 + 1024 + 8 + 32;
   hipLaunchKernelGGL(merge_kernel, dim3(B), dim3(RN_PP_THREADS), lds_m, st, K, max_det, w.sel_scores,
