@@ -246,3 +246,52 @@ def test_soft_nms_kernel_vs_independent_transcription(cuda):
             want_b = np.stack([boxes[b, m[3], m[2]] for m in merged])
             np.testing.assert_array_equal(out["boxes"][b, :v], np.clip(want_b, 0.0, 1.0))
             assert (out["scores"][b, v:] == -1).all() and (out["classes"][b, v:] == -1).all()
+
+
+def _soft_lists(rng, B, n, K, kind):
+    """candidate lists [B,n,K] / [B,n,K,4] for the soft-NMS tests below"""
+    scores = np.zeros((B, n, K), np.float32)
+    boxes = np.zeros((B, n, K, 4), np.float32)
+    for b in range(B):
+        for c in range(K):
+            if kind == "pile":      # every box overlaps every other one: each selection decays the whole list
+                ctr = rng.uniform(0.3, 0.7, 2)
+                cy, cx = ctr[0] + rng.normal(0, 0.02, n), ctr[1] + rng.normal(0, 0.02, n)
+                h, w = rng.uniform(0.15, 0.3, n), rng.uniform(0.15, 0.3, n)
+                sc = rng.uniform(0.3, 0.99, n)
+            else:                    # clusters of a few dozen boxes and a spread background
+                ctr = rng.uniform(0.1, 0.9, (max(n // 40, 1), 2))
+                pick = rng.integers(0, len(ctr), n)
+                cy, cx = ctr[pick, 0] + rng.normal(0, 0.015, n), ctr[pick, 1] + rng.normal(0, 0.015, n)
+                h, w = rng.uniform(0.04, 0.12, n), rng.uniform(0.04, 0.12, n)
+                sc = rng.uniform(0.02, 0.95, n)
+            bx = np.stack([cy - h / 2, cx - w / 2, cy + h / 2, cx + w / 2], -1)
+            boxes[b, :, c] = bx.astype(np.float32)
+            scores[b, :, c] = sc.astype(np.float32)
+    return scores, boxes
+
+
+@pytest.mark.parametrize("kind,n,md", [("pile", 700, 100), ("clusters", 3000, 100), ("clusters", 5120, 64),
+                                        ("clusters", 6000, 100), ("pile", 8192, 40)])
+def test_soft_nms_step_kernel_and_queue_fallback(cuda, kind, n, md):
+    """`rn_nms_per_class` in the reference's soft shape against the oracle's queue (rn_o_nms_v5), bit for bit, on both device
+    forms: lists of up to 5 120 candidates go through soft_nms_kernel (one selection per step; "pile" drives every candidate
+    past four pending weights, the general case of that kernel), longer ones (up to the 8 192 of the sort buffer, here 6 000
+    and 8 192 — a bitonic sort of a size that is not a power of two, too) through the queue loop of nms_per_class_kernel.
+    A few boxes come with their corners swapped: TF's IOU orders them, the output returns them as they came."""
+    from retinanet.model.layers import GenerateDetections
+    rng = np.random.default_rng(n + md)
+    B, K = 2, 3
+    scores, boxes = _soft_lists(rng, B, n, K, kind)
+    sw = rng.random((B, n, K)) < 0.05
+    boxes[sw] = boxes[sw][:, [2, 1, 0, 3]]
+    sw = rng.random((B, n, K)) < 0.05
+    boxes[sw] = boxes[sw][:, [0, 3, 2, 1]]
+    scores[0, : n // 8, 1] = scores[0, 0, 1]          # a run of equal scores: the queue's order is (score, position)
+    gen = GenerateDetections(iou_threshold=0.5, score_threshold=0.05, max_detections=md, soft_nms_sigma=0.5,
+                             num_classes=K, mode="PerClassSoftNMS")
+    out = {k: v.cpu().numpy() for k, v in gen({"scores": torch.from_numpy(scores).to(cuda),
+                                               "boxes": torch.from_numpy(boxes).to(cuda)}).items()}
+    wb, ws, wc, wv = o.per_class_nms(scores, boxes, 0.5, 0.05, 0.5, md)
+    _check(out, wb, ws, wc, wv)
+    assert wv.min() > 0
