@@ -516,7 +516,7 @@ extern "C" int rn_depthwise_conv2d_nhwc_wgrad(const rn_dw_problem* p, float* dw,
 // ---- squeeze-and-excitation --------------------------------------------------------------------
 // pooled[n][c] = bf16(mean over H*W)  (tf.reduce_mean on a bf16 tensor yields bf16)
 // grid (channel slabs, N, HW chunks): partial[chunk][n][c] = sum over the chunk's pixels (deterministic);
-// se_pool_final_kernel adds the chunks in order, divides and rounds.
+// se_mid_fwd_kernel adds the chunks in order, divides and rounds.
 __global__ void __launch_bounds__(256)
 se_pool_kernel(const uint4* __restrict__ x, int HW, int C8, int rows_per_chunk, float* __restrict__ partial) {
   const int n = blockIdx.y, slab = blockIdx.x;  // 8 channel groups (64 channels) per block
@@ -545,18 +545,6 @@ se_pool_kernel(const uint4* __restrict__ x, int HW, int C8, int rows_per_chunk, 
   }
 }
 
-// out[i] = round_bf16?(scale * sum over chunks of partial[chunk][i])
-__global__ void __launch_bounds__(256)
-se_pool_final_kernel(const float* __restrict__ partial, long long n, int chunks, float scale, int round_bf16,
-                     float* __restrict__ out) {
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    float t = 0.0f;
-    for (int c = 0; c < chunks; ++c) t += partial[(long long)c * n + i];
-    t *= scale;
-    out[i] = round_bf16 ? rn_bf16_to_f32(rn_f32_to_bf16(t)) : t;
-  }
-}
-
 static int se_chunks(int HW, int* rows_per_chunk) {
   int chunks = (HW + 1023) / 1024;            // >= 1024 pixels per chunk
   if (chunks > 32) chunks = 32;
@@ -567,44 +555,79 @@ static int se_chunks(int HW, int* rows_per_chunk) {
   return (HW + rows - 1) / rows;
 }
 
-// gate[n][c] = bf16(sigmoid(W2 . bf16(swish(W1 . pooled + b1)) + b2)) in two launches that fill the chip
-// (the first version ran one workgroup per image: 32 workgroups, up to 0.4 ms per call):
-//   se_fc1: one wavefront per (image, reduced channel j): h1 = bf16(W1[j] . pooled[n] + b1[j]), a = bf16(swish(h1))
-//   se_fc2: one thread per (image, channel c): gate = bf16(sigmoid(bf16(W2[c] . a[n] + b2[c])))
-__global__ void __launch_bounds__(256)
-se_fc1_kernel(const float* __restrict__ pooled, const uint16_t* __restrict__ w1 /*[se][C]*/,
-              const float* __restrict__ b1, int N, int C, int se, float* __restrict__ h1 /*[N][se]*/,
-              float* __restrict__ av /*[N][se]*/) {
-  const int lane = threadIdx.x & 63;
-  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);   // (n, j)
-  if (item >= N * se) return;
-  const int n = item / se, j = item - n * se;
-  const float* p = pooled + (long long)n * C;
-  const uint16_t* w = w1 + (long long)j * C;
-  float acc = 0.0f;
-  for (int c = lane; c < C; c += 64) acc += p[c] * rn_bf16_to_f32(w[c]);
-  acc = rn_wave_sum(acc);
-  if (lane == 0) {
-    float v = rn_bf16_to_f32(rn_f32_to_bf16(acc + b1[j]));
-    h1[item] = v;
-    v = v / (1.0f + __expf(-v));
-    av[item] = rn_bf16_to_f32(rn_f32_to_bf16(v));
+// pooled[n][c] = bf16(sum of the chunk partials / HW), gate[n][c] = bf16(sigmoid(W2 . bf16(swish(W1 . pooled + b1)) + b2)):
+// ONE launch, one workgroup of 1 024 threads per image — per-image work of a few hundred KFLOP.  pooled -> LDS (and the
+// state buffer, for the backward pass); fc1 with a wavefront per reduced channel j: h1 = bf16(W1[j] . pooled + b1[j]),
+// a = bf16(swish(h1)); fc2 with a thread per channel.  (Until round 6 three launches — chunk sums, fc1, fc2: 5 - 7 us each
+// plus two gaps, in a block that runs 26 times per EfficientNet-B3 pass; the very first version, one workgroup of 256
+// threads per image doing everything with a thread per output, took up to 0.4 ms.)  C + se floats of LDS: the callers
+// check the 64 KB.
+#define SE_MID_THREADS 1024
+// grid (N, S): the S workgroups of an image each compute pooled and fc1 in full (cheap, coalesced; a grid of N workgroups
+// alone left most of the chip idle behind the serial j-loop of fc2) and fc2 for their own slice of `cps` channels
+__global__ void __launch_bounds__(SE_MID_THREADS)
+se_mid_fwd_kernel(const float* __restrict__ partial, int chunks, float scale, const uint16_t* __restrict__ w1,
+                  const float* __restrict__ b1, const uint16_t* __restrict__ w2, const float* __restrict__ b2, int N, int C,
+                  int se, int cps, float* __restrict__ pooled, float* __restrict__ gate, float* __restrict__ h1,
+                  float* __restrict__ av) {
+  extern __shared__ float se_lds[];   // pooled[C] | a[se]
+  float* s_p = se_lds;
+  float* s_a = se_lds + C;
+  const int n = blockIdx.x, split = blockIdx.y;
+  const long long nel = (long long)N * C;
+  for (int c = threadIdx.x; c < C; c += SE_MID_THREADS) {
+    float t = 0.0f;
+    for (int k = 0; k < chunks; ++k) t += partial[(long long)k * nel + (long long)n * C + c];
+    t *= scale;
+    t = rn_bf16_to_f32(rn_f32_to_bf16(t));
+    s_p[c] = t;
+    if (split == 0) pooled[(long long)n * C + c] = t;
+  }
+  __syncthreads();
+  // fc1: a wavefront per reduced channel j, 16-byte loads of W1[j] (8 weights per lane and load, all loads independent)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int j = wave; j < se; j += SE_MID_THREADS / 64) {
+    const uint4* w = (const uint4*)(w1 + (long long)j * C);
+    float acc = 0.0f;
+    for (int c8 = lane; c8 < (C >> 3); c8 += 64) {
+      const bf8 wv = unpack8(w[c8]);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc += s_p[c8 * 8 + q] * wv.v[q];
+    }
+    acc = rn_wave_sum(acc);
+    if (lane == 0) {
+      float v = rn_bf16_to_f32(rn_f32_to_bf16(acc + b1[j]));
+      if (split == 0) h1[(long long)n * se + j] = v;
+      v = v / (1.0f + __expf(-v));
+      v = rn_bf16_to_f32(rn_f32_to_bf16(v));
+      if (split == 0) av[(long long)n * se + j] = v;
+      s_a[j] = v;
+    }
+  }
+  __syncthreads();
+  // fc2: a wavefront per channel of the slice — W2[c] is one contiguous row of se weights, read by the lanes side by side
+  // (a thread per channel walked its row with se dependent-latency 2-byte loads: 10 - 80 us per launch)
+  const int c1 = (split + 1) * cps < C ? (split + 1) * cps : C;
+  for (int c = split * cps + wave; c < c1; c += SE_MID_THREADS / 64) {
+    const uint16_t* w = w2 + (long long)c * se;
+    float acc = 0.0f;
+    for (int j = lane; j < se; j += 64) acc += s_a[j] * rn_bf16_to_f32(w[j]);
+    acc = rn_wave_sum(acc);
+    if (lane == 0) {
+      float v = rn_bf16_to_f32(rn_f32_to_bf16(acc + b2[c]));
+      v = 1.0f / (1.0f + __expf(-v));
+      gate[(long long)n * C + c] = rn_bf16_to_f32(rn_f32_to_bf16(v));
+    }
   }
 }
-
-__global__ void __launch_bounds__(256)
-se_fc2_kernel(const float* __restrict__ av /*[N][se]*/, const uint16_t* __restrict__ w2 /*[C][se]*/,
-              const float* __restrict__ b2, int N, int C, int se, float* __restrict__ gate /*[N][C]*/) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N * C) return;
-  const int n = i / C, c = i - n * C;
-  const float* a = av + (long long)n * se;
-  const uint16_t* w = w2 + (long long)c * se;
-  float acc = 0.0f;
-  for (int j = 0; j < se; ++j) acc += a[j] * rn_bf16_to_f32(w[j]);
-  float v = rn_bf16_to_f32(rn_f32_to_bf16(acc + b2[c]));
-  v = 1.0f / (1.0f + __expf(-v));
-  gate[i] = rn_bf16_to_f32(rn_f32_to_bf16(v));
+// channels per workgroup of the two per-image kernels: enough workgroups to spread over the chip, slices of >= 64 channels
+static int se_mid_cps(int N, int C, int* splits) {
+  int S = (255 + N) / N;
+  if (S > (C + 63) / 64) S = (C + 63) / 64;
+  if (S < 1) S = 1;
+  int cps = ((C + S - 1) / S + 63) / 64 * 64;
+  *splits = (C + cps - 1) / cps;
+  return cps;
 }
 
 __global__ void __launch_bounds__(DW_THREADS)
@@ -639,17 +662,13 @@ static int se_forward(const void* x, void* y, int N, int HW, int C, const void* 
     hipLaunchKernelGGL(se_pool_kernel, dim3((C + 63) / 64, N, chunks), dim3(256), 0, st, (const uint4*)x, HW, C / 8,
                        rows, partial);
     RN_CHECK_LAUNCH();
-    const long long nel = (long long)N * C;
-    hipLaunchKernelGGL(se_pool_final_kernel, dim3((unsigned)rn_cdiv(nel, 256)), dim3(256), 0, st, partial, nel, chunks,
-                       1.0f / (float)HW, 1, pooled);
+    int splits = 1;
+    const int cps = se_mid_cps(N, C, &splits);
+    hipLaunchKernelGGL(se_mid_fwd_kernel, dim3(N, splits), dim3(SE_MID_THREADS), (size_t)(C + se) * sizeof(float), st, partial,
+                       chunks, 1.0f / (float)HW, (const uint16_t*)w_reduce, b_reduce, (const uint16_t*)w_expand, b_expand, N, C,
+                       se, cps, pooled, gate, h1, av);
     RN_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(se_fc1_kernel, dim3((unsigned)rn_cdiv((long long)N * se, 4)), dim3(256), 0, st, pooled,
-                     (const uint16_t*)w_reduce, b_reduce, N, C, se, h1, av);
-  RN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(se_fc2_kernel, dim3((unsigned)rn_cdiv((long long)N * C, 256)), dim3(256), 0, st, av,
-                     (const uint16_t*)w_expand, b_expand, N, C, se, gate);
-  RN_CHECK_LAUNCH();
   const long long total = (long long)N * HW * (C / 8);
   long long blocks = rn_cdiv(total, DW_THREADS);
   if (blocks > 16384) blocks = 16384;
@@ -719,41 +738,72 @@ se_bwd_pool_kernel(const uint4* __restrict__ x, const uint4* __restrict__ dy, in
   }
 }
 
-// dgate -> dh2[n][c] (thread per element), dh1[n][j] (wavefront per element), dp[n][c] (thread per element)
-__global__ void __launch_bounds__(256)
-se_bwd_dh2_kernel(const float* __restrict__ state, const float* __restrict__ dgate, int N, int C,
-                  float* __restrict__ dh2) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N * C) return;
-  const float g = state[(size_t)N * C + i];
-  dh2[i] = dgate[i] * g * (1.0f - g);
-}
-__global__ void __launch_bounds__(256)
-se_bwd_dh1_kernel(const float* __restrict__ state, const float* __restrict__ dh2, const uint16_t* __restrict__ w2,
-                  int N, int C, int se, float* __restrict__ dh1) {
-  const int lane = threadIdx.x & 63;
-  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);   // (n, j)
-  if (item >= N * se) return;
-  const int n = item / se, j = item - n * se;
-  const float* d = dh2 + (long long)n * C;
-  float acc = 0.0f;
-  for (int c = lane; c < C; c += 64) acc += d[c] * rn_bf16_to_f32(w2[(long long)c * se + j]);
-  acc = rn_wave_sum(acc);
-  if (lane == 0) {
-    const float u = state[(size_t)2 * N * C + item];   // h1
-    const float sg = 1.0f / (1.0f + __expf(-u));
-    dh1[item] = acc * (sg + u * sg * (1.0f - sg));
+// dgate[n][c] = sum of the chunk partials; dh2 = dgate * g * (1 - g) (thread per channel); dh1[n][j] = (W2^T dh2)[j] *
+// swish'(h1) (wavefront per reduced channel); dp[n][c] = (W1^T dh1)[c] (thread per channel): one launch, a workgroup of
+// 1 024 threads per image (see se_mid_fwd_kernel; four launches until round 6)
+__global__ void __launch_bounds__(SE_MID_THREADS)
+se_mid_bwd_kernel(const float* __restrict__ partial, int chunks, const float* __restrict__ state, const uint16_t* __restrict__ w1,
+                  const uint16_t* __restrict__ w2, int N, int C, int se, int cps, float* __restrict__ dh2,
+                  float* __restrict__ dh1, float* __restrict__ dp) {
+  extern __shared__ float se_lds[];   // dh2[C] | dh1[se] | shares[16][se]
+  float* s_d2 = se_lds;
+  float* s_d1 = se_lds + C;
+  const int n = blockIdx.x, split = blockIdx.y;   // (N, S) as in se_mid_fwd_kernel: dh2 / dh1 in full, dp for a slice
+  const long long nel = (long long)N * C;
+  for (int c = threadIdx.x; c < C; c += SE_MID_THREADS) {
+    float t = 0.0f;
+    for (int k = 0; k < chunks; ++k) t += partial[(long long)k * nel + (long long)n * C + c];
+    const float g = state[nel + (long long)n * C + c];
+    const float d = t * g * (1.0f - g);
+    s_d2[c] = d;
+    if (split == 0) dh2[(long long)n * C + c] = d;
   }
-}
-__global__ void __launch_bounds__(256)
-se_bwd_dp_kernel(const float* __restrict__ dh1, const uint16_t* __restrict__ w1, int N, int C, int se,
-                 float* __restrict__ dp) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N * C) return;
-  const int n = i / C, c = i - n * C;
-  float acc = 0.0f;
-  for (int j = 0; j < se; ++j) acc += dh1[(long long)n * se + j] * rn_bf16_to_f32(w1[(long long)j * C + c]);
-  dp[i] = acc;
+  __syncthreads();
+  // dh1 = W2^T dh2: wavefront w walks the rows c = w, w + 16, ... of W2 (contiguous, the lanes side by side over j) and keeps
+  // its share of the sum for the lane's j; the 16 shares are added in wavefront order (deterministic)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* s_part = s_d1 + se;   // [16][se]
+  for (int j0 = 0; j0 < se; j0 += 64) {
+    const int j = j0 + lane;
+    float acc = 0.0f;
+    if (j < se)
+      for (int c = wave; c < C; c += SE_MID_THREADS / 64) acc += s_d2[c] * rn_bf16_to_f32(w2[(long long)c * se + j]);
+    if (j < se) s_part[wave * se + j] = acc;
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < se; j += SE_MID_THREADS) {
+    float acc = 0.0f;
+    for (int w = 0; w < SE_MID_THREADS / 64; ++w) acc += s_part[w * se + j];
+    const float u = state[2 * nel + (long long)n * se + j];   // h1
+    const float sg = 1.0f / (1.0f + __expf(-u));
+    const float d = acc * (sg + u * sg * (1.0f - sg));
+    if (split == 0) dh1[(long long)n * se + j] = d;
+    s_d1[j] = d;
+  }
+  __syncthreads();
+  // dp = W1^T dh1 for the slice: a thread per pair of channels, W1[j] read side by side (4 bytes per lane), 8 rows in flight
+  const int c1 = (split + 1) * cps < C ? (split + 1) * cps : C;
+  for (int c = split * cps + 2 * threadIdx.x; c < c1; c += 2 * SE_MID_THREADS) {
+    float a0 = 0.0f, a1 = 0.0f;
+    int j = 0;
+    for (; j + 8 <= se; j += 8) {
+      unsigned u[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) u[k] = *(const unsigned*)(w1 + (long long)(j + k) * C + c);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        a0 += s_d1[j + k] * rn_bf16_to_f32((uint16_t)(u[k] & 0xffffu));
+        a1 += s_d1[j + k] * rn_bf16_to_f32((uint16_t)(u[k] >> 16));
+      }
+    }
+    for (; j < se; ++j) {
+      const unsigned u = *(const unsigned*)(w1 + (long long)j * C + c);
+      a0 += s_d1[j] * rn_bf16_to_f32((uint16_t)(u & 0xffffu));
+      a1 += s_d1[j] * rn_bf16_to_f32((uint16_t)(u >> 16));
+    }
+    dp[(long long)n * C + c] = a0;
+    dp[(long long)n * C + c + 1] = a1;
+  }
 }
 
 // parameter gradients: sums over the N images (thread per element, fixed order)
@@ -812,15 +862,14 @@ extern "C" int rn_squeeze_excite_bwd(const void* x, const void* dy, void* dx, in
                                      const void* w_expand, int se, const void* state, float* dw1, float* db1,
                                      float* dw2, float* db2, void* workspace, size_t workspace_bytes, void* stream) {
   RN_CHECK_ARG(x && dy && dx && w_reduce && w_expand && state && dw1 && db1 && dw2 && db2 && N > 0 && HW > 0 &&
-                   C % 8 == 0 && se > 0 && se <= C && (size_t)(C + se) * 4 <= 64 * 1024,
+                   C % 8 == 0 && se > 0 && se <= C && (size_t)(C + 17 * se) * 4 <= 64 * 1024,
                "rn_squeeze_excite_bwd: bad argument");
   if (!workspace || workspace_bytes < rn_se_workspace_bytes(N, C)) {
     rn_set_error("rn_squeeze_excite_bwd: workspace too small");
     return RN_ENOMEM;
   }
   hipStream_t st = (hipStream_t)stream;
-  float* dgate = (float*)workspace;
-  float* dh2 = dgate + (size_t)N * C;
+  float* dh2 = (float*)workspace + (size_t)N * C;   // (the first [N][C] slot held dgate until the per-image steps were one launch)
   float* dp = dh2 + (size_t)N * C;
   float* dh1 = dp + (size_t)N * C;
   const float* stf = (const float*)state;
@@ -831,19 +880,12 @@ extern "C" int rn_squeeze_excite_bwd(const void* x, const void* dy, void* dx, in
     hipLaunchKernelGGL(se_bwd_pool_kernel, dim3((C + 63) / 64, N, chunks), dim3(256), 0, st, (const uint4*)x,
                        (const uint4*)dy, HW, C / 8, rows, partial);
     RN_CHECK_LAUNCH();
-    const long long nel = (long long)N * C;
-    hipLaunchKernelGGL(se_pool_final_kernel, dim3((unsigned)rn_cdiv(nel, 256)), dim3(256), 0, st, partial, nel, chunks,
-                       1.0f, 0, dgate);
+    int splits = 1;
+    const int cps = se_mid_cps(N, C, &splits);
+    hipLaunchKernelGGL(se_mid_bwd_kernel, dim3(N, splits), dim3(SE_MID_THREADS), (size_t)(C + 17 * se) * sizeof(float), st, partial,
+                       chunks, stf, (const uint16_t*)w_reduce, (const uint16_t*)w_expand, N, C, se, cps, dh2, dh1, dp);
     RN_CHECK_LAUNCH();
   }
-  const unsigned bnc = (unsigned)rn_cdiv((long long)N * C, 256);
-  hipLaunchKernelGGL(se_bwd_dh2_kernel, dim3(bnc), dim3(256), 0, st, stf, dgate, N, C, dh2);
-  RN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(se_bwd_dh1_kernel, dim3((unsigned)rn_cdiv((long long)N * se, 4)), dim3(256), 0, st, stf, dh2,
-                     (const uint16_t*)w_expand, N, C, se, dh1);
-  RN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(se_bwd_dp_kernel, dim3(bnc), dim3(256), 0, st, dh1, (const uint16_t*)w_reduce, N, C, se, dp);
-  RN_CHECK_LAUNCH();
   const long long nel = 2ll * se * C + se + C;
   hipLaunchKernelGGL(se_bwd_wgrad_kernel, dim3((unsigned)rn_cdiv(nel, 256)), dim3(256), 0, st, stf, dh2, dh1, N, C, se,
                      dw1, db1, dw2, db2);

@@ -400,6 +400,7 @@ class Executor:
         loss = None
         for _ in range(int(num_steps)):
             loss = self._train_step(next(iterator))
+        self._engine.finish_step()      # loss scale / optimizer.iterations of the last step (read right after this call)
         keys = sorted(k for k, v in loss.items() if hasattr(v, "item") or isinstance(v, (int, float)))
         packed = torch.stack([torch.as_tensor(_f(loss[k]) if not hasattr(loss[k], "reshape") else loss[k],
                                               dtype=torch.float32, device=self._model.device).reshape(())

@@ -426,6 +426,7 @@ class TrainEngine:
         with torch.cuda.device(self.dev):
             self.store_to_model(use_ema=False)
             torch.cuda.synchronize()
+        self.finish_step()
         extra = {"SGD/iter": np.asarray(self.step_count, dtype=np.int64)}
         if self.loss_scale:   # Keras' LossScaleOptimizer checkpoints its dynamic state the same way
             extra["loss_scale/current_loss_scale"] = np.asarray(self.loss_scale["scale"], dtype=np.float32)
@@ -443,6 +444,7 @@ class TrainEngine:
             self._fold_frozen()
             self.load_optimizer_slots(slots)
             it = self.model.loaded_extras.get("SGD/iter")
+            self._ls_pending = False
             self.step_count = int(it) if it is not None else 0
             if self.model.optimizer is not None:
                 self.model.optimizer.iterations = self.step_count
@@ -2137,16 +2139,42 @@ class TrainEngine:
 
     def _update_loss_scale(self):
         """tf.keras.mixed_precision.LossScaleOptimizer(dynamic=True) (optimizers/builder.py:56-64): halve the scale
-        when a step's gradients were not finite (the step was dropped), double it after `growth_steps` good steps."""
+        when a step's gradients were not finite (the step was dropped), double it after `growth_steps` good steps.
+
+        The SGD kernel drops the update itself (skip pointer); what the HOST needs — the next loss scale, whether
+        optimizer.iterations advances — it needs only when the NEXT step reaches its loss: the flag goes to pinned
+        memory with an asynchronous copy here and is applied by _resolve_loss_scale(), which the next train_step calls
+        after it has enqueued its forward pass (or finish_step(), for whoever reads the counters in between).  Reading
+        it here (`.item()`) drained the queue at the end of every mixed_float16 step: the device then idled ~1 ms at the
+        head of the next step until the host had launched its first kernels (tools/trace_gaps.py on configs[4])."""
+        if getattr(self, "_ls_host", None) is None:
+            self._ls_host = torch.zeros((1,), dtype=torch.float32, pin_memory=True)
+            self._ls_event = torch.cuda.Event()
+        self._ls_host.copy_(self.G[1:2], non_blocking=True)
+        self._ls_event.record(torch.cuda.current_stream(self.dev))
+        self._ls_pending = True
+
+    def _resolve_loss_scale(self):
+        if not getattr(self, "_ls_pending", False):
+            return
+        self._ls_pending = False
+        self._ls_event.synchronize()
         ls = self.loss_scale
-        bad = float(self.G[1].item()) != 0.0       # host sync: mixed_float16 configs only
+        bad = float(self._ls_host[0]) != 0.0
         ls["skipped"] = bad
         if bad:
             ls["scale"], ls["good"] = max(ls["scale"] / 2.0, 1.0), 0
+            self.step_count -= 1              # a dropped step does not advance optimizer.iterations
+            self.model.optimizer.iterations = self.step_count
         else:
             ls["good"] += 1
             if ls["good"] >= ls["growth_steps"]:
                 ls["scale"], ls["good"] = ls["scale"] * 2.0, 0
+
+    def finish_step(self):
+        """Host-side state of the last train_step (loss scale, optimizer.iterations) brought up to date: call before
+        reading them between steps (the executor does after each execution; state_dict does)."""
+        self._resolve_loss_scale()
 
     def train_step(self, images, targets):
         """(images f32[B,H,W,3], targets from LabelEncoder.encode_batch) -> the loss dict of Executor._train_step
@@ -2159,11 +2187,7 @@ class TrainEngine:
             self.loss_scale = dict(scale=float(opt.initial_loss_scale), good=0, growth_steps=int(opt.loss_scale_growth_steps),
                                    skipped=False)
         with torch.cuda.device(self.dev):
-            step = self.step_count
             alpha = cfg.weight_decay_alpha if cfg.use_weight_decay else 0.0
-            scale = self.loss_scale["scale"] if self.loss_scale else 1.0
-            self._step_args = dict(wdc=alpha / self.world, alpha=alpha, unscale=1.0 / scale,
-                                   clip=float(opt.clipnorm) if opt.clipnorm else 0.0)
             self._prepack_dgrad_weights()
             self._small_msgs = 0
             self._c2_local, self._c2_sent, self.c2_normalizer = None, False, None
@@ -2175,6 +2199,11 @@ class TrainEngine:
                                                      _C.current_stream()), "num-positives + 1")
             preds = self.forward(images)
             self._c2_local = None
+            self._resolve_loss_scale()      # the previous step's "gradients not finite" flag: long since on the host
+            step = self.step_count
+            scale = self.loss_scale["scale"] if self.loss_scale else 1.0
+            self._step_args = dict(wdc=alpha / self.world, alpha=alpha, unscale=1.0 / scale,
+                                   clip=float(opt.clipnorm) if opt.clipnorm else 0.0)
             # per_replica_loss = total / replicas, times the loss scale under mixed_float16 (executor.py:421-425)
             loss = self.model.loss(targets, preds, compute_grads=True, grad_scale=scale / self.world,
                                    grads_bf16=self.loss_grad_buffers(), normalizer=self.c2_normalizer)
@@ -2190,8 +2219,7 @@ class TrainEngine:
                                 opt.ema_decay(step) if opt.use_moving_average else None, nesterov=opt.nesterov,
                                 overlapped=overlapped)
             self.syncbn_messages_per_step = self._small_msgs if self.sync_bn else 0
-            if not (self.loss_scale and self.loss_scale["skipped"]):
-                self.step_count += 1          # a dropped step does not advance optimizer.iterations
+            self.step_count += 1              # (taken back by _resolve_loss_scale when the step turns out dropped)
             opt.iterations = self.step_count
         out = dict(loss)
         out["total-loss"] = loss["weighted-loss"]                # executor.py:414-419

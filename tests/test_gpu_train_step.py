@@ -354,3 +354,40 @@ def test_loss_decreases_over_steps(cuda):
     eng.store_to_model(use_ema=False)   # back to the Keras-named variables + inference engine
     preds = model(images, training=False)
     assert torch.isfinite(preds["class-predictions"]["3"]).all()
+
+
+def test_dynamic_loss_scale_is_applied_one_forward_pass_later(cuda):
+    """mixed_float16 (optimizers/builder.py:56-64, LossScaleOptimizer(dynamic=True)): a step whose gradients are not
+    finite is dropped ON THE DEVICE (weights, momentum untouched); the host learns about it when the next step has
+    enqueued its forward pass (train_engine._resolve_loss_scale) or at finish_step(): the scale halves, the step
+    counter does not advance, and the following step runs with the halved scale; `growth_steps` good steps double it."""
+    p, model, eng, targets, images = _setup(cuda, 128, 2, True, seed=5, precision="mixed_float16")
+    images = images.to(cuda)
+    opt = model.optimizer
+    assert opt.dynamic_loss_scale and eng.f16
+    eng.train_step(images, targets)
+    eng.finish_step()
+    s0 = eng.loss_scale["scale"]
+    assert eng.step_count == 1 and not eng.loss_scale["skipped"] and eng.loss_scale["good"] == 1
+    # an overflowing step: a loss scale far beyond the half range makes the scaled upstream gradients infinite
+    eng.loss_scale["scale"] = 2.0 ** 40
+    before = eng.P.clone()
+    out = eng.train_step(images, targets)
+    assert eng.step_count == 2 and eng._ls_pending            # optimistic until the flag is looked at
+    assert torch.isfinite(out["weighted-loss"])               # the forward pass and the loss are not scaled
+    assert torch.equal(eng.P, before)                         # ... and the device dropped the update by itself
+    eng.finish_step()
+    assert eng.loss_scale["skipped"] and eng.loss_scale["scale"] == 2.0 ** 39 and eng.loss_scale["good"] == 0
+    assert eng.step_count == 1 and opt.iterations == 1
+    # the next step picks the resolved scale up by itself (no finish_step in between): run until the scale fits again
+    eng.loss_scale["scale"] = s0 * 2.0 ** 30
+    eng.train_step(images, targets)                           # overflows again
+    eng.train_step(images, targets)                           # resolves the step before: halved
+    assert eng.loss_scale["scale"] == s0 * 2.0 ** 29 and eng.loss_scale["skipped"]
+    eng.finish_step()
+    eng.loss_scale["scale"], eng.loss_scale["good"] = s0, eng.loss_scale["growth_steps"] - 1
+    n = eng.step_count
+    eng.train_step(images, targets)
+    eng.finish_step()
+    assert eng.step_count == n + 1 and eng.loss_scale["scale"] == 2 * s0 and eng.loss_scale["good"] == 0
+    assert not torch.equal(eng.P, before)

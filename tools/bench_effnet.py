@@ -35,10 +35,21 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         out = eng.train_step(images, enc.encode_batch(gb, gc, cnt))
+        th = time.perf_counter() - t0          # host time to enqueue the step
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if it >= 2:
-            print("train step %.1f ms -> %.1f img/s  loss %.4f" % (dt * 1e3, a.batch / dt, out["weighted-loss"].item()))
+            print("train step %.1f ms -> %.1f img/s  loss %.4f  (host enqueue %.1f ms)"
+                  % (dt * 1e3, a.batch / dt, out["weighted-loss"].item(), th * 1e3))
+    # back to back, as bench.py's extra.config4 times it (no device sync between the steps)
+    targets = enc.encode_batch(gb, gc, cnt)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(a.iters):
+        out = eng.train_step(images, targets)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.iters
+    print("train, %d steps back to back: %.2f ms per step -> %.1f img/s" % (a.iters, dt * 1e3, a.batch / dt))
     del eng
     torch.cuda.empty_cache()
     bi = ModelBuilder(p, "val", device=dev, seed=1)
