@@ -121,6 +121,7 @@ struct BnSegDev {
   const float* gamma; const float* beta; float* moving_mean; float* moving_var; float* dgamma; float* dbeta;
   long long P;
   int C, dres_accumulate, chunks, rows_per_chunk;
+  int slab_groups, nslab;   // bn_colreduce_kernel: 8-channel groups per workgroup slab, slabs per row (bn_slab_plan)
   const float* sample_scale; long long rows_per_sample;
   unsigned char* mask;   // one bit per element: act'(z) != 0 (written by bn_apply, read by the G_MASK backward passes)
   float* colsum;         // rn_bn_segment.dy_colsum_partial: per-chunk column sums of the stored dy (bn_bwd_apply), or null
@@ -141,16 +142,22 @@ struct BnArgs {
 #define BN_KS_CHUNKS 512    // segments with more partial rows than this are split, ~256 rows per part
 
 // mode 0: (sum y, sum y^2); mode 1: (sum g, sum g*xhat), g = dz*mask(z), xhat = (y-mean)*invstd
+// A workgroup = G channel groups (8 channels, 16 bytes each) x RL = 256 / G row lanes of one slab of the rows of its chunk.
+// G is chosen per segment (bn_slab_plan): until round 6 it was 8 — 64-channel slabs — and the channel counts of
+// EfficientNet (144, 288, 816, 1 392; 24 ... 232 behind the projection convs) left the last slab of every row with 25 - 75 %
+// of its lanes dead: the swish form of this kernel is VALU-bound (8 v_exp + 8 v_rcp + ~130 other instructions per 16 bytes
+// of y and dz), so dead lanes were time.
 template <int G>   // G < 0: mode 0 (forward statistics); else the gradient gate of mode 1
 __global__ void __launch_bounds__(TR_THREADS) bn_colreduce_kernel(const BnArgs a) {
   const BnSegDev& s = a.seg[blockIdx.z];
   const int chunk = blockIdx.x;
-  const int slab = blockIdx.y;  // 64-channel slab
-  if (chunk >= s.chunks || slab * 64 >= s.C) return;
+  const int slab = blockIdx.y;
+  if (chunk >= s.chunks || slab >= s.nslab) return;
   const int C8 = s.C >> 3;
-  const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;  // 8 channel groups x 32 row lanes
-  const int c8 = slab * 8 + cg;
-  const bool live = c8 < C8;
+  const int SG = s.slab_groups, RL = TR_THREADS / SG;
+  const int rl = threadIdx.x / SG, cg = threadIdx.x - rl * SG;
+  const int c8 = slab * SG + cg;
+  const bool live = c8 < C8 && rl < RL;
   const long long r0 = (long long)chunk * s.rows_per_chunk;
   long long r1 = r0 + s.rows_per_chunk;
   if (r1 > s.P) r1 = s.P;
@@ -168,7 +175,7 @@ __global__ void __launch_bounds__(TR_THREADS) bn_colreduce_kernel(const BnArgs a
     }
   }
   if (live) {
-    for (long long r = r0 + rl; r < r1; r += 32) {
+    for (long long r = r0 + rl; r < r1; r += RL) {
       const long long o = r * C8 + c8;
       const bf8 y = unpack8(s.y[o]);
       if (G < 0) {
@@ -198,19 +205,54 @@ __global__ void __launch_bounds__(TR_THREADS) bn_colreduce_kernel(const BnArgs a
       }
     }
   }
-  __shared__ float red[2][32][65];
+  // [which][row lane][SG * 8 + 1]: RL * (SG * 8 + 1) <= 256 / SG * (SG * 8 + 1) <= 2 048 + 256 floats per plane
+  __shared__ float red[2 * (TR_THREADS * 8 + TR_THREADS)];
+  const int W = SG * 8 + 1;
+  if (rl < RL) {
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    red[0][rl][cg * 8 + q] = s0[q];
-    red[1][rl][cg * 8 + q] = s1[q];
+    for (int q = 0; q < 8; ++q) {
+      red[rl * W + cg * 8 + q] = s0[q];
+      red[RL * W + rl * W + cg * 8 + q] = s1[q];
+    }
   }
   __syncthreads();
-  if (threadIdx.x < 128) {
-    const int which = threadIdx.x >> 6, c = threadIdx.x & 63;
-    float t = 0.0f;
-    for (int r = 0; r < 32; ++r) t += red[which][r][c];
-    const int ch = slab * 64 + c;
-    if (ch < s.C) a.ws[a.ws_off[blockIdx.z] + ((long long)chunk * 2 + which) * s.C + ch] = t;
+  for (int t = threadIdx.x; t < 2 * SG * 8; t += TR_THREADS) {
+    const int which = t >= SG * 8 ? 1 : 0, c = t - which * SG * 8;
+    float v = 0.0f;
+    for (int r = 0; r < RL; ++r) v += red[which * RL * W + r * W + c];
+    const int ch = slab * SG * 8 + c;
+    if (ch < s.C) a.ws[a.ws_off[blockIdx.z] + ((long long)chunk * 2 + which) * s.C + ch] = v;
+  }
+}
+
+// groups per slab / slabs per row of a segment with C8 = C / 8 channel groups and `chunks` row chunks.  The 64-channel
+// slabs (8 groups x 32 row lanes) stay wherever they keep >= 95 % of the lanes busy; else the split with the fewest dead
+// lanes (groups missing in a row's last slab, threads beyond RL * SG), the widest such slab (longer contiguous pieces of a
+// row) that still gives the launch ~500 workgroups — small launches are bound by their latency chain, not by lanes, and
+// ran slower with half the workgroups (tools/bench_bn.py: 20 x 20 x 1 392, 19 -> 28 us) — and never pieces under 128 bytes.
+static void bn_slab_plan(int C8, int chunks, int* slab_groups, int* nslab) {
+  const int old_n = (C8 + 7) / 8;
+  auto score = [&](int n) {
+    const int g = (C8 + n - 1) / n;
+    return (double)C8 * (TR_THREADS / g) / ((double)n * TR_THREADS);
+  };
+  *slab_groups = C8 < 8 ? C8 : 8;
+  *nslab = old_n;
+  if (C8 >= 8 && (double)C8 / (8.0 * old_n) >= 0.95) return;   // (the last 64-channel slab is the only partial one)
+  double best = 0.0;
+  for (int n = 1; n <= old_n; ++n) {
+    const int g = (C8 + n - 1) / n;
+    if (g > 64 || (g < 8 && n > 1)) continue;
+    if (score(n) > best) best = score(n);
+  }
+  for (int n = 1; n <= old_n; ++n) {
+    const int g = (C8 + n - 1) / n;
+    if (g > 64 || (g < 8 && n > 1) || score(n) < best - 0.01) continue;
+    if ((long long)chunks * n >= 512 || C8 < 8) {
+      *slab_groups = g;
+      *nslab = n;
+      return;
+    }
   }
 }
 
@@ -604,6 +646,7 @@ static int bn_fill(const rn_bn_problem* p, BnArgs& a, int need_ws, int mode = 1)
     d.colsum = s.dy_colsum_partial;
     if (s.sample_scale && p->act == RN_ACT_SWISH) return -1;   // swish' is recomputed without the factor
     d.chunks = bn_chunks_of(s, mode, &d.rows_per_chunk);
+    bn_slab_plan(s.C / 8, d.chunks, &d.slab_groups, &d.nslab);
     a.ws_off[i] = off;
     off += (long long)d.chunks * 2 * s.C;
   }
@@ -703,7 +746,7 @@ static int bn_colreduce(const rn_bn_problem* p, int mode, void* ws, size_t ws_by
     RN_CHECK_ARG(s.y && (mode == 0 ? s.sums != nullptr : (s.dz && s.bsums && s.fwd)), "%s: null tensor", fn);
     RN_CHECK_ARG(mode == 0 || a.act == RN_ACT_NONE || s.z || s.mask, "%s: z needed for the activation mask", fn);
     if (s.chunks > max_chunks) max_chunks = s.chunks;
-    if ((s.C + 63) / 64 > max_slabs) max_slabs = (s.C + 63) / 64;
+    if (s.nslab > max_slabs) max_slabs = s.nslab;
     if (s.C > max_c) max_c = s.C;
   }
   if (n_ext == 0) {   // otherwise the producing convolution already wrote the stage-1 partials
