@@ -517,31 +517,63 @@ extern "C" int rn_depthwise_conv2d_nhwc_wgrad(const rn_dw_problem* p, float* dw,
 // pooled[n][c] = bf16(mean over H*W)  (tf.reduce_mean on a bf16 tensor yields bf16)
 // grid (channel slabs, N, HW chunks): partial[chunk][n][c] = sum over the chunk's pixels (deterministic);
 // se_mid_fwd_kernel adds the chunks in order, divides and rounds.
+// A workgroup = SG channel groups (16 bytes each) x RL = 256 / SG pixel lanes of one slab of a chunk's pixels; SG from
+// se_slab_plan (8 = 64-channel slabs where they keep the lanes busy; the whole pixel for 40 / 144 / 288 ... channels).
 __global__ void __launch_bounds__(256)
-se_pool_kernel(const uint4* __restrict__ x, int HW, int C8, int rows_per_chunk, float* __restrict__ partial) {
-  const int n = blockIdx.y, slab = blockIdx.x;  // 8 channel groups (64 channels) per block
-  const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
-  const int c8 = slab * 8 + cg;
+se_pool_kernel(const uint4* __restrict__ x, int HW, int C8, int rows_per_chunk, int SG, float* __restrict__ partial) {
+  const int n = blockIdx.y, slab = blockIdx.x;
+  const int RL = 256 / SG;
+  const int rl = threadIdx.x / SG, cg = threadIdx.x - rl * SG;
+  const int c8 = slab * SG + cg;
   const int p0 = blockIdx.z * rows_per_chunk;
   const int p1 = p0 + rows_per_chunk < HW ? p0 + rows_per_chunk : HW;
   float acc[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) acc[q] = 0.0f;
-  if (c8 < C8)
-    for (int p = p0 + rl; p < p1; p += 32) {
+  if (c8 < C8 && rl < RL)
+    for (int p = p0 + rl; p < p1; p += RL) {
       const bf8 v = unpack8(x[((long long)n * HW + p) * C8 + c8]);
 #pragma unroll
       for (int q = 0; q < 8; ++q) acc[q] += v.v[q];
     }
-  __shared__ float red[32][65];
+  __shared__ float red[256 * 8 + 256];   // [RL][SG * 8 + 1]
+  const int W = SG * 8 + 1;
+  if (rl < RL) {
 #pragma unroll
-  for (int q = 0; q < 8; ++q) red[rl][cg * 8 + q] = acc[q];
+    for (int q = 0; q < 8; ++q) red[rl * W + cg * 8 + q] = acc[q];
+  }
   __syncthreads();
-  if (threadIdx.x < 64) {
+  for (int c = threadIdx.x; c < SG * 8; c += 256) {
     float t = 0.0f;
-    for (int r = 0; r < 32; ++r) t += red[r][threadIdx.x];
-    const int ch = slab * 64 + threadIdx.x;
+    for (int r = 0; r < RL; ++r) t += red[r * W + c];
+    const int ch = slab * SG * 8 + c;
     if (ch < C8 * 8) partial[((long long)blockIdx.z * gridDim.y + n) * C8 * 8 + ch] = t;
+  }
+}
+// channel groups per slab / slabs per pixel for the two pooling kernels (the policy of rn_train.hip::bn_slab_plan)
+static void se_slab_plan(int C8, long long chunk_groups, int* slab_groups, int* nslab) {
+  const int old_n = (C8 + 7) / 8;
+  auto score = [&](int n) {
+    const int g = (C8 + n - 1) / n;
+    return (double)C8 * (256 / g) / ((double)n * 256);
+  };
+  *slab_groups = C8 < 8 ? C8 : 8;
+  *nslab = old_n;
+  if (C8 >= 8 && (double)C8 / (8.0 * old_n) >= 0.95) return;
+  double best = 0.0;
+  for (int n = 1; n <= old_n; ++n) {
+    const int g = (C8 + n - 1) / n;
+    if (g > 64 || (g < 8 && n > 1)) continue;
+    if (score(n) > best) best = score(n);
+  }
+  for (int n = 1; n <= old_n; ++n) {
+    const int g = (C8 + n - 1) / n;
+    if (g > 64 || (g < 8 && n > 1) || score(n) < best - 0.01) continue;
+    if (chunk_groups * n >= 512 || C8 < 8) {
+      *slab_groups = g;
+      *nslab = n;
+      return;
+    }
   }
 }
 
@@ -659,8 +691,10 @@ static int se_forward(const void* x, void* y, int N, int HW, int C, const void* 
     int rows = 0;
     const int chunks = se_chunks(HW, &rows);
     float* partial = state + (size_t)N * C * 4;
-    hipLaunchKernelGGL(se_pool_kernel, dim3((C + 63) / 64, N, chunks), dim3(256), 0, st, (const uint4*)x, HW, C / 8,
-                       rows, partial);
+    int sg = 8, nslab = 1;
+    se_slab_plan(C / 8, (long long)N * chunks, &sg, &nslab);
+    hipLaunchKernelGGL(se_pool_kernel, dim3(nslab, N, chunks), dim3(256), 0, st, (const uint4*)x, HW, C / 8, rows, sg,
+                       partial);
     RN_CHECK_LAUNCH();
     int splits = 1;
     const int cps = se_mid_cps(N, C, &splits);
@@ -709,31 +743,35 @@ extern "C" int rn_squeeze_excite_fwd(const void* x, void* y, int N, int HW, int 
 // y = x * g[n][c], g = sigmoid(h2), h2 = W2 a + b2, a = swish(h1), h1 = W1 p + b1, p = mean_hw x
 // dgate[n][c] = sum_hw dy * x
 __global__ void __launch_bounds__(256)
-se_bwd_pool_kernel(const uint4* __restrict__ x, const uint4* __restrict__ dy, int HW, int C8, int rows_per_chunk,
+se_bwd_pool_kernel(const uint4* __restrict__ x, const uint4* __restrict__ dy, int HW, int C8, int rows_per_chunk, int SG,
                    float* __restrict__ partial) {
-  const int n = blockIdx.y, slab = blockIdx.x;
-  const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
-  const int c8 = slab * 8 + cg;
+  const int n = blockIdx.y, slab = blockIdx.x;   // (slab geometry: se_pool_kernel)
+  const int RL = 256 / SG;
+  const int rl = threadIdx.x / SG, cg = threadIdx.x - rl * SG;
+  const int c8 = slab * SG + cg;
   const int p0 = blockIdx.z * rows_per_chunk;
   const int p1 = p0 + rows_per_chunk < HW ? p0 + rows_per_chunk : HW;
   float acc[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) acc[q] = 0.0f;
-  if (c8 < C8)
-    for (int p = p0 + rl; p < p1; p += 32) {
+  if (c8 < C8 && rl < RL)
+    for (int p = p0 + rl; p < p1; p += RL) {
       const long long o = ((long long)n * HW + p) * C8 + c8;
       const bf8 v = unpack8(x[o]), g = unpack8(dy[o]);
 #pragma unroll
       for (int q = 0; q < 8; ++q) acc[q] += v.v[q] * g.v[q];
     }
-  __shared__ float red[32][65];
+  __shared__ float red[256 * 8 + 256];   // [RL][SG * 8 + 1]
+  const int W = SG * 8 + 1;
+  if (rl < RL) {
 #pragma unroll
-  for (int q = 0; q < 8; ++q) red[rl][cg * 8 + q] = acc[q];
+    for (int q = 0; q < 8; ++q) red[rl * W + cg * 8 + q] = acc[q];
+  }
   __syncthreads();
-  if (threadIdx.x < 64) {
+  for (int c = threadIdx.x; c < SG * 8; c += 256) {
     float t = 0.0f;
-    for (int r = 0; r < 32; ++r) t += red[r][threadIdx.x];
-    const int ch = slab * 64 + threadIdx.x;
+    for (int r = 0; r < RL; ++r) t += red[r * W + c];
+    const int ch = slab * SG * 8 + c;
     if (ch < C8 * 8) partial[((long long)blockIdx.z * gridDim.y + n) * C8 * 8 + ch] = t;
   }
 }
@@ -877,8 +915,10 @@ extern "C" int rn_squeeze_excite_bwd(const void* x, const void* dy, void* dx, in
     int rows = 0;
     const int chunks = se_chunks(HW, &rows);
     float* partial = (float*)workspace + (size_t)N * C * 4;
-    hipLaunchKernelGGL(se_bwd_pool_kernel, dim3((C + 63) / 64, N, chunks), dim3(256), 0, st, (const uint4*)x,
-                       (const uint4*)dy, HW, C / 8, rows, partial);
+    int sg = 8, nslab = 1;
+    se_slab_plan(C / 8, (long long)N * chunks, &sg, &nslab);
+    hipLaunchKernelGGL(se_bwd_pool_kernel, dim3(nslab, N, chunks), dim3(256), 0, st, (const uint4*)x,
+                       (const uint4*)dy, HW, C / 8, rows, sg, partial);
     RN_CHECK_LAUNCH();
     int splits = 1;
     const int cps = se_mid_cps(N, C, &splits);
