@@ -27,9 +27,12 @@ __device__ __forceinline__ uint4 pack8(const bf8& r) {
   u.z = rn_pack_bf16x2(r.v[4], r.v[5]); u.w = rn_pack_bf16x2(r.v[6], r.v[7]);
   return u;
 }
-// Packed fp32 pairs (v_pk_mul_f32 / v_pk_add_f32: two lanes of fp32 per VALU slot).  The depthwise kernels are
-// VALU-bound — a 5x5 tap loop is ~530 instructions per 16-byte output with scalar fp32 — and the packed forms halve
-// the multiply / add count with the same roundings (a product is still rounded before it is added).
+// Packed fp32 pairs (two lanes of fp32 per VALU slot).  The depthwise kernels are VALU-bound — a 5x5 tap loop is ~530
+// instructions per 16-byte output with scalar fp32 — and the packed forms halve the count.  Round 6: the forward / data-
+// gradient tap loop uses v_pk_fma_f32 (one rounding per tap instead of two: the library is built with -ffp-contract=off
+// for the bit-exact integer / loss kernels, so the fused form has to be asked for; TF's DepthwiseConv2D fixes no order of
+// operations and the parity test is a tolerance against an fp32 convolution) — another 80 of ~260 instructions per filter
+// row of a 5x5 strip.
 typedef float dw_f2 __attribute__((ext_vector_type(2)));
 struct bf8p { dw_f2 v[4]; };
 __device__ __forceinline__ bf8p unpack8p(uint4 u) {
@@ -123,7 +126,7 @@ __global__ void __launch_bounds__(DW_THREADS) depthwise_strip_kernel(const DwArg
           if (ss >= 0 && ss < K) {
             const bf8p wv = unpack8p(wr[ss]);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[tt][q] += xv.v[q] * wv.v[q];
+            for (int q = 0; q < 4; ++q) acc[tt][q] = __builtin_elementwise_fma(xv.v[q], wv.v[q], acc[tt][q]);   // v_pk_fma_f32
           }
         }
       }
