@@ -385,7 +385,7 @@ __global__ void __launch_bounds__(256) depthwise_wgrad_kernel(const DwgArgs a) {
             const int ss = j - tt * S;     // compile-time after unrolling
             if (ss >= 0 && ss < K) {
 #pragma unroll
-              for (int q = 0; q < CP2; ++q) acc[r * K + ss][q] += g[tt][q] * xv[j][q];
+              for (int q = 0; q < CP2; ++q) acc[r * K + ss][q] = __builtin_elementwise_fma(g[tt][q], xv[j][q], acc[r * K + ss][q]);
             }
           }
         }
