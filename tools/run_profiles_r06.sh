@@ -26,4 +26,8 @@ python3 tools/profile_layers.py --batch 1 --iters 20 > $OUT/layers_b1.txt 2>&1
 python3 tools/profile_layers.py --batch 8 --iters 10 > $OUT/layers_b8.txt 2>&1
 python3 tools/bench_bneck.py > $OUT/bneck_bench.txt 2>&1
 python3 tools/bench_dw.py --forms wgrad > $OUT/dw_wgrad.txt 2>&1
+python3 tools/bench_dw.py --forms fwd,dgrad > $OUT/dw_fwd_dgrad.txt 2>&1
+python3 tools/bench_bn.py > $OUT/bn_bench.txt 2>&1
+python3 tools/bench_effnet.py --iters 6 > $OUT/effnet_bench.txt 2>&1
+bash tools/probes/c4_nms_time.sh final > $OUT/c4_nms_time.txt 2>&1
 tail -c 400 $OUT/bench_line.json
