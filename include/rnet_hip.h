@@ -146,6 +146,10 @@ int rn_topk_per_class(const float* scores, int B, int64_t A, int K, int top_k, f
  *      valid i32[B].  soft_nms_sigma == 0 -> PerClassHardNMS, > 0 -> PerClassSoftNMS (the
  *      reference passes sigma/2 to NonMaxSuppressionV5 and iou_threshold 1.0, :448-450;
  *      pass the CONFIG sigma here).  pre_nms_top_k <= 0 disables the top-k filter.
+ *      Soft NMS keeps a whole candidate list on chip: it needs 0 < pre_nms_top_k <= 8192 (or at most 8192
+ *      anchors); lists of up to 5120 candidates (every shipped configuration: 5000) run the one-step-per-
+ *      selection kernel, longer ones the queue loop — the same selections and score bits either way
+ *      (RN_EINVAL beyond 8192).  max_det <= 256, K * max_det <= 16384.
  */
 size_t rn_detect_workspace_bytes(int B, int64_t A, int K, int max_det);
 int rn_detect_per_class(const float* const* class_logits, const int64_t* level_offsets, int num_levels, int B,
