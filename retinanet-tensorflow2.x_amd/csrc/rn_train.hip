@@ -147,14 +147,16 @@ struct BnArgs {
 // EfficientNet (144, 288, 816, 1 392; 24 ... 232 behind the projection convs) left the last slab of every row with 25 - 75 %
 // of its lanes dead: the swish form of this kernel is VALU-bound (8 v_exp + 8 v_rcp + ~130 other instructions per 16 bytes
 // of y and dz), so dead lanes were time.
-template <int G>   // G < 0: mode 0 (forward statistics); else the gradient gate of mode 1
+// SGT = 8: every segment of the launch has 64-channel slabs (ResNet: the index arithmetic folds to shifts, as before
+// round 6); SGT = 0: per segment at run time.
+template <int G, int SGT = 0>   // G < 0: mode 0 (forward statistics); else the gradient gate of mode 1
 __global__ void __launch_bounds__(TR_THREADS) bn_colreduce_kernel(const BnArgs a) {
   const BnSegDev& s = a.seg[blockIdx.z];
   const int chunk = blockIdx.x;
   const int slab = blockIdx.y;
   if (chunk >= s.chunks || slab >= s.nslab) return;
   const int C8 = s.C >> 3;
-  const int SG = s.slab_groups, RL = TR_THREADS / SG;
+  const int SG = SGT ? SGT : s.slab_groups, RL = TR_THREADS / SG;
   const int rl = threadIdx.x / SG, cg = threadIdx.x - rl * SG;
   const int c8 = slab * SG + cg;
   const bool live = c8 < C8 && rl < RL;
@@ -206,7 +208,7 @@ __global__ void __launch_bounds__(TR_THREADS) bn_colreduce_kernel(const BnArgs a
     }
   }
   // [which][row lane][SG * 8 + 1]: RL * (SG * 8 + 1) <= 256 / SG * (SG * 8 + 1) <= 2 048 + 256 floats per plane
-  __shared__ float red[2 * (TR_THREADS * 8 + TR_THREADS)];
+  __shared__ float red[SGT == 8 ? 2 * 32 * 65 : 2 * (TR_THREADS * 8 + TR_THREADS)];
   const int W = SG * 8 + 1;
   if (rl < RL) {
 #pragma unroll
@@ -751,10 +753,15 @@ static int bn_colreduce(const rn_bn_problem* p, int mode, void* ws, size_t ws_by
   }
   if (n_ext == 0) {   // otherwise the producing convolution already wrote the stage-1 partials
     const dim3 grid(max_chunks, max_slabs, a.nseg), block(TR_THREADS);
+    bool all8 = true;
+    for (int i = 0; i < a.nseg; ++i) all8 = all8 && a.seg[i].slab_groups == 8;
     if (mode == 0) {
-      hipLaunchKernelGGL(bn_colreduce_kernel<-1>, grid, block, 0, st, a);
+      if (all8) hipLaunchKernelGGL((bn_colreduce_kernel<-1, 8>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((bn_colreduce_kernel<-1, 0>), grid, block, 0, st, a);
     } else {
-#define BN_CALL_(G_) hipLaunchKernelGGL(bn_colreduce_kernel<G_>, grid, block, 0, st, a)
+#define BN_CALL_(G_)                                                                       \
+  if (all8) hipLaunchKernelGGL((bn_colreduce_kernel<G_, 8>), grid, block, 0, st, a);       \
+  else hipLaunchKernelGGL((bn_colreduce_kernel<G_, 0>), grid, block, 0, st, a)
       BN_DISPATCH_GATE(bn_gate_mode(p), BN_CALL_)
 #undef BN_CALL_
     }
