@@ -272,7 +272,8 @@ def _soft_lists(rng, B, n, K, kind):
 
 
 @pytest.mark.parametrize("kind,n,md", [("pile", 700, 100), ("clusters", 3000, 100), ("clusters", 5120, 64),
-                                        ("clusters", 6000, 100), ("pile", 8192, 40)])
+                                        ("clusters", 6000, 100), ("pile", 8192, 40), ("clusters", 40, 100),
+                                        ("pile", 300, 256), ("clusters", 513, 7)])
 def test_soft_nms_step_kernel_and_queue_fallback(cuda, kind, n, md):
     """`rn_nms_per_class` in the reference's soft shape against the oracle's queue (rn_o_nms_v5), bit for bit, on both device
     forms: lists of up to 5 120 candidates go through soft_nms_kernel (one selection per step; "pile" drives every candidate
@@ -295,3 +296,5 @@ def test_soft_nms_step_kernel_and_queue_fallback(cuda, kind, n, md):
     wb, ws, wc, wv = o.per_class_nms(scores, boxes, 0.5, 0.05, 0.5, md)
     _check(out, wb, ws, wc, wv)
     assert wv.min() > 0
+    if n == 40:
+        assert wv.max() < md          # the queue runs empty before max_detections
