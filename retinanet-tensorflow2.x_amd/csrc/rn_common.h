@@ -94,11 +94,15 @@ __device__ __forceinline__ uint32_t rn_pack_bf16x2(float lo, float hi) {   // on
 // unrolled element loop compiles to a chain of scalar compares and taken branches per element — measured 25 000
 // cycles per 256 x 256 tile epilogue against ~4 000 for the arithmetic): swish behind one uniform branch, identity
 // returns at once, relu / relu6 are max(v, 0) then min(v, 6 or +inf).
+// x * sigmoid(x) with v_rcp_f32 (1 ulp) for the reciprocal: the correctly rounded division the build flags give `/` is
+// ~11 instructions per element in kernels that are VALU-bound on EfficientNet (depthwise epilogue, BatchNorm apply), and the
+// value is rounded to 16 bits right after.  x -> -inf gives -0 like the division did.
+__device__ __forceinline__ float rn_swish(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 template <int N>
 __device__ __forceinline__ void rn_apply_act_n(float (&f)[N], int act) {
   if (act == RN_ACT_SWISH) {
 #pragma unroll
-    for (int q = 0; q < N; ++q) f[q] = f[q] / (1.0f + __expf(-f[q]));
+    for (int q = 0; q < N; ++q) f[q] = rn_swish(f[q]);
     return;
   }
   if (act == RN_ACT_NONE) return;

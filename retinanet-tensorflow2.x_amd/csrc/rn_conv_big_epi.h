@@ -333,7 +333,7 @@ _Pragma("unroll") for (int pass = 0; pass < (LOADS ? 4 : 0); ++pass) {          
               for (int q = 0; q < 8; ++q) f[q] += rr[q];
               if (SWISH == 1 || (SWISH == 2 && act == RN_ACT_SWISH)) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) { const float u = rn_rb(f[q]); f[q] = u / (1.0f + __expf(-u)); }
+                for (int q = 0; q < 8; ++q) f[q] = rn_swish(rn_rb(f[q]));
               }
               ov.x = pack2(f[0], f[1]); ov.y = pack2(f[2], f[3]); ov.z = pack2(f[4], f[5]); ov.w = pack2(f[6], f[7]);
               // relu / relu6 on the packed bf16 pairs: rounding is monotonic and 0 and 6 are bf16 values, so

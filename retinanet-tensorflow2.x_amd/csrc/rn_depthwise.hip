@@ -49,7 +49,7 @@ __device__ __forceinline__ float act_exact(float v, int act) {
   switch (act) {
     case RN_ACT_RELU: return fmaxf(v, 0.0f);
     case RN_ACT_RELU6: return fminf(fmaxf(v, 0.0f), 6.0f);
-    case RN_ACT_SWISH: return v / (1.0f + __expf(-v));
+    case RN_ACT_SWISH: return rn_swish(v);
     default: return v;
   }
 }
