@@ -525,8 +525,17 @@ __global__ void __launch_bounds__(TR_THREADS) bn_apply_kernel(const BnArgs a) {
     if (s.mask) {   // gate bits of the STORED bf16 output (what the backward would otherwise re-read as z)
       const bf8 zs = unpack8(zp);
       unsigned bits = 0u;
+      // (one uniform branch per vector: act_mask's run-time test inside the unrolled loop was two scalar compares and
+      //  branches per ELEMENT in every residual layer of ResNet)
+      if (a.act == RN_ACT_RELU) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) bits |= (act_mask(zs.v[q], a.act) != 0.0f ? 1u : 0u) << q;
+        for (int q = 0; q < 8; ++q) bits |= (zs.v[q] > 0.0f ? 1u : 0u) << q;
+      } else if (a.act == RN_ACT_RELU6) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) bits |= ((zs.v[q] > 0.0f && zs.v[q] < 6.0f) ? 1u : 0u) << q;
+      } else {
+        bits = 0xffu;
+      }
       s.mask[i] = (unsigned char)bits;
     }
   }
