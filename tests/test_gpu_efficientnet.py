@@ -489,3 +489,39 @@ def test_efficientnet_train_steps_reduce_loss(cuda):
     for (off, n), bfo in eng._bf_copies:   # bf16 compute copies follow the f32 masters
         torch.testing.assert_close(eng.Pbf[bfo:bfo + n].float(), eng.P[off:off + n].to(eng.h16).float(), rtol=0, atol=0)
 
+
+
+def test_config4_bench_batch_backward_is_stream_and_run_independent(cuda):
+    """BASELINE configs[4] at the bench's own shard — EfficientNet-B3, 640 x 640, 32 images, mixed_float16 — forward and
+    backward through the default paths (fused squeeze-excite steps, slab plans of the BatchNorm / pooling reductions picked
+    from this batch's chunk counts, depthwise weight gradients, two streams): the gradient buffer must be finite,
+    populated, identical from run to run and identical to the one-stream order bit for bit.  (The float64 comparison
+    above runs 2 images; the launch geometries of 32 exist at no smaller size.)"""
+    from retinanet.cfg import efficientnet_params
+    from retinanet.model import ModelBuilder
+    from retinanet.model.train_engine import TrainEngine
+    size, B = 640, 32
+    p = efficientnet_params("efficientnet-b3", input_size=size)
+    p.architecture.batch_norm.use_sync = False
+    model = ModelBuilder(p, "train", device=cuda, seed=3)()
+    eng = TrainEngine(model, B, frozen_regexes=[])
+    assert eng.f16 and eng.side_stream_on
+    images = torch.randn((B, size, size, 3), generator=torch.Generator().manual_seed(3)).to(cuda)
+    preds = eng.forward(images)
+    g = torch.Generator().manual_seed(4)
+    up = {k: {lv: (torch.randn(preds[k][lv].shape, generator=g) * 1e-3).to(cuda) for lv in preds[k]} for k in preds}
+    grads = []
+    try:
+        for two_streams in (True, False, True):
+            eng.side_stream_on = two_streams
+            eng.G.zero_()
+            eng.forward(images, draw=False)      # the same stochastic-depth masks every time
+            eng.backward(up)
+            torch.cuda.synchronize()
+            grads.append(eng.G.clone())
+    finally:
+        eng.side_stream_on = True
+    assert torch.isfinite(grads[0]).all()
+    assert int((grads[0] != 0).sum()) > grads[0].numel() // 2
+    assert torch.equal(grads[0], grads[1]), "two-stream gradients differ from the one-stream order"
+    assert torch.equal(grads[0], grads[2]), "two runs of the two-stream order differ"

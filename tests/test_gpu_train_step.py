@@ -236,6 +236,36 @@ def test_two_stream_backward_is_bit_identical(cuda):
         assert torch.equal(grads[0], grads[i]), f"run {i} differs from the one-stream gradients"
 
 
+@pytest.mark.parametrize("size,B", [(640, 32), (1024, 16)], ids=["config2-640-b32", "config3-1024-b16"])
+def test_bench_batch_backward_is_stream_and_run_independent(cuda, size, B):
+    """The bench's own shards end to end (BASELINE configs[2]: ResNet-50, 640 x 640, 32 images on the GPU; configs[3]:
+    1024 x 1024, 16 images; `resnet_initial` frozen — the whole-step parity tests above run them at 8 / 4 images):
+    forward + backward through every default path (fused stage-1
+    blocks, grouped weight gradients, BatchNorm reductions in the data-gradient epilogues, two streams); the gradient
+    buffer must be finite, populated, identical from run to run and identical to the one-stream order bit for bit —
+    the launch geometries of this batch (tile counts, split-K parts, chunk plans) exist at no smaller size."""
+    p, model, eng, targets, images = _setup(cuda, size, B, True, depth=50, freeze=True)
+    assert eng.side_stream_on and (len(eng.bneck) > 0 or size != 640)   # (W = 256 at 1024 x 1024: per-layer stage 1)
+    preds = eng.forward(images.to(cuda))
+    g = torch.Generator().manual_seed(7)
+    up = {k: {lv: (torch.randn(preds[k][lv].shape, generator=g) * 1e-3).to(cuda) for lv in preds[k]} for k in preds}
+    grads = []
+    try:
+        for two_streams in (True, False, True):
+            eng.side_stream_on = two_streams
+            eng.G.zero_()
+            eng.forward(images.to(cuda), draw=False)
+            eng.backward(up)
+            torch.cuda.synchronize()
+            grads.append(eng.G.clone())
+    finally:
+        eng.side_stream_on = True
+    assert torch.isfinite(grads[0]).all()
+    assert int((grads[0] != 0).sum()) > grads[0].numel() // 2
+    assert torch.equal(grads[0], grads[1]), "two-stream gradients differ from the one-stream order"
+    assert torch.equal(grads[0], grads[2]), "two runs of the two-stream order differ"
+
+
 @pytest.mark.parametrize("groups", [False, True], ids=["backbone", "backbone+head-towers"])
 def test_bn_backward_reduction_in_the_dgrad_epilogue_matches_the_separate_pass(cuda, monkeypatch, groups):
     """RNET_FUSE_BN_BWD (default on): the data-gradient launch that writes dz of a BatchNorm + ReLU layer with one
